@@ -1,0 +1,87 @@
+"""ctypes binding of libcmcd_hip.so (include/cmcd_hip.h).  No CPU fallback: if the library is
+missing or a call fails, this raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcmcd_hip.so")
+
+MODE = {"MCD_CAIS_sn": 0, "MCD_CAIS_var_sn": 1}
+ARCH = {"geffner": 0, "dds": 1}
+TARGET = {"gmm": 0, "funnel": 1, "many_gmm": 2, "lgcp": 3}
+EPS_SCHEDULE = {None: 0, "": 0, "none": 0, "linear": 1, "cos_sq": 2}
+NSTATS = 5
+
+
+class Desc(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in (
+        "dim", "nbridges", "mode", "arch", "emb_dim", "target", "eps_schedule", "grad_clipping",
+        "ngrid", "reserved")]
+
+
+LAYOUT_FIELDS = (
+    "vd_mean", "vd_logdiag", "eps", "mgridref_y",
+    "g_emb", "g_factor", "g_w1", "g_b1", "g_w2", "g_b2", "g_w3", "g_b3",
+    "d_phase", "d_tw1", "d_tb1", "d_tw2", "d_tb2", "d_sw1", "d_sb1", "d_sw2", "d_sb2", "d_sw3", "d_sb3")
+
+
+class Layout(C.Structure):
+    _fields_ = [(k, C.c_int64) for k in LAYOUT_FIELDS]
+
+
+_lib = None
+
+
+def lib():
+    """Loads the HIP library; raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m cmcd_amd.build` "
+                "(there is no CPU fallback for the CMCD hot path)")
+        L = C.CDLL(LIB_PATH)
+        L.cmcd_version.restype = C.c_int
+        L.cmcd_last_error.restype = C.c_char_p
+        L.cmcd_workspace_bytes.restype = C.c_int64
+        L.cmcd_workspace_bytes.argtypes = [C.POINTER(Desc), C.c_int64]
+        L.cmcd_target_floats.restype = C.c_int64
+        L.cmcd_target_floats.argtypes = [C.POINTER(Desc), C.c_int32]
+        L.cmcd_bound_forward.restype = C.c_int
+        L.cmcd_bound_forward.argtypes = [
+            C.POINTER(Desc), C.POINTER(Layout), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+            C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cmcd_stats_merge.restype = C.c_int
+        L.cmcd_stats_merge.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32,
+                                       C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        for name in ("cmcd_lgcp_workspace_bytes", "cmcd_bound_forward_lgcp"):
+            if hasattr(L, name):
+                pass
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().cmcd_last_error().decode()
+
+
+def check(rc):
+    if rc == 0:
+        return
+    msg = last_error()
+    if rc == -2:
+        raise NotImplementedError(msg)
+    if rc == -1:
+        raise ValueError(msg)
+    raise RuntimeError(f"libcmcd_hip error {rc}: {msg}")
+
+
+def stats_merge(stats_rows, n_per):
+    """Host-side fixed-order merge of per-rank statistics -> (merged5, mean, var, lnZ)."""
+    cnt = len(n_per)
+    flat = (C.c_double * (NSTATS * cnt))(*[float(x) for row in stats_rows for x in row])
+    ns = (C.c_int64 * cnt)(*[int(x) for x in n_per])
+    merged = (C.c_double * NSTATS)()
+    out3 = (C.c_double * 3)()
+    check(lib().cmcd_stats_merge(flat, ns, cnt, merged, out3))
+    return list(merged), out3[0], out3[1], out3[2]

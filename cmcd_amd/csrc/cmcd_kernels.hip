@@ -1,0 +1,813 @@
+// libcmcd_hip.so — hand-written gfx950 (CDNA4) kernels for CMCD's annealed-Langevin bound
+// (`MCD_CAIS_sn` / `MCD_CAIS_var_sn`) and the C ABI of include/cmcd_hip.h.
+//
+// Launch sequence of one cmcd_bound_forward (all on the caller's stream, no host sync):
+//   1. prep_sched_kernel    betas / eps / sigma tables             (mcdboundingmachine.py:146-149,
+//                                                                   mcd_cais.py:34-44,54-63)
+//   2. prep_{dds,geffner}_kernel  per-bridge first-layer bias table: the particle-independent
+//                           time path (nn_dds.py:155-158 / nn.py:68) folded through W1[d:,:]
+//   3. pack_weights_kernel  W2 into MFMA A-fragment order, W1[:d], W3^T, biases, zero padded
+//   4. traj_kernel          the whole K-step trajectory of 16 particles per wave
+//   5. finalize_kernel      fixed-order merge of per-wave statistics -> out_stats[5]
+//
+// Data layout of the trajectory kernel (one wave = 16 particles, all K steps):
+//   lane l = (g = l >> 4, c = l & 15): particle c of the tile; the four lanes g = 0..3 of a particle
+//   each own neurons {16 t + 4 g + r} (t < T tiles, r < 4) of every hidden vector.  That is exactly
+//   the C/D register layout of v_mfma_f32_16x16x4_f32 with rows = output neurons and
+//   columns = particles, AND (with W2 pre-permuted into A fragments) the B-operand layout of the
+//   next MFMA, so activations never leave registers between layers.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "cmcd_device.h"
+#include "cmcd_hip.h"
+
+namespace cmcd {
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, const char* a = "", long long b = 0) {
+  snprintf(g_err, sizeof(g_err), fmt, a, b);
+  return code;
+}
+
+// ------------------------------------------------------------------------------------------
+// workspace carve-up (floats unless noted)
+// ------------------------------------------------------------------------------------------
+struct WsLayout {
+  int64_t beta, eps, sig, logsig;  // [K] each
+  int64_t bias1;                   // [K+1][HP]
+  int64_t utab;                    // [K+1][HP]   (geffner only, else aliases bias1)
+  int64_t w1z;                     // [D][HP]
+  int64_t w2;                      // [T][T][64][4]
+  int64_t b2;                      // [HP]
+  int64_t w3t;                     // [D][HP]
+  int64_t b3;                      // [16]  (b3[D] then factor)
+  int64_t tgt;                     // target constants staged for LDS
+  int64_t tgt_floats;
+  int64_t partials;                // doubles: [n_waves][5]  (offset in floats, 8-byte aligned)
+  int64_t total_floats;
+  int32_t HP, T, n_waves;
+};
+
+static inline int64_t align4(int64_t x) { return (x + 3) & ~int64_t(3); }
+
+static bool hidden_width(const cmcd_desc& d, int& HP) {
+  if (d.arch == CMCD_ARCH_DDS) {
+    HP = 64;
+    return true;
+  }
+  if (d.arch == CMCD_ARCH_GEFFNER) {
+    if (d.emb_dim < 1) return false;
+    HP = ((d.dim + d.emb_dim + 15) / 16) * 16;
+    return true;
+  }
+  return false;
+}
+
+static int64_t target_lds_floats(const cmcd_desc& d, int64_t n_target) {
+  if (d.target == CMCD_TARGET_MANY_GMM) return 4 + (n_target - 1);  // header + means
+  return 0;
+}
+
+static bool make_ws(const cmcd_desc& d, int64_t n, int64_t n_target, WsLayout& w) {
+  int HP;
+  if (!hidden_width(d, HP)) return false;
+  const int64_t K = d.nbridges, D = d.dim;
+  w.HP = HP;
+  w.T = HP / 16;
+  int64_t o = 0;
+  w.beta = o; o += align4(K);
+  w.eps = o; o += align4(K);
+  w.sig = o; o += align4(K);
+  w.logsig = o; o += align4(K);
+  w.bias1 = o; o += (K + 1) * HP;
+  if (d.arch == CMCD_ARCH_GEFFNER) { w.utab = o; o += (K + 1) * HP; } else { w.utab = w.bias1; }
+  w.w1z = o; o += D * HP;
+  w.w2 = o; o += int64_t(HP) * HP;
+  w.b2 = o; o += HP;
+  w.w3t = o; o += D * HP;
+  w.b3 = o; o += 16;
+  w.tgt_floats = align4(target_lds_floats(d, n_target));
+  w.tgt = o; o += w.tgt_floats;
+  o = (o + 1) & ~int64_t(1);
+  w.n_waves = int32_t((n + 15) / 16);
+  w.partials = o; o += int64_t(w.n_waves) * CMCD_NSTATS * 2;
+  w.total_floats = o;
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------
+// 1. schedules
+// ------------------------------------------------------------------------------------------
+struct SchedArgs {
+  const float* params;
+  float* ws;
+  cmcd_layout lay;
+  WsLayout w;
+  int32_t K, ngrid, eps_schedule;
+  int64_t gridref_x, target_x;  // offsets in params, or -1: use linspace
+};
+
+__global__ void prep_sched_kernel(SchedArgs a) {
+  __shared__ float gy[40], gx[40];
+  const int G = a.ngrid;  // mgridref_y has G+1 entries
+  if (threadIdx.x == 0) {
+    // gridref_y = concat([0], cumsum(m)/sum(m))       mcdboundingmachine.py:147-148
+    const float* m = a.params + a.lay.mgridref_y;
+    float tot = 0.f;
+    for (int i = 0; i <= G; ++i) tot += m[i];
+    float run = 0.f;
+    gy[0] = 0.f;
+    for (int i = 0; i <= G; ++i) {
+      run += m[i];
+      gy[i + 1] = run / tot;
+    }
+    for (int i = 0; i < G + 2; ++i) gx[i] = (float)i / (float)(G + 1);  // linspace(0,1,G+2)  :113
+  }
+  __syncthreads();
+  const float eps0 = a.params[a.lay.eps];
+  for (int i = threadIdx.x; i < a.K; i += blockDim.x) {
+    // betas = interp(target_x, gridref_x, gridref_y)     :149, target_x = linspace(0,1,K+2)[1:-1]  :114
+    const float x = (float)(i + 1) / (float)(a.K + 1);
+    int j = 1;
+    while (j < G + 1 && gx[j] <= x) ++j;  // searchsorted(side='right') clipped to [1, G+1]
+    const float dx = gx[j] - gx[j - 1], df = gy[j] - gy[j - 1];
+    a.ws[a.w.beta + i] = gy[j - 1] + ((x - gx[j - 1]) / dx) * df;
+    // eps_i                                              mcd_cais.py:34-44,54-59
+    float e;
+    if (a.eps_schedule == CMCD_EPS_COS_SQ) {
+      const float phase = (float)i / (float)a.K;
+      const float cs = cosf((phase + 0.008f) / 1.008f * 0.5f * 3.14159265358979323846f);
+      e = eps0 * (cs * cs);
+    } else if (a.eps_schedule == CMCD_EPS_LINEAR) {
+      e = (0.0001f - eps0) / (float)(a.K - 1) * (float)i + eps0;
+    } else {
+      e = eps0;
+    }
+    const float s = sqrtf(2.0f * e);  // scale = sqrt(2 eps)   mcd_cais.py:63
+    a.ws[a.w.eps + i] = e;
+    a.ws[a.w.sig + i] = s;
+    a.ws[a.w.logsig + i] = logf(s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// 2a. dds: time path -> per-bridge first-layer bias.  One 64-thread block per bridge index t.
+//     tau(t) = W_b gelu(W_a [sin(c t + phi), cos(c t + phi)] + b_a) + b_b   nn_dds.py:131-143,155-158
+//     bias1[t][n] = sb1[n] + sum_j tau_j * sw1[d + j][n]                    (concat at :159)
+// ------------------------------------------------------------------------------------------
+struct DdsPrepArgs {
+  const float* params;
+  float* ws;
+  cmcd_layout lay;
+  WsLayout w;
+  int32_t D;
+};
+
+__global__ __launch_bounds__(64) void prep_dds_kernel(DdsPrepArgs a) {
+  __shared__ float e[128], h[64], tau[64];
+  const int j = threadIdx.x, t = blockIdx.x;
+  const float* P = a.params;
+  {
+    // timestep_coeff = linspace(0.1, 100, 64) (float32)   nn_dds.py:108
+    const double step = (100.0 - 0.1) / 63.0;
+    const float cj = (j == 63) ? 100.0f : (float)((double)j * step + 0.1);
+    const float arg = cj * (float)t + P[a.lay.d_phase + j];
+    e[j] = sinf(arg);
+    e[64 + j] = cosf(arg);
+  }
+  __syncthreads();
+  float acc = P[a.lay.d_tb1 + j];
+  for (int k = 0; k < 128; ++k) acc = fmaf(e[k], P[a.lay.d_tw1 + k * 64 + j], acc);
+  h[j] = gelu_exact(acc);
+  __syncthreads();
+  acc = P[a.lay.d_tb2 + j];
+  for (int k = 0; k < 64; ++k) acc = fmaf(h[k], P[a.lay.d_tw2 + k * 64 + j], acc);
+  tau[j] = acc;
+  __syncthreads();
+  acc = P[a.lay.d_sb1 + j];
+  for (int k = 0; k < 64; ++k) acc = fmaf(tau[k], P[a.lay.d_sw1 + (a.D + k) * 64 + j], acc);
+  a.ws[a.w.bias1 + (int64_t)t * 64 + j] = acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// 2b. geffner: emb[i] folded through W1[d:, :]; row K re-uses emb[K-1] (JAX clamps the
+//     out-of-range gather of nn.py:68 reached from mcd_cais.py:78 at the last bridge).
+// ------------------------------------------------------------------------------------------
+struct GefPrepArgs {
+  const float* params;
+  float* ws;
+  cmcd_layout lay;
+  WsLayout w;
+  int32_t D, E, K;
+};
+
+__global__ void prep_geffner_kernel(GefPrepArgs a) {
+  const int n = threadIdx.x, row = blockIdx.x;
+  const int ie = row < a.K ? row : a.K - 1;
+  const int in = a.D + a.E;
+  const float* P = a.params;
+  const float* emb = P + a.lay.g_emb + (int64_t)ie * a.E;
+  float b = 0.f, u = 0.f;
+  if (n < in) {
+    b = P[a.lay.g_b1 + n];
+    for (int j = 0; j < a.E; ++j) b = fmaf(emb[j], P[a.lay.g_w1 + (int64_t)(a.D + j) * in + n], b);
+    u = n >= a.D ? emb[n - a.D] : 0.f;
+  }
+  a.ws[a.w.bias1 + (int64_t)row * a.w.HP + n] = b;
+  a.ws[a.w.utab + (int64_t)row * a.w.HP + n] = u;
+}
+
+// ------------------------------------------------------------------------------------------
+// 3. weight packing.  w2[(t_in*T + t_out)*64 + lane][r] = W2[16 t_in + 4 g + r][16 t_out + i],
+//    lane = (g, i): the A operand (rows = output neurons, k = input neurons) of MFMA k-step
+//    (t_in, r) for output tile t_out.  Everything beyond the true width is zero.
+// ------------------------------------------------------------------------------------------
+struct PackArgs {
+  const float* params;
+  const float* tgt;
+  float* ws;
+  WsLayout w;
+  int64_t o_w1, o_w2, o_b2, o_w3, o_b3, o_factor;  // offsets in params (factor: -1 -> 1.0)
+  int32_t D, IN;                                   // true hidden width
+  int32_t target, n_mix;
+};
+
+__global__ void pack_weights_kernel(PackArgs a) {
+  const int HP = a.w.HP, T = a.w.T;
+  const float* P = a.params;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t idx = tid; idx < (int64_t)HP * HP; idx += stride) {
+    const int r = idx & 3, lane = (idx >> 2) & 63;
+    const int tt = int(idx >> 8), t_out = tt % T, t_in = tt / T;
+    const int kin = 16 * t_in + 4 * (lane >> 4) + r, nout = 16 * t_out + (lane & 15);
+    a.ws[a.w.w2 + idx] = (kin < a.IN && nout < a.IN) ? P[a.o_w2 + (int64_t)kin * a.IN + nout] : 0.f;
+  }
+  for (int64_t idx = tid; idx < (int64_t)a.D * HP; idx += stride) {
+    const int j = int(idx / HP), n = int(idx % HP);
+    a.ws[a.w.w1z + idx] = n < a.IN ? P[a.o_w1 + (int64_t)j * a.IN + n] : 0.f;
+    a.ws[a.w.w3t + idx] = n < a.IN ? P[a.o_w3 + (int64_t)n * a.D + j] : 0.f;
+  }
+  for (int64_t idx = tid; idx < HP; idx += stride) a.ws[a.w.b2 + idx] = idx < a.IN ? P[a.o_b2 + idx] : 0.f;
+  for (int64_t idx = tid; idx < 16; idx += stride) {
+    float v = 0.f;
+    if (idx < a.D) v = P[a.o_b3 + idx];
+    if (idx == 15) v = a.o_factor >= 0 ? P[a.o_factor] : 1.0f;
+    a.ws[a.w.b3 + idx] = v;
+  }
+  if (a.target == CMCD_TARGET_MANY_GMM) {
+    // tgt = {scale, means[n_mix][2]} -> {1/scale, logc, n_mix bits, 0, means}
+    for (int64_t idx = tid; idx < a.w.tgt_floats; idx += stride) {
+      float v = 0.f;
+      const float s = a.tgt[0];
+      if (idx == 0) v = 1.0f / s;
+      else if (idx == 1) v = -2.0f * (logf(s) + kHalfLog2Pi) - logf((float)a.n_mix);
+      else if (idx == 2) v = __int_as_float(a.n_mix);
+      else if (idx >= 4 && idx < 4 + 2 * a.n_mix) v = a.tgt[1 + (idx - 4)];
+      a.ws[a.w.tgt + idx] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// 4. the trajectory kernel
+// ------------------------------------------------------------------------------------------
+struct TrajArgs {
+  const int32_t* seeds;
+  const float* params;
+  const float* ws;
+  double* partials;
+  float* out_loss;
+  float* out_z;
+  cmcd_layout lay;
+  WsLayout w;
+  int64_t n;
+  int32_t K, var_mode, grad_clipping;
+};
+
+template <int ARCH>
+__device__ __forceinline__ float act(float pre) {
+  return ARCH == CMCD_ARCH_DDS ? gelu_exact(pre) : softplus(pre);
+}
+
+// One evaluation of the score network s(z, idx) for the 16 particles of this wave.
+//   dds     (nn_dds.py:159-162): h1 = gelu(W1^T[z; tau] + b1); h2 = gelu(W2^T h1 + b2); clip(W3^T h2 + b3)
+//   geffner (nn.py:45-52,66-70): u = [z; emb]; u += softplus(uW1 + b1); u += softplus(uW2 + b2);
+//                                factor_sn * (uW3 + b3)
+template <int ARCH, int D, int T>
+__device__ __forceinline__ void eval_net(const float (&z)[D], const float* __restrict__ brow,
+                                         const float* __restrict__ urow, const float* lds_w2,
+                                         const float* lds_w1z, const float* lds_b2, const float* lds_w3t,
+                                         const float* lds_b3, int lane, float (&s)[D]) {
+  constexpr int HP = 16 * T;
+  const int g = lane >> 4;
+  f32x4 h[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    f32x4 pre = *reinterpret_cast<const f32x4*>(brow + 16 * t + 4 * g);
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(lds_w1z + j * HP + 16 * t + 4 * g);
+      pre += z[j] * wv;
+    }
+    if (ARCH == CMCD_ARCH_DDS) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[t][r] = gelu_fast(pre[r]);
+    } else {
+      f32x4 u = *reinterpret_cast<const f32x4*>(urow + 16 * t + 4 * g);
+      if (16 * t < D) {  // the first D neurons of u are z itself
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int nidx = 16 * t + 4 * g + r;
+#pragma unroll
+          for (int j = 0; j < D; ++j)
+            if (j >= 16 * t && j < 16 * t + 16) u[r] = (nidx == j) ? z[j] : u[r];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[t][r] = u[r] + softplus(pre[r]);
+    }
+  }
+  // layer 2 on the matrix cores: acc[t_out] (rows = neurons 16 t_out + 4 g + r, cols = particles)
+  f32x4 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) acc[t] = *reinterpret_cast<const f32x4*>(lds_b2 + 16 * t + 4 * g);
+#pragma unroll
+  for (int ti = 0; ti < T; ++ti) {
+    // wide nets: keep the A fragments streaming from LDS (a compiler-level fence stops LICM from
+    // hoisting T*T*4 loop-invariant registers out of the bridge loop and spilling them)
+    if (T > 4) asm volatile("" ::: "memory");
+    f32x4 a[T];
+#pragma unroll
+    for (int to = 0; to < T; ++to)
+      a[to] = *reinterpret_cast<const f32x4*>(lds_w2 + ((ti * T + to) * 64 + lane) * 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int to = 0; to < T; ++to)
+        acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[to][r], h[ti][r], acc[to], 0, 0, 0);
+    }
+  }
+  // layer 3: every lane sums over its 4T neurons, then the 4 lanes of a particle combine
+  float part[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) part[j] = 0.f;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    f32x4 h2;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      h2[r] = (ARCH == CMCD_ARCH_DDS) ? gelu_fast(acc[t][r]) : h[t][r] + softplus(acc[t][r]);
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(lds_w3t + j * HP + 16 * t + 4 * g);
+      part[j] += h2[0] * wv[0] + h2[1] * wv[1] + h2[2] * wv[2] + h2[3] * wv[3];
+    }
+  }
+  const float factor = lds_b3[15];
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    const float o = group_sum(part[j]) + lds_b3[j];
+    s[j] = (ARCH == CMCD_ARCH_DDS) ? fminf(fmaxf(o, -1e4f), 1e4f) : o * factor;
+  }
+}
+
+template <int TARGET, int ARCH, int D, int T>
+__global__ __launch_bounds__(512) void traj_kernel(TrajArgs a) {
+  constexpr int HP = 16 * T;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* lds_w2 = lds;                    // HP*HP
+  float* lds_w1z = lds_w2 + HP * HP;      // D*HP
+  float* lds_w3t = lds_w1z + D * HP;      // D*HP
+  float* lds_b2 = lds_w3t + D * HP;       // HP
+  float* lds_b3 = lds_b2 + HP;            // 16
+  float* lds_tgt = lds_b3 + 16;           // tgt_floats
+  {
+    // the packed weights sit contiguously in the workspace in this same order
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.ws + a.w.w1z);
+    f32x4* dst = reinterpret_cast<f32x4*>(lds_w1z);
+    for (int i = threadIdx.x; i < D * HP / 4; i += blockDim.x) dst[i] = src[i];
+    src = reinterpret_cast<const f32x4*>(a.ws + a.w.w2);
+    dst = reinterpret_cast<f32x4*>(lds_w2);
+    for (int i = threadIdx.x; i < HP * HP / 4; i += blockDim.x) dst[i] = src[i];
+    src = reinterpret_cast<const f32x4*>(a.ws + a.w.w3t);
+    dst = reinterpret_cast<f32x4*>(lds_w3t);
+    for (int i = threadIdx.x; i < D * HP / 4; i += blockDim.x) dst[i] = src[i];
+    for (int i = threadIdx.x; i < HP; i += blockDim.x) lds_b2[i] = a.ws[a.w.b2 + i];
+    for (int i = threadIdx.x; i < 16; i += blockDim.x) lds_b3[i] = a.ws[a.w.b3 + i];
+    for (int i = threadIdx.x; i < a.w.tgt_floats; i += blockDim.x) lds_tgt[i] = a.ws[a.w.tgt + i];
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (wave * 16 >= a.n) return;  // whole wave out of range (after the only barrier)
+  const int64_t p = wave * 16 + c;
+  const bool valid = p < a.n;
+  const int32_t seed = a.seeds[valid ? p : a.n - 1];
+  const int K = a.K;
+
+  // q = N(mean, exp(logdiag)^2)                          vardist/diag_gauss.py:15-33
+  float qmean[D], qstd[D], qiv[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    qmean[j] = a.params[a.lay.vd_mean + j];
+    qstd[j] = expf(a.params[a.lay.vd_logdiag + j]);
+    qiv[j] = 1.0f / (qstd[j] * qstd[j]);
+  }
+
+  // ---- key chain (mcdboundingmachine.py:151-162, mcd_cais.py:94).  Lane g computes block (g & 1)
+  //      of a split: counters (b, 2 + b) -> (out[b], out[2 + b]).
+  const int gb = g & 1;
+  uint32_t x0, x1, k0 = 0u, k1 = (uint32_t)seed;  // PRNGKey(seed) = (0, seed)
+  float z[D];
+  {
+    x0 = gb; x1 = 2 + gb;
+    threefry2x32(k0, k1, x0, x1);  // split(PRNGKey(seed)) -> A = (out0,out1), B = (out2,out3)
+    const uint32_t a0 = __shfl(x0, c), a1 = __shfl(x0, c + 16);
+    const uint32_t b0 = __shfl(x1, c), b1 = __shfl(x1, c + 16);
+    // z0 = mean + std * normal(A, (D,))                  diag_gauss.py:49-62
+    constexpr int Hh = (D + 1) / 2;
+    float nz[2 * Hh];
+#pragma unroll
+    for (int j0 = 0; j0 < Hh; j0 += 4) {
+      const int j = j0 + g;  // block j encrypts (ctr[j], ctr[Hh + j]); pad counters are 0
+      uint32_t y0 = j, y1 = (Hh + j < D) ? Hh + j : 0;
+      threefry2x32(a0, a1, y0, y1);
+      const float n0 = bits_to_normal(y0), n1 = bits_to_normal(y1);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (j0 + q < Hh) {
+          nz[j0 + q] = __shfl(n0, c + 16 * q);
+          nz[Hh + j0 + q] = __shfl(n1, c + 16 * q);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) z[j] = qstd[j] * nz[j] + qmean[j];
+    // C = first(split(B)); gen = second(split(C))
+    x0 = gb; x1 = 2 + gb;
+    threefry2x32(b0, b1, x0, x1);
+    const uint32_t c0 = __shfl(x0, c), c1 = __shfl(x0, c + 16);
+    x0 = gb; x1 = 2 + gb;
+    threefry2x32(c0, c1, x0, x1);
+    k0 = __shfl(x1, c);
+    k1 = __shfl(x1, c + 16);
+  }
+
+  // w = -log q(z0)                                       mcdboundingmachine.py:157
+  float w = 0.f;
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    const float dz = z[j] - qmean[j];
+    w -= -(dz * dz) / (2.0f * qstd[j] * qstd[j]) - logf(qstd[j]) - kHalfLog2Pi;
+  }
+
+  const float clipv = a.var_mode ? 1e2f : 1e3f;  // mcd_cais.py:24 / mcd_cais_var.py:33
+  const bool clip_p = a.grad_clipping != 0;
+  const bool clip_q = clip_p && a.var_mode;
+
+  const float* bias1 = a.ws + a.w.bias1;
+  const float* utab = a.ws + a.w.utab;
+
+  // Rotated loop: iteration i evaluates grad log p and the score net ONCE at (z_i, i); that one
+  // evaluation closes step i-1 (its backward kernel, mcd_cais.py:71-79) and opens step i (its
+  // forward kernel, :52-67) — the reference evaluates both twice.
+  float zp[D];           // z_{i-1}
+  float fk_lp = 0.f;     // log F_{i-1}(z_i | z_{i-1})
+  float pbeta = 0.f, peps = 0.f, pinv2s2 = 0.f, plogsig = 0.f;
+  float logp = 0.f;
+#pragma unroll
+  for (int j = 0; j < D; ++j) zp[j] = 0.f;
+
+  for (int i = 0; i <= K; ++i) {
+    float gp[D], sn[D];
+    Target<TARGET, D>::eval(z, g, lds_tgt, logp, gp);
+    eval_net<ARCH, D, T>(z, bias1 + (int64_t)i * HP, utab + (int64_t)i * HP, lds_w2, lds_w1z, lds_b2, lds_w3t,
+                         lds_b3, lane, sn);
+    float gq[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      gq[j] = -(z[j] - qmean[j]) * qiv[j];
+      if (clip_p) gp[j] = fminf(fmaxf(gp[j], -clipv), clipv);
+      if (clip_q) gq[j] = fminf(fmaxf(gq[j], -clipv), clipv);
+    }
+
+    if (i > 0) {
+      // ---- backward kernel of step i-1 at z_new = z with net index i      mcd_cais.py:71-86
+      float bk_lp = 0.f;
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        const float ub = -1.0f * (pbeta * gp[j] + (1.0f - pbeta) * gq[j]);
+        const float bk = z[j] - peps * ub + peps * sn[j];
+        const float db = zp[j] - bk;
+        bk_lp += -(db * db) * pinv2s2 - plogsig - kHalfLog2Pi;  // log_prob_kernel, mcd_utils.py:19-21
+      }
+      w += bk_lp - fk_lp;
+    }
+    if (i == K) break;
+
+    const float beta = a.ws[a.w.beta + i], eps = a.ws[a.w.eps + i];
+    const float sig = a.ws[a.w.sig + i], logsig = a.ws[a.w.logsig + i];
+    const float inv2s2 = 1.0f / (2.0f * sig * sig);
+
+    // ---- noise: (G, H) = split(gen); eps_i = normal(G, (D,)); gen = second(split(H))
+    //      mcd_cais.py:66-67,87
+    x0 = gb; x1 = 2 + gb;
+    threefry2x32(k0, k1, x0, x1);
+    const uint32_t g0 = __shfl(x0, c), g1 = __shfl(x0, c + 16);
+    const uint32_t h0 = __shfl(x1, c), h1 = __shfl(x1, c + 16);
+    constexpr int Hh = (D + 1) / 2;
+    constexpr int NB = 2 + Hh;  // blocks of this stage: 2 for split(H), Hh for normal(G)
+    float nz[2 * Hh];
+#pragma unroll
+    for (int b0 = 0; b0 < NB; b0 += 4) {
+      const int b = b0 + g;               // block handled by this lane in this pass
+      const bool is_split = b < 2;
+      const int jn = b - 2;               // normal block index
+      uint32_t y0 = is_split ? b : jn;
+      uint32_t y1 = is_split ? 2 + b : ((Hh + jn < D) ? Hh + jn : 0);
+      threefry2x32(is_split ? h0 : g0, is_split ? h1 : g1, y0, y1);
+      if (b0 == 0) {
+        k0 = __shfl(y1, c);
+        k1 = __shfl(y1, c + 16);
+      }
+      const float n0 = bits_to_normal(y0), n1 = bits_to_normal(y1);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int jj = b0 + q - 2;
+        if (jj >= 0 && jj < Hh) {
+          nz[jj] = __shfl(n0, c + 16 * q);
+          nz[Hh + jj] = __shfl(n1, c + 16 * q);
+        }
+      }
+    }
+
+    // ---- forward kernel of step i                                          mcd_cais.py:52-67
+    fk_lp = 0.f;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const float uf = -1.0f * (beta * gp[j] + (1.0f - beta) * gq[j]);
+      const float fk = z[j] - eps * uf - eps * sn[j];
+      const float zn = fk + sig * nz[j];
+      const float df = zn - fk;
+      fk_lp += -(df * df) * inv2s2 - logsig - kHalfLog2Pi;
+      zp[j] = z[j];
+      z[j] = zn;
+    }
+    pbeta = beta; peps = eps; pinv2s2 = inv2s2; plogsig = logsig;
+  }
+  w += logp;  // + log p(z_K)   mcdboundingmachine.py:178
+  const float loss = -w;
+
+  if (valid && g == 0) {
+    a.out_loss[p] = loss;
+#pragma unroll
+    for (int j = 0; j < D; ++j) a.out_z[p * D + j] = z[j];
+  }
+
+  // ---- per-wave statistics over lanes 0..15 (g == 0), fixed butterfly order -> deterministic
+  const bool use = valid && g == 0;
+  double cnt = (use && isfinite(loss)) ? 1.0 : 0.0;
+  double sm = use ? (double)loss : 0.0;
+  double sq = use ? (double)loss * (double)loss : 0.0;
+  double mx = use ? -(double)loss : -INFINITY;
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) {
+    cnt += __shfl_xor(cnt, o);
+    sm += __shfl_xor(sm, o);
+    sq += __shfl_xor(sq, o);
+    mx = fmax(mx, __shfl_xor(mx, o));
+  }
+  double ex = (use && mx > -INFINITY && mx < INFINITY) ? exp(-(double)loss - mx) : 0.0;
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) ex += __shfl_xor(ex, o);
+  if (lane == 0) {
+    double* o = a.partials + wave * CMCD_NSTATS;
+    o[0] = cnt; o[1] = sm; o[2] = sq; o[3] = mx; o[4] = ex;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// 5. finalize: merge the per-wave statistics in a fixed order (deterministic).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void stats_merge(double* a, const double* b) {
+  a[0] += b[0];
+  a[1] += b[1];
+  a[2] += b[2];
+  const double m = fmax(a[3], b[3]);
+  const double sa = (a[3] > -INFINITY && m < INFINITY) ? a[4] * exp(a[3] - m) : (a[3] == m ? a[4] : 0.0);
+  const double sb = (b[3] > -INFINITY && m < INFINITY) ? b[4] * exp(b[3] - m) : (b[3] == m ? b[4] : 0.0);
+  a[3] = m;
+  a[4] = sa + sb;
+}
+
+__global__ __launch_bounds__(256) void finalize_kernel(const double* partials, int32_t n_waves, double* out) {
+  __shared__ double sh[256][CMCD_NSTATS];
+  double acc[CMCD_NSTATS] = {0, 0, 0, -INFINITY, 0};
+  // contiguous chunks keep the merge order independent of blockDim-strided races
+  const int per = (n_waves + 255) / 256;
+  const int lo = threadIdx.x * per, hi = min(n_waves, lo + per);
+  for (int i = lo; i < hi; ++i) stats_merge(acc, partials + (int64_t)i * CMCD_NSTATS);
+  for (int k = 0; k < CMCD_NSTATS; ++k) sh[threadIdx.x][k] = acc[k];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) stats_merge(sh[threadIdx.x], sh[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x < CMCD_NSTATS) out[threadIdx.x] = sh[0][threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+typedef void (*traj_fn)(TrajArgs);
+
+template <int TARGET, int ARCH, int D>
+static traj_fn pick_T(int T) {
+  switch (T) {
+    case 2: return traj_kernel<TARGET, ARCH, D, 2>;
+    case 4: return traj_kernel<TARGET, ARCH, D, 4>;
+    case 9: return traj_kernel<TARGET, ARCH, D, 9>;
+    default: return nullptr;
+  }
+}
+
+static traj_fn pick_kernel(const cmcd_desc& d, int T) {
+  if (d.arch == CMCD_ARCH_DDS) {
+    if (T != 4) return nullptr;
+    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2) return traj_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_DDS, 2, 4>;
+    if (d.target == CMCD_TARGET_GMM && d.dim == 2) return traj_kernel<CMCD_TARGET_GMM, CMCD_ARCH_DDS, 2, 4>;
+    if (d.target == CMCD_TARGET_FUNNEL && d.dim == 10) return traj_kernel<CMCD_TARGET_FUNNEL, CMCD_ARCH_DDS, 10, 4>;
+    return nullptr;
+  }
+  if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2) return pick_T<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2>(T);
+  if (d.target == CMCD_TARGET_GMM && d.dim == 2) return pick_T<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER, 2>(T);
+  if (d.target == CMCD_TARGET_FUNNEL && d.dim == 10) return pick_T<CMCD_TARGET_FUNNEL, CMCD_ARCH_GEFFNER, 10>(T);
+  return nullptr;
+}
+
+static int check_desc(const cmcd_desc* d) {
+  if (!d) return fail(CMCD_ERR_BAD_ARG, "null desc%s");
+  if (d->mode != CMCD_MODE_CAIS_SN && d->mode != CMCD_MODE_CAIS_VAR_SN)
+    return fail(CMCD_ERR_UNSUPPORTED, "Mode not implemented.%s");
+  if (d->arch != CMCD_ARCH_DDS && d->arch != CMCD_ARCH_GEFFNER)
+    return fail(CMCD_ERR_UNSUPPORTED, "nn_arch not implemented%s");
+  if (d->nbridges < 1) return fail(CMCD_ERR_BAD_ARG, "nbridges must be >= 1%s");
+  if (d->ngrid < 1 || d->ngrid > 32) return fail(CMCD_ERR_BAD_ARG, "ngrid must be in [1, 32]%s");
+  if (d->eps_schedule == CMCD_EPS_LINEAR && d->nbridges < 2)
+    return fail(CMCD_ERR_BAD_ARG, "linear eps schedule needs nbridges >= 2%s");
+  int HP;
+  if (!hidden_width(*d, HP)) return fail(CMCD_ERR_BAD_ARG, "bad emb_dim%s");
+  if (!pick_kernel(*d, HP / 16))
+    return fail(CMCD_ERR_UNSUPPORTED, "no kernel instance for this (target, dim, arch, width=%s%lld)", "", HP);
+  return CMCD_OK;
+}
+
+}  // namespace cmcd
+
+using namespace cmcd;
+
+extern "C" {
+
+int cmcd_version(void) { return CMCD_ABI_VERSION; }
+const char* cmcd_last_error(void) { return g_err; }
+
+int64_t cmcd_target_floats(const cmcd_desc* desc, int32_t n_mixes) {
+  if (!desc) return -1;
+  switch (desc->target) {
+    case CMCD_TARGET_GMM:
+    case CMCD_TARGET_FUNNEL: return 0;
+    case CMCD_TARGET_MANY_GMM: return 1 + 2 * (int64_t)n_mixes;
+    case CMCD_TARGET_LGCP: return (int64_t)desc->dim * desc->dim + desc->dim + 3;
+    default: return -1;
+  }
+}
+
+int64_t cmcd_workspace_bytes(const cmcd_desc* desc, int64_t n) {
+  if (check_desc(desc) != CMCD_OK || n < 1) return 0;
+  WsLayout w;
+  // size for the largest target-constant block this target can stage (64 mixtures)
+  const int64_t nt = desc->target == CMCD_TARGET_MANY_GMM ? 1 + 2 * 64 : 0;
+  if (!make_ws(*desc, n, nt, w)) return 0;
+  return w.total_floats * 4;
+}
+
+#define CMCD_HIP_CHECK(expr)                                                                   \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) return fail(CMCD_ERR_HIP, "HIP error: %s (code %lld)", hipGetErrorString(e_), (long long)e_); \
+  } while (0)
+
+int cmcd_bound_forward(const cmcd_desc* desc, const cmcd_layout* lay, const int32_t* seeds, int64_t n,
+                       const float* params, int64_t n_params, const float* target_consts, int64_t n_target,
+                       void* workspace, int64_t workspace_bytes, float* out_loss, float* out_z,
+                       double* out_stats, void* stream_) {
+  int rc = check_desc(desc);
+  if (rc != CMCD_OK) return rc;
+  if (!lay || !seeds || !params || !workspace || !out_loss || !out_z || !out_stats)
+    return fail(CMCD_ERR_BAD_ARG, "null pointer argument%s");
+  if (n < 1 || n > (int64_t)1 << 31) return fail(CMCD_ERR_BAD_ARG, "n out of range%s");
+  const cmcd_desc& d = *desc;
+  const int64_t K = d.nbridges, D = d.dim, E = d.emb_dim, IN = D + E;
+
+  // every leaf this configuration reads must lie inside params_flat
+  auto need = [&](int64_t off, int64_t len) { return off >= 0 && off + len <= n_params; };
+  bool ok = need(lay->vd_mean, D) && need(lay->vd_logdiag, D) && need(lay->eps, 1) &&
+            need(lay->mgridref_y, d.ngrid + 1);
+  if (d.arch == CMCD_ARCH_GEFFNER)
+    ok = ok && need(lay->g_emb, K * E) && need(lay->g_factor, 1) && need(lay->g_w1, IN * IN) &&
+         need(lay->g_b1, IN) && need(lay->g_w2, IN * IN) && need(lay->g_b2, IN) && need(lay->g_w3, IN * D) &&
+         need(lay->g_b3, D);
+  else
+    ok = ok && need(lay->d_phase, 64) && need(lay->d_tw1, 128 * 64) && need(lay->d_tb1, 64) &&
+         need(lay->d_tw2, 64 * 64) && need(lay->d_tb2, 64) && need(lay->d_sw1, (D + 64) * 64) &&
+         need(lay->d_sb1, 64) && need(lay->d_sw2, 64 * 64) && need(lay->d_sb2, 64) &&
+         need(lay->d_sw3, 64 * D) && need(lay->d_sb3, D);
+  if (!ok) return fail(CMCD_ERR_BAD_ARG, "layout offset missing or outside params_flat%s");
+
+  int n_mix = 0;
+  if (d.target == CMCD_TARGET_MANY_GMM) {
+    if (!target_consts || n_target < 3 || (n_target - 1) % 2 != 0 || (n_target - 1) / 2 > 64)
+      return fail(CMCD_ERR_BAD_ARG, "many_gmm needs target_consts = {scale, means[n_mixes<=64][2]}%s");
+    n_mix = int((n_target - 1) / 2);
+  } else if (d.target == CMCD_TARGET_LGCP) {
+    return fail(CMCD_ERR_UNSUPPORTED, "lgcp goes through cmcd_bound_forward_lgcp%s");
+  }
+
+  WsLayout w;
+  if (!make_ws(d, n, n_target, w)) return fail(CMCD_ERR_BAD_ARG, "bad descriptor%s");
+  if (workspace_bytes < w.total_floats * 4 || (reinterpret_cast<uintptr_t>(workspace) & 15))
+    return fail(CMCD_ERR_WORKSPACE, "workspace too small or not 16-byte aligned (need %s%lld bytes)", "",
+                w.total_floats * 4);
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  float* ws = static_cast<float*>(workspace);
+
+  {
+    SchedArgs a{params, ws, *lay, w, (int32_t)K, d.ngrid, d.eps_schedule, -1, -1};
+    hipLaunchKernelGGL(prep_sched_kernel, dim3(1), dim3(256), 0, stream, a);
+  }
+  PackArgs pk{};
+  pk.params = params; pk.tgt = target_consts; pk.ws = ws; pk.w = w;
+  pk.D = (int32_t)D; pk.target = d.target; pk.n_mix = n_mix;
+  if (d.arch == CMCD_ARCH_DDS) {
+    DdsPrepArgs a{params, ws, *lay, w, (int32_t)D};
+    hipLaunchKernelGGL(prep_dds_kernel, dim3((unsigned)K + 1), dim3(64), 0, stream, a);
+    pk.o_w1 = lay->d_sw1; pk.o_w2 = lay->d_sw2; pk.o_b2 = lay->d_sb2; pk.o_w3 = lay->d_sw3;
+    pk.o_b3 = lay->d_sb3; pk.o_factor = -1; pk.IN = 64;
+  } else {
+    GefPrepArgs a{params, ws, *lay, w, (int32_t)D, (int32_t)E, (int32_t)K};
+    hipLaunchKernelGGL(prep_geffner_kernel, dim3((unsigned)K + 1), dim3(w.HP), 0, stream, a);
+    pk.o_w1 = lay->g_w1; pk.o_w2 = lay->g_w2; pk.o_b2 = lay->g_b2; pk.o_w3 = lay->g_w3;
+    pk.o_b3 = lay->g_b3; pk.o_factor = lay->g_factor; pk.IN = (int32_t)IN;
+  }
+  hipLaunchKernelGGL(pack_weights_kernel, dim3((w.HP * w.HP + 255) / 256), dim3(256), 0, stream, pk);
+
+  traj_fn fn = pick_kernel(d, w.T);
+  // waves per workgroup: one wave per CU until every CU has one, then grow (weights are
+  // staged once per workgroup, so bigger groups amortise the LDS fill).
+  const int64_t tiles = w.n_waves;
+  const size_t lds_bytes = size_t(w.HP * w.HP + 2 * D * w.HP + w.HP + 16 + w.tgt_floats) * 4;
+  if (lds_bytes > 160 * 1024) return fail(CMCD_ERR_UNSUPPORTED, "network too wide for LDS%s");
+  int64_t per_cu = (160 * 1024) / (int64_t)lds_bytes;
+  if (per_cu > 8) per_cu = 8;
+  int nw = 1;
+  while (nw < 8 && (tiles + nw - 1) / nw > 256 * per_cu) nw *= 2;
+  CMCD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  TrajArgs ta{seeds, params, ws, reinterpret_cast<double*>(ws + w.partials), out_loss, out_z, *lay, w, n,
+              (int32_t)K, d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0, d.grad_clipping};
+  const unsigned blocks = unsigned((tiles + nw - 1) / nw);
+  hipLaunchKernelGGL(fn, dim3(blocks), dim3(64 * nw), lds_bytes, stream, ta);
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, stream,
+                     reinterpret_cast<const double*>(ws + w.partials), w.n_waves, out_stats);
+  CMCD_HIP_CHECK(hipGetLastError());
+  return CMCD_OK;
+}
+
+int cmcd_stats_merge(const double* stats, const int64_t* n_per, int32_t count, double* merged5, double* out3) {
+  if (!stats || !n_per || count < 1 || !merged5 || !out3) return fail(CMCD_ERR_BAD_ARG, "null pointer argument%s");
+  double acc[CMCD_NSTATS] = {0, 0, 0, -INFINITY, 0};
+  int64_t n = 0;
+  for (int i = 0; i < count; ++i) {
+    const double* b = stats + (int64_t)i * CMCD_NSTATS;
+    acc[0] += b[0]; acc[1] += b[1]; acc[2] += b[2];
+    const double m = fmax(acc[3], b[3]);
+    const double sa = (acc[3] > -INFINITY && m < INFINITY) ? acc[4] * exp(acc[3] - m) : (acc[3] == m ? acc[4] : 0.0);
+    const double sb = (b[3] > -INFINITY && m < INFINITY) ? b[4] * exp(b[3] - m) : (b[3] == m ? b[4] : 0.0);
+    acc[3] = m; acc[4] = sa + sb;
+    n += n_per[i];
+  }
+  if (n < 1) return fail(CMCD_ERR_BAD_ARG, "no particles%s");
+  memcpy(merged5, acc, sizeof(acc));
+  const double mean = acc[1] / (double)n;
+  out3[0] = mean;
+  out3[1] = acc[2] / (double)n - mean * mean;        // var(ddof=0); inf - inf = NaN like the reference
+  out3[2] = acc[3] + log(acc[4]) - log((double)n);   // logsumexp(-l) - log n
+  return CMCD_OK;
+}
+
+}  // extern "C"

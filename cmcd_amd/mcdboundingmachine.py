@@ -1,0 +1,264 @@
+"""The drop-in boundary: `initialize`, `compute_bound`, `compute_bound_var`.
+
+Same names, positional signatures and return structure as
+/root/reference/src/mcdboundingmachine.py:11-28,183-231, with torch tensors on a ROCm device in
+place of jax arrays and a `Target` descriptor (cmcd_amd.model_handler) in place of the traceable
+`log_prob` callable.  All arithmetic of the path runs in libcmcd_hip.so (include/cmcd_hip.h);
+there is no CPU fallback.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from . import variationaldist as vd
+from .nn import ScoreNet, initialize_network
+
+_SN_MODES = ["MCD_ULA_sn", "MCD_U_e-lp-sna", "MCD_U_a-lp-sna", "MCD_CAIS_sn", "MCD_CAIS_var_sn"]
+_SUPPORTED = ("MCD_CAIS_sn", "MCD_CAIS_var_sn")
+
+
+# --------------------------------------------------------------------------- ravel_pytree
+def _flatten(tree, prefix=()):
+    """Leaves in jax tree order: dict keys sorted, sequences in order."""
+    if isinstance(tree, dict):
+        for k in sorted(tree):
+            yield from _flatten(tree[k], prefix + (k,))
+    elif isinstance(tree, (list, tuple)):
+        for i, v in enumerate(tree):
+            yield from _flatten(v, prefix + (i,))
+    else:
+        yield prefix, tree
+
+
+def _rebuild(tree, leaves, prefix=()):
+    if isinstance(tree, dict):
+        return {k: _rebuild(tree[k], leaves, prefix + (k,)) for k in tree}
+    if isinstance(tree, (list, tuple)):
+        return type(tree)(_rebuild(v, leaves, prefix + (i,)) for i, v in enumerate(tree))
+    return leaves[prefix]
+
+
+class Unflatten:
+    """Callable inverse of the flattening; also records where each leaf sits (`.layout`)."""
+
+    def __init__(self, tree):
+        self._tree = tree
+        self.layout = {}
+        off = 0
+        for path, leaf in _flatten(tree):
+            shape = tuple(torch.as_tensor(leaf).shape)
+            numel = 1
+            for s in shape:
+                numel *= s
+            self.layout[path] = (off, shape)
+            off += numel
+        self.size = off
+
+    def __call__(self, params_flat):
+        leaves = {p: params_flat[o:o + max(1, _numel(s))].view(s) for p, (o, s) in self.layout.items()}
+        return _rebuild(self._tree, leaves)
+
+    def offset(self, *path):
+        """Offset of a leaf, searched in (params_train, params_notrain)."""
+        for root in (0, 1):
+            if (root,) + path in self.layout:
+                return self.layout[(root,) + path][0]
+        return -1
+
+    def shape(self, *path):
+        for root in (0, 1):
+            if (root,) + path in self.layout:
+                return self.layout[(root,) + path][1]
+        return None
+
+    def __hash__(self):
+        return id(self)
+
+
+def _numel(shape):
+    n = 1
+    for s in shape:
+        n *= s
+    return n
+
+
+def ravel_pytree(tree, device=None):
+    un = Unflatten(tree)
+    flat = torch.cat([torch.as_tensor(leaf, dtype=torch.float32).reshape(-1) for _, leaf in _flatten(tree)])
+    if device is not None:
+        flat = flat.to(device)
+    return flat.contiguous(), un
+
+
+# --------------------------------------------------------------------------- initialize
+def initialize(
+    dim,
+    vdparams=None,
+    nbridges=0,
+    eps=0.01,
+    gamma=10.0,
+    eta=0.5,
+    ngridb=32,
+    mgridref_y=None,
+    trainable=["eps"],
+    use_score_nn=True,
+    emb_dim=48,
+    nlayers=3,
+    seed=1,
+    mode="MCD_U_lp-e",
+    nn_arch="dds",
+    fully_connected_units=None,
+    device=None,
+):
+    """/root/reference/src/mcdboundingmachine.py:11-123.  Returns
+    (params_flat, unflatten, params_fixed) with params_fixed = (dim, nbridges, mode, apply_fun_sn).
+    `device` (extra, keyword-only in practice) defaults to the current ROCm device."""
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    params_train, params_notrain = {}, {}
+
+    def put(name, value):
+        (params_train if name in trainable else params_notrain)[name] = value
+
+    put("vd", vdparams if vdparams is not None else vd.initialize(dim))
+    put("eps", torch.tensor(float(eps), dtype=torch.float32))
+    put("gamma", torch.tensor(float(gamma), dtype=torch.float32))
+    put("eta", torch.tensor(float(eta), dtype=torch.float32))
+
+    if mode in _SN_MODES:
+        init_fun_sn, apply_fun_sn = initialize_network(
+            dim, emb_dim, nbridges, nlayers=nlayers, nn_arch=nn_arch,
+            fully_connected_units=fully_connected_units)
+        params_train["sn"] = init_fun_sn(seed, None)[1]
+    elif mode in ["MCD_U_a-lp-sn", "MCD_U_ea-lp-sn", "MCD_U_a-nv-sn", "MCD_CAIS_UHA_sn"]:
+        raise NotImplementedError("Mode not implemented.")  # momentum modes: outside the hot path
+    else:
+        apply_fun_sn = None
+
+    # betas = interp over the normalised cumulative mgridref_y   (:104-118)
+    if mgridref_y is not None:
+        mgridref_y = torch.as_tensor(mgridref_y, dtype=torch.float32)
+        ngridb = mgridref_y.shape[0] - 1
+    else:
+        if nbridges < ngridb:
+            ngridb = nbridges
+        mgridref_y = torch.ones(ngridb + 1, dtype=torch.float32)
+    params_notrain["gridref_x"] = torch.linspace(0, 1, ngridb + 2, dtype=torch.float32)
+    params_notrain["target_x"] = torch.linspace(0, 1, nbridges + 2, dtype=torch.float32)[1:-1]
+    put("mgridref_y", mgridref_y)
+
+    params_fixed = (dim, nbridges, mode, apply_fun_sn)
+    params_flat, unflatten = ravel_pytree((params_train, params_notrain), device=device)
+    return params_flat, unflatten, params_fixed
+
+
+# --------------------------------------------------------------------------- the HIP call
+_workspaces = {}
+
+
+def _workspace(device, nbytes):
+    key = str(device)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def _layout(unflatten, spec):
+    lay = _lib.Layout(*([-1] * len(_lib.LAYOUT_FIELDS)))
+    o = unflatten.offset
+    lay.vd_mean, lay.vd_logdiag = o("vd", "mean"), o("vd", "logdiag")
+    lay.eps, lay.mgridref_y = o("eps"), o("mgridref_y")
+    if spec.arch == "geffner":
+        lay.g_emb, lay.g_factor = o("sn", "emb"), o("sn", "factor_sn")
+        lay.g_w1, lay.g_b1 = o("sn", "nn", 0, 0), o("sn", "nn", 0, 1)
+        lay.g_w2, lay.g_b2 = o("sn", "nn", 1, 0), o("sn", "nn", 1, 1)
+        lay.g_w3, lay.g_b3 = o("sn", "nn", 2, 0), o("sn", "nn", 2, 1)
+    else:
+        lay.d_phase = o("sn", "drift_net", "timestep_phase")
+        for i, (wn, bn) in enumerate((("d_tw1", "d_tb1"), ("d_tw2", "d_tb2"), ("d_sw1", "d_sb1"), ("d_sw2", "d_sb2"))):
+            mod = "drift_net/~/linear" + ("" if i == 0 else f"_{i}")
+            setattr(lay, wn, o("sn", mod, "w"))
+            setattr(lay, bn, o("sn", mod, "b"))
+        lay.d_sw3, lay.d_sb3 = o("sn", "drift_net/~/linear_zero", "w"), o("sn", "drift_net/~/linear_zero", "b")
+    return lay
+
+
+def bound_forward(seeds, params_flat, unflatten, params_fixed, log_prob, eps_schedule=None, grad_clipping=False):
+    """One launch sequence of the hot path.  Returns (losses[N] f32, z[N,dim] f32, stats[5] f64),
+    all device tensors, enqueued asynchronously on the current stream."""
+    dim, nbridges, mode, spec = params_fixed
+    if mode not in _SUPPORTED:
+        raise NotImplementedError("Mode not implemented.")  # same text as mcd_utils.py:190
+    if not isinstance(spec, ScoreNet):
+        raise ValueError("params_fixed[3] must be the ScoreNet returned by initialize()")
+    if eps_schedule not in _lib.EPS_SCHEDULE:
+        eps_schedule = None  # the reference falls through to constant eps (mcd_cais.py:58-59)
+    if not hasattr(log_prob, "target_id"):
+        raise TypeError("log_prob must be a cmcd_amd.model_handler.Target (see load_model)")
+    if log_prob.dim != dim:
+        raise ValueError(f"target dim {log_prob.dim} != params_fixed dim {dim}")
+    if not params_flat.is_cuda:
+        raise RuntimeError("the CMCD hot path runs on a ROCm device only: params_flat is not a device tensor")
+    L = _lib.lib()
+    device = params_flat.device
+    if params_flat.dtype != torch.float32 or not params_flat.is_contiguous():
+        raise ValueError("params_flat must be contiguous float32")
+    seeds = torch.as_tensor(seeds)
+    if seeds.device != device or seeds.dtype != torch.int32 or not seeds.is_contiguous():
+        seeds = seeds.to(device=device, dtype=torch.int32).contiguous()
+    n = seeds.numel()
+    if n < 1:
+        raise ValueError("seeds is empty")
+
+    desc = _lib.Desc(dim=dim, nbridges=nbridges, mode=_lib.MODE[mode], arch=_lib.ARCH[spec.arch],
+                     emb_dim=spec.emb_dim, target=log_prob.target_id,
+                     eps_schedule=_lib.EPS_SCHEDULE[eps_schedule], grad_clipping=int(bool(grad_clipping)),
+                     ngrid=unflatten.shape("mgridref_y")[0] - 1, reserved=0)
+    lay = _layout(unflatten, spec)
+    if log_prob.name == "lgcp":
+        from .lgcp import bound_forward_lgcp
+        return bound_forward_lgcp(L, desc, lay, seeds, params_flat, log_prob)
+    nbytes = L.cmcd_workspace_bytes(C.byref(desc), n)
+    if nbytes <= 0:
+        _lib.check(-2 if "not implemented" in _lib.last_error() or "no kernel" in _lib.last_error() else -1)
+    ws = _workspace(device, nbytes)
+    consts = log_prob.consts_on(device)
+    losses = torch.empty(n, dtype=torch.float32, device=device)
+    z = torch.empty(n, dim, dtype=torch.float32, device=device)
+    stats = torch.empty(_lib.NSTATS, dtype=torch.float64, device=device)
+    with torch.cuda.device(device):
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = L.cmcd_bound_forward(
+            C.byref(desc), C.byref(lay), seeds.data_ptr(), n, params_flat.data_ptr(), params_flat.numel(),
+            consts.data_ptr() if consts is not None else None, consts.numel() if consts is not None else 0,
+            ws.data_ptr(), ws.numel(), losses.data_ptr(), z.data_ptr(), stats.data_ptr(), stream)
+    _lib.check(rc)
+    return losses, z, stats
+
+
+def compute_bound(seeds, params_flat, unflatten, params_fixed, log_prob, eps_schedule=None, grad_clipping=False):
+    """/root/reference/src/mcdboundingmachine.py:183-205 -> (mean(losses), (losses, z))."""
+    losses, z, stats = bound_forward(seeds, params_flat, unflatten, params_fixed, log_prob,
+                                     eps_schedule=eps_schedule, grad_clipping=grad_clipping)
+    mean = (stats[1] / losses.numel()).to(torch.float32)
+    return mean, (losses, z)
+
+
+def compute_bound_var(seeds, params_flat, unflatten, params_fixed, log_prob, eps_schedule=None,
+                      grad_clipping=False, ln_Z_correction=False):
+    """/root/reference/src/mcdboundingmachine.py:208-231 -> (clip(var(losses, ddof=0), +-1e7), (losses, z)).
+    `ln_Z_correction` is accepted and unused, as in the reference (:216)."""
+    losses, z, stats = bound_forward(seeds, params_flat, unflatten, params_fixed, log_prob,
+                                     eps_schedule=eps_schedule, grad_clipping=grad_clipping)
+    n = losses.numel()
+    mean = stats[1] / n
+    var = stats[2] / n - mean * mean  # inf - inf = nan, which clip passes through like jnp.clip
+    return torch.clamp(var, -1e7, 1e7).to(torch.float32), (losses, z)
+
+
+def ln_z_from_stats(stats, n):
+    """logsumexp(-losses) - log n (/root/reference/src/utils.py:233-235) from the statistics vector."""
+    return stats[3] + torch.log(stats[4]) - torch.log(torch.tensor(float(n), dtype=torch.float64, device=stats.device))

@@ -1,0 +1,135 @@
+/*
+ * cmcd_hip.h — C ABI of libcmcd_hip.so: the MI355X (gfx950) implementation of CMCD's
+ * annealed-Langevin bound evaluation (`MCD_CAIS_sn` / `MCD_CAIS_var_sn`).
+ *
+ * The reference is pure Python/JAX and has no FFI; the "interface each entry point
+ * replaces" is therefore the jitted Python callable the reference builds around the path:
+ *
+ *   cmcd_bound_forward   <->  loss_fn = jax.jit(partial(mcdbm.compute_bound[_var], eps_schedule=…,
+ *                             grad_clipping=…), static_argnums=(2,3,4))
+ *                             /root/reference/src/main.py:161-177, called positionally as
+ *                             f(seeds, params_flat, unflatten, params_fixed, log_prob_model) at
+ *                             /root/reference/src/opt.py:97-99,102-104,188-190; body
+ *                             /root/reference/src/mcdboundingmachine.py:126-231 ->
+ *                             /root/reference/src/mcd_utils.py:134-161 ->
+ *                             /root/reference/src/mcd_cais.py:6-99 / mcd_cais_var.py:7-112.
+ *   cmcd_desc            <->  params_fixed = (dim, nbridges, mode, apply_fun_sn)
+ *                             (/root/reference/src/mcdboundingmachine.py:121) + the static
+ *                             eps_schedule / grad_clipping partial args (main.py:161-172) +
+ *                             the config.model routing of load_model
+ *                             (/root/reference/src/model_handler.py:30-43).
+ *   cmcd_layout          <->  `unflatten` of jax.flatten_util.ravel_pytree
+ *                             (/root/reference/src/mcdboundingmachine.py:122,141-143): where each
+ *                             leaf of (params_train, params_notrain) sits inside params_flat.
+ *   cmcd_stats_merge     <->  batch_log_elbos.mean() / .var(ddof=0) (mcdboundingmachine.py:205,231)
+ *                             and logsumexp(-loss) - log n (/root/reference/src/utils.py:233-235),
+ *                             in a form that merges across ranks.
+ *
+ * Ownership: every pointer marked [device] is caller-owned device memory (e.g. the data_ptr() of
+ * a contiguous torch tensor).  The library allocates nothing persistent, keeps no global state
+ * and is re-entrant.  All work is enqueued asynchronously on `stream` (a hipStream_t, may be 0);
+ * nothing in cmcd_bound_forward synchronises, so it can be captured into a hipGraph.
+ * Errors: 0 on success, negative cmcd_status otherwise; message via cmcd_last_error()
+ * (thread-local).  Nothing throws across this boundary.
+ */
+#ifndef CMCD_HIP_H
+#define CMCD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CMCD_ABI_VERSION 1
+
+typedef enum cmcd_status {
+  CMCD_OK = 0,
+  CMCD_ERR_BAD_ARG = -1,       /* null pointer, bad size, layout offset missing          */
+  CMCD_ERR_UNSUPPORTED = -2,   /* mode / arch / target / shape not implemented           */
+  CMCD_ERR_WORKSPACE = -3,     /* workspace smaller than cmcd_workspace_bytes()          */
+  CMCD_ERR_HIP = -4            /* a HIP runtime call failed                               */
+} cmcd_status;
+
+/* config.boundmode plugin switch (/root/reference/src/mcd_utils.py:34-190).  Only the two
+ * CAIS modes exist here; every other value is CMCD_ERR_UNSUPPORTED ("Mode not implemented."). */
+enum { CMCD_MODE_CAIS_SN = 0, CMCD_MODE_CAIS_VAR_SN = 1 };
+/* config.nn_arch (/root/reference/src/nn.py:21-39) */
+enum { CMCD_ARCH_GEFFNER = 0, CMCD_ARCH_DDS = 1 };
+/* config.model routing (/root/reference/src/model_handler.py:30-43) */
+enum { CMCD_TARGET_GMM = 0, CMCD_TARGET_FUNNEL = 1, CMCD_TARGET_MANY_GMM = 2, CMCD_TARGET_LGCP = 3 };
+/* config.eps_schedule (/root/reference/src/mcd_cais.py:54-59) */
+enum { CMCD_EPS_CONST = 0, CMCD_EPS_LINEAR = 1, CMCD_EPS_COS_SQ = 2 };
+
+typedef struct cmcd_desc {
+  int32_t dim;            /* params_fixed[0]                                              */
+  int32_t nbridges;       /* params_fixed[1]; >= 1                                        */
+  int32_t mode;           /* params_fixed[2] as CMCD_MODE_*                               */
+  int32_t arch;           /* which apply_fun_sn: CMCD_ARCH_*                              */
+  int32_t emb_dim;        /* geffner: config.emb_dim (net width = dim + emb_dim); dds: 64 */
+  int32_t target;         /* CMCD_TARGET_*                                                */
+  int32_t eps_schedule;   /* CMCD_EPS_*                                                   */
+  int32_t grad_clipping;  /* 0 / 1                                                        */
+  int32_t ngrid;          /* len(mgridref_y) - 1  (mcdboundingmachine.py:107-112)         */
+  int32_t reserved;
+} cmcd_desc;
+
+/* Offsets (in floats) of each leaf inside params_flat; -1 = absent for this arch.
+ * Dense weights are [in, out] row-major (stax Dense / haiku Linear: x @ W + b). */
+typedef struct cmcd_layout {
+  int64_t vd_mean, vd_logdiag;           /* [dim] each  (vardist/diag_gauss.py:6-7)       */
+  int64_t eps;                           /* scalar                                        */
+  int64_t mgridref_y;                    /* [ngrid+1]                                     */
+  /* geffner (/root/reference/src/nn.py:42-72), in = dim + emb_dim */
+  int64_t g_emb;                         /* [nbridges, emb_dim]                           */
+  int64_t g_factor;                      /* scalar factor_sn                              */
+  int64_t g_w1, g_b1, g_w2, g_b2;        /* [in,in],[in] x2                               */
+  int64_t g_w3, g_b3;                    /* [in,dim],[dim]                                */
+  /* dds PISNet (/root/reference/src/nn_dds.py:91-164), H = 64 */
+  int64_t d_phase;                       /* timestep_phase [64]                           */
+  int64_t d_tw1, d_tb1, d_tw2, d_tb2;    /* time coder [128,64],[64],[64,64],[64]         */
+  int64_t d_sw1, d_sb1;                  /* [dim+64,64],[64]                              */
+  int64_t d_sw2, d_sb2;                  /* [64,64],[64]                                  */
+  int64_t d_sw3, d_sb3;                  /* LinearZero [64,dim],[dim]                     */
+} cmcd_layout;
+
+/* out_stats: 5 doubles, the mergeable batch statistics of the per-particle losses l_n:
+ *   [0] number of finite l_n   [1] sum l_n   [2] sum l_n^2
+ *   [3] M = max_n(-l_n)        [4] sum_n exp(-l_n - M)
+ * +inf losses are legal (many_gmm floor, /root/reference/src/model_handler.py:279-280) and make
+ * [1],[2] +inf exactly like the reference's mean/var; NaN anywhere means "diverged"
+ * (/root/reference/src/opt.py:122). */
+#define CMCD_NSTATS 5
+
+int cmcd_version(void);
+const char* cmcd_last_error(void);
+
+/* Bytes of [device] scratch cmcd_bound_forward needs for n particles (0 on bad desc). */
+int64_t cmcd_workspace_bytes(const cmcd_desc* desc, int64_t n);
+
+/* Number of floats of target constants expected for desc->target:
+ *   gmm: 0; funnel: 0; many_gmm: 1 + 2*n_mixes = {scale, means[n_mixes,2]} (n_target tells
+ *   n_mixes); lgcp: dim*dim + dim + 3 = {Kinv[dim,dim], counts[dim], mu0, a, lognorm}. */
+int64_t cmcd_target_floats(const cmcd_desc* desc, int32_t n_mixes);
+
+/* One forward evaluation of the bound for n particles:
+ *   seeds[n] int32 [device]  ->  out_loss[n] = -w_n, out_z[n*dim] = z_K  [device, float32],
+ *   out_stats[5] [device, float64].  params[n_params] float32 [device] is params_flat.  */
+int cmcd_bound_forward(const cmcd_desc* desc, const cmcd_layout* layout,
+                       const int32_t* seeds, int64_t n,
+                       const float* params, int64_t n_params,
+                       const float* target_consts, int64_t n_target,
+                       void* workspace, int64_t workspace_bytes,
+                       float* out_loss, float* out_z, double* out_stats,
+                       void* stream);
+
+/* Host-side, no GPU: merge `count` stats vectors (e.g. one per rank, after an all-gather) in
+ * the given fixed order, then produce mean, var(ddof=0), lnZ = logsumexp(-l) - log n_total.
+ * n_per[i] = number of particles behind stats[i].  out3 = {mean, var, lnZ}. */
+int cmcd_stats_merge(const double* stats, const int64_t* n_per, int32_t count,
+                     double* merged5, double* out3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CMCD_HIP_H */

@@ -1,0 +1,237 @@
+"""CPU restatement of the CMCD ``MCD_CAIS_sn`` / ``MCD_CAIS_var_sn`` bound.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  PARITY UNPINNED: the
+reference cannot be imported here and holds no tests; this file follows the
+cited lines and is pinned by PRNG known answers + analytic identities only.
+
+Vectorised over particles with NumPy; ``dtype`` float32 mirrors the reference's
+arithmetic type, float64 is the high-precision check.  The PRNG streams are
+float32/uint32 in both (oracle/prng.py).
+
+Parameter dict (same keys as cmcd_amd's ``unflatten`` output):
+  vd: {mean[d], logdiag[d]}; eps: scalar; mgridref_y[G+1]; gridref_x[G+2]; target_x[K]
+  sn (dds):     timestep_phase[1,64], t_w1[128,64], t_b1[64], t_w2[64,64], t_b2[64],
+                s_w1[d+64,64], s_b1[64], s_w2[64,64], s_b2[64], s_w3[64,d], s_b3[d]
+  sn (geffner): emb[K,e], factor_sn, W1[in,in], b1[in], W2[in,in], b2[in], W3[in,d], b3[d]
+"""
+import math
+
+import numpy as np
+
+try:  # exact erf for GELU (/root/reference/src/nn_dds.py:176 uses jax.scipy.special.erf)
+    from scipy.special import erf as _erf
+except Exception:  # pragma: no cover
+    _erf = np.vectorize(math.erf)
+
+from . import prng
+
+LOG_2PI = 1.8378770664093453
+MODES = ("MCD_CAIS_sn", "MCD_CAIS_var_sn")
+
+
+# --------------------------------------------------------------------------- schedules
+def betas_from_grid(mgridref_y, gridref_x, target_x, dtype):
+    """/root/reference/src/mcdboundingmachine.py:146-149."""
+    m = np.asarray(mgridref_y, dtype)
+    gy = np.cumsum(m) / np.sum(m)
+    gy = np.concatenate([np.zeros(1, dtype), gy])
+    return np.interp(np.asarray(target_x, dtype), np.asarray(gridref_x, dtype), gy).astype(dtype)
+
+
+def eps_table(eps0, nbridges, schedule, dtype):
+    """/root/reference/src/mcd_cais.py:34-44,54-59."""
+    dt = np.dtype(dtype).type
+    i = np.arange(nbridges).astype(dtype)
+    e0 = dt(eps0)
+    if schedule == "cos_sq":
+        phase = i / dt(nbridges)
+        decay = np.cos((phase + dt(0.008)) / dt(1.008) * dt(0.5) * dt(np.pi)) ** 2
+        return (e0 * decay).astype(dtype)
+    if schedule == "linear":
+        return ((dt(0.0001) - e0) / dt(nbridges - 1) * i + e0).astype(dtype)
+    return np.full(nbridges, e0, dtype)
+
+
+# --------------------------------------------------------------------------- q
+def q_sample(vd, noise):
+    """/root/reference/src/vardist/diag_gauss.py:49-62."""
+    return np.exp(vd["logdiag"]) * noise + vd["mean"]
+
+
+def q_log_prob(vd, z):
+    """/root/reference/src/vardist/diag_gauss.py:26-33 (numpyro Normal.log_prob)."""
+    dt = z.dtype.type
+    s = np.exp(vd["logdiag"])
+    return np.sum(-((z - vd["mean"]) ** 2) / (dt(2.0) * s * s) - np.log(s) - dt(0.5 * LOG_2PI), -1)
+
+
+def q_grad(vd, z):
+    s = np.exp(vd["logdiag"])
+    return -(z - vd["mean"]) / (s * s)
+
+
+# --------------------------------------------------------------------------- nets
+def gelu(x):
+    """/root/reference/src/nn_dds.py:167-176."""
+    dt = x.dtype.type
+    return x * dt(0.5) * (dt(1.0) + _erf(x / np.sqrt(dt(2.0))).astype(x.dtype))
+
+
+def softplus(x):
+    """stax.Softplus = logaddexp(x, 0)  (/root/reference/src/nn.py:46)."""
+    return np.logaddexp(x, x.dtype.type(0.0))
+
+
+def dds_time_embedding(sn, t, dtype):
+    """/root/reference/src/nn_dds.py:108,131-143,155-158.  t: integer bridge index."""
+    dt = np.dtype(dtype).type
+    coeff = np.linspace(0.1, 100.0, 64).astype(np.float32)          # fp32 in the reference
+    arg = coeff * np.float32(t) + np.asarray(sn["timestep_phase"], np.float32).reshape(-1)
+    arg = arg.astype(np.float32).astype(np.float64)                 # fp32-rounded argument
+    emb = np.concatenate([np.sin(arg), np.cos(arg)]).astype(dtype)
+    h = gelu(emb @ sn["t_w1"] + sn["t_b1"])
+    return (h @ sn["t_w2"] + sn["t_b2"]).astype(dtype)
+
+
+def apply_dds(sn, z, t, dtype):
+    """PISNet.__call__  /root/reference/src/nn_dds.py:145-164."""
+    dt = np.dtype(dtype).type
+    tau = dds_time_embedding(sn, t, dtype)
+    x = np.concatenate([z, np.broadcast_to(tau, (z.shape[0], tau.shape[0]))], 1)
+    h = gelu(x @ sn["s_w1"] + sn["s_b1"])
+    h = gelu(h @ sn["s_w2"] + sn["s_b2"])
+    out = h @ sn["s_w3"] + sn["s_b3"]
+    return np.clip(out, dt(-1e4), dt(1e4))
+
+
+def apply_geffner(sn, z, i, dtype):
+    """/root/reference/src/nn.py:42-72; out-of-range i clamps like a JAX gather."""
+    nb = sn["emb"].shape[0]
+    emb = sn["emb"][min(max(int(i), 0), nb - 1)]
+    u = np.concatenate([z, np.broadcast_to(emb, (z.shape[0], emb.shape[0]))], 1)
+    u = u + softplus(u @ sn["W1"] + sn["b1"])
+    u = u + softplus(u @ sn["W2"] + sn["b2"])
+    return (u @ sn["W3"] + sn["b3"]) * sn["factor_sn"]
+
+
+def apply_sn(arch, sn, z, i, dtype):
+    return apply_dds(sn, z, i, dtype) if arch == "dds" else apply_geffner(sn, z, i, dtype)
+
+
+# --------------------------------------------------------------------------- kernels
+def log_prob_kernel(x, mean, scale):
+    """/root/reference/src/mcd_utils.py:19-21."""
+    dt = x.dtype.type
+    return np.sum(-((x - mean) ** 2) / (dt(2.0) * scale * scale) - np.log(scale) - dt(0.5 * LOG_2PI), -1)
+
+
+def cast_params(params, dtype):
+    if isinstance(params, dict):
+        return {k: cast_params(v, dtype) for k, v in params.items()}
+    return np.asarray(params, dtype)
+
+
+# --------------------------------------------------------------------------- the bound
+def compute_log_elbo_batch(seeds, params, dim, nbridges, mode, arch, target,
+                           eps_schedule=None, grad_clipping=False, dtype=np.float32, reuse=False):
+    """Per-particle loss and final sample.  /root/reference/src/mcdboundingmachine.py:126-179
+    with the evolve loop of /root/reference/src/mcd_cais.py:46-96 (``MCD_CAIS_sn``) or
+    /root/reference/src/mcd_cais_var.py:57-112 (``MCD_CAIS_var_sn``; forward values differ
+    only through the clip rule :33-40).
+
+    reuse=False evaluates grad/net twice per step like the reference; reuse=True carries the
+    backward evaluation into the next step's forward kernel (bit-identical).
+    Returns (loss[N], z[N, dim]) in ``dtype``.
+    """
+    if mode not in MODES:
+        raise NotImplementedError("Mode not implemented.")
+    dt = np.dtype(dtype).type
+    p = cast_params(params, dtype)
+    vd, sn = p["vd"], p["sn"]
+    seeds = np.asarray(seeds)
+    eps0_noise, noise = prng.particle_noise(seeds, dim, nbridges)
+    betas = betas_from_grid(p["mgridref_y"], p["gridref_x"], p["target_x"], dtype) if nbridges >= 1 else None
+    eps_tab = eps_table(p["eps"], nbridges, eps_schedule, dtype) if nbridges >= 1 else None
+
+    z = q_sample(vd, eps0_noise.astype(dtype))
+    w = -q_log_prob(vd, z)
+
+    var_mode = mode == "MCD_CAIS_var_sn"
+    clip = dt(1e2) if var_mode else dt(1e3)
+
+    def grads(zz):
+        _, gp = target(zz)
+        gq = q_grad(vd, zz)
+        if grad_clipping:
+            gp = np.clip(gp, -clip, clip)
+            if var_mode:
+                gq = np.clip(gq, -clip, clip)
+        return gp, gq
+
+    def grad_u(g, beta):
+        gp, gq = g
+        return dt(-1.0) * (beta * gp + (dt(1.0) - beta) * gq)
+
+    carried = None
+    for i in range(nbridges):
+        beta, eps = betas[i], eps_tab[i]
+        if reuse and carried is not None:
+            g_z, s_z = carried
+        else:
+            g_z, s_z = grads(z), apply_sn(arch, sn, z, i, dtype)
+        uf = grad_u(g_z, beta)
+        fk_mean = z - eps * uf - eps * s_z
+        scale = np.sqrt(dt(2.0) * eps)
+        z_new = fk_mean + scale * noise[:, i, :].astype(dtype)
+        g_n, s_n = grads(z_new), apply_sn(arch, sn, z_new, i + 1, dtype)
+        ub = grad_u(g_n, beta)
+        bk_mean = z_new - eps * ub + eps * s_n
+        w = w + (log_prob_kernel(z, bk_mean, scale) - log_prob_kernel(z_new, fk_mean, scale))
+        z = z_new
+        carried = (g_n, s_n)
+    logp, _ = target(z)
+    w = w + logp
+    return (dt(-1.0) * w).astype(dtype), z.astype(dtype)
+
+
+def compute_bound(seeds, params, dim, nbridges, mode, arch, target, **kw):
+    """/root/reference/src/mcdboundingmachine.py:183-205 -> (mean, (losses, z))."""
+    loss, z = compute_log_elbo_batch(seeds, params, dim, nbridges, mode, arch, target, **kw)
+    with np.errstate(invalid="ignore"):
+        return loss.mean(), (loss, z)
+
+
+def compute_bound_var(seeds, params, dim, nbridges, mode, arch, target, **kw):
+    """/root/reference/src/mcdboundingmachine.py:208-231 -> (clip(var, +-1e7), (losses, z))."""
+    loss, z = compute_log_elbo_batch(seeds, params, dim, nbridges, mode, arch, target, **kw)
+    with np.errstate(invalid="ignore"):
+        return np.clip(loss.var(ddof=0), -1e7, 1e7), (loss, z)
+
+
+def ln_z(loss):
+    """logsumexp(-loss) - log n   (/root/reference/src/utils.py:233-235)."""
+    a = -np.asarray(loss, np.float64)
+    m = np.max(a)
+    if not np.isfinite(m):
+        return float(m)
+    return float(m + np.log(np.sum(np.exp(a - m))) - np.log(a.shape[0]))
+
+
+def stats5(loss):
+    """[n_finite, sum, sum of squares, max(-loss), sum exp(-loss - max)] in float64 — the
+    partial-statistics vector of the C ABI (include/cmcd_hip.h), over FINITE and +inf entries
+    exactly as the reductions of mcdboundingmachine.py:205,231 / utils.py:233 see them."""
+    l = np.asarray(loss, np.float64)
+    a = -l
+    m = np.max(a) if l.size else -np.inf
+    with np.errstate(invalid="ignore", over="ignore"):
+        s = np.sum(np.exp(a - m)) if np.isfinite(m) else 0.0
+        return np.array([np.sum(np.isfinite(l)), np.sum(l), np.sum(l * l), m, s])
+
+
+def log_final_losses(eval_losses):
+    """/root/reference/src/utils.py:219-248 -> (elbo, elbo_std, lnZ, lnZ_std)."""
+    e = np.asarray(eval_losses, np.float64)
+    elbos = -e.mean(1)
+    lnzs = np.array([ln_z(r) for r in e])
+    return elbos.mean(), elbos.std(), lnzs.mean(), lnzs.std()

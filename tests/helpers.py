@@ -1,0 +1,51 @@
+"""Shared test plumbing: run the oracle on the same synthetic inputs as the HIP path."""
+import numpy as np
+
+from cmcd_amd import synthetic
+from oracle import cmcd_oracle as orc
+from oracle import targets as otg
+
+
+def oracle_target(cfg, lgcp_counts=None):
+    m = cfg["model"]
+    if m == "gmm":
+        return otg.Gmm()
+    if m == "funnel":
+        return otg.Funnel(10)
+    if m == "many_gmm":
+        return otg.ManyGmm()
+    if m == "lgcp":
+        return otg.Lgcp(lgcp_counts)
+    raise KeyError(m)
+
+
+def run_oracle(built, seeds, dtype=np.float64, reuse=True, lgcp_counts=None):
+    cfg = built["cfg"]
+    dim, K, mode, spec = built["params_fixed"]
+    p = synthetic.oracle_params(built["unflatten"], built["params_flat"])
+    return orc.compute_log_elbo_batch(
+        np.asarray(seeds), p, dim, K, mode, spec.arch, oracle_target(cfg, lgcp_counts),
+        eps_schedule=cfg["eps_schedule"], grad_clipping=cfg["grad_clipping"], dtype=dtype, reuse=reuse)
+
+
+def compare_losses(l_hip, l_ref, z_hip, z_ref, tag=""):
+    """Parity bar of SURVEY.md section 8c / BASELINE.md section 2 (float32 path vs float64 oracle):
+    identical set of +inf particles; batch mean and lnZ within 1e-3 absolute; per-particle loss
+    p99 relative error <= 5e-3 (rare chaotic outliers allowed)."""
+    l_hip = np.asarray(l_hip, np.float64)
+    l_ref = np.asarray(l_ref, np.float64)
+    assert not np.isnan(l_hip).any(), f"{tag}: NaN loss"
+    inf_h, inf_r = np.isinf(l_hip), np.isinf(l_ref)
+    assert np.array_equal(inf_h, inf_r), f"{tag}: +inf particle sets differ: {np.flatnonzero(inf_h != inf_r)}"
+    f = ~inf_r
+    rel = np.abs(l_hip[f] - l_ref[f]) / np.maximum(1.0, np.abs(l_ref[f]))
+    mean_err = abs(l_hip[f].mean() - l_ref[f].mean())
+    lnz_err = abs(orc.ln_z(l_hip) - orc.ln_z(l_ref))
+    zerr = np.abs(np.asarray(z_hip, np.float64) - np.asarray(z_ref, np.float64))[f]
+    report = dict(n=len(l_ref), n_inf=int(inf_r.sum()), mean_err=mean_err, lnz_err=lnz_err,
+                  rel_p50=float(np.median(rel)), rel_p99=float(np.quantile(rel, 0.99)), rel_max=float(rel.max()),
+                  z_p99=float(np.quantile(zerr, 0.99)))
+    assert mean_err <= 1e-3 * max(1.0, abs(l_ref[f].mean())), f"{tag}: {report}"
+    assert lnz_err <= 1e-3 * max(1.0, abs(orc.ln_z(l_ref))), f"{tag}: {report}"
+    assert report["rel_p99"] <= 5e-3, f"{tag}: {report}"
+    return report

@@ -1,0 +1,45 @@
+"""HIP path vs the CPU oracle on identical seeds and parameters (through the C ABI)."""
+import numpy as np
+import pytest
+import torch
+
+from cmcd_amd import mcdboundingmachine as mcdbm
+from cmcd_amd import synthetic
+from oracle import cmcd_oracle as orc
+
+from helpers import compare_losses, run_oracle
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    ("gmm_n300_k8", 300, {}),
+    ("funnel_n300_k64", 300, {}),
+    ("many_gmm_n2000_k256_dds", 256, {}),
+    ("many_gmm_n2000_k256_dds", 100, dict(nbridges=16)),          # ragged: 100 = 6 tiles + 4
+    ("many_gmm_var_n16000_k256", 128, dict(nbridges=64)),
+    ("many_gmm_n2000_k256_dds", 64, dict(nbridges=8, eps_schedule="linear", init_eps=0.05)),
+    ("gmm_n300_k8", 1, {}),                                       # a single particle
+]
+
+
+@pytest.mark.parametrize("name,n,over", CASES)
+def test_bound_matches_oracle(hip_lib, name, n, over):
+    b = synthetic.build(name, device="cuda", **over)
+    seeds = synthetic.parity_seeds(n)
+    fn = mcdbm.compute_bound_var if "var" in b["cfg"]["boundmode"] else mcdbm.compute_bound
+    val, (losses, z) = fn(torch.from_numpy(seeds).cuda(), b["params_flat"], b["unflatten"], b["params_fixed"],
+                          b["target"], eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
+    torch.cuda.synchronize()
+    l_ref, z_ref = run_oracle(b, seeds, dtype=np.float64)
+    rep = compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"{name} n={n}")
+    print(name, n, over, rep)
+    # the scalar the reference returns
+    lh = losses.double().cpu().numpy()
+    if "var" in b["cfg"]["boundmode"]:
+        want = np.clip(np.var(lh), -1e7, 1e7)
+    else:
+        want = np.mean(lh)
+    if np.isfinite(want):
+        assert abs(float(val) - want) <= 1e-5 * max(1.0, abs(want))
+    else:
+        assert not np.isfinite(float(val))
