@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the CMCD annealed-Langevin bound on MI355X.
+
+A "step" is one `compute_bound` forward over one batch of synthetic particles (the hot path named
+by BASELINE.json: many_gmm, MCD_CAIS_sn, N=2000, nbridges=256, dds net).  Multi-GPU: one process per
+GPU (torch.distributed, backend nccl = RCCL); every rank runs the named batch on its own seeds
+(weak scaling) and one all-gather of the 5-number statistics vector per step merges the ELBO mean /
+ln Z across ranks.  Rank 0 prints ONE JSON line.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 3
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+PEAK_FP32_TFLOPS = 157.3   # MI355X fp32 vector == fp32 MFMA peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def flops_per_particle_step(cfg, dim, width):
+    """Algorithmic work of one particle-bridge-step AFTER the two value-preserving restructurings of
+    DESIGN.md (one net + one target-gradient evaluation per step; time path folded into a per-step
+    bias): 2 * MAC_net + F_target + 24 d.  `survey` is SURVEY.md section 8d's figure (un-folded first layer)."""
+    if cfg["nn_arch"] == "dds":
+        mac = dim * 64 + 64 * 64 + 64 * dim
+        mac_survey = (dim + 64) * 64 + 64 * 64 + 64 * dim
+    else:
+        mac = dim * width + width * width + width * dim
+        mac_survey = 2 * width * width + width * dim
+    f_target = {"gmm": 200, "funnel": 60, "many_gmm": 800, "lgcp": 2 * dim * dim}[cfg["model"]]
+    return 2 * mac + f_target + 24 * dim, 2 * mac_survey + f_target + 24 * dim
+
+
+def cpu_baseline(built, seeds_np, losses_hip, max_particles):
+    """The oracle (a NumPy port of the reference algorithm, reference-faithful: two network and two
+    gradient evaluations per bridge step, float32) timed on this box's host cores on a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import run_oracle
+    from oracle import cmcd_oracle as orc
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = 1
+    n = min(len(seeds_np), max_particles)
+    K = built["params_fixed"][1]
+    t0 = time.perf_counter()
+    l_ref, _ = run_oracle(built, seeds_np[:n], dtype=np.float32, reuse=False)
+    dt = time.perf_counter() - t0
+    lh = losses_hip[:n].astype(np.float64)
+    lr = l_ref.astype(np.float64)
+    fin = np.isfinite(lr)
+    out = {
+        "value": n * K / dt, "unit": "bridge-steps*particles/s", "cores": threads, "kind": "port",
+        "sample": f"one compute_bound call, {n} particles x {K} bridges, NumPy float32 oracle, "
+                  f"2 net + 2 grad evals per step as the reference; BLAS threads={threads} of {os.cpu_count()} cpus; "
+                  f"{dt:.1f}s",
+        "seconds": dt,
+    }
+    parity = {
+        "elbo_abs_err": float(abs(lh[fin].mean() - lr[fin].mean())),
+        "lnz_abs_err": float(abs(orc.ln_z(lh) - orc.ln_z(lr))),
+        "inf_set_equal": bool(np.array_equal(np.isinf(lh), np.isinf(lr))),
+        "n": int(n), "against": "oracle float32 (reference-faithful)",
+    }
+    return out, parity
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default=None, help="name in cmcd_amd.synthetic.CONFIGS")
+    ap.add_argument("--particles", type=int, default=None, help="override N per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-particles", type=int, default=2000)
+    ap.add_argument("--saturated", type=int, default=1 << 18,
+                    help="also time a saturating batch of this many particles (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback for the hot path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from cmcd_amd import _lib, build, synthetic
+    from cmcd_amd import mcdboundingmachine as mcdbm
+    from cmcd_amd import parallel
+    build.build()
+
+    name = args.config or synthetic.NORTH_STAR
+    over = {"N": args.particles} if args.particles else {}
+    b = synthetic.build(name, device=device, **over)
+    cfg = b["cfg"]
+    dim, K, mode, spec = b["params_fixed"]
+    n = cfg["N"]
+    seeds_np = synthetic.throughput_seeds(n, stream=rank)
+    seeds = torch.from_numpy(seeds_np).to(device)  # resident in HBM before the timed region
+
+    def forward(s):
+        return mcdbm.bound_forward(s, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"],
+                                   eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
+
+    def step():
+        losses, z, stats = forward(seeds)
+        if world > 1:
+            stats = parallel.merge_stats(parallel.all_gather_stats(stats))
+        return losses, z, stats
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    _lib.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses, z, stats = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms, launches = _lib.profile_collect()
+    _lib.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    units_per_step = n * K * world
+    value = units_per_step * args.steps / elapsed
+    f_alg, f_survey = flops_per_particle_step(cfg, dim, spec.width)
+    kern_s = kern_ms / 1e3 / max(launches, 1)
+    achieved = n * K * f_alg / kern_s / 1e12
+    fin = parallel.finalize(stats, n * world)
+
+    result = {
+        "metric": "bridge-steps*particles/sec", "value": value, "unit": "bridge-steps*particles/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": name, "model": cfg["model"], "boundmode": cfg["boundmode"],
+                   "particles_per_gpu": n, "nbridges": K, "nn_arch": cfg["nn_arch"], "dim": dim,
+                   "global_particles": n * world, "parallelism": f"particles sharded x{world}, stats all-gather"},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                     "kernel": "traj_kernel", "kernel_ms": kern_s * 1e3, "launches": launches,
+                     "flop_per_particle_step": f_alg, "flop_per_particle_step_survey": f_survey,
+                     "achieved_survey_flops": n * K * f_survey / kern_s / 1e12,
+                     "state_bytes_gbs": n * K * (8 * dim + 8) / kern_s / 1e9},
+        "elbo": float(-fin["mean"]), "ln_z": float(fin["ln_z"]), "n_finite": float(fin["n_finite"]),
+    }
+
+    if rank == 0 and args.saturated and world == 1:
+        ns = args.saturated
+        sseeds = torch.from_numpy(synthetic.throughput_seeds(ns, stream=7)).to(device)
+        forward(sseeds)
+        torch.cuda.synchronize()
+        _lib.profile_enable(True)
+        reps = 3
+        for _ in range(reps):
+            forward(sseeds)
+        torch.cuda.synchronize()
+        ms, cnt = _lib.profile_collect()
+        _lib.profile_enable(False)
+        ks = ms / 1e3 / cnt
+        result["saturated"] = {"particles": ns, "kernel_ms": ks * 1e3, "value": ns * K / ks,
+                               "achieved": ns * K * f_alg / ks / 1e12,
+                               "frac": ns * K * f_alg / ks / 1e12 / PEAK_FP32_TFLOPS}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        base, parity = cpu_baseline(b, seeds_np, losses.cpu().numpy(), args.cpu_particles)
+        result["cpu_baseline"] = base
+        result["parity"] = parity
+        result["speedup_vs_cpu"] = value / base["value"]
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

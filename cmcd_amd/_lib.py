@@ -54,9 +54,10 @@ def lib():
         L.cmcd_stats_merge.restype = C.c_int
         L.cmcd_stats_merge.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32,
                                        C.POINTER(C.c_double), C.POINTER(C.c_double)]
-        for name in ("cmcd_lgcp_workspace_bytes", "cmcd_bound_forward_lgcp"):
-            if hasattr(L, name):
-                pass
+        L.cmcd_profile_enable.restype = C.c_int
+        L.cmcd_profile_enable.argtypes = [C.c_int]
+        L.cmcd_profile_collect.restype = C.c_int
+        L.cmcd_profile_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         _lib = L
     return _lib
 
@@ -85,3 +86,14 @@ def stats_merge(stats_rows, n_per):
     out3 = (C.c_double * 3)()
     check(lib().cmcd_stats_merge(flat, ns, cnt, merged, out3))
     return list(merged), out3[0], out3[1], out3[2]
+
+
+def profile_enable(on=True):
+    check(lib().cmcd_profile_enable(int(bool(on))))
+
+
+def profile_collect():
+    """-> (total trajectory-kernel milliseconds, launches) since the last enable/collect."""
+    ms, cnt = C.c_double(), C.c_int64()
+    check(lib().cmcd_profile_collect(C.byref(ms), C.byref(cnt)))
+    return ms.value, cnt.value

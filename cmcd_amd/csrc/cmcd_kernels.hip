@@ -28,6 +28,18 @@
 namespace cmcd {
 
 static thread_local char g_err[512] = "";
+
+// Optional in-library timing of the trajectory kernel: when enabled, every cmcd_bound_forward
+// brackets its traj_kernel launch with a hipEvent pair on the caller's stream (bench.py reads
+// the average kernel duration from them for the roofline figure).
+struct ProfileState {
+  static constexpr int kMax = 4096;
+  bool on = false;
+  int used = 0;
+  hipEvent_t ev[kMax][2];
+  int created = 0;
+};
+static thread_local ProfileState g_prof;
 static int fail(int code, const char* fmt, const char* a = "", long long b = 0) {
   snprintf(g_err, sizeof(g_err), fmt, a, b);
   return code;
@@ -781,10 +793,44 @@ int cmcd_bound_forward(const cmcd_desc* desc, const cmcd_layout* lay, const int3
   TrajArgs ta{seeds, params, ws, reinterpret_cast<double*>(ws + w.partials), out_loss, out_z, *lay, w, n,
               (int32_t)K, d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0, d.grad_clipping};
   const unsigned blocks = unsigned((tiles + nw - 1) / nw);
+  const bool prof = g_prof.on && g_prof.used < ProfileState::kMax;
+  if (prof) {
+    if (g_prof.used >= g_prof.created) {
+      CMCD_HIP_CHECK(hipEventCreate(&g_prof.ev[g_prof.created][0]));
+      CMCD_HIP_CHECK(hipEventCreate(&g_prof.ev[g_prof.created][1]));
+      ++g_prof.created;
+    }
+    CMCD_HIP_CHECK(hipEventRecord(g_prof.ev[g_prof.used][0], stream));
+  }
   hipLaunchKernelGGL(fn, dim3(blocks), dim3(64 * nw), lds_bytes, stream, ta);
+  if (prof) {
+    CMCD_HIP_CHECK(hipEventRecord(g_prof.ev[g_prof.used][1], stream));
+    ++g_prof.used;
+  }
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, stream,
                      reinterpret_cast<const double*>(ws + w.partials), w.n_waves, out_stats);
   CMCD_HIP_CHECK(hipGetLastError());
+  return CMCD_OK;
+}
+
+int cmcd_profile_enable(int on) {
+  g_prof.on = on != 0;
+  g_prof.used = 0;
+  return CMCD_OK;
+}
+
+int cmcd_profile_collect(double* total_ms, int64_t* launches) {
+  if (!total_ms || !launches) return fail(CMCD_ERR_BAD_ARG, "null pointer argument%s");
+  double tot = 0.0;
+  for (int i = 0; i < g_prof.used; ++i) {
+    float ms = 0.f;
+    CMCD_HIP_CHECK(hipEventSynchronize(g_prof.ev[i][1]));
+    CMCD_HIP_CHECK(hipEventElapsedTime(&ms, g_prof.ev[i][0], g_prof.ev[i][1]));
+    tot += ms;
+  }
+  *total_ms = tot;
+  *launches = g_prof.used;
+  g_prof.used = 0;
   return CMCD_OK;
 }
 

@@ -1,0 +1,79 @@
+"""Particles shard across GPUs; the only exchange is the 5-number statistics vector.
+
+The reference is single-device (no pmap/pjit anywhere under /root/reference/src).  Every particle
+trajectory is independent (`jax.vmap` over seeds, /root/reference/src/mcdboundingmachine.py:193-203);
+the only cross-particle operations are the batch mean / var (:205,231) and logsumexp
+(/root/reference/src/utils.py:233).  So each rank runs the trajectory kernel on a contiguous block
+of seeds and one all-gather of `stats[5]` (float64) per call merges the reductions, in rank order
+(deterministic regardless of the collective's algorithm).  One process per GPU, RCCL via
+torch.distributed (backend "nccl"); the same code runs on gloo for the CPU tests.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+NSTATS = 5
+
+
+def shard_range(n, world_size, rank):
+    """Contiguous block [lo, hi) of rank `rank`: ceil(n / world) per rank, last ranks may be short/empty."""
+    per = (n + world_size - 1) // world_size
+    lo = min(n, rank * per)
+    return lo, min(n, lo + per)
+
+
+def empty_stats(device=None):
+    return torch.tensor([0.0, 0.0, 0.0, -math.inf, 0.0], dtype=torch.float64, device=device)
+
+
+def merge_stats(stats_rows):
+    """Fixed-order merge of [R, 5] statistics rows (device-agnostic torch ops, no host sync)."""
+    s = stats_rows
+    m = torch.max(s[:, 3])
+    scale = torch.where(torch.isfinite(s[:, 3]) & torch.isfinite(m), torch.exp(s[:, 3] - m),
+                        (s[:, 3] == m).to(s.dtype))
+    out = torch.stack([s[:, 0].sum(), s[:, 1].sum(), s[:, 2].sum(), m, (s[:, 4] * scale).sum()])
+    return out
+
+
+def finalize(stats, n_total):
+    """-> dict(mean, var (ddof=0, clipped +-1e7 like compute_bound_var), ln_z, n_finite)."""
+    n = float(n_total)
+    mean = stats[1] / n
+    var = torch.clamp(stats[2] / n - mean * mean, -1e7, 1e7)
+    ln_z = stats[3] + torch.log(stats[4]) - math.log(n)
+    return dict(mean=mean, var=var, ln_z=ln_z, n_finite=stats[0])
+
+
+def all_gather_stats(local_stats, group=None):
+    """[5] -> [world, 5] in rank order."""
+    world = dist.get_world_size(group)
+    out = torch.empty(world * NSTATS, dtype=local_stats.dtype, device=local_stats.device)
+    dist.all_gather_into_tensor(out, local_stats.contiguous().view(-1), group=group)
+    return out.view(world, NSTATS)
+
+
+def sharded_bound(seeds_global, forward_fn, group=None):
+    """Runs `forward_fn(local_seeds) -> (losses, z, stats[5])` on this rank's block of the global
+    seed vector and merges the statistics across ranks.
+
+    Returns dict(losses, z (local shards), lo, hi, stats (global), mean, var, ln_z)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        world, rank = 1, 0
+    else:
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = int(seeds_global.shape[0])
+    lo, hi = shard_range(n, world, rank)
+    if hi > lo:
+        losses, z, stats = forward_fn(seeds_global[lo:hi])
+    else:
+        losses, z, stats = None, None, None
+    if world > 1:
+        if stats is None:
+            stats = empty_stats(seeds_global.device if seeds_global.is_cuda else None)
+        rows = all_gather_stats(stats, group)
+        stats = merge_stats(rows)
+    out = dict(losses=losses, z=z, lo=lo, hi=hi, stats=stats)
+    out.update(finalize(stats, n))
+    return out

@@ -123,6 +123,13 @@ int cmcd_bound_forward(const cmcd_desc* desc, const cmcd_layout* layout,
                        float* out_loss, float* out_z, double* out_stats,
                        void* stream);
 
+/* Measurement hook (bench.py): while enabled (per host thread), every cmcd_bound_forward records a
+ * hipEvent pair around its trajectory-kernel launch on the caller's stream.
+ * cmcd_profile_collect synchronises those events, returns the summed kernel time and the number of
+ * launches since the last enable/collect, and resets the counter.  Not for use under graph capture. */
+int cmcd_profile_enable(int on);
+int cmcd_profile_collect(double* total_ms, int64_t* launches);
+
 /* Host-side, no GPU: merge `count` stats vectors (e.g. one per rank, after an all-gather) in
  * the given fixed order, then produce mean, var(ddof=0), lnZ = logsumexp(-l) - log n_total.
  * n_per[i] = number of particles behind stats[i].  out3 = {mean, var, lnZ}. */

@@ -1,0 +1,105 @@
+"""The C-ABI library: loads, exports every symbol include/cmcd_hip.h declares, validates its
+arguments before touching a GPU, and merges statistics exactly (no compute calls without a GPU)."""
+import ctypes as C
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+from cmcd_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "cmcd_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(cmcd_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_exports_every_declared_symbol(hip_lib):
+    names = declared_functions()
+    assert {"cmcd_version", "cmcd_last_error", "cmcd_workspace_bytes", "cmcd_bound_forward",
+            "cmcd_stats_merge", "cmcd_target_floats", "cmcd_profile_enable", "cmcd_profile_collect"} <= set(names)
+    for n in names:
+        assert hasattr(hip_lib, n), f"{n} declared in cmcd_hip.h but not exported"
+    assert hip_lib.cmcd_version() == 1
+
+
+def _desc(**kw):
+    base = dict(dim=2, nbridges=8, mode=0, arch=1, emb_dim=64, target=2, eps_schedule=2, grad_clipping=1,
+                ngrid=8, reserved=0)
+    base.update(kw)
+    return _lib.Desc(**base)
+
+
+def test_struct_sizes_match_header():
+    assert C.sizeof(_lib.Desc) == 40
+    assert C.sizeof(_lib.Layout) == 8 * len(_lib.LAYOUT_FIELDS) == 8 * 23
+
+
+def test_workspace_bytes_and_plugin_switch(hip_lib):
+    d = _desc()
+    nb = hip_lib.cmcd_workspace_bytes(C.byref(d), 2000)
+    assert nb > 0 and nb % 4 == 0
+    assert hip_lib.cmcd_workspace_bytes(C.byref(d), 4000) > nb          # per-wave partials grow
+    # config.boundmode plugin surface: anything but the two CAIS modes is refused with the
+    # reference's message (mcd_utils.py:190)
+    assert hip_lib.cmcd_workspace_bytes(C.byref(_desc(mode=7)), 2000) == 0
+    assert _lib.last_error() == "Mode not implemented."
+    assert hip_lib.cmcd_workspace_bytes(C.byref(_desc(arch=5)), 2000) == 0
+    assert hip_lib.cmcd_workspace_bytes(C.byref(_desc(nbridges=0)), 2000) == 0
+    assert hip_lib.cmcd_workspace_bytes(C.byref(_desc(arch=0, emb_dim=20, target=0)), 300) > 0
+    assert hip_lib.cmcd_workspace_bytes(C.byref(_desc(arch=0, emb_dim=130)), 300) > 0
+    assert hip_lib.cmcd_workspace_bytes(C.byref(_desc(arch=0, emb_dim=48, target=1, dim=10)), 300) > 0
+
+
+def test_target_floats(hip_lib):
+    assert hip_lib.cmcd_target_floats(C.byref(_desc()), 40) == 81
+    assert hip_lib.cmcd_target_floats(C.byref(_desc(target=0)), 0) == 0
+    assert hip_lib.cmcd_target_floats(C.byref(_desc(target=3, dim=1600)), 0) == 1600 * 1600 + 1600 + 3
+
+
+def test_forward_rejects_bad_arguments_before_any_gpu_work(hip_lib):
+    d = _desc()
+    lay = _lib.Layout(*([-1] * len(_lib.LAYOUT_FIELDS)))
+    rc = hip_lib.cmcd_bound_forward(C.byref(d), C.byref(lay), None, 16, None, 0, None, 0, None, 0, None, None,
+                                    None, None)
+    assert rc == -1 and "null pointer" in _lib.last_error()
+    with pytest.raises(ValueError):
+        _lib.check(rc)
+    rc = hip_lib.cmcd_bound_forward(C.byref(_desc(mode=3)), C.byref(lay), None, 16, None, 0, None, 0, None, 0,
+                                    None, None, None, None)
+    assert rc == -2
+    with pytest.raises(NotImplementedError, match="Mode not implemented."):
+        _lib.check(rc)
+
+
+def test_stats_merge_matches_numpy():
+    rng = np.random.default_rng(0)
+    loss = rng.normal(3.0, 2.0, 1000)
+    loss[[5, 700]] = np.inf
+    from oracle.cmcd_oracle import ln_z, stats5
+    parts = np.array_split(loss, [100, 333, 900])
+    rows = [stats5(p) for p in parts]
+    merged, mean, var, lnz = _lib.stats_merge(rows, [len(p) for p in parts])
+    whole = stats5(loss)
+    assert merged[0] == whole[0] == 998
+    assert math.isinf(mean) and math.isnan(var)                       # inf semantics of the reference
+    assert abs(lnz - ln_z(loss)) < 1e-12
+    fin = loss[np.isfinite(loss)]
+    parts = np.array_split(fin, 7)
+    merged, mean, var, lnz = _lib.stats_merge([stats5(p) for p in parts], [len(p) for p in parts])
+    assert abs(mean - fin.mean()) < 1e-12 and abs(var - fin.var()) < 1e-10 and abs(lnz - ln_z(fin)) < 1e-12
+
+
+def test_stats_merge_empty_rank_and_all_inf():
+    from oracle.cmcd_oracle import stats5
+    empty = [0.0, 0.0, 0.0, -math.inf, 0.0]
+    a = stats5(np.array([1.0, 2.0]))
+    merged, mean, var, lnz = _lib.stats_merge([empty, a, empty], [0, 2, 0])
+    assert merged[0] == 2 and abs(mean - 1.5) < 1e-15
+    merged, mean, var, lnz = _lib.stats_merge([stats5(np.array([np.inf, np.inf]))], [2])
+    assert merged[0] == 0 and lnz == -math.inf

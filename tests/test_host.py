@@ -1,0 +1,90 @@
+"""Host-side mirror of the reference interface: initialize / unflatten / load_model / error behaviour."""
+import numpy as np
+import pytest
+import torch
+
+from cmcd_amd import mcdboundingmachine as mcdbm
+from cmcd_amd import model_handler, synthetic
+from cmcd_amd import variationaldist as vd
+
+
+def test_initialize_signature_and_params_fixed():
+    flat, unflatten, fixed = mcdbm.initialize(
+        dim=2, nbridges=256, vdparams=vd.initialize(2, 60.0), eta=0.0, eps=1.0,
+        trainable=("eta", "gamma", "mgridref_y"), mode="MCD_CAIS_sn", emb_dim=20, nlayers=3, nn_arch="dds",
+        device="cpu")
+    dim, K, mode, spec = fixed
+    assert (dim, K, mode) == (2, 256, "MCD_CAIS_sn") and spec.arch == "dds" and spec.width == 64
+    hash(fixed)                                              # static_argnums-style hashable
+    train, notrain = unflatten(flat)
+    assert set(train) == {"eta", "gamma", "mgridref_y", "sn"}
+    assert set(notrain) == {"vd", "eps", "gridref_x", "target_x"}
+    # dds: 64 + (128*64+64) + (64*64+64) + (66*64+64) + (64*64+64) + (64*2+2) = 21058 floats
+    n_sn = sum(v.numel() for m in train["sn"].values() for v in m.values())
+    assert n_sn == 21058
+    assert train["mgridref_y"].shape == (33,) and notrain["gridref_x"].shape == (34,)
+    assert notrain["target_x"].shape == (256,)
+    assert flat.numel() == unflatten.size == 21058 + 33 + 2 + 4 + 1 + 34 + 256
+    # LinearZero / timestep_phase start at zero (nn_dds.py:101-103,189-190)
+    assert train["sn"]["drift_net/~/linear_zero"]["w"].abs().sum() == 0
+    assert torch.allclose(notrain["vd"]["logdiag"], torch.full((2,), float(np.log(60.0))))
+
+
+def test_flat_layout_follows_ravel_pytree_order():
+    flat, unflatten, _ = mcdbm.initialize(dim=2, nbridges=8, eps=0.01, trainable=("eps", "vd"),
+                                          mode="MCD_CAIS_sn", emb_dim=20, nn_arch="geffner", device="cpu")
+    o = unflatten.offset
+    # params_train first, keys sorted: eps < sn < vd; inside sn: emb < factor_sn < nn (W1,b1,W2,b2,W3,b3)
+    assert o("eps") == 0 and o("sn", "emb") == 1
+    assert o("sn", "factor_sn") == 1 + 8 * 20
+    assert o("sn", "nn", 0, 0) == o("sn", "factor_sn") + 1
+    assert o("sn", "nn", 0, 1) == o("sn", "nn", 0, 0) + 22 * 22
+    assert o("sn", "nn", 2, 1) == o("sn", "nn", 2, 0) + 22 * 2
+    assert o("vd", "logdiag") < o("vd", "mean") < o("eta")          # notrain after train
+    train, _ = unflatten(flat)
+    train["eps"].fill_(0.5)                                          # views alias params_flat
+    assert flat[0] == 0.5
+    assert float(train["sn"]["factor_sn"]) == 0.0                    # nn.py:63
+
+
+def test_ngrid_clamps_to_nbridges():
+    _, unflatten, _ = mcdbm.initialize(dim=2, nbridges=8, mode="MCD_CAIS_sn", nn_arch="geffner", emb_dim=4,
+                                       device="cpu")
+    assert unflatten.shape("mgridref_y") == (9,)                     # min(32, K) + 1
+
+
+def test_load_model_routing():
+    t, d, _ = model_handler.load_model("many_gmm")
+    assert (t.name, d, t.n_mixes) == ("many_gmm", 2, 40)
+    c = t.consts_on("cpu").numpy()
+    assert c.shape == (81,) and abs(c[0] - np.log1p(np.exp(0.1))) < 1e-7
+    np.testing.assert_array_equal(c[1:3], np.float32([-15.758228, 18.116531]))
+    assert model_handler.load_model("gmm")[0].name == "gmm"
+    assert model_handler.load_model("funnel")[1] == 10
+    with pytest.raises(NotImplementedError):
+        model_handler.load_model("lorenz")
+    with pytest.raises(NotImplementedError):
+        t(torch.zeros(2))
+
+
+def test_no_cpu_fallback_and_plugin_errors():
+    b = synthetic.build("gmm_n300_k8", device="cpu")
+    seeds = torch.arange(1, 9, dtype=torch.int32)
+    with pytest.raises(RuntimeError, match="ROCm device only"):
+        mcdbm.compute_bound(seeds, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"])
+    dim, K, _, spec = b["params_fixed"]
+    with pytest.raises(NotImplementedError, match="Mode not implemented."):
+        mcdbm.compute_bound(seeds, b["params_flat"], b["unflatten"], (dim, K, "MCD_ULA_sn", spec), b["target"])
+    with pytest.raises(TypeError):
+        mcdbm.compute_bound(seeds, b["params_flat"], b["unflatten"], b["params_fixed"], lambda z: z.sum())
+    with pytest.raises(NotImplementedError):
+        mcdbm.initialize(dim=2, nbridges=8, mode="MCD_CAIS_UHA_sn", device="cpu")
+
+
+def test_synthetic_configs_resolve():
+    for name, cfg in synthetic.CONFIGS.items():
+        if cfg["model"] == "lgcp":
+            continue
+        b = synthetic.build(name, device="cpu")
+        p = synthetic.oracle_params(b["unflatten"], b["params_flat"])
+        assert p["sn"] and b["params_fixed"][1] == cfg["nbridges"]

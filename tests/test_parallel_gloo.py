@@ -1,0 +1,93 @@
+"""world_size-2 gloo run of the particle sharding + statistics merge (the N>1 path of bench.py)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cmcd_amd import parallel, synthetic
+
+from helpers import run_oracle
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_forward(built):
+    from oracle.cmcd_oracle import stats5
+
+    def fwd(seeds):
+        loss, z = run_oracle(built, seeds.numpy(), dtype=np.float32)
+        return torch.from_numpy(loss), torch.from_numpy(z), torch.from_numpy(stats5(loss))
+    return fwd
+
+
+def _worker(rank, world, port, n, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b = synthetic.build("many_gmm_n2000_k256_dds", device="cpu", nbridges=4)
+    seeds = torch.from_numpy(synthetic.parity_seeds(n))
+    r = parallel.sharded_bound(seeds, _oracle_forward(b))
+    out[rank] = (r["lo"], r["hi"], float(r["mean"]), float(r["var"]), float(r["ln_z"]), float(r["n_finite"]),
+                 None if r["losses"] is None else r["losses"].numpy())
+    dist.destroy_process_group()
+
+
+def _run(world, n):
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), n, out), nprocs=world, join=True)
+    return dict(out)
+
+
+def test_two_ranks_match_single_process():
+    n = 70
+    out = _run(2, n)
+    b = synthetic.build("many_gmm_n2000_k256_dds", device="cpu", nbridges=4)
+    loss, _ = run_oracle(b, synthetic.parity_seeds(n), dtype=np.float32)
+    assert (out[0][0], out[0][1], out[1][0], out[1][1]) == (0, 35, 35, 70)
+    np.testing.assert_array_equal(np.concatenate([out[0][6], out[1][6]]), loss)   # contiguous shards
+    from oracle.cmcd_oracle import ln_z
+    fin = np.isfinite(loss)
+    for r in (0, 1):                                                   # every rank holds the global result
+        assert out[r][5] == fin.sum()
+        assert abs(out[r][4] - ln_z(loss)) < 1e-9
+        if fin.all():
+            assert abs(out[r][2] - loss.astype(np.float64).mean()) < 1e-9
+            assert abs(out[r][3] - loss.astype(np.float64).var()) < 1e-7
+    assert np.array_equal(out[0][2:6], out[1][2:6], equal_nan=True)    # identical on every rank
+    assert np.isinf(out[0][2]) and np.isnan(out[0][3])                 # +inf particle => mean inf, var nan
+
+
+def test_empty_shard():
+    out = _run(2, 1)                                                   # rank 1 gets no particles
+    assert (out[1][0], out[1][1]) == (1, 1) and out[1][6] is None
+    assert np.array_equal(out[0][2:6], out[1][2:6], equal_nan=True)
+
+
+def test_shard_range_covers_everything():
+    for n in (1, 7, 2000, 16001):
+        for w in (1, 2, 3, 8):
+            r = [parallel.shard_range(n, w, k) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n and all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+
+
+def test_merge_stats_matches_c_abi():
+    from cmcd_amd import _lib, build
+    from oracle.cmcd_oracle import stats5
+    build.build()
+    rng = np.random.default_rng(1)
+    parts = [rng.normal(2, 3, k) for k in (5, 1, 100)]
+    rows = [stats5(p) for p in parts]
+    merged_c, mean, var, lnz = _lib.stats_merge(rows, [len(p) for p in parts])
+    m = parallel.merge_stats(torch.tensor(np.array(rows)))
+    np.testing.assert_allclose(m.numpy(), merged_c, rtol=1e-14)
+    f = parallel.finalize(m, 106)
+    assert abs(float(f["mean"]) - mean) < 1e-13 and abs(float(f["ln_z"]) - lnz) < 1e-13
