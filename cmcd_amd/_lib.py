@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcmcd_hip.so")
+LIB_PATH = os.environ.get("CMCD_LIB_PATH", os.path.join(_HERE, "libcmcd_hip.so"))  # override: diagnostic builds
 
 MODE = {"MCD_CAIS_sn": 0, "MCD_CAIS_var_sn": 1}
 ARCH = {"geffner": 0, "dds": 1}

@@ -1,0 +1,49 @@
+// Structs shared by the translation units of libcmcd_hip.so.
+#pragma once
+#include <stdint.h>
+
+#include "cmcd_hip.h"
+
+namespace cmcd {
+
+// ------------------------------------------------------------------------------------------
+// workspace carve-up (floats unless noted)
+// ------------------------------------------------------------------------------------------
+struct WsLayout {
+  int64_t beta, eps, sig, logsig;  // [K] each
+  int64_t sched;                   // [K][8] {beta, eps, sig, logsig + log sqrt(2pi), 1/(2 sig^2), 0,0,0}
+  int64_t bias1;                   // [K+1][HP]
+  int64_t utab;                    // [K+1][HP]   (geffner only, else aliases bias1)
+  int64_t w1z;                     // [D][HP]
+  int64_t w2;                      // [T][T][64][4]
+  int64_t b2;                      // [HP]
+  int64_t w3t;                     // [D][HP]
+  int64_t b3;                      // [16]  (b3[D] then factor)
+  int64_t tgt;                     // target constants staged for LDS
+  int64_t tgt_floats;
+  int64_t partials;                // doubles: [n_waves][5]  (offset in floats, 8-byte aligned)
+  int64_t total_floats;
+  int32_t HP, T, n_waves;
+};
+
+
+// arguments of the trajectory kernels (both variants)
+struct TrajArgs {
+  const int32_t* seeds;
+  const float* params;
+  const float* ws;
+  double* partials;
+  float* out_loss;
+  float* out_z;
+  cmcd_layout lay;
+  WsLayout w;
+  int64_t n;
+  int32_t K, var_mode, grad_clipping;
+};
+
+// cmcd_coop.hip: the CU-cooperative variant (one workgroup per 16-particle tile).
+// Returns nullptr-equivalent (false) when no instance exists for this (target, arch, dim, T).
+bool coop_available(const cmcd_desc& d, int T);
+int coop_launch(const cmcd_desc& d, const TrajArgs& ta, void* stream);
+
+}  // namespace cmcd

@@ -1,0 +1,432 @@
+// coop_kernel — the CU-cooperative trajectory kernel: ONE WORKGROUP per 16-particle tile.
+//
+// Why: the named workload (N = 2000, K = 256) is a 256-long dependent chain on only 125 tiles.  A
+// wave-per-tile kernel leaves 7/8 of the SIMDs idle and its per-bridge latency is one wave's
+// instruction issue (~1800 VALU instructions at ~4.5 cycles each; integer chains ~8.5).  Here the
+// tile's work is spread over T + 4 waves of one CU:
+//   waves 0..T-1  MLP: wave v owns hidden-neuron tile v (16 neurons): 4 first-layer neurons per lane,
+//                 its W2 A-fragments (resident in VGPRs for the whole launch), its MFMA accumulator, its
+//                 slice of the output dot product; advances z redundantly (needs it for layer 1);
+//   waves T, T+1  TGT: grad log p(z) for 8 particles each, 8 lanes per particle;
+//   wave  T+2     RNG: the jax Threefry key chain, one bridge AHEAD, raw bits only (integer chain);
+//   wave  T+3     ACC: bits -> Gaussian deviates (Giles erfinv), and the only owner of the log-weight w
+//                 and of the outputs.
+// Per bridge evaluation i, two raw s_barriers (LDS visibility via s_waitcnt lgkmcnt(0) only):
+//   interval 1:  phase C(i-1) (combine layer-3 partials, grad log p, noise -> z_i)  then
+//                MLP: layer 1 + activation -> hbuf | TGT: squared distances | RNG: split(gen)
+//   barrier 1
+//   interval 2:  MLP: layer 2 on the matrix cores from hbuf, activation, layer-3 partial -> part |
+//                TGT: exp/sums -> gpb | RNG: split(H), normal bits -> raw | ACC: raw -> nzb
+//   barrier 2
+// Same arithmetic as traj_kernel (cmcd_kernels.hip); reference lines are cited there.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "cmcd_common.h"
+#include "cmcd_device.h"
+#include "cmcd_hip.h"
+
+namespace cmcd {
+
+// Diagnostic build only (-DCMCD_STAMPS, tools/probes/stamp_probe.py): per-wave cycle totals of each
+// phase of workgroup 0, written to a buffer nothing else reads.  Never compiled into the product.
+#ifdef CMCD_STAMPS
+__device__ unsigned long long g_stamps[16][16];
+#define STAMP(slot)                                                                      \
+  do {                                                                                   \
+    unsigned long long t_;                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    st_acc[slot] += t_ - st_last;                                                        \
+    st_last = t_;                                                                        \
+  } while (0)
+#else
+#define STAMP(slot)
+#endif
+
+// workgroup barrier that publishes LDS writes but does not drain outstanding global loads
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int TARGET, int ARCH, int D, int T>
+__global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
+  constexpr int HP = 16 * T;
+  constexpr int Hh = (D + 1) / 2;
+  constexpr int NZ = 2 * Hh;                 // noise words per particle (>= D)
+  constexpr int GP = (D + 1 + 3) & ~3;       // grad log p [D], log p, padded to a float4 multiple
+  constexpr int PT = (T * D + 3) & ~3;       // layer-3 partials per particle, padded
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* hbuf = lds;                         // [T][4][16][4]  layer-1 activations, MFMA-B order
+  float* part = hbuf + HP * 16;              // [16][PT]       layer-3 partial sums, [c][v*D + j]
+  float* gpb = part + 16 * PT;               // [2][16][GP]    grad log p, log p
+  float* nzb = gpb + 2 * 16 * GP;            // [2][16][NZ]    Gaussian noise
+  uint32_t* raw = reinterpret_cast<uint32_t*>(nzb + 2 * 16 * NZ);  // [2][16][NZ] raw bits
+  float* lds_tgt = reinterpret_cast<float*>(raw + 2 * 16 * NZ);
+
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, g = lane >> 4;
+  const bool is_mlp = wv < T, is_tgt = wv == T || wv == T + 1, is_rng = wv == T + 2, is_acc = wv == T + 3;
+  // particle column of this lane: TGT waves hold 8 particles x 8 lanes, everyone else 16 x 4
+  const int sub8 = lane >> 3;
+  const int c = is_tgt ? 8 * (wv - T) + (lane & 7) : (lane & 15);
+  const int64_t tile = blockIdx.x;
+  const int64_t p = tile * 16 + c;
+  const bool valid = p < a.n;
+  const int K = a.K;
+#ifdef CMCD_STAMPS
+  const int abl = a.var_mode >> 8;  // diagnostic ablation mask (results are wrong on purpose)
+  a.var_mode &= 0xff;
+#else
+  constexpr int abl = 0;
+#endif
+
+  for (int i = threadIdx.x; i < a.w.tgt_floats; i += blockDim.x) lds_tgt[i] = a.ws[a.w.tgt + i];
+
+  // ---- per-role resident operands
+  f32x4 afrag[T], w1z[D], w3t[D], b2v;
+  if (is_mlp) {
+#pragma unroll
+    for (int ti = 0; ti < T; ++ti)
+      afrag[ti] = *reinterpret_cast<const f32x4*>(a.ws + a.w.w2 + ((ti * T + wv) * 64 + lane) * 4);
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      w1z[j] = *reinterpret_cast<const f32x4*>(a.ws + a.w.w1z + j * HP + 16 * wv + 4 * g);
+      w3t[j] = *reinterpret_cast<const f32x4*>(a.ws + a.w.w3t + j * HP + 16 * wv + 4 * g);
+    }
+    b2v = *reinterpret_cast<const f32x4*>(a.ws + a.w.b2 + 16 * wv + 4 * g);
+  }
+  float b3[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) b3[j] = a.ws[a.w.b3 + j];
+  const float factor = a.ws[a.w.b3 + 15];
+
+  float qmean[D], qstd[D], qiv[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    qmean[j] = a.params[a.lay.vd_mean + j];
+    qstd[j] = expf(a.params[a.lay.vd_logdiag + j]);
+    qiv[j] = 1.0f / (qstd[j] * qstd[j]);
+  }
+
+  // ---- RNG wave: key chain prologue (mcdboundingmachine.py:151-162, mcd_cais.py:94), then the bits
+  //      of bridge 0.  Lane row g computes block (g & 1) of a split / block g of a normal draw.
+  const int gb = g & 1;
+  uint32_t k0 = 0u, k1 = 0u;
+  // normal(key, (D,)) bits: block j encrypts counters (j, Hh + j) -> words j and Hh + j; pad counter 0
+  auto normal_bits = [&](uint32_t nk0, uint32_t nk1, uint32_t hk0, uint32_t hk1, int buf, bool with_split) {
+    constexpr int NB = 2 + Hh;
+#pragma unroll
+    for (int b0 = with_split ? 0 : 2; b0 < NB; b0 += 4) {
+      const int b = b0 + g - (with_split ? 0 : 0);
+      const bool is_split = with_split && b < 2;
+      const int jn = with_split ? b - 2 : b0 - 2 + g;
+      uint32_t y0 = is_split ? b : jn;
+      uint32_t y1 = is_split ? 2 + b : ((Hh + jn < D) ? Hh + jn : 0);
+      threefry2x32(is_split ? hk0 : nk0, is_split ? hk1 : nk1, y0, y1);
+      if (with_split && b0 == 0) rows01(y1, k0, k1);  // gen = second(split(H))   mcd_cais.py:87
+      if (jn >= 0 && jn < Hh) {
+        raw[(buf * 16 + c) * NZ + jn] = y0;
+        raw[(buf * 16 + c) * NZ + Hh + jn] = y1;
+      }
+    }
+  };
+  if (is_rng) {
+    const int32_t seed = a.seeds[valid ? p : a.n - 1];
+    uint32_t x0 = gb, x1 = 2 + gb;
+    threefry2x32(0u, (uint32_t)seed, x0, x1);  // (A, B) = split(PRNGKey(seed))
+    uint32_t a0, a1, bb0, bb1;
+    rows01(x0, a0, a1);
+    rows01(x1, bb0, bb1);
+    normal_bits(a0, a1, 0u, 0u, 1, false);     // z0 noise = normal(A) -> raw[1]
+    x0 = gb; x1 = 2 + gb;
+    threefry2x32(bb0, bb1, x0, x1);            // C = first(split(B))
+    uint32_t c0, c1;
+    rows01(x0, c0, c1);
+    x0 = gb; x1 = 2 + gb;
+    threefry2x32(c0, c1, x0, x1);              // gen = second(split(C))
+    rows01(x1, k0, k1);
+    x0 = gb; x1 = 2 + gb;
+    threefry2x32(k0, k1, x0, x1);              // (G, H) = split(gen)             mcd_cais.py:66
+    uint32_t g0, g1, h0, h1;
+    rows01(x0, g0, g1);
+    rows01(x1, h0, h1);
+    normal_bits(g0, g1, h0, h1, 0, true);      // bridge 0 bits -> raw[0]
+  }
+  lds_barrier();
+  // bits -> deviates, words dealt to the 4 rows of the wave
+  auto convert = [&](int buf) {
+#pragma unroll
+    for (int q0 = 0; q0 < D; q0 += 4) {
+      const int q = q0 + g;
+      if (q < D) nzb[(buf * 16 + c) * NZ + q] = bits_to_normal(raw[(buf * 16 + c) * NZ + q]);
+    }
+  };
+  if (is_acc) convert(1);
+  lds_barrier();
+
+  // z0 = mean + std * normal(A, (D,)); w = -log q(z0)      diag_gauss.py:49-62, mcdboundingmachine.py:157
+  float z[D], zp[D];
+  float w = 0.f;
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    z[j] = qstd[j] * nzb[(16 + c) * NZ + j] + qmean[j];
+    zp[j] = 0.f;
+    const float dz = z[j] - qmean[j];
+    w -= -(dz * dz) / (2.0f * qstd[j] * qstd[j]) - logf(qstd[j]) - kHalfLog2Pi;
+  }
+
+  const float clipv = a.var_mode ? 1e2f : 1e3f;
+  const bool clip_p = a.grad_clipping != 0;
+  const bool clip_q = clip_p && a.var_mode;
+  const float* brow_ptr = a.ws + a.w.bias1 + 16 * wv + 4 * g;
+  const float* urow_ptr = a.ws + a.w.utab + 16 * wv + 4 * g;
+  // per-lane copy of the (uniform) schedule pointer so that the loads are vector loads
+  const float* sched_v = a.ws + a.w.sched + (lane & 0);
+  asm volatile("" : "+v"(sched_v));
+  float* const my_h = hbuf + ((wv * 4 + g) * 16 + (lane & 15)) * 4;
+  const float* const rd_h = hbuf + (g * 16 + (lane & 15)) * 4;
+
+  float fk_lp = 0.f, pbeta = 0.f, peps = 0.f, pinv2s2 = 0.f, pcst = 0.f, logp = 0.f;
+  f32x4 brow = {0.f, 0.f, 0.f, 0.f}, urow = {0.f, 0.f, 0.f, 0.f};
+  if (is_mlp) {
+    brow = *reinterpret_cast<const f32x4*>(brow_ptr);
+    if (ARCH == CMCD_ARCH_GEFFNER) urow = *reinterpret_cast<const f32x4*>(urow_ptr);
+  }
+
+#ifdef CMCD_STAMPS
+  unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+#endif
+  for (int i = 0; i <= K; ++i) {
+    const int buf = i & 1;
+    // per-bridge scalars {beta, eps, sigma, log sigma + log sqrt(2 pi), 1/(2 sigma^2)}.  VECTOR loads
+    // (vmcnt) issued a whole bridge before use: a scalar load here would sit on lgkmcnt, which every
+    // LDS wait of the step drains, exposing its full L2 latency on the critical path.
+    const f32x4 sc0 = *reinterpret_cast<const f32x4*>(sched_v);
+    const float inv2s2 = sched_v[4];
+    sched_v += (i + 1 < K) ? 8 : 0;
+    const float beta = sc0[0], eps = sc0[1], sig = sc0[2], cst = sc0[3];
+    f32x4 h = {0.f, 0.f, 0.f, 0.f};
+    typename Target<TARGET, D>::State tst;
+    uint32_t g0 = 0, g1 = 0, h0 = 0, h1 = 0;
+    // ------------------------------------------------------------------ interval 1 (after phase C)
+    if (is_mlp) {
+      f32x4 pre = brow;
+#pragma unroll
+      for (int j = 0; j < D; ++j) pre += z[j] * w1z[j];
+      if (ARCH == CMCD_ARCH_DDS) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = (abl & 16) ? pre[r] : gelu_fast(pre[r]);
+      } else {
+        f32x4 u = urow;
+        if (wv == 0) {  // the first D neurons of u are z itself (D <= 16)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int nidx = 4 * g + r;
+#pragma unroll
+            for (int j = 0; j < D; ++j) u[r] = (nidx == j) ? z[j] : u[r];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = u[r] + softplus(pre[r]);
+      }
+      STAMP(5);
+      *reinterpret_cast<f32x4*>(my_h) = h;
+    } else if (is_tgt) {
+      if (!(abl & 1)) Target<TARGET, D>::template pass1<8>(z, sub8, lds_tgt, tst);
+    } else if (is_rng && i + 1 < K && !(abl & 2)) {
+      uint32_t x0 = gb, x1 = 2 + gb;
+      threefry2x32(k0, k1, x0, x1);            // (G, H) = split(gen) of bridge i+1
+      rows01(x0, g0, g1);
+      rows01(x1, h0, h1);
+    }
+    STAMP(0);
+    lds_barrier();
+    STAMP(1);
+    // ------------------------------------------------------------------ interval 2
+    if (is_mlp) {
+      // prefetch the next bridge's first-layer bias row (L2-resident); lands during the MFMAs
+      brow_ptr += (i < K) ? HP : 0;
+      brow = *reinterpret_cast<const f32x4*>(brow_ptr);
+      if (ARCH == CMCD_ARCH_GEFFNER) {
+        urow_ptr += (i < K) ? HP : 0;
+        urow = *reinterpret_cast<const f32x4*>(urow_ptr);
+      }
+      // layer 2: rows = my 16 output neurons, cols = particles, k = all HP inputs from LDS
+      f32x4 acc = b2v;
+      STAMP(6);
+      if (!(abl & 8))
+#pragma unroll
+      for (int ti = 0; ti < T; ++ti) {
+        const f32x4 hb = *reinterpret_cast<const f32x4*>(rd_h + ti * 256);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ti][r], hb[r], acc, 0, 0, 0);
+      }
+      f32x4 h2;
+      asm volatile("" : "+v"(acc));
+      STAMP(7);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        h2[r] = (abl & 16) ? acc[r] : ((ARCH == CMCD_ARCH_DDS) ? gelu_fast(acc[r]) : h[r] + softplus(acc[r]));
+      asm volatile("" : "+v"(h2));
+      STAMP(8);
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        float pj = h2[0] * w3t[j][0] + h2[1] * w3t[j][1] + h2[2] * w3t[j][2] + h2[3] * w3t[j][3];
+        pj = group_sum(pj);
+        if (g == 0) part[c * PT + wv * D + j] = pj;
+      }
+    } else if (is_tgt) {
+      float gp[D], lp = 0.f;
+#pragma unroll
+      for (int j = 0; j < D; ++j) gp[j] = 0.f;
+      if (!(abl & 1)) Target<TARGET, D>::template pass2<8>(z, sub8, lds_tgt, tst, lp, gp);
+      if (sub8 == 0) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) gpb[(buf * 16 + c) * GP + j] = gp[j];
+        gpb[(buf * 16 + c) * GP + D] = lp;
+      }
+    } else if (is_rng) {
+      if (i + 1 < K && !(abl & 2)) normal_bits(g0, g1, h0, h1, buf ^ 1, true);
+    } else {
+      if (i < K && !(abl & 4)) convert(buf);
+    }
+    STAMP(2);
+    lds_barrier();
+    STAMP(3);
+    // ------------------------------------------------------------------ phase C
+    if (is_rng) continue;
+    float sn[D], gp[D], gq[D];
+    {
+      float pt[PT], gv[GP];
+#pragma unroll
+      for (int q = 0; q < PT; q += 4)
+        *reinterpret_cast<f32x4*>(pt + q) = *reinterpret_cast<const f32x4*>(part + c * PT + q);
+#pragma unroll
+      for (int q = 0; q < GP; q += 4)
+        *reinterpret_cast<f32x4*>(gv + q) = *reinterpret_cast<const f32x4*>(gpb + (buf * 16 + c) * GP + q);
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        float o = b3[j];
+#pragma unroll
+        for (int v = 0; v < T; ++v) o += pt[v * D + j];
+        sn[j] = (ARCH == CMCD_ARCH_DDS) ? fminf(fmaxf(o, -1e4f), 1e4f) : o * factor;
+        gp[j] = gv[j];
+        gq[j] = -(z[j] - qmean[j]) * qiv[j];
+        if (clip_p) gp[j] = fminf(fmaxf(gp[j], -clipv), clipv);
+        if (clip_q) gq[j] = fminf(fmaxf(gq[j], -clipv), clipv);
+      }
+      logp = gv[D];
+    }
+    STAMP(9);
+    if (is_acc && i > 0) {  // backward kernel of step i-1 (mcd_cais.py:71-86): only ACC tracks w
+      float bk_lp = 0.f;
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        const float ub = -1.0f * (pbeta * gp[j] + (1.0f - pbeta) * gq[j]);
+        const float bk = z[j] - peps * ub + peps * sn[j];
+        const float db = zp[j] - bk;
+        bk_lp += -(db * db) * pinv2s2 - pcst;
+      }
+      w += bk_lp - fk_lp;
+    }
+    if (i == K) break;
+    fk_lp = 0.f;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {  // forward kernel of step i (mcd_cais.py:52-67)
+      const float uf = -1.0f * (beta * gp[j] + (1.0f - beta) * gq[j]);
+      const float fk = z[j] - eps * uf - eps * sn[j];
+      const float zn = fk + sig * nzb[(buf * 16 + c) * NZ + j];
+      if (is_acc) {
+        const float df = zn - fk;
+        fk_lp += -(df * df) * inv2s2 - cst;
+        zp[j] = z[j];
+      }
+      z[j] = zn;
+    }
+    pbeta = beta; peps = eps; pinv2s2 = inv2s2; pcst = cst;
+    STAMP(4);
+  }
+#ifdef CMCD_STAMPS
+  if (blockIdx.x == 0 && lane == 0)
+    for (int k = 0; k < 16; ++k) g_stamps[wv][k] = st_acc[k];
+#endif
+
+  if (!is_acc) return;
+  w += logp;  // + log p(z_K)   mcdboundingmachine.py:178
+  const float loss = -w;
+  if (valid && g == 0) {
+    a.out_loss[p] = loss;
+#pragma unroll
+    for (int j = 0; j < D; ++j) a.out_z[p * D + j] = z[j];
+  }
+  const bool use = valid && g == 0;
+  double cnt = (use && isfinite(loss)) ? 1.0 : 0.0;
+  double sm = use ? (double)loss : 0.0;
+  double sq = use ? (double)loss * (double)loss : 0.0;
+  double mx = use ? -(double)loss : -INFINITY;
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) {
+    cnt += __shfl_xor(cnt, o);
+    sm += __shfl_xor(sm, o);
+    sq += __shfl_xor(sq, o);
+    mx = fmax(mx, __shfl_xor(mx, o));
+  }
+  double ex = (use && mx > -INFINITY && mx < INFINITY) ? exp(-(double)loss - mx) : 0.0;
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) ex += __shfl_xor(ex, o);
+  if (lane == 0) {
+    double* o = a.partials + tile * CMCD_NSTATS;
+    o[0] = cnt; o[1] = sm; o[2] = sq; o[3] = mx; o[4] = ex;
+  }
+}
+
+typedef void (*coop_fn)(TrajArgs);
+
+template <int TARGET, int ARCH, int D>
+static coop_fn pick_T(int T) {
+  switch (T) {
+    case 2: return coop_kernel<TARGET, ARCH, D, 2>;
+    case 4: return coop_kernel<TARGET, ARCH, D, 4>;
+    case 9: return coop_kernel<TARGET, ARCH, D, 9>;
+    default: return nullptr;
+  }
+}
+
+static coop_fn pick(const cmcd_desc& d, int T) {
+  if (d.arch == CMCD_ARCH_DDS) {
+    if (T != 4) return nullptr;
+    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2) return coop_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_DDS, 2, 4>;
+    if (d.target == CMCD_TARGET_GMM && d.dim == 2) return coop_kernel<CMCD_TARGET_GMM, CMCD_ARCH_DDS, 2, 4>;
+    if (d.target == CMCD_TARGET_FUNNEL && d.dim == 10) return coop_kernel<CMCD_TARGET_FUNNEL, CMCD_ARCH_DDS, 10, 4>;
+    return nullptr;
+  }
+  if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2) return pick_T<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2>(T);
+  if (d.target == CMCD_TARGET_GMM && d.dim == 2) return pick_T<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER, 2>(T);
+  if (d.target == CMCD_TARGET_FUNNEL && d.dim == 10) return pick_T<CMCD_TARGET_FUNNEL, CMCD_ARCH_GEFFNER, 10>(T);
+  return nullptr;
+}
+
+#ifdef CMCD_STAMPS
+extern "C" int cmcd_debug_read_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16 * 16);
+}
+#endif
+
+bool coop_available(const cmcd_desc& d, int T) { return pick(d, T) != nullptr; }
+
+int coop_launch(const cmcd_desc& d, const TrajArgs& ta, void* stream) {
+  const int T = ta.w.T, D = d.dim, Hh = (D + 1) / 2, NZ = 2 * Hh;
+  const int GP = (D + 1 + 3) & ~3, PT = (T * D + 3) & ~3;
+  coop_fn fn = pick(d, T);
+  if (!fn) return CMCD_ERR_UNSUPPORTED;
+  const size_t lds_bytes = size_t(16 * T * 16 + 16 * PT + 2 * 16 * GP + 2 * 16 * NZ + 2 * 16 * NZ + ta.w.tgt_floats) * 4;
+  hipLaunchKernelGGL(fn, dim3((unsigned)ta.w.n_waves), dim3(64 * (T + 4)), lds_bytes,
+                     static_cast<hipStream_t>(stream), ta);
+  return CMCD_OK;
+}
+
+}  // namespace cmcd

@@ -43,7 +43,9 @@ __device__ __forceinline__ void threefry2x32(uint32_t k0, uint32_t k1, uint32_t&
 
 // XLA's f32 erf_inv (Giles' single-precision polynomial), as used by jax.random.normal.
 __device__ __forceinline__ float erfinv_giles(float x) {
-  float w = -log1pf(-x * x);
+  // w = -log(1 - x^2) = -ln2 * log2((1 - x)(1 + x)): both factors are exact near |x| = 1, one
+  // v_log_f32; absolute error of w < 1e-6, i.e. <= 2 ulp of the resulting normal deviate.
+  float w = -0.69314718055994530942f * __builtin_amdgcn_logf((1.0f - x) * (1.0f + x));
   float p;
   if (w < 5.0f) {
     w = w - 2.5f;
@@ -113,16 +115,64 @@ __device__ __forceinline__ float softplus(float x) {
   return fmaf(0.69314718055994530942f, __builtin_amdgcn_logf(1.0f + e), fmaxf(x, 0.0f));
 }
 
+// Cross-row exchange with the gfx950 row-swap instructions (VALU, no LDS round trip).  Measured
+// semantics (tools/probes/permlane_probe.hip), rows = 16-lane groups of the wave:
+//   v_permlane32_swap(a, b) -> r0 = rows [a0 a1 b0 b1], r1 = rows [a2 a3 b2 b3]
+//   v_permlane16_swap(a, b) -> r0 = rows [a0 b0 a2 b2], r1 = rows [a1 b1 a3 b3]
+__device__ __forceinline__ void swap32(uint32_t a, uint32_t b, uint32_t& r0, uint32_t& r1) {
+  auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  r0 = r[0];
+  r1 = r[1];
+}
+__device__ __forceinline__ void swap16(uint32_t a, uint32_t b, uint32_t& r0, uint32_t& r1) {
+  auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+  r0 = r[0];
+  r1 = r[1];
+}
 // lanes l, l^16, l^32, l^48 hold the four k-slices of one particle: butterfly over them
 __device__ __forceinline__ float group_sum(float v) {
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 32);
-  return v;
+  uint32_t a, b;
+  swap32(__float_as_uint(v), __float_as_uint(v), a, b);
+  v = __uint_as_float(a) + __uint_as_float(b);
+  swap16(__float_as_uint(v), __float_as_uint(v), a, b);
+  return __uint_as_float(a) + __uint_as_float(b);
 }
+__device__ __forceinline__ float group_sum_swap(float v) { return group_sum(v); }
 __device__ __forceinline__ float group_max(float v) {
-  v = fmaxf(v, __shfl_xor(v, 16));
-  v = fmaxf(v, __shfl_xor(v, 32));
-  return v;
+  uint32_t a, b;
+  swap32(__float_as_uint(v), __float_as_uint(v), a, b);
+  v = fmaxf(__uint_as_float(a), __uint_as_float(b));
+  swap16(__float_as_uint(v), __float_as_uint(v), a, b);
+  return fmaxf(__uint_as_float(a), __uint_as_float(b));
+}
+// xor-8 exchange inside each 16-lane row (DPP row_ror:8)
+__device__ __forceinline__ float xor8(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));
+}
+// sum / max over the LP lanes that share a particle: LP = 4 -> lanes {c, c+16, c+32, c+48};
+// LP = 8 -> lanes {c8 + 8 s, s < 8}
+template <int LP>
+__device__ __forceinline__ float part_sum(float v) {
+  if (LP == 8) v += xor8(v);
+  return group_sum(v);
+}
+template <int LP>
+__device__ __forceinline__ float part_max(float v) {
+  if (LP == 8) v = fmaxf(v, xor8(v));
+  return group_max(v);
+}
+// every lane receives x of row 0 (r0) and of row 1 (r1) at its own column
+__device__ __forceinline__ void rows01(uint32_t x, uint32_t& r0, uint32_t& r1) {
+  uint32_t a, b;
+  swap32(x, x, a, b);   // a = rows [x0 x1 x0 x1]
+  swap16(a, a, r0, r1); // r0 = [x0 x0 x0 x0], r1 = [x1 x1 x1 x1]
+}
+// every lane receives x of all four rows at its own column
+__device__ __forceinline__ void rows0123(uint32_t x, uint32_t (&r)[4]) {
+  uint32_t a, b;
+  swap32(x, x, a, b);   // a = [x0 x1 x0 x1], b = [x2 x3 x2 x3]
+  swap16(a, a, r[0], r[1]);
+  swap16(b, b, r[2], r[3]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -133,50 +183,87 @@ __device__ __forceinline__ float group_max(float v) {
 template <int TARGET, int D>
 struct Target;
 
-// many_gmm: /root/reference/src/model_handler.py:245-281.  tc = {inv_scale, logc, n_mixes(bits),
-// pad, means[n_mixes][2]}; components are dealt round-robin to the 4 lanes of a particle.
+// many_gmm: /root/reference/src/model_handler.py:245-281.  tc = {inv_scale, c2, n_mixes(bits), c0,
+// means[n_mixes][2]} with logit_k (in log2 units) = c0 + c2 * |z - mu_k|^2.  Components are dealt
+// round-robin to the 4 lanes of a particle; evaluation is split in two halves so that a
+// cooperative kernel can put a workgroup barrier between them:
+//   pass1: squared distances (kept in registers) and their minimum  -> the log-sum-exp shift
+//   pass2: exp2, weighted sums, combine over the 4 lanes, log p and its gradient.
 template <>
 struct Target<CMCD_TARGET_MANY_GMM, 2> {
   static constexpr int kLdsHeader = 4;
-  __device__ static __forceinline__ void eval(const float (&z)[2], int g, const float* tc, float& logp,
-                                              float (&grad)[2]) {
-    const float inv_s = tc[0], logc = tc[1];
+  static constexpr int kFastMix = 40;  // register-resident fast path: n_mixes == 40
+  struct State {
+    float d2[10], dx[10], dy[10], dmin;
+  };
+  // `sub` in [0, LP): which share of the components this lane owns
+  template <int LP>
+  __device__ static __forceinline__ void pass1(const float (&z)[2], int sub, const float* tc, State& st) {
+    constexpr int kQ = kFastMix / LP;
     const int nm = __float_as_int(tc[2]);
     const float2* mu = reinterpret_cast<const float2*>(tc + kLdsHeader);
-    constexpr int kMaxPer = 16;  // up to 64 mixtures
-    float lg[kMaxPer], dx[kMaxPer], dy[kMaxPer];
-    float m = -INFINITY;
+    float dmin = INFINITY;
+    if (nm == kFastMix) {
 #pragma unroll
-    for (int q = 0; q < kMaxPer; ++q) {
-      const int k = g + 4 * q;
-      if (4 * q < nm) {  // wave-uniform trip bound
-        const float2 mk = mu[k < nm ? k : 0];
-        dx[q] = (z[0] - mk.x) * inv_s;
-        dy[q] = (z[1] - mk.y) * inv_s;
-        lg[q] = (k < nm) ? fmaf(-0.5f, dx[q] * dx[q] + dy[q] * dy[q], logc) : -INFINITY;
-        m = fmaxf(m, lg[q]);
+      for (int q = 0; q < kQ; ++q) {
+        const float2 mk = mu[sub + LP * q];
+        st.dx[q] = z[0] - mk.x;
+        st.dy[q] = z[1] - mk.y;
+        st.d2[q] = fmaf(st.dx[q], st.dx[q], st.dy[q] * st.dy[q]);
+        dmin = fminf(dmin, st.d2[q]);
+      }
+    } else {
+      for (int k = sub; k < nm; k += LP) {
+        const float2 mk = mu[k];
+        const float dx = z[0] - mk.x, dy = z[1] - mk.y;
+        dmin = fminf(dmin, fmaf(dx, dx, dy * dy));
       }
     }
-    m = group_max(m);
+    st.dmin = dmin;
+  }
+  template <int LP>
+  __device__ static __forceinline__ void pass2(const float (&z)[2], int sub, const float* tc, const State& st,
+                                               float& logp, float (&grad)[2]) {
+    constexpr int kQ = kFastMix / LP;
+    const float inv_s = tc[0], c2 = tc[1], c0 = tc[3];
+    const int nm = __float_as_int(tc[2]);
+    const float2* mu = reinterpret_cast<const float2*>(tc + kLdsHeader);
+    const float dmin = -part_max<LP>(-st.dmin);
     float s = 0.f, sx = 0.f, sy = 0.f;
+    if (nm == kFastMix) {
 #pragma unroll
-    for (int q = 0; q < kMaxPer; ++q) {
-      if (4 * q < nm) {
-        const float e = __expf(lg[q] - m);  // exp(-inf) = 0 for padded slots
+      for (int q = 0; q < kQ; ++q) {
+        const float e = __builtin_amdgcn_exp2f(c2 * (st.d2[q] - dmin));
         s += e;
-        sx = fmaf(e, dx[q], sx);
-        sy = fmaf(e, dy[q], sy);
+        sx = fmaf(e, st.dx[q], sx);
+        sy = fmaf(e, st.dy[q], sy);
+      }
+    } else {
+      for (int k = sub; k < nm; k += LP) {
+        const float2 mk = mu[k];
+        const float dx = z[0] - mk.x, dy = z[1] - mk.y;
+        const float e = __builtin_amdgcn_exp2f(c2 * (fmaf(dx, dx, dy * dy) - dmin));
+        s += e;
+        sx = fmaf(e, dx, sx);
+        sy = fmaf(e, dy, sy);
       }
     }
-    s = group_sum(s);
-    sx = group_sum(sx);
-    sy = group_sum(sy);
-    const float lp = m + logf(s);
+    s = part_sum<LP>(s);
+    sx = part_sum<LP>(sx);
+    sy = part_sum<LP>(sy);
+    // log p = ln2 * (c0 + c2 dmin + log2 s)
+    const float lp = 0.69314718055994530942f * (fmaf(c2, dmin, c0) + __builtin_amdgcn_logf(s));
     const bool valid = lp > -1e4f;  // model_handler.py:279-280
-    const float sc = -inv_s / s;
+    const float sc = -(inv_s * inv_s) * __builtin_amdgcn_rcpf(s);
     logp = valid ? lp : -INFINITY;
     grad[0] = valid ? sx * sc : 0.f;
     grad[1] = valid ? sy * sc : 0.f;
+  }
+  __device__ static __forceinline__ void eval(const float (&z)[2], int g, const float* tc, float& logp,
+                                              float (&grad)[2]) {
+    State st;
+    pass1<4>(z, g, tc, st);
+    pass2<4>(z, g, tc, st, logp, grad);
   }
 };
 
@@ -208,6 +295,14 @@ struct Target<CMCD_TARGET_GMM, 2> {
     gx = (ea * pa0 + eb * pb0 + ec * pc0) * is;
     gy = (ea * pa1 + eb * pb1 + ec * pc1) * is;
   }
+  struct State {};
+  template <int LP>
+  __device__ static __forceinline__ void pass1(const float (&)[2], int, const float*, State&) {}
+  template <int LP>
+  __device__ static __forceinline__ void pass2(const float (&z)[2], int g, const float* tc, const State&,
+                                               float& logp, float (&grad)[2]) {
+    eval(z, g, tc, logp, grad);
+  }
   __device__ static __forceinline__ void eval(const float (&z)[2], int, const float*, float& logp,
                                               float (&grad)[2]) {
     float fa, gax, gay, fb, gbx, gby;
@@ -226,6 +321,14 @@ struct Target<CMCD_TARGET_GMM, 2> {
 template <int D>
 struct Target<CMCD_TARGET_FUNNEL, D> {
   static constexpr int kLdsHeader = 0;
+  struct State {};
+  template <int LP>
+  __device__ static __forceinline__ void pass1(const float (&)[D], int, const float*, State&) {}
+  template <int LP>
+  __device__ static __forceinline__ void pass2(const float (&z)[D], int g, const float* tc, const State&,
+                                               float& logp, float (&grad)[D]) {
+    eval(z, g, tc, logp, grad);
+  }
   __device__ static __forceinline__ void eval(const float (&z)[D], int, const float*, float& logp,
                                               float (&grad)[D]) {
     const float v = z[0];

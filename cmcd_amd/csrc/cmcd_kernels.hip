@@ -20,8 +20,10 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include "cmcd_common.h"
 #include "cmcd_device.h"
 #include "cmcd_hip.h"
 
@@ -40,29 +42,18 @@ struct ProfileState {
   int created = 0;
 };
 static thread_local ProfileState g_prof;
+
+// Tiles (16 particles each) up to which the CU-cooperative kernel is preferred; measured crossovers on
+// MI355X (tools/probes/variant_sweep.py): dds/geffner T<=4 between 512 and 1024 tiles, the 132-wide
+// net between 256 and 1000; the d=10 wave-per-tile instance still spills, so funnel stays cooperative.
+static int coop_max_tiles(const cmcd_desc& d, int T) {
+  if (d.dim >= 8) return 8192;
+  return T >= 8 ? 256 : 512;
+}
 static int fail(int code, const char* fmt, const char* a = "", long long b = 0) {
   snprintf(g_err, sizeof(g_err), fmt, a, b);
   return code;
 }
-
-// ------------------------------------------------------------------------------------------
-// workspace carve-up (floats unless noted)
-// ------------------------------------------------------------------------------------------
-struct WsLayout {
-  int64_t beta, eps, sig, logsig;  // [K] each
-  int64_t bias1;                   // [K+1][HP]
-  int64_t utab;                    // [K+1][HP]   (geffner only, else aliases bias1)
-  int64_t w1z;                     // [D][HP]
-  int64_t w2;                      // [T][T][64][4]
-  int64_t b2;                      // [HP]
-  int64_t w3t;                     // [D][HP]
-  int64_t b3;                      // [16]  (b3[D] then factor)
-  int64_t tgt;                     // target constants staged for LDS
-  int64_t tgt_floats;
-  int64_t partials;                // doubles: [n_waves][5]  (offset in floats, 8-byte aligned)
-  int64_t total_floats;
-  int32_t HP, T, n_waves;
-};
 
 static inline int64_t align4(int64_t x) { return (x + 3) & ~int64_t(3); }
 
@@ -95,6 +86,7 @@ static bool make_ws(const cmcd_desc& d, int64_t n, int64_t n_target, WsLayout& w
   w.eps = o; o += align4(K);
   w.sig = o; o += align4(K);
   w.logsig = o; o += align4(K);
+  w.sched = o; o += 8 * K;
   w.bias1 = o; o += (K + 1) * HP;
   if (d.arch == CMCD_ARCH_GEFFNER) { w.utab = o; o += (K + 1) * HP; } else { w.utab = w.bias1; }
   w.w1z = o; o += D * HP;
@@ -163,6 +155,13 @@ __global__ void prep_sched_kernel(SchedArgs a) {
     a.ws[a.w.eps + i] = e;
     a.ws[a.w.sig + i] = s;
     a.ws[a.w.logsig + i] = logf(s);
+    float* sc = a.ws + a.w.sched + 8 * (int64_t)i;
+    sc[0] = a.ws[a.w.beta + i];
+    sc[1] = e;
+    sc[2] = s;
+    sc[3] = logf(s) + kHalfLog2Pi;
+    sc[4] = 1.0f / (2.0f * s * s);
+    sc[5] = sc[6] = sc[7] = 0.f;
   }
 }
 
@@ -272,13 +271,16 @@ __global__ void pack_weights_kernel(PackArgs a) {
     a.ws[a.w.b3 + idx] = v;
   }
   if (a.target == CMCD_TARGET_MANY_GMM) {
-    // tgt = {scale, means[n_mix][2]} -> {1/scale, logc, n_mix bits, 0, means}
+    // tgt = {scale, means[n_mix][2]} -> {1/scale, c2, n_mix bits, c0, means}
     for (int64_t idx = tid; idx < a.w.tgt_floats; idx += stride) {
       float v = 0.f;
       const float s = a.tgt[0];
+      // logit_k / ln2 = c0 + c2 |z - mu_k|^2 : c2 = -log2(e) / (2 s^2),
+      // c0 = log2(e) * (-2 (log s + log sqrt(2 pi)) - log n_mix)
       if (idx == 0) v = 1.0f / s;
-      else if (idx == 1) v = -2.0f * (logf(s) + kHalfLog2Pi) - logf((float)a.n_mix);
+      else if (idx == 1) v = -0.5f * 1.44269504088896340736f / (s * s);
       else if (idx == 2) v = __int_as_float(a.n_mix);
+      else if (idx == 3) v = 1.44269504088896340736f * (-2.0f * (logf(s) + kHalfLog2Pi) - logf((float)a.n_mix));
       else if (idx >= 4 && idx < 4 + 2 * a.n_mix) v = a.tgt[1 + (idx - 4)];
       a.ws[a.w.tgt + idx] = v;
     }
@@ -288,18 +290,6 @@ __global__ void pack_weights_kernel(PackArgs a) {
 // ------------------------------------------------------------------------------------------
 // 4. the trajectory kernel
 // ------------------------------------------------------------------------------------------
-struct TrajArgs {
-  const int32_t* seeds;
-  const float* params;
-  const float* ws;
-  double* partials;
-  float* out_loss;
-  float* out_z;
-  cmcd_layout lay;
-  WsLayout w;
-  int64_t n;
-  int32_t K, var_mode, grad_clipping;
-};
 
 template <int ARCH>
 __device__ __forceinline__ float act(float pre) {
@@ -440,8 +430,9 @@ __global__ __launch_bounds__(512) void traj_kernel(TrajArgs a) {
   {
     x0 = gb; x1 = 2 + gb;
     threefry2x32(k0, k1, x0, x1);  // split(PRNGKey(seed)) -> A = (out0,out1), B = (out2,out3)
-    const uint32_t a0 = __shfl(x0, c), a1 = __shfl(x0, c + 16);
-    const uint32_t b0 = __shfl(x1, c), b1 = __shfl(x1, c + 16);
+    uint32_t a0, a1, b0, b1;
+    rows01(x0, a0, a1);
+    rows01(x1, b0, b1);
     // z0 = mean + std * normal(A, (D,))                  diag_gauss.py:49-62
     constexpr int Hh = (D + 1) / 2;
     float nz[2 * Hh];
@@ -450,12 +441,14 @@ __global__ __launch_bounds__(512) void traj_kernel(TrajArgs a) {
       const int j = j0 + g;  // block j encrypts (ctr[j], ctr[Hh + j]); pad counters are 0
       uint32_t y0 = j, y1 = (Hh + j < D) ? Hh + j : 0;
       threefry2x32(a0, a1, y0, y1);
-      const float n0 = bits_to_normal(y0), n1 = bits_to_normal(y1);
+      uint32_t r0[4], r1[4];
+      rows0123(__float_as_uint(bits_to_normal(y0)), r0);
+      rows0123(__float_as_uint(bits_to_normal(y1)), r1);
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         if (j0 + q < Hh) {
-          nz[j0 + q] = __shfl(n0, c + 16 * q);
-          nz[Hh + j0 + q] = __shfl(n1, c + 16 * q);
+          nz[j0 + q] = __uint_as_float(r0[q]);
+          nz[Hh + j0 + q] = __uint_as_float(r1[q]);
         }
     }
 #pragma unroll
@@ -463,11 +456,11 @@ __global__ __launch_bounds__(512) void traj_kernel(TrajArgs a) {
     // C = first(split(B)); gen = second(split(C))
     x0 = gb; x1 = 2 + gb;
     threefry2x32(b0, b1, x0, x1);
-    const uint32_t c0 = __shfl(x0, c), c1 = __shfl(x0, c + 16);
+    uint32_t c0, c1;
+    rows01(x0, c0, c1);
     x0 = gb; x1 = 2 + gb;
     threefry2x32(c0, c1, x0, x1);
-    k0 = __shfl(x1, c);
-    k1 = __shfl(x1, c + 16);
+    rows01(x1, k0, k1);
   }
 
   // w = -log q(z0)                                       mcdboundingmachine.py:157
@@ -530,8 +523,9 @@ __global__ __launch_bounds__(512) void traj_kernel(TrajArgs a) {
     //      mcd_cais.py:66-67,87
     x0 = gb; x1 = 2 + gb;
     threefry2x32(k0, k1, x0, x1);
-    const uint32_t g0 = __shfl(x0, c), g1 = __shfl(x0, c + 16);
-    const uint32_t h0 = __shfl(x1, c), h1 = __shfl(x1, c + 16);
+    uint32_t g0, g1, h0, h1;
+    rows01(x0, g0, g1);
+    rows01(x1, h0, h1);
     constexpr int Hh = (D + 1) / 2;
     constexpr int NB = 2 + Hh;  // blocks of this stage: 2 for split(H), Hh for normal(G)
     float nz[2 * Hh];
@@ -543,17 +537,16 @@ __global__ __launch_bounds__(512) void traj_kernel(TrajArgs a) {
       uint32_t y0 = is_split ? b : jn;
       uint32_t y1 = is_split ? 2 + b : ((Hh + jn < D) ? Hh + jn : 0);
       threefry2x32(is_split ? h0 : g0, is_split ? h1 : g1, y0, y1);
-      if (b0 == 0) {
-        k0 = __shfl(y1, c);
-        k1 = __shfl(y1, c + 16);
-      }
-      const float n0 = bits_to_normal(y0), n1 = bits_to_normal(y1);
+      if (b0 == 0) rows01(y1, k0, k1);
+      uint32_t r0[4], r1[4];
+      rows0123(__float_as_uint(bits_to_normal(y0)), r0);
+      rows0123(__float_as_uint(bits_to_normal(y1)), r1);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int jj = b0 + q - 2;
         if (jj >= 0 && jj < Hh) {
-          nz[jj] = __shfl(n0, c + 16 * q);
-          nz[Hh + jj] = __shfl(n1, c + 16 * q);
+          nz[jj] = __uint_as_float(r0[q]);
+          nz[Hh + jj] = __uint_as_float(r1[q]);
         }
       }
     }
@@ -778,6 +771,37 @@ int cmcd_bound_forward(const cmcd_desc* desc, const cmcd_layout* lay, const int3
   }
   hipLaunchKernelGGL(pack_weights_kernel, dim3((w.HP * w.HP + 255) / 256), dim3(256), 0, stream, pk);
 
+  TrajArgs ta{seeds, params, ws, reinterpret_cast<double*>(ws + w.partials), out_loss, out_z, *lay, w, n,
+              (int32_t)K, d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0, d.grad_clipping};
+#ifdef CMCD_STAMPS
+  if (const char* e = getenv("CMCD_ABLATE")) ta.var_mode |= atoi(e) << 8;
+#endif
+  // Kernel variant (desc.reserved: 0 auto, 1 wave-per-tile, 2 CU-cooperative).  Auto: the
+  // cooperative kernel while the batch cannot fill the chip with one wave per tile.
+  const bool coop_ok = coop_available(d, w.T);
+  bool use_coop = d.reserved == 2 ? coop_ok : (d.reserved == 1 ? false : (coop_ok && w.n_waves <= coop_max_tiles(d, w.T)));
+  if (d.reserved == 2 && !coop_ok) return fail(CMCD_ERR_UNSUPPORTED, "no cooperative kernel instance%s");
+  if (use_coop) {
+    const bool prof = g_prof.on && g_prof.used < ProfileState::kMax;
+    if (prof) {
+      if (g_prof.used >= g_prof.created) {
+        CMCD_HIP_CHECK(hipEventCreate(&g_prof.ev[g_prof.created][0]));
+        CMCD_HIP_CHECK(hipEventCreate(&g_prof.ev[g_prof.created][1]));
+        ++g_prof.created;
+      }
+      CMCD_HIP_CHECK(hipEventRecord(g_prof.ev[g_prof.used][0], stream));
+    }
+    rc = coop_launch(d, ta, stream);
+    if (rc != CMCD_OK) return fail(rc, "cooperative launch failed%s");
+    if (prof) {
+      CMCD_HIP_CHECK(hipEventRecord(g_prof.ev[g_prof.used][1], stream));
+      ++g_prof.used;
+    }
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, stream,
+                       reinterpret_cast<const double*>(ws + w.partials), w.n_waves, out_stats);
+    CMCD_HIP_CHECK(hipGetLastError());
+    return CMCD_OK;
+  }
   traj_fn fn = pick_kernel(d, w.T);
   // waves per workgroup: one wave per CU until every CU has one, then grow (weights are
   // staged once per workgroup, so bigger groups amortise the LDS fill).
@@ -790,8 +814,6 @@ int cmcd_bound_forward(const cmcd_desc* desc, const cmcd_layout* lay, const int3
   while (nw < 8 && (tiles + nw - 1) / nw > 256 * per_cu) nw *= 2;
   CMCD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  TrajArgs ta{seeds, params, ws, reinterpret_cast<double*>(ws + w.partials), out_loss, out_z, *lay, w, n,
-              (int32_t)K, d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0, d.grad_clipping};
   const unsigned blocks = unsigned((tiles + nw - 1) / nw);
   const bool prof = g_prof.on && g_prof.used < ProfileState::kMax;
   if (prof) {

@@ -156,6 +156,10 @@ def initialize(
 # --------------------------------------------------------------------------- the HIP call
 _workspaces = {}
 
+# Kernel variant handed to the library in cmcd_desc.reserved: 0 = auto (library heuristic),
+# 1 = wave-per-tile kernel, 2 = CU-cooperative kernel.  For tests / benchmarking only.
+KERNEL_VARIANT = int(__import__("os").environ.get("CMCD_KERNEL_VARIANT", "0"))
+
 
 def _workspace(device, nbytes):
     key = str(device)
@@ -216,7 +220,7 @@ def bound_forward(seeds, params_flat, unflatten, params_fixed, log_prob, eps_sch
     desc = _lib.Desc(dim=dim, nbridges=nbridges, mode=_lib.MODE[mode], arch=_lib.ARCH[spec.arch],
                      emb_dim=spec.emb_dim, target=log_prob.target_id,
                      eps_schedule=_lib.EPS_SCHEDULE[eps_schedule], grad_clipping=int(bool(grad_clipping)),
-                     ngrid=unflatten.shape("mgridref_y")[0] - 1, reserved=0)
+                     ngrid=unflatten.shape("mgridref_y")[0] - 1, reserved=KERNEL_VARIANT)
     lay = _layout(unflatten, spec)
     if log_prob.name == "lgcp":
         from .lgcp import bound_forward_lgcp

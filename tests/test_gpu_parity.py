@@ -22,8 +22,14 @@ CASES = [
 ]
 
 
+@pytest.fixture(params=[1, 2], ids=["wave_per_tile", "cooperative"])
+def variant(request, monkeypatch):
+    monkeypatch.setattr(mcdbm, "KERNEL_VARIANT", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("name,n,over", CASES)
-def test_bound_matches_oracle(hip_lib, name, n, over):
+def test_bound_matches_oracle(hip_lib, variant, name, n, over):
     b = synthetic.build(name, device="cuda", **over)
     seeds = synthetic.parity_seeds(n)
     fn = mcdbm.compute_bound_var if "var" in b["cfg"]["boundmode"] else mcdbm.compute_bound

@@ -1,0 +1,41 @@
+"""Diagnostic: where does one bridge step of coop_kernel spend its cycles?  Builds a separate
+library with -DCMCD_STAMPS (s_memtime around every phase), runs the north-star batch once and prints
+per-wave cycle shares of workgroup 0.  Read SHARES, not totals (stamps serialise the schedule)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+lib = "/tmp/libcmcd_hip_stamps.so"
+csrc = os.path.join(ROOT, "cmcd_amd", "csrc")
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                "-DCMCD_STAMPS", "-I", os.path.join(ROOT, "include"), "-I", csrc, "-Wno-format-security",
+                "-o", lib, os.path.join(csrc, "cmcd_kernels.hip"), os.path.join(csrc, "cmcd_coop.hip")], check=True)
+os.environ["CMCD_LIB_PATH"] = lib
+os.environ["CMCD_KERNEL_VARIANT"] = "2"
+import torch  # noqa: E402
+from cmcd_amd import _lib, synthetic  # noqa: E402
+from cmcd_amd import mcdboundingmachine as mcdbm  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else synthetic.NORTH_STAR
+b = synthetic.build(name, device="cuda")
+n = b["cfg"]["N"]
+seeds = torch.from_numpy(synthetic.throughput_seeds(n)).cuda()
+for _ in range(3):
+    mcdbm.bound_forward(seeds, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"],
+                        eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
+torch.cuda.synchronize()
+L = _lib.lib()
+buf = (C.c_ulonglong * 256)()
+L.cmcd_debug_read_stamps(buf)
+K = b["params_fixed"][1]
+names = ["int1 work", "wait bar1", "int2 work", "wait bar2", "phase C"]
+T = b["params_fixed"][3].width // 16 if b["params_fixed"][3].arch == "geffner" else 4
+print("cycles per bridge step, workgroup 0:")
+for wv in range(T + 4):
+    row = [buf[wv * 16 + k] / (K + 1) for k in range(5)]
+    fine = [buf[wv * 16 + k] / (K + 1) for k in range(5, 10)]
+    role = "MLP%d" % wv if wv < T else ["TGT0", "TGT1", "RNG", "ACC"][wv - T]
+    print("%5s " % role + "  ".join("%s=%7.0f" % (nm, v) for nm, v in zip(names, row)) + "  total=%7.0f" % (sum(row) + sum(fine)) + "  | fine[L1,preMFMA,MFMA,act,C-reads]=" + " ".join("%5.0f" % v for v in fine))
