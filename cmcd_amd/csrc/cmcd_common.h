@@ -46,4 +46,11 @@ struct TrajArgs {
 bool coop_available(const cmcd_desc& d, int T);
 int coop_launch(const cmcd_desc& d, const TrajArgs& ta, void* stream);
 
+
+// cmcd_lgcp.hip: the d = 1600 path (per-bridge launch sequence)
+int64_t lgcp_workspace_floats(const cmcd_desc& d, int64_t n, int64_t base);
+int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, const int32_t* seeds, int64_t n,
+                 const float* params, const float* tc, float* ws, float* out_loss, float* out_z,
+                 double** partials_out, void* stream);
+
 }  // namespace cmcd

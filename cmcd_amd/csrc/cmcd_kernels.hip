@@ -75,6 +75,21 @@ static int64_t target_lds_floats(const cmcd_desc& d, int64_t n_target) {
   return 0;
 }
 
+// lgcp: only the schedule tables live in the common layout; the rest is carved by cmcd_lgcp.hip
+static bool make_ws_lgcp(const cmcd_desc& d, int64_t n, WsLayout& w) {
+  const int64_t K = d.nbridges;
+  memset(&w, 0, sizeof(w));
+  int64_t o = 0;
+  w.beta = o; o += align4(K);
+  w.eps = o; o += align4(K);
+  w.sig = o; o += align4(K);
+  w.logsig = o; o += align4(K);
+  w.sched = o; o += 8 * K;
+  w.n_waves = (int32_t)n;  // one statistics record per particle
+  w.total_floats = o;
+  return true;
+}
+
 static bool make_ws(const cmcd_desc& d, int64_t n, int64_t n_target, WsLayout& w) {
   int HP;
   if (!hidden_width(d, HP)) return false;
@@ -667,6 +682,11 @@ static int check_desc(const cmcd_desc* d) {
     return fail(CMCD_ERR_BAD_ARG, "linear eps schedule needs nbridges >= 2%s");
   int HP;
   if (!hidden_width(*d, HP)) return fail(CMCD_ERR_BAD_ARG, "bad emb_dim%s");
+  if (d->target == CMCD_TARGET_LGCP) {
+    if (d->arch != CMCD_ARCH_GEFFNER || d->dim < 4 || d->dim > 4096)
+      return fail(CMCD_ERR_UNSUPPORTED, "lgcp runs with the geffner net only%s");
+    return CMCD_OK;
+  }
   if (!pick_kernel(*d, HP / 16))
     return fail(CMCD_ERR_UNSUPPORTED, "no kernel instance for this (target, dim, arch, width=%s%lld)", "", HP);
   return CMCD_OK;
@@ -695,6 +715,10 @@ int64_t cmcd_target_floats(const cmcd_desc* desc, int32_t n_mixes) {
 int64_t cmcd_workspace_bytes(const cmcd_desc* desc, int64_t n) {
   if (check_desc(desc) != CMCD_OK || n < 1) return 0;
   WsLayout w;
+  if (desc->target == CMCD_TARGET_LGCP) {
+    make_ws_lgcp(*desc, n, w);
+    return lgcp_workspace_floats(*desc, n, w.total_floats) * 4;
+  }
   // size for the largest target-constant block this target can stage (64 mixtures)
   const int64_t nt = desc->target == CMCD_TARGET_MANY_GMM ? 1 + 2 * 64 : 0;
   if (!make_ws(*desc, n, nt, w)) return 0;
@@ -740,7 +764,23 @@ int cmcd_bound_forward(const cmcd_desc* desc, const cmcd_layout* lay, const int3
       return fail(CMCD_ERR_BAD_ARG, "many_gmm needs target_consts = {scale, means[n_mixes<=64][2]}%s");
     n_mix = int((n_target - 1) / 2);
   } else if (d.target == CMCD_TARGET_LGCP) {
-    return fail(CMCD_ERR_UNSUPPORTED, "lgcp goes through cmcd_bound_forward_lgcp%s");
+    if (!target_consts || n_target != D * D + D + 3)
+      return fail(CMCD_ERR_BAD_ARG, "lgcp needs target_consts = {Kinv[d,d], counts[d], mu0, a, lognorm}%s");
+    WsLayout lw;
+    make_ws_lgcp(d, n, lw);
+    const int64_t need = lgcp_workspace_floats(d, n, lw.total_floats) * 4;
+    if (workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15))
+      return fail(CMCD_ERR_WORKSPACE, "workspace too small or not 16-byte aligned (need %s%lld bytes)", "", need);
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    float* wsf = static_cast<float*>(workspace);
+    SchedArgs sa{params, wsf, *lay, lw, (int32_t)K, d.ngrid, d.eps_schedule, -1, -1};
+    hipLaunchKernelGGL(prep_sched_kernel, dim3(1), dim3(256), 0, st, sa);
+    double* partials = nullptr;
+    rc = lgcp_forward(d, *lay, lw, seeds, n, params, target_consts, wsf, out_loss, out_z, &partials, stream_);
+    if (rc != CMCD_OK) return fail(rc, "lgcp launch sequence failed%s");
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, partials, (int32_t)n, out_stats);
+    CMCD_HIP_CHECK(hipGetLastError());
+    return CMCD_OK;
   }
 
   WsLayout w;

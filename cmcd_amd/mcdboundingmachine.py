@@ -222,9 +222,6 @@ def bound_forward(seeds, params_flat, unflatten, params_fixed, log_prob, eps_sch
                      eps_schedule=_lib.EPS_SCHEDULE[eps_schedule], grad_clipping=int(bool(grad_clipping)),
                      ngrid=unflatten.shape("mgridref_y")[0] - 1, reserved=KERNEL_VARIANT)
     lay = _layout(unflatten, spec)
-    if log_prob.name == "lgcp":
-        from .lgcp import bound_forward_lgcp
-        return bound_forward_lgcp(L, desc, lay, seeds, params_flat, log_prob)
     nbytes = L.cmcd_workspace_bytes(C.byref(desc), n)
     if nbytes <= 0:
         _lib.check(-2 if "not implemented" in _lib.last_error() or "no kernel" in _lib.last_error() else -1)

@@ -49,3 +49,20 @@ def test_bound_matches_oracle(hip_lib, variant, name, n, over):
         assert abs(float(val) - want) <= 1e-5 * max(1.0, abs(want))
     else:
         assert not np.isfinite(float(val))
+
+
+@pytest.mark.parametrize("n,k", [(20, 8), (5, 3), (30, 2)])
+def test_lgcp_matches_oracle(hip_lib, n, k):
+    """d = 1600 (config 5): per-bridge GEMM path.  30 particles = two passes of the 24-row GEMM."""
+    import os
+    counts = np.load(os.path.join(os.path.dirname(__file__), "golden", "lgcp_bin_counts.npy"))
+    b = synthetic.build("lgcp_n20_k128", device="cuda", lgcp_counts=counts, nbridges=k)
+    seeds = synthetic.parity_seeds(n)
+    val, (losses, z) = mcdbm.compute_bound(torch.from_numpy(seeds).cuda(), b["params_flat"], b["unflatten"],
+                                           b["params_fixed"], b["target"], eps_schedule=b["eps_schedule"],
+                                           grad_clipping=b["grad_clipping"])
+    torch.cuda.synchronize()
+    l_ref, z_ref = run_oracle(b, seeds, dtype=np.float64, lgcp_counts=counts)
+    rep = compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"lgcp n={n} k={k}")
+    print("lgcp", n, k, rep, "mean loss", float(val), l_ref.mean())
+    assert abs(float(val) - losses.double().mean().item()) <= 1e-5 * abs(l_ref.mean())
