@@ -98,10 +98,11 @@ def main():
         raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback for the hot path)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ   # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from cmcd_amd import _lib, build, synthetic
     from cmcd_amd import mcdboundingmachine as mcdbm
@@ -121,14 +122,18 @@ def main():
         return mcdbm.bound_forward(s, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"],
                                    eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
 
+    # Multi-GPU: one RCCL all-gather of the 40-byte statistics vector + one merge kernel per step.
+    gathered = torch.zeros(world * parallel.NSTATS, dtype=torch.float64, device=device)
+
     def step():
         losses, z, stats = forward(seeds)
-        if world > 1:
-            stats = parallel.merge_stats(parallel.all_gather_stats(stats))
+        if use_dist:
+            dist.all_gather_into_tensor(gathered, stats)
+            stats = parallel.merge_stats(gathered.view(world, parallel.NSTATS))
         return losses, z, stats
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -143,7 +148,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms, launches = _lib.profile_collect()
     _lib.profile_enable(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -197,7 +202,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

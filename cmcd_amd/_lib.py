@@ -54,6 +54,8 @@ def lib():
         L.cmcd_stats_merge.restype = C.c_int
         L.cmcd_stats_merge.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32,
                                        C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.cmcd_stats_merge_device.restype = C.c_int
+        L.cmcd_stats_merge_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.cmcd_profile_enable.restype = C.c_int
         L.cmcd_profile_enable.argtypes = [C.c_int]
         L.cmcd_profile_collect.restype = C.c_int

@@ -875,6 +875,13 @@ int cmcd_bound_forward(const cmcd_desc* desc, const cmcd_layout* lay, const int3
   return CMCD_OK;
 }
 
+int cmcd_stats_merge_device(const double* rows, int32_t count, double* out5, void* stream_) {
+  if (!rows || !out5 || count < 1) return fail(CMCD_ERR_BAD_ARG, "null pointer argument%s");
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream_), rows, count, out5);
+  CMCD_HIP_CHECK(hipGetLastError());
+  return CMCD_OK;
+}
+
 int cmcd_profile_enable(int on) {
   g_prof.on = on != 0;
   g_prof.used = 0;

@@ -28,8 +28,18 @@ def empty_stats(device=None):
 
 
 def merge_stats(stats_rows):
-    """Fixed-order merge of [R, 5] statistics rows (device-agnostic torch ops, no host sync)."""
+    """Fixed-order merge of [R, 5] statistics rows, no host sync.  On a ROCm device this is ONE launch
+    of the library's merge kernel (cmcd_stats_merge_device); on CPU tensors (gloo tests) the same
+    arithmetic in torch ops."""
     s = stats_rows
+    if s.is_cuda:
+        from . import _lib
+        s = s.contiguous()
+        out = torch.empty(NSTATS, dtype=torch.float64, device=s.device)
+        with torch.cuda.device(s.device):
+            _lib.check(_lib.lib().cmcd_stats_merge_device(s.data_ptr(), s.shape[0], out.data_ptr(),
+                                                           torch.cuda.current_stream().cuda_stream))
+        return out
     m = torch.max(s[:, 3])
     scale = torch.where(torch.isfinite(s[:, 3]) & torch.isfinite(m), torch.exp(s[:, 3] - m),
                         (s[:, 3] == m).to(s.dtype))

@@ -130,6 +130,11 @@ int cmcd_bound_forward(const cmcd_desc* desc, const cmcd_layout* layout,
 int cmcd_profile_enable(int on);
 int cmcd_profile_collect(double* total_ms, int64_t* launches);
 
+/* Device-side merge of `count` statistics vectors rows[count][5] (e.g. the result of an RCCL
+ * all-gather of every rank's out_stats, in rank order) into out5[5], fixed order, one small kernel
+ * on `stream`.  [device] pointers. */
+int cmcd_stats_merge_device(const double* rows, int32_t count, double* out5, void* stream);
+
 /* Host-side, no GPU: merge `count` stats vectors (e.g. one per rank, after an all-gather) in
  * the given fixed order, then produce mean, var(ddof=0), lnZ = logsumexp(-l) - log n_total.
  * n_per[i] = number of particles behind stats[i].  out3 = {mean, var, lnZ}. */

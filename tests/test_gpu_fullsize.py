@@ -1,0 +1,135 @@
+"""BASELINE.json's full sizes: size-independent properties of the HIP path (the oracle is too slow
+to re-run some of these in seconds, so they rest on determinism, batch-composition invariance,
+statistics consistency and the float32 oracle where it is affordable)."""
+import math
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+
+from cmcd_amd import mcdboundingmachine as mcdbm
+from cmcd_amd import parallel, synthetic, utils
+from oracle import cmcd_oracle as orc
+
+from helpers import compare_losses, run_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _fwd(b, seeds):
+    s = torch.as_tensor(seeds).cuda()
+    out = mcdbm.bound_forward(s, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"],
+                              eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
+    torch.cuda.synchronize()
+    return out
+
+
+def test_north_star_full_batch_against_oracle(hip_lib):
+    """config 3 at its named size (N = 2000, K = 256) vs the float32 reference-faithful oracle (~6 s)."""
+    b = synthetic.build("many_gmm_n2000_k256_dds", device="cuda")
+    seeds = synthetic.throughput_seeds(2000)
+    losses, z, stats = _fwd(b, seeds)
+    l_ref, z_ref = run_oracle(b, seeds, dtype=np.float32, reuse=False)
+    rep = compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag="config 3 full")
+    assert rep["n_inf"] > 0                                     # init_sigma = 60 leaves particles beyond the floor
+    lh = losses.double().cpu().numpy()
+    assert abs(orc.ln_z(lh) - orc.ln_z(l_ref)) < 0.05           # BASELINE.json's ln Z bar
+    np.testing.assert_allclose(stats.cpu().numpy()[[0, 3]], orc.stats5(lh)[[0, 3]], rtol=1e-12)
+    assert abs(float(mcdbm.ln_z_from_stats(stats, 2000)) - orc.ln_z(lh)) < 1e-9
+
+
+@pytest.mark.parametrize("name,n", [("many_gmm_n2000_k256_dds", 2000), ("many_gmm_var_n16000_k256", 16000),
+                                    ("funnel_n300_k64", 300), ("gmm_n300_k8", 300)])
+def test_determinism_and_batch_composition_invariance(hip_lib, monkeypatch, name, n):
+    """Same seeds -> bitwise identical losses; a particle's loss does not depend on which batch
+    (or which kernel variant's tile) it was launched in."""
+    b = synthetic.build(name, device="cuda")
+    seeds = synthetic.throughput_seeds(n, stream=5)
+    perm = np.random.default_rng(0).permutation(n)
+    for v in (1, 2):   # bitwise claims hold per kernel variant (auto-selection depends on batch size)
+        monkeypatch.setattr(mcdbm, "KERNEL_VARIANT", v)
+        l1, z1, s1 = _fwd(b, seeds)
+        l2, z2, s2 = _fwd(b, seeds)
+        assert torch.equal(l1, l2) and torch.equal(z1, z2) and torch.equal(s1.nan_to_num(1.0), s2.nan_to_num(1.0))
+        lp, zp, _ = _fwd(b, seeds[perm])
+        assert torch.equal(lp.cpu(), l1.cpu()[perm]) and torch.equal(zp.cpu(), z1.cpu()[perm])
+        ls, _, _ = _fwd(b, seeds[37:37 + 101])
+        assert torch.equal(ls.cpu(), l1.cpu()[37:37 + 101])
+    # both kernel variants compute the same arithmetic per particle up to reduction order
+    outs = []
+    for v in (1, 2):
+        monkeypatch.setattr(mcdbm, "KERNEL_VARIANT", v)
+        outs.append(_fwd(b, seeds[:512])[0].double().cpu().numpy())
+    f = np.isfinite(outs[0])
+    assert np.array_equal(f, np.isfinite(outs[1]))
+    rel = np.abs(outs[0][f] - outs[1][f]) / np.maximum(1, np.abs(outs[0][f]))
+    assert np.quantile(rel, 0.99) < 5e-3
+
+
+def test_vargrad_config_full_batch_statistics(hip_lib):
+    """config 4 (N = 16000, K = 256, 132-wide net): the returned scalar is var(ddof=0) of the returned
+    per-particle losses, statistics agree with torch reductions, and a 64-particle slice agrees with
+    the float64 oracle."""
+    b = synthetic.build("many_gmm_var_n16000_k256", device="cuda")
+    seeds = synthetic.throughput_seeds(16000)
+    val, (losses, z) = mcdbm.compute_bound_var(torch.from_numpy(seeds).cuda(), b["params_flat"], b["unflatten"],
+                                               b["params_fixed"], b["target"], eps_schedule=b["eps_schedule"],
+                                               grad_clipping=b["grad_clipping"])
+    torch.cuda.synchronize()
+    lh = losses.double()
+    assert torch.isfinite(lh).all()
+    want = min(1e7, float(lh.var(unbiased=False)))
+    assert abs(float(val) - want) <= 1e-6 * want
+    l_ref, z_ref = run_oracle(b, seeds[:64], dtype=np.float64)
+    compare_losses(losses[:64].cpu().numpy(), l_ref, z[:64].cpu().numpy(), z_ref, tag="config 4 slice")
+
+
+def test_sharded_statistics_equal_single_launch(hip_lib):
+    """Running the batch as 8 contiguous shards and merging the 5-number statistics (what 8 ranks do)
+    gives the single-launch mean / ln Z."""
+    b = synthetic.build("many_gmm_n2000_k256_dds", device="cuda", init_sigma=15.0)
+    seeds = synthetic.throughput_seeds(2000, stream=2)
+    l_all, _, s_all = _fwd(b, seeds)
+    rows = []
+    for r in range(8):
+        lo, hi = parallel.shard_range(2000, 8, r)
+        rows.append(_fwd(b, seeds[lo:hi])[2])
+    merged = parallel.merge_stats(torch.stack(rows))                 # device merge kernel
+    merged_cpu = parallel.merge_stats(torch.stack(rows).cpu())       # torch-op merge (gloo path)
+    np.testing.assert_allclose(merged.cpu().numpy(), merged_cpu.numpy(), rtol=1e-13)
+    fa, fb = parallel.finalize(merged, 2000), parallel.finalize(s_all, 2000)
+    for k in ("mean", "ln_z", "n_finite"):
+        assert abs(float(fa[k]) - float(fb[k])) <= 1e-9 * max(1.0, abs(float(fb[k])))
+
+
+def test_eval_harness_and_final_metrics(hip_lib):
+    """opt.sample + utils.log_final_losses (the numbers the paper reports) on 30 x 500 seeds."""
+    b = synthetic.build("gmm_n300_k8", device="cuda", init_sigma=2.0)
+    loss_fn = partial(mcdbm.compute_bound, eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
+    seeds = torch.from_numpy(synthetic.throughput_seeds(30 * 500, stream=11)).cuda()
+    elbos, zs = utils.sample(None, 500, 30, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"],
+                             loss_fn, seeds)
+    assert elbos.shape == (30, 500) and zs.shape == (15000, 2)
+    elbo, ln_z = utils.log_final_losses(elbos.cpu())
+    e = elbos.double().cpu().numpy()
+    assert abs(elbo - (-e.mean(1)).mean()) < 1e-9
+    assert abs(ln_z - np.mean([orc.ln_z(r) for r in e])) < 1e-9
+    assert abs(ln_z) < 0.2 and elbo < ln_z + 0.05               # normalised target: ln Z ~ 0 >= ELBO
+
+
+def test_error_paths_on_device(hip_lib):
+    b = synthetic.build("gmm_n300_k8", device="cuda")
+    dim, K, _, spec = b["params_fixed"]
+    seeds = torch.arange(1, 17, dtype=torch.int32).cuda()
+    with pytest.raises(NotImplementedError, match="Mode not implemented."):
+        mcdbm.compute_bound(seeds, b["params_flat"], b["unflatten"], (dim, K, "MCD_U_a-lp-sn", spec), b["target"])
+    with pytest.raises(ValueError):
+        mcdbm.compute_bound(seeds[:0], b["params_flat"], b["unflatten"], b["params_fixed"], b["target"])
+    from cmcd_amd.model_handler import load_model
+    with pytest.raises(ValueError):   # funnel target (d = 10) against a d = 2 parameter set
+        mcdbm.compute_bound(seeds, b["params_flat"], b["unflatten"], b["params_fixed"], load_model("funnel")[0])
+    int64_seeds = torch.arange(1, 17).cuda()                    # accepted, converted to int32
+    a = mcdbm.compute_bound(int64_seeds, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"])[1][0]
+    c = mcdbm.compute_bound(seeds, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"])[1][0]
+    assert torch.equal(a, c)
