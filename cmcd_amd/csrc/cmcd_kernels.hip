@@ -45,9 +45,9 @@ static thread_local ProfileState g_prof;
 
 // Tiles (16 particles each) up to which the CU-cooperative kernel is preferred; measured crossovers on
 // MI355X (tools/probes/variant_sweep.py): dds/geffner T<=4 between 512 and 1024 tiles, the 132-wide
-// net between 256 and 1000; the d=10 wave-per-tile instance still spills, so funnel stays cooperative.
+// net between 256 and 1000.
 static int coop_max_tiles(const cmcd_desc& d, int T) {
-  if (d.dim >= 8) return 8192;
+  (void)d;
   return T >= 8 ? 256 : 512;
 }
 static int fail(int code, const char* fmt, const char* a = "", long long b = 0) {
@@ -322,6 +322,7 @@ __device__ __forceinline__ void eval_net(const float (&z)[D], const float* __res
                                          const float* lds_b3, int lane, float (&s)[D]) {
   constexpr int HP = 16 * T;
   const int g = lane >> 4;
+  asm volatile("" ::: "memory");  // keep the LDS-resident weights streaming (no LICM into VGPRs)
   f32x4 h[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) {
@@ -357,7 +358,7 @@ __device__ __forceinline__ void eval_net(const float (&z)[D], const float* __res
   for (int ti = 0; ti < T; ++ti) {
     // wide nets: keep the A fragments streaming from LDS (a compiler-level fence stops LICM from
     // hoisting T*T*4 loop-invariant registers out of the bridge loop and spilling them)
-    if (T > 4) asm volatile("" ::: "memory");
+    asm volatile("" ::: "memory");
     f32x4 a[T];
 #pragma unroll
     for (int to = 0; to < T; ++to)
@@ -394,7 +395,7 @@ __device__ __forceinline__ void eval_net(const float (&z)[D], const float* __res
 }
 
 template <int TARGET, int ARCH, int D, int T>
-__global__ __launch_bounds__(512) void traj_kernel(TrajArgs a) {
+__global__ __launch_bounds__(512, (T > 4 || D > 4) ? 2 : 4) void traj_kernel(TrajArgs a) {
   constexpr int HP = 16 * T;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* lds_w2 = lds;                    // HP*HP
@@ -848,10 +849,13 @@ int cmcd_bound_forward(const cmcd_desc* desc, const cmcd_layout* lay, const int3
   const int64_t tiles = w.n_waves;
   const size_t lds_bytes = size_t(w.HP * w.HP + 2 * D * w.HP + w.HP + 16 + w.tgt_floats) * 4;
   if (lds_bytes > 160 * 1024) return fail(CMCD_ERR_UNSUPPORTED, "network too wide for LDS%s");
+  // Waves per workgroup.  Up to 1024 tiles: one wave per workgroup spreads over all SIMDs.  Beyond
+  // that single-wave workgroups pile onto the same SIMD of a CU (measured: 2048 x 1 wave ran 2.4x
+  // longer than 1024 x 1), so use 4-wave workgroups (one wave per SIMD), 8 for very large batches
+  // or when LDS limits the CU to one resident workgroup.
   int64_t per_cu = (160 * 1024) / (int64_t)lds_bytes;
-  if (per_cu > 8) per_cu = 8;
-  int nw = 1;
-  while (nw < 8 && (tiles + nw - 1) / nw > 256 * per_cu) nw *= 2;
+  int nw = tiles <= 1024 ? 1 : (tiles <= 8192 ? 4 : 8);
+  if (per_cu < 2 && tiles > 256) nw = tiles <= 1024 ? 4 : 8;
   CMCD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   const unsigned blocks = unsigned((tiles + nw - 1) / nw);
