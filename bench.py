@@ -160,6 +160,17 @@ def main():
     achieved = n * K * f_alg / kern_s / 1e12
     fin = parallel.finalize(stats, n * world)
 
+    # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc
+    # passes of this same command; profiles/r01_pmc/summary.json) — a measured constant of the kernel,
+    # bench.py cannot collect counters on itself.
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc", "summary.json")))
+        if name == synthetic.NORTH_STAR and n == 2000:
+            traffic = pmc["coop_kernel"]["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+
     result = {
         "metric": "bridge-steps*particles/sec", "value": value, "unit": "bridge-steps*particles/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -169,7 +180,7 @@ def main():
                    "particles_per_gpu": n, "nbridges": K, "nn_arch": cfg["nn_arch"], "dim": dim,
                    "global_particles": n * world, "parallelism": f"particles sharded x{world}, stats all-gather"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                     "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch (PMC)",
                      "kernel": "traj_kernel", "kernel_ms": kern_s * 1e3, "launches": launches,
                      "flop_per_particle_step": f_alg, "flop_per_particle_step_survey": f_survey,
                      "achieved_survey_flops": n * K * f_survey / kern_s / 1e12,

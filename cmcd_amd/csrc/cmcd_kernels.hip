@@ -130,18 +130,19 @@ struct SchedArgs {
   int64_t gridref_x, target_x;  // offsets in params, or -1: use linspace
 };
 
-__global__ void prep_sched_kernel(SchedArgs a) {
-  __shared__ float gy[40], gx[40];
+__device__ __forceinline__ void prep_sched_body(const SchedArgs& a) {
+  __shared__ float gy[40], gx[40], gm[40];
   const int G = a.ngrid;  // mgridref_y has G+1 entries
+  if (threadIdx.x <= G) gm[threadIdx.x] = a.params[a.lay.mgridref_y + threadIdx.x];
+  __syncthreads();
   if (threadIdx.x == 0) {
     // gridref_y = concat([0], cumsum(m)/sum(m))       mcdboundingmachine.py:147-148
-    const float* m = a.params + a.lay.mgridref_y;
     float tot = 0.f;
-    for (int i = 0; i <= G; ++i) tot += m[i];
+    for (int i = 0; i <= G; ++i) tot += gm[i];
     float run = 0.f;
     gy[0] = 0.f;
     for (int i = 0; i <= G; ++i) {
-      run += m[i];
+      run += gm[i];
       gy[i + 1] = run / tot;
     }
     for (int i = 0; i < G + 2; ++i) gx[i] = (float)i / (float)(G + 1);  // linspace(0,1,G+2)  :113
@@ -180,6 +181,8 @@ __global__ void prep_sched_kernel(SchedArgs a) {
   }
 }
 
+__global__ void prep_sched_kernel(SchedArgs a) { prep_sched_body(a); }
+
 // ------------------------------------------------------------------------------------------
 // 2a. dds: time path -> per-bridge first-layer bias.  One 64-thread block per bridge index t.
 //     tau(t) = W_b gelu(W_a [sin(c t + phi), cos(c t + phi)] + b_a) + b_b   nn_dds.py:131-143,155-158
@@ -193,11 +196,13 @@ struct DdsPrepArgs {
   int32_t D;
 };
 
-__global__ __launch_bounds__(64) void prep_dds_kernel(DdsPrepArgs a) {
+// `t` = bridge index; threads j >= 64 only take part in the barriers
+__device__ __forceinline__ void prep_dds_body(const DdsPrepArgs& a, int t) {
   __shared__ float e[128], h[64], tau[64];
-  const int j = threadIdx.x, t = blockIdx.x;
+  const int j = threadIdx.x;
+  const bool on = j < 64;
   const float* P = a.params;
-  {
+  if (on) {
     // timestep_coeff = linspace(0.1, 100, 64) (float32)   nn_dds.py:108
     const double step = (100.0 - 0.1) / 63.0;
     const float cj = (j == 63) ? 100.0f : (float)((double)j * step + 0.1);
@@ -206,17 +211,24 @@ __global__ __launch_bounds__(64) void prep_dds_kernel(DdsPrepArgs a) {
     e[64 + j] = cosf(arg);
   }
   __syncthreads();
-  float acc = P[a.lay.d_tb1 + j];
-  for (int k = 0; k < 128; ++k) acc = fmaf(e[k], P[a.lay.d_tw1 + k * 64 + j], acc);
-  h[j] = gelu_exact(acc);
+  float acc = 0.f;
+  if (on) {
+    acc = P[a.lay.d_tb1 + j];
+    for (int k = 0; k < 128; ++k) acc = fmaf(e[k], P[a.lay.d_tw1 + k * 64 + j], acc);
+    h[j] = gelu_exact(acc);
+  }
   __syncthreads();
-  acc = P[a.lay.d_tb2 + j];
-  for (int k = 0; k < 64; ++k) acc = fmaf(h[k], P[a.lay.d_tw2 + k * 64 + j], acc);
-  tau[j] = acc;
+  if (on) {
+    acc = P[a.lay.d_tb2 + j];
+    for (int k = 0; k < 64; ++k) acc = fmaf(h[k], P[a.lay.d_tw2 + k * 64 + j], acc);
+    tau[j] = acc;
+  }
   __syncthreads();
-  acc = P[a.lay.d_sb1 + j];
-  for (int k = 0; k < 64; ++k) acc = fmaf(tau[k], P[a.lay.d_sw1 + (a.D + k) * 64 + j], acc);
-  a.ws[a.w.bias1 + (int64_t)t * 64 + j] = acc;
+  if (on) {
+    acc = P[a.lay.d_sb1 + j];
+    for (int k = 0; k < 64; ++k) acc = fmaf(tau[k], P[a.lay.d_sw1 + (a.D + k) * 64 + j], acc);
+    a.ws[a.w.bias1 + (int64_t)t * 64 + j] = acc;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -231,20 +243,21 @@ struct GefPrepArgs {
   int32_t D, E, K;
 };
 
-__global__ void prep_geffner_kernel(GefPrepArgs a) {
-  const int n = threadIdx.x, row = blockIdx.x;
+__device__ __forceinline__ void prep_geffner_body(const GefPrepArgs& a, int row) {
   const int ie = row < a.K ? row : a.K - 1;
   const int in = a.D + a.E;
   const float* P = a.params;
   const float* emb = P + a.lay.g_emb + (int64_t)ie * a.E;
-  float b = 0.f, u = 0.f;
-  if (n < in) {
-    b = P[a.lay.g_b1 + n];
-    for (int j = 0; j < a.E; ++j) b = fmaf(emb[j], P[a.lay.g_w1 + (int64_t)(a.D + j) * in + n], b);
-    u = n >= a.D ? emb[n - a.D] : 0.f;
+  for (int n = threadIdx.x; n < a.w.HP; n += blockDim.x) {
+    float b = 0.f, u = 0.f;
+    if (n < in) {
+      b = P[a.lay.g_b1 + n];
+      for (int j = 0; j < a.E; ++j) b = fmaf(emb[j], P[a.lay.g_w1 + (int64_t)(a.D + j) * in + n], b);
+      u = n >= a.D ? emb[n - a.D] : 0.f;
+    }
+    a.ws[a.w.bias1 + (int64_t)row * a.w.HP + n] = b;
+    a.ws[a.w.utab + (int64_t)row * a.w.HP + n] = u;
   }
-  a.ws[a.w.bias1 + (int64_t)row * a.w.HP + n] = b;
-  a.ws[a.w.utab + (int64_t)row * a.w.HP + n] = u;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -262,11 +275,11 @@ struct PackArgs {
   int32_t target, n_mix;
 };
 
-__global__ void pack_weights_kernel(PackArgs a) {
+__device__ __forceinline__ void pack_weights_body(const PackArgs& a, int vblock, int nblocks) {
   const int HP = a.w.HP, T = a.w.T;
   const float* P = a.params;
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t tid = (int64_t)vblock * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)nblocks * blockDim.x;
   for (int64_t idx = tid; idx < (int64_t)HP * HP; idx += stride) {
     const int r = idx & 3, lane = (idx >> 2) & 63;
     const int tt = int(idx >> 8), t_out = tt % T, t_in = tt / T;
@@ -299,6 +312,28 @@ __global__ void pack_weights_kernel(PackArgs a) {
       else if (idx >= 4 && idx < 4 + 2 * a.n_mix) v = a.tgt[1 + (idx - 4)];
       a.ws[a.w.tgt + idx] = v;
     }
+  }
+}
+
+// One launch for all per-call preparation: blocks [0, K] build the per-bridge bias rows, block K+1 the
+// schedule tables, the remaining blocks pack the weights (three dependent-free jobs, one boundary).
+struct PrepArgs {
+  SchedArgs sched;
+  DdsPrepArgs dds;
+  GefPrepArgs gef;
+  PackArgs pack;
+  int32_t K, arch, npack;
+};
+
+__global__ __launch_bounds__(256) void prep_fused_kernel(PrepArgs a) {
+  const int b = blockIdx.x;
+  if (b <= a.K) {
+    if (a.arch == CMCD_ARCH_DDS) prep_dds_body(a.dds, b);
+    else prep_geffner_body(a.gef, b);
+  } else if (b == a.K + 1) {
+    prep_sched_body(a.sched);
+  } else {
+    pack_weights_body(a.pack, b - a.K - 2, a.npack);
   }
 }
 
@@ -792,25 +827,25 @@ int cmcd_bound_forward(const cmcd_desc* desc, const cmcd_layout* lay, const int3
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   float* ws = static_cast<float*>(workspace);
 
-  {
-    SchedArgs a{params, ws, *lay, w, (int32_t)K, d.ngrid, d.eps_schedule, -1, -1};
-    hipLaunchKernelGGL(prep_sched_kernel, dim3(1), dim3(256), 0, stream, a);
-  }
-  PackArgs pk{};
+  PrepArgs pa{};
+  pa.sched = SchedArgs{params, ws, *lay, w, (int32_t)K, d.ngrid, d.eps_schedule, -1, -1};
+  PackArgs& pk = pa.pack;
   pk.params = params; pk.tgt = target_consts; pk.ws = ws; pk.w = w;
   pk.D = (int32_t)D; pk.target = d.target; pk.n_mix = n_mix;
   if (d.arch == CMCD_ARCH_DDS) {
-    DdsPrepArgs a{params, ws, *lay, w, (int32_t)D};
-    hipLaunchKernelGGL(prep_dds_kernel, dim3((unsigned)K + 1), dim3(64), 0, stream, a);
+    pa.dds = DdsPrepArgs{params, ws, *lay, w, (int32_t)D};
     pk.o_w1 = lay->d_sw1; pk.o_w2 = lay->d_sw2; pk.o_b2 = lay->d_sb2; pk.o_w3 = lay->d_sw3;
     pk.o_b3 = lay->d_sb3; pk.o_factor = -1; pk.IN = 64;
   } else {
-    GefPrepArgs a{params, ws, *lay, w, (int32_t)D, (int32_t)E, (int32_t)K};
-    hipLaunchKernelGGL(prep_geffner_kernel, dim3((unsigned)K + 1), dim3(w.HP), 0, stream, a);
+    pa.gef = GefPrepArgs{params, ws, *lay, w, (int32_t)D, (int32_t)E, (int32_t)K};
     pk.o_w1 = lay->g_w1; pk.o_w2 = lay->g_w2; pk.o_b2 = lay->g_b2; pk.o_w3 = lay->g_w3;
     pk.o_b3 = lay->g_b3; pk.o_factor = lay->g_factor; pk.IN = (int32_t)IN;
   }
-  hipLaunchKernelGGL(pack_weights_kernel, dim3((w.HP * w.HP + 255) / 256), dim3(256), 0, stream, pk);
+  pa.K = (int32_t)K; pa.arch = d.arch;
+  pa.npack = (w.HP * w.HP + 255) / 256;
+  if (pa.npack > 64) pa.npack = 64;
+  hipLaunchKernelGGL(prep_fused_kernel, dim3((unsigned)(K + 2 + pa.npack)), dim3(256), 0, stream, pa);
+
 
   TrajArgs ta{seeds, params, ws, reinterpret_cast<double*>(ws + w.partials), out_loss, out_z, *lay, w, n,
               (int32_t)K, d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0, d.grad_clipping};
