@@ -49,3 +49,22 @@ def compare_losses(l_hip, l_ref, z_hip, z_ref, tag=""):
     assert lnz_err <= 1e-3 * max(1.0, abs(orc.ln_z(l_ref))), f"{tag}: {report}"
     assert report["rel_p99"] <= 5e-3, f"{tag}: {report}"
     return report
+
+
+def run_c_oracle(built, seeds):
+    """The plain-C restatement (oracle/cmcd_oracle.c) on the same inputs; float32, reference-faithful."""
+    from cmcd_amd import _lib as hip_abi
+    from cmcd_amd import mcdboundingmachine as mcdbm
+    from oracle import c_oracle
+    cfg = built["cfg"]
+    dim, K, mode, spec = built["params_fixed"]
+    un = built["unflatten"]
+    desc = hip_abi.Desc(dim=dim, nbridges=K, mode=hip_abi.MODE[mode], arch=hip_abi.ARCH[spec.arch],
+                        emb_dim=spec.emb_dim, target=built["target"].target_id,
+                        eps_schedule=hip_abi.EPS_SCHEDULE.get(cfg["eps_schedule"], 0),
+                        grad_clipping=int(bool(cfg["grad_clipping"])), ngrid=un.shape("mgridref_y")[0] - 1,
+                        reserved=0)
+    lay = mcdbm._layout(un, spec)
+    consts = built["target"].consts_on("cpu")
+    return c_oracle.bound(desc, lay, np.asarray(seeds), built["params_flat"].detach().cpu().numpy(),
+                          None if consts is None else consts.numpy())
