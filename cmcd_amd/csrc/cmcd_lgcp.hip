@@ -3,16 +3,22 @@
 // (K^-1 10.2 MB + W1 10.4 MB + W2 10.5 MB + W3 10.4 MB) that cannot live on-chip per tile.
 //
 // Per evaluation i = 0..K (one evaluation serves the backward kernel of step i-1 and the forward
-// kernel of step i, as in traj_kernel):
-//   gemm A: [x - mu0] K^-1 -> kr          and   x W1[:d] + bias1_i -> pre1    (one launch, two segments)
-//   gemm B: u1 = u + softplus(pre1) (formed in the prologue);  u1 W2 + b2 -> pre2
-//   gemm C: u2 = u1 + softplus(pre2) (prologue);  factor_sn (u2 W3 + b3) -> sn
-//   step  : grad log p = -kr + counts - a e^x  (model_handler.py:386-396, cp_utils.py:102-104),
-//           close step i-1, draw eps_i = normal(G_i, (1600,)) (800 Threefry blocks), open step i.
+// kernel of step i, as in traj_kernel), 7 launches:
+//   act 0 : x - mu0
+//   gemm A: [x - mu0] K^-1 -> kr slabs      and   x W1[:d] -> pre1 slabs      (one launch, two segments)
+//   act 1 : pre1 = sum(slabs) + bias1_i ;  u1 = [x; emb_i] + softplus(pre1)           nn.py:45-47,68
+//   gemm B: u1 W2 -> pre2 slabs
+//   act 2 : pre2 = sum(slabs) + b2 ;       u2 = u1 + softplus(pre2)                   nn.py:48-50
+//   gemm C: u2 W3 -> sn slabs
+//   step  : sn = factor_sn (sum(slabs) + b3); grad log p = -kr + counts - a e^x
+//           (model_handler.py:386-396, cp_utils.py:102-104); close step i-1, draw
+//           eps_i = normal(G_i, (1600,)) (800 Threefry blocks), open step i.
 // The skinny GEMM ([<=24 particles] x [K] x [N]) is weight-bandwidth bound: a workgroup owns 64
-// output columns, its 16 waves split K, every lane keeps one column's partial sums for all particles
-// in registers, W rows are read once as coalesced 256-byte rows, the activation slice is staged in
-// wave-private LDS and broadcast, and the 16 partial tiles are summed through LDS (fixed order).
+// output columns of one of kSplit K-slices, its 16 waves split the slice, every lane keeps one
+// column's partial sums for all particles in registers, W rows are read once as coalesced 256-byte
+// rows, the activation slice is staged in wave-private LDS and broadcast, the 16 partial tiles are
+// summed through LDS and written as a partial slab; the consumer sums the kSplit slabs in a fixed
+// order (bitwise deterministic, no atomics).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -27,48 +33,35 @@ constexpr int kMP = 24;      // particles per pass (rows of the skinny GEMM)
 constexpr int kGemmWaves = 16;
 constexpr int kChunk = 32;   // k rows staged per round
 
-enum { PRO_X_MINUS_MU = 0, PRO_X = 1, PRO_U1 = 2, PRO_U2 = 3 };
+constexpr int kSplit = 4;    // K split across workgroups (partial slabs, summed in fixed order downstream)
 
 struct GemmSeg {
+  const float* A;      // [kMP][lda]  activations (already formed)
   const float* W;      // [Kdim][ldw]
-  const float* bias;   // [N] or nullptr
-  float* out;          // [kMP][ldo]
-  int N, ldw, ldo, pro;
-  float scale;
+  float* out;          // [kSplit][kMP][ldo] partial slabs
+  int N, lda, ldw, ldo;
 };
 
 struct GemmArgs {
   GemmSeg seg[2];
-  int nblk0;           // blocks of segment 0
-  const float* x;      // [kMP][D]
-  const float* pre1;   // [kMP][IN]
-  const float* pre2;   // [kMP][IN]
-  const float* emb;    // [E] embedding row of this evaluation
-  const float* factor; // device scalar factor_sn (gemm C) or nullptr
-  float mu0;
-  int M, Kdim, D, IN;
+  int nblk0;           // column blocks of segment 0
+  int M, Kdim;
 };
 
-__device__ __forceinline__ float lgcp_a(const GemmArgs& a, int pro, int m, int k) {
-  if (m >= a.M) return 0.f;
-  if (pro == PRO_X_MINUS_MU) return a.x[m * a.D + k] - a.mu0;
-  if (pro == PRO_X) return a.x[m * a.D + k];
-  const float u = k < a.D ? a.x[m * a.D + k] : a.emb[k - a.D];
-  float v = u + softplus(a.pre1[m * a.IN + k]);                    // nn.py:45-47
-  if (pro == PRO_U2) v += softplus(a.pre2[m * a.IN + k]);          // nn.py:48-50
-  return v;
-}
-
+// out[ks][m][n] = sum_{k in slice ks, wave w} A[m][k] W[k][n]   (no bias: added when the slabs are summed)
 __global__ __launch_bounds__(64 * kGemmWaves) void lgcp_gemm_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int s = blockIdx.x < a.nblk0 ? 0 : 1;
   const GemmSeg sg = a.seg[s];
   const int n0 = (blockIdx.x - (s ? a.nblk0 : 0)) * 64;
+  const int ksplit = blockIdx.y;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float* As = lds + wv * (kChunk * kMP);                             // wave-private [kChunk][kMP]
   float* red = lds + kGemmWaves * kChunk * kMP;                      // [16][kMP][64]
-  const int ks = (a.Kdim + kGemmWaves - 1) / kGemmWaves;
-  const int k_lo = wv * ks, k_hi = min(a.Kdim, k_lo + ks);
+  const int kslice = (a.Kdim + kSplit - 1) / kSplit;
+  const int s_lo = ksplit * kslice, s_hi = min(a.Kdim, s_lo + kslice);
+  const int ks = (s_hi - s_lo + kGemmWaves - 1) / kGemmWaves;
+  const int k_lo = s_lo + wv * ks, k_hi = min(s_hi, k_lo + ks);
   const int n = n0 + lane;
   const bool ncol = n < sg.N;
 
@@ -78,26 +71,24 @@ __global__ __launch_bounds__(64 * kGemmWaves) void lgcp_gemm_kernel(GemmArgs a) 
 
   for (int kc = k_lo; kc < k_hi; kc += kChunk) {
     const int len = min(kChunk, k_hi - kc);
-    // W rows of this chunk: issue all loads first (one coalesced 256-byte row per k)
     float wrow[kChunk];
 #pragma unroll
     for (int kk = 0; kk < kChunk; ++kk)
       wrow[kk] = (kk < len && ncol) ? sg.W[(int64_t)(kc + kk) * sg.ldw + n] : 0.f;
-    // stage the activation slice (prologue applied) into wave-private LDS, k-major
-    for (int e = lane; e < len * kMP; e += 64) {
-      const int m = e / len, kk = e - m * len;
-      As[kk * kMP + m] = lgcp_a(a, sg.pro, m, kc + kk);
+    // stage A[:, kc:kc+len] into wave-private LDS, k-major: lane -> (m = e / 32, kk = e % 32), coalesced in k
+#pragma unroll
+    for (int e0 = 0; e0 < kChunk * kMP; e0 += 64) {
+      const int e = e0 + lane, m = e >> 5, kk = e & 31;
+      As[kk * kMP + m] = (m < a.M && kk < len) ? sg.A[(int64_t)m * sg.lda + kc + kk] : 0.f;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
     for (int kk = 0; kk < kChunk; ++kk) {
-      if (kk < len) {
 #pragma unroll
-        for (int m4 = 0; m4 < kMP / 4; ++m4) {
-          const f32x4 av = *reinterpret_cast<const f32x4*>(As + kk * kMP + 4 * m4);
+      for (int m4 = 0; m4 < kMP / 4; ++m4) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(As + kk * kMP + 4 * m4);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) acc[4 * m4 + q] = fmaf(av[q], wrow[kk], acc[4 * m4 + q]);
-        }
+        for (int q = 0; q < 4; ++q) acc[4 * m4 + q] = fmaf(av[q], wrow[kk], acc[4 * m4 + q]);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -105,17 +96,50 @@ __global__ __launch_bounds__(64 * kGemmWaves) void lgcp_gemm_kernel(GemmArgs a) 
 #pragma unroll
   for (int m = 0; m < kMP; ++m) red[(wv * kMP + m) * 64 + lane] = acc[m];
   __syncthreads();
-  const float fac = a.factor ? a.factor[0] : 1.0f;
+  float* slab = sg.out + (int64_t)ksplit * kMP * sg.ldo;
   for (int o = threadIdx.x; o < kMP * 64; o += blockDim.x) {
     const int m = o >> 6, nl = o & 63;
     if (m < a.M && n0 + nl < sg.N) {
       float v = 0.f;
 #pragma unroll
       for (int w = 0; w < kGemmWaves; ++w) v += red[(w * kMP + m) * 64 + nl];  // fixed order
-      if (sg.bias) v += sg.bias[n0 + nl];
-      sg.out[(int64_t)m * sg.ldo + n0 + nl] = v * sg.scale * fac;
+      slab[(int64_t)m * sg.ldo + n0 + nl] = v;
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// activation kernels: sum the split-K slabs in fixed order, add the bias, form the next GEMM's input
+// ------------------------------------------------------------------------------------------
+struct ActArgs {
+  const float* x;        // [kMP][D]
+  const float* emb;      // [E]
+  const float* slab_a;   // [kSplit][kMP][lda]  partials of the previous GEMM (segment a)
+  const float* bias_a;   // [IN] or nullptr
+  float* sum_a;          // [kMP][IN] summed pre-activation (kept: the next layer's residual needs it)
+  const float* u_prev;   // [kMP][IN] previous layer's u (act2 only)
+  float* u_out;          // [kMP][IN]
+  float* xm;             // [kMP][D]   x - mu0 (act0 only)
+  float mu0;
+  int M, D, IN, mode;    // mode 0: xm = x - mu0 ; 1: u1 = u + softplus(pre1) ; 2: u2 = u1 + softplus(pre2)
+};
+
+__global__ void lgcp_act_kernel(ActArgs a) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a.mode == 0) {
+    if (idx < a.M * a.D) a.xm[idx] = a.x[idx] - a.mu0;
+    return;
+  }
+  if (idx >= a.M * a.IN) return;
+  const int m = idx / a.IN, k = idx - m * a.IN;
+  float pre = a.bias_a[k];
+#pragma unroll
+  for (int ks = 0; ks < kSplit; ++ks) pre += a.slab_a[((int64_t)ks * kMP + m) * a.IN + k];
+  a.sum_a[idx] = pre;
+  float u;
+  if (a.mode == 1) u = k < a.D ? a.x[m * a.D + k] : a.emb[k - a.D];   // u = [x; emb_i]      nn.py:68-69
+  else u = a.u_prev[idx];
+  a.u_out[idx] = u + softplus(pre);                                   // nn.py:45-50
 }
 
 // ------------------------------------------------------------------------------------------
@@ -148,8 +172,10 @@ struct LgcpStateArgs {
   const float* sched;        // [K][8]
   float* x;                  // [kMP][D]   current z
   float* xp;                 // [kMP][D]   previous z
-  const float* kr;           // [kMP][D]   K^-1 (x - mu0)
-  const float* sn;           // [kMP][D]   score net output
+  const float* kr;           // [kSplit][kMP][D]   partial slabs of K^-1 (x - mu0)
+  const float* sn;           // [kSplit][kMP][D]   partial slabs of u2 W3
+  const float* b3;           // [D]
+  const float* factor;       // factor_sn (device scalar)
   float* w;                  // [kMP]
   float* fklp;               // [kMP]
   uint32_t* keys;            // [kMP][2]   gen key of the chain
@@ -244,7 +270,13 @@ __global__ __launch_bounds__(256) void lgcp_step_kernel(LgcpStateArgs a) {
       const int e = idx[q];
       if (e < D) {
         const float z = a.x[p * D + e];
-        const float kr = a.kr[p * D + e];
+        float kr = 0.f, s = a.b3[e];
+#pragma unroll
+        for (int ks = 0; ks < kSplit; ++ks) {   // fixed-order sum of the split-K slabs
+          kr += a.kr[((int64_t)ks * kMP + p) * D + e];
+          s += a.sn[((int64_t)ks * kMP + p) * D + e];
+        }
+        s *= a.factor[0];                       // factor_sn (u2 W3 + b3)           nn.py:70
         const float ez = expf(z);
         float gp = -kr + counts[e] - pa * ez;                                  // grad log p
         const float mean = a.params[a.lay.vd_mean + e];
@@ -252,7 +284,6 @@ __global__ __launch_bounds__(256) void lgcp_step_kernel(LgcpStateArgs a) {
         float gq = -(z - mean) / (sd * sd);
         if (clip_p) gp = fminf(fmaxf(gp, -clipv), clipv);
         if (clip_q) gq = fminf(fmaxf(gq, -clipv), clipv);
-        const float s = a.sn[p * D + e];
         if (i > 0) {   // backward kernel of step i-1                           mcd_cais.py:71-86
           const float ub = -1.0f * (pbeta * gp + (1.0f - pbeta) * gq);
           const float bk = z - peps * ub + peps * s;
@@ -307,7 +338,7 @@ __global__ __launch_bounds__(256) void lgcp_step_kernel(LgcpStateArgs a) {
 // host side
 // ------------------------------------------------------------------------------------------
 struct LgcpWs {
-  int64_t bias1, x, xp, kr, pre1, pre2, sn, w, fklp, keys, partials, total;
+  int64_t bias1, x, xp, xm, u1, u2, pre1, pre2, kr, slab1, slab2, sn, w, fklp, keys, partials, total;
 };
 
 static LgcpWs lgcp_ws(const cmcd_desc& d, int64_t n, int64_t base) {
@@ -316,8 +347,10 @@ static LgcpWs lgcp_ws(const cmcd_desc& d, int64_t n, int64_t base) {
   int64_t o = base;
   auto take = [&](int64_t cnt) { int64_t r = o; o += (cnt + 3) & ~int64_t(3); return r; };
   w.bias1 = take((K + 1) * IN);
-  w.x = take(kMP * D); w.xp = take(kMP * D); w.kr = take(kMP * D);
-  w.pre1 = take(kMP * IN); w.pre2 = take(kMP * IN); w.sn = take(kMP * D);
+  w.x = take(kMP * D); w.xp = take(kMP * D); w.xm = take(kMP * D);
+  w.u1 = take(kMP * IN); w.u2 = take(kMP * IN); w.pre1 = take(kMP * IN); w.pre2 = take(kMP * IN);
+  w.kr = take(kSplit * kMP * D); w.slab1 = take(kSplit * kMP * IN); w.slab2 = take(kSplit * kMP * IN);
+  w.sn = take(kSplit * kMP * D);
   w.w = take(kMP); w.fklp = take(kMP); w.keys = take(2 * kMP);
   o = (o + 1) & ~int64_t(1);
   w.partials = take(n * CMCD_NSTATS * 2);
@@ -344,42 +377,57 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
   const float* kinv = tc;
   double* partials = reinterpret_cast<double*>(ws + w.partials);
   *partials_out = partials;
-  // mu0 is needed on the host side of the launch (prologue constant): it is a model constant,
-  // log(126) - 0.5 * 1.91 (model_handler.py:346); the device copy in tc is used by the step kernel.
+  // mu0 is a model constant, log(126) - 0.5 * 1.91 (model_handler.py:346); the step kernel reads the
+  // device copy in tc, the activation kernel takes it as a launch argument.
   const float mu0 = 3.8812819069514780f;
+  const dim3 gblock(64 * kGemmWaves);
+  const int cbD = (D + 63) / 64, cbIN = (IN + 63) / 64;
 
   for (int64_t base = 0; base < n; base += kMP) {
     const int M = (int)((n - base) < kMP ? (n - base) : kMP);
     LgcpStateArgs st{};
     st.seeds = seeds + base; st.params = params; st.tc = tc; st.sched = ws + sw.sched;
     st.x = ws + w.x; st.xp = ws + w.xp; st.kr = ws + w.kr; st.sn = ws + w.sn;
+    st.b3 = params + lay.g_b3; st.factor = params + lay.g_factor;
     st.w = ws + w.w; st.fklp = ws + w.fklp; st.keys = reinterpret_cast<uint32_t*>(ws + w.keys);
     st.out_loss = out_loss + base; st.out_z = out_z + base * D; st.partials = partials + base * CMCD_NSTATS;
     st.lay = lay; st.M = M; st.D = D; st.K = K;
     st.var_mode = d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0; st.grad_clipping = d.grad_clipping;
     hipLaunchKernelGGL(lgcp_init_kernel, dim3(M), dim3(256), 0, stream, st);
 
+    ActArgs act{};
+    act.x = ws + w.x; act.mu0 = mu0; act.M = M; act.D = D; act.IN = IN; act.xm = ws + w.xm;
     GemmArgs g{};
-    g.x = ws + w.x; g.pre1 = ws + w.pre1; g.pre2 = ws + w.pre2; g.mu0 = mu0; g.M = M; g.D = D; g.IN = IN;
+    g.M = M;
     for (int i = 0; i <= K; ++i) {
       const int ie = i < K ? i : K - 1;
-      g.emb = params + lay.g_emb + (int64_t)ie * E;
-      // A: [x - mu0] Kinv -> kr  |  x W1[:D] + bias1_i -> pre1
-      g.Kdim = D; g.factor = nullptr;
-      g.seg[0] = GemmSeg{kinv, nullptr, ws + w.kr, D, D, D, PRO_X_MINUS_MU, 1.0f};
-      g.seg[1] = GemmSeg{params + lay.g_w1, ws + w.bias1 + (int64_t)i * IN, ws + w.pre1, IN, IN, IN, PRO_X, 1.0f};
-      g.nblk0 = (D + 63) / 64;
-      hipLaunchKernelGGL(lgcp_gemm_kernel, dim3(g.nblk0 + (IN + 63) / 64), dim3(64 * kGemmWaves), gemm_lds, stream, g);
-      // B: u1 W2 + b2 -> pre2
+      act.emb = params + lay.g_emb + (int64_t)ie * E;
+      // x - mu0
+      act.mode = 0;
+      hipLaunchKernelGGL(lgcp_act_kernel, dim3((M * D + 255) / 256), dim3(256), 0, stream, act);
+      // A: [x - mu0] Kinv -> kr slabs  |  x W1[:D] -> pre1 slabs
+      g.Kdim = D;
+      g.seg[0] = GemmSeg{ws + w.xm, kinv, ws + w.kr, D, D, D, D};
+      g.seg[1] = GemmSeg{ws + w.x, params + lay.g_w1, ws + w.slab1, IN, D, IN, IN};
+      g.nblk0 = cbD;
+      hipLaunchKernelGGL(lgcp_gemm_kernel, dim3(cbD + cbIN, kSplit), gblock, gemm_lds, stream, g);
+      // u1 = u + softplus(pre1 + bias1_i)
+      act.mode = 1; act.slab_a = ws + w.slab1; act.bias_a = ws + w.bias1 + (int64_t)i * IN;
+      act.sum_a = ws + w.pre1; act.u_prev = nullptr; act.u_out = ws + w.u1;
+      hipLaunchKernelGGL(lgcp_act_kernel, dim3((M * IN + 255) / 256), dim3(256), 0, stream, act);
+      // B: u1 W2 -> pre2 slabs
       g.Kdim = IN;
-      g.seg[0] = GemmSeg{params + lay.g_w2, params + lay.g_b2, ws + w.pre2, IN, IN, IN, PRO_U1, 1.0f};
-      g.nblk0 = (IN + 63) / 64;
-      hipLaunchKernelGGL(lgcp_gemm_kernel, dim3(g.nblk0), dim3(64 * kGemmWaves), gemm_lds, stream, g);
-      // C: factor_sn (u2 W3 + b3) -> sn
-      g.seg[0] = GemmSeg{params + lay.g_w3, params + lay.g_b3, ws + w.sn, D, D, D, PRO_U2, 1.0f};
-      g.nblk0 = (D + 63) / 64;
-      g.factor = params + lay.g_factor;
-      hipLaunchKernelGGL(lgcp_gemm_kernel, dim3(g.nblk0), dim3(64 * kGemmWaves), gemm_lds, stream, g);
+      g.seg[0] = GemmSeg{ws + w.u1, params + lay.g_w2, ws + w.slab2, IN, IN, IN, IN};
+      g.nblk0 = cbIN;
+      hipLaunchKernelGGL(lgcp_gemm_kernel, dim3(cbIN, kSplit), gblock, gemm_lds, stream, g);
+      // u2 = u1 + softplus(pre2 + b2)
+      act.mode = 2; act.slab_a = ws + w.slab2; act.bias_a = params + lay.g_b2;
+      act.sum_a = ws + w.pre2; act.u_prev = ws + w.u1; act.u_out = ws + w.u2;
+      hipLaunchKernelGGL(lgcp_act_kernel, dim3((M * IN + 255) / 256), dim3(256), 0, stream, act);
+      // C: u2 W3 -> sn slabs (bias and factor_sn applied in the step kernel)
+      g.seg[0] = GemmSeg{ws + w.u2, params + lay.g_w3, ws + w.sn, D, IN, D, D};
+      g.nblk0 = cbD;
+      hipLaunchKernelGGL(lgcp_gemm_kernel, dim3(cbD, kSplit), gblock, gemm_lds, stream, g);
       st.i = i;
       hipLaunchKernelGGL(lgcp_step_kernel, dim3(M), dim3(256), 0, stream, st);
     }
