@@ -54,6 +54,14 @@ def lib():
         L.cmcd_stats_merge.restype = C.c_int
         L.cmcd_stats_merge.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32,
                                        C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.cmcd_grad_workspace_bytes.restype = C.c_int64
+        L.cmcd_grad_workspace_bytes.argtypes = [C.POINTER(Desc), C.c_int64]
+        L.cmcd_vargrad_weights.restype = C.c_int
+        L.cmcd_vargrad_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+        L.cmcd_bound_var_grad.restype = C.c_int
+        L.cmcd_bound_var_grad.argtypes = [C.POINTER(Desc), C.POINTER(Layout), C.c_void_p, C.c_int64, C.c_void_p,
+                                          C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
+                                          C.c_void_p, C.c_void_p]
         L.cmcd_stats_merge_device.restype = C.c_int
         L.cmcd_stats_merge_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.cmcd_profile_enable.restype = C.c_int

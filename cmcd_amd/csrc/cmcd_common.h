@@ -53,4 +53,11 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
                  const float* params, const float* tc, float* ws, float* out_loss, float* out_z,
                  double** partials_out, void* stream);
 
+// cmcd_grad.hip: VarGrad gradient (widths <= 64)
+bool grad_available(const cmcd_desc& d, int T);
+int64_t grad_workspace_floats(const cmcd_desc& d, int HP, int64_t n);
+int grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, const int32_t* seeds, int64_t n,
+                const float* params, int64_t n_params, const float* ws_fwd, const float* omega, float* gws,
+                float* grad, void* stream);
+
 }  // namespace cmcd

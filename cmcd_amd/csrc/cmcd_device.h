@@ -104,6 +104,31 @@ __device__ __forceinline__ float gelu_fast(float x) {
   const float e = __builtin_amdgcn_exp2f(-(s * r));
   return fmaf(-0.5f * ax, e, fmaxf(x, 0.0f));
 }
+// d gelu / dx = Phi(x) + x phi(x), Phi from the same erfc polynomial as gelu_fast.
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+  const float ax = fabsf(x);
+  const float s = fminf(ax, 6.0f);
+  float r = 5.626459558e-08f;
+  r = fmaf(r, s, -1.389874702e-06f);
+  r = fmaf(r, s, 1.521236383e-05f);
+  r = fmaf(r, s, -9.455732447e-05f);
+  r = fmaf(r, s, 3.240720773e-04f);
+  r = fmaf(r, s, -6.315276129e-05f);
+  r = fmaf(r, s, -6.896958595e-03f);
+  r = fmaf(r, s, 5.242151140e-02f);
+  r = fmaf(r, s, 4.592238824e-01f);
+  r = fmaf(r, s, 1.151104120e+00f);
+  const float he = 0.5f * __builtin_amdgcn_exp2f(-(s * r));           // erfc(|x|/sqrt2) / 2
+  const float cdf = x >= 0.f ? 1.0f - he : he;
+  const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);
+  return fmaf(x, pdf, cdf);
+}
+// d softplus / dx = sigmoid(x), branch-free and overflow-free
+__device__ __forceinline__ float sigmoid_fast(float x) {
+  const float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * fabsf(x));
+  const float inv = __builtin_amdgcn_rcpf(1.0f + e);
+  return x >= 0.f ? inv : e * inv;
+}
 // reference-grade version (ocml erff), used by the prep kernel's time coder
 __device__ __forceinline__ float gelu_exact(float x) {
   return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
@@ -160,6 +185,15 @@ template <int LP>
 __device__ __forceinline__ float part_max(float v) {
   if (LP == 8) v = fmaxf(v, xor8(v));
   return group_max(v);
+}
+// sum over the 16 lanes of a row (the 16 particles of a tile, for a value held per particle), DPP only:
+// quad butterflies then row rotations by 4 and 8.  Every lane of the row receives the total.
+__device__ __forceinline__ float row_sum16(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));  // row_ror:4
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));  // row_ror:8
+  return v;
 }
 // every lane receives x of row 0 (r0) and of row 1 (r1) at its own column
 __device__ __forceinline__ void rows01(uint32_t x, uint32_t& r0, uint32_t& r1) {

@@ -1,0 +1,791 @@
+// grad_kernel — VarGrad gradient of the CMCD bound (the build's `compute_log_var_grad`):
+//   d/d params_flat of  sum_n omega_n * w_n   with z detached at every step boundary, exactly the
+// autodiff graph of `MCD_CAIS_var_sn` (/root/reference/src/mcd_cais_var.py:59,79: z = stop_gradient(z),
+// z_new = stop_gradient(z_new)) under jax.grad(compute_bound_var, 1) (/root/reference/src/main.py:161-176).
+// The caller supplies omega_n = d value / d w_n (for the variance: -(2/N)(l_n - mean l)).
+//
+// Because z is detached, the gradient is LOCAL per bridge evaluation e = 0..K:
+//   cotangent of s(z_e, e):   c_e = omega/2 [ (z_{e-1} - bk_{e-1}) [e>=1] + (z_{e+1} - fk_e) [e<=K-1] ]
+//   d w / d beta_i = 1/2 [ (z_i - bk_i).(gp' - gq') - (z_{i+1} - fk_i).(gp - gq) ]
+//   d w / d eps_i  = (|z_i-bk_i|^2 - |z_{i+1}-fk_i|^2)/(4 eps^2) + [(z_i-bk_i).(s'-ub) + (z_{i+1}-fk_i).(uf+s)]/(2 eps)
+//   d w / d gq     = -(1-beta)/2 (z_{i+1}-fk_i) at z_i,  +(1-beta)/2 (z_i-bk_i) at z_{i+1};  d w0 / d logdiag = 1
+// so the kernel re-runs the trajectory (same seeds => same z) and back-propagates through the MLP at
+// every evaluation while the activations are still in registers.
+//
+// Mapping: 4-wave workgroups, wave q runs forward + backward of its OWN 16-particle tile.  All
+// parameter-gradient contractions over particles are MFMA outer products C += X^T Y with X, Y staged
+// per tile in LDS as [feature][particle] (XOR-swizzled), e.g. dW2 += u1^T da2.  The dW2 / dW3
+// accumulator row-tiles are distributed over the 4 waves (wave w owns row tile w of all four tiles'
+// products) so that nothing but 16-32 accumulator registers per wave persists across evaluations.
+// W2^T da2 re-uses the forward A-fragment copy in LDS through a gathered read.  Per-evaluation
+// quantities (bias-table, beta, eps gradients) go to small global tables by float atomics; the
+// particle-independent tails (time coder / embedding / schedules) are small kernels at the end.
+//
+// Scope: hidden width <= 64 (T <= 4).  The 132-wide net needs a different accumulator plan (next).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "cmcd_common.h"
+#include "cmcd_device.h"
+#include "cmcd_hip.h"
+
+namespace cmcd {
+
+struct GradArgs {
+  const int32_t* seeds;
+  const float* params;
+  const float* ws;           // forward workspace (tables + packed weights of cmcd_bound_forward's prep)
+  const float* omega;        // [n]
+  float* gtab;               // gradient tables (zeroed): S[(K+1)][HP], S2[(K+1)][HP], gbeta[K], geps[K], gvd[2D], gfac[1]
+  float* slabs;              // per-workgroup slabs
+  cmcd_layout lay;
+  WsLayout w;
+  int64_t n;
+  int32_t K, var_mode, grad_clipping, nquads;
+  int64_t o_S, o_S2, o_gbeta, o_geps, o_gvd, o_gfac;   // offsets inside gtab
+  int64_t slab_stride;                                   // floats per workgroup slab
+};
+
+// element (feature f, particle p) of a staged [features][16] array
+__device__ __forceinline__ int sw(int f, int p) { return f * 16 + (p ^ (f & 15)); }
+
+template <int TARGET, int ARCH, int D, int T>
+__global__ __launch_bounds__(256) void grad_kernel(GradArgs a) {
+  constexpr int HP = 16 * T;
+  constexpr int Hh = (D + 1) / 2;
+  constexpr bool GEF = ARCH == CMCD_ARCH_GEFFNER;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* lds_w2 = lds;                    // HP*HP   forward A fragments
+  float* lds_w1z = lds_w2 + HP * HP;      // D*HP
+  float* lds_w3t = lds_w1z + D * HP;      // D*HP
+  float* lds_b2 = lds_w3t + D * HP;       // HP
+  float* lds_b3 = lds_b2 + HP;            // 16
+  float* lds_tgt = lds_b3 + 16;           // tgt_floats
+  float* stage = lds_tgt + a.w.tgt_floats;
+  constexpr int STG = (5 * HP + 32) * 16; // per tile: u1T, u2T, da2T, da1T, du1T [HP][16]; z1, doT [16][16]
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.ws + a.w.w1z);
+    f32x4* dst = reinterpret_cast<f32x4*>(lds_w1z);
+    for (int i = threadIdx.x; i < D * HP / 4; i += blockDim.x) dst[i] = src[i];
+    src = reinterpret_cast<const f32x4*>(a.ws + a.w.w2);
+    dst = reinterpret_cast<f32x4*>(lds_w2);
+    for (int i = threadIdx.x; i < HP * HP / 4; i += blockDim.x) dst[i] = src[i];
+    src = reinterpret_cast<const f32x4*>(a.ws + a.w.w3t);
+    dst = reinterpret_cast<f32x4*>(lds_w3t);
+    for (int i = threadIdx.x; i < D * HP / 4; i += blockDim.x) dst[i] = src[i];
+    for (int i = threadIdx.x; i < HP; i += blockDim.x) lds_b2[i] = a.ws[a.w.b2 + i];
+    for (int i = threadIdx.x; i < 16; i += blockDim.x) lds_b3[i] = a.ws[a.w.b3 + i];
+    for (int i = threadIdx.x; i < a.w.tgt_floats; i += blockDim.x) lds_tgt[i] = a.ws[a.w.tgt + i];
+  }
+  __syncthreads();
+
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  float* my = stage + wv * STG;
+  float* u1T = my;
+  float* u2T = u1T + HP * 16;
+  float* da2T = u2T + HP * 16;
+  float* da1T = da2T + HP * 16;
+  float* du1T = da1T + HP * 16;
+  float* z1T = du1T + HP * 16;            // rows 0..D-1 = z_j, row D = 1, rest 0
+  float* doT = z1T + 256;                 // rows 0..D-1 = d o_j, rest 0
+  const int K = a.K;
+  const float factor = lds_b3[15];
+
+  float qmean[D], qstd[D], qiv[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    qmean[j] = a.params[a.lay.vd_mean + j];
+    qstd[j] = expf(a.params[a.lay.vd_logdiag + j]);
+    qiv[j] = 1.0f / (qstd[j] * qstd[j]);
+  }
+  const float clipv = a.var_mode ? 1e2f : 1e3f;
+  const bool clip_p = a.grad_clipping != 0;
+  const bool clip_q = clip_p && a.var_mode;
+  const float* bias1 = a.ws + a.w.bias1;
+  const float* utab = a.ws + a.w.utab;
+  float* gS = a.gtab + a.o_S;
+  float* gS2 = a.gtab + a.o_S2;
+
+  // persistent accumulators (C layout: lane (g,c), reg r <-> row 16*tile + 4g + r, col 16*tile' + c)
+  constexpr int OWN = (T + 3) / 4;        // dW2 / dW3 row tiles owned by this wave: ti = wv + 4*k < T
+  f32x4 gW2[OWN][T], gW3[OWN];
+  f32x4 gZ1[T];                           // rows j < D: dW1z[j][n]
+  f32x4 gB2[T];                           // row D: db2[n]   (A = z1 against da2)
+  f32x4 gB3;                              // row D: db3[j]   (A = z1 against do)
+#pragma unroll
+  for (int k = 0; k < OWN; ++k) {
+    gW3[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < T; ++t) gW2[k][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t) { gZ1[t] = f32x4{0.f, 0.f, 0.f, 0.f}; gB2[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  gB3 = f32x4{0.f, 0.f, 0.f, 0.f};
+  float gfac = 0.f, gmu[D], glam[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) { gmu[j] = 0.f; glam[j] = 0.f; }
+
+  for (int quad = blockIdx.x; quad < a.nquads; quad += gridDim.x) {
+    const int64_t tile = (int64_t)quad * 4 + wv;
+    const int64_t p = tile * 16 + c;
+    const bool valid = p < a.n;
+    const int32_t seed = a.seeds[valid ? p : a.n - 1];
+    const float om = valid ? a.omega[p] : 0.f;
+
+    // ---- key chain + z0 (identical to traj_kernel)
+    const int gb = g & 1;
+    uint32_t x0, x1, k0 = 0u, k1 = (uint32_t)seed;
+    float z[D], zp[D];
+    {
+      x0 = gb; x1 = 2 + gb;
+      threefry2x32(k0, k1, x0, x1);
+      uint32_t a0, a1, b0, b1;
+      rows01(x0, a0, a1);
+      rows01(x1, b0, b1);
+      float nz[2 * Hh];
+#pragma unroll
+      for (int j0 = 0; j0 < Hh; j0 += 4) {
+        const int j = j0 + g;
+        uint32_t y0 = j, y1 = (Hh + j < D) ? Hh + j : 0;
+        threefry2x32(a0, a1, y0, y1);
+        uint32_t r0[4], r1[4];
+        rows0123(__float_as_uint(bits_to_normal(y0)), r0);
+        rows0123(__float_as_uint(bits_to_normal(y1)), r1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (j0 + q < Hh) {
+            nz[j0 + q] = __uint_as_float(r0[q]);
+            nz[Hh + j0 + q] = __uint_as_float(r1[q]);
+          }
+      }
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        z[j] = qstd[j] * nz[j] + qmean[j];
+        zp[j] = 0.f;
+        glam[j] += om;   // d(-log q(z0))/d logdiag_j = +1 under the reparameterisation; mean: 0
+      }
+      x0 = gb; x1 = 2 + gb;
+      threefry2x32(b0, b1, x0, x1);
+      uint32_t c0, c1;
+      rows01(x0, c0, c1);
+      x0 = gb; x1 = 2 + gb;
+      threefry2x32(c0, c1, x0, x1);
+      rows01(x1, k0, k1);
+    }
+    float pbeta = 0.f, peps = 0.f;
+    float fkd[D];  // z_{i+1} - fk_i of the step opened at the previous evaluation
+    float puf[D], psn[D], pgd[D];  // uf, s, (gp - gq) of that step's forward side
+#pragma unroll
+    for (int j = 0; j < D; ++j) { fkd[j] = 0.f; puf[j] = 0.f; psn[j] = 0.f; pgd[j] = 0.f; }
+    float pend_beta = 0.f, pend_eps = 0.f;   // forward-side contributions of step i, completed at e = i+1
+
+    for (int e = 0; e <= K; ++e) {
+      // ---------------------------------------------------------------- forward (keeps pre-activations)
+      const float* brow = bias1 + (int64_t)e * HP;
+      f32x4 a1[T], u1[T], a2[T], u2[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        f32x4 pre = *reinterpret_cast<const f32x4*>(brow + 16 * t + 4 * g);
+#pragma unroll
+        for (int j = 0; j < D; ++j) pre += z[j] * *reinterpret_cast<const f32x4*>(lds_w1z + j * HP + 16 * t + 4 * g);
+        a1[t] = pre;
+        if (!GEF) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) u1[t][r] = gelu_fast(pre[r]);
+        } else {
+          f32x4 u = *reinterpret_cast<const f32x4*>(utab + (int64_t)e * HP + 16 * t + 4 * g);
+          if (16 * t < D) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int nidx = 16 * t + 4 * g + r;
+#pragma unroll
+              for (int j = 0; j < D; ++j)
+                if (j >= 16 * t && j < 16 * t + 16) u[r] = (nidx == j) ? z[j] : u[r];
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) u1[t][r] = u[r] + softplus(pre[r]);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < T; ++t) a2[t] = *reinterpret_cast<const f32x4*>(lds_b2 + 16 * t + 4 * g);
+#pragma unroll
+      for (int ti = 0; ti < T; ++ti) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int to = 0; to < T; ++to) {
+          const f32x4 af = *reinterpret_cast<const f32x4*>(lds_w2 + ((ti * T + to) * 64 + lane) * 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a2[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r], u1[ti][r], a2[to], 0, 0, 0);
+        }
+      }
+      float opre[D], sn[D];
+      {
+        float part[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) part[j] = 0.f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) u2[t][r] = GEF ? u1[t][r] + softplus(a2[t][r]) : gelu_fast(a2[t][r]);
+#pragma unroll
+          for (int j = 0; j < D; ++j) {
+            const f32x4 wv4 = *reinterpret_cast<const f32x4*>(lds_w3t + j * HP + 16 * t + 4 * g);
+            part[j] += u2[t][0] * wv4[0] + u2[t][1] * wv4[1] + u2[t][2] * wv4[2] + u2[t][3] * wv4[3];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          opre[j] = group_sum(part[j]) + lds_b3[j];
+          sn[j] = GEF ? opre[j] * factor : fminf(fmaxf(opre[j], -1e4f), 1e4f);
+        }
+      }
+      float gp[D], gq[D], logp;
+      bool gq_live[D];
+      Target<TARGET, D>::eval(z, g, lds_tgt, logp, gp);
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        gq[j] = -(z[j] - qmean[j]) * qiv[j];
+        gq_live[j] = true;
+        if (clip_p) gp[j] = fminf(fmaxf(gp[j], -clipv), clipv);
+        if (clip_q) {
+          gq_live[j] = fabsf(gq[j]) < clipv;
+          gq[j] = fminf(fmaxf(gq[j], -clipv), clipv);
+        }
+      }
+
+      // ---------------------------------------------------------------- cotangents and scalar gradients
+      float cot[D];
+#pragma unroll
+      for (int j = 0; j < D; ++j) cot[j] = 0.f;
+      if (e > 0) {  // backward kernel of step i = e-1 at z' = z (mcd_cais_var.py:81-89)
+        float sb = 0.f, se = 0.f, dn2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          const float ub = -1.0f * (pbeta * gp[j] + (1.0f - pbeta) * gq[j]);
+          const float bk = z[j] - peps * ub + peps * sn[j];
+          const float db = zp[j] - bk;
+          cot[j] += 0.5f * db;
+          sb += db * (gp[j] - gq[j]);
+          se += db * (sn[j] - ub);
+          dn2 += db * db;
+          const float cq = om * 0.5f * (1.0f - pbeta) * db;          // d w / d gq_j(z')
+          if (gq_live[j]) { gmu[j] += cq * qiv[j]; glam[j] += cq * (-2.0f * gq[j]); }
+        }
+        const float inv2e = 0.5f / peps;
+        const float gbe = pend_beta + om * 0.5f * sb;
+        const float gep = pend_eps + om * (dn2 * inv2e * inv2e + se * inv2e);
+        // one value per particle; lanes g = 0 hold it: sum over the tile, one atomic per tile and step
+        const float tb = row_sum16(gbe), te = row_sum16(gep);
+        if (lane == 0) {
+          atomicAdd(a.gtab + a.o_gbeta + (e - 1), tb);
+          atomicAdd(a.gtab + a.o_geps + (e - 1), te);
+        }
+      }
+      float beta = 0.f, eps = 0.f, sig = 0.f;
+      float zn[D];
+      if (e < K) {
+        beta = a.ws[a.w.beta + e]; eps = a.ws[a.w.eps + e]; sig = a.ws[a.w.sig + e];
+        x0 = gb; x1 = 2 + gb;
+        threefry2x32(k0, k1, x0, x1);
+        uint32_t g0, g1, h0, h1;
+        rows01(x0, g0, g1);
+        rows01(x1, h0, h1);
+        constexpr int NB = 2 + Hh;
+        float nz[2 * Hh];
+#pragma unroll
+        for (int b0 = 0; b0 < NB; b0 += 4) {
+          const int b = b0 + g;
+          const bool is_split = b < 2;
+          const int jn = b - 2;
+          uint32_t y0 = is_split ? b : jn;
+          uint32_t y1 = is_split ? 2 + b : ((Hh + jn < D) ? Hh + jn : 0);
+          threefry2x32(is_split ? h0 : g0, is_split ? h1 : g1, y0, y1);
+          if (b0 == 0) rows01(y1, k0, k1);
+          uint32_t r0[4], r1[4];
+          rows0123(__float_as_uint(bits_to_normal(y0)), r0);
+          rows0123(__float_as_uint(bits_to_normal(y1)), r1);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int jj = b0 + q - 2;
+            if (jj >= 0 && jj < Hh) {
+              nz[jj] = __uint_as_float(r0[q]);
+              nz[Hh + jj] = __uint_as_float(r1[q]);
+            }
+          }
+        }
+        float sb = 0.f, se = 0.f, dn2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {  // forward kernel of step e
+          const float uf = -1.0f * (beta * gp[j] + (1.0f - beta) * gq[j]);
+          const float fk = z[j] - eps * uf - eps * sn[j];
+          zn[j] = fk + sig * nz[j];
+          const float df = zn[j] - fk;
+          cot[j] += 0.5f * df;
+          sb += df * (gp[j] - gq[j]);
+          se += df * (uf + sn[j]);
+          dn2 += df * df;
+          const float cq = -om * 0.5f * (1.0f - beta) * df;           // d w / d gq_j(z)
+          if (gq_live[j]) { gmu[j] += cq * qiv[j]; glam[j] += cq * (-2.0f * gq[j]); }
+        }
+        const float inv2e = 0.5f / eps;
+        pend_beta = -om * 0.5f * sb;
+        pend_eps = om * (-dn2 * inv2e * inv2e + se * inv2e);
+      }
+
+      // ---------------------------------------------------------------- MLP backward
+      float dob[D];  // d (sum omega w) / d o_j  (pre-clip / pre-factor output)
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        const float cj = om * cot[j];
+        if (GEF) {
+          dob[j] = cj * factor;
+          if (g == 0) gfac += cj * opre[j];
+        } else {
+          dob[j] = fabsf(opre[j]) < 1e4f ? cj : 0.f;
+        }
+      }
+      f32x4 d2[T];  // d / d a2
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        f32x4 du2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < D; ++j) du2 += dob[j] * *reinterpret_cast<const f32x4*>(lds_w3t + j * HP + 16 * t + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d2[t][r] = du2[r] * (GEF ? sigmoid_fast(a2[t][r]) : gelu_grad_fast(a2[t][r]));
+        if (GEF) a2[t] = du2;  // keep d u2 (residual path) in a2's registers
+      }
+      // d u1 = [d u2 +] W2 d a2 : rows = input neuron k, contraction over output neuron n (gathered A')
+      f32x4 d1[T];
+#pragma unroll
+      for (int tk = 0; tk < T; ++tk) d1[tk] = GEF ? a2[tk] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tn = 0; tn < T; ++tn) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int tk = 0; tk < T; ++tk) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            // A'[i = c][kk = g] = W2[16 tk + c][16 tn + 4 g + r] from the forward packing
+            const float av = lds_w2[((tk * T + tn) * 64 + (c >> 2) * 16 + 4 * g + r) * 4 + (c & 3)];
+            d1[tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, d2[tn][r], d1[tk], 0, 0, 0);
+          }
+        }
+      }
+      f32x4 du1s[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        du1s[t] = d1[t];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d1[t][r] *= GEF ? sigmoid_fast(a1[t][r]) : gelu_grad_fast(a1[t][r]);
+      }
+      // ---------------------------------------------------------------- stage [feature][particle]
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = 16 * t + 4 * g + r, o = sw(f, c);
+          u1T[o] = u1[t][r];
+          u2T[o] = u2[t][r];
+          da2T[o] = d2[t][r];
+          da1T[o] = d1[t][r];
+          if (GEF) du1T[o] = du1s[t][r];
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int f = 4 * g + r;
+        float zv = 0.f, dv = 0.f;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          zv = (f == j) ? z[j] : zv;
+          dv = (f == j) ? dob[j] : dv;
+        }
+        if (f == D) zv = 1.0f;
+        z1T[sw(f, c)] = zv;
+        doT[sw(f, c)] = dv;
+      }
+      __syncthreads();
+      // ---------------------------------------------------------------- outer products over particles
+      {
+        float za[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) za[s] = z1T[sw(c, 4 * s + g)];
+        f32x4 sacc[T], s2acc[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          sacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+          s2acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const float b1v = da1T[sw(16 * t + c, 4 * s + g)];
+            const float b2v = da2T[sw(16 * t + c, 4 * s + g)];
+            sacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[s], b1v, sacc[t], 0, 0, 0);
+            gB2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[s], b2v, gB2[t], 0, 0, 0);
+            if (GEF) {
+              const float b3v = du1T[sw(16 * t + c, 4 * s + g)];
+              s2acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[s], b3v, s2acc[t], 0, 0, 0);
+            }
+          }
+          gZ1[t] += sacc[t];  // rows j < D are dW1z; row D is re-read below, other rows are unused
+          // row D of z1 is the all-ones row: sum over particles of d a1 (and d u1) = d / d bias-table row e
+          if (4 * g <= D && D < 4 * g + 4) {
+            atomicAdd(gS + (int64_t)e * HP + 16 * t + c, sacc[t][D - 4 * (D / 4)]);
+            if (GEF) atomicAdd(gS2 + (int64_t)e * HP + 16 * t + c, s2acc[t][D - 4 * (D / 4)]);
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) gB3 = __builtin_amdgcn_mfma_f32_16x16x4f32(za[s], doT[sw(c, 4 * s + g)], gB3, 0, 0, 0);
+      }
+#pragma unroll
+      for (int k = 0; k < OWN; ++k) {
+        const int ti = wv + 4 * k;
+        if (ti < T) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {  // all four tiles of the workgroup
+            const float* base = stage + q * STG;
+            float xa[4], x2[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              xa[s] = base[sw(16 * ti + c, 4 * s + g)];                  // u1T
+              x2[s] = base[HP * 16 + sw(16 * ti + c, 4 * s + g)];        // u2T
+            }
+#pragma unroll
+            for (int to = 0; to < T; ++to)
+#pragma unroll
+              for (int s = 0; s < 4; ++s)
+                gW2[k][to] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], base[2 * HP * 16 + sw(16 * to + c, 4 * s + g)],
+                                                                  gW2[k][to], 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+              gW3[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(x2[s], base[5 * HP * 16 + 256 + sw(c, 4 * s + g)], gW3[k], 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();
+      // ---------------------------------------------------------------- advance
+      if (e < K) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) { zp[j] = z[j]; z[j] = zn[j]; }
+        pbeta = beta; peps = eps;
+      }
+    }
+  }
+
+  // ---------------------------------------------------------------- write the workgroup slab
+  float* slab = a.slabs + (int64_t)blockIdx.x * a.slab_stride;
+  // layout: dW2 [HP][HP] | dW3 [HP][16] | per wave: gZ1 [16][HP], gB2 [16][HP], gB3 [16][16], scalars [32]
+#pragma unroll
+  for (int k = 0; k < OWN; ++k) {
+    const int ti = wv + 4 * k;
+    if (ti < T) {
+#pragma unroll
+      for (int to = 0; to < T; ++to)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[(16 * ti + 4 * g + r) * HP + 16 * to + c] = gW2[k][to][r];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) slab[HP * HP + (16 * ti + 4 * g + r) * 16 + c] = gW3[k][r];
+    }
+  }
+  float* pw = slab + HP * HP + HP * 16 + wv * (2 * 16 * HP + 256 + 32);
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      pw[(4 * g + r) * HP + 16 * t + c] = gZ1[t][r];
+      pw[16 * HP + (4 * g + r) * HP + 16 * t + c] = gB2[t][r];
+    }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) pw[2 * 16 * HP + (4 * g + r) * 16 + c] = gB3[r];
+  {
+    float* sc = pw + 2 * 16 * HP + 256;
+    const float tf = row_sum16(gfac);
+    if (lane == 0) sc[0] = tf;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const float tm = row_sum16(gmu[j]), tl = row_sum16(glam[j]);
+      if (lane == 0) { sc[1 + 2 * j] = tm; sc[2 + 2 * j] = tl; }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// reduction of the workgroup slabs into grad_flat (fixed order) + particle-independent tails
+// ------------------------------------------------------------------------------------------
+struct TailArgs {
+  const float* params;
+  const float* ws;
+  const float* gtab;
+  const float* slabs;
+  float* grad;         // [n_params]
+  cmcd_layout lay;
+  WsLayout w;
+  int64_t o_S, o_S2, o_gbeta, o_geps, o_gvd, o_gfac, slab_stride, n_params;
+  int32_t K, D, E, IN, HP, arch, nslabs, eps_schedule, ngrid;
+};
+
+__device__ __forceinline__ float slab_sum(const TailArgs& a, int64_t off) {
+  float v = 0.f;
+  for (int s = 0; s < a.nslabs; ++s) v += a.slabs[(int64_t)s * a.slab_stride + off];
+  return v;
+}
+__device__ __forceinline__ float wave_slab_sum(const TailArgs& a, int64_t off) {  // per-wave regions, 4 per slab
+  const int64_t per = 2 * 16 * a.HP + 256 + 32, base = (int64_t)a.HP * a.HP + a.HP * 16;
+  float v = 0.f;
+  for (int s = 0; s < a.nslabs; ++s)
+    for (int w = 0; w < 4; ++w) v += a.slabs[(int64_t)s * a.slab_stride + base + w * per + off];
+  return v;
+}
+
+// grid-stride over every entry of grad_flat that is a plain sum of slab entries
+__global__ void grad_reduce_kernel(TailArgs a) {
+  const int HP = a.HP, D = a.D, IN = a.IN;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+  const bool dds = a.arch == CMCD_ARCH_DDS;
+  const int64_t o_w1 = dds ? a.lay.d_sw1 : a.lay.g_w1, o_w2 = dds ? a.lay.d_sw2 : a.lay.g_w2;
+  const int64_t o_b2 = dds ? a.lay.d_sb2 : a.lay.g_b2, o_w3 = dds ? a.lay.d_sw3 : a.lay.g_w3;
+  const int64_t o_b3 = dds ? a.lay.d_sb3 : a.lay.g_b3;
+  const int wid = dds ? 64 : IN;  // true width, row length of W1 / W2
+  for (int64_t i = tid; i < (int64_t)wid * wid; i += stride) {         // dW2[k][n]
+    const int k = int(i / wid), n = int(i % wid);
+    a.grad[o_w2 + i] = slab_sum(a, (int64_t)k * HP + n);
+  }
+  for (int64_t i = tid; i < (int64_t)wid * D; i += stride) {           // dW3[n][j]
+    const int n = int(i / D), j = int(i % D);
+    a.grad[o_w3 + i] = slab_sum(a, (int64_t)HP * HP + n * 16 + j);
+  }
+  for (int64_t i = tid; i < (int64_t)D * wid; i += stride) {           // dW1[j][n], j < D (z rows)
+    const int j = int(i / wid), n = int(i % wid);
+    a.grad[o_w1 + i] = wave_slab_sum(a, (int64_t)j * HP + n);
+  }
+  for (int64_t i = tid; i < wid; i += stride) a.grad[o_b2 + i] = wave_slab_sum(a, 16 * HP + (int64_t)D * HP + i);
+  for (int64_t i = tid; i < D; i += stride) {
+    a.grad[o_b3 + i] = wave_slab_sum(a, 2 * 16 * HP + D * 16 + i);
+    a.grad[a.lay.vd_mean + i] = wave_slab_sum(a, 2 * 16 * HP + 256 + 1 + 2 * i);
+    a.grad[a.lay.vd_logdiag + i] = wave_slab_sum(a, 2 * 16 * HP + 256 + 2 + 2 * i);
+  }
+  if (tid == 0 && !dds) a.grad[a.lay.g_factor] = wave_slab_sum(a, 2 * 16 * HP + 256);
+}
+
+// d / d eps0 and d / d mgridref_y from the per-step tables (one block)
+__global__ void grad_sched_tail_kernel(TailArgs a) {
+  __shared__ float gm[40], gyg[40];
+  const int K = a.K, G = a.ngrid;
+  const float* gbeta = a.gtab + a.o_gbeta;
+  const float* geps = a.gtab + a.o_geps;
+  if (threadIdx.x == 0) {
+    float ge = 0.f;
+    for (int i = 0; i < K; ++i) {
+      float dedeps0 = 1.0f;                                                       // constant schedule
+      if (a.eps_schedule == CMCD_EPS_COS_SQ) {
+        const float cs = cosf(((float)i / (float)K + 0.008f) / 1.008f * 0.5f * 3.14159265358979323846f);
+        dedeps0 = cs * cs;
+      } else if (a.eps_schedule == CMCD_EPS_LINEAR) {
+        dedeps0 = 1.0f - (float)i / (float)(K - 1);
+      }
+      ge += geps[i] * dedeps0;
+    }
+    a.grad[a.lay.eps] = ge;
+    // beta_i = gy[j-1] + frac_i (gy[j] - gy[j-1]),  gy = [0, cumsum(m)/sum(m)]
+    for (int q = 0; q <= G + 1; ++q) gyg[q] = 0.f;
+    for (int i = 0; i < K; ++i) {
+      const float x = (float)(i + 1) / (float)(K + 1);
+      int j = 1;
+      while (j < G + 1 && (float)j / (float)(G + 1) <= x) ++j;
+      const float x0 = (float)(j - 1) / (float)(G + 1), x1 = (float)j / (float)(G + 1);
+      const float fr = (x - x0) / (x1 - x0);
+      gyg[j - 1] += gbeta[i] * (1.0f - fr);
+      gyg[j] += gbeta[i] * fr;
+    }
+    // gy[q] = C_q / S, C_q = sum_{r<q} m_r (q >= 1), S = sum m:  d gy[q] / d m_r = ([r < q] - gy[q]) / S
+    const float* m = a.params + a.lay.mgridref_y;
+    float S = 0.f;
+    for (int r = 0; r <= G; ++r) S += m[r];
+    float run = 0.f, dot = 0.f;
+    float gyv[40];
+    gyv[0] = 0.f;
+    for (int r = 0; r <= G; ++r) { run += m[r]; gyv[r + 1] = run / S; }
+    for (int q = 1; q <= G + 1; ++q) dot += gyg[q] * gyv[q];
+    float suffix = 0.f;  // sum_{q > r} gyg[q]
+    for (int r = G; r >= 0; --r) {
+      suffix += gyg[r + 1];
+      gm[r] = (suffix - dot) / S;
+    }
+    for (int r = 0; r <= G; ++r) a.grad[a.lay.mgridref_y + r] = gm[r];
+  }
+}
+
+// geffner tail: S[e][n] = d/d bias-table, S2[e][n] = sum_p d u1.   emb row of evaluation e is min(e, K-1).
+//   db1[n] = sum_e S[e][n];  dW1[D+j][n] = sum_e emb[ie][j] S[e][n];
+//   demb[i][j] = sum_{e: ie(e) = i} ( S2[e][D+j] + sum_n W1[D+j][n] S[e][n] )
+__global__ void grad_geffner_tail_kernel(TailArgs a) {
+  const int K = a.K, D = a.D, E = a.E, IN = a.IN, HP = a.HP;
+  const float* S = a.gtab + a.o_S;
+  const float* S2 = a.gtab + a.o_S2;
+  const float* P = a.params;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = tid; i < IN; i += stride) {
+    float v = 0.f;
+    for (int e = 0; e <= K; ++e) v += S[(int64_t)e * HP + i];
+    a.grad[a.lay.g_b1 + i] = v;
+  }
+  for (int64_t i = tid; i < (int64_t)E * IN; i += stride) {
+    const int j = int(i / IN), n = int(i % IN);
+    float v = 0.f;
+    for (int e = 0; e <= K; ++e) v += P[a.lay.g_emb + (int64_t)(e < K ? e : K - 1) * E + j] * S[(int64_t)e * HP + n];
+    a.grad[a.lay.g_w1 + (int64_t)(D + j) * IN + n] = v;
+  }
+  for (int64_t i = tid; i < (int64_t)K * E; i += stride) {
+    const int row = int(i / E), j = int(i % E);
+    float v = 0.f;
+    for (int e = row; e <= (row == K - 1 ? K : row); ++e) {
+      v += S2[(int64_t)e * HP + D + j];
+      for (int n = 0; n < IN; ++n) v += P[a.lay.g_w1 + (int64_t)(D + j) * IN + n] * S[(int64_t)e * HP + n];
+    }
+    a.grad[a.lay.g_emb + i] = v;
+  }
+}
+
+// dds tail: S[e][n] = d / d bias1[e][n] with bias1[e] = sb1 + tau(e) sw1[D:, :], tau(e) the time coder
+// (nn_dds.py:131-143,155-158).  One 64-thread block per e recomputes the time path and back-propagates;
+// per-e contributions are accumulated with float atomics (257 adders per address).
+__global__ __launch_bounds__(64) void grad_dds_tail_kernel(TailArgs a) {
+  __shared__ float emb[128], arg_s[64], ha[64], hh[64], tau[64], dtau[64], dh[64], dact[64], demb[128];
+  const int j = threadIdx.x, t = blockIdx.x, D = a.D;
+  const float* P = a.params;
+  const float* S = a.gtab + a.o_S + (int64_t)t * 64;
+  {
+    const double step = (100.0 - 0.1) / 63.0;
+    const float cj = (j == 63) ? 100.0f : (float)((double)j * step + 0.1);
+    const float arg = cj * (float)t + P[a.lay.d_phase + j];
+    arg_s[j] = arg;
+    emb[j] = sinf(arg);
+    emb[64 + j] = cosf(arg);
+  }
+  __syncthreads();
+  float acc = P[a.lay.d_tb1 + j];
+  for (int k = 0; k < 128; ++k) acc = fmaf(emb[k], P[a.lay.d_tw1 + k * 64 + j], acc);
+  ha[j] = acc;
+  hh[j] = gelu_exact(acc);
+  __syncthreads();
+  acc = P[a.lay.d_tb2 + j];
+  for (int k = 0; k < 64; ++k) acc = fmaf(hh[k], P[a.lay.d_tw2 + k * 64 + j], acc);
+  tau[j] = acc;
+  __syncthreads();
+  // sb1, sw1[D:, :]
+  atomicAdd(a.grad + a.lay.d_sb1 + j, S[j]);
+  for (int k = 0; k < 64; ++k) atomicAdd(a.grad + a.lay.d_sw1 + (int64_t)(D + k) * 64 + j, tau[k] * S[j]);
+  // d tau_k = sum_n sw1[D+k][n] S[n]
+  acc = 0.f;
+  for (int n = 0; n < 64; ++n) acc = fmaf(P[a.lay.d_sw1 + (int64_t)(D + j) * 64 + n], S[n], acc);
+  dtau[j] = acc;
+  __syncthreads();
+  atomicAdd(a.grad + a.lay.d_tb2 + j, dtau[j]);
+  for (int k = 0; k < 64; ++k) atomicAdd(a.grad + a.lay.d_tw2 + k * 64 + j, hh[k] * dtau[j]);
+  acc = 0.f;
+  for (int n = 0; n < 64; ++n) acc = fmaf(P[a.lay.d_tw2 + j * 64 + n], dtau[n], acc);
+  dh[j] = acc;
+  // exact gelu': Phi(x) + x phi(x)
+  {
+    const float x = ha[j];
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+    dact[j] = dh[j] * (cdf + x * pdf);
+  }
+  __syncthreads();
+  atomicAdd(a.grad + a.lay.d_tb1 + j, dact[j]);
+  for (int k = 0; k < 128; ++k) atomicAdd(a.grad + a.lay.d_tw1 + k * 64 + j, emb[k] * dact[j]);
+  for (int q = 0; q < 2; ++q) {
+    const int k = j + 64 * q;
+    acc = 0.f;
+    for (int n = 0; n < 64; ++n) acc = fmaf(P[a.lay.d_tw1 + k * 64 + n], dact[n], acc);
+    demb[k] = acc;
+  }
+  __syncthreads();
+  // emb = [sin(arg), cos(arg)], arg = c t + phase:  d phase_j = demb_j cos(arg_j) - demb_{64+j} sin(arg_j)
+  atomicAdd(a.grad + a.lay.d_phase + j, demb[j] * emb[64 + j] - demb[64 + j] * emb[j]);
+}
+
+typedef void (*grad_fn)(GradArgs);
+
+static grad_fn pick_grad(const cmcd_desc& d, int T) {
+  if (d.arch == CMCD_ARCH_DDS && T == 4) {
+    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_DDS, 2, 4>;
+    if (d.target == CMCD_TARGET_GMM && d.dim == 2) return grad_kernel<CMCD_TARGET_GMM, CMCD_ARCH_DDS, 2, 4>;
+    return nullptr;
+  }
+  if (d.arch == CMCD_ARCH_GEFFNER) {
+    if (d.target == CMCD_TARGET_GMM && d.dim == 2 && T == 2) return grad_kernel<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER, 2, 2>;
+    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 2) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 2>;
+    if (d.target == CMCD_TARGET_FUNNEL && d.dim == 10 && T == 4) return grad_kernel<CMCD_TARGET_FUNNEL, CMCD_ARCH_GEFFNER, 10, 4>;
+  }
+  return nullptr;
+}
+
+bool grad_available(const cmcd_desc& d, int T) { return pick_grad(d, T) != nullptr; }
+
+static void grad_offsets(const cmcd_desc& d, int HP, int64_t& o_S, int64_t& o_S2, int64_t& o_gbeta, int64_t& o_geps,
+                         int64_t& o_gvd, int64_t& o_gfac, int64_t& total) {
+  const int64_t K = d.nbridges;
+  int64_t o = 0;
+  o_S = o; o += (K + 1) * HP;
+  o_S2 = o; o += (K + 1) * HP;
+  o_gbeta = o; o += (K + 3) & ~int64_t(3);
+  o_geps = o; o += (K + 3) & ~int64_t(3);
+  o_gvd = o; o += 32;
+  o_gfac = o; o += 4;
+  total = o;
+}
+
+static int grad_nslabs(int64_t n) {
+  const int64_t nquads = (n + 63) / 64;
+  return (int)(nquads < 256 ? nquads : 256);
+}
+
+int64_t grad_workspace_floats(const cmcd_desc& d, int HP, int64_t n) {
+  int64_t oS, oS2, ob, oe, ov, of, tot;
+  grad_offsets(d, HP, oS, oS2, ob, oe, ov, of, tot);
+  const int64_t slab = (int64_t)HP * HP + HP * 16 + 4 * (2 * 16 * HP + 256 + 32);
+  return tot + slab * grad_nslabs(n);
+}
+
+// ws_fwd: the forward workspace as left by cmcd_bound_forward's prep on the SAME desc/params;
+// gws: gradient workspace (grad_workspace_floats).  grad: [n_params], fully overwritten.
+int grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, const int32_t* seeds, int64_t n,
+                const float* params, int64_t n_params, const float* ws_fwd, const float* omega, float* gws,
+                float* grad, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  grad_fn fn = pick_grad(d, w.T);
+  if (!fn) return CMCD_ERR_UNSUPPORTED;
+  const int D = d.dim, HP = w.HP, K = d.nbridges;
+  GradArgs ga{};
+  int64_t tot;
+  grad_offsets(d, HP, ga.o_S, ga.o_S2, ga.o_gbeta, ga.o_geps, ga.o_gvd, ga.o_gfac, tot);
+  const int nslabs = grad_nslabs(n);
+  ga.seeds = seeds; ga.params = params; ga.ws = ws_fwd; ga.omega = omega; ga.gtab = gws; ga.slabs = gws + tot;
+  ga.lay = lay; ga.w = w; ga.n = n; ga.K = K; ga.var_mode = d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0;
+  ga.grad_clipping = d.grad_clipping; ga.nquads = (int)((n + 63) / 64);
+  ga.slab_stride = (int64_t)HP * HP + HP * 16 + 4 * (2 * 16 * HP + 256 + 32);
+  if (hipMemsetAsync(gws, 0, sizeof(float) * tot, stream) != hipSuccess) return CMCD_ERR_HIP;
+  if (hipMemsetAsync(grad, 0, sizeof(float) * n_params, stream) != hipSuccess) return CMCD_ERR_HIP;
+  const size_t lds_bytes = size_t(HP * HP + 2 * D * HP + HP + 16 + w.tgt_floats + 4 * (5 * HP + 32) * 16) * 4;
+  if (lds_bytes > 160 * 1024) return CMCD_ERR_UNSUPPORTED;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)lds_bytes) != hipSuccess)
+    return CMCD_ERR_HIP;
+  hipLaunchKernelGGL(fn, dim3(nslabs), dim3(256), lds_bytes, stream, ga);
+
+  TailArgs ta{};
+  ta.params = params; ta.ws = ws_fwd; ta.gtab = gws; ta.slabs = gws + tot; ta.grad = grad; ta.lay = lay; ta.w = w;
+  ta.o_S = ga.o_S; ta.o_S2 = ga.o_S2; ta.o_gbeta = ga.o_gbeta; ta.o_geps = ga.o_geps; ta.o_gvd = ga.o_gvd;
+  ta.o_gfac = ga.o_gfac; ta.slab_stride = ga.slab_stride; ta.n_params = n_params;
+  ta.K = K; ta.D = D; ta.E = d.emb_dim; ta.IN = D + d.emb_dim; ta.HP = HP; ta.arch = d.arch; ta.nslabs = nslabs;
+  ta.eps_schedule = d.eps_schedule; ta.ngrid = d.ngrid;
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3(64), dim3(256), 0, stream, ta);
+  hipLaunchKernelGGL(grad_sched_tail_kernel, dim3(1), dim3(64), 0, stream, ta);
+  if (d.arch == CMCD_ARCH_DDS) hipLaunchKernelGGL(grad_dds_tail_kernel, dim3(K + 1), dim3(64), 0, stream, ta);
+  else hipLaunchKernelGGL(grad_geffner_tail_kernel, dim3(64), dim3(256), 0, stream, ta);
+  return hipGetLastError() == hipSuccess ? CMCD_OK : CMCD_ERR_HIP;
+}
+
+}  // namespace cmcd

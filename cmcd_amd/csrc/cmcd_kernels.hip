@@ -677,6 +677,15 @@ __global__ __launch_bounds__(256) void finalize_kernel(const double* partials, i
   if (threadIdx.x < CMCD_NSTATS) out[threadIdx.x] = sh[0][threadIdx.x];
 }
 
+// omega_n = d var(l, ddof=0) / d w_n = -(2 / N)(l_n - mean l), from the merged statistics {.., sum l, ..}
+__global__ void vargrad_weights_kernel(const float* loss, const double* stats, int64_t n, int64_t n_total,
+                                       float* omega) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double mean = stats[1] / (double)n_total;
+  omega[i] = (float)(-2.0 / (double)n_total * ((double)loss[i] - mean));
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -704,6 +713,32 @@ static traj_fn pick_kernel(const cmcd_desc& d, int T) {
   if (d.target == CMCD_TARGET_GMM && d.dim == 2) return pick_T<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER, 2>(T);
   if (d.target == CMCD_TARGET_FUNNEL && d.dim == 10) return pick_T<CMCD_TARGET_FUNNEL, CMCD_ARCH_GEFFNER, 10>(T);
   return nullptr;
+}
+
+static void launch_prep(const cmcd_desc& d, const cmcd_layout& layr, const WsLayout& w, const float* params,
+                        const float* target_consts, int n_mix, float* ws, hipStream_t stream) {
+  const cmcd_layout* lay = &layr;
+  const int64_t K = d.nbridges, D = d.dim, E = d.emb_dim, IN = D + E;
+  PrepArgs pa{};
+  pa.sched = SchedArgs{params, ws, *lay, w, (int32_t)K, d.ngrid, d.eps_schedule, -1, -1};
+  PackArgs& pk = pa.pack;
+  pk.params = params; pk.tgt = target_consts; pk.ws = ws; pk.w = w;
+  pk.D = (int32_t)D; pk.target = d.target; pk.n_mix = n_mix;
+  if (d.arch == CMCD_ARCH_DDS) {
+    pa.dds = DdsPrepArgs{params, ws, *lay, w, (int32_t)D};
+    pk.o_w1 = lay->d_sw1; pk.o_w2 = lay->d_sw2; pk.o_b2 = lay->d_sb2; pk.o_w3 = lay->d_sw3;
+    pk.o_b3 = lay->d_sb3; pk.o_factor = -1; pk.IN = 64;
+  } else {
+    pa.gef = GefPrepArgs{params, ws, *lay, w, (int32_t)D, (int32_t)E, (int32_t)K};
+    pk.o_w1 = lay->g_w1; pk.o_w2 = lay->g_w2; pk.o_b2 = lay->g_b2; pk.o_w3 = lay->g_w3;
+    pk.o_b3 = lay->g_b3; pk.o_factor = lay->g_factor; pk.IN = (int32_t)IN;
+  }
+  pa.K = (int32_t)K; pa.arch = d.arch;
+  pa.npack = (w.HP * w.HP + 255) / 256;
+  if (pa.npack > 64) pa.npack = 64;
+  hipLaunchKernelGGL(prep_fused_kernel, dim3((unsigned)(K + 2 + pa.npack)), dim3(256), 0, stream, pa);
+
+
 }
 
 static int check_desc(const cmcd_desc* d) {
@@ -827,25 +862,7 @@ int cmcd_bound_forward(const cmcd_desc* desc, const cmcd_layout* lay, const int3
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   float* ws = static_cast<float*>(workspace);
 
-  PrepArgs pa{};
-  pa.sched = SchedArgs{params, ws, *lay, w, (int32_t)K, d.ngrid, d.eps_schedule, -1, -1};
-  PackArgs& pk = pa.pack;
-  pk.params = params; pk.tgt = target_consts; pk.ws = ws; pk.w = w;
-  pk.D = (int32_t)D; pk.target = d.target; pk.n_mix = n_mix;
-  if (d.arch == CMCD_ARCH_DDS) {
-    pa.dds = DdsPrepArgs{params, ws, *lay, w, (int32_t)D};
-    pk.o_w1 = lay->d_sw1; pk.o_w2 = lay->d_sw2; pk.o_b2 = lay->d_sb2; pk.o_w3 = lay->d_sw3;
-    pk.o_b3 = lay->d_sb3; pk.o_factor = -1; pk.IN = 64;
-  } else {
-    pa.gef = GefPrepArgs{params, ws, *lay, w, (int32_t)D, (int32_t)E, (int32_t)K};
-    pk.o_w1 = lay->g_w1; pk.o_w2 = lay->g_w2; pk.o_b2 = lay->g_b2; pk.o_w3 = lay->g_w3;
-    pk.o_b3 = lay->g_b3; pk.o_factor = lay->g_factor; pk.IN = (int32_t)IN;
-  }
-  pa.K = (int32_t)K; pa.arch = d.arch;
-  pa.npack = (w.HP * w.HP + 255) / 256;
-  if (pa.npack > 64) pa.npack = 64;
-  hipLaunchKernelGGL(prep_fused_kernel, dim3((unsigned)(K + 2 + pa.npack)), dim3(256), 0, stream, pa);
-
+  launch_prep(d, *lay, w, params, target_consts, n_mix, ws, stream);
 
   TrajArgs ta{seeds, params, ws, reinterpret_cast<double*>(ws + w.partials), out_loss, out_z, *lay, w, n,
               (int32_t)K, d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0, d.grad_clipping};
@@ -911,6 +928,57 @@ int cmcd_bound_forward(const cmcd_desc* desc, const cmcd_layout* lay, const int3
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, stream,
                      reinterpret_cast<const double*>(ws + w.partials), w.n_waves, out_stats);
   CMCD_HIP_CHECK(hipGetLastError());
+  return CMCD_OK;
+}
+
+int64_t cmcd_grad_workspace_bytes(const cmcd_desc* desc, int64_t n) {
+  if (check_desc(desc) != CMCD_OK || n < 1 || desc->target == CMCD_TARGET_LGCP) return 0;
+  WsLayout w;
+  const int64_t nt = desc->target == CMCD_TARGET_MANY_GMM ? 1 + 2 * 64 : 0;
+  if (!make_ws(*desc, n, nt, w)) return 0;
+  if (!grad_available(*desc, w.T)) {
+    fail(CMCD_ERR_UNSUPPORTED, "no gradient kernel instance for this (target, dim, arch, width)%s");
+    return 0;
+  }
+  return (align4(w.total_floats) + grad_workspace_floats(*desc, w.HP, n)) * 4;
+}
+
+int cmcd_vargrad_weights(const float* loss, const double* stats, int64_t n, int64_t n_total, float* omega,
+                         void* stream_) {
+  if (!loss || !stats || !omega || n < 1 || n_total < n) return fail(CMCD_ERR_BAD_ARG, "bad argument%s");
+  hipLaunchKernelGGL(vargrad_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream_), loss, stats, n, n_total, omega);
+  CMCD_HIP_CHECK(hipGetLastError());
+  return CMCD_OK;
+}
+
+int cmcd_bound_var_grad(const cmcd_desc* desc, const cmcd_layout* lay, const int32_t* seeds, int64_t n,
+                        const float* params, int64_t n_params, const float* target_consts, int64_t n_target,
+                        const float* omega, void* workspace, int64_t workspace_bytes, float* grad, void* stream_) {
+  int rc = check_desc(desc);
+  if (rc != CMCD_OK) return rc;
+  if (!lay || !seeds || !params || !omega || !workspace || !grad) return fail(CMCD_ERR_BAD_ARG, "null pointer argument%s");
+  if (desc->mode != CMCD_MODE_CAIS_VAR_SN)
+    return fail(CMCD_ERR_UNSUPPORTED, "the local (stop_gradient) gradient exists for MCD_CAIS_var_sn only%s");
+  if (desc->target == CMCD_TARGET_LGCP) return fail(CMCD_ERR_UNSUPPORTED, "no lgcp gradient%s");
+  const cmcd_desc& d = *desc;
+  int n_mix = 0;
+  if (d.target == CMCD_TARGET_MANY_GMM) {
+    if (!target_consts || n_target < 3 || (n_target - 1) % 2 != 0 || (n_target - 1) / 2 > 64)
+      return fail(CMCD_ERR_BAD_ARG, "many_gmm needs target_consts = {scale, means[n_mixes<=64][2]}%s");
+    n_mix = int((n_target - 1) / 2);
+  }
+  WsLayout w;
+  if (!make_ws(d, n, n_target, w)) return fail(CMCD_ERR_BAD_ARG, "bad descriptor%s");
+  if (!grad_available(d, w.T)) return fail(CMCD_ERR_UNSUPPORTED, "no gradient kernel instance for this (target, dim, arch, width)%s");
+  const int64_t need = (align4(w.total_floats) + grad_workspace_floats(d, w.HP, n)) * 4;
+  if (workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15))
+    return fail(CMCD_ERR_WORKSPACE, "workspace too small or not 16-byte aligned (need %s%lld bytes)", "", need);
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  float* ws = static_cast<float*>(workspace);
+  launch_prep(d, *lay, w, params, target_consts, n_mix, ws, stream);
+  rc = grad_launch(d, *lay, w, seeds, n, params, n_params, ws, omega, ws + align4(w.total_floats), grad, stream_);
+  if (rc != CMCD_OK) return fail(rc, "gradient launch failed%s");
   return CMCD_OK;
 }
 

@@ -263,3 +263,54 @@ def compute_bound_var(seeds, params_flat, unflatten, params_fixed, log_prob, eps
 def ln_z_from_stats(stats, n):
     """logsumexp(-losses) - log n (/root/reference/src/utils.py:233-235) from the statistics vector."""
     return stats[3] + torch.log(stats[4]) - torch.log(torch.tensor(float(n), dtype=torch.float64, device=stats.device))
+
+
+def compute_log_var_grad(seeds, params_flat, unflatten, params_fixed, log_prob, eps_schedule=None,
+                         grad_clipping=False, n_total=None, stats_total=None):
+    """Value-and-gradient of `compute_bound_var`: what the reference builds as
+    `jax.jit(jax.grad(compute_bound_fn, 1, has_aux=True))` (/root/reference/src/main.py:161-176) and calls as
+    `grad, (loss, z) = grad_and_loss(seeds, params_flat, unflatten, params_fixed, log_prob_model)`
+    (/root/reference/src/opt.py:97-99).  Returns (grad_flat, (losses, z)); `grad_flat` has the layout of
+    `params_flat` (zeros for leaves the loss does not reach).  `MCD_CAIS_var_sn` only: its per-step
+    `stop_gradient` (/root/reference/src/mcd_cais_var.py:59,79) makes the gradient local per bridge, which
+    is what the HIP kernel exploits.  Multi-GPU: pass the merged statistics and the global particle count
+    (`stats_total`, `n_total`) and all-reduce the returned gradient."""
+    dim, nbridges, mode, spec = params_fixed
+    if mode != "MCD_CAIS_var_sn":
+        raise NotImplementedError("Mode not implemented.")
+    losses, z, stats = bound_forward(seeds, params_flat, unflatten, params_fixed, log_prob,
+                                     eps_schedule=eps_schedule, grad_clipping=grad_clipping)
+    L = _lib.lib()
+    device = params_flat.device
+    seeds = torch.as_tensor(seeds)
+    if seeds.device != device or seeds.dtype != torch.int32 or not seeds.is_contiguous():
+        seeds = seeds.to(device=device, dtype=torch.int32).contiguous()
+    n = seeds.numel()
+    if eps_schedule not in _lib.EPS_SCHEDULE:
+        eps_schedule = None
+    desc = _lib.Desc(dim=dim, nbridges=nbridges, mode=_lib.MODE[mode], arch=_lib.ARCH[spec.arch],
+                     emb_dim=spec.emb_dim, target=log_prob.target_id,
+                     eps_schedule=_lib.EPS_SCHEDULE[eps_schedule], grad_clipping=int(bool(grad_clipping)),
+                     ngrid=unflatten.shape("mgridref_y")[0] - 1, reserved=0)
+    lay = _layout(unflatten, spec)
+    nbytes = L.cmcd_grad_workspace_bytes(C.byref(desc), n)
+    if nbytes <= 0:
+        raise NotImplementedError(_lib.last_error() or "no gradient kernel for this configuration")
+    key = str(device) + ":grad"
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    consts = log_prob.consts_on(device)
+    omega = torch.empty(n, dtype=torch.float32, device=device)
+    grad = torch.empty_like(params_flat)
+    st = stats if stats_total is None else stats_total
+    with torch.cuda.device(device):
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(L.cmcd_vargrad_weights(losses.data_ptr(), st.data_ptr(), n, n if n_total is None else int(n_total),
+                                          omega.data_ptr(), stream))
+        _lib.check(L.cmcd_bound_var_grad(
+            C.byref(desc), C.byref(lay), seeds.data_ptr(), n, params_flat.data_ptr(), params_flat.numel(),
+            consts.data_ptr() if consts is not None else None, consts.numel() if consts is not None else 0,
+            omega.data_ptr(), ws.data_ptr(), ws.numel(), grad.data_ptr(), stream))
+    return grad, (losses, z)

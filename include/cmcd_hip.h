@@ -130,6 +130,22 @@ int cmcd_bound_forward(const cmcd_desc* desc, const cmcd_layout* layout,
 int cmcd_profile_enable(int on);
 int cmcd_profile_collect(double* total_ms, int64_t* launches);
 
+/* ---- VarGrad gradient ("compute_log_var_grad"): d/d params_flat of compute_bound_var
+ * (/root/reference/src/main.py:161-176 takes jax.grad of it; /root/reference/src/mcd_cais_var.py:59,79
+ * detach z, which makes the gradient local per bridge).  Two calls after a cmcd_bound_forward on the
+ * same seeds / params:
+ *   cmcd_vargrad_weights  omega[n] = d var / d w_n = -(2/N)(l_n - mean l) from loss[n] and the (merged,
+ *                         for multi-GPU) statistics; n_total = global particle count.
+ *   cmcd_bound_var_grad   grad[n_params] (overwritten; zeros for leaves without gradient) =
+ *                         sum_n omega_n d w_n / d params_flat.  Across ranks: all-reduce(sum) of grad.
+ * MCD_CAIS_var_sn only; hidden width <= 64 in this build (CMCD_ERR_UNSUPPORTED otherwise). */
+int64_t cmcd_grad_workspace_bytes(const cmcd_desc* desc, int64_t n);
+int cmcd_vargrad_weights(const float* loss, const double* stats, int64_t n, int64_t n_total, float* omega,
+                         void* stream);
+int cmcd_bound_var_grad(const cmcd_desc* desc, const cmcd_layout* layout, const int32_t* seeds, int64_t n,
+                        const float* params, int64_t n_params, const float* target_consts, int64_t n_target,
+                        const float* omega, void* workspace, int64_t workspace_bytes, float* grad, void* stream);
+
 /* Device-side merge of `count` statistics vectors rows[count][5] (e.g. the result of an RCCL
  * all-gather of every rank's out_stats, in rank order) into out5[5], fixed order, one small kernel
  * on `stream`.  [device] pointers. */

@@ -1,0 +1,86 @@
+"""VarGrad gradient (compute_log_var_grad) of the HIP path vs torch-autograd on the float64 restatement."""
+import numpy as np
+import pytest
+import torch
+
+from cmcd_amd import mcdboundingmachine as mcdbm
+from cmcd_amd import synthetic
+from oracle import cmcd_oracle_torch as ot
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_grad_flat(b, seeds):
+    """The oracle's gradient re-assembled in params_flat order."""
+    cfg = b["cfg"]
+    dim, K, mode, spec = b["params_fixed"]
+    p = synthetic.oracle_params(b["unflatten"], b["params_flat"])
+    val, losses, z, g = ot.bound_and_grad(seeds, p, dim, K, mode, spec.arch, cfg["model"], cfg["eps_schedule"],
+                                          cfg["grad_clipping"])
+    flat = torch.zeros(b["params_flat"].numel(), dtype=torch.float64)
+    train, notrain = b["unflatten"](flat)
+    allp = {**train, **notrain}
+    t = lambda a: torch.as_tensor(np.asarray(a))
+    allp["vd"]["mean"].copy_(t(g["vd"]["mean"])); allp["vd"]["logdiag"].copy_(t(g["vd"]["logdiag"]))
+    allp["eps"].copy_(t(g["eps"])); allp["mgridref_y"].copy_(t(g["mgridref_y"]))
+    sn, gs = allp["sn"], g["sn"]
+    if "nn" in sn:
+        (w1, b1), (w2, b2), (w3, b3) = sn["nn"]
+        for dst, k in ((w1, "W1"), (b1, "b1"), (w2, "W2"), (b2, "b2"), (w3, "W3"), (b3, "b3")):
+            dst.copy_(t(gs[k]))
+        sn["emb"].copy_(t(gs["emb"])); sn["factor_sn"].copy_(t(gs["factor_sn"]))
+    else:
+        m = lambda n: sn["drift_net/~/" + n]
+        sn["drift_net"]["timestep_phase"].copy_(t(gs["timestep_phase"]))
+        for mod, (wk, bk) in (("linear", ("t_w1", "t_b1")), ("linear_1", ("t_w2", "t_b2")), ("linear_2", ("s_w1", "s_b1")),
+                              ("linear_3", ("s_w2", "s_b2")), ("linear_zero", ("s_w3", "s_b3"))):
+            m(mod)["w"].copy_(t(gs[wk])); m(mod)["b"].copy_(t(gs[bk]))
+    return val, losses, flat
+
+
+CASES = [
+    ("many_gmm_n2000_k256_dds", 96, dict(boundmode="MCD_CAIS_var_sn", nbridges=8, init_sigma=15.0)),
+    ("many_gmm_n2000_k256_dds", 50, dict(boundmode="MCD_CAIS_var_sn", nbridges=5, init_sigma=15.0, eps_schedule="linear",
+                                         init_eps=0.3)),
+    ("gmm_n300_k8", 128, dict(boundmode="MCD_CAIS_var_sn", grad_clipping=True)),
+    ("funnel_n300_k64", 70, dict(boundmode="MCD_CAIS_var_sn", nbridges=6)),
+    ("many_gmm_var_n16000_k256", 64, dict(nbridges=6, emb_dim=20)),
+]
+
+
+@pytest.mark.parametrize("name,n,over", CASES)
+def test_vargrad_matches_autograd(hip_lib, name, n, over):
+    b = synthetic.build(name, device="cuda", **over)
+    seeds = synthetic.parity_seeds(n)
+    grad, (losses, z) = mcdbm.compute_log_var_grad(torch.from_numpy(seeds).cuda(), b["params_flat"], b["unflatten"],
+                                                   b["params_fixed"], b["target"], eps_schedule=b["eps_schedule"],
+                                                   grad_clipping=b["grad_clipping"])
+    torch.cuda.synchronize()
+    val, l_ref, g_ref = oracle_grad_flat(b, seeds)
+    assert np.isfinite(l_ref).all(), "pick a case without +inf particles for the gradient check"
+    g = grad.double().cpu()
+    un = b["unflatten"]
+    worst = {}
+    for path, (off, shape) in un.layout.items():
+        numel = max(1, int(np.prod(shape)))
+        a, r = g[off:off + numel], g_ref[off:off + numel]
+        scale = max(float(r.abs().max()), 1e-12)
+        err = float((a - r).abs().max())
+        worst["/".join(map(str, path))] = (err / scale, scale)
+        if float(r.abs().max()) == 0.0:
+            assert float(a.abs().max()) == 0.0, f"{path}: expected exactly zero gradient"
+    bad = {k: v for k, v in worst.items() if v[0] > 2e-3 and v[1] > 1e-9}
+    print(name, over, {k: "%.1e" % v[0] for k, v in worst.items()})
+    assert not bad, f"gradient mismatch (max abs err / max |ref|, max |ref|): {bad}"
+    cos = float((g * g_ref).sum() / (g.norm() * g_ref.norm()))
+    assert cos > 1 - 1e-5
+
+
+def test_unsupported_configurations_fail_loudly(hip_lib):
+    b = synthetic.build("many_gmm_var_n16000_k256", device="cuda", nbridges=4)      # 132-wide net
+    seeds = torch.arange(1, 33, dtype=torch.int32).cuda()
+    with pytest.raises(NotImplementedError):
+        mcdbm.compute_log_var_grad(seeds, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"])
+    b = synthetic.build("gmm_n300_k8", device="cuda")                                 # MCD_CAIS_sn
+    with pytest.raises(NotImplementedError, match="Mode not implemented."):
+        mcdbm.compute_log_var_grad(seeds, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"])
