@@ -524,17 +524,30 @@ struct TailArgs {
   int32_t K, D, E, IN, HP, arch, nslabs, eps_schedule, ngrid;
 };
 
+// fixed-order sums over the workgroup slabs; four independent partial sums keep the loads in flight
 __device__ __forceinline__ float slab_sum(const TailArgs& a, int64_t off) {
-  float v = 0.f;
-  for (int s = 0; s < a.nslabs; ++s) v += a.slabs[(int64_t)s * a.slab_stride + off];
-  return v;
+  float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+  int s = 0;
+  for (; s + 4 <= a.nslabs; s += 4) {
+    v0 += a.slabs[(int64_t)s * a.slab_stride + off];
+    v1 += a.slabs[(int64_t)(s + 1) * a.slab_stride + off];
+    v2 += a.slabs[(int64_t)(s + 2) * a.slab_stride + off];
+    v3 += a.slabs[(int64_t)(s + 3) * a.slab_stride + off];
+  }
+  for (; s < a.nslabs; ++s) v0 += a.slabs[(int64_t)s * a.slab_stride + off];
+  return (v0 + v1) + (v2 + v3);
 }
 __device__ __forceinline__ float wave_slab_sum(const TailArgs& a, int64_t off) {  // per-wave regions, 4 per slab
   const int64_t per = 2 * 16 * a.HP + 256 + 32, base = (int64_t)a.HP * a.HP + a.HP * 16;
-  float v = 0.f;
-  for (int s = 0; s < a.nslabs; ++s)
-    for (int w = 0; w < 4; ++w) v += a.slabs[(int64_t)s * a.slab_stride + base + w * per + off];
-  return v;
+  float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+  for (int s = 0; s < a.nslabs; ++s) {
+    const float* q = a.slabs + (int64_t)s * a.slab_stride + base + off;
+    v0 += q[0];
+    v1 += q[per];
+    v2 += q[2 * per];
+    v3 += q[3 * per];
+  }
+  return (v0 + v1) + (v2 + v3);
 }
 
 // grid-stride over every entry of grad_flat that is a plain sum of slab entries
@@ -567,51 +580,54 @@ __global__ void grad_reduce_kernel(TailArgs a) {
   if (tid == 0 && !dds) a.grad[a.lay.g_factor] = wave_slab_sum(a, 2 * 16 * HP + 256);
 }
 
-// d / d eps0 and d / d mgridref_y from the per-step tables (one block)
-__global__ void grad_sched_tail_kernel(TailArgs a) {
-  __shared__ float gm[40], gyg[40];
+// d / d eps0 and d / d mgridref_y from the per-step tables (one 256-thread block, thread per bridge)
+__global__ __launch_bounds__(256) void grad_sched_tail_kernel(TailArgs a) {
+  __shared__ float gyg[40], gyv[40], red[256];
   const int K = a.K, G = a.ngrid;
   const float* gbeta = a.gtab + a.o_gbeta;
   const float* geps = a.gtab + a.o_geps;
-  if (threadIdx.x == 0) {
-    float ge = 0.f;
-    for (int i = 0; i < K; ++i) {
-      float dedeps0 = 1.0f;                                                       // constant schedule
-      if (a.eps_schedule == CMCD_EPS_COS_SQ) {
-        const float cs = cosf(((float)i / (float)K + 0.008f) / 1.008f * 0.5f * 3.14159265358979323846f);
-        dedeps0 = cs * cs;
-      } else if (a.eps_schedule == CMCD_EPS_LINEAR) {
-        dedeps0 = 1.0f - (float)i / (float)(K - 1);
-      }
-      ge += geps[i] * dedeps0;
+  if (threadIdx.x < 40) gyg[threadIdx.x] = 0.f;
+  __syncthreads();
+  float ge = 0.f;
+  for (int i = threadIdx.x; i < K; i += blockDim.x) {
+    float dedeps0 = 1.0f;                                                         // constant schedule
+    if (a.eps_schedule == CMCD_EPS_COS_SQ) {
+      const float cs = cosf(((float)i / (float)K + 0.008f) / 1.008f * 0.5f * 3.14159265358979323846f);
+      dedeps0 = cs * cs;
+    } else if (a.eps_schedule == CMCD_EPS_LINEAR) {
+      dedeps0 = 1.0f - (float)i / (float)(K - 1);
     }
-    a.grad[a.lay.eps] = ge;
+    ge += geps[i] * dedeps0;
     // beta_i = gy[j-1] + frac_i (gy[j] - gy[j-1]),  gy = [0, cumsum(m)/sum(m)]
-    for (int q = 0; q <= G + 1; ++q) gyg[q] = 0.f;
-    for (int i = 0; i < K; ++i) {
-      const float x = (float)(i + 1) / (float)(K + 1);
-      int j = 1;
-      while (j < G + 1 && (float)j / (float)(G + 1) <= x) ++j;
-      const float x0 = (float)(j - 1) / (float)(G + 1), x1 = (float)j / (float)(G + 1);
-      const float fr = (x - x0) / (x1 - x0);
-      gyg[j - 1] += gbeta[i] * (1.0f - fr);
-      gyg[j] += gbeta[i] * fr;
-    }
+    const float x = (float)(i + 1) / (float)(K + 1);
+    int j = 1;
+    while (j < G + 1 && (float)j / (float)(G + 1) <= x) ++j;
+    const float x0 = (float)(j - 1) / (float)(G + 1), x1 = (float)j / (float)(G + 1);
+    const float fr = (x - x0) / (x1 - x0);
+    atomicAdd(&gyg[j - 1], gbeta[i] * (1.0f - fr));
+    atomicAdd(&gyg[j], gbeta[i] * fr);
+  }
+  red[threadIdx.x] = ge;
+  __syncthreads();
+  for (int s2 = 128; s2 > 0; s2 >>= 1) {
+    if (threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    a.grad[a.lay.eps] = red[0];
     // gy[q] = C_q / S, C_q = sum_{r<q} m_r (q >= 1), S = sum m:  d gy[q] / d m_r = ([r < q] - gy[q]) / S
     const float* m = a.params + a.lay.mgridref_y;
     float S = 0.f;
     for (int r = 0; r <= G; ++r) S += m[r];
     float run = 0.f, dot = 0.f;
-    float gyv[40];
     gyv[0] = 0.f;
     for (int r = 0; r <= G; ++r) { run += m[r]; gyv[r + 1] = run / S; }
     for (int q = 1; q <= G + 1; ++q) dot += gyg[q] * gyv[q];
     float suffix = 0.f;  // sum_{q > r} gyg[q]
     for (int r = G; r >= 0; --r) {
       suffix += gyg[r + 1];
-      gm[r] = (suffix - dot) / S;
+      a.grad[a.lay.mgridref_y + r] = (suffix - dot) / S;
     }
-    for (int r = 0; r <= G; ++r) a.grad[a.lay.mgridref_y + r] = gm[r];
   }
 }
 
@@ -781,8 +797,8 @@ int grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, c
   ta.o_gfac = ga.o_gfac; ta.slab_stride = ga.slab_stride; ta.n_params = n_params;
   ta.K = K; ta.D = D; ta.E = d.emb_dim; ta.IN = D + d.emb_dim; ta.HP = HP; ta.arch = d.arch; ta.nslabs = nslabs;
   ta.eps_schedule = d.eps_schedule; ta.ngrid = d.ngrid;
-  hipLaunchKernelGGL(grad_reduce_kernel, dim3(64), dim3(256), 0, stream, ta);
-  hipLaunchKernelGGL(grad_sched_tail_kernel, dim3(1), dim3(64), 0, stream, ta);
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3(32), dim3(256), 0, stream, ta);
+  hipLaunchKernelGGL(grad_sched_tail_kernel, dim3(1), dim3(256), 0, stream, ta);
   if (d.arch == CMCD_ARCH_DDS) hipLaunchKernelGGL(grad_dds_tail_kernel, dim3(K + 1), dim3(64), 0, stream, ta);
   else hipLaunchKernelGGL(grad_geffner_tail_kernel, dim3(64), dim3(256), 0, stream, ta);
   return hipGetLastError() == hipSuccess ? CMCD_OK : CMCD_ERR_HIP;

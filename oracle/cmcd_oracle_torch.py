@@ -189,4 +189,4 @@ def bound_and_grad(seeds, params_np, dim, nbridges, mode, arch, target_name, eps
         for k in path[:-1]:
             d = d.setdefault(k, {})
         d[path[-1]] = np.zeros(tuple(v.shape)) if g is None else g.detach().numpy()
-    return float(value), l.detach().numpy(), z.detach().numpy(), grads
+    return float(value.detach()), l.detach().numpy(), z.detach().numpy(), grads

@@ -91,3 +91,48 @@ def test_merge_stats_matches_c_abi():
     np.testing.assert_allclose(m.numpy(), merged_c, rtol=1e-14)
     f = parallel.finalize(m, 106)
     assert abs(float(f["mean"]) - mean) < 1e-13 and abs(float(f["ln_z"]) - lnz) < 1e-13
+
+
+def _grad_worker(rank, world, port, n, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import cmcd_oracle_torch as ot
+    from oracle.cmcd_oracle import stats5
+    b = synthetic.build("gmm_n300_k8", device="cpu", boundmode="MCD_CAIS_var_sn", nbridges=3)
+    dim, K, mode, spec = b["params_fixed"]
+    p = synthetic.oracle_params(b["unflatten"], b["params_flat"])
+
+    def fwd(seeds):
+        loss, z = run_oracle(b, seeds.numpy(), dtype=np.float64)
+        return torch.from_numpy(loss), torch.from_numpy(z), torch.from_numpy(stats5(loss))
+
+    def grad(seeds, losses, stats, n_total):
+        # local sum_n omega_n dw_n/dtheta with omega from the GLOBAL mean: autograd of sum(omega * w)
+        pt = ot.to_torch(p)
+        l, _ = ot.losses(seeds.numpy(), pt, dim, K, mode, spec.arch, "gmm", b["cfg"]["eps_schedule"], False)
+        mean = float(stats[1]) / n_total
+        omega = (-2.0 / n_total) * (l.detach() - mean)
+        (g,) = torch.autograd.grad((omega * (-l)).sum(), [pt["sn"]["W3"]])
+        return g.reshape(-1).clone()
+
+    seeds = torch.from_numpy(synthetic.parity_seeds(n))
+    r = parallel.sharded_var_grad(seeds, fwd, grad)
+    out[rank] = (r["grad"].numpy(), float(r["var"]))
+    dist.destroy_process_group()
+
+
+def test_sharded_vargrad_equals_single_process():
+    """Two ranks, global mean through the statistics merge, one gradient all-reduce == one process."""
+    from oracle import cmcd_oracle_torch as ot
+    n = 22
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_grad_worker, args=(2, _free_port(), n, out), nprocs=2, join=True)
+    b = synthetic.build("gmm_n300_k8", device="cpu", boundmode="MCD_CAIS_var_sn", nbridges=3)
+    dim, K, mode, spec = b["params_fixed"]
+    p = synthetic.oracle_params(b["unflatten"], b["params_flat"])
+    val, _, _, g = ot.bound_and_grad(synthetic.parity_seeds(n), p, dim, K, mode, spec.arch, "gmm",
+                                     b["cfg"]["eps_schedule"], False)
+    for r in (0, 1):
+        np.testing.assert_allclose(out[r][0], g["sn"]["W3"].reshape(-1), rtol=1e-9, atol=1e-12)
+        assert abs(out[r][1] - val) < 1e-9
