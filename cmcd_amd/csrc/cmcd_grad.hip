@@ -21,7 +21,8 @@
 // quantities (bias-table, beta, eps gradients) go to small global tables by float atomics; the
 // particle-independent tails (time coder / embedding / schedules) are small kernels at the end.
 //
-// Scope: hidden width <= 64 (T <= 4).  The 132-wide net needs a different accumulator plan (next).
+// Widths <= 64 keep W2 / W2^T fragments in LDS with 4 tiles per workgroup; the 132-wide net (T = 9) runs 3
+// tiles per workgroup (3 accumulator row tiles per wave) and streams both fragment copies from L2.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -50,14 +51,17 @@ struct GradArgs {
 // element (feature f, particle p) of a staged [features][16] array
 __device__ __forceinline__ int sw(int f, int p) { return f * 16 + (p ^ (f & 15)); }
 
-template <int TARGET, int ARCH, int D, int T>
-__global__ __launch_bounds__(256) void grad_kernel(GradArgs a) {
+// NW waves per workgroup (one tile each); WGLOBAL: W2 / W2^T fragments streamed from L2 instead of LDS
+template <int TARGET, int ARCH, int D, int T, int NW, bool WGLOBAL>
+__global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
   constexpr int HP = 16 * T;
   constexpr int Hh = (D + 1) / 2;
   constexpr bool GEF = ARCH == CMCD_ARCH_GEFFNER;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* lds_w2 = lds;                    // HP*HP   forward A fragments
-  float* lds_w1z = lds_w2 + HP * HP;      // D*HP
+  constexpr int WLDS = WGLOBAL ? 0 : 2 * HP * HP;
+  float* lds_w2 = lds;                    // HP*HP   forward A fragments   (absent when WGLOBAL)
+  float* lds_w2t = lds + HP * HP;         // HP*HP   A fragments of W2^T
+  float* lds_w1z = lds + WLDS;            // D*HP
   float* lds_w3t = lds_w1z + D * HP;      // D*HP
   float* lds_b2 = lds_w3t + D * HP;       // HP
   float* lds_b3 = lds_b2 + HP;            // 16
@@ -68,9 +72,11 @@ __global__ __launch_bounds__(256) void grad_kernel(GradArgs a) {
     const f32x4* src = reinterpret_cast<const f32x4*>(a.ws + a.w.w1z);
     f32x4* dst = reinterpret_cast<f32x4*>(lds_w1z);
     for (int i = threadIdx.x; i < D * HP / 4; i += blockDim.x) dst[i] = src[i];
-    src = reinterpret_cast<const f32x4*>(a.ws + a.w.w2);
-    dst = reinterpret_cast<f32x4*>(lds_w2);
-    for (int i = threadIdx.x; i < HP * HP / 4; i += blockDim.x) dst[i] = src[i];
+    if (!WGLOBAL) {
+      src = reinterpret_cast<const f32x4*>(a.ws + a.w.w2);   // w2 and w2t are adjacent in the workspace
+      dst = reinterpret_cast<f32x4*>(lds_w2);
+      for (int i = threadIdx.x; i < 2 * HP * HP / 4; i += blockDim.x) dst[i] = src[i];
+    }
     src = reinterpret_cast<const f32x4*>(a.ws + a.w.w3t);
     dst = reinterpret_cast<f32x4*>(lds_w3t);
     for (int i = threadIdx.x; i < D * HP / 4; i += blockDim.x) dst[i] = src[i];
@@ -91,6 +97,8 @@ __global__ __launch_bounds__(256) void grad_kernel(GradArgs a) {
   float* doT = z1T + 256;                 // rows 0..D-1 = d o_j, rest 0
   const int K = a.K;
   const float factor = lds_b3[15];
+  const float* w2f = WGLOBAL ? a.ws + a.w.w2 : lds_w2;
+  const float* w2tf = WGLOBAL ? a.ws + a.w.w2t : lds_w2t;
 
   float qmean[D], qstd[D], qiv[D];
 #pragma unroll
@@ -108,7 +116,7 @@ __global__ __launch_bounds__(256) void grad_kernel(GradArgs a) {
   float* gS2 = a.gtab + a.o_S2;
 
   // persistent accumulators (C layout: lane (g,c), reg r <-> row 16*tile + 4g + r, col 16*tile' + c)
-  constexpr int OWN = (T + 3) / 4;        // dW2 / dW3 row tiles owned by this wave: ti = wv + 4*k < T
+  constexpr int OWN = (T + NW - 1) / NW;  // dW2 / dW3 row tiles owned by this wave: ti = wv + NW*k < T
   f32x4 gW2[OWN][T], gW3[OWN];
   f32x4 gZ1[T];                           // rows j < D: dW1z[j][n]
   f32x4 gB2[T];                           // row D: db2[n]   (A = z1 against da2)
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(256) void grad_kernel(GradArgs a) {
   for (int j = 0; j < D; ++j) { gmu[j] = 0.f; glam[j] = 0.f; }
 
   for (int quad = blockIdx.x; quad < a.nquads; quad += gridDim.x) {
-    const int64_t tile = (int64_t)quad * 4 + wv;
+    const int64_t tile = (int64_t)quad * NW + wv;
     const int64_t p = tile * 16 + c;
     const bool valid = p < a.n;
     const int32_t seed = a.seeds[valid ? p : a.n - 1];
@@ -215,7 +223,7 @@ __global__ __launch_bounds__(256) void grad_kernel(GradArgs a) {
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int to = 0; to < T; ++to) {
-          const f32x4 af = *reinterpret_cast<const f32x4*>(lds_w2 + ((ti * T + to) * 64 + lane) * 4);
+          const f32x4 af = *reinterpret_cast<const f32x4*>(w2f + ((ti * T + to) * 64 + lane) * 4);
 #pragma unroll
           for (int r = 0; r < 4; ++r) a2[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r], u1[ti][r], a2[to], 0, 0, 0);
         }
@@ -356,7 +364,7 @@ __global__ __launch_bounds__(256) void grad_kernel(GradArgs a) {
         for (int r = 0; r < 4; ++r) d2[t][r] = du2[r] * (GEF ? sigmoid_fast(a2[t][r]) : gelu_grad_fast(a2[t][r]));
         if (GEF) a2[t] = du2;  // keep d u2 (residual path) in a2's registers
       }
-      // d u1 = [d u2 +] W2 d a2 : rows = input neuron k, contraction over output neuron n (gathered A')
+      // d u1 = [d u2 +] W2 d a2 : rows = input neuron k, contraction over output neuron n (W2^T fragments)
       f32x4 d1[T];
 #pragma unroll
       for (int tk = 0; tk < T; ++tk) d1[tk] = GEF ? a2[tk] : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -365,12 +373,9 @@ __global__ __launch_bounds__(256) void grad_kernel(GradArgs a) {
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int tk = 0; tk < T; ++tk) {
+          const f32x4 af = *reinterpret_cast<const f32x4*>(w2tf + ((tk * T + tn) * 64 + lane) * 4);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            // A'[i = c][kk = g] = W2[16 tk + c][16 tn + 4 g + r] from the forward packing
-            const float av = lds_w2[((tk * T + tn) * 64 + (c >> 2) * 16 + 4 * g + r) * 4 + (c & 3)];
-            d1[tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, d2[tn][r], d1[tk], 0, 0, 0);
-          }
+          for (int r = 0; r < 4; ++r) d1[tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r], d2[tn][r], d1[tk], 0, 0, 0);
         }
       }
       f32x4 du1s[T];
@@ -439,10 +444,10 @@ __global__ __launch_bounds__(256) void grad_kernel(GradArgs a) {
       }
 #pragma unroll
       for (int k = 0; k < OWN; ++k) {
-        const int ti = wv + 4 * k;
+        const int ti = wv + NW * k;
         if (ti < T) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {  // all four tiles of the workgroup
+          for (int q = 0; q < NW; ++q) {  // all tiles of the workgroup
             const float* base = stage + q * STG;
             float xa[4], x2[4];
 #pragma unroll
@@ -477,7 +482,7 @@ __global__ __launch_bounds__(256) void grad_kernel(GradArgs a) {
   // layout: dW2 [HP][HP] | dW3 [HP][16] | per wave: gZ1 [16][HP], gB2 [16][HP], gB3 [16][16], scalars [32]
 #pragma unroll
   for (int k = 0; k < OWN; ++k) {
-    const int ti = wv + 4 * k;
+    const int ti = wv + NW * k;
     if (ti < T) {
 #pragma unroll
       for (int to = 0; to < T; ++to)
@@ -521,7 +526,7 @@ struct TailArgs {
   cmcd_layout lay;
   WsLayout w;
   int64_t o_S, o_S2, o_gbeta, o_geps, o_gvd, o_gfac, slab_stride, n_params;
-  int32_t K, D, E, IN, HP, arch, nslabs, eps_schedule, ngrid;
+  int32_t K, D, E, IN, HP, arch, nslabs, eps_schedule, ngrid, nw;
 };
 
 // fixed-order sums over the workgroup slabs; four independent partial sums keep the loads in flight
@@ -545,7 +550,7 @@ __device__ __forceinline__ float wave_slab_sum(const TailArgs& a, int64_t off) {
     v0 += q[0];
     v1 += q[per];
     v2 += q[2 * per];
-    v3 += q[3 * per];
+    if (a.nw > 3) v3 += q[3 * per];
   }
   return (v0 + v1) + (v2 + v3);
 }
@@ -724,16 +729,19 @@ __global__ __launch_bounds__(64) void grad_dds_tail_kernel(TailArgs a) {
 
 typedef void (*grad_fn)(GradArgs);
 
+static int grad_nw(int T) { return T > 4 ? 3 : 4; }
+
 static grad_fn pick_grad(const cmcd_desc& d, int T) {
   if (d.arch == CMCD_ARCH_DDS && T == 4) {
-    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_DDS, 2, 4>;
-    if (d.target == CMCD_TARGET_GMM && d.dim == 2) return grad_kernel<CMCD_TARGET_GMM, CMCD_ARCH_DDS, 2, 4>;
+    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_DDS, 2, 4, 4, false>;
+    if (d.target == CMCD_TARGET_GMM && d.dim == 2) return grad_kernel<CMCD_TARGET_GMM, CMCD_ARCH_DDS, 2, 4, 4, false>;
     return nullptr;
   }
   if (d.arch == CMCD_ARCH_GEFFNER) {
-    if (d.target == CMCD_TARGET_GMM && d.dim == 2 && T == 2) return grad_kernel<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER, 2, 2>;
-    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 2) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 2>;
-    if (d.target == CMCD_TARGET_FUNNEL && d.dim == 10 && T == 4) return grad_kernel<CMCD_TARGET_FUNNEL, CMCD_ARCH_GEFFNER, 10, 4>;
+    if (d.target == CMCD_TARGET_GMM && d.dim == 2 && T == 2) return grad_kernel<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER, 2, 2, 4, false>;
+    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 2) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 2, 4, false>;
+    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 9) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 9, 3, true>;
+    if (d.target == CMCD_TARGET_FUNNEL && d.dim == 10 && T == 4) return grad_kernel<CMCD_TARGET_FUNNEL, CMCD_ARCH_GEFFNER, 10, 4, 4, false>;
   }
   return nullptr;
 }
@@ -753,8 +761,8 @@ static void grad_offsets(const cmcd_desc& d, int HP, int64_t& o_S, int64_t& o_S2
   total = o;
 }
 
-static int grad_nslabs(int64_t n) {
-  const int64_t nquads = (n + 63) / 64;
+static int grad_nslabs(int64_t n, int nw) {
+  const int64_t nquads = (n + 16 * nw - 1) / (16 * nw);
   return (int)(nquads < 256 ? nquads : 256);
 }
 
@@ -762,7 +770,7 @@ int64_t grad_workspace_floats(const cmcd_desc& d, int HP, int64_t n) {
   int64_t oS, oS2, ob, oe, ov, of, tot;
   grad_offsets(d, HP, oS, oS2, ob, oe, ov, of, tot);
   const int64_t slab = (int64_t)HP * HP + HP * 16 + 4 * (2 * 16 * HP + 256 + 32);
-  return tot + slab * grad_nslabs(n);
+  return tot + slab * grad_nslabs(n, grad_nw(HP / 16));
 }
 
 // ws_fwd: the forward workspace as left by cmcd_bound_forward's prep on the SAME desc/params;
@@ -777,26 +785,27 @@ int grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, c
   GradArgs ga{};
   int64_t tot;
   grad_offsets(d, HP, ga.o_S, ga.o_S2, ga.o_gbeta, ga.o_geps, ga.o_gvd, ga.o_gfac, tot);
-  const int nslabs = grad_nslabs(n);
+  const int nw = grad_nw(w.T);
+  const int nslabs = grad_nslabs(n, nw);
   ga.seeds = seeds; ga.params = params; ga.ws = ws_fwd; ga.omega = omega; ga.gtab = gws; ga.slabs = gws + tot;
   ga.lay = lay; ga.w = w; ga.n = n; ga.K = K; ga.var_mode = d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0;
-  ga.grad_clipping = d.grad_clipping; ga.nquads = (int)((n + 63) / 64);
+  ga.grad_clipping = d.grad_clipping; ga.nquads = (int)((n + 16 * nw - 1) / (16 * nw));
   ga.slab_stride = (int64_t)HP * HP + HP * 16 + 4 * (2 * 16 * HP + 256 + 32);
   if (hipMemsetAsync(gws, 0, sizeof(float) * tot, stream) != hipSuccess) return CMCD_ERR_HIP;
   if (hipMemsetAsync(grad, 0, sizeof(float) * n_params, stream) != hipSuccess) return CMCD_ERR_HIP;
-  const size_t lds_bytes = size_t(HP * HP + 2 * D * HP + HP + 16 + w.tgt_floats + 4 * (5 * HP + 32) * 16) * 4;
+  const size_t lds_bytes = size_t((w.T > 4 ? 0 : 2 * HP * HP) + 2 * D * HP + HP + 16 + w.tgt_floats + nw * (5 * HP + 32) * 16) * 4;
   if (lds_bytes > 160 * 1024) return CMCD_ERR_UNSUPPORTED;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)lds_bytes) != hipSuccess)
     return CMCD_ERR_HIP;
-  hipLaunchKernelGGL(fn, dim3(nslabs), dim3(256), lds_bytes, stream, ga);
+  hipLaunchKernelGGL(fn, dim3(nslabs), dim3(64 * nw), lds_bytes, stream, ga);
 
   TailArgs ta{};
   ta.params = params; ta.ws = ws_fwd; ta.gtab = gws; ta.slabs = gws + tot; ta.grad = grad; ta.lay = lay; ta.w = w;
   ta.o_S = ga.o_S; ta.o_S2 = ga.o_S2; ta.o_gbeta = ga.o_gbeta; ta.o_geps = ga.o_geps; ta.o_gvd = ga.o_gvd;
   ta.o_gfac = ga.o_gfac; ta.slab_stride = ga.slab_stride; ta.n_params = n_params;
   ta.K = K; ta.D = D; ta.E = d.emb_dim; ta.IN = D + d.emb_dim; ta.HP = HP; ta.arch = d.arch; ta.nslabs = nslabs;
-  ta.eps_schedule = d.eps_schedule; ta.ngrid = d.ngrid;
+  ta.eps_schedule = d.eps_schedule; ta.ngrid = d.ngrid; ta.nw = nw;
   hipLaunchKernelGGL(grad_reduce_kernel, dim3(32), dim3(256), 0, stream, ta);
   hipLaunchKernelGGL(grad_sched_tail_kernel, dim3(1), dim3(256), 0, stream, ta);
   if (d.arch == CMCD_ARCH_DDS) hipLaunchKernelGGL(grad_dds_tail_kernel, dim3(K + 1), dim3(64), 0, stream, ta);

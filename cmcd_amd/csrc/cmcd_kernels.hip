@@ -106,6 +106,7 @@ static bool make_ws(const cmcd_desc& d, int64_t n, int64_t n_target, WsLayout& w
   if (d.arch == CMCD_ARCH_GEFFNER) { w.utab = o; o += (K + 1) * HP; } else { w.utab = w.bias1; }
   w.w1z = o; o += D * HP;
   w.w2 = o; o += int64_t(HP) * HP;
+  w.w2t = o; o += int64_t(HP) * HP;
   w.b2 = o; o += HP;
   w.w3t = o; o += D * HP;
   w.b3 = o; o += 16;
@@ -285,6 +286,9 @@ __device__ __forceinline__ void pack_weights_body(const PackArgs& a, int vblock,
     const int tt = int(idx >> 8), t_out = tt % T, t_in = tt / T;
     const int kin = 16 * t_in + 4 * (lane >> 4) + r, nout = 16 * t_out + (lane & 15);
     a.ws[a.w.w2 + idx] = (kin < a.IN && nout < a.IN) ? P[a.o_w2 + (int64_t)kin * a.IN + nout] : 0.f;
+    // transposed product d u1[k] = sum_n W2[k][n] d a2[n]: rows = k (tile t_in here), contraction over n
+    const int krow = 16 * t_in + (lane & 15), ncon = 16 * t_out + 4 * (lane >> 4) + r;
+    a.ws[a.w.w2t + idx] = (krow < a.IN && ncon < a.IN) ? P[a.o_w2 + (int64_t)krow * a.IN + ncon] : 0.f;
   }
   for (int64_t idx = tid; idx < (int64_t)a.D * HP; idx += stride) {
     const int j = int(idx / HP), n = int(idx % HP);

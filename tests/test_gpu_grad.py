@@ -45,6 +45,7 @@ CASES = [
     ("gmm_n300_k8", 128, dict(boundmode="MCD_CAIS_var_sn", grad_clipping=True)),
     ("funnel_n300_k64", 70, dict(boundmode="MCD_CAIS_var_sn", nbridges=6)),
     ("many_gmm_var_n16000_k256", 64, dict(nbridges=6, emb_dim=20)),
+    ("many_gmm_var_n16000_k256", 80, dict(nbridges=5)),                  # 132-wide net (config 4), 3-wave groups
 ]
 
 
@@ -77,9 +78,9 @@ def test_vargrad_matches_autograd(hip_lib, name, n, over):
 
 
 def test_unsupported_configurations_fail_loudly(hip_lib):
-    b = synthetic.build("many_gmm_var_n16000_k256", device="cuda", nbridges=4)      # 132-wide net
     seeds = torch.arange(1, 33, dtype=torch.int32).cuda()
-    with pytest.raises(NotImplementedError):
+    b = synthetic.build("funnel_n300_k64", device="cuda", boundmode="MCD_CAIS_var_sn", nbridges=4, emb_dim=20)
+    with pytest.raises(NotImplementedError):                                          # width 30: no instance
         mcdbm.compute_log_var_grad(seeds, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"])
     b = synthetic.build("gmm_n300_k8", device="cuda")                                 # MCD_CAIS_sn
     with pytest.raises(NotImplementedError, match="Mode not implemented."):
