@@ -67,7 +67,8 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
   float* lds_b3 = lds_b2 + HP;            // 16
   float* lds_tgt = lds_b3 + 16;           // tgt_floats
   float* stage = lds_tgt + a.w.tgt_floats;
-  constexpr int STG = (5 * HP + 32) * 16; // per tile: u1T, u2T, da2T, da1T, du1T [HP][16]; z1, doT [16][16]
+  constexpr int STG = (5 * HP + 32) * 16 + (D + 1) * HP;  // per tile: u1T, u2T, da2T, da1T, du1T [HP][16]; z1, doT [16][16];
+                                                          // then accZ1 [D][HP], accB2 [HP] (wave-private sums over evaluations)
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(a.ws + a.w.w1z);
     f32x4* dst = reinterpret_cast<f32x4*>(lds_w1z);
@@ -95,8 +96,20 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
   float* du1T = da1T + HP * 16;
   float* z1T = du1T + HP * 16;            // rows 0..D-1 = z_j, row D = 1, rest 0
   float* doT = z1T + 256;                 // rows 0..D-1 = d o_j, rest 0
+  float* accZ1 = doT + 256;               // [D][HP]  dW1[j][n], j < D
+  float* accB2 = accZ1 + D * HP;          // [HP]     db2[n]
+  for (int i = lane; i < (D + 1) * HP; i += 64) accZ1[i] = 0.f;
   const int K = a.K;
   const float factor = lds_b3[15];
+  // staged [feature][particle] tiles: element (f, p) sits at f*16 + (p ^ (f & 15)).  With f = 16 t + 4 g + r
+  // (writes) or f = 16 t + c (reads) the swizzle term does not depend on t, so every access is one of
+  // these lane-dependent bases plus a compile-time offset of t*256 floats (an LDS immediate).
+  int wb[4], rb[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    wb[r] = (4 * g + r) * 16 + (c ^ (4 * g + r));   // write base of register r:  feature 16 t + 4 g + r, particle c
+    rb[r] = c * 16 + ((4 * r + g) ^ c);             // read base of k-step r:     feature 16 t + c, particle 4 r + g
+  }
   const float* w2f = WGLOBAL ? a.ws + a.w.w2 : lds_w2;
   const float* w2tf = WGLOBAL ? a.ws + a.w.w2t : lds_w2t;
 
@@ -118,8 +131,6 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
   // persistent accumulators (C layout: lane (g,c), reg r <-> row 16*tile + 4g + r, col 16*tile' + c)
   constexpr int OWN = (T + NW - 1) / NW;  // dW2 / dW3 row tiles owned by this wave: ti = wv + NW*k < T
   f32x4 gW2[OWN][T], gW3[OWN];
-  f32x4 gZ1[T];                           // rows j < D: dW1z[j][n]
-  f32x4 gB2[T];                           // row D: db2[n]   (A = z1 against da2)
   f32x4 gB3;                              // row D: db3[j]   (A = z1 against do)
 #pragma unroll
   for (int k = 0; k < OWN; ++k) {
@@ -127,8 +138,6 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
 #pragma unroll
     for (int t = 0; t < T; ++t) gW2[k][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-#pragma unroll
-  for (int t = 0; t < T; ++t) { gZ1[t] = f32x4{0.f, 0.f, 0.f, 0.f}; gB2[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   gB3 = f32x4{0.f, 0.f, 0.f, 0.f};
   float gfac = 0.f, gmu[D], glam[D];
 #pragma unroll
@@ -191,7 +200,7 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
     for (int e = 0; e <= K; ++e) {
       // ---------------------------------------------------------------- forward (keeps pre-activations)
       const float* brow = bias1 + (int64_t)e * HP;
-      f32x4 a1[T], u1[T], a2[T], u2[T];
+      f32x4 a1[T], u1[T], a2[T];
 #pragma unroll
       for (int t = 0; t < T; ++t) {
         f32x4 pre = *reinterpret_cast<const f32x4*>(brow + 16 * t + 4 * g);
@@ -215,6 +224,9 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) u1[t][r] = u[r] + softplus(pre[r]);
         }
+        // stage u1^T now (every wave finished reading the previous evaluation's tiles at the closing barrier)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) u1T[wb[r] + 256 * t] = u1[t][r];
       }
 #pragma unroll
       for (int t = 0; t < T; ++t) a2[t] = *reinterpret_cast<const f32x4*>(lds_b2 + 16 * t + 4 * g);
@@ -235,12 +247,16 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
         for (int j = 0; j < D; ++j) part[j] = 0.f;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
+          f32x4 u2t;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) u2[t][r] = GEF ? u1[t][r] + softplus(a2[t][r]) : gelu_fast(a2[t][r]);
+          for (int r = 0; r < 4; ++r) {
+            u2t[r] = GEF ? u1[t][r] + softplus(a2[t][r]) : gelu_fast(a2[t][r]);
+            u2T[wb[r] + 256 * t] = u2t[r];
+          }
 #pragma unroll
           for (int j = 0; j < D; ++j) {
             const f32x4 wv4 = *reinterpret_cast<const f32x4*>(lds_w3t + j * HP + 16 * t + 4 * g);
-            part[j] += u2[t][0] * wv4[0] + u2[t][1] * wv4[1] + u2[t][2] * wv4[2] + u2[t][3] * wv4[3];
+            part[j] += u2t[0] * wv4[0] + u2t[1] * wv4[1] + u2t[2] * wv4[2] + u2t[3] * wv4[3];
           }
         }
 #pragma unroll
@@ -361,7 +377,10 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
 #pragma unroll
         for (int j = 0; j < D; ++j) du2 += dob[j] * *reinterpret_cast<const f32x4*>(lds_w3t + j * HP + 16 * t + 4 * g);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) d2[t][r] = du2[r] * (GEF ? sigmoid_fast(a2[t][r]) : gelu_grad_fast(a2[t][r]));
+        for (int r = 0; r < 4; ++r) {
+          d2[t][r] = du2[r] * (GEF ? sigmoid_fast(a2[t][r]) : gelu_grad_fast(a2[t][r]));
+          da2T[wb[r] + 256 * t] = d2[t][r];
+        }
         if (GEF) a2[t] = du2;  // keep d u2 (residual path) in a2's registers
       }
       // d u1 = [d u2 +] W2 d a2 : rows = input neuron k, contraction over output neuron n (W2^T fragments)
@@ -378,25 +397,16 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
           for (int r = 0; r < 4; ++r) d1[tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r], d2[tn][r], d1[tk], 0, 0, 0);
         }
       }
-      f32x4 du1s[T];
-#pragma unroll
-      for (int t = 0; t < T; ++t) {
-        du1s[t] = d1[t];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) d1[t][r] *= GEF ? sigmoid_fast(a1[t][r]) : gelu_grad_fast(a1[t][r]);
-      }
-      // ---------------------------------------------------------------- stage [feature][particle]
 #pragma unroll
       for (int t = 0; t < T; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int f = 16 * t + 4 * g + r, o = sw(f, c);
-          u1T[o] = u1[t][r];
-          u2T[o] = u2[t][r];
-          da2T[o] = d2[t][r];
+          const int o = wb[r] + 256 * t;
+          if (GEF) du1T[o] = d1[t][r];
+          d1[t][r] *= GEF ? sigmoid_fast(a1[t][r]) : gelu_grad_fast(a1[t][r]);
           da1T[o] = d1[t][r];
-          if (GEF) du1T[o] = du1s[t][r];
         }
+      // ---------------------------------------------------------------- stage the two small tiles
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int f = 4 * g + r;
@@ -407,40 +417,43 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
           dv = (f == j) ? dob[j] : dv;
         }
         if (f == D) zv = 1.0f;
-        z1T[sw(f, c)] = zv;
-        doT[sw(f, c)] = dv;
+        z1T[wb[r]] = zv;
+        doT[wb[r]] = dv;
       }
       __syncthreads();
       // ---------------------------------------------------------------- outer products over particles
       {
         float za[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) za[s] = z1T[sw(c, 4 * s + g)];
-        f32x4 sacc[T], s2acc[T];
+        for (int s = 0; s < 4; ++s) za[s] = z1T[rb[s]];
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-          sacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-          s2acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+          f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, s2acc = {0.f, 0.f, 0.f, 0.f}, bacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
-            const float b1v = da1T[sw(16 * t + c, 4 * s + g)];
-            const float b2v = da2T[sw(16 * t + c, 4 * s + g)];
-            sacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[s], b1v, sacc[t], 0, 0, 0);
-            gB2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[s], b2v, gB2[t], 0, 0, 0);
+            const float b1v = da1T[rb[s] + 256 * t];
+            const float b2v = da2T[rb[s] + 256 * t];
+            sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(za[s], b1v, sacc, 0, 0, 0);
+            bacc = __builtin_amdgcn_mfma_f32_16x16x4f32(za[s], b2v, bacc, 0, 0, 0);
             if (GEF) {
-              const float b3v = du1T[sw(16 * t + c, 4 * s + g)];
-              s2acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[s], b3v, s2acc[t], 0, 0, 0);
+              const float b3v = du1T[rb[s] + 256 * t];
+              s2acc = __builtin_amdgcn_mfma_f32_16x16x4f32(za[s], b3v, s2acc, 0, 0, 0);
             }
           }
-          gZ1[t] += sacc[t];  // rows j < D are dW1z; row D is re-read below, other rows are unused
-          // row D of z1 is the all-ones row: sum over particles of d a1 (and d u1) = d / d bias-table row e
-          if (4 * g <= D && D < 4 * g + 4) {
-            atomicAdd(gS + (int64_t)e * HP + 16 * t + c, sacc[t][D - 4 * (D / 4)]);
-            if (GEF) atomicAdd(gS2 + (int64_t)e * HP + 16 * t + c, s2acc[t][D - 4 * (D / 4)]);
+          // C rows are the features of z1 = [z_0 .. z_{D-1}, 1, 0 ...]: lane (g, c), register r <-> row 4 g + r
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 4 * g + r;
+            if (row < D) atomicAdd(accZ1 + row * HP + 16 * t + c, sacc[r]);            // dW1[row][n] += z_row . d a1[n]
+            if (row == D) {
+              atomicAdd(accB2 + 16 * t + c, bacc[r]);                                  // db2[n] += sum_p d a2
+              atomicAdd(gS + (int64_t)e * HP + 16 * t + c, sacc[r]);                   // d / d bias-table row e
+              if (GEF) atomicAdd(gS2 + (int64_t)e * HP + 16 * t + c, s2acc[r]);
+            }
           }
         }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) gB3 = __builtin_amdgcn_mfma_f32_16x16x4f32(za[s], doT[sw(c, 4 * s + g)], gB3, 0, 0, 0);
+        for (int s = 0; s < 4; ++s) gB3 = __builtin_amdgcn_mfma_f32_16x16x4f32(za[s], doT[rb[s]], gB3, 0, 0, 0);
       }
 #pragma unroll
       for (int k = 0; k < OWN; ++k) {
@@ -452,18 +465,18 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
             float xa[4], x2[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-              xa[s] = base[sw(16 * ti + c, 4 * s + g)];                  // u1T
-              x2[s] = base[HP * 16 + sw(16 * ti + c, 4 * s + g)];        // u2T
+              xa[s] = base[rb[s] + 256 * ti];                            // u1T
+              x2[s] = base[HP * 16 + rb[s] + 256 * ti];                  // u2T
             }
 #pragma unroll
             for (int to = 0; to < T; ++to)
 #pragma unroll
               for (int s = 0; s < 4; ++s)
-                gW2[k][to] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], base[2 * HP * 16 + sw(16 * to + c, 4 * s + g)],
+                gW2[k][to] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], base[2 * HP * 16 + rb[s] + 256 * to],
                                                                   gW2[k][to], 0, 0, 0);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
-              gW3[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(x2[s], base[5 * HP * 16 + 256 + sw(c, 4 * s + g)], gW3[k], 0, 0, 0);
+              gW3[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(x2[s], base[5 * HP * 16 + 256 + rb[s]], gW3[k], 0, 0, 0);
           }
         }
       }
@@ -493,13 +506,8 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
     }
   }
   float* pw = slab + HP * HP + HP * 16 + wv * (2 * 16 * HP + 256 + 32);
-#pragma unroll
-  for (int t = 0; t < T; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      pw[(4 * g + r) * HP + 16 * t + c] = gZ1[t][r];
-      pw[16 * HP + (4 * g + r) * HP + 16 * t + c] = gB2[t][r];
-    }
+  for (int i = lane; i < D * HP; i += 64) pw[i] = accZ1[i];                       // rows j < D of the [16][HP] region
+  for (int i = lane; i < HP; i += 64) pw[16 * HP + D * HP + i] = accB2[i];      // row D of the second region
 #pragma unroll
   for (int r = 0; r < 4; ++r) pw[2 * 16 * HP + (4 * g + r) * 16 + c] = gB3[r];
   {
@@ -793,7 +801,7 @@ int grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, c
   ga.slab_stride = (int64_t)HP * HP + HP * 16 + 4 * (2 * 16 * HP + 256 + 32);
   if (hipMemsetAsync(gws, 0, sizeof(float) * tot, stream) != hipSuccess) return CMCD_ERR_HIP;
   if (hipMemsetAsync(grad, 0, sizeof(float) * n_params, stream) != hipSuccess) return CMCD_ERR_HIP;
-  const size_t lds_bytes = size_t((w.T > 4 ? 0 : 2 * HP * HP) + 2 * D * HP + HP + 16 + w.tgt_floats + nw * (5 * HP + 32) * 16) * 4;
+  const size_t lds_bytes = size_t((w.T > 4 ? 0 : 2 * HP * HP) + 2 * D * HP + HP + 16 + w.tgt_floats + nw * ((5 * HP + 32) * 16 + (D + 1) * HP)) * 4;
   if (lds_bytes > 160 * 1024) return CMCD_ERR_UNSUPPORTED;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)lds_bytes) != hipSuccess)

@@ -138,7 +138,8 @@ int cmcd_profile_collect(double* total_ms, int64_t* launches);
  *                         for multi-GPU) statistics; n_total = global particle count.
  *   cmcd_bound_var_grad   grad[n_params] (overwritten; zeros for leaves without gradient) =
  *                         sum_n omega_n d w_n / d params_flat.  Across ranks: all-reduce(sum) of grad.
- * MCD_CAIS_var_sn only; hidden width <= 64 in this build (CMCD_ERR_UNSUPPORTED otherwise). */
+ * MCD_CAIS_var_sn only; kernel instances exist for the BASELINE nets (dds 64; geffner 22 / 58 / 132),
+ * CMCD_ERR_UNSUPPORTED otherwise. */
 int64_t cmcd_grad_workspace_bytes(const cmcd_desc* desc, int64_t n);
 int cmcd_vargrad_weights(const float* loss, const double* stats, int64_t n, int64_t n_total, float* omega,
                          void* stream);

@@ -24,3 +24,13 @@ for n in (2000, 16000, 65536):
     K = 256
     print("n=%6d  forward %.3f ms (%.3e steps/s)   value+grad %.3f ms (%.3e steps/s)  ratio %.2f" % (
         n, tf, n * K / tf * 1e3, tg, n * K / tg * 1e3, tg / tf))
+
+for n in (2000, 16000):
+    b = synthetic.build("many_gmm_var_n16000_k256", device="cuda")
+    seeds = torch.from_numpy(synthetic.throughput_seeds(n)).cuda()
+    args = (seeds, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"])
+    kw = dict(eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
+    tf = timeit(lambda: mcdbm.compute_bound_var(*args, **kw), reps=3)
+    tg = timeit(lambda: mcdbm.compute_log_var_grad(*args, **kw), reps=3)
+    print("config 4 (132-wide) n=%6d  forward %.3f ms (%.3e steps/s)   value+grad %.3f ms (%.3e steps/s)  ratio %.2f" % (
+        n, tf, n * 256 / tf * 1e3, tg, n * 256 / tg * 1e3, tg / tf))
