@@ -313,4 +313,8 @@ def compute_log_var_grad(seeds, params_flat, unflatten, params_fixed, log_prob, 
             C.byref(desc), C.byref(lay), seeds.data_ptr(), n, params_flat.data_ptr(), params_flat.numel(),
             consts.data_ptr() if consts is not None else None, consts.numel() if consts is not None else 0,
             omega.data_ptr(), ws.data_ptr(), ws.numel(), grad.data_ptr(), stream))
+    # params_notrain = stop_gradient(params_notrain) (mcdboundingmachine.py:142): only the leaves of
+    # params_train carry a gradient; they are the leading block of params_flat
+    n_train = min((off for path, (off, _) in unflatten.layout.items() if path[0] == 1), default=params_flat.numel())
+    grad[n_train:].zero_()
     return grad, (losses, z)

@@ -1,0 +1,83 @@
+"""Optimiser loop around the hot path.
+
+Mirrors /root/reference/src/opt.py:14-35 (`project`, `create_optimizer`: optax.chain(clip(5.0), adam)) and
+:67-164 (`run`), with torch tensors on the device; W&B logging and sample plots are left out.  The
+gradient comes from `grad_and_loss(seeds, params_flat, unflatten, params_fixed, log_prob_model)` exactly as
+in the reference (e.g. functools.partial(mcdboundingmachine.compute_log_var_grad, eps_schedule=...)).
+"""
+import copy
+
+import torch
+
+
+def project(x, unflatten, trainable):
+    """/root/reference/src/opt.py:14-24 (in place on the views of `x`)."""
+    x_train, _ = unflatten(x)
+    if "eps" in trainable:
+        x_train["eps"].clamp_(0.0000001, 0.5)
+    if "eta" in trainable:
+        x_train["eta"].clamp_(0, 0.99)
+    if "gamma" in trainable:
+        x_train["gamma"].clamp_(min=0.001)
+    if "mgridref_y" in trainable:
+        x_train["mgridref_y"].copy_(torch.relu(x_train["mgridref_y"] - 0.001) + 0.001)
+    return x
+
+
+class _ClipAdam:
+    """optax.chain(optax.clip(5.0), optax.adam(lr, b1, b2, eps)): elementwise clip, then Adam with bias
+    correction and eps outside the square root."""
+
+    def __init__(self, step_size, b1=0.9, b2=0.999, eps=1e-8):
+        self.lr, self.b1, self.b2, self.eps = step_size, b1, b2, eps
+
+    def init(self, params):
+        return {"count": 0, "mu": torch.zeros_like(params), "nu": torch.zeros_like(params)}
+
+    def update(self, grad, state, params=None):
+        g = grad.clamp(-5.0, 5.0)
+        state["count"] += 1
+        t = state["count"]
+        state["mu"].mul_(self.b1).add_(g, alpha=1 - self.b1)
+        state["nu"].mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
+        mu_hat = state["mu"] / (1 - self.b1 ** t)
+        nu_hat = state["nu"] / (1 - self.b2 ** t)
+        return -self.lr * mu_hat / (nu_hat.sqrt() + self.eps), state
+
+
+def create_optimizer(step_size, b1=0.9, b2=0.999, eps=1e-8, trainable=None):
+    """/root/reference/src/opt.py:27-35"""
+    return _ClipAdam(step_size, b1, b2, eps)
+
+
+def run(info, lr, iters, params_flat, unflatten, params_fixed, log_prob_model, grad_and_loss, trainable, rng_key_gen,
+        extra=True, log_prefix="", target_samples=None, use_ema=False):
+    """/root/reference/src/opt.py:67-164 -> (losses, params_flat, ema_params).
+
+    `rng_key_gen`: an int seed (a torch generator draws the per-iteration particle seeds with
+    randint(1, 1e6), opt.py:93-94) or a ready torch.Generator.  `info.N` particles per iteration.  A NaN
+    mean loss stops the run ("Diverged", opt.py:122-124) and returns what the reference *meant* to
+    return, a 3-tuple."""
+    optimizer = create_optimizer(lr, trainable=trainable)
+    params_flat = params_flat.clone()
+    opt_state = optimizer.init(params_flat)
+    ema_params = copy.deepcopy(params_flat) if use_ema else None
+    gen = rng_key_gen if isinstance(rng_key_gen, torch.Generator) else torch.Generator().manual_seed(int(rng_key_gen))
+    losses = []
+    n = info.N if hasattr(info, "N") else info["N"]
+    every = max(iters // 1000, 1)
+    for i in range(iters):
+        seeds = torch.randint(1, 1000000, (n,), generator=gen, dtype=torch.int32).to(params_flat.device)
+        grad, (loss, z) = grad_and_loss(seeds, params_flat, unflatten, params_fixed, log_prob_model)
+        if i % every == 0:
+            mean_loss = float(loss.mean())                   # the only host sync, every 0.1 % of the steps
+            if mean_loss != mean_loss:
+                print("Diverged")
+                return losses, params_flat, ema_params
+            losses.append(mean_loss)
+        updates, opt_state = optimizer.update(grad, opt_state, params_flat)
+        params_flat.add_(updates)
+        project(params_flat, unflatten, trainable)
+        if use_ema:
+            ema_params.mul_(1 - 0.001).add_(params_flat, alpha=0.001)   # optax.incremental_update(step_size=0.001)
+    return losses, params_flat, ema_params

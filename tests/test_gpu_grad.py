@@ -85,3 +85,29 @@ def test_unsupported_configurations_fail_loudly(hip_lib):
     b = synthetic.build("gmm_n300_k8", device="cuda")                                 # MCD_CAIS_sn
     with pytest.raises(NotImplementedError, match="Mode not implemented."):
         mcdbm.compute_log_var_grad(seeds, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"])
+
+
+def test_training_with_vargrad_reduces_the_loss(hip_lib):
+    """opt.run (Adam + clip + project, reference opt.py:14-35,67-164) driven by compute_log_var_grad: the
+    log-variance loss on FRESH seeds must drop and stay finite; non-trainable leaves must not move."""
+    import types
+    from functools import partial
+    from cmcd_amd import opt
+    b = synthetic.build("many_gmm_var_n16000_k256", device="cuda", emb_dim=20, nbridges=16, init_sigma=15.0)
+    dim, K, mode, spec = b["params_fixed"]
+    flat, unflatten, fixed = mcdbm.initialize(
+        dim=dim, nbridges=K, vdparams={"mean": torch.zeros(dim), "logdiag": torch.full((dim,), float(np.log(15.0)))},
+        eps=0.65, trainable=("eta", "gamma", "mgridref_y"), mode=mode, emb_dim=20, nn_arch="geffner", device="cuda")
+    kw = dict(eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
+    fresh = torch.from_numpy(synthetic.throughput_seeds(4000, stream=5)).cuda()
+    v0 = float(mcdbm.compute_bound_var(fresh, flat, unflatten, fixed, b["target"], **kw)[0])
+    losses, flat2, _ = opt.run(types.SimpleNamespace(N=1000), 5e-3, 400, flat, unflatten, fixed, b["target"],
+                               partial(mcdbm.compute_log_var_grad, **kw), ("eta", "gamma", "mgridref_y"), 0)
+    v1 = float(mcdbm.compute_bound_var(fresh, flat2, unflatten, fixed, b["target"], **kw)[0])
+    print("log-variance loss", v0, "->", v1)
+    assert np.isfinite(v1) and v1 < 0.6 * v0
+    _, notrain0 = unflatten(flat)
+    _, notrain1 = unflatten(flat2)
+    assert torch.equal(notrain0["eps"], notrain1["eps"]) and torch.equal(notrain0["vd"]["mean"], notrain1["vd"]["mean"])
+    train1, _ = unflatten(flat2)
+    assert float(train1["sn"]["factor_sn"]) != 0.0 and float(train1["mgridref_y"].min()) >= 0.001
