@@ -85,6 +85,15 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
 
   for (int i = threadIdx.x; i < a.w.tgt_floats; i += blockDim.x) lds_tgt[i] = a.ws[a.w.tgt + i];
 
+  // Static issue priority (diagnostic knob in the stamp build): the waves dispatched second
+  // on each SIMD (the aux waves) otherwise only get the issue slots their older partner leaves.
+#ifdef CMCD_STAMPS
+  {
+    const int pm = (abl >> 8) & 3;   // 0 none, 1 aux waves high, 2 MLP waves high, 3 TGT only high
+    if ((pm == 1 && !is_mlp) || (pm == 2 && is_mlp) || (pm == 3 && is_tgt)) __builtin_amdgcn_s_setprio(3);
+  }
+#endif
+
   // ---- per-role resident operands
   f32x4 afrag[T], w1z[D], w3t[D], b2v;
   if (is_mlp) {

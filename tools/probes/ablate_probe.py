@@ -6,7 +6,8 @@ lib = "/tmp/libcmcd_hip_stamps.so"
 csrc = os.path.join(ROOT, "cmcd_amd", "csrc")
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DCMCD_STAMPS",
                 "-I", os.path.join(ROOT, "include"), "-I", csrc, "-Wno-format-security", "-o", lib,
-                os.path.join(csrc, "cmcd_kernels.hip"), os.path.join(csrc, "cmcd_coop.hip")], check=True)
+                os.path.join(csrc, "cmcd_kernels.hip"), os.path.join(csrc, "cmcd_coop.hip"),
+                os.path.join(csrc, "cmcd_lgcp.hip"), os.path.join(csrc, "cmcd_grad.hip")], check=True)
 os.environ["CMCD_LIB_PATH"] = lib
 os.environ["CMCD_KERNEL_VARIANT"] = "2"
 import torch
@@ -14,7 +15,7 @@ from cmcd_amd import _lib, synthetic
 from cmcd_amd import mcdboundingmachine as mcdbm
 b = synthetic.build(synthetic.NORTH_STAR, device="cuda")
 seeds = torch.from_numpy(synthetic.throughput_seeds(b["cfg"]["N"])).cuda()
-names = {0: "full", 1: "no TGT", 2: "no RNG", 4: "no CONV", 8: "no MFMA", 16: "no gelu", 7: "no aux at all", 31: "skeleton only"}
+names = {0: "full", 256: "prio: aux high", 512: "prio: MLP high", 768: "prio: TGT high", 1: "no TGT", 7: "no aux at all", 31: "skeleton only", 31 + 256: "skeleton, aux high"}
 for mask, nm in names.items():
     os.environ["CMCD_ABLATE"] = str(mask)
     for _ in range(2):

@@ -12,7 +12,8 @@ lib = "/tmp/libcmcd_hip_stamps.so"
 csrc = os.path.join(ROOT, "cmcd_amd", "csrc")
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                 "-DCMCD_STAMPS", "-I", os.path.join(ROOT, "include"), "-I", csrc, "-Wno-format-security",
-                "-o", lib, os.path.join(csrc, "cmcd_kernels.hip"), os.path.join(csrc, "cmcd_coop.hip")], check=True)
+                "-o", lib, os.path.join(csrc, "cmcd_kernels.hip"), os.path.join(csrc, "cmcd_coop.hip"),
+                os.path.join(csrc, "cmcd_lgcp.hip"), os.path.join(csrc, "cmcd_grad.hip")], check=True)
 os.environ["CMCD_LIB_PATH"] = lib
 os.environ["CMCD_KERNEL_VARIANT"] = "2"
 import torch  # noqa: E402
