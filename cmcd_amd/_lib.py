@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CMCD_LIB_PATH", os.path.join(_HERE, "libcmcd_hip.so"))  # override: diagnostic builds
 
-MODE = {"MCD_CAIS_sn": 0, "MCD_CAIS_var_sn": 1}
+MODE = {"MCD_CAIS_sn": 0, "MCD_CAIS_var_sn": 1, "MCD_ULA": 2, "MCD_ULA_sn": 3}
 ARCH = {"geffner": 0, "dds": 1}
 TARGET = {"gmm": 0, "funnel": 1, "many_gmm": 2, "lgcp": 3}
 EPS_SCHEDULE = {None: 0, "": 0, "none": 0, "linear": 1, "cos_sq": 2}

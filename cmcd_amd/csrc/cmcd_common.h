@@ -40,6 +40,7 @@ struct TrajArgs {
   WsLayout w;
   int64_t n;
   int32_t K, var_mode, grad_clipping;
+  int32_t ula;  // 0: CAIS; 1: MCD_ULA (no network); 2: MCD_ULA_sn (network in the backward kernel only, index i)
 };
 
 // cmcd_coop.hip: the CU-cooperative variant (one workgroup per 16-particle tile).

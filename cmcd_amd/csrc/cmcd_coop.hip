@@ -257,13 +257,11 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
     STAMP(1);
     // ------------------------------------------------------------------ interval 2
     if (is_mlp) {
-      // prefetch the next bridge's first-layer bias row (L2-resident); lands during the MFMAs
-      brow_ptr += (i < K) ? HP : 0;
-      brow = *reinterpret_cast<const f32x4*>(brow_ptr);
-      if (ARCH == CMCD_ARCH_GEFFNER) {
-        urow_ptr += (i < K) ? HP : 0;
-        urow = *reinterpret_cast<const f32x4*>(urow_ptr);
-      }
+      // prefetch the next evaluation's first-layer bias row (L2-resident); lands during the MFMAs.
+      // CAIS evaluates s(z_{i+1}, i+1); MCD_ULA_sn evaluates s(z_{i+1}, i) (mcd_over_orig.py:44).
+      const int nrow = (i < K ? i + 1 : K) - (a.ula == 2 ? 1 : 0);
+      brow = *reinterpret_cast<const f32x4*>(brow_ptr + (int64_t)nrow * HP);
+      if (ARCH == CMCD_ARCH_GEFFNER) urow = *reinterpret_cast<const f32x4*>(urow_ptr + (int64_t)nrow * HP);
       // layer 2: rows = my 16 output neurons, cols = particles, k = all HP inputs from LDS
       f32x4 acc = b2v;
       STAMP(6);
@@ -347,7 +345,7 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
 #pragma unroll
     for (int j = 0; j < D; ++j) {  // forward kernel of step i (mcd_cais.py:52-67)
       const float uf = -1.0f * (beta * gp[j] + (1.0f - beta) * gq[j]);
-      const float fk = z[j] - eps * uf - eps * sn[j];
+      const float fk = z[j] - eps * uf - eps * (a.ula ? 0.f : sn[j]);
       const float zn = fk + sig * nzb[(buf * 16 + c) * NZ + j];
       if (is_acc) {
         const float df = zn - fk;

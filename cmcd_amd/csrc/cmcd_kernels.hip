@@ -281,7 +281,8 @@ __device__ __forceinline__ void pack_weights_body(const PackArgs& a, int vblock,
   const float* P = a.params;
   const int64_t tid = (int64_t)vblock * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)nblocks * blockDim.x;
-  for (int64_t idx = tid; idx < (int64_t)HP * HP; idx += stride) {
+  const bool has_net = a.o_w2 >= 0;
+  for (int64_t idx = tid; has_net && idx < (int64_t)HP * HP; idx += stride) {
     const int r = idx & 3, lane = (idx >> 2) & 63;
     const int tt = int(idx >> 8), t_out = tt % T, t_in = tt / T;
     const int kin = 16 * t_in + 4 * (lane >> 4) + r, nout = 16 * t_out + (lane & 15);
@@ -290,15 +291,15 @@ __device__ __forceinline__ void pack_weights_body(const PackArgs& a, int vblock,
     const int krow = 16 * t_in + (lane & 15), ncon = 16 * t_out + 4 * (lane >> 4) + r;
     a.ws[a.w.w2t + idx] = (krow < a.IN && ncon < a.IN) ? P[a.o_w2 + (int64_t)krow * a.IN + ncon] : 0.f;
   }
-  for (int64_t idx = tid; idx < (int64_t)a.D * HP; idx += stride) {
+  for (int64_t idx = tid; has_net && idx < (int64_t)a.D * HP; idx += stride) {
     const int j = int(idx / HP), n = int(idx % HP);
     a.ws[a.w.w1z + idx] = n < a.IN ? P[a.o_w1 + (int64_t)j * a.IN + n] : 0.f;
     a.ws[a.w.w3t + idx] = n < a.IN ? P[a.o_w3 + (int64_t)n * a.D + j] : 0.f;
   }
-  for (int64_t idx = tid; idx < HP; idx += stride) a.ws[a.w.b2 + idx] = idx < a.IN ? P[a.o_b2 + idx] : 0.f;
+  for (int64_t idx = tid; has_net && idx < HP; idx += stride) a.ws[a.w.b2 + idx] = idx < a.IN ? P[a.o_b2 + idx] : 0.f;
   for (int64_t idx = tid; idx < 16; idx += stride) {
     float v = 0.f;
-    if (idx < a.D) v = P[a.o_b3 + idx];
+    if (has_net && idx < a.D) v = P[a.o_b3 + idx];
     if (idx == 15) v = a.o_factor >= 0 ? P[a.o_factor] : 1.0f;
     a.ws[a.w.b3 + idx] = v;
   }
@@ -332,6 +333,7 @@ struct PrepArgs {
 __global__ __launch_bounds__(256) void prep_fused_kernel(PrepArgs a) {
   const int b = blockIdx.x;
   if (b <= a.K) {
+    if (a.arch < 0) return;  // MCD_ULA: no network, no bias table
     if (a.arch == CMCD_ARCH_DDS) prep_dds_body(a.dds, b);
     else prep_geffner_body(a.gef, b);
   } else if (b == a.K + 1) {
@@ -546,8 +548,15 @@ __global__ __launch_bounds__(512, (T > 4 || D > 4) ? 2 : 4) void traj_kernel(Tra
   for (int i = 0; i <= K; ++i) {
     float gp[D], sn[D];
     Target<TARGET, D>::eval(z, g, lds_tgt, logp, gp);
-    eval_net<ARCH, D, T>(z, bias1 + (int64_t)i * HP, utab + (int64_t)i * HP, lds_w2, lds_w1z, lds_b2, lds_w3t,
-                         lds_b3, lane, sn);
+    if (a.ula == 1) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) sn[j] = 0.f;
+    } else {
+      // CAIS: s(z_i, i) serves both kernels; MCD_ULA_sn: s(z_i, i - 1) serves the backward kernel only
+      const int64_t row = (a.ula == 2) ? (i > 0 ? i - 1 : 0) : i;
+      eval_net<ARCH, D, T>(z, bias1 + row * HP, utab + row * HP, lds_w2, lds_w1z, lds_b2, lds_w3t, lds_b3, lane, sn);
+    }
+    const float fsn = a.ula ? 0.f : 1.f;  // the ULA forward kernel has no network term
     float gq[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) {
@@ -611,7 +620,7 @@ __global__ __launch_bounds__(512, (T > 4 || D > 4) ? 2 : 4) void traj_kernel(Tra
 #pragma unroll
     for (int j = 0; j < D; ++j) {
       const float uf = -1.0f * (beta * gp[j] + (1.0f - beta) * gq[j]);
-      const float fk = z[j] - eps * uf - eps * sn[j];
+      const float fk = z[j] - eps * uf - eps * (fsn * sn[j]);
       const float zn = fk + sig * nz[j];
       const float df = zn - fk;
       fk_lp += -(df * df) * inv2s2 - logsig - kHalfLog2Pi;
@@ -724,11 +733,14 @@ static void launch_prep(const cmcd_desc& d, const cmcd_layout& layr, const WsLay
   const cmcd_layout* lay = &layr;
   const int64_t K = d.nbridges, D = d.dim, E = d.emb_dim, IN = D + E;
   PrepArgs pa{};
-  pa.sched = SchedArgs{params, ws, *lay, w, (int32_t)K, d.ngrid, d.eps_schedule, -1, -1};
+  const bool ula_mode = d.mode == CMCD_MODE_ULA || d.mode == CMCD_MODE_ULA_SN;
+  pa.sched = SchedArgs{params, ws, *lay, w, (int32_t)K, d.ngrid, ula_mode ? CMCD_EPS_CONST : d.eps_schedule, -1, -1};
   PackArgs& pk = pa.pack;
   pk.params = params; pk.tgt = target_consts; pk.ws = ws; pk.w = w;
   pk.D = (int32_t)D; pk.target = d.target; pk.n_mix = n_mix;
-  if (d.arch == CMCD_ARCH_DDS) {
+  if (d.mode == CMCD_MODE_ULA) {
+    pk.o_w1 = pk.o_w2 = pk.o_b2 = pk.o_w3 = pk.o_b3 = pk.o_factor = -1; pk.IN = 0;
+  } else if (d.arch == CMCD_ARCH_DDS) {
     pa.dds = DdsPrepArgs{params, ws, *lay, w, (int32_t)D};
     pk.o_w1 = lay->d_sw1; pk.o_w2 = lay->d_sw2; pk.o_b2 = lay->d_sb2; pk.o_w3 = lay->d_sw3;
     pk.o_b3 = lay->d_sb3; pk.o_factor = -1; pk.IN = 64;
@@ -737,7 +749,7 @@ static void launch_prep(const cmcd_desc& d, const cmcd_layout& layr, const WsLay
     pk.o_w1 = lay->g_w1; pk.o_w2 = lay->g_w2; pk.o_b2 = lay->g_b2; pk.o_w3 = lay->g_w3;
     pk.o_b3 = lay->g_b3; pk.o_factor = lay->g_factor; pk.IN = (int32_t)IN;
   }
-  pa.K = (int32_t)K; pa.arch = d.arch;
+  pa.K = (int32_t)K; pa.arch = d.mode == CMCD_MODE_ULA ? -1 : d.arch;
   pa.npack = (w.HP * w.HP + 255) / 256;
   if (pa.npack > 64) pa.npack = 64;
   hipLaunchKernelGGL(prep_fused_kernel, dim3((unsigned)(K + 2 + pa.npack)), dim3(256), 0, stream, pa);
@@ -747,8 +759,12 @@ static void launch_prep(const cmcd_desc& d, const cmcd_layout& layr, const WsLay
 
 static int check_desc(const cmcd_desc* d) {
   if (!d) return fail(CMCD_ERR_BAD_ARG, "null desc%s");
-  if (d->mode != CMCD_MODE_CAIS_SN && d->mode != CMCD_MODE_CAIS_VAR_SN)
+  if (d->mode < CMCD_MODE_CAIS_SN || d->mode > CMCD_MODE_ULA_SN)
     return fail(CMCD_ERR_UNSUPPORTED, "Mode not implemented.%s");
+  if (d->mode == CMCD_MODE_ULA && d->arch != CMCD_ARCH_DDS)
+    return fail(CMCD_ERR_BAD_ARG, "MCD_ULA has no network: pass arch = CMCD_ARCH_DDS as the placeholder%s");
+  if (d->target == CMCD_TARGET_LGCP && d->mode > CMCD_MODE_CAIS_VAR_SN)
+    return fail(CMCD_ERR_UNSUPPORTED, "lgcp runs the CAIS modes only%s");
   if (d->arch != CMCD_ARCH_DDS && d->arch != CMCD_ARCH_GEFFNER)
     return fail(CMCD_ERR_UNSUPPORTED, "nn_arch not implemented%s");
   if (d->nbridges < 1) return fail(CMCD_ERR_BAD_ARG, "nbridges must be >= 1%s");
@@ -822,7 +838,9 @@ int cmcd_bound_forward(const cmcd_desc* desc, const cmcd_layout* lay, const int3
   auto need = [&](int64_t off, int64_t len) { return off >= 0 && off + len <= n_params; };
   bool ok = need(lay->vd_mean, D) && need(lay->vd_logdiag, D) && need(lay->eps, 1) &&
             need(lay->mgridref_y, d.ngrid + 1);
-  if (d.arch == CMCD_ARCH_GEFFNER)
+  if (d.mode == CMCD_MODE_ULA) {
+    // no network leaves
+  } else if (d.arch == CMCD_ARCH_GEFFNER)
     ok = ok && need(lay->g_emb, K * E) && need(lay->g_factor, 1) && need(lay->g_w1, IN * IN) &&
          need(lay->g_b1, IN) && need(lay->g_w2, IN * IN) && need(lay->g_b2, IN) && need(lay->g_w3, IN * D) &&
          need(lay->g_b3, D);
@@ -869,13 +887,15 @@ int cmcd_bound_forward(const cmcd_desc* desc, const cmcd_layout* lay, const int3
   launch_prep(d, *lay, w, params, target_consts, n_mix, ws, stream);
 
   TrajArgs ta{seeds, params, ws, reinterpret_cast<double*>(ws + w.partials), out_loss, out_z, *lay, w, n,
-              (int32_t)K, d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0, d.grad_clipping};
+              (int32_t)K, d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0,
+              (d.mode == CMCD_MODE_ULA || d.mode == CMCD_MODE_ULA_SN) ? 0 : d.grad_clipping,
+              d.mode == CMCD_MODE_ULA ? 1 : (d.mode == CMCD_MODE_ULA_SN ? 2 : 0)};
 #ifdef CMCD_STAMPS
   if (const char* e = getenv("CMCD_ABLATE")) ta.var_mode |= atoi(e) << 8;
 #endif
   // Kernel variant (desc.reserved: 0 auto, 1 wave-per-tile, 2 CU-cooperative).  Auto: the
   // cooperative kernel while the batch cannot fill the chip with one wave per tile.
-  const bool coop_ok = coop_available(d, w.T);
+  const bool coop_ok = coop_available(d, w.T) && d.mode != CMCD_MODE_ULA;
   bool use_coop = d.reserved == 2 ? coop_ok : (d.reserved == 1 ? false : (coop_ok && w.n_waves <= coop_max_tiles(d, w.T)));
   if (d.reserved == 2 && !coop_ok) return fail(CMCD_ERR_UNSUPPORTED, "no cooperative kernel instance%s");
   if (use_coop) {

@@ -15,7 +15,7 @@ from . import variationaldist as vd
 from .nn import ScoreNet, initialize_network
 
 _SN_MODES = ["MCD_ULA_sn", "MCD_U_e-lp-sna", "MCD_U_a-lp-sna", "MCD_CAIS_sn", "MCD_CAIS_var_sn"]
-_SUPPORTED = ("MCD_CAIS_sn", "MCD_CAIS_var_sn")
+_SUPPORTED = ("MCD_CAIS_sn", "MCD_CAIS_var_sn", "MCD_ULA", "MCD_ULA_sn")
 
 
 # --------------------------------------------------------------------------- ravel_pytree
@@ -190,13 +190,23 @@ def _layout(unflatten, spec):
     return lay
 
 
+def _layout_no_net(unflatten):
+    lay = _lib.Layout(*([-1] * len(_lib.LAYOUT_FIELDS)))
+    o = unflatten.offset
+    lay.vd_mean, lay.vd_logdiag = o("vd", "mean"), o("vd", "logdiag")
+    lay.eps, lay.mgridref_y = o("eps"), o("mgridref_y")
+    return lay
+
+
 def bound_forward(seeds, params_flat, unflatten, params_fixed, log_prob, eps_schedule=None, grad_clipping=False):
     """One launch sequence of the hot path.  Returns (losses[N] f32, z[N,dim] f32, stats[5] f64),
     all device tensors, enqueued asynchronously on the current stream."""
     dim, nbridges, mode, spec = params_fixed
     if mode not in _SUPPORTED:
         raise NotImplementedError("Mode not implemented.")  # same text as mcd_utils.py:190
-    if not isinstance(spec, ScoreNet):
+    if mode == "MCD_ULA":
+        spec = ScoreNet("dds", dim, 64, 0, 64)   # placeholder: MCD_ULA has no network (apply_fun_sn is None)
+    elif not isinstance(spec, ScoreNet):
         raise ValueError("params_fixed[3] must be the ScoreNet returned by initialize()")
     if eps_schedule not in _lib.EPS_SCHEDULE:
         eps_schedule = None  # the reference falls through to constant eps (mcd_cais.py:58-59)
@@ -221,7 +231,7 @@ def bound_forward(seeds, params_flat, unflatten, params_fixed, log_prob, eps_sch
                      emb_dim=spec.emb_dim, target=log_prob.target_id,
                      eps_schedule=_lib.EPS_SCHEDULE[eps_schedule], grad_clipping=int(bool(grad_clipping)),
                      ngrid=unflatten.shape("mgridref_y")[0] - 1, reserved=KERNEL_VARIANT)
-    lay = _layout(unflatten, spec)
+    lay = _layout(unflatten, spec) if mode != "MCD_ULA" else _layout_no_net(unflatten)
     nbytes = L.cmcd_workspace_bytes(C.byref(desc), n)
     if nbytes <= 0:
         _lib.check(-2 if "not implemented" in _lib.last_error() or "no kernel" in _lib.last_error() else -1)

@@ -80,7 +80,8 @@ def build(config_name=None, device=None, lgcp_counts=None, **overrides):
         trainable=("eta", "gamma", "eps", "vd", "mgridref_y"), mode=cfg["boundmode"],
         emb_dim=cfg["emb_dim"], nlayers=3, nn_arch=cfg["nn_arch"], device="cpu")
     train, _ = unflatten(flat)
-    _fill_synthetic_sn(train["sn"], cfg["nn_arch"], np.random.default_rng(1))
+    if "sn" in train:   # MCD_ULA keeps no network
+        _fill_synthetic_sn(train["sn"], cfg["nn_arch"], np.random.default_rng(1))
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
     flat = flat.to(device)

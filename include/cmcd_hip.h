@@ -51,9 +51,12 @@ typedef enum cmcd_status {
   CMCD_ERR_HIP = -4            /* a HIP runtime call failed                               */
 } cmcd_status;
 
-/* config.boundmode plugin switch (/root/reference/src/mcd_utils.py:34-190).  Only the two
- * CAIS modes exist here; every other value is CMCD_ERR_UNSUPPORTED ("Mode not implemented."). */
-enum { CMCD_MODE_CAIS_SN = 0, CMCD_MODE_CAIS_VAR_SN = 1 };
+/* config.boundmode plugin switch (/root/reference/src/mcd_utils.py:34-190).  The two CAIS modes and
+ * the two overdamped siblings on the same skeleton (MCD_ULA = Thin et al., MCD_ULA_sn = Doucet et al.,
+ * /root/reference/src/mcd_over_orig.py:6-65) exist here; every other value is CMCD_ERR_UNSUPPORTED
+ * ("Mode not implemented.").  MCD_ULA has no network: pass arch = CMCD_ARCH_DDS and network layout
+ * offsets of -1; eps_schedule / grad_clipping are ignored for both ULA modes, as in the reference. */
+enum { CMCD_MODE_CAIS_SN = 0, CMCD_MODE_CAIS_VAR_SN = 1, CMCD_MODE_ULA = 2, CMCD_MODE_ULA_SN = 3 };
 /* config.nn_arch (/root/reference/src/nn.py:21-39) */
 enum { CMCD_ARCH_GEFFNER = 0, CMCD_ARCH_DDS = 1 };
 /* config.model routing (/root/reference/src/model_handler.py:30-43) */

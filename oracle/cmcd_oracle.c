@@ -246,6 +246,7 @@ int cmcd_oracle_bound(const cmcd_desc* desc, const cmcd_layout* lay, const int32
                       float* out_z) {
   const int d = desc->dim, K = desc->nbridges;
   if (desc->target == CMCD_TARGET_LGCP || d > MAXD) return -2;
+  if (desc->mode != CMCD_MODE_CAIS_SN && desc->mode != CMCD_MODE_CAIS_VAR_SN) return -2;
   Net net = {desc->arch, d, desc->emb_dim, d + desc->emb_dim, K, P, lay, NULL};
   if (desc->arch == CMCD_ARCH_GEFFNER && net.in > MAXW) return -2;
   Target tgt = {desc->target, d, desc->target == CMCD_TARGET_MANY_GMM ? (int)((n_target - 1) / 2) : 0, target_consts};

@@ -26,7 +26,7 @@ except Exception:  # pragma: no cover
 from . import prng
 
 LOG_2PI = 1.8378770664093453
-MODES = ("MCD_CAIS_sn", "MCD_CAIS_var_sn")
+MODES = ("MCD_CAIS_sn", "MCD_CAIS_var_sn", "MCD_ULA", "MCD_ULA_sn")
 
 
 # --------------------------------------------------------------------------- schedules
@@ -147,7 +147,7 @@ def compute_log_elbo_batch(seeds, params, dim, nbridges, mode, arch, target,
         raise NotImplementedError("Mode not implemented.")
     dt = np.dtype(dtype).type
     p = cast_params(params, dtype)
-    vd, sn = p["vd"], p["sn"]
+    vd, sn = p["vd"], p.get("sn")
     seeds = np.asarray(seeds)
     eps0_noise, noise = prng.particle_noise(seeds, dim, nbridges)
     betas = betas_from_grid(p["mgridref_y"], p["gridref_x"], p["target_x"], dtype) if nbridges >= 1 else None
@@ -158,6 +158,14 @@ def compute_log_elbo_batch(seeds, params, dim, nbridges, mode, arch, target,
 
     var_mode = mode == "MCD_CAIS_var_sn"
     clip = dt(1e2) if var_mode else dt(1e3)
+    # MCD_ULA / MCD_ULA_sn: /root/reference/src/mcd_over_orig.py:6-65 via mcd_utils.py:35-58 — constant eps,
+    # no clipping (the dispatcher does not even pass eps_schedule / grad_clipping), no network in the
+    # forward kernel, and the backward kernel's network (ULA_sn only) takes index i, not i + 1.
+    ula = mode in ("MCD_ULA", "MCD_ULA_sn")
+    if ula:
+        grad_clipping = False
+        eps_tab = np.full(nbridges, dt(p["eps"]), dtype) if nbridges >= 1 else None
+        reuse = False
 
     def grads(zz):
         _, gp = target(zz)
@@ -178,14 +186,20 @@ def compute_log_elbo_batch(seeds, params, dim, nbridges, mode, arch, target,
         if reuse and carried is not None:
             g_z, s_z = carried
         else:
-            g_z, s_z = grads(z), apply_sn(arch, sn, z, i, dtype)
+            g_z, s_z = grads(z), (None if ula else apply_sn(arch, sn, z, i, dtype))
         uf = grad_u(g_z, beta)
-        fk_mean = z - eps * uf - eps * s_z
+        if ula:
+            fk_mean = z - eps * uf
+        else:
+            fk_mean = z - eps * uf - eps * s_z
         scale = np.sqrt(dt(2.0) * eps)
         z_new = fk_mean + scale * noise[:, i, :].astype(dtype)
-        g_n, s_n = grads(z_new), apply_sn(arch, sn, z_new, i + 1, dtype)
+        if mode == "MCD_ULA":
+            g_n, s_n = grads(z_new), None
+        else:
+            g_n, s_n = grads(z_new), apply_sn(arch, sn, z_new, i if ula else i + 1, dtype)
         ub = grad_u(g_n, beta)
-        bk_mean = z_new - eps * ub + eps * s_n
+        bk_mean = z_new - eps * ub if s_n is None else z_new - eps * ub + eps * s_n
         w = w + (log_prob_kernel(z, bk_mean, scale) - log_prob_kernel(z_new, fk_mean, scale))
         z = z_new
         carried = (g_n, s_n)

@@ -49,6 +49,9 @@ def test_workspace_bytes_and_plugin_switch(hip_lib):
     # reference's message (mcd_utils.py:190)
     assert hip_lib.cmcd_workspace_bytes(C.byref(_desc(mode=7)), 2000) == 0
     assert _lib.last_error() == "Mode not implemented."
+    assert hip_lib.cmcd_workspace_bytes(C.byref(_desc(mode=2)), 2000) > 0          # MCD_ULA (arch placeholder dds)
+    assert hip_lib.cmcd_workspace_bytes(C.byref(_desc(mode=3, arch=0, emb_dim=20, target=0)), 300) > 0   # MCD_ULA_sn
+    assert hip_lib.cmcd_workspace_bytes(C.byref(_desc(mode=2, arch=0, emb_dim=20)), 300) == 0
     assert hip_lib.cmcd_workspace_bytes(C.byref(_desc(arch=5)), 2000) == 0
     assert hip_lib.cmcd_workspace_bytes(C.byref(_desc(nbridges=0)), 2000) == 0
     assert hip_lib.cmcd_workspace_bytes(C.byref(_desc(arch=0, emb_dim=20, target=0)), 300) > 0
@@ -70,7 +73,7 @@ def test_forward_rejects_bad_arguments_before_any_gpu_work(hip_lib):
     assert rc == -1 and "null pointer" in _lib.last_error()
     with pytest.raises(ValueError):
         _lib.check(rc)
-    rc = hip_lib.cmcd_bound_forward(C.byref(_desc(mode=3)), C.byref(lay), None, 16, None, 0, None, 0, None, 0,
+    rc = hip_lib.cmcd_bound_forward(C.byref(_desc(mode=9)), C.byref(lay), None, 16, None, 0, None, 0, None, 0,
                                     None, None, None, None)
     assert rc == -2
     with pytest.raises(NotImplementedError, match="Mode not implemented."):

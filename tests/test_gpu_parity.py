@@ -66,3 +66,42 @@ def test_lgcp_matches_oracle(hip_lib, n, k):
     rep = compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"lgcp n={n} k={k}")
     print("lgcp", n, k, rep, "mean loss", float(val), l_ref.mean())
     assert abs(float(val) - losses.double().mean().item()) <= 1e-5 * abs(l_ref.mean())
+
+
+@pytest.mark.parametrize("name,mode,n,over", [
+    ("gmm_n300_k8", "MCD_ULA", 300, {}),
+    ("gmm_n300_k8", "MCD_ULA_sn", 300, {}),
+    ("many_gmm_n2000_k256_dds", "MCD_ULA_sn", 200, dict(nbridges=32, init_eps=0.3, init_sigma=15.0)),
+    ("many_gmm_n2000_k256_dds", "MCD_ULA", 200, dict(nbridges=32, init_eps=0.3, init_sigma=15.0)),
+    ("funnel_n300_k64", "MCD_ULA_sn", 100, dict(nbridges=16)),
+])
+def test_sibling_overdamped_modes_match_oracle(hip_lib, variant, name, mode, n, over):
+    """config.boundmode = MCD_ULA / MCD_ULA_sn (reference mcd_over_orig.py) on the same kernels."""
+    if mode == "MCD_ULA" and variant == 2:
+        pytest.skip("MCD_ULA has no network: the cooperative (MLP-split) kernel does not apply")
+    b = synthetic.build(name, device="cuda", boundmode=mode, **over)
+    dim, K, _, spec = b["params_fixed"]
+    if mode == "MCD_ULA":    # the reference keeps no network for this mode: params_fixed[3] is None
+        flat, unflatten, fixed = mcdbm.initialize(dim=dim, nbridges=K, vdparams=None, eps=b["cfg"]["init_eps"],
+                                                  trainable=("eps",), mode="MCD_ULA", device="cuda")
+        assert fixed[3] is None
+        b = dict(b, params_flat=flat, unflatten=unflatten, params_fixed=fixed)
+    seeds = synthetic.parity_seeds(n)
+    _, (losses, z) = mcdbm.compute_bound(torch.from_numpy(seeds).cuda(), b["params_flat"], b["unflatten"],
+                                         b["params_fixed"], b["target"], eps_schedule=b["eps_schedule"],
+                                         grad_clipping=b["grad_clipping"])
+    torch.cuda.synchronize()
+    train, notrain = b["unflatten"](b["params_flat"].cpu())
+    if mode == "MCD_ULA":
+        allp = {**train, **notrain}
+        f = lambda t: np.asarray(t.numpy(), np.float64)
+        p = {"vd": {k: f(v) for k, v in allp["vd"].items()}, "eps": f(allp["eps"]), "mgridref_y": f(allp["mgridref_y"]),
+             "gridref_x": f(allp["gridref_x"]), "target_x": f(allp["target_x"])}
+        arch = "dds"
+    else:
+        p = synthetic.oracle_params(b["unflatten"], b["params_flat"])
+        arch = spec.arch
+    from helpers import oracle_target
+    l_ref, z_ref = orc.compute_log_elbo_batch(seeds, p, dim, K, mode, arch, oracle_target(b["cfg"]), dtype=np.float64)
+    rep = compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"{name} {mode}")
+    print(name, mode, rep)

@@ -74,7 +74,7 @@ def test_no_cpu_fallback_and_plugin_errors():
         mcdbm.compute_bound(seeds, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"])
     dim, K, _, spec = b["params_fixed"]
     with pytest.raises(NotImplementedError, match="Mode not implemented."):
-        mcdbm.compute_bound(seeds, b["params_flat"], b["unflatten"], (dim, K, "MCD_ULA_sn", spec), b["target"])
+        mcdbm.compute_bound(seeds, b["params_flat"], b["unflatten"], (dim, K, "MCD_U_a-lp", spec), b["target"])
     with pytest.raises(TypeError):
         mcdbm.compute_bound(seeds, b["params_flat"], b["unflatten"], b["params_fixed"], lambda z: z.sum())
     with pytest.raises(NotImplementedError):

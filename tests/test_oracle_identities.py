@@ -94,7 +94,7 @@ def test_unknown_mode_raises():
     b = synthetic.build("gmm_n300_k8", device="cpu")
     p = synthetic.oracle_params(b["unflatten"], b["params_flat"])
     with pytest.raises(NotImplementedError, match="Mode not implemented."):
-        orc.compute_log_elbo_batch(np.array([1]), p, 2, 8, "MCD_ULA", "geffner", oracle_target(b["cfg"]))
+        orc.compute_log_elbo_batch(np.array([1]), p, 2, 8, "MCD_U_a-lp", "geffner", oracle_target(b["cfg"]))
 
 
 def test_reductions_and_inf_semantics():
@@ -104,3 +104,40 @@ def test_reductions_and_inf_semantics():
     assert np.isclose(orc.ln_z(loss), np.log(np.exp(-1) + np.exp(-2) + np.exp(-.5)) - np.log(4))
     e = orc.log_final_losses(np.array([[1.0, 2.0], [3.0, 5.0]]))
     assert np.isclose(e[0], -2.75)
+
+
+def test_ula_modes_against_cais_and_longhand():
+    """MCD_ULA (mcd_over_orig.py, use_sn=False) == MCD_CAIS_sn with a zero network, constant eps, no clip
+    (same formulas); MCD_ULA_sn differs from CAIS only by dropping the forward drift and shifting the
+    backward index — checked against a longhand loop."""
+    b = synthetic.build("gmm_n300_k8", device="cpu")
+    seeds = synthetic.parity_seeds(30)
+    p = synthetic.oracle_params(b["unflatten"], b["params_flat"])
+    tgt = oracle_target(b["cfg"])
+    dim, K = 2, 8
+    p0 = dict(p)
+    p0["sn"] = dict(p["sn"]); p0["sn"]["factor_sn"] = np.zeros(())
+    l_cais, z_cais = orc.compute_log_elbo_batch(seeds, p0, dim, K, "MCD_CAIS_sn", "geffner", tgt, dtype=np.float64)
+    p_nosn = {k: v for k, v in p.items() if k != "sn"}
+    l_ula, z_ula = orc.compute_log_elbo_batch(seeds, p_nosn, dim, K, "MCD_ULA", "geffner", tgt, dtype=np.float64,
+                                              eps_schedule="cos_sq", grad_clipping=True)   # both ignored
+    np.testing.assert_allclose(l_ula, l_cais, rtol=1e-12)
+    np.testing.assert_allclose(z_ula, z_cais, rtol=1e-12)
+
+    l_sn, z_sn = orc.compute_log_elbo_batch(seeds, p, dim, K, "MCD_ULA_sn", "geffner", tgt, dtype=np.float64)
+    e0, e = prng.particle_noise(seeds, dim, K)
+    mean, std = p["vd"]["mean"], np.exp(p["vd"]["logdiag"])
+    x = mean + std * e0
+    w = -np.sum(-0.5 * ((x - mean) / std) ** 2 - np.log(std) - 0.5 * np.log(2 * np.pi), -1)
+    eps = float(p["eps"])
+    for i in range(K):
+        beta = (i + 1) / (K + 1)
+        gu = lambda y: -(beta * tgt(y)[1] + (1 - beta) * (-(y - mean) / std ** 2))
+        fk = x - eps * gu(x)
+        xn = fk + np.sqrt(2 * eps) * e[:, i]
+        bk = xn - eps * gu(xn) + eps * orc.apply_geffner(p["sn"], xn, i, np.float64)     # index i  (:44)
+        w += (-np.sum((x - bk) ** 2, -1) + np.sum((xn - fk) ** 2, -1)) / (4 * eps)
+        x = xn
+    w += tgt(x)[0]
+    np.testing.assert_allclose(l_sn, -w, rtol=1e-9, atol=1e-9)
+    assert np.abs(l_sn - l_ula).max() > 1e-4     # the network matters
