@@ -117,7 +117,10 @@ def main():
     from cmcd_amd import _lib, build, synthetic
     from cmcd_amd import mcdboundingmachine as mcdbm
     from cmcd_amd import parallel
-    build.build()
+    if local_rank == 0:
+        build.build()          # only one process per node may (re)build the in-tree library
+    if use_dist:
+        dist.barrier()
 
     name = args.config or synthetic.NORTH_STAR
     over = {"N": args.particles} if args.particles else {}
@@ -214,6 +217,25 @@ def main():
         result["saturated"] = {"particles": ns, "kernel_ms": ks * 1e3, "value": ns * K / ks,
                                "achieved": ns * K * f_alg / ks / 1e12,
                                "frac": ns * K * f_alg / ks / 1e12 / PEAK_FP32_TFLOPS}
+
+    if rank == 0 and world == 1 and name == synthetic.NORTH_STAR:
+        # value-and-gradient of the VarGrad loss on the same batch (boundmode MCD_CAIS_var_sn, same net/target)
+        try:
+            bv = synthetic.build(name, device=device, boundmode="MCD_CAIS_var_sn", **over)
+            gargs = (seeds, bv["params_flat"], bv["unflatten"], bv["params_fixed"], bv["target"])
+            gkw = dict(eps_schedule=bv["eps_schedule"], grad_clipping=bv["grad_clipping"])
+            for _ in range(2):
+                mcdbm.compute_log_var_grad(*gargs, **gkw)
+            torch.cuda.synchronize()
+            tg0 = time.perf_counter()
+            for _ in range(5):
+                mcdbm.compute_log_var_grad(*gargs, **gkw)
+            torch.cuda.synchronize()
+            tg = (time.perf_counter() - tg0) / 5
+            result["vargrad"] = {"ms_per_value_and_grad": tg * 1e3, "value": n * K / tg,
+                                 "unit": "bridge-steps*particles/s (forward + backward)"}
+        except NotImplementedError as e:
+            result["vargrad"] = {"error": str(e)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, parity = cpu_baseline(b, seeds_np, losses.cpu().numpy(), args.cpu_particles)
