@@ -11,7 +11,7 @@ namespace cmcd {
 // ------------------------------------------------------------------------------------------
 struct WsLayout {
   int64_t beta, eps, sig, logsig;  // [K] each
-  int64_t sched;                   // [K][8] {beta, eps, sig, logsig + log sqrt(2pi), 1/(2 sig^2), 0,0,0}
+  int64_t sched;                   // [K][8] {beta, eps, sig, logsig + log sqrt(2pi), 1/(2 sig^2), eps*beta, eps*(1-beta), 0}
   int64_t bias1;                   // [K+1][HP]
   int64_t utab;                    // [K+1][HP]   (geffner only, else aliases bias1)
   int64_t w1z;                     // [D][HP]

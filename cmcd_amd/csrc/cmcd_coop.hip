@@ -7,16 +7,18 @@
 //   waves 0..T-1  MLP: wave v owns hidden-neuron tile v (16 neurons): 4 first-layer neurons per lane,
 //                 its W2 A-fragments (resident in VGPRs for the whole launch), its MFMA accumulator, its
 //                 slice of the output dot product; advances z redundantly (needs it for layer 1);
-//   waves T, T+1  TGT: grad log p(z) for 8 particles each, 8 lanes per particle;
+//   waves T, T+1  TGT: grad log p(z) for 8 particles each, 8 lanes per particle (z read from LDS);
 //   wave  T+2     RNG: the jax Threefry key chain, one bridge AHEAD, raw bits only (integer chain);
 //   wave  T+3     ACC: bits -> Gaussian deviates (Giles erfinv), and the only owner of the log-weight w
 //                 and of the outputs.
 // Per bridge evaluation i, two raw s_barriers (LDS visibility via s_waitcnt lgkmcnt(0) only):
-//   interval 1:  phase C(i-1) (combine layer-3 partials, grad log p, noise -> z_i)  then
-//                MLP: layer 1 + activation -> hbuf | TGT: squared distances | RNG: split(gen)
+//   interval 1:  MLP only: phase C(i-1) (layer-3 partials, grad log p, noise -> z_i), publish z_i,
+//                layer 1 + activation -> hbuf.   (RNG: split(gen); TGT / ACC idle: VALU issue is a per-SIMD
+//                resource and they share SIMDs with the MLP waves)
 //   barrier 1
 //   interval 2:  MLP: layer 2 on the matrix cores from hbuf, activation, layer-3 partial -> part |
-//                TGT: exp/sums -> gpb | RNG: split(H), normal bits -> raw | ACC: raw -> nzb
+//                TGT: both target passes -> gpb | RNG: split(H), normal bits -> raw |
+//                ACC: raw -> nzb, and phase C(i-1) again (one bridge late) for the log-weight
 //   barrier 2
 // Same arithmetic as traj_kernel (cmcd_kernels.hip); reference lines are cited there.
 #include <hip/hip_runtime.h>
@@ -60,8 +62,10 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
   constexpr int PT = (T * D + 3) & ~3;       // layer-3 partials per particle, padded
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* hbuf = lds;                         // [T][4][16][4]  layer-1 activations, MFMA-B order
-  float* part = hbuf + HP * 16;              // [16][PT]       layer-3 partial sums, [c][v*D + j]
-  float* gpb = part + 16 * PT;               // [2][16][GP]    grad log p, log p
+  constexpr int ZP = (D + 3) & ~3;
+  float* part = hbuf + HP * 16;              // [2][16][PT]    layer-3 partial sums, [c][v*D + j]
+  float* zbuf = part + 2 * 16 * PT;          // [16][ZP]       z_i published by MLP wave 0
+  float* gpb = zbuf + 16 * ZP;               // [2][16][GP]    grad log p, log p
   float* nzb = gpb + 2 * 16 * GP;            // [2][16][NZ]    Gaussian noise
   uint32_t* raw = reinterpret_cast<uint32_t*>(nzb + 2 * 16 * NZ);  // [2][16][NZ] raw bits
   float* lds_tgt = reinterpret_cast<float*>(raw + 2 * 16 * NZ);
@@ -76,23 +80,8 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
   const int64_t p = tile * 16 + c;
   const bool valid = p < a.n;
   const int K = a.K;
-#ifdef CMCD_STAMPS
-  const int abl = a.var_mode >> 8;  // diagnostic ablation mask (results are wrong on purpose)
-  a.var_mode &= 0xff;
-#else
-  constexpr int abl = 0;
-#endif
 
   for (int i = threadIdx.x; i < a.w.tgt_floats; i += blockDim.x) lds_tgt[i] = a.ws[a.w.tgt + i];
-
-  // Static issue priority (diagnostic knob in the stamp build): the waves dispatched second
-  // on each SIMD (the aux waves) otherwise only get the issue slots their older partner leaves.
-#ifdef CMCD_STAMPS
-  {
-    const int pm = (abl >> 8) & 3;   // 0 none, 1 aux waves high, 2 MLP waves high, 3 TGT only high
-    if ((pm == 1 && !is_mlp) || (pm == 2 && is_mlp) || (pm == 3 && is_tgt)) __builtin_amdgcn_s_setprio(3);
-  }
-#endif
 
   // ---- per-role resident operands
   f32x4 afrag[T], w1z[D], w3t[D], b2v;
@@ -198,12 +187,73 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
   float* const my_h = hbuf + ((wv * 4 + g) * 16 + (lane & 15)) * 4;
   const float* const rd_h = hbuf + (g * 16 + (lane & 15)) * 4;
 
-  float fk_lp = 0.f, pbeta = 0.f, peps = 0.f, pinv2s2 = 0.f, pcst = 0.f, logp = 0.f;
+  float fk_lp = 0.f, peps = 0.f, pinv2s2 = 0.f, pcst = 0.f, logp = 0.f;
   f32x4 brow = {0.f, 0.f, 0.f, 0.f}, urow = {0.f, 0.f, 0.f, 0.f};
   if (is_mlp) {
     brow = *reinterpret_cast<const f32x4*>(brow_ptr);
     if (ARCH == CMCD_ARCH_GEFFNER) urow = *reinterpret_cast<const f32x4*>(urow_ptr);
   }
+
+  // Phase C of evaluation e: s(z_e, e) from the layer-3 partials, grad log p, grad log q; [track_w: close
+  // step e-1 into the log-weight, mcd_cais.py:71-86]; open step e (forward kernel, mcd_cais.py:52-67) ->
+  // z_{e+1}.  VALU issue is a per-SIMD resource shared by co-resident waves (measured: the younger wave of
+  // a SIMD runs 2.2x slower while its partner issues), so only the waves that need z_{e+1} immediately (the
+  // MLP waves) run this after barrier 2; ACC repeats it one bridge later inside interval 2, for w.
+  // Arithmetic note: uf = -(beta gp + (1-beta) gq), fk = z - eps uf - eps s  (mcd_cais.py:52-61) is evaluated
+  // as fk = fma(eps beta, gp, fma(eps (1-beta), gq, fma(-eps, s, z))) with the two products precombined in
+  // the schedule table: same value up to the last rounding, a third of the instructions.  Clips are
+  // v_med3_f32 against +-inf when clipping is off (no branch).
+  const float cp = clip_p ? clipv : INFINITY, cq = clip_q ? clipv : INFINITY;
+  float pA = 0.f, pB = 0.f;
+  auto phase_c = [&](int e, bool track_w, const f32x4& sc, const f32x4& sd) {
+    const int pb = e & 1;
+    const float eps = sc[1], sig = sc[2], cst = sc[3], inv2s2 = sd[0], cA = sd[1], cB = sd[2];
+    float sn[D], gp[D], gq[D];
+    {
+      float pt[PT], gv[GP];
+#pragma unroll
+      for (int q = 0; q < PT; q += 4)
+        *reinterpret_cast<f32x4*>(pt + q) = *reinterpret_cast<const f32x4*>(part + (pb * 16 + c) * PT + q);
+#pragma unroll
+      for (int q = 0; q < GP; q += 4)
+        *reinterpret_cast<f32x4*>(gv + q) = *reinterpret_cast<const f32x4*>(gpb + (pb * 16 + c) * GP + q);
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        float o = b3[j];
+#pragma unroll
+        for (int v = 0; v < T; ++v) o += pt[v * D + j];
+        sn[j] = (ARCH == CMCD_ARCH_DDS) ? __builtin_amdgcn_fmed3f(o, -1e4f, 1e4f) : o * factor;
+        gp[j] = __builtin_amdgcn_fmed3f(gv[j], -cp, cp);
+        gq[j] = __builtin_amdgcn_fmed3f((qmean[j] - z[j]) * qiv[j], -cq, cq);
+      }
+      logp = gv[D];
+    }
+    if (track_w && e > 0) {  // backward kernel of step e-1: bk = z - eps ub + eps s, ub = -(beta gp + (1-beta) gq)
+      float bk_lp = 0.f;
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        const float bk = fmaf(pA, gp[j], fmaf(pB, gq[j], fmaf(peps, sn[j], z[j])));
+        const float db = zp[j] - bk;
+        bk_lp += -(db * db) * pinv2s2 - pcst;
+      }
+      w += bk_lp - fk_lp;
+    }
+    if (e == K) return;
+    fk_lp = 0.f;
+    const float seps = a.ula ? 0.f : -eps;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const float fk = fmaf(cA, gp[j], fmaf(cB, gq[j], fmaf(seps, sn[j], z[j])));
+      const float zn = fmaf(sig, nzb[(pb * 16 + c) * NZ + j], fk);
+      if (track_w) {
+        const float df = zn - fk;
+        fk_lp += -(df * df) * inv2s2 - cst;
+        zp[j] = z[j];
+      }
+      z[j] = zn;
+    }
+    peps = eps; pinv2s2 = inv2s2; pcst = cst; pA = cA; pB = cB;
+  };
 
 #ifdef CMCD_STAMPS
   unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last;
@@ -212,23 +262,25 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
   for (int i = 0; i <= K; ++i) {
     const int buf = i & 1;
     // per-bridge scalars {beta, eps, sigma, log sigma + log sqrt(2 pi), 1/(2 sigma^2)}.  VECTOR loads
-    // (vmcnt) issued a whole bridge before use: a scalar load here would sit on lgkmcnt, which every
-    // LDS wait of the step drains, exposing its full L2 latency on the critical path.
-    const f32x4 sc0 = *reinterpret_cast<const f32x4*>(sched_v);
-    const float inv2s2 = sched_v[4];
-    sched_v += (i + 1 < K) ? 8 : 0;
-    const float beta = sc0[0], eps = sc0[1], sig = sc0[2], cst = sc0[3];
+    // (vmcnt) issued early: a scalar load would sit on lgkmcnt, which every LDS wait of the step drains,
+    // exposing its full L2 latency.  MLP waves need row i (phase C(i) after barrier 2), ACC row i-1.
+    const int srow = is_acc ? (i > 0 ? i - 1 : 0) : (i < K ? i : K - 1);
+    const f32x4 sc0 = *reinterpret_cast<const f32x4*>(sched_v + 8 * srow);
+    const f32x4 sc1 = *reinterpret_cast<const f32x4*>(sched_v + 8 * srow + 4);
     f32x4 h = {0.f, 0.f, 0.f, 0.f};
-    typename Target<TARGET, D>::State tst;
     uint32_t g0 = 0, g1 = 0, h0 = 0, h1 = 0;
-    // ------------------------------------------------------------------ interval 1 (after phase C)
+    // ------------------------------------------------------------------ interval 1
     if (is_mlp) {
+      if (wv == 0 && g == 0) {  // publish z_i for the TGT waves
+#pragma unroll
+        for (int j = 0; j < D; ++j) zbuf[c * ZP + j] = z[j];
+      }
       f32x4 pre = brow;
 #pragma unroll
       for (int j = 0; j < D; ++j) pre += z[j] * w1z[j];
       if (ARCH == CMCD_ARCH_DDS) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) h[r] = (abl & 16) ? pre[r] : gelu_fast(pre[r]);
+        for (int r = 0; r < 4; ++r) h[r] = gelu_fast(pre[r]);
       } else {
         f32x4 u = urow;
         if (wv == 0) {  // the first D neurons of u are z itself (D <= 16)
@@ -242,11 +294,8 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) h[r] = u[r] + softplus(pre[r]);
       }
-      STAMP(5);
       *reinterpret_cast<f32x4*>(my_h) = h;
-    } else if (is_tgt) {
-      if (!(abl & 1)) Target<TARGET, D>::template pass1<8>(z, sub8, lds_tgt, tst);
-    } else if (is_rng && i + 1 < K && !(abl & 2)) {
+    } else if (is_rng && i + 1 < K) {
       uint32_t x0 = gb, x1 = 2 + gb;
       threefry2x32(k0, k1, x0, x1);            // (G, H) = split(gen) of bridge i+1
       rows01(x0, g0, g1);
@@ -264,8 +313,6 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
       if (ARCH == CMCD_ARCH_GEFFNER) urow = *reinterpret_cast<const f32x4*>(urow_ptr + (int64_t)nrow * HP);
       // layer 2: rows = my 16 output neurons, cols = particles, k = all HP inputs from LDS
       f32x4 acc = b2v;
-      STAMP(6);
-      if (!(abl & 8))
 #pragma unroll
       for (int ti = 0; ti < T; ++ti) {
         const f32x4 hb = *reinterpret_cast<const f32x4*>(rd_h + ti * 256);
@@ -273,89 +320,43 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
         for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ti][r], hb[r], acc, 0, 0, 0);
       }
       f32x4 h2;
-      asm volatile("" : "+v"(acc));
-      STAMP(7);
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        h2[r] = (abl & 16) ? acc[r] : ((ARCH == CMCD_ARCH_DDS) ? gelu_fast(acc[r]) : h[r] + softplus(acc[r]));
-      asm volatile("" : "+v"(h2));
-      STAMP(8);
+      for (int r = 0; r < 4; ++r) h2[r] = (ARCH == CMCD_ARCH_DDS) ? gelu_fast(acc[r]) : h[r] + softplus(acc[r]);
 #pragma unroll
       for (int j = 0; j < D; ++j) {
         float pj = h2[0] * w3t[j][0] + h2[1] * w3t[j][1] + h2[2] * w3t[j][2] + h2[3] * w3t[j][3];
         pj = group_sum(pj);
-        if (g == 0) part[c * PT + wv * D + j] = pj;
+        if (g == 0) part[(buf * 16 + c) * PT + wv * D + j] = pj;
       }
     } else if (is_tgt) {
-      float gp[D], lp = 0.f;
+      // z_i from LDS; both passes here, while the SIMD partner (an MLP wave) sits in its MFMA chain
+      float zt[D], gp[D], lp = 0.f;
 #pragma unroll
-      for (int j = 0; j < D; ++j) gp[j] = 0.f;
-      if (!(abl & 1)) Target<TARGET, D>::template pass2<8>(z, sub8, lds_tgt, tst, lp, gp);
+      for (int j = 0; j < D; ++j) zt[j] = zbuf[c * ZP + j];
+      typename Target<TARGET, D>::State tst;
+      Target<TARGET, D>::template pass1<8>(zt, sub8, lds_tgt, tst);
+      Target<TARGET, D>::template pass2<8>(zt, sub8, lds_tgt, tst, lp, gp);
       if (sub8 == 0) {
 #pragma unroll
         for (int j = 0; j < D; ++j) gpb[(buf * 16 + c) * GP + j] = gp[j];
         gpb[(buf * 16 + c) * GP + D] = lp;
       }
     } else if (is_rng) {
-      if (i + 1 < K && !(abl & 2)) normal_bits(g0, g1, h0, h1, buf ^ 1, true);
+      if (i + 1 < K) normal_bits(g0, g1, h0, h1, buf ^ 1, true);
     } else {
-      if (i < K && !(abl & 4)) convert(buf);
+      if (i < K) convert(buf);                       // noise of bridge i, read in phase C(i)
+      if (i > 0) phase_c(i - 1, true, sc0, sc1);     // shadow of the trajectory, one bridge late: w
     }
     STAMP(2);
     lds_barrier();
     STAMP(3);
-    // ------------------------------------------------------------------ phase C
-    if (is_rng) continue;
-    float sn[D], gp[D], gq[D];
-    {
-      float pt[PT], gv[GP];
-#pragma unroll
-      for (int q = 0; q < PT; q += 4)
-        *reinterpret_cast<f32x4*>(pt + q) = *reinterpret_cast<const f32x4*>(part + c * PT + q);
-#pragma unroll
-      for (int q = 0; q < GP; q += 4)
-        *reinterpret_cast<f32x4*>(gv + q) = *reinterpret_cast<const f32x4*>(gpb + (buf * 16 + c) * GP + q);
-#pragma unroll
-      for (int j = 0; j < D; ++j) {
-        float o = b3[j];
-#pragma unroll
-        for (int v = 0; v < T; ++v) o += pt[v * D + j];
-        sn[j] = (ARCH == CMCD_ARCH_DDS) ? fminf(fmaxf(o, -1e4f), 1e4f) : o * factor;
-        gp[j] = gv[j];
-        gq[j] = -(z[j] - qmean[j]) * qiv[j];
-        if (clip_p) gp[j] = fminf(fmaxf(gp[j], -clipv), clipv);
-        if (clip_q) gq[j] = fminf(fmaxf(gq[j], -clipv), clipv);
-      }
-      logp = gv[D];
-    }
-    STAMP(9);
-    if (is_acc && i > 0) {  // backward kernel of step i-1 (mcd_cais.py:71-86): only ACC tracks w
-      float bk_lp = 0.f;
-#pragma unroll
-      for (int j = 0; j < D; ++j) {
-        const float ub = -1.0f * (pbeta * gp[j] + (1.0f - pbeta) * gq[j]);
-        const float bk = z[j] - peps * ub + peps * sn[j];
-        const float db = zp[j] - bk;
-        bk_lp += -(db * db) * pinv2s2 - pcst;
-      }
-      w += bk_lp - fk_lp;
-    }
-    if (i == K) break;
-    fk_lp = 0.f;
-#pragma unroll
-    for (int j = 0; j < D; ++j) {  // forward kernel of step i (mcd_cais.py:52-67)
-      const float uf = -1.0f * (beta * gp[j] + (1.0f - beta) * gq[j]);
-      const float fk = z[j] - eps * uf - eps * (a.ula ? 0.f : sn[j]);
-      const float zn = fk + sig * nzb[(buf * 16 + c) * NZ + j];
-      if (is_acc) {
-        const float df = zn - fk;
-        fk_lp += -(df * df) * inv2s2 - cst;
-        zp[j] = z[j];
-      }
-      z[j] = zn;
-    }
-    pbeta = beta; peps = eps; pinv2s2 = inv2s2; pcst = cst;
+    // ------------------------------------------------------------------ phase C (MLP waves only)
+    if (is_mlp && i < K) phase_c(i, false, sc0, sc1);
     STAMP(4);
+  }
+  if (is_acc) {  // last evaluation: closes step K-1 and picks up log p(z_K)
+    const f32x4 dummy = {0.f, 0.f, 0.f, 0.f};
+    phase_c(K, true, dummy, dummy);
   }
 #ifdef CMCD_STAMPS
   if (blockIdx.x == 0 && lane == 0)
@@ -430,7 +431,8 @@ int coop_launch(const cmcd_desc& d, const TrajArgs& ta, void* stream) {
   const int GP = (D + 1 + 3) & ~3, PT = (T * D + 3) & ~3;
   coop_fn fn = pick(d, T);
   if (!fn) return CMCD_ERR_UNSUPPORTED;
-  const size_t lds_bytes = size_t(16 * T * 16 + 16 * PT + 2 * 16 * GP + 2 * 16 * NZ + 2 * 16 * NZ + ta.w.tgt_floats) * 4;
+  const int ZP = (D + 3) & ~3;
+  const size_t lds_bytes = size_t(16 * T * 16 + 2 * 16 * PT + 16 * ZP + 2 * 16 * GP + 2 * 16 * NZ + 2 * 16 * NZ + ta.w.tgt_floats) * 4;
   hipLaunchKernelGGL(fn, dim3((unsigned)ta.w.n_waves), dim3(64 * (T + 4)), lds_bytes,
                      static_cast<hipStream_t>(stream), ta);
   return CMCD_OK;

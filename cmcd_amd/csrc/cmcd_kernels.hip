@@ -178,7 +178,9 @@ __device__ __forceinline__ void prep_sched_body(const SchedArgs& a) {
     sc[2] = s;
     sc[3] = logf(s) + kHalfLog2Pi;
     sc[4] = 1.0f / (2.0f * s * s);
-    sc[5] = sc[6] = sc[7] = 0.f;
+    sc[5] = e * sc[0];            // eps * beta
+    sc[6] = e * (1.0f - sc[0]);   // eps * (1 - beta)
+    sc[7] = 0.f;
   }
 }
 
@@ -890,9 +892,6 @@ int cmcd_bound_forward(const cmcd_desc* desc, const cmcd_layout* lay, const int3
               (int32_t)K, d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0,
               (d.mode == CMCD_MODE_ULA || d.mode == CMCD_MODE_ULA_SN) ? 0 : d.grad_clipping,
               d.mode == CMCD_MODE_ULA ? 1 : (d.mode == CMCD_MODE_ULA_SN ? 2 : 0)};
-#ifdef CMCD_STAMPS
-  if (const char* e = getenv("CMCD_ABLATE")) ta.var_mode |= atoi(e) << 8;
-#endif
   // Kernel variant (desc.reserved: 0 auto, 1 wave-per-tile, 2 CU-cooperative).  Auto: the
   // cooperative kernel while the batch cannot fill the chip with one wave per tile.
   const bool coop_ok = coop_available(d, w.T) && d.mode != CMCD_MODE_ULA;
