@@ -236,6 +236,23 @@ def main():
                                  "unit": "bridge-steps*particles/s (forward + backward)"}
         except NotImplementedError as e:
             result["vargrad"] = {"error": str(e)}
+        # value-and-gradient of the north-star's own training loss (MCD_CAIS_sn, reparameterised gradient:
+        # forward with stored trajectory + reverse sweep) on the same batch
+        try:
+            gargs = (seeds, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"])
+            gkw = dict(eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
+            for _ in range(2):
+                mcdbm.compute_bound_grad(*gargs, **gkw)
+            torch.cuda.synchronize()
+            tg0 = time.perf_counter()
+            for _ in range(5):
+                mcdbm.compute_bound_grad(*gargs, **gkw)
+            torch.cuda.synchronize()
+            tg = (time.perf_counter() - tg0) / 5
+            result["training_step"] = {"ms_per_value_and_grad": tg * 1e3, "value": n * K / tg,
+                                       "unit": "bridge-steps*particles/s (forward + reverse sweep)"}
+        except NotImplementedError as e:
+            result["training_step"] = {"error": str(e)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, parity = cpu_baseline(b, seeds_np, losses.cpu().numpy(), args.cpu_particles)

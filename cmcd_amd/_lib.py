@@ -62,6 +62,12 @@ def lib():
         L.cmcd_bound_var_grad.argtypes = [C.POINTER(Desc), C.POINTER(Layout), C.c_void_p, C.c_int64, C.c_void_p,
                                           C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
                                           C.c_void_p, C.c_void_p]
+        L.cmcd_bound_grad_workspace_bytes.restype = C.c_int64
+        L.cmcd_bound_grad_workspace_bytes.argtypes = [C.POINTER(Desc), C.c_int64]
+        L.cmcd_bound_grad.restype = C.c_int
+        L.cmcd_bound_grad.argtypes = [C.POINTER(Desc), C.POINTER(Layout), C.c_void_p, C.c_int64, C.c_void_p,
+                                      C.c_int64, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_int64,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.cmcd_stats_merge_device.restype = C.c_int
         L.cmcd_stats_merge_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.cmcd_profile_enable.restype = C.c_int

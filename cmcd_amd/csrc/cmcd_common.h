@@ -40,6 +40,7 @@ struct TrajArgs {
   WsLayout w;
   int64_t n;
   int32_t K, var_mode, grad_clipping;
+  float* traj;  // optional [K+1][n][D] trajectory z_0..z_K (the reparameterised gradient's reverse sweep reads it)
   int32_t ula;  // 0: CAIS; 1: MCD_ULA (no network); 2: MCD_ULA_sn (network in the backward kernel only, index i)
 };
 
@@ -58,8 +59,11 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
 // cmcd_grad.hip: VarGrad gradient (widths <= 64)
 bool grad_available(const cmcd_desc& d, int T);
 int64_t grad_workspace_floats(const cmcd_desc& d, int HP, int64_t n);
+// omega: per-particle weights (VarGrad), or nullptr with omega_scalar; traj: nullptr => VarGrad (local)
+// gradient, else the reverse sweep of the reparameterised gradient over the stored trajectory.
 int grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, const int32_t* seeds, int64_t n,
-                const float* params, int64_t n_params, const float* ws_fwd, const float* omega, float* gws,
-                float* grad, void* stream);
+                const float* params, int64_t n_params, const float* ws_fwd, const float* omega, float omega_scalar,
+                const float* traj, float* gws, float* grad, void* stream);
+bool bptt_available(const cmcd_desc& d, int T);
 
 }  // namespace cmcd

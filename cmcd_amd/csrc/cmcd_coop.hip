@@ -175,6 +175,10 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
     const float dz = z[j] - qmean[j];
     w -= -(dz * dz) / (2.0f * qstd[j] * qstd[j]) - logf(qstd[j]) - kHalfLog2Pi;
   }
+  if (is_acc && a.traj && valid && g == 0) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) a.traj[p * D + j] = z[j];
+  }
 
   const float clipv = a.var_mode ? 1e2f : 1e3f;
   const bool clip_p = a.grad_clipping != 0;
@@ -251,6 +255,10 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
         zp[j] = z[j];
       }
       z[j] = zn;
+    }
+    if (track_w && a.traj && valid && g == 0) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) a.traj[((int64_t)(e + 1) * a.n + p) * D + j] = z[j];
     }
     peps = eps; pinv2s2 = inv2s2; pcst = cst; pA = cA; pB = cB;
   };

@@ -299,6 +299,50 @@ struct Target<CMCD_TARGET_MANY_GMM, 2> {
     pass1<4>(z, g, tc, st);
     pass2<4>(z, g, tc, st, logp, grad);
   }
+  // Second order (reparameterised gradient): with responsibilities r_k and d_k = z - mu_k,
+  //   grad = -(1/s^2) sum r d,   Hessian = -I/s^2 + (1/s^4) (sum r d d^T - (sum r d)(sum r d)^T);  H = {h00, h01, h11}
+  static constexpr int HN = 3;
+  __device__ static __forceinline__ void eval_hess(const float (&z)[2], int g, const float* tc, float& logp,
+                                                   float (&grad)[2], float (&H)[3]) {
+    const float inv_s = tc[0], c2 = tc[1], c0 = tc[3];
+    const int nm = __float_as_int(tc[2]);
+    const float2* mu = reinterpret_cast<const float2*>(tc + kLdsHeader);
+    float dmin = INFINITY;
+    for (int k = g; k < nm; k += 4) {
+      const float2 mk = mu[k];
+      const float dx = z[0] - mk.x, dy = z[1] - mk.y;
+      dmin = fminf(dmin, fmaf(dx, dx, dy * dy));
+    }
+    dmin = -group_max(-dmin);
+    float s = 0.f, sx = 0.f, sy = 0.f, sxx = 0.f, sxy = 0.f, syy = 0.f;
+    for (int k = g; k < nm; k += 4) {
+      const float2 mk = mu[k];
+      const float dx = z[0] - mk.x, dy = z[1] - mk.y;
+      const float e = __builtin_amdgcn_exp2f(c2 * (fmaf(dx, dx, dy * dy) - dmin));
+      s += e;
+      sx = fmaf(e, dx, sx);
+      sy = fmaf(e, dy, sy);
+      sxx = fmaf(e * dx, dx, sxx);
+      sxy = fmaf(e * dx, dy, sxy);
+      syy = fmaf(e * dy, dy, syy);
+    }
+    s = group_sum(s); sx = group_sum(sx); sy = group_sum(sy);
+    sxx = group_sum(sxx); sxy = group_sum(sxy); syy = group_sum(syy);
+    const float lp = 0.69314718055994530942f * (fmaf(c2, dmin, c0) + __builtin_amdgcn_logf(s));
+    const bool valid = lp > -1e4f;
+    const float rs = 1.0f / s, i2 = inv_s * inv_s;
+    const float mx = sx * rs, my = sy * rs;
+    logp = valid ? lp : -INFINITY;
+    grad[0] = valid ? -i2 * mx : 0.f;
+    grad[1] = valid ? -i2 * my : 0.f;
+    H[0] = valid ? fmaf(i2 * i2, fmaf(sxx, rs, -mx * mx), -i2) : 0.f;
+    H[1] = valid ? i2 * i2 * fmaf(sxy, rs, -mx * my) : 0.f;
+    H[2] = valid ? fmaf(i2 * i2, fmaf(syy, rs, -my * my), -i2) : 0.f;
+  }
+  __device__ static __forceinline__ void hvp(const float (&H)[3], const float (&)[2], const float (&v)[2], float (&hv)[2]) {
+    hv[0] = H[0] * v[0] + H[1] * v[1];
+    hv[1] = H[1] * v[0] + H[2] * v[1];
+  }
 };
 
 // gmm: /root/reference/src/model_handler.py:157-200 (3 components, symmetrised by flip).
@@ -349,6 +393,53 @@ struct Target<CMCD_TARGET_GMM, 2> {
     grad[0] = wa * gax + wb * gby;  // un-flip the second gradient
     grad[1] = wa * gay + wb * gbx;
   }
+  // Second order: per half  M = sum_k r_k (-P_k + q_k q_k^T), q_k = -P_k (x - mu_k);  Hessian = sum_halves w M - grad grad^T
+  __device__ static __forceinline__ void raw2(float x, float y, float& f, float& gx, float& gy, float (&M)[3]) {
+    constexpr float pa00 = 1.0f / 0.7f, pa11 = 20.0f;
+    constexpr float pc00 = 10.256410256410257f, pc01 = -9.743589743589743f;
+    constexpr float lca = -1.2602857463310935f, lcc = -1.7725379045882876f;
+    float d0 = x - 3.0f, d1 = y;
+    const float pa0 = pa00 * d0, pa1 = pa11 * d1;
+    const float la = fmaf(-0.5f, d0 * pa0 + d1 * pa1, lca);
+    d0 = x + 2.5f;
+    const float pb0 = pa00 * d0, pb1 = pa11 * d1;
+    const float lb = fmaf(-0.5f, d0 * pb0 + d1 * pb1, lca);
+    d0 = x - 2.0f;
+    d1 = y - 3.0f;
+    const float pc0 = pc00 * d0 + pc01 * d1, pc1 = pc01 * d0 + pc00 * d1;
+    const float lc = fmaf(-0.5f, d0 * pc0 + d1 * pc1, lcc);
+    const float m = fmaxf(la, fmaxf(lb, lc));
+    const float ea = expf(la - m), eb = expf(lb - m), ec = expf(lc - m);
+    const float s = ea + eb + ec;
+    f = m + logf(s);
+    const float rs = 1.0f / s;
+    const float ra = ea * rs, rb = eb * rs, rc = ec * rs;
+    gx = -(ra * pa0 + rb * pb0 + rc * pc0);
+    gy = -(ra * pa1 + rb * pb1 + rc * pc1);
+    M[0] = ra * (pa0 * pa0 - pa00) + rb * (pb0 * pb0 - pa00) + rc * (pc0 * pc0 - pc00);
+    M[1] = ra * (pa0 * pa1) + rb * (pb0 * pb1) + rc * (pc0 * pc1 - pc01);
+    M[2] = ra * (pa1 * pa1 - pa11) + rb * (pb1 * pb1 - pa11) + rc * (pc1 * pc1 - pc00);
+  }
+  static constexpr int HN = 3;
+  __device__ static __forceinline__ void eval_hess(const float (&z)[2], int, const float*, float& logp,
+                                                   float (&grad)[2], float (&H)[3]) {
+    float fa, gax, gay, fb, gbx, gby, Ma[3], Mb[3];
+    raw2(z[0], z[1], fa, gax, gay, Ma);
+    raw2(z[1], z[0], fb, gbx, gby, Mb);
+    const float m = fmaxf(fa, fb);
+    const float lse = m + logf(expf(fa - m) + expf(fb - m));
+    logp = lse - 0.69314718055994530942f;
+    const float wa = expf(fa - lse), wb = expf(fb - lse);
+    grad[0] = wa * gax + wb * gby;
+    grad[1] = wa * gay + wb * gbx;
+    H[0] = wa * Ma[0] + wb * Mb[2] - grad[0] * grad[0];
+    H[1] = wa * Ma[1] + wb * Mb[1] - grad[0] * grad[1];
+    H[2] = wa * Ma[2] + wb * Mb[0] - grad[1] * grad[1];
+  }
+  __device__ static __forceinline__ void hvp(const float (&H)[3], const float (&)[2], const float (&v)[2], float (&hv)[2]) {
+    hv[0] = H[0] * v[0] + H[1] * v[1];
+    hv[1] = H[1] * v[0] + H[2] * v[1];
+  }
 };
 
 // funnel: /root/reference/src/model_handler.py:124-143 (scale of v hard-coded 3.0).
@@ -376,6 +467,26 @@ struct Target<CMCD_TARGET_FUNNEL, D> {
     grad[0] = -v / 9.0f - 0.5f * (D - 1) + 0.5f * emv * ss;
 #pragma unroll
     for (int j = 1; j < D; ++j) grad[j] = -z[j] * emv;
+  }
+  // Second order: d2/dv2 = -1/9 - e^{-v} ss / 2,  d2/dv dz_j = z_j e^{-v},  d2/dz_j2 = -e^{-v};  H = {e^{-v}, ss}
+  static constexpr int HN = 2;
+  __device__ static __forceinline__ void eval_hess(const float (&z)[D], int g, const float* tc, float& logp,
+                                                   float (&grad)[D], float (&H)[2]) {
+    eval(z, g, tc, logp, grad);
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 1; j < D; ++j) ss = fmaf(z[j], z[j], ss);
+    H[0] = expf(-z[0]);
+    H[1] = ss;
+  }
+  __device__ static __forceinline__ void hvp(const float (&H)[2], const float (&z)[D], const float (&v)[D], float (&hv)[D]) {
+    const float emv = H[0];
+    float zv = 0.f;
+#pragma unroll
+    for (int j = 1; j < D; ++j) zv = fmaf(z[j], v[j], zv);
+    hv[0] = (-1.0f / 9.0f - 0.5f * emv * H[1]) * v[0] + emv * zv;
+#pragma unroll
+    for (int j = 1; j < D; ++j) hv[j] = emv * (z[j] * v[0] - v[j]);
   }
 };
 

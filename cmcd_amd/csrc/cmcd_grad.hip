@@ -21,6 +21,19 @@
 // quantities (bias-table, beta, eps gradients) go to small global tables by float atomics; the
 // particle-independent tails (time coder / embedding / schedules) are small kernels at the end.
 //
+// BPTT = true is the reparameterised gradient of `MCD_CAIS_sn` (jax.grad(compute_bound, 1), /root/reference/src/
+// main.py:174-176 over mcd_cais.py:46-89, no stop_gradient): the forward kernel stores z_0..z_K, this kernel
+// walks the evaluations in REVERSE order carrying lambda_e = d L / d z_e (L = sum_n omega loss_n):
+//   g_i      = d L / d bk_i = -omega (z_i - bk_i) / (2 eps_i)
+//   a_s(e)   = -eps_e lambda_{e+1} [e<K] + eps_{e-1} g_{e-1} [e>0]                 cotangent of s(z_e, e)
+//   a_gp(e)  = eps_e beta_e lambda_{e+1} [e<K] + eps_{e-1} beta_{e-1} g_{e-1} [e>0]  (a_gq: 1 - beta)
+//   lambda_e = lambda_{e+1} - g_e [e<K] + g_{e-1} [e>0] + J_s(z_e)^T a_s + H_p(z_e) (clipmask a_gp) + H_q a_gq
+//              - omega grad log p(z_K) [e=K] + omega grad log q(z_0) [e=0]
+//   d/d beta_i = eps_i [(gp_i - gq_i).lambda_{i+1} + (gp_{i+1} - gq_{i+1}).g_i]
+//   d/d eps_i  = (-uf_i - s_i + n_i / sigma_i).lambda_{i+1} + (-ub_i + s_{i+1}).g_i - omega |z_i - bk_i|^2 / (4 eps_i^2)
+// (the two log-normalisers cancel and log N(z_{i+1}; fk_i, sigma_i) = -|n_i|^2/2 - ... carries no gradient).
+// The parameter contractions, slabs and tails are shared with the local gradient.
+//
 // Widths <= 64 keep W2 / W2^T fragments in LDS with 4 tiles per workgroup; the 132-wide net (T = 9) runs 3
 // tiles per workgroup (3 accumulator row tiles per wave) and streams both fragment copies from L2.
 #include <hip/hip_runtime.h>
@@ -37,7 +50,9 @@ struct GradArgs {
   const int32_t* seeds;
   const float* params;
   const float* ws;           // forward workspace (tables + packed weights of cmcd_bound_forward's prep)
-  const float* omega;        // [n]
+  const float* omega;        // [n], or nullptr: omega_scalar for every particle
+  const float* traj;         // BPTT: [K+1][n][D] trajectory stored by the forward kernel
+  float omega_scalar;
   float* gtab;               // gradient tables (zeroed): S[(K+1)][HP], S2[(K+1)][HP], gbeta[K], geps[K], gvd[2D], gfac[1]
   float* slabs;              // per-workgroup slabs
   cmcd_layout lay;
@@ -52,7 +67,7 @@ struct GradArgs {
 __device__ __forceinline__ int sw(int f, int p) { return f * 16 + (p ^ (f & 15)); }
 
 // NW waves per workgroup (one tile each); WGLOBAL: W2 / W2^T fragments streamed from L2 instead of LDS
-template <int TARGET, int ARCH, int D, int T, int NW, bool WGLOBAL>
+template <int TARGET, int ARCH, int D, int T, int NW, bool WGLOBAL, bool BPTT>
 __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
   constexpr int HP = 16 * T;
   constexpr int Hh = (D + 1) / 2;
@@ -148,13 +163,16 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
     const int64_t p = tile * 16 + c;
     const bool valid = p < a.n;
     const int32_t seed = a.seeds[valid ? p : a.n - 1];
-    const float om = valid ? a.omega[p] : 0.f;
+    const float om = valid ? (a.omega ? a.omega[p] : a.omega_scalar) : 0.f;
+    const int64_t pc = valid ? p : a.n - 1;
 
     // ---- key chain + z0 (identical to traj_kernel)
     const int gb = g & 1;
     uint32_t x0, x1, k0 = 0u, k1 = (uint32_t)seed;
     float z[D], zp[D];
-    {
+#pragma unroll
+    for (int j = 0; j < D; ++j) { z[j] = 0.f; zp[j] = 0.f; }
+    if (!BPTT) {
       x0 = gb; x1 = 2 + gb;
       threefry2x32(k0, k1, x0, x1);
       uint32_t a0, a1, b0, b1;
@@ -196,8 +214,19 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
 #pragma unroll
     for (int j = 0; j < D; ++j) { fkd[j] = 0.f; puf[j] = 0.f; psn[j] = 0.f; pgd[j] = 0.f; }
     float pend_beta = 0.f, pend_eps = 0.f;   // forward-side contributions of step i, completed at e = i+1
+    float lamn[D], gE[D], znext[D];          // BPTT: lambda_{e+1}, g_e, z_{e+1}
+#pragma unroll
+    for (int j = 0; j < D; ++j) { lamn[j] = 0.f; gE[j] = 0.f; znext[j] = 0.f; }
 
-    for (int e = 0; e <= K; ++e) {
+    for (int it = 0; it <= K; ++it) {
+      const int e = BPTT ? K - it : it;
+      if (BPTT) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          z[j] = a.traj[((int64_t)e * a.n + pc) * D + j];
+          zp[j] = e > 0 ? a.traj[((int64_t)(e - 1) * a.n + pc) * D + j] : 0.f;
+        }
+      }
       // ---------------------------------------------------------------- forward (keeps pre-activations)
       const float* brow = bias1 + (int64_t)e * HP;
       f32x4 a1[T], u1[T], a2[T];
@@ -267,11 +296,15 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
       }
       float gp[D], gq[D], logp;
       bool gq_live[D];
-      Target<TARGET, D>::eval(z, g, lds_tgt, logp, gp);
+      constexpr int HN = Target<TARGET, D>::HN;
+      float hs[HN], gpraw[D];
+      if (BPTT) Target<TARGET, D>::eval_hess(z, g, lds_tgt, logp, gp, hs);
+      else Target<TARGET, D>::eval(z, g, lds_tgt, logp, gp);
 #pragma unroll
       for (int j = 0; j < D; ++j) {
         gq[j] = -(z[j] - qmean[j]) * qiv[j];
         gq_live[j] = true;
+        gpraw[j] = gp[j];
         if (clip_p) gp[j] = fminf(fmaxf(gp[j], -clipv), clipv);
         if (clip_q) {
           gq_live[j] = fabsf(gq[j]) < clipv;
@@ -280,10 +313,75 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
       }
 
       // ---------------------------------------------------------------- cotangents and scalar gradients
-      float cot[D];
+      float cot[D];   // local gradient: cotangent of s / omega;  BPTT: a_s (omega included)
+      float lam[D];
 #pragma unroll
-      for (int j = 0; j < D; ++j) cot[j] = 0.f;
-      if (e > 0) {  // backward kernel of step i = e-1 at z' = z (mcd_cais_var.py:81-89)
+      for (int j = 0; j < D; ++j) { cot[j] = 0.f; lam[j] = 0.f; }
+      if (BPTT) {
+        float a_gp[D], a_gq[D], gprev[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) { a_gp[j] = 0.f; a_gq[j] = 0.f; gprev[j] = 0.f; }
+        float npb = 0.f, npe = 0.f;
+        if (e > 0) {  // backward kernel of step i = e-1, whose mean is built from this evaluation
+          const float pb = a.ws[a.w.beta + e - 1], pe = a.ws[a.w.eps + e - 1];
+          const float inv2e = 0.5f / pe;
+          float sb = 0.f, se = 0.f, r2 = 0.f;
+#pragma unroll
+          for (int j = 0; j < D; ++j) {
+            const float ub = -1.0f * (pb * gp[j] + (1.0f - pb) * gq[j]);
+            const float bk = z[j] - pe * ub + pe * sn[j];
+            const float r = zp[j] - bk;
+            gprev[j] = -om * r * inv2e;
+            cot[j] += pe * gprev[j];
+            a_gp[j] += pe * pb * gprev[j];
+            a_gq[j] += pe * (1.0f - pb) * gprev[j];
+            lam[j] += gprev[j];
+            sb += (gp[j] - gq[j]) * gprev[j];
+            se += (sn[j] - ub) * gprev[j];
+            r2 += r * r;
+          }
+          npb = pe * sb;
+          npe = se - om * r2 * inv2e * inv2e;
+        }
+        if (e < K) {  // forward kernel of step e, which produced z_{e+1}
+          const float be = a.ws[a.w.beta + e], ee = a.ws[a.w.eps + e];
+          const float inv2e = 0.5f / ee;
+          float sb = 0.f, se = 0.f;
+#pragma unroll
+          for (int j = 0; j < D; ++j) {
+            const float uf = -1.0f * (be * gp[j] + (1.0f - be) * gq[j]);
+            const float fk = z[j] - ee * uf - ee * sn[j];
+            const float nsig = (znext[j] - fk) * inv2e;        // n_e / sigma_e
+            cot[j] -= ee * lamn[j];
+            a_gp[j] += ee * be * lamn[j];
+            a_gq[j] += ee * (1.0f - be) * lamn[j];
+            lam[j] += lamn[j] - gE[j];
+            sb += (gp[j] - gq[j]) * lamn[j];
+            se += (nsig - uf - sn[j]) * lamn[j];
+          }
+          const float tb = row_sum16(pend_beta + ee * sb), te = row_sum16(pend_eps + se);
+          if (lane == 0) {
+            atomicAdd(a.gtab + a.o_gbeta + e, tb);
+            atomicAdd(a.gtab + a.o_geps + e, te);
+          }
+        }
+        pend_beta = npb; pend_eps = npe;
+        float v[D], hv[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          if (e == K) lam[j] -= om * gpraw[j];                 // - log p(z_K)
+          if (e == 0) lam[j] += om * gq[j];                    // + log q(z_0)
+          gmu[j] += a_gq[j] * qiv[j];
+          glam[j] += a_gq[j] * (-2.0f * gq[j]);
+          lam[j] -= a_gq[j] * qiv[j];                          // H_q = -diag(1 / std^2)
+          v[j] = (!clip_p || fabsf(gpraw[j]) < clipv) ? a_gp[j] : 0.f;
+          gE[j] = gprev[j];
+        }
+        Target<TARGET, D>::hvp(hs, z, v, hv);
+#pragma unroll
+        for (int j = 0; j < D; ++j) lam[j] += hv[j];
+      }
+      if (!BPTT && e > 0) {  // backward kernel of step i = e-1 at z' = z (mcd_cais_var.py:81-89)
         float sb = 0.f, se = 0.f, dn2 = 0.f;
 #pragma unroll
         for (int j = 0; j < D; ++j) {
@@ -309,7 +407,7 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
       }
       float beta = 0.f, eps = 0.f, sig = 0.f;
       float zn[D];
-      if (e < K) {
+      if (!BPTT && e < K) {
         beta = a.ws[a.w.beta + e]; eps = a.ws[a.w.eps + e]; sig = a.ws[a.w.sig + e];
         x0 = gb; x1 = 2 + gb;
         threefry2x32(k0, k1, x0, x1);
@@ -362,7 +460,7 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
       float dob[D];  // d (sum omega w) / d o_j  (pre-clip / pre-factor output)
 #pragma unroll
       for (int j = 0; j < D; ++j) {
-        const float cj = om * cot[j];
+        const float cj = BPTT ? cot[j] : om * cot[j];
         if (GEF) {
           dob[j] = cj * factor;
           if (g == 0) gfac += cj * opre[j];
@@ -397,15 +495,44 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
           for (int r = 0; r < 4; ++r) d1[tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r], d2[tn][r], d1[tk], 0, 0, 0);
         }
       }
+      float jpart[D];  // BPTT: J_s(z_e)^T a_s, this lane's share of the hidden units
 #pragma unroll
-      for (int t = 0; t < T; ++t)
+      for (int j = 0; j < D; ++j) jpart[j] = 0.f;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int o = wb[r] + 256 * t;
           if (GEF) du1T[o] = d1[t][r];
+          if (BPTT && GEF && 16 * t < D) {  // residual path of the first block: d x_j += d u1_j
+#pragma unroll
+            for (int j = 0; j < D; ++j)
+              if (j >= 16 * t && j < 16 * t + 16) jpart[j] += (16 * t + 4 * g + r == j) ? d1[t][r] : 0.f;
+          }
           d1[t][r] *= GEF ? sigmoid_fast(a1[t][r]) : gelu_grad_fast(a1[t][r]);
           da1T[o] = d1[t][r];
         }
+        if (BPTT) {
+#pragma unroll
+          for (int j = 0; j < D; ++j) {
+            const f32x4 wv4 = *reinterpret_cast<const f32x4*>(lds_w1z + j * HP + 16 * t + 4 * g);
+            jpart[j] += d1[t][0] * wv4[0] + d1[t][1] * wv4[1] + d1[t][2] * wv4[2] + d1[t][3] * wv4[3];
+          }
+        }
+      }
+      if (BPTT) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          lam[j] += group_sum(jpart[j]);
+          if (e == 0) {  // z_0 = mean + std e0 and the explicit parameters of log q(z_0)
+            const float dz = z[j] - qmean[j];
+            gmu[j] += lam[j] - om * gq[j];
+            glam[j] += lam[j] * dz + om * (dz * dz * qiv[j] - 1.0f);
+          }
+          lamn[j] = lam[j];
+          znext[j] = z[j];
+        }
+      }
       // ---------------------------------------------------------------- stage the two small tiles
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -482,7 +609,7 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
       }
       __syncthreads();
       // ---------------------------------------------------------------- advance
-      if (e < K) {
+      if (!BPTT && e < K) {
 #pragma unroll
         for (int j = 0; j < D; ++j) { zp[j] = z[j]; z[j] = zn[j]; }
         pbeta = beta; peps = eps;
@@ -739,22 +866,25 @@ typedef void (*grad_fn)(GradArgs);
 
 static int grad_nw(int T) { return T > 4 ? 3 : 4; }
 
-static grad_fn pick_grad(const cmcd_desc& d, int T) {
+template <bool BPTT>
+static grad_fn pick_grad_t(const cmcd_desc& d, int T) {
   if (d.arch == CMCD_ARCH_DDS && T == 4) {
-    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_DDS, 2, 4, 4, false>;
-    if (d.target == CMCD_TARGET_GMM && d.dim == 2) return grad_kernel<CMCD_TARGET_GMM, CMCD_ARCH_DDS, 2, 4, 4, false>;
+    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_DDS, 2, 4, 4, false, BPTT>;
+    if (d.target == CMCD_TARGET_GMM && d.dim == 2) return grad_kernel<CMCD_TARGET_GMM, CMCD_ARCH_DDS, 2, 4, 4, false, BPTT>;
     return nullptr;
   }
   if (d.arch == CMCD_ARCH_GEFFNER) {
-    if (d.target == CMCD_TARGET_GMM && d.dim == 2 && T == 2) return grad_kernel<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER, 2, 2, 4, false>;
-    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 2) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 2, 4, false>;
-    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 9) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 9, 3, true>;
-    if (d.target == CMCD_TARGET_FUNNEL && d.dim == 10 && T == 4) return grad_kernel<CMCD_TARGET_FUNNEL, CMCD_ARCH_GEFFNER, 10, 4, 4, false>;
+    if (d.target == CMCD_TARGET_GMM && d.dim == 2 && T == 2) return grad_kernel<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER, 2, 2, 4, false, BPTT>;
+    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 2) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 2, 4, false, BPTT>;
+    if (!BPTT && d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 9) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 9, 3, true, false>;
+    if (d.target == CMCD_TARGET_FUNNEL && d.dim == 10 && T == 4) return grad_kernel<CMCD_TARGET_FUNNEL, CMCD_ARCH_GEFFNER, 10, 4, 4, false, BPTT>;
   }
   return nullptr;
 }
+static grad_fn pick_grad(const cmcd_desc& d, int T, bool bptt) { return bptt ? pick_grad_t<true>(d, T) : pick_grad_t<false>(d, T); }
 
-bool grad_available(const cmcd_desc& d, int T) { return pick_grad(d, T) != nullptr; }
+bool grad_available(const cmcd_desc& d, int T) { return pick_grad(d, T, false) != nullptr; }
+bool bptt_available(const cmcd_desc& d, int T) { return pick_grad(d, T, true) != nullptr; }
 
 static void grad_offsets(const cmcd_desc& d, int HP, int64_t& o_S, int64_t& o_S2, int64_t& o_gbeta, int64_t& o_geps,
                          int64_t& o_gvd, int64_t& o_gfac, int64_t& total) {
@@ -784,10 +914,10 @@ int64_t grad_workspace_floats(const cmcd_desc& d, int HP, int64_t n) {
 // ws_fwd: the forward workspace as left by cmcd_bound_forward's prep on the SAME desc/params;
 // gws: gradient workspace (grad_workspace_floats).  grad: [n_params], fully overwritten.
 int grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, const int32_t* seeds, int64_t n,
-                const float* params, int64_t n_params, const float* ws_fwd, const float* omega, float* gws,
-                float* grad, void* stream_) {
+                const float* params, int64_t n_params, const float* ws_fwd, const float* omega, float omega_scalar,
+                const float* traj, float* gws, float* grad, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  grad_fn fn = pick_grad(d, w.T);
+  grad_fn fn = pick_grad(d, w.T, traj != nullptr);
   if (!fn) return CMCD_ERR_UNSUPPORTED;
   const int D = d.dim, HP = w.HP, K = d.nbridges;
   GradArgs ga{};
@@ -795,7 +925,7 @@ int grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, c
   grad_offsets(d, HP, ga.o_S, ga.o_S2, ga.o_gbeta, ga.o_geps, ga.o_gvd, ga.o_gfac, tot);
   const int nw = grad_nw(w.T);
   const int nslabs = grad_nslabs(n, nw);
-  ga.seeds = seeds; ga.params = params; ga.ws = ws_fwd; ga.omega = omega; ga.gtab = gws; ga.slabs = gws + tot;
+  ga.seeds = seeds; ga.params = params; ga.ws = ws_fwd; ga.omega = omega; ga.omega_scalar = omega_scalar; ga.traj = traj; ga.gtab = gws; ga.slabs = gws + tot;
   ga.lay = lay; ga.w = w; ga.n = n; ga.K = K; ga.var_mode = d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0;
   ga.grad_clipping = d.grad_clipping; ga.nquads = (int)((n + 16 * nw - 1) / (16 * nw));
   ga.slab_stride = (int64_t)HP * HP + HP * 16 + 4 * (2 * 16 * HP + 256 + 32);

@@ -512,6 +512,10 @@ __global__ __launch_bounds__(512, (T > 4 || D > 4) ? 2 : 4) void traj_kernel(Tra
     }
 #pragma unroll
     for (int j = 0; j < D; ++j) z[j] = qstd[j] * nz[j] + qmean[j];
+    if (a.traj && valid && g == 0) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) a.traj[p * D + j] = z[j];
+    }
     // C = first(split(B)); gen = second(split(C))
     x0 = gb; x1 = 2 + gb;
     threefry2x32(b0, b1, x0, x1);
@@ -628,6 +632,10 @@ __global__ __launch_bounds__(512, (T > 4 || D > 4) ? 2 : 4) void traj_kernel(Tra
       fk_lp += -(df * df) * inv2s2 - logsig - kHalfLog2Pi;
       zp[j] = z[j];
       z[j] = zn;
+    }
+    if (a.traj && valid && g == 0) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) a.traj[((int64_t)(i + 1) * a.n + p) * D + j] = z[j];
     }
     pbeta = beta; peps = eps; pinv2s2 = inv2s2; plogsig = logsig;
   }
@@ -824,10 +832,10 @@ int64_t cmcd_workspace_bytes(const cmcd_desc* desc, int64_t n) {
     if (e_ != hipSuccess) return fail(CMCD_ERR_HIP, "HIP error: %s (code %lld)", hipGetErrorString(e_), (long long)e_); \
   } while (0)
 
-int cmcd_bound_forward(const cmcd_desc* desc, const cmcd_layout* lay, const int32_t* seeds, int64_t n,
-                       const float* params, int64_t n_params, const float* target_consts, int64_t n_target,
-                       void* workspace, int64_t workspace_bytes, float* out_loss, float* out_z,
-                       double* out_stats, void* stream_) {
+static int forward_impl(const cmcd_desc* desc, const cmcd_layout* lay, const int32_t* seeds, int64_t n,
+                        const float* params, int64_t n_params, const float* target_consts, int64_t n_target,
+                        void* workspace, int64_t workspace_bytes, float* out_loss, float* out_z,
+                        double* out_stats, float* traj, void* stream_) {
   int rc = check_desc(desc);
   if (rc != CMCD_OK) return rc;
   if (!lay || !seeds || !params || !workspace || !out_loss || !out_z || !out_stats)
@@ -890,7 +898,7 @@ int cmcd_bound_forward(const cmcd_desc* desc, const cmcd_layout* lay, const int3
 
   TrajArgs ta{seeds, params, ws, reinterpret_cast<double*>(ws + w.partials), out_loss, out_z, *lay, w, n,
               (int32_t)K, d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0,
-              (d.mode == CMCD_MODE_ULA || d.mode == CMCD_MODE_ULA_SN) ? 0 : d.grad_clipping,
+              (d.mode == CMCD_MODE_ULA || d.mode == CMCD_MODE_ULA_SN) ? 0 : d.grad_clipping, traj,
               d.mode == CMCD_MODE_ULA ? 1 : (d.mode == CMCD_MODE_ULA_SN ? 2 : 0)};
   // Kernel variant (desc.reserved: 0 auto, 1 wave-per-tile, 2 CU-cooperative).  Auto: the
   // cooperative kernel while the batch cannot fill the chip with one wave per tile.
@@ -954,6 +962,55 @@ int cmcd_bound_forward(const cmcd_desc* desc, const cmcd_layout* lay, const int3
   return CMCD_OK;
 }
 
+int cmcd_bound_forward(const cmcd_desc* desc, const cmcd_layout* lay, const int32_t* seeds, int64_t n,
+                       const float* params, int64_t n_params, const float* target_consts, int64_t n_target,
+                       void* workspace, int64_t workspace_bytes, float* out_loss, float* out_z,
+                       double* out_stats, void* stream_) {
+  return forward_impl(desc, lay, seeds, n, params, n_params, target_consts, n_target, workspace, workspace_bytes,
+                      out_loss, out_z, out_stats, nullptr, stream_);
+}
+
+int64_t cmcd_bound_grad_workspace_bytes(const cmcd_desc* desc, int64_t n) {
+  if (check_desc(desc) != CMCD_OK || n < 1 || desc->target == CMCD_TARGET_LGCP) return 0;
+  WsLayout w;
+  const int64_t nt = desc->target == CMCD_TARGET_MANY_GMM ? 1 + 2 * 64 : 0;
+  if (!make_ws(*desc, n, nt, w)) return 0;
+  if (desc->mode != CMCD_MODE_CAIS_SN || !bptt_available(*desc, w.T)) {
+    fail(CMCD_ERR_UNSUPPORTED, "no reparameterised-gradient kernel instance for this (mode, target, dim, arch, width)%s");
+    return 0;
+  }
+  return (align4(w.total_floats) + align4(grad_workspace_floats(*desc, w.HP, n)) +
+          (int64_t)(desc->nbridges + 1) * n * desc->dim) * 4;
+}
+
+int cmcd_bound_grad(const cmcd_desc* desc, const cmcd_layout* lay, const int32_t* seeds, int64_t n,
+                    const float* params, int64_t n_params, const float* target_consts, int64_t n_target,
+                    float omega, void* workspace, int64_t workspace_bytes, float* out_loss, float* out_z,
+                    double* out_stats, float* grad, void* stream_) {
+  int rc = check_desc(desc);
+  if (rc != CMCD_OK) return rc;
+  if (!grad) return fail(CMCD_ERR_BAD_ARG, "null pointer argument%s");
+  if (desc->mode != CMCD_MODE_CAIS_SN)
+    return fail(CMCD_ERR_UNSUPPORTED, "the reparameterised gradient exists for MCD_CAIS_sn only (MCD_CAIS_var_sn: cmcd_bound_var_grad)%s");
+  if (desc->target == CMCD_TARGET_LGCP) return fail(CMCD_ERR_UNSUPPORTED, "no lgcp gradient%s");
+  const cmcd_desc& d = *desc;
+  WsLayout w;
+  if (!make_ws(d, n, n_target, w)) return fail(CMCD_ERR_BAD_ARG, "bad descriptor%s");
+  if (!bptt_available(d, w.T)) return fail(CMCD_ERR_UNSUPPORTED, "no reparameterised-gradient kernel instance for this (target, dim, arch, width)%s");
+  const int64_t fwd = align4(w.total_floats), gfl = align4(grad_workspace_floats(d, w.HP, n));
+  const int64_t need = (fwd + gfl + (int64_t)(d.nbridges + 1) * n * d.dim) * 4;
+  if (workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15))
+    return fail(CMCD_ERR_WORKSPACE, "workspace too small or not 16-byte aligned (need %s%lld bytes)", "", need);
+  float* ws = static_cast<float*>(workspace);
+  float* traj = ws + fwd + gfl;
+  rc = forward_impl(desc, lay, seeds, n, params, n_params, target_consts, n_target, workspace, fwd * 4, out_loss,
+                    out_z, out_stats, traj, stream_);
+  if (rc != CMCD_OK) return rc;
+  rc = grad_launch(d, *lay, w, seeds, n, params, n_params, ws, nullptr, omega, traj, ws + fwd, grad, stream_);
+  if (rc != CMCD_OK) return fail(rc, "gradient launch failed%s");
+  return CMCD_OK;
+}
+
 int64_t cmcd_grad_workspace_bytes(const cmcd_desc* desc, int64_t n) {
   if (check_desc(desc) != CMCD_OK || n < 1 || desc->target == CMCD_TARGET_LGCP) return 0;
   WsLayout w;
@@ -1000,7 +1057,7 @@ int cmcd_bound_var_grad(const cmcd_desc* desc, const cmcd_layout* lay, const int
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   float* ws = static_cast<float*>(workspace);
   launch_prep(d, *lay, w, params, target_consts, n_mix, ws, stream);
-  rc = grad_launch(d, *lay, w, seeds, n, params, n_params, ws, omega, ws + align4(w.total_floats), grad, stream_);
+  rc = grad_launch(d, *lay, w, seeds, n, params, n_params, ws, omega, 0.f, nullptr, ws + align4(w.total_floats), grad, stream_);
   if (rc != CMCD_OK) return fail(rc, "gradient launch failed%s");
   return CMCD_OK;
 }

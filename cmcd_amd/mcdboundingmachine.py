@@ -328,3 +328,66 @@ def compute_log_var_grad(seeds, params_flat, unflatten, params_fixed, log_prob, 
     n_train = min((off for path, (off, _) in unflatten.layout.items() if path[0] == 1), default=params_flat.numel())
     grad[n_train:].zero_()
     return grad, (losses, z)
+
+
+def compute_bound_grad(seeds, params_flat, unflatten, params_fixed, log_prob, eps_schedule=None,
+                       grad_clipping=False, n_total=None, return_stats=False):
+    """Value-and-gradient of `compute_bound` for `MCD_CAIS_sn`: the reference's
+    `jax.jit(jax.grad(compute_bound, 1, has_aux=True))` (/root/reference/src/main.py:174-176), called as
+    `grad, (loss, z) = grad_and_loss(seeds, params_flat, unflatten, params_fixed, log_prob_model)`
+    (/root/reference/src/opt.py:97-99).  No stop_gradient in this mode (/root/reference/src/mcd_cais.py:46-89):
+    the gradient is the full reparameterised one, back through every z_i.  One library call runs the forward
+    launch sequence (keeping z_0..z_K in the workspace) and the reverse sweep.
+    Returns (grad_flat, (losses, z)) [+ stats with return_stats]; multi-GPU: pass the global particle count
+    as `n_total` and all-reduce the returned gradient."""
+    dim, nbridges, mode, spec = params_fixed
+    if mode != "MCD_CAIS_sn":
+        raise NotImplementedError("Mode not implemented.")
+    if not isinstance(spec, ScoreNet):
+        raise ValueError("params_fixed[3] must be the ScoreNet returned by initialize()")
+    if not hasattr(log_prob, "target_id"):
+        raise TypeError("log_prob must be a cmcd_amd.model_handler.Target (see load_model)")
+    if not params_flat.is_cuda:
+        raise RuntimeError("the CMCD hot path runs on a ROCm device only: params_flat is not a device tensor")
+    if params_flat.dtype != torch.float32 or not params_flat.is_contiguous():
+        raise ValueError("params_flat must be contiguous float32")
+    L = _lib.lib()
+    device = params_flat.device
+    seeds = torch.as_tensor(seeds)
+    if seeds.device != device or seeds.dtype != torch.int32 or not seeds.is_contiguous():
+        seeds = seeds.to(device=device, dtype=torch.int32).contiguous()
+    n = seeds.numel()
+    if n < 1:
+        raise ValueError("seeds is empty")
+    if eps_schedule not in _lib.EPS_SCHEDULE:
+        eps_schedule = None
+    desc = _lib.Desc(dim=dim, nbridges=nbridges, mode=_lib.MODE[mode], arch=_lib.ARCH[spec.arch],
+                     emb_dim=spec.emb_dim, target=log_prob.target_id,
+                     eps_schedule=_lib.EPS_SCHEDULE[eps_schedule], grad_clipping=int(bool(grad_clipping)),
+                     ngrid=unflatten.shape("mgridref_y")[0] - 1, reserved=KERNEL_VARIANT)
+    lay = _layout(unflatten, spec)
+    nbytes = L.cmcd_bound_grad_workspace_bytes(C.byref(desc), n)
+    if nbytes <= 0:
+        raise NotImplementedError(_lib.last_error() or "no gradient kernel for this configuration")
+    key = str(device) + ":bptt"
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    consts = log_prob.consts_on(device)
+    losses = torch.empty(n, dtype=torch.float32, device=device)
+    z = torch.empty(n, dim, dtype=torch.float32, device=device)
+    stats = torch.empty(_lib.NSTATS, dtype=torch.float64, device=device)
+    grad = torch.empty_like(params_flat)
+    with torch.cuda.device(device):
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(L.cmcd_bound_grad(
+            C.byref(desc), C.byref(lay), seeds.data_ptr(), n, params_flat.data_ptr(), params_flat.numel(),
+            consts.data_ptr() if consts is not None else None, consts.numel() if consts is not None else 0,
+            1.0 / float(n if n_total is None else n_total), ws.data_ptr(), ws.numel(),
+            losses.data_ptr(), z.data_ptr(), stats.data_ptr(), grad.data_ptr(), stream))
+    n_train = min((off for path, (off, _) in unflatten.layout.items() if path[0] == 1), default=params_flat.numel())
+    grad[n_train:].zero_()
+    if return_stats:
+        return grad, (losses, z), stats
+    return grad, (losses, z)

@@ -150,6 +150,21 @@ int cmcd_bound_var_grad(const cmcd_desc* desc, const cmcd_layout* layout, const 
                         const float* params, int64_t n_params, const float* target_consts, int64_t n_target,
                         const float* omega, void* workspace, int64_t workspace_bytes, float* grad, void* stream);
 
+/* ---- Reparameterised gradient of the mean bound: what jax.value_and_grad(compute_bound, 1, has_aux=True)
+ * returns for MCD_CAIS_sn (/root/reference/src/main.py:174-176 over mcdboundingmachine.py:183-205 and
+ * mcd_cais.py:46-89 — no stop_gradient, so the gradient flows back through every z_i: the net's input
+ * Jacobian, the Hessians of log p and log q, and the step-size / beta schedules).
+ * One call = forward (losses, z_K, statistics as cmcd_bound_forward; the trajectory z_0..z_K is kept in
+ * the workspace) + reverse sweep.  grad[n_params] (overwritten) = omega * sum_n d loss_n / d params_flat;
+ * omega = d value / d loss_n = 1 / N_total (across ranks: all-reduce(sum) of grad).
+ * MCD_CAIS_sn with targets gmm / funnel / many_gmm and the BASELINE nets (dds 64; geffner 22 / 58);
+ * CMCD_ERR_UNSUPPORTED otherwise (lgcp, width 132). */
+int64_t cmcd_bound_grad_workspace_bytes(const cmcd_desc* desc, int64_t n);
+int cmcd_bound_grad(const cmcd_desc* desc, const cmcd_layout* layout, const int32_t* seeds, int64_t n,
+                    const float* params, int64_t n_params, const float* target_consts, int64_t n_target,
+                    float omega, void* workspace, int64_t workspace_bytes,
+                    float* out_loss, float* out_z, double* out_stats, float* grad, void* stream);
+
 /* Device-side merge of `count` statistics vectors rows[count][5] (e.g. the result of an RCCL
  * all-gather of every rank's out_stats, in rank order) into out5[5], fixed order, one small kernel
  * on `stream`.  [device] pointers. */

@@ -1,4 +1,5 @@
-"""VarGrad gradient (compute_log_var_grad) of the HIP path vs torch-autograd on the float64 restatement."""
+"""Gradients of the HIP path — VarGrad (compute_log_var_grad) and the reparameterised MCD_CAIS_sn gradient
+(compute_bound_grad) — vs torch-autograd on the float64 restatement."""
 import numpy as np
 import pytest
 import torch
@@ -77,6 +78,93 @@ def test_vargrad_matches_autograd(hip_lib, name, n, over):
     assert cos > 1 - 1e-5
 
 
+def _compare(name, over, un, g, g_ref, tol=2e-3):
+    worst = {}
+    for path, (off, shape) in un.layout.items():
+        numel = max(1, int(np.prod(shape)))
+        a, r = g[off:off + numel], g_ref[off:off + numel]
+        scale = max(float(r.abs().max()), 1e-12)
+        worst["/".join(map(str, path))] = (float((a - r).abs().max()) / scale, scale)
+        if float(r.abs().max()) == 0.0:
+            assert float(a.abs().max()) == 0.0, f"{path}: expected exactly zero gradient"
+    bad = {k: v for k, v in worst.items() if v[0] > tol and v[1] > 1e-9}
+    print(name, over, {k: "%.1e" % v[0] for k, v in worst.items()})
+    assert not bad, f"gradient mismatch (max abs err / max |ref|, max |ref|): {bad}"
+    cos = float((g * g_ref).sum() / (g.norm() * g_ref.norm()))
+    assert cos > 1 - 1e-5
+
+
+# the reparameterised gradient: no stop_gradient, back-propagation through all K steps
+BPTT_CASES = [
+    ("many_gmm_n2000_k256_dds", 96, dict(nbridges=8, init_sigma=15.0)),                      # clipping on, cos_sq
+    ("many_gmm_n2000_k256_dds", 50, dict(nbridges=5, init_sigma=15.0, eps_schedule="linear", init_eps=0.3,
+                                         grad_clipping=False)),
+    ("many_gmm_n2000_k256_dds", 40, dict(nbridges=24, init_sigma=15.0, init_eps=0.2)),        # longer chain
+    ("gmm_n300_k8", 128, dict()),                                                             # geffner 22
+    ("gmm_n300_k8", 64, dict(nn_arch="dds", grad_clipping=True)),
+    ("funnel_n300_k64", 70, dict(nbridges=6)),                                                # d = 10, geffner 58
+    ("many_gmm_n2000_k256_dds", 64, dict(nbridges=6, nn_arch="geffner", emb_dim=20, init_sigma=15.0, init_eps=0.3)),
+]
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("name,n,over", BPTT_CASES)
+def test_reparameterised_gradient_matches_autograd(hip_lib, monkeypatch, name, n, over, variant):
+    """compute_bound_grad == jax.grad(compute_bound, 1): values from autograd through the float64 restatement
+    with no detach (oracle/cmcd_oracle_torch.py).  Both forward kernel variants store the trajectory."""
+    monkeypatch.setattr(mcdbm, "KERNEL_VARIANT", variant)
+    b = synthetic.build(name, device="cuda", **over)
+    assert b["params_fixed"][2] == "MCD_CAIS_sn"
+    seeds = synthetic.parity_seeds(n)
+    try:
+        grad, (losses, z) = mcdbm.compute_bound_grad(torch.from_numpy(seeds).cuda(), b["params_flat"], b["unflatten"],
+                                                     b["params_fixed"], b["target"], eps_schedule=b["eps_schedule"],
+                                                     grad_clipping=b["grad_clipping"])
+    except NotImplementedError as e:
+        if variant == 2 and "cooperative" in str(e):
+            pytest.skip("no cooperative instance for this net")
+        raise
+    torch.cuda.synchronize()
+    val, l_ref, g_ref = oracle_grad_flat(b, seeds)
+    assert np.isfinite(l_ref).all(), "pick a case without +inf particles for the gradient check"
+    np.testing.assert_allclose(losses.cpu().numpy(), l_ref, rtol=2e-3, atol=2e-3)
+    _compare(name, over, b["unflatten"], grad.double().cpu(), g_ref)
+
+
+def test_reparameterised_gradient_shards_add_up(hip_lib):
+    """Two particle shards with omega = 1 / N_total sum to the single-call gradient (the multi-GPU contract)."""
+    b = synthetic.build("many_gmm_n2000_k256_dds", device="cuda", nbridges=12, init_sigma=15.0)
+    seeds = torch.from_numpy(synthetic.parity_seeds(200)).cuda()
+    args = (b["params_flat"], b["unflatten"], b["params_fixed"], b["target"])
+    kw = dict(eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
+    g_all, _ = mcdbm.compute_bound_grad(seeds, *args, **kw)
+    g_a, _ = mcdbm.compute_bound_grad(seeds[:112], *args, n_total=200, **kw)
+    g_b, _ = mcdbm.compute_bound_grad(seeds[112:], *args, n_total=200, **kw)
+    g_sum = (g_a + g_b).double().cpu()
+    g_all = g_all.double().cpu()
+    assert float((g_sum - g_all).abs().max()) <= 1e-4 * float(g_all.abs().max())
+
+
+def test_training_with_the_reparameterised_gradient_raises_the_elbo(hip_lib):
+    """opt.run on MCD_CAIS_sn (the reference's default training mode): mean loss on fresh seeds drops."""
+    import types
+    from functools import partial
+    from cmcd_amd import opt
+    b = synthetic.build("many_gmm_n2000_k256_dds", device="cuda", nbridges=16, init_sigma=15.0, init_eps=0.3)
+    dim, K, mode, spec = b["params_fixed"]
+    flat, unflatten, fixed = mcdbm.initialize(
+        dim=dim, nbridges=K, vdparams={"mean": torch.zeros(dim), "logdiag": torch.full((dim,), float(np.log(15.0)))},
+        eps=0.3, trainable=("eps", "vd", "mgridref_y"), mode=mode, emb_dim=20, nn_arch="dds", device="cuda")
+    kw = dict(eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
+    fresh = torch.from_numpy(synthetic.throughput_seeds(4000, stream=5)).cuda()
+    v0 = float(mcdbm.compute_bound(fresh, flat, unflatten, fixed, b["target"], **kw)[0])
+    losses, flat2, _ = opt.run(types.SimpleNamespace(N=500), 5e-3, 300, flat, unflatten, fixed, b["target"],
+                               partial(mcdbm.compute_bound_grad, **kw), ("eps", "vd", "mgridref_y"), 0)
+    v1 = float(mcdbm.compute_bound(fresh, flat2, unflatten, fixed, b["target"], **kw)[0])
+    print("mean loss (-ELBO)", v0, "->", v1)
+    assert np.isfinite(v1) and v1 < v0 - 0.5
+
+
 def test_unsupported_configurations_fail_loudly(hip_lib):
     seeds = torch.arange(1, 33, dtype=torch.int32).cuda()
     b = synthetic.build("funnel_n300_k64", device="cuda", boundmode="MCD_CAIS_var_sn", nbridges=4, emb_dim=20)
@@ -85,6 +173,12 @@ def test_unsupported_configurations_fail_loudly(hip_lib):
     b = synthetic.build("gmm_n300_k8", device="cuda")                                 # MCD_CAIS_sn
     with pytest.raises(NotImplementedError, match="Mode not implemented."):
         mcdbm.compute_log_var_grad(seeds, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"])
+    b = synthetic.build("gmm_n300_k8", device="cuda", boundmode="MCD_CAIS_var_sn")    # wrong mode for the full gradient
+    with pytest.raises(NotImplementedError, match="Mode not implemented."):
+        mcdbm.compute_bound_grad(seeds, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"])
+    b = synthetic.build("many_gmm_var_n16000_k256", device="cuda", boundmode="MCD_CAIS_sn", nbridges=4)   # width 132
+    with pytest.raises(NotImplementedError):
+        mcdbm.compute_bound_grad(seeds, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"])
 
 
 def test_training_with_vargrad_reduces_the_loss(hip_lib):

@@ -25,6 +25,16 @@ for n in (2000, 16000, 65536):
     print("n=%6d  forward %.3f ms (%.3e steps/s)   value+grad %.3f ms (%.3e steps/s)  ratio %.2f" % (
         n, tf, n * K / tf * 1e3, tg, n * K / tg * 1e3, tg / tf))
 
+for n in (2000, 16000, 65536):
+    b = synthetic.build("many_gmm_n2000_k256_dds", device="cuda", init_sigma=15.0)
+    seeds = torch.from_numpy(synthetic.throughput_seeds(n)).cuda()
+    args = (seeds, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"])
+    kw = dict(eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
+    tf = timeit(lambda: mcdbm.compute_bound(*args, **kw))
+    tg = timeit(lambda: mcdbm.compute_bound_grad(*args, **kw))
+    print("MCD_CAIS_sn reparameterised n=%6d  forward %.3f ms   value+grad %.3f ms (%.3e steps/s)  ratio %.2f" % (
+        n, tf, tg, n * 256 / tg * 1e3, tg / tf))
+
 for n in (2000, 16000):
     b = synthetic.build("many_gmm_var_n16000_k256", device="cuda")
     seeds = torch.from_numpy(synthetic.throughput_seeds(n)).cuda()
