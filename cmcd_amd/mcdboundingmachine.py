@@ -391,3 +391,15 @@ def compute_bound_grad(seeds, params_flat, unflatten, params_fixed, log_prob, ep
     if return_stats:
         return grad, (losses, z), stats
     return grad, (losses, z)
+
+
+def make_grad_and_loss(boundmode, eps_schedule=None, grad_clipping=False):
+    """The pair the reference's driver builds per run (/root/reference/src/main.py:161-176):
+    `grad_and_loss = jit(grad(compute_bound_fn, 1, has_aux=True))`, `loss_fn = jit(compute_bound_fn)`, with
+    `compute_bound_var` when "var" is in the boundmode and `compute_bound` otherwise.
+    -> (grad_and_loss, loss_fn), both taking (seeds, params_flat, unflatten, params_fixed, log_prob_model)."""
+    from functools import partial
+    kw = dict(eps_schedule=eps_schedule, grad_clipping=grad_clipping)
+    if "var" in boundmode:
+        return partial(compute_log_var_grad, **kw), partial(compute_bound_var, **kw)
+    return partial(compute_bound_grad, **kw), partial(compute_bound, **kw)

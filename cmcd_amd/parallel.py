@@ -112,3 +112,28 @@ def sharded_var_grad(seeds_global, forward_fn, grad_fn, group=None):
     out = dict(grad=grad, losses=losses, z=z, lo=lo, hi=hi, stats=stats)
     out.update(finalize(stats, n))
     return out
+
+
+def sharded_bound_grad(seeds_global, value_and_grad_fn, group=None):
+    """Reparameterised `MCD_CAIS_sn` value-and-gradient with particles sharded over ranks.
+
+    `value_and_grad_fn(local_seeds, n_total) -> (grad_flat, (losses, z), stats[5])` — e.g.
+    `partial(mcdbm.compute_bound_grad, ..., return_stats=True)` with `n_total` forwarded — returns this rank's
+    sum over its particles of (1 / n_total) d loss_n / d params; the weights do not depend on the other
+    ranks (mean loss), so the forward statistics and the gradient travel together: one all-gather of the
+    5-double statistics and ONE all-reduce(sum) of the gradient vector.  Returns dict(grad, mean, ...)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        world, rank = 1, 0
+    else:
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = int(seeds_global.shape[0])
+    lo, hi = shard_range(n, world, rank)
+    if hi <= lo:
+        raise ValueError("fewer particles than ranks: every rank needs at least one particle for the gradient")
+    grad, (losses, z), stats = value_and_grad_fn(seeds_global[lo:hi], n)
+    if world > 1:
+        stats = merge_stats(all_gather_stats(stats, group))
+        dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=group)
+    out = dict(grad=grad, losses=losses, z=z, lo=lo, hi=hi, stats=stats)
+    out.update(finalize(stats, n))
+    return out

@@ -136,3 +136,40 @@ def test_sharded_vargrad_equals_single_process():
     for r in (0, 1):
         np.testing.assert_allclose(out[r][0], g["sn"]["W3"].reshape(-1), rtol=1e-9, atol=1e-12)
         assert abs(out[r][1] - val) < 1e-9
+
+
+def _bptt_worker(rank, world, port, n, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import cmcd_oracle_torch as ot
+    from oracle.cmcd_oracle import stats5
+    b = synthetic.build("gmm_n300_k8", device="cpu", nbridges=3)
+    dim, K, mode, spec = b["params_fixed"]
+    p = synthetic.oracle_params(b["unflatten"], b["params_flat"])
+
+    def value_and_grad(seeds, n_total):
+        pt = ot.to_torch(p)
+        l, z = ot.losses(seeds.numpy(), pt, dim, K, mode, spec.arch, "gmm", b["cfg"]["eps_schedule"], False)
+        (g,) = torch.autograd.grad(l.sum() / n_total, [pt["sn"]["W3"]])
+        return g.reshape(-1).clone(), (l.detach(), z.detach()), torch.from_numpy(stats5(l.detach().numpy()))
+
+    r = parallel.sharded_bound_grad(torch.from_numpy(synthetic.parity_seeds(n)), value_and_grad)
+    out[rank] = (r["grad"].numpy(), float(r["mean"]))
+    dist.destroy_process_group()
+
+
+def test_sharded_reparameterised_gradient_equals_single_process():
+    """MCD_CAIS_sn: local gradients weighted 1 / N_total + one all-reduce == jax.grad of the global mean."""
+    from oracle import cmcd_oracle_torch as ot
+    n = 21
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_bptt_worker, args=(2, _free_port(), n, out), nprocs=2, join=True)
+    b = synthetic.build("gmm_n300_k8", device="cpu", nbridges=3)
+    dim, K, mode, spec = b["params_fixed"]
+    p = synthetic.oracle_params(b["unflatten"], b["params_flat"])
+    val, _, _, g = ot.bound_and_grad(synthetic.parity_seeds(n), p, dim, K, mode, spec.arch, "gmm",
+                                     b["cfg"]["eps_schedule"], False)
+    for r in (0, 1):
+        np.testing.assert_allclose(out[r][0], g["sn"]["W3"].reshape(-1), rtol=1e-9, atol=1e-12)
+        assert abs(out[r][1] - val) < 1e-9
