@@ -68,6 +68,12 @@ def lib():
         L.cmcd_bound_grad.argtypes = [C.POINTER(Desc), C.POINTER(Layout), C.c_void_p, C.c_int64, C.c_void_p,
                                       C.c_int64, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_int64,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cmcd_mfvi_workspace_bytes.restype = C.c_int64
+        L.cmcd_mfvi_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int64]
+        L.cmcd_mfvi_bound_grad.restype = C.c_int
+        L.cmcd_mfvi_bound_grad.argtypes = [C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
+                                           C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_float, C.c_void_p,
+                                           C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.cmcd_stats_merge_device.restype = C.c_int
         L.cmcd_stats_merge_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.cmcd_profile_enable.restype = C.c_int

@@ -1,0 +1,105 @@
+"""Host mirror of /root/reference/src/boundingmachine.py for the part the CMCD runs depend on: the
+mean-field VI bound (`nbridges = 0`) that /root/reference/src/main.py:82-109 optimises
+(`config.pretrain_mfvi`, trainable = ("vd",)) to obtain `vdparams_init` for every MCD mode.
+
+`initialize` reproduces the reference's parameter tree (and so the `params_flat` layout) for any
+`nbridges`; `compute_bound` / `grad_and_loss` run on the GPU through the C ABI (`cmcd_mfvi_bound_grad`)
+for `nbridges = 0` and raise `NotImplementedError` for the UHA chain (`nbridges >= 1`, ais_utils.evolve —
+outside this build's scope)."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from . import variationaldist as vd
+from .mcdboundingmachine import ravel_pytree, _workspaces
+
+
+def initialize(dim, vdparams=None, nbridges=0, lfsteps=1, eps=0.0, eta=0.5, mdparams=None, ngridb=32,
+               mgridref_y=None, trainable=("eps", "eta"), init_sigma=1.0, device=None):
+    """/root/reference/src/boundingmachine.py:9-70 -> (params_flat, unflatten, params_fixed = (dim, nbridges, lfsteps))."""
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    params_train, params_notrain = {}, {}
+
+    def put(name, value):
+        (params_train if name in trainable else params_notrain)[name] = value
+
+    put("vd", vdparams if vdparams is not None else vd.initialize(dim, init_sigma=init_sigma))
+    put("eps", torch.tensor(float(eps), dtype=torch.float32))
+    put("eta", torch.tensor(float(eta), dtype=torch.float32))
+    put("md", mdparams if mdparams is not None else torch.zeros(dim, dtype=torch.float32))   # momdist.py:8-10
+    if mgridref_y is not None:
+        mgridref_y = torch.as_tensor(mgridref_y, dtype=torch.float32)
+        ngridb = mgridref_y.shape[0] - 1
+    else:
+        if nbridges < ngridb:
+            ngridb = nbridges
+        mgridref_y = torch.ones(ngridb + 1, dtype=torch.float32)
+    params_notrain["gridref_x"] = torch.linspace(0, 1, ngridb + 2, dtype=torch.float32)
+    params_notrain["target_x"] = torch.linspace(0, 1, nbridges + 2, dtype=torch.float32)[1:-1]
+    put("mgridref_y", mgridref_y)
+    params_fixed = (dim, nbridges, lfsteps)
+    params_flat, unflatten = ravel_pytree((params_train, params_notrain), device=device)
+    return params_flat, unflatten, params_fixed
+
+
+def _call(seeds, params_flat, unflatten, params_fixed, log_prob, want_grad, n_total=None):
+    dim, nbridges, _ = params_fixed
+    if nbridges >= 1:
+        raise NotImplementedError("UHA (nbridges >= 1) is not implemented: only the mean-field bound (nbridges = 0).")
+    if not hasattr(log_prob, "target_id"):
+        raise TypeError("log_prob must be a cmcd_amd.model_handler.Target (see load_model)")
+    if log_prob.dim != dim:
+        raise ValueError(f"target dim {log_prob.dim} != params_fixed dim {dim}")
+    if not params_flat.is_cuda:
+        raise RuntimeError("the CMCD hot path runs on a ROCm device only: params_flat is not a device tensor")
+    if params_flat.dtype != torch.float32 or not params_flat.is_contiguous():
+        raise ValueError("params_flat must be contiguous float32")
+    L = _lib.lib()
+    device = params_flat.device
+    seeds = torch.as_tensor(seeds)
+    if seeds.device != device or seeds.dtype != torch.int32 or not seeds.is_contiguous():
+        seeds = seeds.to(device=device, dtype=torch.int32).contiguous()
+    n = seeds.numel()
+    if n < 1:
+        raise ValueError("seeds is empty")
+    nbytes = L.cmcd_mfvi_workspace_bytes(log_prob.target_id, dim, n)
+    if nbytes <= 0:
+        raise NotImplementedError(_lib.last_error() or "no mean-field kernel for this target")
+    key = str(device) + ":mfvi"
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    consts = log_prob.consts_on(device)
+    losses = torch.empty(n, dtype=torch.float32, device=device)
+    z = torch.empty(n, dim, dtype=torch.float32, device=device)
+    stats = torch.empty(_lib.NSTATS, dtype=torch.float64, device=device)
+    grad = torch.empty_like(params_flat) if want_grad else None
+    with torch.cuda.device(device):
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(L.cmcd_mfvi_bound_grad(
+            log_prob.target_id, dim, unflatten.offset("vd", "mean"), unflatten.offset("vd", "logdiag"),
+            seeds.data_ptr(), n, params_flat.data_ptr(), params_flat.numel(),
+            consts.data_ptr() if consts is not None else None, consts.numel() if consts is not None else 0,
+            1.0 / float(n if n_total is None else n_total), ws.data_ptr(), ws.numel(),
+            losses.data_ptr(), z.data_ptr(), stats.data_ptr(), grad.data_ptr() if want_grad else None, stream))
+    if want_grad:
+        # params_notrain = stop_gradient(params_notrain) (boundingmachine.py:75): "vd" outside `trainable` => zero
+        n_train = min((off for path, (off, _) in unflatten.layout.items() if path[0] == 1), default=params_flat.numel())
+        grad[n_train:].zero_()
+    return grad, losses, z, stats
+
+
+def compute_bound(seeds, params_flat, unflatten, params_fixed, log_prob):
+    """/root/reference/src/boundingmachine.py:114-118 -> (ratios.mean(), (ratios, z))."""
+    _, losses, z, stats = _call(seeds, params_flat, unflatten, params_fixed, log_prob, False)
+    return (stats[1] / losses.numel()).to(torch.float32), (losses, z)
+
+
+def grad_and_loss(seeds, params_flat, unflatten, params_fixed, log_prob, n_total=None):
+    """`jax.jit(jax.grad(bm.compute_bound, 1, has_aux=True))` (/root/reference/src/main.py:87-89)
+    -> (grad_flat, (ratios, z))."""
+    grad, losses, z, _ = _call(seeds, params_flat, unflatten, params_fixed, log_prob, True, n_total)
+    return grad, (losses, z)

@@ -56,6 +56,14 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
                  const float* params, const float* tc, float* ws, float* out_loss, float* out_z,
                  double** partials_out, void* stream);
 
+// mean-field VI on lgcp (cmcd_lgcp.hip) and the statistics merge launcher (cmcd_kernels.hip), used by cmcd_mfvi.hip
+int64_t lgcp_mfvi_workspace_floats(int D, int64_t n, bool with_grad);
+int lgcp_mfvi(int D, int64_t o_mean, int64_t o_logdiag, const int32_t* seeds, int64_t n, const float* params,
+              const float* tc, float* ws, float* out_loss, float* out_z, double** partials_out, float** gbuf_out,
+              bool with_grad, void* stream);
+int launch_finalize(const double* partials, int32_t count, double* out5, void* stream);
+int fail_msg(int code, const char* msg);
+
 // cmcd_grad.hip: VarGrad gradient (widths <= 64)
 bool grad_available(const cmcd_desc& d, int T);
 int64_t grad_workspace_floats(const cmcd_desc& d, int HP, int64_t n);

@@ -767,6 +767,13 @@ static void launch_prep(const cmcd_desc& d, const cmcd_layout& layr, const WsLay
 
 }
 
+int fail_msg(int code, const char* msg) { return fail(code, "%s", msg); }
+
+int launch_finalize(const double* partials, int32_t count, double* out5, void* stream) {
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), partials, count, out5);
+  return hipGetLastError() == hipSuccess ? CMCD_OK : fail(CMCD_ERR_HIP, "finalize launch failed%s");
+}
+
 static int check_desc(const cmcd_desc* d) {
   if (!d) return fail(CMCD_ERR_BAD_ARG, "null desc%s");
   if (d->mode < CMCD_MODE_CAIS_SN || d->mode > CMCD_MODE_ULA_SN)

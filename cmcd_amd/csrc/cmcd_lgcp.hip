@@ -435,4 +435,113 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
   return hipGetLastError() == hipSuccess ? CMCD_OK : CMCD_ERR_HIP;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Mean-field VI on the lgcp target (nbridges = 0; /root/reference/src/boundingmachine.py:73-111 with
+// /root/reference/src/main.py:82-109): z = mean + std e, loss = log q(z) - log p(z), and under the
+// reparameterisation d loss / d mean = -grad log p(z), d loss / d logdiag = -1 - grad log p(z) std e.
+// Per pass of <= kMP particles: init (z, -log q) -> x - mu0 -> one skinny GEMM with K^-1 -> finish.
+// ------------------------------------------------------------------------------------------
+struct LgcpMfviArgs {
+  const float* params;
+  const float* tc;
+  const float* x;        // [kMP][D]
+  const float* kr;       // [kSplit][kMP][D]
+  const float* w;        // [kMP]  -log q(z)
+  float* out_loss;       // [M]
+  float* out_z;          // [M][D]
+  double* partials;      // [M][5]
+  float* gbuf;           // [M][2][D] per-particle gradient rows (nullable)
+  int64_t o_mean;
+  int D;
+};
+
+__global__ __launch_bounds__(256) void lgcp_mfvi_finish_kernel(LgcpMfviArgs a) {
+  __shared__ float sh[4];
+  const int p = blockIdx.x, D = a.D;
+  const float* counts = a.tc + (int64_t)D * D;
+  const float mu0 = a.tc[(int64_t)D * D + D], pa = a.tc[(int64_t)D * D + D + 1];
+  const float lognorm = a.tc[(int64_t)D * D + D + 2];
+  float lp_acc = 0.f;
+  for (int e = threadIdx.x; e < D; e += blockDim.x) {
+    const float z = a.x[p * D + e];
+    float kr = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < kSplit; ++ks) kr += a.kr[((int64_t)ks * kMP + p) * D + e];
+    const float ez = expf(z);
+    const float gp = -kr + counts[e] - pa * ez;
+    lp_acc += -0.5f * (z - mu0) * kr + z * counts[e] - pa * ez;
+    a.out_z[(int64_t)p * D + e] = z;
+    if (a.gbuf) {
+      a.gbuf[((int64_t)p * 2) * D + e] = -gp;
+      a.gbuf[((int64_t)p * 2 + 1) * D + e] = -1.0f - gp * (z - a.params[a.o_mean + e]);
+    }
+  }
+  const float lp = block_sum_256(lp_acc, sh);
+  if (threadIdx.x == 0) {
+    const float loss = -(a.w[p] + lp + lognorm);
+    a.out_loss[p] = loss;
+    double* o = a.partials + (int64_t)p * CMCD_NSTATS;
+    o[0] = isfinite(loss) ? 1.0 : 0.0;
+    o[1] = loss;
+    o[2] = (double)loss * (double)loss;
+    o[3] = -(double)loss;
+    o[4] = isfinite(loss) ? 1.0 : 0.0;
+  }
+}
+
+int64_t lgcp_mfvi_workspace_floats(int D, int64_t n, bool with_grad) {
+  int64_t o = 0;
+  auto take = [&](int64_t cnt) { o += (cnt + 3) & ~int64_t(3); };
+  take(kMP * (int64_t)D); take(kMP * (int64_t)D); take(kSplit * kMP * (int64_t)D);
+  take(kMP); take(kMP); take(2 * kMP);
+  take(n * CMCD_NSTATS * 2);
+  if (with_grad) take(n * 2 * (int64_t)D);
+  return o;
+}
+
+int lgcp_mfvi(int D, int64_t o_mean, int64_t o_logdiag, const int32_t* seeds, int64_t n, const float* params,
+              const float* tc, float* ws, float* out_loss, float* out_z, double** partials_out, float** gbuf_out,
+              bool with_grad, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  int64_t o = 0;
+  auto take = [&](int64_t cnt) { int64_t r = o; o += (cnt + 3) & ~int64_t(3); return r; };
+  const int64_t ox = take(kMP * (int64_t)D), oxm = take(kMP * (int64_t)D), okr = take(kSplit * kMP * (int64_t)D);
+  const int64_t ow = take(kMP), ofk = take(kMP), okeys = take(2 * kMP);
+  const int64_t opart = take(n * CMCD_NSTATS * 2);
+  const int64_t ogb = with_grad ? take(n * 2 * (int64_t)D) : 0;
+  double* partials = reinterpret_cast<double*>(ws + opart);
+  float* gbuf = with_grad ? ws + ogb : nullptr;
+  *partials_out = partials;
+  *gbuf_out = gbuf;
+  const size_t gemm_lds = size_t(kGemmWaves * kChunk * kMP + kGemmWaves * kMP * 64) * 4;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(lgcp_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)gemm_lds) != hipSuccess)
+    return CMCD_ERR_HIP;
+  const float mu0 = 3.8812819069514780f;
+  const int cbD = (D + 63) / 64;
+  cmcd_layout lay{};
+  lay.vd_mean = o_mean; lay.vd_logdiag = o_logdiag;
+  for (int64_t base = 0; base < n; base += kMP) {
+    const int M = (int)((n - base) < kMP ? (n - base) : kMP);
+    LgcpStateArgs st{};
+    st.seeds = seeds + base; st.params = params; st.tc = tc; st.x = ws + ox;
+    st.w = ws + ow; st.fklp = ws + ofk; st.keys = reinterpret_cast<uint32_t*>(ws + okeys);
+    st.lay = lay; st.M = M; st.D = D; st.K = 0;
+    hipLaunchKernelGGL(lgcp_init_kernel, dim3(M), dim3(256), 0, stream, st);
+    ActArgs act{};
+    act.x = ws + ox; act.mu0 = mu0; act.M = M; act.D = D; act.IN = D; act.xm = ws + oxm; act.mode = 0;
+    hipLaunchKernelGGL(lgcp_act_kernel, dim3((M * D + 255) / 256), dim3(256), 0, stream, act);
+    GemmArgs g{};
+    g.M = M; g.Kdim = D;
+    g.seg[0] = GemmSeg{ws + oxm, tc, ws + okr, D, D, D, D};
+    g.nblk0 = cbD;
+    hipLaunchKernelGGL(lgcp_gemm_kernel, dim3(cbD, kSplit), dim3(64 * kGemmWaves), gemm_lds, stream, g);
+    LgcpMfviArgs fa{params, tc, ws + ox, ws + okr, ws + ow, out_loss + base, out_z + base * D,
+                    partials + base * CMCD_NSTATS, gbuf ? gbuf + base * 2 * D : nullptr, o_mean, D};
+    hipLaunchKernelGGL(lgcp_mfvi_finish_kernel, dim3(M), dim3(256), 0, stream, fa);
+  }
+  return hipGetLastError() == hipSuccess ? CMCD_OK : CMCD_ERR_HIP;
+}
+
 }  // namespace cmcd

@@ -165,6 +165,21 @@ int cmcd_bound_grad(const cmcd_desc* desc, const cmcd_layout* layout, const int3
                     float omega, void* workspace, int64_t workspace_bytes,
                     float* out_loss, float* out_z, double* out_stats, float* grad, void* stream);
 
+/* ---- Mean-field VI ("pretrain_mfvi"): the reference's plain bounding machine with nbridges = 0
+ * (/root/reference/src/boundingmachine.py:73-111, bm.compute_bound :114-118), which
+ * /root/reference/src/main.py:82-109 optimises with trainable = ("vd",) to obtain the q every CMCD run
+ * starts from.  Per seed: z = mean + exp(logdiag) * normal(first(split(PRNGKey(seed)))) (the same z_0 as
+ * cmcd_bound_forward draws), loss = log q(z) - log p(z).  out_loss / out_z / out_stats as cmcd_bound_forward.
+ * grad (nullable: forward only) [n_params], overwritten: omega * sum_n d loss_n / d {vd.mean, vd.logdiag}
+ * under the reparameterisation, zeros elsewhere; omega = 1 / N_total.
+ * Targets: gmm, many_gmm (dim 2), funnel (dim 10), lgcp (dim = m^2). */
+int64_t cmcd_mfvi_workspace_bytes(int32_t target, int32_t dim, int64_t n);
+int cmcd_mfvi_bound_grad(int32_t target, int32_t dim, int64_t off_vd_mean, int64_t off_vd_logdiag,
+                         const int32_t* seeds, int64_t n, const float* params, int64_t n_params,
+                         const float* target_consts, int64_t n_target, float omega,
+                         void* workspace, int64_t workspace_bytes,
+                         float* out_loss, float* out_z, double* out_stats, float* grad, void* stream);
+
 /* Device-side merge of `count` statistics vectors rows[count][5] (e.g. the result of an RCCL
  * all-gather of every rank's out_stats, in rank order) into out5[5], fixed order, one small kernel
  * on `stream`.  [device] pointers. */

@@ -222,6 +222,30 @@ def compute_bound_var(seeds, params, dim, nbridges, mode, arch, target, **kw):
         return np.clip(loss.var(ddof=0), -1e7, 1e7), (loss, z)
 
 
+def mfvi_losses(seeds, vd, dim, target, dtype=np.float64):
+    """Mean-field VI bound, per seed: /root/reference/src/boundingmachine.py:73-111 with nbridges = 0
+    (rng_key, _ = split(PRNGKey(seed)); z = vd.sample_rep(rng_key); w = -vd.log_prob(z) + log_prob(z); -w).
+    `vd` = {"mean", "logdiag"} float arrays.  -> (losses[N], z[N, dim])."""
+    vdp = {k: np.asarray(v, dtype) for k, v in vd.items()}
+    e0, _ = prng.particle_noise(np.asarray(seeds), dim, 0)
+    z = q_sample(vdp, e0.astype(dtype))
+    logp, _ = target(z)
+    return (q_log_prob(vdp, z) - logp).astype(dtype), z
+
+
+def mfvi_grad(seeds, vd, dim, target, dtype=np.float64):
+    """d mean(losses) / d {mean, logdiag} of `mfvi_losses`, i.e. what jax.grad(bm.compute_bound, 1)
+    (/root/reference/src/main.py:87-89) returns for the "vd" leaves: with z = mean + std e,
+    log q(z) = -|e|^2/2 - sum logdiag - c does not depend on mean, so
+    d/d mean = -E[grad log p(z)],  d/d logdiag = -1 - E[grad log p(z) * std e].
+    (tests/test_oracle_mfvi.py checks this against finite differences of `mfvi_losses`.)"""
+    vdp = {k: np.asarray(v, dtype) for k, v in vd.items()}
+    e0, _ = prng.particle_noise(np.asarray(seeds), dim, 0)
+    z = q_sample(vdp, e0.astype(dtype))
+    _, gp = target(z)
+    return {"mean": -gp.mean(0), "logdiag": (-1.0 - gp * (z - vdp["mean"])).mean(0)}
+
+
 def ln_z(loss):
     """logsumexp(-loss) - log n   (/root/reference/src/utils.py:233-235)."""
     a = -np.asarray(loss, np.float64)

@@ -68,3 +68,9 @@ def run_c_oracle(built, seeds):
     consts = built["target"].consts_on("cpu")
     return c_oracle.bound(desc, lay, np.asarray(seeds), built["params_flat"].detach().cpu().numpy(),
                           None if consts is None else consts.numpy())
+
+
+def lgcp_counts_fixture():
+    """The 40x40 bin counts of the Finnish pines point set (tests/golden/lgcp_bin_counts.npy: data)."""
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "lgcp_bin_counts.npy"))
