@@ -62,6 +62,10 @@ def lib():
         L.cmcd_bound_var_grad.argtypes = [C.POINTER(Desc), C.POINTER(Layout), C.c_void_p, C.c_int64, C.c_void_p,
                                           C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
                                           C.c_void_p, C.c_void_p]
+        L.cmcd_bound_var_grad_kept.restype = C.c_int
+        L.cmcd_bound_var_grad_kept.argtypes = L.cmcd_bound_var_grad.argtypes
+        L.cmcd_bound_var_forward.restype = C.c_int
+        L.cmcd_bound_var_forward.argtypes = L.cmcd_bound_forward.argtypes
         L.cmcd_bound_grad_workspace_bytes.restype = C.c_int64
         L.cmcd_bound_grad_workspace_bytes.argtypes = [C.POINTER(Desc), C.c_int64]
         L.cmcd_bound_grad.restype = C.c_int

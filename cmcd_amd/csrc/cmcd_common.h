@@ -67,11 +67,14 @@ int fail_msg(int code, const char* msg);
 // cmcd_grad.hip: VarGrad gradient (widths <= 64)
 bool grad_available(const cmcd_desc& d, int T);
 int64_t grad_workspace_floats(const cmcd_desc& d, int HP, int64_t n);
-// omega: per-particle weights (VarGrad), or nullptr with omega_scalar; traj: nullptr => VarGrad (local)
-// gradient, else the reverse sweep of the reparameterised gradient over the stored trajectory.
+// omega: per-particle weights (VarGrad), or nullptr with omega_scalar.  bptt: reparameterised gradient (reverse
+// sweep over the stored trajectory `traj`) vs the local gradient.  item: the work-item path for small batches
+// (needs `traj`; with bptt also `item_ws` of bptt_item_floats floats).
 int grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, const int32_t* seeds, int64_t n,
                 const float* params, int64_t n_params, const float* ws_fwd, const float* omega, float omega_scalar,
-                const float* traj, float* gws, float* grad, void* stream);
+                bool bptt, bool item, const float* traj, float* item_ws, float* gws, float* grad, void* stream);
 bool bptt_available(const cmcd_desc& d, int T);
+bool grad_item_mode(const cmcd_desc& d, int T, int64_t n);
+int64_t bptt_item_floats(const cmcd_desc& d, int64_t n);
 
 }  // namespace cmcd

@@ -39,6 +39,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "cmcd_common.h"
 #include "cmcd_device.h"
@@ -51,8 +52,10 @@ struct GradArgs {
   const float* params;
   const float* ws;           // forward workspace (tables + packed weights of cmcd_bound_forward's prep)
   const float* omega;        // [n], or nullptr: omega_scalar for every particle
-  const float* traj;         // BPTT: [K+1][n][D] trajectory stored by the forward kernel
+  const float* traj;         // BPTT / ITEM: [K+1][n][D] trajectory stored by the forward kernel
+  const float* lam;          // BPTT + ITEM: [K+1][n][D] adjoints lambda_e from the scan
   float omega_scalar;
+  int64_t nitems;            // ITEM: ntiles * (K + 1) independent (tile, evaluation) work items
   float* gtab;               // gradient tables (zeroed): S[(K+1)][HP], S2[(K+1)][HP], gbeta[K], geps[K], gvd[2D], gfac[1]
   float* slabs;              // per-workgroup slabs
   cmcd_layout lay;
@@ -67,7 +70,10 @@ struct GradArgs {
 __device__ __forceinline__ int sw(int f, int p) { return f * 16 + (p ^ (f & 15)); }
 
 // NW waves per workgroup (one tile each); WGLOBAL: W2 / W2^T fragments streamed from L2 instead of LDS
-template <int TARGET, int ARCH, int D, int T, int NW, bool WGLOBAL, bool BPTT>
+// ITEM: with the trajectory stored, every (tile, evaluation) pair is independent (the local gradient is local
+// by construction; the reparameterised one once lambda_e is known from the scan), so a wave takes work
+// items instead of whole chains: small batches then fill the chip instead of 1/8 of it.
+template <int TARGET, int ARCH, int D, int T, int NW, bool WGLOBAL, bool BPTT, bool ITEM>
 __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
   constexpr int HP = 16 * T;
   constexpr int Hh = (D + 1) / 2;
@@ -158,10 +164,20 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
 #pragma unroll
   for (int j = 0; j < D; ++j) { gmu[j] = 0.f; glam[j] = 0.f; }
 
-  for (int quad = blockIdx.x; quad < a.nquads; quad += gridDim.x) {
-    const int64_t tile = (int64_t)quad * NW + wv;
+  const int64_t n_outer = ITEM ? (a.nitems + NW - 1) / NW : a.nquads;
+  for (int64_t quad = blockIdx.x; quad < n_outer; quad += gridDim.x) {
+    int64_t tile = quad * NW + wv;
+    int e_item = 0;
+    bool live = true;
+    if (ITEM) {
+      int64_t item = quad * NW + wv;
+      live = item < a.nitems;
+      if (!live) item = a.nitems - 1;
+      tile = item / (K + 1);
+      e_item = (int)(item - tile * (K + 1));
+    }
     const int64_t p = tile * 16 + c;
-    const bool valid = p < a.n;
+    const bool valid = live && p < a.n;
     const int32_t seed = a.seeds[valid ? p : a.n - 1];
     const float om = valid ? (a.omega ? a.omega[p] : a.omega_scalar) : 0.f;
     const int64_t pc = valid ? p : a.n - 1;
@@ -172,7 +188,7 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
     float z[D], zp[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) { z[j] = 0.f; zp[j] = 0.f; }
-    if (!BPTT) {
+    if (!BPTT && !ITEM) {
       x0 = gb; x1 = 2 + gb;
       threefry2x32(k0, k1, x0, x1);
       uint32_t a0, a1, b0, b1;
@@ -218,14 +234,21 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
 #pragma unroll
     for (int j = 0; j < D; ++j) { lamn[j] = 0.f; gE[j] = 0.f; znext[j] = 0.f; }
 
-    for (int it = 0; it <= K; ++it) {
-      const int e = BPTT ? K - it : it;
-      if (BPTT) {
+    const int n_it = ITEM ? 1 : K + 1;
+    for (int it = 0; it < n_it; ++it) {
+      const int e = ITEM ? e_item : (BPTT ? K - it : it);
+      if (BPTT || ITEM) {
 #pragma unroll
         for (int j = 0; j < D; ++j) {
           z[j] = a.traj[((int64_t)e * a.n + pc) * D + j];
           zp[j] = e > 0 ? a.traj[((int64_t)(e - 1) * a.n + pc) * D + j] : 0.f;
+          if (ITEM) {
+            znext[j] = e < K ? a.traj[((int64_t)(e + 1) * a.n + pc) * D + j] : 0.f;
+            if (BPTT) lamn[j] = (valid && e < K) ? a.lam[((int64_t)(e + 1) * a.n + pc) * D + j] : 0.f;   // padding lanes carry no adjoint
+            else if (e == 0) glam[j] += om;   // d(-log q(z0))/d logdiag_j, once per particle
+          }
         }
+        if (ITEM && e > 0) { pbeta = a.ws[a.w.beta + e - 1]; peps = a.ws[a.w.eps + e - 1]; }
       }
       // ---------------------------------------------------------------- forward (keeps pre-activations)
       const float* brow = bias1 + (int64_t)e * HP;
@@ -298,7 +321,7 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
       bool gq_live[D];
       constexpr int HN = Target<TARGET, D>::HN;
       float hs[HN], gpraw[D];
-      if (BPTT) Target<TARGET, D>::eval_hess(z, g, lds_tgt, logp, gp, hs);
+      if (BPTT && !ITEM) Target<TARGET, D>::eval_hess(z, g, lds_tgt, logp, gp, hs);
       else Target<TARGET, D>::eval(z, g, lds_tgt, logp, gp);
 #pragma unroll
       for (int j = 0; j < D; ++j) {
@@ -366,6 +389,13 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
           }
         }
         pend_beta = npb; pend_eps = npe;
+        if (ITEM && e > 0) {  // no carry between work items: the backward-kernel part of step e-1 goes out now
+          const float tb = row_sum16(npb), te = row_sum16(npe);
+          if (lane == 0) {
+            atomicAdd(a.gtab + a.o_gbeta + (e - 1), tb);
+            atomicAdd(a.gtab + a.o_geps + (e - 1), te);
+          }
+        }
         float v[D], hv[D];
 #pragma unroll
         for (int j = 0; j < D; ++j) {
@@ -377,9 +407,11 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
           v[j] = (!clip_p || fabsf(gpraw[j]) < clipv) ? a_gp[j] : 0.f;
           gE[j] = gprev[j];
         }
-        Target<TARGET, D>::hvp(hs, z, v, hv);
+        if (!ITEM) {
+          Target<TARGET, D>::hvp(hs, z, v, hv);
 #pragma unroll
-        for (int j = 0; j < D; ++j) lam[j] += hv[j];
+          for (int j = 0; j < D; ++j) lam[j] += hv[j];
+        }
       }
       if (!BPTT && e > 0) {  // backward kernel of step i = e-1 at z' = z (mcd_cais_var.py:81-89)
         float sb = 0.f, se = 0.f, dn2 = 0.f;
@@ -409,13 +441,16 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
       float zn[D];
       if (!BPTT && e < K) {
         beta = a.ws[a.w.beta + e]; eps = a.ws[a.w.eps + e]; sig = a.ws[a.w.sig + e];
+        float nz[2 * Hh];
+#pragma unroll
+        for (int j = 0; j < 2 * Hh; ++j) nz[j] = 0.f;
+        if (!ITEM) {
         x0 = gb; x1 = 2 + gb;
         threefry2x32(k0, k1, x0, x1);
         uint32_t g0, g1, h0, h1;
         rows01(x0, g0, g1);
         rows01(x1, h0, h1);
         constexpr int NB = 2 + Hh;
-        float nz[2 * Hh];
 #pragma unroll
         for (int b0 = 0; b0 < NB; b0 += 4) {
           const int b = b0 + g;
@@ -437,12 +472,13 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
             }
           }
         }
+        }
         float sb = 0.f, se = 0.f, dn2 = 0.f;
 #pragma unroll
         for (int j = 0; j < D; ++j) {  // forward kernel of step e
           const float uf = -1.0f * (beta * gp[j] + (1.0f - beta) * gq[j]);
           const float fk = z[j] - eps * uf - eps * sn[j];
-          zn[j] = fk + sig * nz[j];
+          zn[j] = ITEM ? znext[j] : fk + sig * nz[j];
           const float df = zn[j] - fk;
           cot[j] += 0.5f * df;
           sb += df * (gp[j] - gq[j]);
@@ -454,6 +490,13 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
         const float inv2e = 0.5f / eps;
         pend_beta = -om * 0.5f * sb;
         pend_eps = om * (-dn2 * inv2e * inv2e + se * inv2e);
+        if (ITEM) {  // no carry between work items: the forward-kernel part of step e goes out now
+          const float tb = row_sum16(pend_beta), te = row_sum16(pend_eps);
+          if (lane == 0) {
+            atomicAdd(a.gtab + a.o_gbeta + e, tb);
+            atomicAdd(a.gtab + a.o_geps + e, te);
+          }
+        }
       }
 
       // ---------------------------------------------------------------- MLP backward
@@ -504,7 +547,7 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
         for (int r = 0; r < 4; ++r) {
           const int o = wb[r] + 256 * t;
           if (GEF) du1T[o] = d1[t][r];
-          if (BPTT && GEF && 16 * t < D) {  // residual path of the first block: d x_j += d u1_j
+          if (BPTT && !ITEM && GEF && 16 * t < D) {  // residual path of the first block: d x_j += d u1_j
 #pragma unroll
             for (int j = 0; j < D; ++j)
               if (j >= 16 * t && j < 16 * t + 16) jpart[j] += (16 * t + 4 * g + r == j) ? d1[t][r] : 0.f;
@@ -512,7 +555,7 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
           d1[t][r] *= GEF ? sigmoid_fast(a1[t][r]) : gelu_grad_fast(a1[t][r]);
           da1T[o] = d1[t][r];
         }
-        if (BPTT) {
+        if (BPTT && !ITEM) {
 #pragma unroll
           for (int j = 0; j < D; ++j) {
             const f32x4 wv4 = *reinterpret_cast<const f32x4*>(lds_w1z + j * HP + 16 * t + 4 * g);
@@ -523,11 +566,12 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
       if (BPTT) {
 #pragma unroll
         for (int j = 0; j < D; ++j) {
-          lam[j] += group_sum(jpart[j]);
+          if (!ITEM) lam[j] += group_sum(jpart[j]);
           if (e == 0) {  // z_0 = mean + std e0 and the explicit parameters of log q(z_0)
             const float dz = z[j] - qmean[j];
-            gmu[j] += lam[j] - om * gq[j];
-            glam[j] += lam[j] * dz + om * (dz * dz * qiv[j] - 1.0f);
+            const float l0 = ITEM ? (valid ? a.lam[pc * D + j] : 0.f) : lam[j];
+            gmu[j] += l0 - om * gq[j];
+            glam[j] += l0 * dz + om * (dz * dz * qiv[j] - 1.0f);
           }
           lamn[j] = lam[j];
           znext[j] = z[j];
@@ -609,7 +653,7 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
       }
       __syncthreads();
       // ---------------------------------------------------------------- advance
-      if (!BPTT && e < K) {
+      if (!BPTT && !ITEM && e < K) {
 #pragma unroll
         for (int j = 0; j < D; ++j) { zp[j] = z[j]; z[j] = zn[j]; }
         pbeta = beta; peps = eps;
@@ -650,6 +694,310 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Small-batch path of the reparameterised gradient.  lambda_e = M_e lambda_{e+1} + c_e is LINEAR in lambda and
+// M_e, c_e depend only on the stored trajectory, so the K-long dependent chain shrinks to a d x d
+// matrix-vector recursion:
+//   jac kernel  (parallel over (tile, evaluation)):  J_s(z_e) by d forward-mode passes through the net,
+//               the target Hessian, g_{e-1}  ->  M_e [d][d], C1_e [d], G_{e-1} [d]
+//     M_e  = I - eps_e J_s^T + eps_e beta_e H_p diag(m) - eps_e (1 - beta_e) diag(1/std_q^2)           (e < K; M_K = 0)
+//     C1_e = g_{e-1} + eps_{e-1} [J_s^T + beta_{e-1} H_p diag(m) - (1 - beta_{e-1}) diag(1/std_q^2)] g_{e-1}
+//            - omega grad log p(z_K) [e = K] + omega grad log q(z_0) [e = 0]
+//   scan kernel (one thread per particle):           lambda_e = M_e lambda_{e+1} + C1_e - G_e
+//   grad_kernel<..., BPTT, ITEM> (parallel over (tile, evaluation)): parameter contractions with lambda known.
+// ------------------------------------------------------------------------------------------
+struct JacArgs {
+  const float* params;
+  const float* ws;
+  const float* traj;      // [K+1][n][D]
+  float* jac;             // [K+1][n][D*D + 2*D]
+  cmcd_layout lay;
+  WsLayout w;
+  int64_t n, nitems;
+  int32_t K, grad_clipping;
+  float omega;
+};
+
+template <int TARGET, int ARCH, int D, int T>
+__global__ __launch_bounds__(256) void bptt_jac_kernel(JacArgs a) {
+  constexpr int HP = 16 * T;
+  constexpr bool GEF = ARCH == CMCD_ARCH_GEFFNER;
+  constexpr int S = D * D + 2 * D;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* lds_w2 = lds;
+  float* lds_w1z = lds_w2 + HP * HP;
+  float* lds_w3t = lds_w1z + D * HP;
+  float* lds_b2 = lds_w3t + D * HP;
+  float* lds_b3 = lds_b2 + HP;
+  float* lds_tgt = lds_b3 + 16;
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.ws + a.w.w2);
+    f32x4* dst = reinterpret_cast<f32x4*>(lds_w2);
+    for (int i = threadIdx.x; i < HP * HP / 4; i += blockDim.x) dst[i] = src[i];
+    src = reinterpret_cast<const f32x4*>(a.ws + a.w.w1z);
+    dst = reinterpret_cast<f32x4*>(lds_w1z);
+    for (int i = threadIdx.x; i < D * HP / 4; i += blockDim.x) dst[i] = src[i];
+    src = reinterpret_cast<const f32x4*>(a.ws + a.w.w3t);
+    dst = reinterpret_cast<f32x4*>(lds_w3t);
+    for (int i = threadIdx.x; i < D * HP / 4; i += blockDim.x) dst[i] = src[i];
+    for (int i = threadIdx.x; i < HP; i += blockDim.x) lds_b2[i] = a.ws[a.w.b2 + i];
+    for (int i = threadIdx.x; i < 16; i += blockDim.x) lds_b3[i] = a.ws[a.w.b3 + i];
+    for (int i = threadIdx.x; i < a.w.tgt_floats; i += blockDim.x) lds_tgt[i] = a.ws[a.w.tgt + i];
+  }
+  __syncthreads();
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  const int K = a.K;
+  const float factor = lds_b3[15];
+  float qmean[D], qiv[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    qmean[j] = a.params[a.lay.vd_mean + j];
+    const float sd = expf(a.params[a.lay.vd_logdiag + j]);
+    qiv[j] = 1.0f / (sd * sd);
+  }
+  const bool clip_p = a.grad_clipping != 0;
+  const float clipv = 1e3f;
+  const float* bias1 = a.ws + a.w.bias1;
+  const float* utab = a.ws + a.w.utab;
+
+  for (int64_t item = (int64_t)blockIdx.x * 4 + wv; item < a.nitems; item += (int64_t)gridDim.x * 4) {
+    const int64_t tile = item / (K + 1);
+    const int e = (int)(item - tile * (K + 1));
+    const int64_t p = tile * 16 + c;
+    const bool valid = p < a.n;
+    const int64_t pc = valid ? p : a.n - 1;
+    const float om = valid ? a.omega : 0.f;
+    float z[D], zp[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      z[j] = a.traj[((int64_t)e * a.n + pc) * D + j];
+      zp[j] = e > 0 ? a.traj[((int64_t)(e - 1) * a.n + pc) * D + j] : 0.f;
+    }
+    // ---- forward, keeping the activation derivatives
+    const float* brow = bias1 + (int64_t)e * HP;
+    f32x4 u1[T], s1[T], a2[T], s2[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      f32x4 pre = *reinterpret_cast<const f32x4*>(brow + 16 * t + 4 * g);
+#pragma unroll
+      for (int j = 0; j < D; ++j) pre += z[j] * *reinterpret_cast<const f32x4*>(lds_w1z + j * HP + 16 * t + 4 * g);
+      if (!GEF) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { u1[t][r] = gelu_fast(pre[r]); s1[t][r] = gelu_grad_fast(pre[r]); }
+      } else {
+        f32x4 u = *reinterpret_cast<const f32x4*>(utab + (int64_t)e * HP + 16 * t + 4 * g);
+        if (16 * t < D) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int nidx = 16 * t + 4 * g + r;
+#pragma unroll
+            for (int j = 0; j < D; ++j)
+              if (j >= 16 * t && j < 16 * t + 16) u[r] = (nidx == j) ? z[j] : u[r];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { u1[t][r] = u[r] + softplus(pre[r]); s1[t][r] = sigmoid_fast(pre[r]); }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) a2[t] = *reinterpret_cast<const f32x4*>(lds_b2 + 16 * t + 4 * g);
+#pragma unroll
+    for (int ti = 0; ti < T; ++ti) {
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int to = 0; to < T; ++to) {
+        const f32x4 af = *reinterpret_cast<const f32x4*>(lds_w2 + ((ti * T + to) * 64 + lane) * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a2[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r], u1[ti][r], a2[to], 0, 0, 0);
+      }
+    }
+    float opre[D], sn[D];
+    {
+      float part[D];
+#pragma unroll
+      for (int j = 0; j < D; ++j) part[j] = 0.f;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        f32x4 u2t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          u2t[r] = GEF ? u1[t][r] + softplus(a2[t][r]) : gelu_fast(a2[t][r]);
+          s2[t][r] = GEF ? sigmoid_fast(a2[t][r]) : gelu_grad_fast(a2[t][r]);
+        }
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          const f32x4 wv4 = *reinterpret_cast<const f32x4*>(lds_w3t + j * HP + 16 * t + 4 * g);
+          part[j] += u2t[0] * wv4[0] + u2t[1] * wv4[1] + u2t[2] * wv4[2] + u2t[3] * wv4[3];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        opre[j] = group_sum(part[j]) + lds_b3[j];
+        sn[j] = GEF ? opre[j] * factor : fminf(fmaxf(opre[j], -1e4f), 1e4f);
+      }
+    }
+    // ---- J_s: forward-mode pass per input coordinate;  Js[j][k] = d s_k / d z_j
+    float Js[D][D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      f32x4 t1[T], t2[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const f32x4 wz = *reinterpret_cast<const f32x4*>(lds_w1z + j * HP + 16 * t + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          t1[t][r] = s1[t][r] * wz[r];
+          if (GEF && 16 * t <= j && j < 16 * t + 16) t1[t][r] += (16 * t + 4 * g + r == j) ? 1.0f : 0.f;
+        }
+        t2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int ti = 0; ti < T; ++ti) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int to = 0; to < T; ++to) {
+          const f32x4 af = *reinterpret_cast<const f32x4*>(lds_w2 + ((ti * T + to) * 64 + lane) * 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) t2[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r], t1[ti][r], t2[to], 0, 0, 0);
+        }
+      }
+      float part[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) part[k] = 0.f;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        f32x4 d2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d2[r] = GEF ? t1[t][r] + s2[t][r] * t2[t][r] : s2[t][r] * t2[t][r];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          const f32x4 wv4 = *reinterpret_cast<const f32x4*>(lds_w3t + k * HP + 16 * t + 4 * g);
+          part[k] += d2[0] * wv4[0] + d2[1] * wv4[1] + d2[2] * wv4[2] + d2[3] * wv4[3];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const float ds = group_sum(part[k]);
+        Js[j][k] = GEF ? ds * factor : (fabsf(opre[k]) < 1e4f ? ds : 0.f);
+      }
+    }
+    // ---- target, q
+    constexpr int HN = Target<TARGET, D>::HN;
+    float gp[D], gq[D], hs[HN], logp, gpraw[D], m[D];
+    Target<TARGET, D>::eval_hess(z, g, lds_tgt, logp, gp, hs);
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      gq[j] = -(z[j] - qmean[j]) * qiv[j];
+      gpraw[j] = gp[j];
+      m[j] = (!clip_p || fabsf(gp[j]) < clipv) ? 1.0f : 0.f;
+      if (clip_p) gp[j] = fminf(fmaxf(gp[j], -clipv), clipv);
+    }
+    float Hm[D][D];   // Hm[j][k] = H[j][k] m_k
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      float v[D], hv[D];
+#pragma unroll
+      for (int j = 0; j < D; ++j) v[j] = (j == k) ? m[k] : 0.f;
+      Target<TARGET, D>::hvp(hs, z, v, hv);
+#pragma unroll
+      for (int j = 0; j < D; ++j) Hm[j][k] = hv[j];
+    }
+    float gprev[D], c1[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) { gprev[j] = 0.f; c1[j] = 0.f; }
+    if (e > 0) {
+      const float pb = a.ws[a.w.beta + e - 1], pe = a.ws[a.w.eps + e - 1];
+      const float inv2e = 0.5f / pe;
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        const float ub = -1.0f * (pb * gp[j] + (1.0f - pb) * gq[j]);
+        const float bk = z[j] - pe * ub + pe * sn[j];
+        gprev[j] = -om * (zp[j] - bk) * inv2e;
+      }
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < D; ++k) acc += (Js[j][k] + pb * Hm[j][k]) * gprev[k];
+        c1[j] = gprev[j] + pe * (acc - (1.0f - pb) * qiv[j] * gprev[j]);
+      }
+    }
+    if (e == K) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) c1[j] -= om * gpraw[j];
+    }
+    if (e == 0) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) c1[j] += om * gq[j];
+    }
+    if (valid && g == 0) {
+      float* row = a.jac + ((int64_t)e * a.n + p) * S;
+      const float be = e < K ? a.ws[a.w.beta + e] : 0.f, ee = e < K ? a.ws[a.w.eps + e] : 0.f;
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          float v = -ee * Js[j][k] + ee * be * Hm[j][k];
+          if (j == k) v += 1.0f - ee * (1.0f - be) * qiv[k];
+          row[j * D + k] = e < K ? v : 0.f;
+        }
+        row[D * D + j] = c1[j];
+      }
+      if (e > 0) {
+        float* prow = a.jac + ((int64_t)(e - 1) * a.n + p) * S;
+#pragma unroll
+        for (int j = 0; j < D; ++j) prow[D * D + D + j] = gprev[j];
+      }
+    }
+  }
+}
+
+struct ScanArgs {
+  const float* jac;   // [K+1][n][S]
+  float* lam;         // [K+1][n][D]
+  int64_t n;
+  int32_t K, D;
+};
+
+template <int D, int EB>
+__global__ void bptt_scan_kernel(ScanArgs a) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= a.n) return;
+  constexpr int S = D * D + 2 * D;
+  float lam[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) lam[j] = 0.f;
+  // rows do not depend on lambda: fetch EB of them ahead of the EB dependent matrix-vector products
+  for (int e1 = a.K; e1 >= 0; e1 -= EB) {
+    float rows[EB][S];
+#pragma unroll
+    for (int q = 0; q < EB; ++q) {
+      const int e = e1 - q;
+      const float* row = a.jac + ((int64_t)(e > 0 ? e : 0) * a.n + p) * S;
+#pragma unroll
+      for (int i = 0; i < S; ++i) rows[q][i] = row[i];
+    }
+#pragma unroll
+    for (int q = 0; q < EB; ++q) {
+      const int e = e1 - q;
+      if (e < 0) break;
+      float nl[D];
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        float acc = rows[q][D * D + j] - (e < a.K ? rows[q][D * D + D + j] : 0.f);
+#pragma unroll
+        for (int k = 0; k < D; ++k) acc = fmaf(rows[q][j * D + k], lam[k], acc);
+        nl[j] = acc;
+      }
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        lam[j] = nl[j];
+        a.lam[((int64_t)e * a.n + p) * D + j] = nl[j];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // reduction of the workgroup slabs into grad_flat (fixed order) + particle-independent tails
 // ------------------------------------------------------------------------------------------
 struct TailArgs {
@@ -664,60 +1012,55 @@ struct TailArgs {
   int32_t K, D, E, IN, HP, arch, nslabs, eps_schedule, ngrid, nw;
 };
 
-// fixed-order sums over the workgroup slabs; four independent partial sums keep the loads in flight
-__device__ __forceinline__ float slab_sum(const TailArgs& a, int64_t off) {
-  float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-  int s = 0;
-  for (; s + 4 <= a.nslabs; s += 4) {
-    v0 += a.slabs[(int64_t)s * a.slab_stride + off];
-    v1 += a.slabs[(int64_t)(s + 1) * a.slab_stride + off];
-    v2 += a.slabs[(int64_t)(s + 2) * a.slab_stride + off];
-    v3 += a.slabs[(int64_t)(s + 3) * a.slab_stride + off];
-  }
-  for (; s < a.nslabs; ++s) v0 += a.slabs[(int64_t)s * a.slab_stride + off];
-  return (v0 + v1) + (v2 + v3);
-}
-__device__ __forceinline__ float wave_slab_sum(const TailArgs& a, int64_t off) {  // per-wave regions, 4 per slab
-  const int64_t per = 2 * 16 * a.HP + 256 + 32, base = (int64_t)a.HP * a.HP + a.HP * 16;
-  float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-  for (int s = 0; s < a.nslabs; ++s) {
-    const float* q = a.slabs + (int64_t)s * a.slab_stride + base + off;
-    v0 += q[0];
-    v1 += q[per];
-    v2 += q[2 * per];
-    if (a.nw > 3) v3 += q[3 * per];
-  }
-  return (v0 + v1) + (v2 + v3);
-}
-
-// grid-stride over every entry of grad_flat that is a plain sum of slab entries
-__global__ void grad_reduce_kernel(TailArgs a) {
+// Every entry of grad_flat that is a plain sum of slab entries: 16 lanes per output element, each lane a fixed
+// strided subset of the slabs (or of the (slab, wave) regions), then a fixed butterfly: deterministic, and
+// 256 slabs cost 16 loads per lane instead of a 256-long serial walk.
+__global__ __launch_bounds__(256) void grad_reduce_kernel(TailArgs a) {
   const int HP = a.HP, D = a.D, IN = a.IN;
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
   const bool dds = a.arch == CMCD_ARCH_DDS;
   const int64_t o_w1 = dds ? a.lay.d_sw1 : a.lay.g_w1, o_w2 = dds ? a.lay.d_sw2 : a.lay.g_w2;
   const int64_t o_b2 = dds ? a.lay.d_sb2 : a.lay.g_b2, o_w3 = dds ? a.lay.d_sw3 : a.lay.g_w3;
   const int64_t o_b3 = dds ? a.lay.d_sb3 : a.lay.g_b3;
   const int wid = dds ? 64 : IN;  // true width, row length of W1 / W2
-  for (int64_t i = tid; i < (int64_t)wid * wid; i += stride) {         // dW2[k][n]
-    const int k = int(i / wid), n = int(i % wid);
-    a.grad[o_w2 + i] = slab_sum(a, (int64_t)k * HP + n);
+  const int sub = threadIdx.x & 15;
+  int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int64_t per = 2 * 16 * HP + 256 + 32, base = (int64_t)HP * HP + HP * 16;   // per-wave regions of a slab
+  int64_t dst = -1, off = 0;
+  bool perwave = false;
+  if (i < (int64_t)wid * wid) {                                   // dW2[k][n]
+    dst = o_w2 + i; off = (i / wid) * HP + (i % wid);
+  } else if ((i -= (int64_t)wid * wid) < (int64_t)wid * D) {      // dW3[n][j]
+    dst = o_w3 + i; off = (int64_t)HP * HP + (i / D) * 16 + (i % D);
+  } else if ((i -= (int64_t)wid * D) < (int64_t)D * wid) {        // dW1[j][n], j < D (z rows)
+    dst = o_w1 + i; off = (i / wid) * HP + (i % wid); perwave = true;
+  } else if ((i -= (int64_t)D * wid) < wid) {                     // db2
+    dst = o_b2 + i; off = 16 * HP + (int64_t)D * HP + i; perwave = true;
+  } else if ((i -= wid) < D) {                                    // db3
+    dst = o_b3 + i; off = 2 * 16 * HP + D * 16 + i; perwave = true;
+  } else if ((i -= D) < D) {                                      // d vd.mean
+    dst = a.lay.vd_mean + i; off = 2 * 16 * HP + 256 + 1 + 2 * i; perwave = true;
+  } else if ((i -= D) < D) {                                      // d vd.logdiag
+    dst = a.lay.vd_logdiag + i; off = 2 * 16 * HP + 256 + 2 + 2 * i; perwave = true;
+  } else if ((i -= D) < 1 && !dds) {                              // d factor_sn
+    dst = a.lay.g_factor; off = 2 * 16 * HP + 256; perwave = true;
   }
-  for (int64_t i = tid; i < (int64_t)wid * D; i += stride) {           // dW3[n][j]
-    const int n = int(i / D), j = int(i % D);
-    a.grad[o_w3 + i] = slab_sum(a, (int64_t)HP * HP + n * 16 + j);
+  float v = 0.f;
+  if (dst >= 0) {
+    if (!perwave) {
+      for (int sl = sub; sl < a.nslabs; sl += 16) v += a.slabs[(int64_t)sl * a.slab_stride + off];
+    } else {
+      const int tot = a.nslabs * a.nw;
+      for (int t = sub; t < tot; t += 16) {
+        const int sl = t / a.nw, q = t - sl * a.nw;
+        v += a.slabs[(int64_t)sl * a.slab_stride + base + q * per + off];
+      }
+    }
   }
-  for (int64_t i = tid; i < (int64_t)D * wid; i += stride) {           // dW1[j][n], j < D (z rows)
-    const int j = int(i / wid), n = int(i % wid);
-    a.grad[o_w1 + i] = wave_slab_sum(a, (int64_t)j * HP + n);
-  }
-  for (int64_t i = tid; i < wid; i += stride) a.grad[o_b2 + i] = wave_slab_sum(a, 16 * HP + (int64_t)D * HP + i);
-  for (int64_t i = tid; i < D; i += stride) {
-    a.grad[o_b3 + i] = wave_slab_sum(a, 2 * 16 * HP + D * 16 + i);
-    a.grad[a.lay.vd_mean + i] = wave_slab_sum(a, 2 * 16 * HP + 256 + 1 + 2 * i);
-    a.grad[a.lay.vd_logdiag + i] = wave_slab_sum(a, 2 * 16 * HP + 256 + 2 + 2 * i);
-  }
-  if (tid == 0 && !dds) a.grad[a.lay.g_factor] = wave_slab_sum(a, 2 * 16 * HP + 256);
+  v += __shfl_xor(v, 8);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 1);
+  if (dst >= 0 && sub == 0) a.grad[dst] = v;
 }
 
 // d / d eps0 and d / d mgridref_y from the per-step tables (one 256-thread block, thread per bridge)
@@ -866,25 +1209,55 @@ typedef void (*grad_fn)(GradArgs);
 
 static int grad_nw(int T) { return T > 4 ? 3 : 4; }
 
-template <bool BPTT>
+template <bool BPTT, bool ITEM>
 static grad_fn pick_grad_t(const cmcd_desc& d, int T) {
   if (d.arch == CMCD_ARCH_DDS && T == 4) {
-    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_DDS, 2, 4, 4, false, BPTT>;
-    if (d.target == CMCD_TARGET_GMM && d.dim == 2) return grad_kernel<CMCD_TARGET_GMM, CMCD_ARCH_DDS, 2, 4, 4, false, BPTT>;
+    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_DDS, 2, 4, 4, false, BPTT, ITEM>;
+    if (d.target == CMCD_TARGET_GMM && d.dim == 2) return grad_kernel<CMCD_TARGET_GMM, CMCD_ARCH_DDS, 2, 4, 4, false, BPTT, ITEM>;
     return nullptr;
   }
   if (d.arch == CMCD_ARCH_GEFFNER) {
-    if (d.target == CMCD_TARGET_GMM && d.dim == 2 && T == 2) return grad_kernel<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER, 2, 2, 4, false, BPTT>;
-    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 2) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 2, 4, false, BPTT>;
-    if (!BPTT && d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 9) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 9, 3, true, false>;
-    if (d.target == CMCD_TARGET_FUNNEL && d.dim == 10 && T == 4) return grad_kernel<CMCD_TARGET_FUNNEL, CMCD_ARCH_GEFFNER, 10, 4, 4, false, BPTT>;
+    if (d.target == CMCD_TARGET_GMM && d.dim == 2 && T == 2) return grad_kernel<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER, 2, 2, 4, false, BPTT, ITEM>;
+    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 2) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 2, 4, false, BPTT, ITEM>;
+    if (!BPTT && !ITEM && d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 9) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 9, 3, true, false, false>;
+    if (d.target == CMCD_TARGET_FUNNEL && d.dim == 10 && T == 4) return grad_kernel<CMCD_TARGET_FUNNEL, CMCD_ARCH_GEFFNER, 10, 4, 4, false, BPTT, ITEM>;
   }
   return nullptr;
 }
-static grad_fn pick_grad(const cmcd_desc& d, int T, bool bptt) { return bptt ? pick_grad_t<true>(d, T) : pick_grad_t<false>(d, T); }
+static grad_fn pick_grad(const cmcd_desc& d, int T, bool bptt, bool item = false) {
+  if (item) return bptt ? pick_grad_t<true, true>(d, T) : pick_grad_t<false, true>(d, T);
+  return bptt ? pick_grad_t<true, false>(d, T) : pick_grad_t<false, false>(d, T);
+}
+
+typedef void (*jac_fn)(JacArgs);
+static jac_fn pick_jac(const cmcd_desc& d, int T) {
+  if (d.arch == CMCD_ARCH_DDS && T == 4) {
+    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2) return bptt_jac_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_DDS, 2, 4>;
+    if (d.target == CMCD_TARGET_GMM && d.dim == 2) return bptt_jac_kernel<CMCD_TARGET_GMM, CMCD_ARCH_DDS, 2, 4>;
+    return nullptr;
+  }
+  if (d.arch == CMCD_ARCH_GEFFNER) {
+    if (d.target == CMCD_TARGET_GMM && d.dim == 2 && T == 2) return bptt_jac_kernel<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER, 2, 2>;
+    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 2) return bptt_jac_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 2>;
+    if (d.target == CMCD_TARGET_FUNNEL && d.dim == 10 && T == 4) return bptt_jac_kernel<CMCD_TARGET_FUNNEL, CMCD_ARCH_GEFFNER, 10, 4>;
+  }
+  return nullptr;
+}
 
 bool grad_available(const cmcd_desc& d, int T) { return pick_grad(d, T, false) != nullptr; }
 bool bptt_available(const cmcd_desc& d, int T) { return pick_grad(d, T, true) != nullptr; }
+
+// Work-item (small-batch) path: worthwhile while whole-chain waves cannot fill the chip.  CMCD_GRAD_ITEM=0/1 overrides.
+bool grad_item_mode(const cmcd_desc& d, int T, int64_t n) {
+  if (pick_grad(d, T, false, true) == nullptr) return false;
+  if (const char* e = getenv("CMCD_GRAD_ITEM")) return atoi(e) != 0;
+  return n <= 8192;
+}
+// extra floats the work-item path of the reparameterised gradient keeps: jac rows + lambda table
+int64_t bptt_item_floats(const cmcd_desc& d, int64_t n) {
+  const int64_t D = d.dim;
+  return (int64_t)(d.nbridges + 1) * n * (D * D + 2 * D + D);
+}
 
 static void grad_offsets(const cmcd_desc& d, int HP, int64_t& o_S, int64_t& o_S2, int64_t& o_gbeta, int64_t& o_geps,
                          int64_t& o_gvd, int64_t& o_gfac, int64_t& total) {
@@ -908,29 +1281,55 @@ int64_t grad_workspace_floats(const cmcd_desc& d, int HP, int64_t n) {
   int64_t oS, oS2, ob, oe, ov, of, tot;
   grad_offsets(d, HP, oS, oS2, ob, oe, ov, of, tot);
   const int64_t slab = (int64_t)HP * HP + HP * 16 + 4 * (2 * 16 * HP + 256 + 32);
-  return tot + slab * grad_nslabs(n, grad_nw(HP / 16));
+  return tot + slab * 256;   // up to one slab per workgroup of a full-chip launch (either path)
 }
 
 // ws_fwd: the forward workspace as left by cmcd_bound_forward's prep on the SAME desc/params;
 // gws: gradient workspace (grad_workspace_floats).  grad: [n_params], fully overwritten.
+// bptt: reparameterised gradient (needs traj) vs local gradient; item: work-item path (needs traj; with bptt
+// also item_ws = bptt_item_floats floats for the jac rows and the lambda table).
 int grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, const int32_t* seeds, int64_t n,
                 const float* params, int64_t n_params, const float* ws_fwd, const float* omega, float omega_scalar,
-                const float* traj, float* gws, float* grad, void* stream_) {
+                bool bptt, bool item, const float* traj, float* item_ws, float* gws, float* grad, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  grad_fn fn = pick_grad(d, w.T, traj != nullptr);
-  if (!fn) return CMCD_ERR_UNSUPPORTED;
+  grad_fn fn = pick_grad(d, w.T, bptt, item);
+  if (!fn || ((bptt || item) && !traj) || (bptt && item && !item_ws)) return CMCD_ERR_UNSUPPORTED;
   const int D = d.dim, HP = w.HP, K = d.nbridges;
   GradArgs ga{};
   int64_t tot;
   grad_offsets(d, HP, ga.o_S, ga.o_S2, ga.o_gbeta, ga.o_geps, ga.o_gvd, ga.o_gfac, tot);
   const int nw = grad_nw(w.T);
-  const int nslabs = grad_nslabs(n, nw);
+  const int64_t ntiles = (n + 15) / 16;
+  const int64_t nitems = ntiles * (K + 1);
+  const int64_t n_outer = (nitems + nw - 1) / nw;
+  const int nslabs = item ? (int)(n_outer < 256 ? n_outer : 256) : grad_nslabs(n, nw);
   ga.seeds = seeds; ga.params = params; ga.ws = ws_fwd; ga.omega = omega; ga.omega_scalar = omega_scalar; ga.traj = traj; ga.gtab = gws; ga.slabs = gws + tot;
   ga.lay = lay; ga.w = w; ga.n = n; ga.K = K; ga.var_mode = d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0;
   ga.grad_clipping = d.grad_clipping; ga.nquads = (int)((n + 16 * nw - 1) / (16 * nw));
+  ga.nitems = nitems;
   ga.slab_stride = (int64_t)HP * HP + HP * 16 + 4 * (2 * 16 * HP + 256 + 32);
   if (hipMemsetAsync(gws, 0, sizeof(float) * tot, stream) != hipSuccess) return CMCD_ERR_HIP;
   if (hipMemsetAsync(grad, 0, sizeof(float) * n_params, stream) != hipSuccess) return CMCD_ERR_HIP;
+
+  if (bptt && item) {
+    jac_fn jf = pick_jac(d, w.T);
+    if (!jf) return CMCD_ERR_UNSUPPORTED;
+    const int64_t S = (int64_t)D * D + 2 * D;
+    float* jac = item_ws;
+    float* lam = item_ws + (int64_t)(K + 1) * n * S;
+    JacArgs ja{params, ws_fwd, traj, jac, lay, w, n, nitems, K, d.grad_clipping, omega_scalar};
+    const size_t jl = size_t(HP * HP + 2 * D * HP + HP + 16 + w.tgt_floats) * 4;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(jf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)jl) != hipSuccess)
+      return CMCD_ERR_HIP;
+    const int64_t jb = (nitems + 3) / 4;
+    hipLaunchKernelGGL(jf, dim3((unsigned)(jb < 2048 ? jb : 2048)), dim3(256), jl, stream, ja);
+    ScanArgs sa{jac, lam, n, K, D};
+    if (D == 2) hipLaunchKernelGGL((bptt_scan_kernel<2, 16>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, sa);
+    else if (D == 10) hipLaunchKernelGGL((bptt_scan_kernel<10, 1>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, sa);
+    else return CMCD_ERR_UNSUPPORTED;
+    ga.lam = lam;
+  }
+
   const size_t lds_bytes = size_t((w.T > 4 ? 0 : 2 * HP * HP) + 2 * D * HP + HP + 16 + w.tgt_floats + nw * ((5 * HP + 32) * 16 + (D + 1) * HP)) * 4;
   if (lds_bytes > 160 * 1024) return CMCD_ERR_UNSUPPORTED;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -944,7 +1343,11 @@ int grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, c
   ta.o_gfac = ga.o_gfac; ta.slab_stride = ga.slab_stride; ta.n_params = n_params;
   ta.K = K; ta.D = D; ta.E = d.emb_dim; ta.IN = D + d.emb_dim; ta.HP = HP; ta.arch = d.arch; ta.nslabs = nslabs;
   ta.eps_schedule = d.eps_schedule; ta.ngrid = d.ngrid; ta.nw = nw;
-  hipLaunchKernelGGL(grad_reduce_kernel, dim3(32), dim3(256), 0, stream, ta);
+  {
+    const int64_t wid = d.arch == CMCD_ARCH_DDS ? 64 : D + d.emb_dim;
+    const int64_t outs = wid * wid + 2 * wid * D + wid + 3 * D + 1;
+    hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((outs * 16 + 255) / 256)), dim3(256), 0, stream, ta);
+  }
   hipLaunchKernelGGL(grad_sched_tail_kernel, dim3(1), dim3(256), 0, stream, ta);
   if (d.arch == CMCD_ARCH_DDS) hipLaunchKernelGGL(grad_dds_tail_kernel, dim3(K + 1), dim3(64), 0, stream, ta);
   else hipLaunchKernelGGL(grad_geffner_tail_kernel, dim3(64), dim3(256), 0, stream, ta);

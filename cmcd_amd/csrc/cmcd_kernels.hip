@@ -987,7 +987,8 @@ int64_t cmcd_bound_grad_workspace_bytes(const cmcd_desc* desc, int64_t n) {
     return 0;
   }
   return (align4(w.total_floats) + align4(grad_workspace_floats(*desc, w.HP, n)) +
-          (int64_t)(desc->nbridges + 1) * n * desc->dim) * 4;
+          align4((int64_t)(desc->nbridges + 1) * n * desc->dim) +
+          (grad_item_mode(*desc, w.T, n) ? bptt_item_floats(*desc, n) : 0)) * 4;
 }
 
 int cmcd_bound_grad(const cmcd_desc* desc, const cmcd_layout* lay, const int32_t* seeds, int64_t n,
@@ -1005,7 +1006,9 @@ int cmcd_bound_grad(const cmcd_desc* desc, const cmcd_layout* lay, const int32_t
   if (!make_ws(d, n, n_target, w)) return fail(CMCD_ERR_BAD_ARG, "bad descriptor%s");
   if (!bptt_available(d, w.T)) return fail(CMCD_ERR_UNSUPPORTED, "no reparameterised-gradient kernel instance for this (target, dim, arch, width)%s");
   const int64_t fwd = align4(w.total_floats), gfl = align4(grad_workspace_floats(d, w.HP, n));
-  const int64_t need = (fwd + gfl + (int64_t)(d.nbridges + 1) * n * d.dim) * 4;
+  const int64_t tfl = align4((int64_t)(d.nbridges + 1) * n * d.dim);
+  const bool item = grad_item_mode(d, w.T, n);
+  const int64_t need = (fwd + gfl + tfl + (item ? bptt_item_floats(d, n) : 0)) * 4;
   if (workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15))
     return fail(CMCD_ERR_WORKSPACE, "workspace too small or not 16-byte aligned (need %s%lld bytes)", "", need);
   float* ws = static_cast<float*>(workspace);
@@ -1013,7 +1016,8 @@ int cmcd_bound_grad(const cmcd_desc* desc, const cmcd_layout* lay, const int32_t
   rc = forward_impl(desc, lay, seeds, n, params, n_params, target_consts, n_target, workspace, fwd * 4, out_loss,
                     out_z, out_stats, traj, stream_);
   if (rc != CMCD_OK) return rc;
-  rc = grad_launch(d, *lay, w, seeds, n, params, n_params, ws, nullptr, omega, traj, ws + fwd, grad, stream_);
+  rc = grad_launch(d, *lay, w, seeds, n, params, n_params, ws, nullptr, omega, true, item, traj,
+                   item ? traj + tfl : nullptr, ws + fwd, grad, stream_);
   if (rc != CMCD_OK) return fail(rc, "gradient launch failed%s");
   return CMCD_OK;
 }
@@ -1027,7 +1031,10 @@ int64_t cmcd_grad_workspace_bytes(const cmcd_desc* desc, int64_t n) {
     fail(CMCD_ERR_UNSUPPORTED, "no gradient kernel instance for this (target, dim, arch, width)%s");
     return 0;
   }
-  return (align4(w.total_floats) + grad_workspace_floats(*desc, w.HP, n)) * 4;
+  int64_t fl = align4(w.total_floats) + align4(grad_workspace_floats(*desc, w.HP, n));
+  if (grad_item_mode(*desc, w.T, n))   // trajectory + scratch outputs of the internal forward pass
+    fl += align4((int64_t)(desc->nbridges + 1) * n * desc->dim) + align4(n) + align4(n * desc->dim) + 16;
+  return fl * 4;
 }
 
 int cmcd_vargrad_weights(const float* loss, const double* stats, int64_t n, int64_t n_total, float* omega,
@@ -1039,9 +1046,10 @@ int cmcd_vargrad_weights(const float* loss, const double* stats, int64_t n, int6
   return CMCD_OK;
 }
 
-int cmcd_bound_var_grad(const cmcd_desc* desc, const cmcd_layout* lay, const int32_t* seeds, int64_t n,
-                        const float* params, int64_t n_params, const float* target_consts, int64_t n_target,
-                        const float* omega, void* workspace, int64_t workspace_bytes, float* grad, void* stream_) {
+static int var_grad_impl(const cmcd_desc* desc, const cmcd_layout* lay, const int32_t* seeds, int64_t n,
+                         const float* params, int64_t n_params, const float* target_consts, int64_t n_target,
+                         const float* omega, void* workspace, int64_t workspace_bytes, float* grad, bool kept,
+                         void* stream_) {
   int rc = check_desc(desc);
   if (rc != CMCD_OK) return rc;
   if (!lay || !seeds || !params || !omega || !workspace || !grad) return fail(CMCD_ERR_BAD_ARG, "null pointer argument%s");
@@ -1058,15 +1066,67 @@ int cmcd_bound_var_grad(const cmcd_desc* desc, const cmcd_layout* lay, const int
   WsLayout w;
   if (!make_ws(d, n, n_target, w)) return fail(CMCD_ERR_BAD_ARG, "bad descriptor%s");
   if (!grad_available(d, w.T)) return fail(CMCD_ERR_UNSUPPORTED, "no gradient kernel instance for this (target, dim, arch, width)%s");
-  const int64_t need = (align4(w.total_floats) + grad_workspace_floats(d, w.HP, n)) * 4;
+  const int64_t need = cmcd_grad_workspace_bytes(desc, n);
   if (workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15))
     return fail(CMCD_ERR_WORKSPACE, "workspace too small or not 16-byte aligned (need %s%lld bytes)", "", need);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   float* ws = static_cast<float*>(workspace);
-  launch_prep(d, *lay, w, params, target_consts, n_mix, ws, stream);
-  rc = grad_launch(d, *lay, w, seeds, n, params, n_params, ws, omega, 0.f, nullptr, ws + align4(w.total_floats), grad, stream_);
+  const int64_t fwd = align4(w.total_floats), gfl = align4(grad_workspace_floats(d, w.HP, n));
+  const bool item = grad_item_mode(d, w.T, n);
+  float* traj = nullptr;
+  if (item && kept) {
+    traj = ws + fwd + gfl;   // left there, with the prep tables, by cmcd_bound_var_forward
+  } else if (item) {
+    // the work-item path reads the trajectory: run the forward launch sequence once more, keeping z_0..z_K
+    traj = ws + fwd + gfl;
+    float* sl = traj + align4((int64_t)(d.nbridges + 1) * n * d.dim);
+    float* sz = sl + align4(n);
+    double* sst = reinterpret_cast<double*>(sz + align4(n * d.dim));
+    rc = forward_impl(desc, lay, seeds, n, params, n_params, target_consts, n_target, workspace, fwd * 4, sl, sz, sst,
+                      traj, stream_);
+    if (rc != CMCD_OK) return rc;
+  } else if (!kept) {
+    launch_prep(d, *lay, w, params, target_consts, n_mix, ws, stream);
+  }
+  rc = grad_launch(d, *lay, w, seeds, n, params, n_params, ws, omega, 0.f, false, item, traj, nullptr, ws + fwd, grad,
+                   stream_);
   if (rc != CMCD_OK) return fail(rc, "gradient launch failed%s");
   return CMCD_OK;
+}
+
+int cmcd_bound_var_grad(const cmcd_desc* desc, const cmcd_layout* lay, const int32_t* seeds, int64_t n,
+                        const float* params, int64_t n_params, const float* target_consts, int64_t n_target,
+                        const float* omega, void* workspace, int64_t workspace_bytes, float* grad, void* stream_) {
+  return var_grad_impl(desc, lay, seeds, n, params, n_params, target_consts, n_target, omega, workspace,
+                       workspace_bytes, grad, false, stream_);
+}
+
+int cmcd_bound_var_forward(const cmcd_desc* desc, const cmcd_layout* lay, const int32_t* seeds, int64_t n,
+                           const float* params, int64_t n_params, const float* target_consts, int64_t n_target,
+                           void* workspace, int64_t workspace_bytes, float* out_loss, float* out_z,
+                           double* out_stats, void* stream_) {
+  int rc = check_desc(desc);
+  if (rc != CMCD_OK) return rc;
+  if (desc->mode != CMCD_MODE_CAIS_VAR_SN || desc->target == CMCD_TARGET_LGCP)
+    return fail(CMCD_ERR_UNSUPPORTED, "the local (stop_gradient) gradient exists for MCD_CAIS_var_sn only%s");
+  const int64_t need = cmcd_grad_workspace_bytes(desc, n);
+  if (need <= 0) return CMCD_ERR_UNSUPPORTED;
+  if (workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15))
+    return fail(CMCD_ERR_WORKSPACE, "workspace too small or not 16-byte aligned (need %s%lld bytes)", "", need);
+  WsLayout w;
+  if (!make_ws(*desc, n, n_target, w)) return fail(CMCD_ERR_BAD_ARG, "bad descriptor%s");
+  const int64_t fwd = align4(w.total_floats), gfl = align4(grad_workspace_floats(*desc, w.HP, n));
+  float* traj = grad_item_mode(*desc, w.T, n) ? static_cast<float*>(workspace) + fwd + gfl : nullptr;
+  return forward_impl(desc, lay, seeds, n, params, n_params, target_consts, n_target, workspace, fwd * 4, out_loss,
+                      out_z, out_stats, traj, stream_);
+}
+
+int cmcd_bound_var_grad_kept(const cmcd_desc* desc, const cmcd_layout* lay, const int32_t* seeds, int64_t n,
+                             const float* params, int64_t n_params, const float* target_consts, int64_t n_target,
+                             const float* omega, void* workspace, int64_t workspace_bytes, float* grad,
+                             void* stream_) {
+  return var_grad_impl(desc, lay, seeds, n, params, n_params, target_consts, n_target, omega, workspace,
+                       workspace_bytes, grad, true, stream_);
 }
 
 int cmcd_stats_merge_device(const double* rows, int32_t count, double* out5, void* stream_) {

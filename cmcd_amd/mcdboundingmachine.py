@@ -283,25 +283,34 @@ def compute_log_var_grad(seeds, params_flat, unflatten, params_fixed, log_prob, 
     (/root/reference/src/opt.py:97-99).  Returns (grad_flat, (losses, z)); `grad_flat` has the layout of
     `params_flat` (zeros for leaves the loss does not reach).  `MCD_CAIS_var_sn` only: its per-step
     `stop_gradient` (/root/reference/src/mcd_cais_var.py:59,79) makes the gradient local per bridge, which
-    is what the HIP kernel exploits.  Multi-GPU: pass the merged statistics and the global particle count
-    (`stats_total`, `n_total`) and all-reduce the returned gradient."""
+    is what the HIP kernel exploits.  Multi-GPU: pass the global particle count `n_total` and `stats_total` —
+    the merged statistics, or a callable `local_stats -> merged_stats` that runs the all-gather between the
+    forward and the gradient launch — and all-reduce the returned gradient."""
     dim, nbridges, mode, spec = params_fixed
     if mode != "MCD_CAIS_var_sn":
         raise NotImplementedError("Mode not implemented.")
-    losses, z, stats = bound_forward(seeds, params_flat, unflatten, params_fixed, log_prob,
-                                     eps_schedule=eps_schedule, grad_clipping=grad_clipping)
+    if not isinstance(spec, ScoreNet):
+        raise ValueError("params_fixed[3] must be the ScoreNet returned by initialize()")
+    if not hasattr(log_prob, "target_id"):
+        raise TypeError("log_prob must be a cmcd_amd.model_handler.Target (see load_model)")
+    if not params_flat.is_cuda:
+        raise RuntimeError("the CMCD hot path runs on a ROCm device only: params_flat is not a device tensor")
+    if params_flat.dtype != torch.float32 or not params_flat.is_contiguous():
+        raise ValueError("params_flat must be contiguous float32")
     L = _lib.lib()
     device = params_flat.device
     seeds = torch.as_tensor(seeds)
     if seeds.device != device or seeds.dtype != torch.int32 or not seeds.is_contiguous():
         seeds = seeds.to(device=device, dtype=torch.int32).contiguous()
     n = seeds.numel()
+    if n < 1:
+        raise ValueError("seeds is empty")
     if eps_schedule not in _lib.EPS_SCHEDULE:
         eps_schedule = None
     desc = _lib.Desc(dim=dim, nbridges=nbridges, mode=_lib.MODE[mode], arch=_lib.ARCH[spec.arch],
                      emb_dim=spec.emb_dim, target=log_prob.target_id,
                      eps_schedule=_lib.EPS_SCHEDULE[eps_schedule], grad_clipping=int(bool(grad_clipping)),
-                     ngrid=unflatten.shape("mgridref_y")[0] - 1, reserved=0)
+                     ngrid=unflatten.shape("mgridref_y")[0] - 1, reserved=KERNEL_VARIANT)
     lay = _layout(unflatten, spec)
     nbytes = L.cmcd_grad_workspace_bytes(C.byref(desc), n)
     if nbytes <= 0:
@@ -312,17 +321,27 @@ def compute_log_var_grad(seeds, params_flat, unflatten, params_fixed, log_prob, 
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         _workspaces[key] = ws
     consts = log_prob.consts_on(device)
+    cptr, cnum = (consts.data_ptr(), consts.numel()) if consts is not None else (None, 0)
+    losses = torch.empty(n, dtype=torch.float32, device=device)
+    z = torch.empty(n, dim, dtype=torch.float32, device=device)
+    stats = torch.empty(_lib.NSTATS, dtype=torch.float64, device=device)
     omega = torch.empty(n, dtype=torch.float32, device=device)
     grad = torch.empty_like(params_flat)
-    st = stats if stats_total is None else stats_total
     with torch.cuda.device(device):
         stream = torch.cuda.current_stream().cuda_stream
+        # forward on the gradient workspace: the per-call tables (and, for small batches, the trajectory) stay
+        # there for the gradient call, so the chain runs once
+        _lib.check(L.cmcd_bound_var_forward(
+            C.byref(desc), C.byref(lay), seeds.data_ptr(), n, params_flat.data_ptr(), params_flat.numel(),
+            cptr, cnum, ws.data_ptr(), ws.numel(), losses.data_ptr(), z.data_ptr(), stats.data_ptr(), stream))
+        st = stats if stats_total is None else stats_total
+        if callable(st):   # multi-GPU: the caller merges the local statistics across ranks here
+            st = st(stats)
         _lib.check(L.cmcd_vargrad_weights(losses.data_ptr(), st.data_ptr(), n, n if n_total is None else int(n_total),
                                           omega.data_ptr(), stream))
-        _lib.check(L.cmcd_bound_var_grad(
+        _lib.check(L.cmcd_bound_var_grad_kept(
             C.byref(desc), C.byref(lay), seeds.data_ptr(), n, params_flat.data_ptr(), params_flat.numel(),
-            consts.data_ptr() if consts is not None else None, consts.numel() if consts is not None else 0,
-            omega.data_ptr(), ws.data_ptr(), ws.numel(), grad.data_ptr(), stream))
+            cptr, cnum, omega.data_ptr(), ws.data_ptr(), ws.numel(), grad.data_ptr(), stream))
     # params_notrain = stop_gradient(params_notrain) (mcdboundingmachine.py:142): only the leaves of
     # params_train carry a gradient; they are the leading block of params_flat
     n_train = min((off for path, (off, _) in unflatten.layout.items() if path[0] == 1), default=params_flat.numel())

@@ -149,6 +149,18 @@ int cmcd_vargrad_weights(const float* loss, const double* stats, int64_t n, int6
 int cmcd_bound_var_grad(const cmcd_desc* desc, const cmcd_layout* layout, const int32_t* seeds, int64_t n,
                         const float* params, int64_t n_params, const float* target_consts, int64_t n_target,
                         const float* omega, void* workspace, int64_t workspace_bytes, float* grad, void* stream);
+/* The same two steps without running the chain twice: cmcd_bound_var_forward is cmcd_bound_forward on the
+ * GRADIENT workspace (cmcd_grad_workspace_bytes) and leaves the per-call tables — and, for batches small
+ * enough for the work-item gradient path, the trajectory z_0..z_K — there; cmcd_bound_var_grad_kept then
+ * needs the same desc / seeds / params / workspace, untouched in between (weights from
+ * cmcd_vargrad_weights as before). */
+int cmcd_bound_var_forward(const cmcd_desc* desc, const cmcd_layout* layout, const int32_t* seeds, int64_t n,
+                           const float* params, int64_t n_params, const float* target_consts, int64_t n_target,
+                           void* workspace, int64_t workspace_bytes, float* out_loss, float* out_z,
+                           double* out_stats, void* stream);
+int cmcd_bound_var_grad_kept(const cmcd_desc* desc, const cmcd_layout* layout, const int32_t* seeds, int64_t n,
+                             const float* params, int64_t n_params, const float* target_consts, int64_t n_target,
+                             const float* omega, void* workspace, int64_t workspace_bytes, float* grad, void* stream);
 
 /* ---- Reparameterised gradient of the mean bound: what jax.value_and_grad(compute_bound, 1, has_aux=True)
  * returns for MCD_CAIS_sn (/root/reference/src/main.py:174-176 over mcdboundingmachine.py:183-205 and

@@ -50,8 +50,11 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("item", [0, 1])
 @pytest.mark.parametrize("name,n,over", CASES)
-def test_vargrad_matches_autograd(hip_lib, name, n, over):
+def test_vargrad_matches_autograd(hip_lib, monkeypatch, name, n, over, item):
+    """item = 1: the work-item path (trajectory stored, (tile, evaluation) pairs in parallel); 0: whole chains."""
+    monkeypatch.setenv("CMCD_GRAD_ITEM", str(item))
     b = synthetic.build(name, device="cuda", **over)
     seeds = synthetic.parity_seeds(n)
     grad, (losses, z) = mcdbm.compute_log_var_grad(torch.from_numpy(seeds).cuda(), b["params_flat"], b["unflatten"],
@@ -107,12 +110,14 @@ BPTT_CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant,item", [(1, 0), (2, 0), (1, 1), (2, 1)])
 @pytest.mark.parametrize("name,n,over", BPTT_CASES)
-def test_reparameterised_gradient_matches_autograd(hip_lib, monkeypatch, name, n, over, variant):
+def test_reparameterised_gradient_matches_autograd(hip_lib, monkeypatch, name, n, over, variant, item):
     """compute_bound_grad == jax.grad(compute_bound, 1): values from autograd through the float64 restatement
-    with no detach (oracle/cmcd_oracle_torch.py).  Both forward kernel variants store the trajectory."""
+    with no detach (oracle/cmcd_oracle_torch.py).  Both forward kernel variants store the trajectory; item = 0 is
+    the sequential reverse sweep, item = 1 the Jacobian + scan + work-item path for small batches."""
     monkeypatch.setattr(mcdbm, "KERNEL_VARIANT", variant)
+    monkeypatch.setenv("CMCD_GRAD_ITEM", str(item))
     b = synthetic.build(name, device="cuda", **over)
     assert b["params_fixed"][2] == "MCD_CAIS_sn"
     seeds = synthetic.parity_seeds(n)
@@ -131,8 +136,10 @@ def test_reparameterised_gradient_matches_autograd(hip_lib, monkeypatch, name, n
     _compare(name, over, b["unflatten"], grad.double().cpu(), g_ref)
 
 
-def test_reparameterised_gradient_shards_add_up(hip_lib):
+@pytest.mark.parametrize("item", [0, 1])
+def test_reparameterised_gradient_shards_add_up(hip_lib, monkeypatch, item):
     """Two particle shards with omega = 1 / N_total sum to the single-call gradient (the multi-GPU contract)."""
+    monkeypatch.setenv("CMCD_GRAD_ITEM", str(item))
     b = synthetic.build("many_gmm_n2000_k256_dds", device="cuda", nbridges=12, init_sigma=15.0)
     seeds = torch.from_numpy(synthetic.parity_seeds(200)).cuda()
     args = (b["params_flat"], b["unflatten"], b["params_fixed"], b["target"])
