@@ -184,6 +184,12 @@ def main():
     except Exception:
         pass
 
+    # which trajectory kernel the library's auto-selection ran (cmcd_kernels.hip: cooperative up to 512 tiles,
+    # 256 for nets wider than 128; CMCD_KERNEL_VARIANT pins it)
+    tiles = (n + 15) // 16
+    coop = mcdbm.KERNEL_VARIANT == 2 or (mcdbm.KERNEL_VARIANT == 0 and tiles <= (256 if spec.width >= 128 else 512))
+    kernel_name = "coop_kernel" if coop else "traj_kernel"
+
     result = {
         "metric": "bridge-steps*particles/sec", "value": value, "unit": "bridge-steps*particles/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -194,7 +200,7 @@ def main():
                    "global_particles": n * world, "parallelism": f"particles sharded x{world}, stats all-gather"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch (PMC)",
-                     "kernel": "traj_kernel", "kernel_ms": kern_s * 1e3, "launches": launches,
+                     "kernel": kernel_name, "kernel_ms": kern_s * 1e3, "launches": launches,
                      "flop_per_particle_step": f_alg, "flop_per_particle_step_survey": f_survey,
                      "achieved_survey_flops": n * K * f_survey / kern_s / 1e12,
                      "state_bytes_gbs": n * K * (8 * dim + 8) / kern_s / 1e9},

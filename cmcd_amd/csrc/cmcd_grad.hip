@@ -1251,7 +1251,9 @@ bool bptt_available(const cmcd_desc& d, int T) { return pick_grad(d, T, true) !=
 bool grad_item_mode(const cmcd_desc& d, int T, int64_t n) {
   if (pick_grad(d, T, false, true) == nullptr) return false;
   if (const char* e = getenv("CMCD_GRAD_ITEM")) return atoi(e) != 0;
-  return n <= 8192;
+  // measured crossover on MI355X (tools/probes/grad_item_sweep.py, dds net, K = 256): ~11k particles for the
+  // reparameterised gradient (it pays the Jacobian pass), ~17k for the local one
+  return n <= (d.mode == CMCD_MODE_CAIS_VAR_SN ? 16384 : 10240);
 }
 // extra floats the work-item path of the reparameterised gradient keeps: jac rows + lambda table
 int64_t bptt_item_floats(const cmcd_desc& d, int64_t n) {
