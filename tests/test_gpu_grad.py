@@ -137,6 +137,28 @@ def test_reparameterised_gradient_matches_autograd(hip_lib, monkeypatch, name, n
 
 
 @pytest.mark.parametrize("item", [0, 1])
+@pytest.mark.parametrize("mode", ["MCD_CAIS_sn", "MCD_CAIS_var_sn"])
+@pytest.mark.parametrize("n,K", [(1, 1), (17, 2), (3, 1), (33, 3)])
+def test_gradient_edge_shapes(hip_lib, monkeypatch, mode, n, K, item):
+    """Single particle, single bridge, ragged last tile — both gradients, both kernel paths."""
+    monkeypatch.setenv("CMCD_GRAD_ITEM", str(item))
+    b = synthetic.build("gmm_n300_k8", device="cuda", boundmode=mode, nbridges=K)
+    seeds = synthetic.parity_seeds(n)
+    fn = mcdbm.compute_bound_grad if mode == "MCD_CAIS_sn" else mcdbm.compute_log_var_grad
+    grad, (losses, z) = fn(torch.from_numpy(seeds).cuda(), b["params_flat"], b["unflatten"], b["params_fixed"],
+                           b["target"], eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
+    torch.cuda.synchronize()
+    val, l_ref, g_ref = oracle_grad_flat(b, seeds)
+    np.testing.assert_allclose(losses.cpu().numpy(), l_ref, rtol=2e-3, atol=2e-3)
+    g = grad.double().cpu()
+    if n == 1 and mode == "MCD_CAIS_var_sn":
+        assert float(g.abs().max()) == 0.0 and float(g_ref.abs().max()) < 1e-12   # variance of one particle
+        return
+    scale = float(g_ref.abs().max())
+    assert float((g - g_ref).abs().max()) <= 3e-3 * scale, (float((g - g_ref).abs().max()), scale)
+
+
+@pytest.mark.parametrize("item", [0, 1])
 def test_reparameterised_gradient_shards_add_up(hip_lib, monkeypatch, item):
     """Two particle shards with omega = 1 / N_total sum to the single-call gradient (the multi-GPU contract)."""
     monkeypatch.setenv("CMCD_GRAD_ITEM", str(item))
