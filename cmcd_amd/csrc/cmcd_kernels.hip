@@ -358,6 +358,12 @@ __device__ __forceinline__ float act(float pre) {
 //   dds     (nn_dds.py:159-162): h1 = gelu(W1^T[z; tau] + b1); h2 = gelu(W2^T h1 + b2); clip(W3^T h2 + b3)
 //   geffner (nn.py:45-52,66-70): u = [z; emb]; u += softplus(uW1 + b1); u += softplus(uW2 + b2);
 //                                factor_sn * (uW3 + b3)
+// Diagnostic builds only (-DCMCD_TRAJ_ABL=mask, tools/probes/traj_ablate.py): drop one ingredient of the
+// evaluation to see what a saturating batch spends its time on.  1: layer-2 MFMAs, 2: activations,
+// 4: target gradient, 8: noise generation.  Results are wrong by design; never defined in the product build.
+#ifndef CMCD_TRAJ_ABL
+#define CMCD_TRAJ_ABL 0
+#endif
 template <int ARCH, int D, int T>
 __device__ __forceinline__ void eval_net(const float (&z)[D], const float* __restrict__ brow,
                                          const float* __restrict__ urow, const float* lds_w2,
@@ -377,7 +383,7 @@ __device__ __forceinline__ void eval_net(const float (&z)[D], const float* __res
     }
     if (ARCH == CMCD_ARCH_DDS) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) h[t][r] = gelu_fast(pre[r]);
+      for (int r = 0; r < 4; ++r) h[t][r] = (CMCD_TRAJ_ABL & 2) ? pre[r] : gelu_fast(pre[r]);
     } else {
       f32x4 u = *reinterpret_cast<const f32x4*>(urow + 16 * t + 4 * g);
       if (16 * t < D) {  // the first D neurons of u are z itself
@@ -394,6 +400,7 @@ __device__ __forceinline__ void eval_net(const float (&z)[D], const float* __res
     }
   }
   // layer 2 on the matrix cores: acc[t_out] (rows = neurons 16 t_out + 4 g + r, cols = particles)
+  float dummy = z[0];
   f32x4 acc[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) acc[t] = *reinterpret_cast<const f32x4*>(lds_b2 + 16 * t + 4 * g);
@@ -409,9 +416,19 @@ __device__ __forceinline__ void eval_net(const float (&z)[D], const float* __res
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
-      for (int to = 0; to < T; ++to)
-        acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[to][r], h[ti][r], acc[to], 0, 0, 0);
+      for (int to = 0; to < T; ++to) {
+        if (CMCD_TRAJ_ABL & 1) acc[to][r] += a[to][r] * h[ti][r];
+        else acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[to][r], h[ti][r], acc[to], 0, 0, 0);
+      }
+      if (CMCD_TRAJ_ABL & 16) {   // probe: 24 dependent VALU instructions in the shadow of these T MFMAs
+#pragma unroll
+        for (int q = 0; q < 24; ++q) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(dummy) : "v"(z[0]));
+      }
     }
+  }
+  if (CMCD_TRAJ_ABL & 32) {       // probe: the same 384 instructions after the MFMA loop
+#pragma unroll
+    for (int q = 0; q < 24 * 4 * T; ++q) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(dummy) : "v"(z[0]));
   }
   // layer 3: every lane sums over its 4T neurons, then the 4 lanes of a particle combine
   float part[D];
@@ -422,7 +439,7 @@ __device__ __forceinline__ void eval_net(const float (&z)[D], const float* __res
     f32x4 h2;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      h2[r] = (ARCH == CMCD_ARCH_DDS) ? gelu_fast(acc[t][r]) : h[t][r] + softplus(acc[t][r]);
+      h2[r] = (ARCH == CMCD_ARCH_DDS) ? ((CMCD_TRAJ_ABL & 2) ? acc[t][r] : gelu_fast(acc[t][r])) : h[t][r] + softplus(acc[t][r]);
 #pragma unroll
     for (int j = 0; j < D; ++j) {
       const f32x4 wv = *reinterpret_cast<const f32x4*>(lds_w3t + j * HP + 16 * t + 4 * g);
@@ -435,6 +452,7 @@ __device__ __forceinline__ void eval_net(const float (&z)[D], const float* __res
     const float o = group_sum(part[j]) + lds_b3[j];
     s[j] = (ARCH == CMCD_ARCH_DDS) ? fminf(fmaxf(o, -1e4f), 1e4f) : o * factor;
   }
+  if (CMCD_TRAJ_ABL & 48) s[0] += dummy * 1e-30f;
 }
 
 template <int TARGET, int ARCH, int D, int T>
@@ -553,7 +571,13 @@ __global__ __launch_bounds__(512, (T > 4 || D > 4) ? 2 : 4) void traj_kernel(Tra
 
   for (int i = 0; i <= K; ++i) {
     float gp[D], sn[D];
-    Target<TARGET, D>::eval(z, g, lds_tgt, logp, gp);
+    if (CMCD_TRAJ_ABL & 4) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) gp[j] = -z[j];
+      logp = z[0];
+    } else {
+      Target<TARGET, D>::eval(z, g, lds_tgt, logp, gp);
+    }
     if (a.ula == 1) {
 #pragma unroll
       for (int j = 0; j < D; ++j) sn[j] = 0.f;
@@ -606,11 +630,11 @@ __global__ __launch_bounds__(512, (T > 4 || D > 4) ? 2 : 4) void traj_kernel(Tra
       const int jn = b - 2;               // normal block index
       uint32_t y0 = is_split ? b : jn;
       uint32_t y1 = is_split ? 2 + b : ((Hh + jn < D) ? Hh + jn : 0);
-      threefry2x32(is_split ? h0 : g0, is_split ? h1 : g1, y0, y1);
+      if (!(CMCD_TRAJ_ABL & 8)) threefry2x32(is_split ? h0 : g0, is_split ? h1 : g1, y0, y1);
       if (b0 == 0) rows01(y1, k0, k1);
       uint32_t r0[4], r1[4];
-      rows0123(__float_as_uint(bits_to_normal(y0)), r0);
-      rows0123(__float_as_uint(bits_to_normal(y1)), r1);
+      rows0123(__float_as_uint((CMCD_TRAJ_ABL & 8) ? __uint_as_float(y0) * 1e-9f : bits_to_normal(y0)), r0);
+      rows0123(__float_as_uint((CMCD_TRAJ_ABL & 8) ? __uint_as_float(y1) * 1e-9f : bits_to_normal(y1)), r1);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int jj = b0 + q - 2;
