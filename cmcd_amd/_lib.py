@@ -29,6 +29,12 @@ class Layout(C.Structure):
     _fields_ = [(k, C.c_int64) for k in LAYOUT_FIELDS]
 
 
+class ProjectRange(C.Structure):
+    """cmcd_project_range of include/cmcd_hip.h."""
+    _fields_ = [("offset", C.c_int64), ("length", C.c_int64), ("kind", C.c_int32), ("reserved", C.c_int32),
+                ("lo", C.c_float), ("hi", C.c_float)]
+
+
 _lib = None
 
 
@@ -78,6 +84,10 @@ def lib():
         L.cmcd_mfvi_bound_grad.argtypes = [C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
                                            C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_float, C.c_void_p,
                                            C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cmcd_adam_step.restype = C.c_int
+        L.cmcd_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                     C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, C.c_float,
+                                     C.POINTER(ProjectRange), C.c_int32, C.c_void_p]
         L.cmcd_stats_merge_device.restype = C.c_int
         L.cmcd_stats_merge_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.cmcd_profile_enable.restype = C.c_int

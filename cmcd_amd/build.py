@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcmcd_hip.so")
-SOURCES = ["cmcd_kernels.hip", "cmcd_coop.hip", "cmcd_lgcp.hip", "cmcd_grad.hip", "cmcd_mfvi.hip"]
+SOURCES = ["cmcd_kernels.hip", "cmcd_coop.hip", "cmcd_lgcp.hip", "cmcd_grad.hip", "cmcd_mfvi.hip", "cmcd_opt.hip"]
 HEADERS = ["cmcd_device.h", os.path.join(ROOT, "include", "cmcd_hip.h")]
 
 

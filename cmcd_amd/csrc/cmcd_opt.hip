@@ -1,0 +1,69 @@
+// Fused optimiser step of the reference's training loop (/root/reference/src/opt.py:14-35,100-116):
+//   optax.chain(optax.clip(5.0), optax.adam(lr, b1, b2, eps))  ->  params += updates  ->  project(params)
+//   [-> ema = optax.incremental_update(params, ema, 0.001)]
+// as ONE elementwise launch over params_flat instead of ~15 framework kernels.  Adam as in optax: moments of
+// the clipped gradient, bias correction by 1 - b^t, eps outside the square root.  The projection ranges
+// (eps in [1e-7, 0.5], eta in [0, 0.99], gamma >= 1e-3, mgridref_y -> relu(x - 1e-3) + 1e-3) are passed as up
+// to 8 (offset, length, kind, lo, hi) records in the launch arguments.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "cmcd_common.h"
+#include "cmcd_hip.h"
+
+namespace cmcd {
+
+struct OptArgs {
+  float* params;
+  const float* grad;
+  float* mu;
+  float* nu;
+  float* ema;          // nullable
+  int64_t n;
+  float lr, b1, b2, eps, clip, c1, c2, ema_step;   // c1 = 1 / (1 - b1^t), c2 = 1 / (1 - b2^t)
+  int32_t n_ranges;
+  cmcd_project_range ranges[8];
+};
+
+__global__ void adam_step_kernel(OptArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const float g = fminf(fmaxf(a.grad[i], -a.clip), a.clip);
+  const float m = a.b1 * a.mu[i] + (1.0f - a.b1) * g;
+  const float v = a.b2 * a.nu[i] + (1.0f - a.b2) * g * g;
+  a.mu[i] = m;
+  a.nu[i] = v;
+  float p = a.params[i] - a.lr * (m * a.c1) / (sqrtf(v * a.c2) + a.eps);
+  for (int r = 0; r < a.n_ranges; ++r) {
+    const cmcd_project_range q = a.ranges[r];
+    if (i >= q.offset && i < q.offset + q.length)
+      p = q.kind == CMCD_PROJECT_CLAMP ? fminf(fmaxf(p, q.lo), q.hi) : fmaxf(p - q.lo, 0.0f) + q.lo;
+  }
+  a.params[i] = p;
+  if (a.ema) a.ema[i] = (1.0f - a.ema_step) * a.ema[i] + a.ema_step * p;
+}
+
+}  // namespace cmcd
+
+using namespace cmcd;
+
+extern "C" int cmcd_adam_step(float* params, const float* grad, float* mu, float* nu, float* ema, int64_t n,
+                              float lr, float b1, float b2, float eps, float clip, int64_t step, float ema_step,
+                              const cmcd_project_range* ranges, int32_t n_ranges, void* stream) {
+  if (!params || !grad || !mu || !nu || n < 1 || step < 1) return fail_msg(CMCD_ERR_BAD_ARG, "bad argument");
+  if (n_ranges < 0 || n_ranges > 8 || (n_ranges > 0 && !ranges)) return fail_msg(CMCD_ERR_BAD_ARG, "at most 8 projection ranges");
+  OptArgs a{};
+  a.params = params; a.grad = grad; a.mu = mu; a.nu = nu; a.ema = ema; a.n = n;
+  a.lr = lr; a.b1 = b1; a.b2 = b2; a.eps = eps; a.clip = clip; a.ema_step = ema_step;
+  a.c1 = (float)(1.0 / (1.0 - pow((double)b1, (double)step)));
+  a.c2 = (float)(1.0 / (1.0 - pow((double)b2, (double)step)));
+  a.n_ranges = n_ranges;
+  for (int r = 0; r < n_ranges; ++r) {
+    if (ranges[r].offset < 0 || ranges[r].length < 0 || ranges[r].offset + ranges[r].length > n)
+      return fail_msg(CMCD_ERR_BAD_ARG, "projection range outside params_flat");
+    a.ranges[r] = ranges[r];
+  }
+  hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return hipGetLastError() == hipSuccess ? CMCD_OK : fail_msg(CMCD_ERR_HIP, "launch failed");
+}

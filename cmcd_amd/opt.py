@@ -45,9 +45,50 @@ class _ClipAdam:
         return -self.lr * mu_hat / (nu_hat.sqrt() + self.eps), state
 
 
+def _project_ranges(unflatten, trainable):
+    """The reference's `project` (opt.py:14-24) as (offset, length, kind, lo, hi) records of params_flat."""
+    from . import _lib
+    out = []
+
+    def add(name, kind, lo, hi):
+        if name in trainable and (0, name) in unflatten.layout:
+            off, shape = unflatten.layout[(0, name)]
+            n = 1
+            for d in shape:
+                n *= d
+            out.append(_lib.ProjectRange(off, max(n, 1), kind, 0, lo, hi))
+    add("eps", 0, 0.0000001, 0.5)
+    add("eta", 0, 0.0, 0.99)
+    add("gamma", 0, 0.001, float("inf"))
+    add("mgridref_y", 1, 0.001, 0.0)
+    return out
+
+
+class _FusedClipAdam(_ClipAdam):
+    """The same optimiser, with clip -> Adam -> apply -> project (-> EMA) as ONE launch of the library's
+    `cmcd_adam_step` on device tensors (the reference gets this fusion from jit; eager torch would issue ~15
+    small kernels per iteration, which at 1 ms per training step is a third of the loop)."""
+
+    def step(self, params, grad, state, unflatten, trainable, ema=None, ema_step=0.001):
+        import ctypes as C
+        from . import _lib
+        L = _lib.lib()
+        state["count"] += 1
+        ranges = state.get("ranges")
+        if ranges is None:
+            rl = _project_ranges(unflatten, trainable)
+            ranges = state["ranges"] = (_lib.ProjectRange * max(len(rl), 1))(*rl), len(rl)
+        arr, cnt = ranges
+        with torch.cuda.device(params.device):
+            _lib.check(L.cmcd_adam_step(
+                params.data_ptr(), grad.data_ptr(), state["mu"].data_ptr(), state["nu"].data_ptr(),
+                ema.data_ptr() if ema is not None else None, params.numel(), self.lr, self.b1, self.b2, self.eps,
+                5.0, state["count"], ema_step, arr, cnt, torch.cuda.current_stream().cuda_stream))
+
+
 def create_optimizer(step_size, b1=0.9, b2=0.999, eps=1e-8, trainable=None):
     """/root/reference/src/opt.py:27-35"""
-    return _ClipAdam(step_size, b1, b2, eps)
+    return _FusedClipAdam(step_size, b1, b2, eps)
 
 
 def run(info, lr, iters, params_flat, unflatten, params_fixed, log_prob_model, grad_and_loss, trainable, rng_key_gen,
@@ -66,8 +107,15 @@ def run(info, lr, iters, params_flat, unflatten, params_fixed, log_prob_model, g
     losses = []
     n = info.N if hasattr(info, "N") else info["N"]
     every = max(iters // 1000, 1)
+    fused = params_flat.is_cuda and params_flat.dtype == torch.float32 and params_flat.is_contiguous()
+    # seeds for a block of iterations are drawn at once (same generator stream as one draw per iteration) and
+    # shipped to the device in one copy
+    block = max(1, min(iters, (1 << 22) // max(n, 1)))
     for i in range(iters):
-        seeds = torch.randint(1, 1000000, (n,), generator=gen, dtype=torch.int32).to(params_flat.device)
+        if i % block == 0:
+            nb = min(block, iters - i)
+            seed_block = torch.randint(1, 1000000, (nb * n,), generator=gen, dtype=torch.int32).to(params_flat.device)
+        seeds = seed_block[(i % block) * n:(i % block + 1) * n]
         grad, (loss, z) = grad_and_loss(seeds, params_flat, unflatten, params_fixed, log_prob_model)
         if i % every == 0:
             mean_loss = float(loss.mean())                   # the only host sync, every 0.1 % of the steps
@@ -75,9 +123,12 @@ def run(info, lr, iters, params_flat, unflatten, params_fixed, log_prob_model, g
                 print("Diverged")
                 return losses, params_flat, ema_params
             losses.append(mean_loss)
-        updates, opt_state = optimizer.update(grad, opt_state, params_flat)
-        params_flat.add_(updates)
-        project(params_flat, unflatten, trainable)
-        if use_ema:
-            ema_params.mul_(1 - 0.001).add_(params_flat, alpha=0.001)   # optax.incremental_update(step_size=0.001)
+        if fused:
+            optimizer.step(params_flat, grad, opt_state, unflatten, trainable, ema=ema_params if use_ema else None)
+        else:
+            updates, opt_state = optimizer.update(grad, opt_state, params_flat)
+            params_flat.add_(updates)
+            project(params_flat, unflatten, trainable)
+            if use_ema:
+                ema_params.mul_(1 - 0.001).add_(params_flat, alpha=0.001)   # optax.incremental_update(step_size=0.001)
     return losses, params_flat, ema_params

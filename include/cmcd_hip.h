@@ -192,6 +192,22 @@ int cmcd_mfvi_bound_grad(int32_t target, int32_t dim, int64_t off_vd_mean, int64
                          void* workspace, int64_t workspace_bytes,
                          float* out_loss, float* out_z, double* out_stats, float* grad, void* stream);
 
+/* ---- Optimiser step of the training loop (/root/reference/src/opt.py:14-35,100-116) fused into one launch:
+ * g = clip(grad, +-clip); Adam moments (optax.adam: bias correction 1 - b^step, eps outside the root);
+ * params += -lr * m_hat / (sqrt(v_hat) + eps); projection of the listed ranges (opt.py:14-24);
+ * optional ema = (1 - ema_step) ema + ema_step params (optax.incremental_update, opt.py:114-116).
+ * step is the 1-based iteration count.  All pointers device, length n; ema may be NULL. */
+enum { CMCD_PROJECT_CLAMP = 0,      /* x -> min(max(x, lo), hi) */
+       CMCD_PROJECT_RELU_FLOOR = 1  /* x -> relu(x - lo) + lo   (mgridref_y, opt.py:22-23) */ };
+typedef struct cmcd_project_range {
+  int64_t offset, length;
+  int32_t kind, reserved;
+  float lo, hi;
+} cmcd_project_range;
+int cmcd_adam_step(float* params, const float* grad, float* mu, float* nu, float* ema, int64_t n,
+                   float lr, float b1, float b2, float eps, float clip, int64_t step, float ema_step,
+                   const cmcd_project_range* ranges, int32_t n_ranges, void* stream);
+
 /* Device-side merge of `count` statistics vectors rows[count][5] (e.g. the result of an RCCL
  * all-gather of every rank's out_stats, in rank order) into out5[5], fixed order, one small kernel
  * on `stream`.  [device] pointers. */

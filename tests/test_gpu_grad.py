@@ -234,3 +234,30 @@ def test_training_with_vargrad_reduces_the_loss(hip_lib):
     assert torch.equal(notrain0["eps"], notrain1["eps"]) and torch.equal(notrain0["vd"]["mean"], notrain1["vd"]["mean"])
     train1, _ = unflatten(flat2)
     assert float(train1["sn"]["factor_sn"]) != 0.0 and float(train1["mgridref_y"].min()) >= 0.001
+
+
+def test_fused_optimiser_step_equals_the_eager_one(hip_lib):
+    """cmcd_adam_step (clip -> Adam -> apply -> project -> EMA in one launch) == the eager torch arithmetic of
+    opt._ClipAdam + opt.project (reference opt.py:14-35,100-116), step by step."""
+    from cmcd_amd import opt
+    flat, unflatten, _ = mcdbm.initialize(dim=2, nbridges=8, eps=0.4, eta=0.9, gamma=0.002,
+                                          trainable=("eps", "eta", "gamma", "mgridref_y"), mode="MCD_CAIS_sn",
+                                          nn_arch="geffner", emb_dim=4, device="cuda")
+    trainable = ("eps", "eta", "gamma", "mgridref_y")
+    g = torch.Generator().manual_seed(0)
+    pa, pb = flat.clone(), flat.clone()
+    ema_a, ema_b = flat.clone(), flat.clone()
+    fused, eager = opt.create_optimizer(0.05), opt._ClipAdam(0.05)
+    sa, sb = fused.init(pa), eager.init(pb)
+    for it in range(5):
+        grad = (torch.randn(flat.numel(), generator=g) * 8.0).cuda()      # some entries beyond the +-5 clip
+        fused.step(pa, grad, sa, unflatten, trainable, ema=ema_a)
+        upd, sb = eager.update(grad, sb, pb)
+        pb.add_(upd)
+        opt.project(pb, unflatten, trainable)
+        ema_b.mul_(1 - 0.001).add_(pb, alpha=0.001)
+        assert float((pa - pb).abs().max()) <= 1e-6 * max(1.0, float(pb.abs().max())), it
+        assert float((ema_a - ema_b).abs().max()) <= 1e-6 * max(1.0, float(ema_b.abs().max()))
+    train, _ = unflatten(pa)
+    assert 1e-7 <= float(train["eps"]) <= 0.5 and 0 <= float(train["eta"]) <= 0.99 and float(train["gamma"]) >= 0.001
+    assert float(train["mgridref_y"].min()) >= 0.001
