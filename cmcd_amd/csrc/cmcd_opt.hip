@@ -22,6 +22,7 @@ struct OptArgs {
   float* ema;          // nullable
   int64_t n;
   float lr, b1, b2, eps, clip, c1, c2, ema_step;   // c1 = 1 / (1 - b1^t), c2 = 1 / (1 - b2^t)
+  const int64_t* step_dev;                          // non-null: t = *step_dev + 1 (graph replay: the count lives on the device)
   int32_t n_ranges;
   cmcd_project_range ranges[8];
 };
@@ -34,7 +35,13 @@ __global__ void adam_step_kernel(OptArgs a) {
   const float v = a.b2 * a.nu[i] + (1.0f - a.b2) * g * g;
   a.mu[i] = m;
   a.nu[i] = v;
-  float p = a.params[i] - a.lr * (m * a.c1) / (sqrtf(v * a.c2) + a.eps);
+  float c1 = a.c1, c2 = a.c2;
+  if (a.step_dev) {
+    const double t = (double)(*a.step_dev + 1);
+    c1 = (float)(1.0 / (1.0 - pow((double)a.b1, t)));
+    c2 = (float)(1.0 / (1.0 - pow((double)a.b2, t)));
+  }
+  float p = a.params[i] - a.lr * (m * c1) / (sqrtf(v * c2) + a.eps);
   for (int r = 0; r < a.n_ranges; ++r) {
     const cmcd_project_range q = a.ranges[r];
     if (i >= q.offset && i < q.offset + q.length)
@@ -44,26 +51,48 @@ __global__ void adam_step_kernel(OptArgs a) {
   if (a.ema) a.ema[i] = (1.0f - a.ema_step) * a.ema[i] + a.ema_step * p;
 }
 
+__global__ void step_counter_kernel(int64_t* counter) { *counter += 1; }
+
 }  // namespace cmcd
 
 using namespace cmcd;
+
+static int adam_launch(OptArgs& a, int64_t step, const cmcd_project_range* ranges, int32_t n_ranges, void* stream) {
+  if (n_ranges < 0 || n_ranges > 8 || (n_ranges > 0 && !ranges)) return fail_msg(CMCD_ERR_BAD_ARG, "at most 8 projection ranges");
+  a.c1 = (float)(1.0 / (1.0 - pow((double)a.b1, (double)step)));
+  a.c2 = (float)(1.0 / (1.0 - pow((double)a.b2, (double)step)));
+  a.n_ranges = n_ranges;
+  for (int r = 0; r < n_ranges; ++r) {
+    if (ranges[r].offset < 0 || ranges[r].length < 0 || ranges[r].offset + ranges[r].length > a.n)
+      return fail_msg(CMCD_ERR_BAD_ARG, "projection range outside params_flat");
+    a.ranges[r] = ranges[r];
+  }
+  hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return hipGetLastError() == hipSuccess ? CMCD_OK : fail_msg(CMCD_ERR_HIP, "launch failed");
+}
+
+// The same step with the iteration count kept on the device (*step_counter = completed steps; incremented by a
+// one-thread launch after the update), so that the whole training iteration can be captured in a hipGraph and
+// replayed: no launch argument changes between iterations.
+extern "C" int cmcd_adam_step_dev(float* params, const float* grad, float* mu, float* nu, float* ema, int64_t n,
+                                  float lr, float b1, float b2, float eps, float clip, int64_t* step_counter,
+                                  float ema_step, const cmcd_project_range* ranges, int32_t n_ranges, void* stream) {
+  if (!params || !grad || !mu || !nu || !step_counter || n < 1) return fail_msg(CMCD_ERR_BAD_ARG, "bad argument");
+  OptArgs a{};
+  a.params = params; a.grad = grad; a.mu = mu; a.nu = nu; a.ema = ema; a.n = n;
+  a.lr = lr; a.b1 = b1; a.b2 = b2; a.eps = eps; a.clip = clip; a.ema_step = ema_step; a.step_dev = step_counter;
+  int rc = adam_launch(a, 1, ranges, n_ranges, stream);
+  if (rc != CMCD_OK) return rc;
+  hipLaunchKernelGGL(step_counter_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), step_counter);
+  return hipGetLastError() == hipSuccess ? CMCD_OK : fail_msg(CMCD_ERR_HIP, "launch failed");
+}
 
 extern "C" int cmcd_adam_step(float* params, const float* grad, float* mu, float* nu, float* ema, int64_t n,
                               float lr, float b1, float b2, float eps, float clip, int64_t step, float ema_step,
                               const cmcd_project_range* ranges, int32_t n_ranges, void* stream) {
   if (!params || !grad || !mu || !nu || n < 1 || step < 1) return fail_msg(CMCD_ERR_BAD_ARG, "bad argument");
-  if (n_ranges < 0 || n_ranges > 8 || (n_ranges > 0 && !ranges)) return fail_msg(CMCD_ERR_BAD_ARG, "at most 8 projection ranges");
   OptArgs a{};
   a.params = params; a.grad = grad; a.mu = mu; a.nu = nu; a.ema = ema; a.n = n;
-  a.lr = lr; a.b1 = b1; a.b2 = b2; a.eps = eps; a.clip = clip; a.ema_step = ema_step;
-  a.c1 = (float)(1.0 / (1.0 - pow((double)b1, (double)step)));
-  a.c2 = (float)(1.0 / (1.0 - pow((double)b2, (double)step)));
-  a.n_ranges = n_ranges;
-  for (int r = 0; r < n_ranges; ++r) {
-    if (ranges[r].offset < 0 || ranges[r].length < 0 || ranges[r].offset + ranges[r].length > n)
-      return fail_msg(CMCD_ERR_BAD_ARG, "projection range outside params_flat");
-    a.ranges[r] = ranges[r];
-  }
-  hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
-  return hipGetLastError() == hipSuccess ? CMCD_OK : fail_msg(CMCD_ERR_HIP, "launch failed");
+  a.lr = lr; a.b1 = b1; a.b2 = b2; a.eps = eps; a.clip = clip; a.ema_step = ema_step; a.step_dev = nullptr;
+  return adam_launch(a, step, ranges, n_ranges, stream);
 }

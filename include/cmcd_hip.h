@@ -207,6 +207,12 @@ typedef struct cmcd_project_range {
 int cmcd_adam_step(float* params, const float* grad, float* mu, float* nu, float* ema, int64_t n,
                    float lr, float b1, float b2, float eps, float clip, int64_t step, float ema_step,
                    const cmcd_project_range* ranges, int32_t n_ranges, void* stream);
+/* The same step with the iteration count on the device (*step_counter = completed steps, int64, incremented by the
+ * call): every launch argument is then constant across iterations, so a whole training iteration (gradient call
+ * + this) can be captured once in a hipGraph and replayed (cmcd_amd.opt.run does, for launch-bound configs). */
+int cmcd_adam_step_dev(float* params, const float* grad, float* mu, float* nu, float* ema, int64_t n,
+                       float lr, float b1, float b2, float eps, float clip, int64_t* step_counter, float ema_step,
+                       const cmcd_project_range* ranges, int32_t n_ranges, void* stream);
 
 /* Device-side merge of `count` statistics vectors rows[count][5] (e.g. the result of an RCCL
  * all-gather of every rank's out_stats, in rank order) into out5[5], fixed order, one small kernel

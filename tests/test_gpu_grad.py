@@ -261,3 +261,25 @@ def test_fused_optimiser_step_equals_the_eager_one(hip_lib):
     train, _ = unflatten(pa)
     assert 1e-7 <= float(train["eps"]) <= 0.5 and 0 <= float(train["eta"]) <= 0.99 and float(train["gamma"]) >= 0.001
     assert float(train["mgridref_y"].min()) >= 0.001
+
+
+@pytest.mark.parametrize("mode", ["MCD_CAIS_sn", "MCD_CAIS_var_sn"])
+def test_graph_replayed_training_equals_eager_training(hip_lib, mode):
+    """opt.run with the iteration captured in a HIP graph (static seed buffer, device-side Adam step count) ends
+    where the eager loop ends, from the same seeds."""
+    import types
+    from cmcd_amd import opt
+    b = synthetic.build("gmm_n300_k8", device="cuda", boundmode=mode)
+    dim, K, _, spec = b["params_fixed"]
+    flat, unflatten, fixed = mcdbm.initialize(dim=dim, nbridges=K, eps=0.01, trainable=("eps", "vd", "mgridref_y"),
+                                              mode=mode, emb_dim=20, nn_arch="geffner", device="cuda")
+    gl, _ = mcdbm.make_grad_and_loss(mode, eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
+    out = {}
+    for use_graph in (False, True):
+        losses, p, ema = opt.run(types.SimpleNamespace(N=300), 1e-3, 60, flat, unflatten, fixed, b["target"], gl,
+                                 ("eps", "vd", "mgridref_y"), 7, use_ema=True, use_graph=use_graph)
+        out[use_graph] = (np.array(losses), p.double().cpu(), ema.double().cpu())
+    assert float((out[True][1] - out[False][1]).abs().max()) <= 2e-5 * max(1.0, float(out[False][1].abs().max()))
+    assert float((out[True][2] - out[False][2]).abs().max()) <= 2e-5 * max(1.0, float(out[False][2].abs().max()))
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=1e-4, atol=1e-4)
+    assert float((out[True][1] - flat.double().cpu()).abs().max()) > 1e-3      # and it did train
