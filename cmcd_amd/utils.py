@@ -44,3 +44,57 @@ def sample(info, n_samples, n_input_dist_seeds, params_flat, unflatten, params_f
     _, (loss_list, z) = loss_fn(eval_seeds, params_flat, unflatten, params_fixed, log_prob_model)
     elbos = loss_list.view(n_input_dist_seeds, n_samples)
     return elbos, z
+
+
+def params_to_numpy(params_flat, unflatten):
+    """`params = {**params_train, **params_notrain}` (/root/reference/src/main.py:283-284) as nested dicts / lists
+    of NumPy arrays — the structure the reference pickles as `params.pkl` (:286-296), minus the jax array type."""
+    import numpy as np
+
+    def conv(t):
+        if isinstance(t, dict):
+            return {k: conv(v) for k, v in t.items()}
+        if isinstance(t, (list, tuple)):
+            return type(t)(conv(v) for v in t)
+        return np.asarray(t.detach().cpu().numpy())
+    train, notrain = unflatten(params_flat.detach().cpu())
+    return conv({**train, **notrain})
+
+
+def save_params(path, params_flat, unflatten):
+    """Writes `params.pkl` like the reference's W&B artifact (main.py:286-296): one pickle of the merged dict."""
+    import pickle
+    with open(path, "wb") as f:
+        pickle.dump(params_to_numpy(params_flat, unflatten), f)
+
+
+def load_params(path_or_dict, params_flat, unflatten):
+    """Inverse of `save_params`: copies every leaf of a merged `params` dict (a pickle path, or the dict itself,
+    e.g. a reference run's `jax.tree_util.tree_map(np.asarray, params)`) into a copy of `params_flat` at the
+    offsets of `unflatten`.  Leaves are matched by name and must have the reference's shapes."""
+    import pickle
+    import numpy as np
+    params = path_or_dict
+    if not isinstance(params, dict):
+        with open(path_or_dict, "rb") as f:
+            params = pickle.load(f)
+    out = params_flat.detach().clone()
+
+    def walk(node, prefix):
+        if isinstance(node, dict):
+            for k, v in node.items():
+                walk(v, prefix + (k,))
+        elif isinstance(node, (list, tuple)):
+            for i, v in enumerate(node):
+                walk(v, prefix + (i,))
+        else:
+            arr = np.asarray(node, np.float32)
+            hit = [(path, off, shape) for path, (off, shape) in unflatten.layout.items() if path[1:] == prefix]
+            if not hit:
+                raise KeyError(f"leaf {prefix} is not part of this parameter tree")
+            _, off, shape = hit[0]
+            if tuple(arr.shape) != tuple(shape):
+                raise ValueError(f"leaf {prefix}: shape {arr.shape} != {tuple(shape)}")
+            out[off:off + max(arr.size, 1)] = torch.from_numpy(arr.reshape(-1)).to(out.device)
+    walk(params, ())
+    return out

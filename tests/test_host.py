@@ -88,3 +88,23 @@ def test_synthetic_configs_resolve():
         b = synthetic.build(name, device="cpu")
         p = synthetic.oracle_params(b["unflatten"], b["params_flat"])
         assert p["sn"] and b["params_fixed"][1] == cfg["nbridges"]
+
+
+def test_params_pickle_round_trip(tmp_path):
+    """utils.save_params / load_params: the merged `params` dict the reference pickles (main.py:283-296)."""
+    import pickle
+    from cmcd_amd import utils
+    for arch in ("dds", "geffner"):
+        flat, unflatten, _ = mcdbm.initialize(dim=2, nbridges=6, eps=0.3, trainable=("eps", "vd"), mode="MCD_CAIS_sn",
+                                              nn_arch=arch, emb_dim=12, device="cpu")
+        flat = flat + torch.arange(flat.numel(), dtype=torch.float32) * 1e-3      # make every leaf distinct
+        path = tmp_path / f"params_{arch}.pkl"
+        utils.save_params(path, flat, unflatten)
+        d = pickle.load(open(path, "rb"))
+        assert {"vd", "eps", "sn", "mgridref_y", "gridref_x", "target_x"} <= set(d)
+        assert d["vd"]["mean"].shape == (2,) and isinstance(d["eps"], np.ndarray)
+        back = utils.load_params(path, torch.zeros_like(flat), unflatten)
+        assert torch.equal(back, flat)
+        d["vd"]["mean"] = np.zeros(3)
+        with pytest.raises(ValueError):
+            utils.load_params(d, flat, unflatten)
