@@ -1219,7 +1219,7 @@ static grad_fn pick_grad_t(const cmcd_desc& d, int T) {
   if (d.arch == CMCD_ARCH_GEFFNER) {
     if (d.target == CMCD_TARGET_GMM && d.dim == 2 && T == 2) return grad_kernel<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER, 2, 2, 4, false, BPTT, ITEM>;
     if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 2) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 2, 4, false, BPTT, ITEM>;
-    if (!BPTT && !ITEM && d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 9) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 9, 3, true, false, false>;
+    if (!BPTT && d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 9) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 9, 3, true, false, ITEM>;
     if (d.target == CMCD_TARGET_FUNNEL && d.dim == 10 && T == 4) return grad_kernel<CMCD_TARGET_FUNNEL, CMCD_ARCH_GEFFNER, 10, 4, 4, false, BPTT, ITEM>;
   }
   return nullptr;
@@ -1253,6 +1253,9 @@ bool grad_item_mode(const cmcd_desc& d, int T, int64_t n) {
   if (const char* e = getenv("CMCD_GRAD_ITEM")) return atoi(e) != 0;
   // measured crossover on MI355X (tools/probes/grad_item_sweep.py, dds net, K = 256): ~11k particles for the
   // reparameterised gradient (it pays the Jacobian pass), ~17k for the local one
+  // the 132-wide net (3-wave workgroups, fragments from L2) is faster item-wise at every size measured (N = 2000:
+  // 14.5 -> 5.2 ms, N = 16000: 39.3 -> 33.6 ms)
+  if (T > 4) return n <= 65536;
   return n <= (d.mode == CMCD_MODE_CAIS_VAR_SN ? 16384 : 10240);
 }
 // extra floats the work-item path of the reparameterised gradient keeps: jac rows + lambda table

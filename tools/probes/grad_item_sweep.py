@@ -25,3 +25,14 @@ for mode, fn in (("MCD_CAIS_sn", mcdbm.compute_bound_grad), ("MCD_CAIS_var_sn", 
             os.environ["CMCD_GRAD_ITEM"] = item
             t[item] = timeit(lambda: fn(*args, **kw))
         print("%-16s n=%6d  chain %.3f ms   item %.3f ms" % (mode, n, t["0"], t["1"]))
+
+b = synthetic.build("many_gmm_var_n16000_k256", device="cuda")
+kw = dict(eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
+for n in (2000, 4000, 16000):
+    seeds = torch.from_numpy(synthetic.throughput_seeds(n)).cuda()
+    args = (seeds, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"])
+    t = {}
+    for item in ("0", "1"):
+        os.environ["CMCD_GRAD_ITEM"] = item
+        t[item] = timeit(lambda: mcdbm.compute_log_var_grad(*args, **kw), reps=2)
+    print("config 4 (132-wide, VarGrad) n=%6d  chain %.3f ms   item %.3f ms" % (n, t["0"], t["1"]))
