@@ -237,6 +237,9 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
     const int n_it = ITEM ? 1 : K + 1;
     for (int it = 0; it < n_it; ++it) {
       const int e = ITEM ? e_item : (BPTT ? K - it : it);
+      // LDS contents are loop-invariant, so LICM would hoist every w1z / w3t / b2 read out of the work loop into
+      // ~180 registers (132-wide net) and spill them to scratch: a compiler-level fence keeps them in LDS
+      asm volatile("" ::: "memory");
       if (BPTT || ITEM) {
 #pragma unroll
         for (int j = 0; j < D; ++j) {
@@ -252,13 +255,16 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
       }
       // ---------------------------------------------------------------- forward (keeps pre-activations)
       const float* brow = bias1 + (int64_t)e * HP;
-      f32x4 a1[T], u1[T], a2[T];
+      // wide nets (T > 4): the first pre-activation is not kept, it is rebuilt from the bias row and z where the
+      // backward pass needs it (2 D FMAs per value against 4 T registers held across both MFMA phases)
+      constexpr bool KEEP_A1 = T <= 4;
+      f32x4 a1[KEEP_A1 ? T : 1], u1[T], a2[T];
 #pragma unroll
       for (int t = 0; t < T; ++t) {
         f32x4 pre = *reinterpret_cast<const f32x4*>(brow + 16 * t + 4 * g);
 #pragma unroll
         for (int j = 0; j < D; ++j) pre += z[j] * *reinterpret_cast<const f32x4*>(lds_w1z + j * HP + 16 * t + 4 * g);
-        a1[t] = pre;
+        if (KEEP_A1) a1[KEEP_A1 ? t : 0] = pre;
         if (!GEF) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) u1[t][r] = gelu_fast(pre[r]);
@@ -285,9 +291,13 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
 #pragma unroll
       for (int ti = 0; ti < T; ++ti) {
         asm volatile("" ::: "memory");
+        // fragments streamed from L2: keep the address arithmetic inside the loop (an opaque lane offset), or the
+        // T*T loop-invariant 64-bit addresses are hoisted into registers and spilled (324 dwords for T = 9)
+        int lofs = lane * 4;
+        if (WGLOBAL) asm volatile("" : "+v"(lofs));
 #pragma unroll
         for (int to = 0; to < T; ++to) {
-          const f32x4 af = *reinterpret_cast<const f32x4*>(w2f + ((ti * T + to) * 64 + lane) * 4);
+          const f32x4 af = *reinterpret_cast<const f32x4*>(w2f + (ti * T + to) * 256 + lofs);
 #pragma unroll
           for (int r = 0; r < 4; ++r) a2[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r], u1[ti][r], a2[to], 0, 0, 0);
         }
@@ -500,6 +510,7 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
       }
 
       // ---------------------------------------------------------------- MLP backward
+      asm volatile("" ::: "memory");
       float dob[D];  // d (sum omega w) / d o_j  (pre-clip / pre-factor output)
 #pragma unroll
       for (int j = 0; j < D; ++j) {
@@ -531,9 +542,11 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
 #pragma unroll
       for (int tn = 0; tn < T; ++tn) {
         asm volatile("" ::: "memory");
+        int lofs = lane * 4;
+        if (WGLOBAL) asm volatile("" : "+v"(lofs));
 #pragma unroll
         for (int tk = 0; tk < T; ++tk) {
-          const f32x4 af = *reinterpret_cast<const f32x4*>(w2tf + ((tk * T + tn) * 64 + lane) * 4);
+          const f32x4 af = *reinterpret_cast<const f32x4*>(w2tf + (tk * T + tn) * 256 + lofs);
 #pragma unroll
           for (int r = 0; r < 4; ++r) d1[tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r], d2[tn][r], d1[tk], 0, 0, 0);
         }
@@ -543,6 +556,14 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
       for (int j = 0; j < D; ++j) jpart[j] = 0.f;
 #pragma unroll
       for (int t = 0; t < T; ++t) {
+        f32x4 pre1;
+        if (KEEP_A1) {
+          pre1 = a1[KEEP_A1 ? t : 0];
+        } else {
+          pre1 = *reinterpret_cast<const f32x4*>(brow + 16 * t + 4 * g);
+#pragma unroll
+          for (int j = 0; j < D; ++j) pre1 += z[j] * *reinterpret_cast<const f32x4*>(lds_w1z + j * HP + 16 * t + 4 * g);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int o = wb[r] + 256 * t;
@@ -552,7 +573,7 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
             for (int j = 0; j < D; ++j)
               if (j >= 16 * t && j < 16 * t + 16) jpart[j] += (16 * t + 4 * g + r == j) ? d1[t][r] : 0.f;
           }
-          d1[t][r] *= GEF ? sigmoid_fast(a1[t][r]) : gelu_grad_fast(a1[t][r]);
+          d1[t][r] *= GEF ? sigmoid_fast(pre1[r]) : gelu_grad_fast(pre1[r]);
           da1T[o] = d1[t][r];
         }
         if (BPTT && !ITEM) {
