@@ -54,7 +54,16 @@ int coop_launch(const cmcd_desc& d, const TrajArgs& ta, void* stream);
 int64_t lgcp_workspace_floats(const cmcd_desc& d, int64_t n, int64_t base);
 int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, const int32_t* seeds, int64_t n,
                  const float* params, const float* tc, float* ws, float* out_loss, float* out_z,
-                 double** partials_out, void* stream);
+                 double** partials_out, float* traj, void* stream);
+// reverse sweep of the reparameterised gradient on the d = 1600 path (cmcd_lgcp.hip); traj as left by lgcp_forward
+int64_t lgcp_grad_workspace_floats(const cmcd_desc& d, int64_t n);
+int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, int64_t n, const float* params,
+              int64_t n_params, const float* tc, float* ws_fwd, const float* traj, float* gws, float omega, float* grad,
+              void* stream);
+// cmcd_grad.hip: the particle-independent tails of a geffner net's gradient from the S / S2 / beta / eps tables
+int launch_geffner_tails(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, const float* params,
+                         const float* gtab, int64_t o_S, int64_t o_S2, int64_t o_gbeta, int64_t o_geps, int HP,
+                         float* grad, void* stream);
 
 // mean-field VI on lgcp (cmcd_lgcp.hip) and the statistics merge launcher (cmcd_kernels.hip), used by cmcd_mfvi.hip
 int64_t lgcp_mfvi_workspace_floats(int D, int64_t n, bool with_grad);

@@ -1380,4 +1380,18 @@ int grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, c
   return hipGetLastError() == hipSuccess ? CMCD_OK : CMCD_ERR_HIP;
 }
 
+int launch_geffner_tails(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, const float* params,
+                         const float* gtab, int64_t o_S, int64_t o_S2, int64_t o_gbeta, int64_t o_geps, int HP,
+                         float* grad, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TailArgs ta{};
+  ta.params = params; ta.gtab = gtab; ta.grad = grad; ta.lay = lay; ta.w = w;
+  ta.o_S = o_S; ta.o_S2 = o_S2; ta.o_gbeta = o_gbeta; ta.o_geps = o_geps;
+  ta.K = d.nbridges; ta.D = d.dim; ta.E = d.emb_dim; ta.IN = d.dim + d.emb_dim; ta.HP = HP; ta.arch = d.arch;
+  ta.eps_schedule = d.eps_schedule; ta.ngrid = d.ngrid;
+  hipLaunchKernelGGL(grad_sched_tail_kernel, dim3(1), dim3(256), 0, stream, ta);
+  hipLaunchKernelGGL(grad_geffner_tail_kernel, dim3(256), dim3(256), 0, stream, ta);
+  return hipGetLastError() == hipSuccess ? CMCD_OK : CMCD_ERR_HIP;
+}
+
 }  // namespace cmcd

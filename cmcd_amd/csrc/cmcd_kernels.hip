@@ -910,7 +910,7 @@ static int forward_impl(const cmcd_desc* desc, const cmcd_layout* lay, const int
     SchedArgs sa{params, wsf, *lay, lw, (int32_t)K, d.ngrid, d.eps_schedule, -1, -1};
     hipLaunchKernelGGL(prep_sched_kernel, dim3(1), dim3(256), 0, st, sa);
     double* partials = nullptr;
-    rc = lgcp_forward(d, *lay, lw, seeds, n, params, target_consts, wsf, out_loss, out_z, &partials, stream_);
+    rc = lgcp_forward(d, *lay, lw, seeds, n, params, target_consts, wsf, out_loss, out_z, &partials, traj, stream_);
     if (rc != CMCD_OK) return fail(rc, "lgcp launch sequence failed%s");
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, partials, (int32_t)n, out_stats);
     CMCD_HIP_CHECK(hipGetLastError());
@@ -1002,7 +1002,17 @@ int cmcd_bound_forward(const cmcd_desc* desc, const cmcd_layout* lay, const int3
 }
 
 int64_t cmcd_bound_grad_workspace_bytes(const cmcd_desc* desc, int64_t n) {
-  if (check_desc(desc) != CMCD_OK || n < 1 || desc->target == CMCD_TARGET_LGCP) return 0;
+  if (check_desc(desc) != CMCD_OK || n < 1) return 0;
+  if (desc->target == CMCD_TARGET_LGCP) {
+    if (desc->mode != CMCD_MODE_CAIS_SN) {
+      fail(CMCD_ERR_UNSUPPORTED, "the reparameterised gradient exists for MCD_CAIS_sn only%s");
+      return 0;
+    }
+    WsLayout lw;
+    make_ws_lgcp(*desc, n, lw);
+    return (align4(lgcp_workspace_floats(*desc, n, lw.total_floats)) + align4(lgcp_grad_workspace_floats(*desc, n)) +
+            (int64_t)(desc->nbridges + 1) * n * desc->dim) * 4;
+  }
   WsLayout w;
   const int64_t nt = desc->target == CMCD_TARGET_MANY_GMM ? 1 + 2 * 64 : 0;
   if (!make_ws(*desc, n, nt, w)) return 0;
@@ -1024,8 +1034,25 @@ int cmcd_bound_grad(const cmcd_desc* desc, const cmcd_layout* lay, const int32_t
   if (!grad) return fail(CMCD_ERR_BAD_ARG, "null pointer argument%s");
   if (desc->mode != CMCD_MODE_CAIS_SN)
     return fail(CMCD_ERR_UNSUPPORTED, "the reparameterised gradient exists for MCD_CAIS_sn only (MCD_CAIS_var_sn: cmcd_bound_var_grad)%s");
-  if (desc->target == CMCD_TARGET_LGCP) return fail(CMCD_ERR_UNSUPPORTED, "no lgcp gradient%s");
   const cmcd_desc& d = *desc;
+  if (d.target == CMCD_TARGET_LGCP) {
+    // d = 1600: launch-sequence forward (trajectory kept) + launch-sequence reverse sweep (cmcd_lgcp.hip)
+    WsLayout lw;
+    make_ws_lgcp(d, n, lw);
+    const int64_t fwd = align4(lgcp_workspace_floats(d, n, lw.total_floats));
+    const int64_t gfl = align4(lgcp_grad_workspace_floats(d, n));
+    const int64_t need = (fwd + gfl + (int64_t)(d.nbridges + 1) * n * d.dim) * 4;
+    if (workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15))
+      return fail(CMCD_ERR_WORKSPACE, "workspace too small or not 16-byte aligned (need %s%lld bytes)", "", need);
+    float* ws = static_cast<float*>(workspace);
+    float* traj = ws + fwd + gfl;
+    rc = forward_impl(desc, lay, seeds, n, params, n_params, target_consts, n_target, workspace, fwd * 4, out_loss,
+                      out_z, out_stats, traj, stream_);
+    if (rc != CMCD_OK) return rc;
+    rc = lgcp_grad(d, *lay, lw, n, params, n_params, target_consts, ws, traj, ws + fwd, omega, grad, stream_);
+    if (rc != CMCD_OK) return fail(rc, "lgcp gradient launch sequence failed%s");
+    return CMCD_OK;
+  }
   WsLayout w;
   if (!make_ws(d, n, n_target, w)) return fail(CMCD_ERR_BAD_ARG, "bad descriptor%s");
   if (!bptt_available(d, w.T)) return fail(CMCD_ERR_UNSUPPORTED, "no reparameterised-gradient kernel instance for this (target, dim, arch, width)%s");

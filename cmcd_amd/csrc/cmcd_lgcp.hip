@@ -182,6 +182,8 @@ struct LgcpStateArgs {
   float* out_loss;           // [M]
   float* out_z;              // [M][D]
   double* partials;          // [M][5]
+  float* traj;               // optional [K+1][n_total][D]: z_0..z_K of every particle (reverse sweep of the gradient)
+  int64_t n_total, base;     // trajectory row of particle p of this pass: base + p
   cmcd_layout lay;
   int M, D, K, i, var_mode, grad_clipping;
 };
@@ -218,6 +220,7 @@ __global__ __launch_bounds__(256) void lgcp_init_kernel(LgcpStateArgs a) {
         const float sd = expf(a.params[a.lay.vd_logdiag + idx[q]]);
         const float z = sd * bits_to_normal(bits[q]) + mean;
         a.x[p * D + idx[q]] = z;
+        if (a.traj) a.traj[(a.base + p) * D + idx[q]] = z;
         const float dz = z - mean;
         acc += -(dz * dz) / (2.0f * sd * sd) - logf(sd) - kHalfLog2Pi;
       }
@@ -300,6 +303,7 @@ __global__ __launch_bounds__(256) void lgcp_step_kernel(LgcpStateArgs a) {
           fk_acc += -(df * df) * inv2s2 - cst;
           a.xp[p * D + e] = z;
           a.x[p * D + e] = zn;
+          if (a.traj) a.traj[((int64_t)(i + 1) * a.n_total + a.base + p) * D + e] = zn;
         }
       }
     }
@@ -362,7 +366,7 @@ int64_t lgcp_workspace_floats(const cmcd_desc& d, int64_t n, int64_t base) { ret
 
 int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, const int32_t* seeds, int64_t n,
                  const float* params, const float* tc, float* ws, float* out_loss, float* out_z,
-                 double** partials_out, void* stream_) {
+                 double** partials_out, float* traj, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const int D = d.dim, E = d.emb_dim, IN = D + E, K = d.nbridges;
   const LgcpWs w = lgcp_ws(d, n, sw.total_floats);
@@ -392,6 +396,7 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
     st.w = ws + w.w; st.fklp = ws + w.fklp; st.keys = reinterpret_cast<uint32_t*>(ws + w.keys);
     st.out_loss = out_loss + base; st.out_z = out_z + base * D; st.partials = partials + base * CMCD_NSTATS;
     st.lay = lay; st.M = M; st.D = D; st.K = K;
+    st.traj = traj; st.n_total = n; st.base = base;
     st.var_mode = d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0; st.grad_clipping = d.grad_clipping;
     hipLaunchKernelGGL(lgcp_init_kernel, dim3(M), dim3(256), 0, stream, st);
 
@@ -541,6 +546,432 @@ int lgcp_mfvi(int D, int64_t o_mean, int64_t o_logdiag, const int32_t* seeds, in
                     partials + base * CMCD_NSTATS, gbuf ? gbuf + base * 2 * D : nullptr, o_mean, D};
     hipLaunchKernelGGL(lgcp_mfvi_finish_kernel, dim3(M), dim3(256), 0, stream, fa);
   }
+  return hipGetLastError() == hipSuccess ? CMCD_OK : CMCD_ERR_HIP;
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Reparameterised gradient on the lgcp path (jax.grad(compute_bound, 1) for MCD_CAIS_sn, d = 1600): the same
+// reverse recursion as cmcd_grad.hip (header there), as a launch sequence.  Per evaluation e = K..0:
+//   recompute the forward at the stored z_e (6 launches of the forward path) ->
+//   adjoint step (g_{e-1}, cotangents a_s / a_gp / a_gq, beta / eps / q gradients) ->
+//   net backward through three skinny GEMMs against TRANSPOSED weight copies (made once per call), the
+//   Hessian product H_p v = -K^-1 v - a e^z v through one more GEMM -> lambda_e.
+// The O(width^2) parameter gradients are deferred: every evaluation's (u1, u2, d a1, d a2, d o) rows are kept
+// and contracted at the end by three A^T B products on the matrix cores (inner dimension (K+1) n).
+// ------------------------------------------------------------------------------------------
+__global__ void lgcp_transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C, int lds_, int ldd) {
+  __shared__ float tile[32][33];
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int r = r0 + i, c = c0 + threadIdx.x;
+    tile[i][threadIdx.x] = (r < R && c < C) ? src[(int64_t)r * lds_ + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int c = c0 + i, r = r0 + threadIdx.x;
+    if (r < R && c < C) dst[(int64_t)c * ldd + r] = tile[threadIdx.x][i];
+  }
+}
+
+struct LgcpAdjArgs {
+  const float* params;
+  const float* tc;
+  const float* sched;        // [K][8] {beta, eps, ...}
+  const float* traj;         // [K+1][n][D]
+  const float* kr;           // [kSplit][kMP][D]
+  const float* sn;           // [kSplit][kMP][D]
+  const float* b3;
+  const float* factor;
+  const float* lamn;         // [kMP][D] lambda_{e+1}
+  const float* gE;           // [kMP][D] g_e
+  float* gprev;              // [kMP][D] g_{e-1}
+  float* dO;                 // [kMP][D] cotangent of o = u2 W3 + b3
+  float* v;                  // [kMP][D] clipmask . a_gp
+  float* lam_part;           // [kMP][D]
+  float* gmu_acc;            // [kMP][D] running d / d vd.mean per particle
+  float* glam_acc;           // [kMP][D]
+  float* gbeta;              // [K]
+  float* geps;               // [K]
+  float* gfac;               // scalar
+  float* DObig;              // [(K+1) n][D]
+  cmcd_layout lay;
+  int64_t n, base;
+  int M, D, K, e, grad_clipping;
+  float omega;
+};
+
+__global__ __launch_bounds__(256) void lgcp_adj_step_kernel(LgcpAdjArgs a) {
+  __shared__ float sh[4];
+  const int p = blockIdx.x, D = a.D, e = a.e, K = a.K;
+  const float* counts = a.tc + (int64_t)D * D;
+  const float pa = a.tc[(int64_t)D * D + D + 1];
+  const float clipv = 1e3f;
+  const bool clip_p = a.grad_clipping != 0;
+  const float om = a.omega;
+  const float pb = e > 0 ? a.sched[8 * (e - 1)] : 0.f, pe = e > 0 ? a.sched[8 * (e - 1) + 1] : 1.f;
+  const float be = e < K ? a.sched[8 * e] : 0.f, ee = e < K ? a.sched[8 * e + 1] : 1.f;
+  const float fac = a.factor[0];
+  const float* ze = a.traj + ((int64_t)e * a.n + a.base + p) * D;
+  const float* zpv = a.traj + ((int64_t)(e > 0 ? e - 1 : 0) * a.n + a.base + p) * D;
+  const float* znv = a.traj + ((int64_t)(e < K ? e + 1 : K) * a.n + a.base + p) * D;
+  float sb = 0.f, se = 0.f, r2 = 0.f, sb2 = 0.f, se2 = 0.f, gf = 0.f;
+  for (int j = threadIdx.x; j < D; j += blockDim.x) {
+    const float z = ze[j];
+    float kr = 0.f, o = a.b3[j];
+#pragma unroll
+    for (int ks = 0; ks < kSplit; ++ks) {
+      kr += a.kr[((int64_t)ks * kMP + p) * D + j];
+      o += a.sn[((int64_t)ks * kMP + p) * D + j];
+    }
+    const float s = o * fac;
+    const float graw = -kr + counts[j] - pa * expf(z);
+    const float m = (!clip_p || fabsf(graw) < clipv) ? 1.0f : 0.f;
+    const float gp = clip_p ? fminf(fmaxf(graw, -clipv), clipv) : graw;
+    const float mean = a.params[a.lay.vd_mean + j];
+    const float sd = expf(a.params[a.lay.vd_logdiag + j]);
+    const float qiv = 1.0f / (sd * sd);
+    const float gq = -(z - mean) * qiv;
+    float a_s = 0.f, a_gp = 0.f, a_gq = 0.f, lam = 0.f, gpv = 0.f;
+    if (e > 0) {
+      const float ub = -1.0f * (pb * gp + (1.0f - pb) * gq);
+      const float bk = z - pe * ub + pe * s;
+      const float r = zpv[j] - bk;
+      gpv = -om * r * (0.5f / pe);
+      a_s += pe * gpv; a_gp += pe * pb * gpv; a_gq += pe * (1.0f - pb) * gpv; lam += gpv;
+      sb += (gp - gq) * gpv; se += (s - ub) * gpv; r2 += r * r;
+    }
+    if (e < K) {
+      const float ln = a.lamn[p * D + j];
+      const float uf = -1.0f * (be * gp + (1.0f - be) * gq);
+      const float fk = z - ee * uf - ee * s;
+      const float nsig = (znv[j] - fk) * (0.5f / ee);
+      a_s -= ee * ln; a_gp += ee * be * ln; a_gq += ee * (1.0f - be) * ln; lam += ln - a.gE[p * D + j];
+      sb2 += (gp - gq) * ln; se2 += (nsig - uf - s) * ln;
+    }
+    if (e == K) lam -= om * graw;
+    if (e == 0) lam += om * gq;
+    a.gmu_acc[p * D + j] += a_gq * qiv;
+    a.glam_acc[p * D + j] += a_gq * (-2.0f * gq);
+    lam -= a_gq * qiv;
+    gf += a_s * o;
+    a.gprev[p * D + j] = gpv;
+    a.dO[p * D + j] = a_s * fac;
+    a.DObig[((int64_t)e * a.n + a.base + p) * D + j] = a_s * fac;
+    a.v[p * D + j] = m * a_gp;
+    a.lam_part[p * D + j] = lam;
+  }
+  const float tsb = block_sum_256(sb, sh), tse = block_sum_256(se, sh), tr2 = block_sum_256(r2, sh);
+  const float tsb2 = block_sum_256(sb2, sh), tse2 = block_sum_256(se2, sh), tgf = block_sum_256(gf, sh);
+  if (threadIdx.x == 0) {
+    if (e > 0) {
+      const float inv2e = 0.5f / pe;
+      atomicAdd(a.gbeta + (e - 1), pe * tsb);
+      atomicAdd(a.geps + (e - 1), tse - om * tr2 * inv2e * inv2e);
+    }
+    if (e < K) {
+      atomicAdd(a.gbeta + e, ee * tsb2);
+      atomicAdd(a.geps + e, tse2);
+    }
+    atomicAdd(a.gfac, tgf);
+  }
+}
+
+// backward activations: one thread per hidden unit k, loop over the <= kMP particles of the pass
+struct LgcpActbArgs {
+  const float* slab;       // [kSplit][kMP][IN] partials of the incoming GEMM
+  const float* pre;        // [kMP][IN] pre-activation of this layer
+  const float* du_prev;    // [kMP][IN] (mode 1: d u2)
+  const float* u_src;      // [kMP][IN] this layer's input activation to keep (u2 for mode 2, u1 for mode 1)
+  float* du_out;           // [kMP][IN]
+  float* da_out;           // [kMP][IN]
+  float* da_big;           // [(K+1) n][IN]
+  float* u_big;            // [(K+1) n][IN]
+  float* S;                // mode 1: S[e][k]  = sum_m d a1   (row of the table)
+  float* S2;               // mode 1: S2[e][k] = sum_m d u1
+  float* gb;               // mode 2: d b2[k] += sum_m d a2
+  int64_t row0;            // e * n + base
+  int M, IN, mode;
+};
+
+__global__ void lgcp_actb_kernel(LgcpActbArgs a) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= a.IN) return;
+  float sa = 0.f, su = 0.f;
+  for (int m = 0; m < a.M; ++m) {
+    float du = a.mode == 1 ? a.du_prev[m * a.IN + k] : 0.f;
+#pragma unroll
+    for (int ks = 0; ks < kSplit; ++ks) du += a.slab[((int64_t)ks * kMP + m) * a.IN + k];
+    const float da = du * sigmoid_fast(a.pre[m * a.IN + k]);
+    a.du_out[m * a.IN + k] = du;
+    a.da_out[m * a.IN + k] = da;
+    a.da_big[(a.row0 + m) * a.IN + k] = da;
+    a.u_big[(a.row0 + m) * a.IN + k] = a.u_src[m * a.IN + k];
+    sa += da;
+    su += du;
+  }
+  if (a.mode == 1) { a.S[k] += sa; a.S2[k] += su; }   // accumulated over the passes of a large batch
+  else a.gb[k] += sa;
+}
+
+struct LgcpLamArgs {
+  const float* params;
+  const float* tc;
+  const float* traj;
+  const float* dxf;        // [kSplit][kMP][D]   d a1 W1[:D]^T partials
+  const float* hv;         // [kSplit][kMP][D]   v K^-1 partials
+  const float* du1;        // [kMP][IN]
+  const float* v;          // [kMP][D]
+  const float* lam_part;   // [kMP][D]
+  const float* gprev;      // [kMP][D]
+  float* lamn;             // [kMP][D]
+  float* gE;               // [kMP][D]
+  float* gmu_acc;
+  float* glam_acc;
+  cmcd_layout lay;
+  int64_t n, base;
+  int M, D, IN, e;
+  float omega;
+};
+
+__global__ void lgcp_lam_finish_kernel(LgcpLamArgs a) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.M * a.D) return;
+  const int m = idx / a.D, j = idx - m * a.D, D = a.D;
+  const float pa = a.tc[(int64_t)D * D + D + 1];
+  const float z = a.traj[((int64_t)a.e * a.n + a.base + m) * D + j];
+  float dx = a.du1[m * a.IN + j], hv = 0.f;     // residual path: d x_j += d u1_j
+#pragma unroll
+  for (int ks = 0; ks < kSplit; ++ks) {
+    dx += a.dxf[((int64_t)ks * kMP + m) * D + j];
+    hv += a.hv[((int64_t)ks * kMP + m) * D + j];
+  }
+  const float lam = a.lam_part[idx] + dx - hv - pa * expf(z) * a.v[idx];   // H_p v = -K^-1 v - a e^z v
+  a.lamn[idx] = lam;
+  a.gE[idx] = a.gprev[idx];
+  if (a.e == 0) {
+    const float mean = a.params[a.lay.vd_mean + j];
+    const float sd = expf(a.params[a.lay.vd_logdiag + j]);
+    const float qiv = 1.0f / (sd * sd), dz = z - mean;
+    const float gq = -dz * qiv;
+    a.gmu_acc[idx] += lam - a.omega * gq;
+    a.glam_acc[idx] += lam * dz + a.omega * (dz * dz * qiv - 1.0f);
+  }
+}
+
+// C[Ma][Nb] (ldc) = sum_r A[r][Ma]^T B[r][Nb]: contraction over the (K+1) n stored rows on the matrix cores.
+// A workgroup of 4 waves owns a 64 x 64 tile of C, wave w the 16-row band w; operands come straight from global
+// memory in MFMA order (lane (g, c): A[r0 + g][i0 + c], B[r0 + g][j0 + 16 t + c]): rows are contiguous along c.
+__global__ __launch_bounds__(256) void lgcp_tn_gemm_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                           float* __restrict__ C, int64_t R, int Ma, int Nb, int lda,
+                                                           int ldb, int ldc) {
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  const int i0 = blockIdx.y * 64 + wv * 16, j0 = blockIdx.x * 64;
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool ia = i0 + c < Ma;
+  bool jb[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) jb[t] = j0 + 16 * t + c < Nb;
+  for (int64_t r0 = 0; r0 < R; r0 += 4) {
+    const int64_t r = r0 + g;
+    const bool rv = r < R;
+    const float av = (rv && ia) ? A[r * lda + i0 + c] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float bv = (rv && jb[t]) ? B[r * ldb + j0 + 16 * t + c] : 0.f;
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0);
+    }
+  }
+  // C layout: lane (g, c), register q <-> row 4 g + q, column c
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = i0 + 4 * g + q, col = j0 + 16 * t + c;
+      if (row < Ma && col < Nb) C[(int64_t)row * ldc + col] = acc[t][q];
+    }
+}
+
+// column sums of a [R][C] matrix (d b3), and the final reduction of the per-particle q gradients
+__global__ void lgcp_colsum_kernel(const float* __restrict__ A, int64_t R, int C, int lda, float* out, float scale, int accumulate) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= C) return;
+  float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+  int64_t r = 0;
+  for (; r + 4 <= R; r += 4) {
+    v0 += A[r * lda + j]; v1 += A[(r + 1) * lda + j]; v2 += A[(r + 2) * lda + j]; v3 += A[(r + 3) * lda + j];
+  }
+  for (; r < R; ++r) v0 += A[r * lda + j];
+  const float v = ((v0 + v1) + (v2 + v3)) * scale;
+  out[j] = accumulate ? out[j] + v : v;
+}
+
+struct LgcpGradWs {
+  int64_t wt1, wt2, wt3;                       // transposed weights
+  int64_t lamn, lam_part, gE, gprev, dO, v;    // [kMP][D]
+  int64_t hv, dxf;                             // [kSplit][kMP][D]
+  int64_t du2s, ts;                            // [kSplit][kMP][IN] slabs of the two IN-wide backward GEMMs
+  int64_t du2, du1, da2, da1;                  // [kMP][IN]
+  int64_t gmu_acc, glam_acc;                   // [kMP][D]
+  int64_t U1, U2, DA1, DA2;                    // [(K+1) n][IN]
+  int64_t DO;                                  // [(K+1) n][D]
+  int64_t S, S2, gbeta, geps, gfac, gb2;       // tables
+  int64_t zero_lo, zero_hi;                    // range to clear per call
+  int64_t total;
+};
+
+static LgcpGradWs lgcp_grad_ws(const cmcd_desc& d, int64_t n) {
+  const int64_t D = d.dim, IN = D + d.emb_dim, K = d.nbridges, R = (K + 1) * n;
+  LgcpGradWs w;
+  int64_t o = 0;
+  auto take = [&](int64_t cnt) { int64_t r = o; o += (cnt + 3) & ~int64_t(3); return r; };
+  w.wt1 = take(IN * IN); w.wt2 = take(IN * IN); w.wt3 = take(D * IN);
+  w.dO = take(kMP * D); w.v = take(kMP * D); w.lam_part = take(kMP * D); w.gprev = take(kMP * D);
+  w.hv = take(kSplit * kMP * D); w.dxf = take(kSplit * kMP * D);
+  w.du2s = take(kSplit * kMP * IN); w.ts = take(kSplit * kMP * IN);
+  w.du2 = take(kMP * IN); w.du1 = take(kMP * IN); w.da2 = take(kMP * IN); w.da1 = take(kMP * IN);
+  w.U1 = take(R * IN); w.U2 = take(R * IN); w.DA1 = take(R * IN); w.DA2 = take(R * IN); w.DO = take(R * D);
+  w.zero_lo = o;
+  w.lamn = take(kMP * D); w.gE = take(kMP * D);
+  w.gmu_acc = take(kMP * D); w.glam_acc = take(kMP * D);
+  w.S = take((K + 1) * IN); w.S2 = take((K + 1) * IN);
+  w.gbeta = take(K); w.geps = take(K); w.gfac = take(4); w.gb2 = take(IN);
+  w.zero_hi = o;
+  w.total = o;
+  return w;
+}
+
+int64_t lgcp_grad_workspace_floats(const cmcd_desc& d, int64_t n) { return lgcp_grad_ws(d, n).total; }
+
+int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, int64_t n, const float* params,
+              int64_t n_params, const float* tc, float* ws, const float* traj, float* gws, float omega, float* grad,
+              void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int D = d.dim, E = d.emb_dim, IN = D + E, K = d.nbridges;
+  const LgcpWs w = lgcp_ws(d, n, sw.total_floats);
+  const LgcpGradWs g = lgcp_grad_ws(d, n);
+  if (hipMemsetAsync(grad, 0, sizeof(float) * n_params, stream) != hipSuccess) return CMCD_ERR_HIP;
+  if (hipMemsetAsync(gws + g.zero_lo, 0, sizeof(float) * (g.zero_hi - g.zero_lo), stream) != hipSuccess) return CMCD_ERR_HIP;
+  // transposed weight copies: the backward GEMMs are then the forward kernel on W^T
+  {
+    const dim3 tb(32, 8);
+    hipLaunchKernelGGL(lgcp_transpose_kernel, dim3((IN + 31) / 32, (IN + 31) / 32), tb, 0, stream, params + lay.g_w1,
+                       gws + g.wt1, IN, IN, IN, IN);
+    hipLaunchKernelGGL(lgcp_transpose_kernel, dim3((IN + 31) / 32, (IN + 31) / 32), tb, 0, stream, params + lay.g_w2,
+                       gws + g.wt2, IN, IN, IN, IN);
+    hipLaunchKernelGGL(lgcp_transpose_kernel, dim3((D + 31) / 32, (IN + 31) / 32), tb, 0, stream, params + lay.g_w3,
+                       gws + g.wt3, IN, D, D, IN);
+  }
+  const size_t gemm_lds = size_t(kGemmWaves * kChunk * kMP + kGemmWaves * kMP * 64) * 4;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(lgcp_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)gemm_lds) != hipSuccess)
+    return CMCD_ERR_HIP;
+  const float* kinv = tc;
+  const float mu0 = 3.8812819069514780f;
+  const dim3 gblock(64 * kGemmWaves);
+  const int cbD = (D + 63) / 64, cbIN = (IN + 63) / 64;
+  // bias1 rows are still in the forward workspace (lgcp_forward's prep)
+  for (int64_t base = 0; base < n; base += kMP) {
+    const int M = (int)((n - base) < kMP ? (n - base) : kMP);
+    if (base > 0) {  // lambda / g start from zero for every pass
+      if (hipMemsetAsync(gws + g.lamn, 0, sizeof(float) * 2 * ((kMP * (int64_t)D + 3) & ~3), stream) != hipSuccess) return CMCD_ERR_HIP;
+      if (hipMemsetAsync(gws + g.gmu_acc, 0, sizeof(float) * 2 * ((kMP * (int64_t)D + 3) & ~3), stream) != hipSuccess) return CMCD_ERR_HIP;
+    }
+    ActArgs act{};
+    act.mu0 = mu0; act.M = M; act.D = D; act.IN = IN; act.xm = ws + w.xm;
+    GemmArgs gm{};
+    gm.M = M;
+    for (int e = K; e >= 0; --e) {
+      const int ie = e < K ? e : K - 1;
+      const float* xe = traj + ((int64_t)e * n + base) * D;
+      const int64_t row0 = (int64_t)e * n + base;
+      // ---- forward recompute at z_e
+      act.x = xe; act.emb = params + lay.g_emb + (int64_t)ie * E;
+      act.mode = 0;
+      hipLaunchKernelGGL(lgcp_act_kernel, dim3((M * D + 255) / 256), dim3(256), 0, stream, act);
+      gm.Kdim = D;
+      gm.seg[0] = GemmSeg{ws + w.xm, kinv, ws + w.kr, D, D, D, D};
+      gm.seg[1] = GemmSeg{xe, params + lay.g_w1, ws + w.slab1, IN, D, IN, IN};
+      gm.nblk0 = cbD;
+      hipLaunchKernelGGL(lgcp_gemm_kernel, dim3(cbD + cbIN, kSplit), gblock, gemm_lds, stream, gm);
+      act.mode = 1; act.slab_a = ws + w.slab1; act.bias_a = ws + w.bias1 + (int64_t)e * IN;
+      act.sum_a = ws + w.pre1; act.u_prev = nullptr; act.u_out = ws + w.u1;
+      hipLaunchKernelGGL(lgcp_act_kernel, dim3((M * IN + 255) / 256), dim3(256), 0, stream, act);
+      gm.Kdim = IN;
+      gm.seg[0] = GemmSeg{ws + w.u1, params + lay.g_w2, ws + w.slab2, IN, IN, IN, IN};
+      gm.nblk0 = cbIN;
+      hipLaunchKernelGGL(lgcp_gemm_kernel, dim3(cbIN, kSplit), gblock, gemm_lds, stream, gm);
+      act.mode = 2; act.slab_a = ws + w.slab2; act.bias_a = params + lay.g_b2;
+      act.sum_a = ws + w.pre2; act.u_prev = ws + w.u1; act.u_out = ws + w.u2;
+      hipLaunchKernelGGL(lgcp_act_kernel, dim3((M * IN + 255) / 256), dim3(256), 0, stream, act);
+      gm.seg[0] = GemmSeg{ws + w.u2, params + lay.g_w3, ws + w.sn, D, IN, D, D};
+      gm.nblk0 = cbD;
+      hipLaunchKernelGGL(lgcp_gemm_kernel, dim3(cbD, kSplit), gblock, gemm_lds, stream, gm);
+      // ---- adjoint step
+      LgcpAdjArgs aa{};
+      aa.params = params; aa.tc = tc; aa.sched = ws + sw.sched; aa.traj = traj; aa.kr = ws + w.kr; aa.sn = ws + w.sn;
+      aa.b3 = params + lay.g_b3; aa.factor = params + lay.g_factor; aa.lamn = gws + g.lamn; aa.gE = gws + g.gE;
+      aa.gprev = gws + g.gprev; aa.dO = gws + g.dO; aa.v = gws + g.v; aa.lam_part = gws + g.lam_part;
+      aa.gmu_acc = gws + g.gmu_acc; aa.glam_acc = gws + g.glam_acc; aa.gbeta = gws + g.gbeta; aa.geps = gws + g.geps;
+      aa.gfac = gws + g.gfac; aa.DObig = gws + g.DO; aa.lay = lay; aa.n = n; aa.base = base;
+      aa.M = M; aa.D = D; aa.K = K; aa.e = e; aa.grad_clipping = d.grad_clipping; aa.omega = omega;
+      hipLaunchKernelGGL(lgcp_adj_step_kernel, dim3(M), dim3(256), 0, stream, aa);
+      // ---- net backward: d u2 = d o W3^T
+      gm.Kdim = D;
+      gm.seg[0] = GemmSeg{gws + g.dO, gws + g.wt3, gws + g.du2s, IN, D, IN, IN};
+      gm.nblk0 = cbIN;
+      hipLaunchKernelGGL(lgcp_gemm_kernel, dim3(cbIN, kSplit), gblock, gemm_lds, stream, gm);
+      LgcpActbArgs ab{};
+      ab.slab = gws + g.du2s; ab.pre = ws + w.pre2; ab.du_prev = nullptr; ab.u_src = ws + w.u2;
+      ab.du_out = gws + g.du2; ab.da_out = gws + g.da2; ab.da_big = gws + g.DA2; ab.u_big = gws + g.U2;
+      ab.gb = gws + g.gb2; ab.row0 = row0; ab.M = M; ab.IN = IN; ab.mode = 2;
+      hipLaunchKernelGGL(lgcp_actb_kernel, dim3((IN + 255) / 256), dim3(256), 0, stream, ab);
+      // d u1 = d u2 + d a2 W2^T
+      gm.Kdim = IN;
+      gm.seg[0] = GemmSeg{gws + g.da2, gws + g.wt2, gws + g.ts, IN, IN, IN, IN};
+      gm.nblk0 = cbIN;
+      hipLaunchKernelGGL(lgcp_gemm_kernel, dim3(cbIN, kSplit), gblock, gemm_lds, stream, gm);
+      ab.slab = gws + g.ts; ab.pre = ws + w.pre1; ab.du_prev = gws + g.du2; ab.u_src = ws + w.u1;
+      ab.du_out = gws + g.du1; ab.da_out = gws + g.da1; ab.da_big = gws + g.DA1; ab.u_big = gws + g.U1;
+      ab.S = gws + g.S + (int64_t)e * IN; ab.S2 = gws + g.S2 + (int64_t)e * IN; ab.mode = 1;
+      hipLaunchKernelGGL(lgcp_actb_kernel, dim3((IN + 255) / 256), dim3(256), 0, stream, ab);
+      // d x = d u1[:D] + d a1 W1[:D]^T   |   v K^-1
+      gm.Kdim = IN;
+      gm.seg[0] = GemmSeg{gws + g.da1, gws + g.wt1, gws + g.dxf, D, IN, IN, D};
+      gm.nblk0 = cbD;
+      hipLaunchKernelGGL(lgcp_gemm_kernel, dim3(cbD, kSplit), gblock, gemm_lds, stream, gm);
+      gm.Kdim = D;
+      gm.seg[0] = GemmSeg{gws + g.v, kinv, gws + g.hv, D, D, D, D};
+      gm.nblk0 = cbD;
+      hipLaunchKernelGGL(lgcp_gemm_kernel, dim3(cbD, kSplit), gblock, gemm_lds, stream, gm);
+      LgcpLamArgs la{};
+      la.params = params; la.tc = tc; la.traj = traj; la.dxf = gws + g.dxf; la.hv = gws + g.hv; la.du1 = gws + g.du1;
+      la.v = gws + g.v; la.lam_part = gws + g.lam_part; la.gprev = gws + g.gprev; la.lamn = gws + g.lamn;
+      la.gE = gws + g.gE; la.gmu_acc = gws + g.gmu_acc; la.glam_acc = gws + g.glam_acc; la.lay = lay; la.n = n;
+      la.base = base; la.M = M; la.D = D; la.IN = IN; la.e = e; la.omega = omega;
+      hipLaunchKernelGGL(lgcp_lam_finish_kernel, dim3((M * D + 255) / 256), dim3(256), 0, stream, la);
+    }
+    // q gradients of this pass: sum over its particles, accumulated into grad
+    hipLaunchKernelGGL(lgcp_colsum_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, gws + g.gmu_acc, (int64_t)M, D, D,
+                       grad + lay.vd_mean, 1.0f, 1);
+    hipLaunchKernelGGL(lgcp_colsum_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, gws + g.glam_acc, (int64_t)M, D, D,
+                       grad + lay.vd_logdiag, 1.0f, 1);
+  }
+  // ---- deferred parameter contractions over all (K+1) n rows
+  const int64_t R = (int64_t)(K + 1) * n;
+  hipLaunchKernelGGL(lgcp_tn_gemm_kernel, dim3((IN + 63) / 64, (IN + 63) / 64), dim3(256), 0, stream, gws + g.U1, gws + g.DA2,
+                     grad + lay.g_w2, R, IN, IN, IN, IN, IN);                                   // dW2 = U1^T dA2
+  hipLaunchKernelGGL(lgcp_tn_gemm_kernel, dim3((D + 63) / 64, (IN + 63) / 64), dim3(256), 0, stream, gws + g.U2, gws + g.DO,
+                     grad + lay.g_w3, R, IN, D, IN, D, D);                                      // dW3 = U2^T dO
+  hipLaunchKernelGGL(lgcp_tn_gemm_kernel, dim3((IN + 63) / 64, (D + 63) / 64), dim3(256), 0, stream, traj, gws + g.DA1,
+                     grad + lay.g_w1, R, D, IN, D, IN, IN);                                     // dW1[:D] = X^T dA1
+  hipLaunchKernelGGL(lgcp_colsum_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, gws + g.DO, R, D, D, grad + lay.g_b3, 1.0f, 0);
+  hipLaunchKernelGGL(lgcp_colsum_kernel, dim3((IN + 255) / 256), dim3(256), 0, stream, gws + g.gb2, (int64_t)1, IN, IN, grad + lay.g_b2, 1.0f, 0);
+  hipLaunchKernelGGL(lgcp_colsum_kernel, dim3(1), dim3(256), 0, stream, gws + g.gfac, (int64_t)1, 1, 1, grad + lay.g_factor, 1.0f, 0);
+  int rc = launch_geffner_tails(d, lay, sw, params, gws, g.S, g.S2, g.gbeta, g.geps, IN, grad, stream_);
+  if (rc != CMCD_OK) return rc;
   return hipGetLastError() == hipSuccess ? CMCD_OK : CMCD_ERR_HIP;
 }
 

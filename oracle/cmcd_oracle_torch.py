@@ -51,6 +51,20 @@ def logp_many_gmm(z):
     return torch.where(lp > -1e4, lp, torch.full_like(lp, -math.inf))   # model_handler.py:279-280
 
 
+def make_logp_lgcp(flat_bin_counts, m=40):
+    """Log-Gaussian Cox process on an m x m grid, un-whitened (/root/reference/src/model_handler.py:304-396,
+    /root/reference/src/cp_utils.py:45-155), from the constants of oracle.targets.Lgcp (float64)."""
+    from .targets import Lgcp
+    t = Lgcp(flat_bin_counts, m)
+    kinv = torch.tensor(t.kinv)
+    counts = torch.tensor(t.counts)
+
+    def logp(z):
+        r = z - t.mu0
+        return -0.5 * ((r @ kinv) * r).sum(-1) + (z * counts - t.a * torch.exp(z)).sum(-1) + t.lognorm
+    return logp
+
+
 TARGETS = {"gmm": logp_gmm, "funnel": logp_funnel, "many_gmm": logp_many_gmm}
 
 
@@ -120,7 +134,7 @@ def to_torch(params, requires_grad=True):
 def losses(seeds, p, dim, nbridges, mode, arch, target_name, eps_schedule=None, grad_clipping=False):
     """Per-particle losses [N] (float64), differentiable wrt the leaves of `p`."""
     var_mode = mode == "MCD_CAIS_var_sn"
-    logp_fn = TARGETS[target_name]
+    logp_fn = TARGETS[target_name] if isinstance(target_name, str) else target_name   # or a log-density callable
     e0, noise = prng.particle_noise(np.asarray(seeds), dim, nbridges)
     e0 = torch.tensor(e0.astype(np.float64))
     noise = torch.tensor(noise.astype(np.float64))
