@@ -169,8 +169,8 @@ int cmcd_bound_var_grad_kept(const cmcd_desc* desc, const cmcd_layout* layout, c
  * One call = forward (losses, z_K, statistics as cmcd_bound_forward; the trajectory z_0..z_K is kept in
  * the workspace) + reverse sweep.  grad[n_params] (overwritten) = omega * sum_n d loss_n / d params_flat;
  * omega = d value / d loss_n = 1 / N_total (across ranks: all-reduce(sum) of grad).
- * MCD_CAIS_sn with targets gmm / funnel / many_gmm and the BASELINE nets (dds 64; geffner 22 / 58);
- * CMCD_ERR_UNSUPPORTED otherwise (lgcp, width 132). */
+ * MCD_CAIS_sn with targets gmm / funnel / many_gmm and the BASELINE nets (dds 64; geffner 22 / 58), and lgcp
+ * (geffner, any width: launch-sequence reverse sweep); CMCD_ERR_UNSUPPORTED otherwise (width 132 on the 2-d targets). */
 int64_t cmcd_bound_grad_workspace_bytes(const cmcd_desc* desc, int64_t n);
 int cmcd_bound_grad(const cmcd_desc* desc, const cmcd_layout* layout, const int32_t* seeds, int64_t n,
                     const float* params, int64_t n_params, const float* target_consts, int64_t n_target,

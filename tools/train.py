@@ -39,9 +39,17 @@ ap.add_argument("--lr", type=float, default=1e-3)
 ap.add_argument("--n_samples", type=int, default=500)
 ap.add_argument("--n_input_dist_seeds", type=int, default=30)
 ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--file_path", default="", help="lgcp: pines.csv (default: the bin-count fixture under tests/golden)")
 cfg = ap.parse_args()
 
-log_prob_model, dim, _ = load_model(cfg.model, cfg)
+if "lgcp" in cfg.model and not cfg.file_path:
+    # the Finnish-pines point set is reference content; its 40 x 40 bin counts ship as a test fixture
+    import numpy as np
+    from cmcd_amd.lgcp import load_model_lgcp
+    res = load_model_lgcp(cfg.model, cfg, flat_bin_counts=np.load(os.path.join(ROOT, "tests", "golden", "lgcp_bin_counts.npy")))
+else:
+    res = load_model(cfg.model, cfg)
+log_prob_model, dim = res[0], res[1]
 gen = torch.Generator().manual_seed(cfg.seed)
 eval_seeds = torch.randint(1, 1000000, (cfg.n_samples * cfg.n_input_dist_seeds,), generator=torch.Generator().manual_seed(cfg.seed + 1),
                            dtype=torch.int32).cuda()
