@@ -60,6 +60,12 @@ int64_t lgcp_grad_workspace_floats(const cmcd_desc& d, int64_t n);
 int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, int64_t n, const float* params,
               int64_t n_params, const float* tc, float* ws_fwd, const float* traj, float* gws, float omega, float* grad,
               void* stream);
+// cmcd_grad.hip: MCD_ULA (no network) reverse sweep
+bool ula_grad_available(const cmcd_desc& d);
+int64_t ula_grad_workspace_floats(const cmcd_desc& d, int64_t n);
+int ula_grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, int64_t n, const float* params,
+                    int64_t n_params, const float* ws_fwd, const float* traj, float* gws, float omega, float* grad,
+                    void* stream);
 // cmcd_grad.hip: the particle-independent tails of a geffner net's gradient from the S / S2 / beta / eps tables
 int launch_geffner_tails(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, const float* params,
                          const float* gtab, int64_t o_S, int64_t o_S2, int64_t o_gbeta, int64_t o_geps, int HP,

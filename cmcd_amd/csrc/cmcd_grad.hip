@@ -62,6 +62,7 @@ struct GradArgs {
   WsLayout w;
   int64_t n;
   int32_t K, var_mode, grad_clipping, nquads;
+  int32_t ula;               // 0: CAIS; 2: MCD_ULA_sn — no network in the forward kernel, s(z_{i+1}, i) in the backward one
   int64_t o_S, o_S2, o_gbeta, o_geps, o_gvd, o_gfac;   // offsets inside gtab
   int64_t slab_stride;                                   // floats per workgroup slab
 };
@@ -254,7 +255,10 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
         if (ITEM && e > 0) { pbeta = a.ws[a.w.beta + e - 1]; peps = a.ws[a.w.eps + e - 1]; }
       }
       // ---------------------------------------------------------------- forward (keeps pre-activations)
-      const float* brow = bias1 + (int64_t)e * HP;
+      // MCD_ULA_sn (mcd_over_orig.py:40-46): evaluation e >= 1 serves only the backward kernel of step e-1, index e-1
+      const int64_t erow = a.ula ? (e > 0 ? e - 1 : 0) : e;
+      const float fsn = a.ula ? 0.f : 1.f;
+      const float* brow = bias1 + erow * HP;
       // wide nets (T > 4): the first pre-activation is not kept, it is rebuilt from the bias row and z where the
       // backward pass needs it (2 D FMAs per value against 4 T registers held across both MFMA phases)
       constexpr bool KEEP_A1 = T <= 4;
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) u1[t][r] = gelu_fast(pre[r]);
         } else {
-          f32x4 u = *reinterpret_cast<const f32x4*>(utab + (int64_t)e * HP + 16 * t + 4 * g);
+          f32x4 u = *reinterpret_cast<const f32x4*>(utab + erow * HP + 16 * t + 4 * g);
           if (16 * t < D) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -383,14 +387,14 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
 #pragma unroll
           for (int j = 0; j < D; ++j) {
             const float uf = -1.0f * (be * gp[j] + (1.0f - be) * gq[j]);
-            const float fk = z[j] - ee * uf - ee * sn[j];
+            const float fk = z[j] - ee * uf - fsn * ee * sn[j];
             const float nsig = (znext[j] - fk) * inv2e;        // n_e / sigma_e
-            cot[j] -= ee * lamn[j];
+            cot[j] -= fsn * ee * lamn[j];
             a_gp[j] += ee * be * lamn[j];
             a_gq[j] += ee * (1.0f - be) * lamn[j];
             lam[j] += lamn[j] - gE[j];
             sb += (gp[j] - gq[j]) * lamn[j];
-            se += (nsig - uf - sn[j]) * lamn[j];
+            se += (nsig - uf - fsn * sn[j]) * lamn[j];
           }
           const float tb = row_sum16(pend_beta + ee * sb), te = row_sum16(pend_eps + se);
           if (lane == 0) {
@@ -639,8 +643,8 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
             if (row < D) atomicAdd(accZ1 + row * HP + 16 * t + c, sacc[r]);            // dW1[row][n] += z_row . d a1[n]
             if (row == D) {
               atomicAdd(accB2 + 16 * t + c, bacc[r]);                                  // db2[n] += sum_p d a2
-              atomicAdd(gS + (int64_t)e * HP + 16 * t + c, sacc[r]);                   // d / d bias-table row e
-              if (GEF) atomicAdd(gS2 + (int64_t)e * HP + 16 * t + c, s2acc[r]);
+              atomicAdd(gS + erow * HP + 16 * t + c, sacc[r]);                        // d / d bias-table row used
+              if (GEF) atomicAdd(gS2 + erow * HP + 16 * t + c, s2acc[r]);
             }
           }
         }
@@ -734,7 +738,7 @@ struct JacArgs {
   cmcd_layout lay;
   WsLayout w;
   int64_t n, nitems;
-  int32_t K, grad_clipping;
+  int32_t K, grad_clipping, ula;
   float omega;
 };
 
@@ -794,7 +798,9 @@ __global__ __launch_bounds__(256) void bptt_jac_kernel(JacArgs a) {
       zp[j] = e > 0 ? a.traj[((int64_t)(e - 1) * a.n + pc) * D + j] : 0.f;
     }
     // ---- forward, keeping the activation derivatives
-    const float* brow = bias1 + (int64_t)e * HP;
+    const int64_t erow = a.ula ? (e > 0 ? e - 1 : 0) : e;
+    const float fsn = a.ula ? 0.f : 1.f;
+    const float* brow = bias1 + erow * HP;
     f32x4 u1[T], s1[T], a2[T], s2[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
@@ -805,7 +811,7 @@ __global__ __launch_bounds__(256) void bptt_jac_kernel(JacArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { u1[t][r] = gelu_fast(pre[r]); s1[t][r] = gelu_grad_fast(pre[r]); }
       } else {
-        f32x4 u = *reinterpret_cast<const f32x4*>(utab + (int64_t)e * HP + 16 * t + 4 * g);
+        f32x4 u = *reinterpret_cast<const f32x4*>(utab + erow * HP + 16 * t + 4 * g);
         if (16 * t < D) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -957,7 +963,7 @@ __global__ __launch_bounds__(256) void bptt_jac_kernel(JacArgs a) {
       for (int j = 0; j < D; ++j) {
 #pragma unroll
         for (int k = 0; k < D; ++k) {
-          float v = -ee * Js[j][k] + ee * be * Hm[j][k];
+          float v = -fsn * ee * Js[j][k] + ee * be * Hm[j][k];
           if (j == k) v += 1.0f - ee * (1.0f - be) * qiv[k];
           row[j * D + k] = e < K ? v : 0.f;
         }
@@ -1016,6 +1022,142 @@ __global__ void bptt_scan_kernel(ScanArgs a) {
       }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// MCD_ULA (no network; /root/reference/src/mcd_over_orig.py with use_sn = False): the reverse recursion
+// without the MLP — target Hessian product, q, schedules.  One wave per 16-particle tile, whole chain.
+// ------------------------------------------------------------------------------------------
+struct UlaGradArgs {
+  const float* params;
+  const float* ws;
+  const float* traj;     // [K+1][n][D]
+  float* gtab;           // gbeta at o_gbeta, geps at o_geps
+  float* gvd;            // [ntiles][2 D] per-tile q-gradient rows
+  cmcd_layout lay;
+  WsLayout w;
+  int64_t n, o_gbeta, o_geps;
+  int32_t K;
+  float omega;
+};
+
+template <int TARGET, int D>
+__global__ __launch_bounds__(256) void ula_grad_kernel(UlaGradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds_tgt[];
+  for (int i = threadIdx.x; i < a.w.tgt_floats; i += blockDim.x) lds_tgt[i] = a.ws[a.w.tgt + i];
+  __syncthreads();
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  const int64_t tile = (int64_t)blockIdx.x * 4 + wv;
+  if (tile * 16 >= a.n) return;
+  const int64_t p = tile * 16 + c;
+  const bool valid = p < a.n;
+  const int64_t pc = valid ? p : a.n - 1;
+  const float om = valid ? a.omega : 0.f;
+  const int K = a.K;
+  float qmean[D], qiv[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    qmean[j] = a.params[a.lay.vd_mean + j];
+    const float sd = expf(a.params[a.lay.vd_logdiag + j]);
+    qiv[j] = 1.0f / (sd * sd);
+  }
+  constexpr int HN = Target<TARGET, D>::HN;
+  float lamn[D], gE[D], znext[D], gmu[D], glam[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) { lamn[j] = 0.f; gE[j] = 0.f; znext[j] = 0.f; gmu[j] = 0.f; glam[j] = 0.f; }
+  float pend_beta = 0.f, pend_eps = 0.f;
+  for (int e = K; e >= 0; --e) {
+    float z[D], zp[D], gp[D], gq[D], hs[HN], logp;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      z[j] = a.traj[((int64_t)e * a.n + pc) * D + j];
+      zp[j] = e > 0 ? a.traj[((int64_t)(e - 1) * a.n + pc) * D + j] : 0.f;
+    }
+    Target<TARGET, D>::eval_hess(z, g, lds_tgt, logp, gp, hs);
+#pragma unroll
+    for (int j = 0; j < D; ++j) gq[j] = -(z[j] - qmean[j]) * qiv[j];
+    float a_gp[D], a_gq[D], gprev[D], lam[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) { a_gp[j] = 0.f; a_gq[j] = 0.f; gprev[j] = 0.f; lam[j] = 0.f; }
+    float npb = 0.f, npe = 0.f;
+    if (e > 0) {
+      const float pb = a.ws[a.w.beta + e - 1], pe = a.ws[a.w.eps + e - 1];
+      const float inv2e = 0.5f / pe;
+      float sb = 0.f, se = 0.f, r2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        const float ub = -1.0f * (pb * gp[j] + (1.0f - pb) * gq[j]);
+        const float r = zp[j] - (z[j] - pe * ub);
+        gprev[j] = -om * r * inv2e;
+        a_gp[j] += pe * pb * gprev[j];
+        a_gq[j] += pe * (1.0f - pb) * gprev[j];
+        lam[j] += gprev[j];
+        sb += (gp[j] - gq[j]) * gprev[j];
+        se += -ub * gprev[j];
+        r2 += r * r;
+      }
+      npb = pe * sb;
+      npe = se - om * r2 * inv2e * inv2e;
+    }
+    if (e < K) {
+      const float be = a.ws[a.w.beta + e], ee = a.ws[a.w.eps + e];
+      const float inv2e = 0.5f / ee;
+      float sb = 0.f, se = 0.f;
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        const float uf = -1.0f * (be * gp[j] + (1.0f - be) * gq[j]);
+        const float fk = z[j] - ee * uf;
+        const float nsig = (znext[j] - fk) * inv2e;
+        a_gp[j] += ee * be * lamn[j];
+        a_gq[j] += ee * (1.0f - be) * lamn[j];
+        lam[j] += lamn[j] - gE[j];
+        sb += (gp[j] - gq[j]) * lamn[j];
+        se += (nsig - uf) * lamn[j];
+      }
+      const float tb = row_sum16(pend_beta + ee * sb), te = row_sum16(pend_eps + se);
+      if (lane == 0) {
+        atomicAdd(a.gtab + a.o_gbeta + e, tb);
+        atomicAdd(a.gtab + a.o_geps + e, te);
+      }
+    }
+    pend_beta = npb; pend_eps = npe;
+    float hv[D];
+    Target<TARGET, D>::hvp(hs, z, a_gp, hv);
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      if (e == K) lam[j] -= om * gp[j];
+      if (e == 0) lam[j] += om * gq[j];
+      gmu[j] += a_gq[j] * qiv[j];
+      glam[j] += a_gq[j] * (-2.0f * gq[j]);
+      lam[j] += hv[j] - a_gq[j] * qiv[j];
+      if (e == 0) {
+        const float dz = z[j] - qmean[j];
+        gmu[j] += lam[j] - om * gq[j];
+        glam[j] += lam[j] * dz + om * (dz * dz * qiv[j] - 1.0f);
+      }
+      gE[j] = gprev[j];
+      lamn[j] = lam[j];
+      znext[j] = z[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    const float tm = row_sum16(gmu[j]), tl = row_sum16(glam[j]);
+    if (lane == 0) {
+      a.gvd[tile * (2 * D) + j] = tm;
+      a.gvd[tile * (2 * D) + D + j] = tl;
+    }
+  }
+}
+
+// d vd.mean / d vd.logdiag: fixed-order sum of the per-tile rows
+__global__ void ula_vd_reduce_kernel(const float* rows, int64_t ntiles, int D, float* grad, int64_t o_mean, int64_t o_logdiag) {
+  const int j = threadIdx.x;
+  if (j >= 2 * D) return;
+  float v = 0.f;
+  for (int64_t t = 0; t < ntiles; ++t) v += rows[t * 2 * D + j];
+  if (j < D) grad[o_mean + j] = v;
+  else grad[o_logdiag + (j - D)] = v;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1332,6 +1474,7 @@ int grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, c
   ga.seeds = seeds; ga.params = params; ga.ws = ws_fwd; ga.omega = omega; ga.omega_scalar = omega_scalar; ga.traj = traj; ga.gtab = gws; ga.slabs = gws + tot;
   ga.lay = lay; ga.w = w; ga.n = n; ga.K = K; ga.var_mode = d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0;
   ga.grad_clipping = d.grad_clipping; ga.nquads = (int)((n + 16 * nw - 1) / (16 * nw));
+  ga.ula = d.mode == CMCD_MODE_ULA_SN ? 2 : 0;
   ga.nitems = nitems;
   ga.slab_stride = (int64_t)HP * HP + HP * 16 + 4 * (2 * 16 * HP + 256 + 32);
   if (hipMemsetAsync(gws, 0, sizeof(float) * tot, stream) != hipSuccess) return CMCD_ERR_HIP;
@@ -1343,7 +1486,7 @@ int grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, c
     const int64_t S = (int64_t)D * D + 2 * D;
     float* jac = item_ws;
     float* lam = item_ws + (int64_t)(K + 1) * n * S;
-    JacArgs ja{params, ws_fwd, traj, jac, lay, w, n, nitems, K, d.grad_clipping, omega_scalar};
+    JacArgs ja{params, ws_fwd, traj, jac, lay, w, n, nitems, K, d.grad_clipping, d.mode == CMCD_MODE_ULA_SN ? 2 : 0, omega_scalar};
     const size_t jl = size_t(HP * HP + 2 * D * HP + HP + 16 + w.tgt_floats) * 4;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(jf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)jl) != hipSuccess)
       return CMCD_ERR_HIP;
@@ -1377,6 +1520,39 @@ int grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, c
   hipLaunchKernelGGL(grad_sched_tail_kernel, dim3(1), dim3(256), 0, stream, ta);
   if (d.arch == CMCD_ARCH_DDS) hipLaunchKernelGGL(grad_dds_tail_kernel, dim3(K + 1), dim3(64), 0, stream, ta);
   else hipLaunchKernelGGL(grad_geffner_tail_kernel, dim3(64), dim3(256), 0, stream, ta);
+  return hipGetLastError() == hipSuccess ? CMCD_OK : CMCD_ERR_HIP;
+}
+
+typedef void (*ula_fn)(UlaGradArgs);
+static ula_fn pick_ula(const cmcd_desc& d) {
+  if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2) return ula_grad_kernel<CMCD_TARGET_MANY_GMM, 2>;
+  if (d.target == CMCD_TARGET_GMM && d.dim == 2) return ula_grad_kernel<CMCD_TARGET_GMM, 2>;
+  if (d.target == CMCD_TARGET_FUNNEL && d.dim == 10) return ula_grad_kernel<CMCD_TARGET_FUNNEL, 10>;
+  return nullptr;
+}
+bool ula_grad_available(const cmcd_desc& d) { return pick_ula(d) != nullptr; }
+int64_t ula_grad_workspace_floats(const cmcd_desc& d, int64_t n) {
+  return (((int64_t)d.nbridges + 3) & ~int64_t(3)) * 2 + ((n + 15) / 16) * 2 * d.dim + 8;
+}
+
+// MCD_ULA: reverse sweep without a network.  gws: ula_grad_workspace_floats; ws_fwd / traj as left by the forward.
+int ula_grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, int64_t n, const float* params,
+                    int64_t n_params, const float* ws_fwd, const float* traj, float* gws, float omega, float* grad,
+                    void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  ula_fn fn = pick_ula(d);
+  if (!fn) return CMCD_ERR_UNSUPPORTED;
+  const int64_t K4 = ((int64_t)d.nbridges + 3) & ~int64_t(3), ntiles = (n + 15) / 16;
+  if (hipMemsetAsync(grad, 0, sizeof(float) * n_params, stream) != hipSuccess) return CMCD_ERR_HIP;
+  if (hipMemsetAsync(gws, 0, sizeof(float) * 2 * K4, stream) != hipSuccess) return CMCD_ERR_HIP;
+  UlaGradArgs a{params, ws_fwd, traj, gws, gws + 2 * K4, lay, w, n, 0, K4, d.nbridges, omega};
+  hipLaunchKernelGGL(fn, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), (size_t)(w.tgt_floats + 4) * 4, stream, a);
+  hipLaunchKernelGGL(ula_vd_reduce_kernel, dim3(1), dim3(64), 0, stream, gws + 2 * K4, ntiles, d.dim, grad, lay.vd_mean,
+                     lay.vd_logdiag);
+  TailArgs ta{};
+  ta.params = params; ta.gtab = gws; ta.grad = grad; ta.lay = lay; ta.w = w; ta.o_gbeta = 0; ta.o_geps = K4;
+  ta.K = d.nbridges; ta.D = d.dim; ta.eps_schedule = CMCD_EPS_CONST; ta.ngrid = d.ngrid;
+  hipLaunchKernelGGL(grad_sched_tail_kernel, dim3(1), dim3(256), 0, stream, ta);
   return hipGetLastError() == hipSuccess ? CMCD_OK : CMCD_ERR_HIP;
 }
 

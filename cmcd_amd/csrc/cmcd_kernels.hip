@@ -1016,7 +1016,12 @@ int64_t cmcd_bound_grad_workspace_bytes(const cmcd_desc* desc, int64_t n) {
   WsLayout w;
   const int64_t nt = desc->target == CMCD_TARGET_MANY_GMM ? 1 + 2 * 64 : 0;
   if (!make_ws(*desc, n, nt, w)) return 0;
-  if (desc->mode != CMCD_MODE_CAIS_SN || !bptt_available(*desc, w.T)) {
+  if (desc->mode == CMCD_MODE_ULA) {
+    if (!ula_grad_available(*desc)) { fail(CMCD_ERR_UNSUPPORTED, "no MCD_ULA gradient instance for this target%s"); return 0; }
+    return (align4(w.total_floats) + align4(ula_grad_workspace_floats(*desc, n)) +
+            (int64_t)(desc->nbridges + 1) * n * desc->dim) * 4;
+  }
+  if ((desc->mode != CMCD_MODE_CAIS_SN && desc->mode != CMCD_MODE_ULA_SN) || !bptt_available(*desc, w.T)) {
     fail(CMCD_ERR_UNSUPPORTED, "no reparameterised-gradient kernel instance for this (mode, target, dim, arch, width)%s");
     return 0;
   }
@@ -1032,9 +1037,13 @@ int cmcd_bound_grad(const cmcd_desc* desc, const cmcd_layout* lay, const int32_t
   int rc = check_desc(desc);
   if (rc != CMCD_OK) return rc;
   if (!grad) return fail(CMCD_ERR_BAD_ARG, "null pointer argument%s");
-  if (desc->mode != CMCD_MODE_CAIS_SN)
-    return fail(CMCD_ERR_UNSUPPORTED, "the reparameterised gradient exists for MCD_CAIS_sn only (MCD_CAIS_var_sn: cmcd_bound_var_grad)%s");
-  const cmcd_desc& d = *desc;
+  if (desc->mode != CMCD_MODE_CAIS_SN &&
+      !((desc->mode == CMCD_MODE_ULA_SN || desc->mode == CMCD_MODE_ULA) && desc->target != CMCD_TARGET_LGCP))
+    return fail(CMCD_ERR_UNSUPPORTED, "the reparameterised gradient exists for MCD_CAIS_sn and MCD_ULA_sn (MCD_CAIS_var_sn: cmcd_bound_var_grad)%s");
+  // MCD_ULA_sn: the reference's dispatcher passes neither eps_schedule nor grad_clipping (mcd_utils.py:35-58)
+  cmcd_desc dd = *desc;
+  if (dd.mode == CMCD_MODE_ULA_SN || dd.mode == CMCD_MODE_ULA) { dd.eps_schedule = CMCD_EPS_CONST; dd.grad_clipping = 0; }
+  const cmcd_desc& d = dd;
   if (d.target == CMCD_TARGET_LGCP) {
     // d = 1600: launch-sequence forward (trajectory kept) + launch-sequence reverse sweep (cmcd_lgcp.hip)
     WsLayout lw;
@@ -1055,6 +1064,21 @@ int cmcd_bound_grad(const cmcd_desc* desc, const cmcd_layout* lay, const int32_t
   }
   WsLayout w;
   if (!make_ws(d, n, n_target, w)) return fail(CMCD_ERR_BAD_ARG, "bad descriptor%s");
+  if (d.mode == CMCD_MODE_ULA) {   // no network: forward with the trajectory kept + the network-free reverse sweep
+    if (!ula_grad_available(d)) return fail(CMCD_ERR_UNSUPPORTED, "no MCD_ULA gradient instance for this target%s");
+    const int64_t fwd = align4(w.total_floats), gfl = align4(ula_grad_workspace_floats(d, n));
+    const int64_t need = (fwd + gfl + (int64_t)(d.nbridges + 1) * n * d.dim) * 4;
+    if (workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15))
+      return fail(CMCD_ERR_WORKSPACE, "workspace too small or not 16-byte aligned (need %s%lld bytes)", "", need);
+    float* ws = static_cast<float*>(workspace);
+    float* traj = ws + fwd + gfl;
+    rc = forward_impl(desc, lay, seeds, n, params, n_params, target_consts, n_target, workspace, fwd * 4, out_loss,
+                      out_z, out_stats, traj, stream_);
+    if (rc != CMCD_OK) return rc;
+    rc = ula_grad_launch(d, *lay, w, n, params, n_params, ws, traj, ws + fwd, omega, grad, stream_);
+    if (rc != CMCD_OK) return fail(rc, "gradient launch failed%s");
+    return CMCD_OK;
+  }
   if (!bptt_available(d, w.T)) return fail(CMCD_ERR_UNSUPPORTED, "no reparameterised-gradient kernel instance for this (target, dim, arch, width)%s");
   const int64_t fwd = align4(w.total_floats), gfl = align4(grad_workspace_floats(d, w.HP, n));
   const int64_t tfl = align4((int64_t)(d.nbridges + 1) * n * d.dim);

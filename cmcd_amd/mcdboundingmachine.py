@@ -360,9 +360,11 @@ def compute_bound_grad(seeds, params_flat, unflatten, params_fixed, log_prob, ep
     Returns (grad_flat, (losses, z)) [+ stats with return_stats]; multi-GPU: pass the global particle count
     as `n_total` and all-reduce the returned gradient."""
     dim, nbridges, mode, spec = params_fixed
-    if mode != "MCD_CAIS_sn":
+    if mode not in ("MCD_CAIS_sn", "MCD_ULA_sn", "MCD_ULA"):   # the two overdamped baselines take the same call
         raise NotImplementedError("Mode not implemented.")
-    if not isinstance(spec, ScoreNet):
+    if mode == "MCD_ULA":
+        spec = ScoreNet("dds", dim, 64, 0, 64)   # placeholder: MCD_ULA has no network (apply_fun_sn is None)
+    elif not isinstance(spec, ScoreNet):
         raise ValueError("params_fixed[3] must be the ScoreNet returned by initialize()")
     if not hasattr(log_prob, "target_id"):
         raise TypeError("log_prob must be a cmcd_amd.model_handler.Target (see load_model)")
@@ -384,7 +386,7 @@ def compute_bound_grad(seeds, params_flat, unflatten, params_fixed, log_prob, ep
                      emb_dim=spec.emb_dim, target=log_prob.target_id,
                      eps_schedule=_lib.EPS_SCHEDULE[eps_schedule], grad_clipping=int(bool(grad_clipping)),
                      ngrid=unflatten.shape("mgridref_y")[0] - 1, reserved=KERNEL_VARIANT)
-    lay = _layout(unflatten, spec)
+    lay = _layout(unflatten, spec) if mode != "MCD_ULA" else _layout_no_net(unflatten)
     nbytes = L.cmcd_bound_grad_workspace_bytes(C.byref(desc), n)
     if nbytes <= 0:
         raise NotImplementedError(_lib.last_error() or "no gradient kernel for this configuration")

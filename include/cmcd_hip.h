@@ -169,6 +169,7 @@ int cmcd_bound_var_grad_kept(const cmcd_desc* desc, const cmcd_layout* layout, c
  * One call = forward (losses, z_K, statistics as cmcd_bound_forward; the trajectory z_0..z_K is kept in
  * the workspace) + reverse sweep.  grad[n_params] (overwritten) = omega * sum_n d loss_n / d params_flat;
  * omega = d value / d loss_n = 1 / N_total (across ranks: all-reduce(sum) of grad).
+ * Also MCD_ULA_sn and MCD_ULA (/root/reference/src/mcd_over_orig.py; 2-d targets and funnel).
  * MCD_CAIS_sn with targets gmm / funnel / many_gmm and the BASELINE nets (dds 64; geffner 22 / 58), and lgcp
  * (geffner, any width: launch-sequence reverse sweep); CMCD_ERR_UNSUPPORTED otherwise (width 132 on the 2-d targets). */
 int64_t cmcd_bound_grad_workspace_bytes(const cmcd_desc* desc, int64_t n);

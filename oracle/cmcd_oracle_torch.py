@@ -134,11 +134,16 @@ def to_torch(params, requires_grad=True):
 def losses(seeds, p, dim, nbridges, mode, arch, target_name, eps_schedule=None, grad_clipping=False):
     """Per-particle losses [N] (float64), differentiable wrt the leaves of `p`."""
     var_mode = mode == "MCD_CAIS_var_sn"
+    # MCD_ULA / MCD_ULA_sn (/root/reference/src/mcd_over_orig.py:6-65 via mcd_utils.py:35-58): constant eps, no
+    # clipping, no network in the forward kernel; the backward kernel's network (ULA_sn only) takes index i
+    ula = mode in ("MCD_ULA", "MCD_ULA_sn")
+    if ula:
+        grad_clipping, eps_schedule = False, None
     logp_fn = TARGETS[target_name] if isinstance(target_name, str) else target_name   # or a log-density callable
     e0, noise = prng.particle_noise(np.asarray(seeds), dim, nbridges)
     e0 = torch.tensor(e0.astype(np.float64))
     noise = torch.tensor(noise.astype(np.float64))
-    vd, sn = p["vd"], p["sn"]
+    vd, sn = p["vd"], p.get("sn")
     std = torch.exp(vd["logdiag"])
     betas = betas_from_grid(p["mgridref_y"], nbridges)
     eps_tab = eps_table(p["eps"], nbridges, eps_schedule)
@@ -168,13 +173,16 @@ def losses(seeds, p, dim, nbridges, mode, arch, target_name, eps_schedule=None, 
         if var_mode:
             z = z.detach()                             # mcd_cais_var.py:59
         uf = grad_u(z, beta)
-        fk = z - eps * uf - eps * apply(sn, z, i)
+        fk = z - eps * uf if ula else z - eps * uf - eps * apply(sn, z, i)
         scale = torch.sqrt(2 * eps)
         z_new = fk + scale * noise[:, i, :]
         if var_mode:
             z_new = z_new.detach()                     # mcd_cais_var.py:79
         ub = grad_u(z_new, beta)
-        bk = z_new - eps * ub + eps * apply(sn, z_new, i + 1)
+        if mode == "MCD_ULA":
+            bk = z_new - eps * ub
+        else:
+            bk = z_new - eps * ub + eps * apply(sn, z_new, i if ula else i + 1)
         w = w + log_kernel(z, bk, scale) - log_kernel(z_new, fk, scale)
         z = z_new
     w = w + logp_fn(z)

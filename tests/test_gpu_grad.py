@@ -324,3 +324,55 @@ def test_lgcp_reparameterised_gradient_matches_autograd(hip_lib, n, K, clip):
     print({k: "%.1e (|ref| %.1e)" % v for k, v in worst.items()})
     bad = {k: v for k, v in worst.items() if v[0] > 5e-3 and v[1] > 1e-9}
     assert not bad, bad
+
+
+ULA_CASES = [
+    ("many_gmm_n2000_k256_dds", 70, dict(nbridges=6, init_sigma=15.0, init_eps=0.2)),
+    ("gmm_n300_k8", 96, dict()),
+    ("funnel_n300_k64", 40, dict(nbridges=5)),
+]
+
+
+@pytest.mark.parametrize("variant,item", [(1, 0), (2, 1), (1, 1)])
+@pytest.mark.parametrize("name,n,over", ULA_CASES)
+def test_ula_sn_gradient_matches_autograd(hip_lib, monkeypatch, name, n, over, variant, item):
+    """MCD_ULA_sn (the "MCD" baseline, /root/reference/src/mcd_over_orig.py): network only in the backward kernel
+    with index i, constant eps, no clipping — same reverse recursion, through both gradient paths."""
+    monkeypatch.setattr(mcdbm, "KERNEL_VARIANT", variant)
+    monkeypatch.setenv("CMCD_GRAD_ITEM", str(item))
+    b = synthetic.build(name, device="cuda", boundmode="MCD_ULA_sn", **over)
+    seeds = synthetic.parity_seeds(n)
+    grad, (losses, z) = mcdbm.compute_bound_grad(torch.from_numpy(seeds).cuda(), b["params_flat"], b["unflatten"],
+                                                 b["params_fixed"], b["target"], eps_schedule=b["eps_schedule"],
+                                                 grad_clipping=b["grad_clipping"])
+    torch.cuda.synchronize()
+    val, l_ref, g_ref = oracle_grad_flat(b, seeds)
+    assert np.isfinite(l_ref).all()
+    np.testing.assert_allclose(losses.cpu().numpy(), l_ref, rtol=2e-3, atol=2e-3)
+    _compare(name, over, b["unflatten"], grad.double().cpu(), g_ref)
+
+
+@pytest.mark.parametrize("name,n,over", ULA_CASES)
+def test_ula_gradient_matches_autograd(hip_lib, name, n, over):
+    """MCD_ULA (no network): gradient w.r.t. eps, the schedule grid and q through the network-free reverse sweep."""
+    b = synthetic.build(name, device="cuda", boundmode="MCD_ULA", **over)
+    seeds = synthetic.parity_seeds(n)
+    grad, (losses, z) = mcdbm.compute_bound_grad(torch.from_numpy(seeds).cuda(), b["params_flat"], b["unflatten"],
+                                                 b["params_fixed"], b["target"])
+    torch.cuda.synchronize()
+    dim, K, mode, _ = b["params_fixed"]
+    flat = b["params_flat"].detach().cpu()
+    train, notrain = b["unflatten"](flat)
+    allp = {**train, **notrain}
+    f = lambda t: np.asarray(t.numpy(), np.float64)
+    p = {"vd": {k: f(v) for k, v in allp["vd"].items()}, "eps": f(allp["eps"]), "mgridref_y": f(allp["mgridref_y"]),
+         "gridref_x": f(allp["gridref_x"]), "target_x": f(allp["target_x"])}
+    val, l_ref, _, g = ot.bound_and_grad(seeds, p, dim, K, mode, "dds", b["cfg"]["model"], None, False)
+    np.testing.assert_allclose(losses.cpu().numpy(), l_ref, rtol=2e-3, atol=2e-3)
+    un, gh = b["unflatten"], grad.double().cpu().numpy()
+    for path, ref in ((("vd", "mean"), g["vd"]["mean"]), (("vd", "logdiag"), g["vd"]["logdiag"]), (("eps",), g["eps"]),
+                      (("mgridref_y",), g["mgridref_y"])):
+        off = un.offset(*path)
+        ref = np.asarray(ref, np.float64).reshape(-1)
+        got = gh[off:off + ref.size]
+        assert np.abs(got - ref).max() <= 2e-3 * max(np.abs(ref).max(), 1e-9), (path, got, ref)
