@@ -268,10 +268,15 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
         f32x4 pre = *reinterpret_cast<const f32x4*>(brow + 16 * t + 4 * g);
 #pragma unroll
         for (int j = 0; j < D; ++j) pre += z[j] * *reinterpret_cast<const f32x4*>(lds_w1z + j * HP + 16 * t + 4 * g);
-        if (KEEP_A1) a1[KEEP_A1 ? t : 0] = pre;
+        // a1 / a2 hold the activation DERIVATIVES from here on (one polynomial + exponential for both)
+        f32x4 dact = {0.f, 0.f, 0.f, 0.f};
         if (!GEF) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) u1[t][r] = gelu_fast(pre[r]);
+          for (int r = 0; r < 4; ++r) {
+            float dv = 0.f;
+            u1[t][r] = KEEP_A1 ? gelu_fast_both(pre[r], dv) : gelu_fast(pre[r]);
+            dact[r] = dv;
+          }
         } else {
           f32x4 u = *reinterpret_cast<const f32x4*>(utab + erow * HP + 16 * t + 4 * g);
           if (16 * t < D) {
@@ -284,8 +289,13 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
             }
           }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) u1[t][r] = u[r] + softplus(pre[r]);
+          for (int r = 0; r < 4; ++r) {
+            float dv = 0.f;
+            u1[t][r] = u[r] + (KEEP_A1 ? softplus_both(pre[r], dv) : softplus(pre[r]));
+            dact[r] = dv;
+          }
         }
+        if (KEEP_A1) a1[KEEP_A1 ? t : 0] = dact;
         // stage u1^T now (every wave finished reading the previous evaluation's tiles at the closing barrier)
 #pragma unroll
         for (int r = 0; r < 4; ++r) u1T[wb[r] + 256 * t] = u1[t][r];
@@ -316,7 +326,9 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
           f32x4 u2t;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            u2t[r] = GEF ? u1[t][r] + softplus(a2[t][r]) : gelu_fast(a2[t][r]);
+            float dact2;
+            u2t[r] = GEF ? u1[t][r] + softplus_both(a2[t][r], dact2) : gelu_fast_both(a2[t][r], dact2);
+            a2[t][r] = dact2;
             u2T[wb[r] + 256 * t] = u2t[r];
           }
 #pragma unroll
@@ -534,7 +546,7 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
         for (int j = 0; j < D; ++j) du2 += dob[j] * *reinterpret_cast<const f32x4*>(lds_w3t + j * HP + 16 * t + 4 * g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          d2[t][r] = du2[r] * (GEF ? sigmoid_fast(a2[t][r]) : gelu_grad_fast(a2[t][r]));
+          d2[t][r] = du2[r] * a2[t][r];
           da2T[wb[r] + 256 * t] = d2[t][r];
         }
         if (GEF) a2[t] = du2;  // keep d u2 (residual path) in a2's registers
@@ -577,7 +589,7 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
             for (int j = 0; j < D; ++j)
               if (j >= 16 * t && j < 16 * t + 16) jpart[j] += (16 * t + 4 * g + r == j) ? d1[t][r] : 0.f;
           }
-          d1[t][r] *= GEF ? sigmoid_fast(pre1[r]) : gelu_grad_fast(pre1[r]);
+          d1[t][r] *= KEEP_A1 ? pre1[r] : (GEF ? sigmoid_fast(pre1[r]) : gelu_grad_fast(pre1[r]));
           da1T[o] = d1[t][r];
         }
         if (BPTT && !ITEM) {
@@ -809,7 +821,11 @@ __global__ __launch_bounds__(256) void bptt_jac_kernel(JacArgs a) {
       for (int j = 0; j < D; ++j) pre += z[j] * *reinterpret_cast<const f32x4*>(lds_w1z + j * HP + 16 * t + 4 * g);
       if (!GEF) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { u1[t][r] = gelu_fast(pre[r]); s1[t][r] = gelu_grad_fast(pre[r]); }
+        for (int r = 0; r < 4; ++r) {
+          float dv;
+          u1[t][r] = gelu_fast_both(pre[r], dv);
+          s1[t][r] = dv;
+        }
       } else {
         f32x4 u = *reinterpret_cast<const f32x4*>(utab + erow * HP + 16 * t + 4 * g);
         if (16 * t < D) {
@@ -822,7 +838,11 @@ __global__ __launch_bounds__(256) void bptt_jac_kernel(JacArgs a) {
           }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { u1[t][r] = u[r] + softplus(pre[r]); s1[t][r] = sigmoid_fast(pre[r]); }
+        for (int r = 0; r < 4; ++r) {
+          float dv;
+          u1[t][r] = u[r] + softplus_both(pre[r], dv);
+          s1[t][r] = dv;
+        }
       }
     }
 #pragma unroll
@@ -847,8 +867,9 @@ __global__ __launch_bounds__(256) void bptt_jac_kernel(JacArgs a) {
         f32x4 u2t;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          u2t[r] = GEF ? u1[t][r] + softplus(a2[t][r]) : gelu_fast(a2[t][r]);
-          s2[t][r] = GEF ? sigmoid_fast(a2[t][r]) : gelu_grad_fast(a2[t][r]);
+          float dv;
+          u2t[r] = GEF ? u1[t][r] + softplus_both(a2[t][r], dv) : gelu_fast_both(a2[t][r], dv);
+          s2[t][r] = dv;
         }
 #pragma unroll
         for (int j = 0; j < D; ++j) {
