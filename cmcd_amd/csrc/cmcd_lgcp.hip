@@ -182,6 +182,7 @@ struct LgcpStateArgs {
   float* out_loss;           // [M]
   float* out_z;              // [M][D]
   double* partials;          // [M][5]
+  float* xm;                 // [kMP][D]   z - mu0 of the CURRENT z: the next GEMM's input (no separate launch)
   float* traj;               // optional [K+1][n_total][D]: z_0..z_K of every particle (reverse sweep of the gradient)
   int64_t n_total, base;     // trajectory row of particle p of this pass: base + p
   cmcd_layout lay;
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(256) void lgcp_init_kernel(LgcpStateArgs a) {
         const float sd = expf(a.params[a.lay.vd_logdiag + idx[q]]);
         const float z = sd * bits_to_normal(bits[q]) + mean;
         a.x[p * D + idx[q]] = z;
+        if (a.xm) a.xm[p * D + idx[q]] = z - a.tc[(int64_t)D * D + D];
         if (a.traj) a.traj[(a.base + p) * D + idx[q]] = z;
         const float dz = z - mean;
         acc += -(dz * dz) / (2.0f * sd * sd) - logf(sd) - kHalfLog2Pi;
@@ -303,6 +305,7 @@ __global__ __launch_bounds__(256) void lgcp_step_kernel(LgcpStateArgs a) {
           fk_acc += -(df * df) * inv2s2 - cst;
           a.xp[p * D + e] = z;
           a.x[p * D + e] = zn;
+          a.xm[p * D + e] = zn - mu0;
           if (a.traj) a.traj[((int64_t)(i + 1) * a.n_total + a.base + p) * D + e] = zn;
         }
       }
@@ -396,7 +399,7 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
     st.w = ws + w.w; st.fklp = ws + w.fklp; st.keys = reinterpret_cast<uint32_t*>(ws + w.keys);
     st.out_loss = out_loss + base; st.out_z = out_z + base * D; st.partials = partials + base * CMCD_NSTATS;
     st.lay = lay; st.M = M; st.D = D; st.K = K;
-    st.traj = traj; st.n_total = n; st.base = base;
+    st.traj = traj; st.n_total = n; st.base = base; st.xm = ws + w.xm;
     st.var_mode = d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0; st.grad_clipping = d.grad_clipping;
     hipLaunchKernelGGL(lgcp_init_kernel, dim3(M), dim3(256), 0, stream, st);
 
@@ -407,10 +410,7 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
     for (int i = 0; i <= K; ++i) {
       const int ie = i < K ? i : K - 1;
       act.emb = params + lay.g_emb + (int64_t)ie * E;
-      // x - mu0
-      act.mode = 0;
-      hipLaunchKernelGGL(lgcp_act_kernel, dim3((M * D + 255) / 256), dim3(256), 0, stream, act);
-      // A: [x - mu0] Kinv -> kr slabs  |  x W1[:D] -> pre1 slabs
+      // A: [x - mu0] Kinv -> kr slabs  |  x W1[:D] -> pre1 slabs   (x - mu0 written by the init / step kernel)
       g.Kdim = D;
       g.seg[0] = GemmSeg{ws + w.xm, kinv, ws + w.kr, D, D, D, D};
       g.seg[1] = GemmSeg{ws + w.x, params + lay.g_w1, ws + w.slab1, IN, D, IN, IN};
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(256) void lgcp_adj_step_kernel(LgcpAdjArgs a) {
   }
 }
 
-// backward activations: one thread per hidden unit k, loop over the <= kMP particles of the pass
+// backward activations: one thread per (particle, hidden unit)
 struct LgcpActbArgs {
   const float* slab;       // [kSplit][kMP][IN] partials of the incoming GEMM
   const float* pre;        // [kMP][IN] pre-activation of this layer
@@ -695,23 +695,19 @@ struct LgcpActbArgs {
 };
 
 __global__ void lgcp_actb_kernel(LgcpActbArgs a) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
   if (k >= a.IN) return;
-  float sa = 0.f, su = 0.f;
-  for (int m = 0; m < a.M; ++m) {
-    float du = a.mode == 1 ? a.du_prev[m * a.IN + k] : 0.f;
+  float du = a.mode == 1 ? a.du_prev[m * a.IN + k] : 0.f;
 #pragma unroll
-    for (int ks = 0; ks < kSplit; ++ks) du += a.slab[((int64_t)ks * kMP + m) * a.IN + k];
-    const float da = du * sigmoid_fast(a.pre[m * a.IN + k]);
-    a.du_out[m * a.IN + k] = du;
-    a.da_out[m * a.IN + k] = da;
-    a.da_big[(a.row0 + m) * a.IN + k] = da;
-    a.u_big[(a.row0 + m) * a.IN + k] = a.u_src[m * a.IN + k];
-    sa += da;
-    su += du;
-  }
-  if (a.mode == 1) { a.S[k] += sa; a.S2[k] += su; }   // accumulated over the passes of a large batch
-  else a.gb[k] += sa;
+  for (int ks = 0; ks < kSplit; ++ks) du += a.slab[((int64_t)ks * kMP + m) * a.IN + k];
+  const float da = du * sigmoid_fast(a.pre[m * a.IN + k]);
+  a.du_out[m * a.IN + k] = du;
+  a.da_out[m * a.IN + k] = da;
+  a.da_big[(a.row0 + m) * a.IN + k] = da;
+  a.u_big[(a.row0 + m) * a.IN + k] = a.u_src[m * a.IN + k];
+  // sums over the particles of the pass (<= 24 adders per address)
+  if (a.mode == 1) { atomicAdd(a.S + k, da); atomicAdd(a.S2 + k, du); }
+  else atomicAdd(a.gb + k, da);
 }
 
 struct LgcpLamArgs {
@@ -927,7 +923,7 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
       ab.slab = gws + g.du2s; ab.pre = ws + w.pre2; ab.du_prev = nullptr; ab.u_src = ws + w.u2;
       ab.du_out = gws + g.du2; ab.da_out = gws + g.da2; ab.da_big = gws + g.DA2; ab.u_big = gws + g.U2;
       ab.gb = gws + g.gb2; ab.row0 = row0; ab.M = M; ab.IN = IN; ab.mode = 2;
-      hipLaunchKernelGGL(lgcp_actb_kernel, dim3((IN + 255) / 256), dim3(256), 0, stream, ab);
+      hipLaunchKernelGGL(lgcp_actb_kernel, dim3((IN + 255) / 256, M), dim3(256), 0, stream, ab);
       // d u1 = d u2 + d a2 W2^T
       gm.Kdim = IN;
       gm.seg[0] = GemmSeg{gws + g.da2, gws + g.wt2, gws + g.ts, IN, IN, IN, IN};
@@ -936,7 +932,7 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
       ab.slab = gws + g.ts; ab.pre = ws + w.pre1; ab.du_prev = gws + g.du2; ab.u_src = ws + w.u1;
       ab.du_out = gws + g.du1; ab.da_out = gws + g.da1; ab.da_big = gws + g.DA1; ab.u_big = gws + g.U1;
       ab.S = gws + g.S + (int64_t)e * IN; ab.S2 = gws + g.S2 + (int64_t)e * IN; ab.mode = 1;
-      hipLaunchKernelGGL(lgcp_actb_kernel, dim3((IN + 255) / 256), dim3(256), 0, stream, ab);
+      hipLaunchKernelGGL(lgcp_actb_kernel, dim3((IN + 255) / 256, M), dim3(256), 0, stream, ab);
       // d x = d u1[:D] + d a1 W1[:D]^T   |   v K^-1
       gm.Kdim = IN;
       gm.seg[0] = GemmSeg{gws + g.da1, gws + g.wt1, gws + g.dxf, D, IN, IN, D};
