@@ -137,3 +137,37 @@ def sharded_bound_grad(seeds_global, value_and_grad_fn, group=None):
     out = dict(grad=grad, losses=losses, z=z, lo=lo, hi=hi, stats=stats)
     out.update(finalize(stats, n))
     return out
+
+
+def make_sharded_grad_and_loss(boundmode, eps_schedule=None, grad_clipping=False, group=None):
+    """`grad_and_loss` for `opt.run` under torchrun (one process per GPU): every rank draws the SAME global seed
+    vector (same generator seed), works on its contiguous block, and the gradient is all-reduced — the data-parallel
+    form of /root/reference/src/main.py:161-176.
+
+    * MCD_CAIS_var_sn: local forward -> all-gather + merge of the 5-double statistics (the global mean loss the
+      VarGrad weights need: BASELINE's "RCCL log-w all-reduce") -> local gradient -> one all-reduce of grad_flat;
+    * MCD_CAIS_sn / MCD_ULA_sn / MCD_ULA: weights 1 / N_total are known up front -> local value-and-gradient -> one
+      all-reduce of grad_flat.
+    Returns (grad_flat, (local losses, local z)); with no process group it is the plain single-GPU call."""
+    from . import mcdboundingmachine as mcdbm
+
+    def grad_and_loss(seeds_global, params_flat, unflatten, params_fixed, log_prob):
+        on = dist.is_available() and dist.is_initialized()
+        world, rank = (dist.get_world_size(group), dist.get_rank(group)) if on else (1, 0)
+        n = int(seeds_global.shape[0])
+        lo, hi = shard_range(n, world, rank)
+        if hi <= lo:
+            raise ValueError("fewer particles than ranks")
+        local = seeds_global[lo:hi]
+        if "var" in boundmode:
+            merge = (lambda st: merge_stats(all_gather_stats(st, group))) if world > 1 else None
+            grad, aux = mcdbm.compute_log_var_grad(local, params_flat, unflatten, params_fixed, log_prob,
+                                                   eps_schedule=eps_schedule, grad_clipping=grad_clipping,
+                                                   n_total=n, stats_total=merge)
+        else:
+            grad, aux = mcdbm.compute_bound_grad(local, params_flat, unflatten, params_fixed, log_prob,
+                                                 eps_schedule=eps_schedule, grad_clipping=grad_clipping, n_total=n)
+        if world > 1:
+            dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=group)
+        return grad, aux
+    return grad_and_loss

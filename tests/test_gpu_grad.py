@@ -376,3 +376,17 @@ def test_ula_gradient_matches_autograd(hip_lib, name, n, over):
         ref = np.asarray(ref, np.float64).reshape(-1)
         got = gh[off:off + ref.size]
         assert np.abs(got - ref).max() <= 2e-3 * max(np.abs(ref).max(), 1e-9), (path, got, ref)
+
+
+@pytest.mark.parametrize("mode", ["MCD_CAIS_sn", "MCD_CAIS_var_sn"])
+def test_sharded_grad_and_loss_without_a_process_group_is_the_plain_call(hip_lib, mode):
+    from cmcd_amd import parallel
+    b = synthetic.build("gmm_n300_k8", device="cuda", boundmode=mode)
+    seeds = torch.from_numpy(synthetic.parity_seeds(100)).cuda()
+    args = (seeds, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"])
+    gl = parallel.make_sharded_grad_and_loss(mode, eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
+    plain, _ = mcdbm.make_grad_and_loss(mode, eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
+    g1, (l1, _) = gl(*args)
+    g2, (l2, _) = plain(*args)
+    assert torch.equal(l1, l2)
+    assert float((g1 - g2).abs().max()) <= 1e-5 * float(g2.abs().max())

@@ -42,6 +42,16 @@ ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--file_path", default="", help="lgcp: pines.csv (default: the bin-count fixture under tests/golden)")
 cfg = ap.parse_args()
 
+# under torchrun (one process per GPU): particles of every iteration are sharded over the ranks, gradients all-reduced
+import torch.distributed as dist
+WORLD, RANK = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+if "RANK" in os.environ and "MASTER_PORT" in os.environ:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
+if RANK != 0:
+    sys.stdout = open(os.devnull, "w")
+
 if "lgcp" in cfg.model and not cfg.file_path:
     # the Finnish-pines point set is reference content; its 40 x 40 bin counts ship as a test fixture
     import numpy as np
@@ -78,6 +88,10 @@ flat, unflatten, fixed = mcdbm.initialize(dim=dim, nbridges=cfg.nbridges, vdpara
                                           trainable=trainable, mode=cfg.boundmode, emb_dim=cfg.emb_dim,
                                           nn_arch=cfg.nn_arch, device="cuda")
 grad_and_loss, loss_fn = mcdbm.make_grad_and_loss(cfg.boundmode, eps_schedule=cfg.eps_schedule, grad_clipping=cfg.grad_clipping)
+if WORLD > 1:
+    from cmcd_amd import parallel
+    grad_and_loss = parallel.make_sharded_grad_and_loss(cfg.boundmode, eps_schedule=cfg.eps_schedule,
+                                                        grad_clipping=cfg.grad_clipping)
 
 
 def evaluate(p, tag):
@@ -97,3 +111,5 @@ print("%s %s K=%d N=%d: %d iterations in %.1f s (%.2f ms/iter)" % (cfg.model, cf
 print("recorded mean losses:", ["%.3f" % x for x in losses[:: max(1, len(losses) // 8)]])
 # 4. evaluation
 evaluate(flat, "after ")
+if dist.is_initialized():
+    dist.destroy_process_group()
