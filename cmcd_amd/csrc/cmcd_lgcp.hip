@@ -804,6 +804,12 @@ __global__ void lgcp_colsum_kernel(const float* __restrict__ A, int64_t R, int C
   out[j] = accumulate ? out[j] + v : v;
 }
 
+// buffers of one forward recompute (two sets: evaluation e-1 is recomputed on a side stream while the backward
+// pass of evaluation e reads the other set)
+struct LgcpFwdSet {
+  int64_t xm, kr, slab1, pre1, u1, slab2, pre2, u2, sn;
+};
+
 struct LgcpGradWs {
   int64_t wt1, wt2, wt3;                       // transposed weights
   int64_t lamn, lam_part, gE, gprev, dO, v;    // [kMP][D]
@@ -815,6 +821,7 @@ struct LgcpGradWs {
   int64_t DO;                                  // [(K+1) n][D]
   int64_t S, S2, gbeta, geps, gfac, gb2;       // tables
   int64_t zero_lo, zero_hi;                    // range to clear per call
+  LgcpFwdSet fs[2];
   int64_t total;
 };
 
@@ -829,6 +836,12 @@ static LgcpGradWs lgcp_grad_ws(const cmcd_desc& d, int64_t n) {
   w.du2s = take(kSplit * kMP * IN); w.ts = take(kSplit * kMP * IN);
   w.du2 = take(kMP * IN); w.du1 = take(kMP * IN); w.da2 = take(kMP * IN); w.da1 = take(kMP * IN);
   w.U1 = take(R * IN); w.U2 = take(R * IN); w.DA1 = take(R * IN); w.DA2 = take(R * IN); w.DO = take(R * D);
+  for (int b = 0; b < 2; ++b) {
+    LgcpFwdSet& f = w.fs[b];
+    f.xm = take(kMP * D); f.kr = take(kSplit * kMP * D); f.slab1 = take(kSplit * kMP * IN); f.pre1 = take(kMP * IN);
+    f.u1 = take(kMP * IN); f.slab2 = take(kSplit * kMP * IN); f.pre2 = take(kMP * IN); f.u2 = take(kMP * IN);
+    f.sn = take(kSplit * kMP * D);
+  }
   w.zero_lo = o;
   w.lamn = take(kMP * D); w.gE = take(kMP * D);
   w.gmu_acc = take(kMP * D); w.glam_acc = take(kMP * D);
@@ -868,6 +881,19 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
   const float mu0 = 3.8812819069514780f;
   const dim3 gblock(64 * kGemmWaves);
   const int cbD = (D + 63) / 64, cbIN = (IN + 63) / 64;
+  // Two streams: the forward recompute of evaluation e-1 (side stream, its own buffer set) overlaps the adjoint /
+  // backward launches of evaluation e (caller's stream).  Every kernel here is launch-latency-bound, so the two
+  // chains run side by side; events order the hand-overs (fork / join, capturable in a graph).
+  static thread_local hipStream_t side = nullptr;
+  static thread_local hipEvent_t ev_fwd[2] = {nullptr, nullptr}, ev_bwd[2] = {nullptr, nullptr}, ev_fork = nullptr;
+  if (!side) {
+    if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) return CMCD_ERR_HIP;
+    for (int b = 0; b < 2; ++b) {
+      if (hipEventCreateWithFlags(&ev_fwd[b], hipEventDisableTiming) != hipSuccess) return CMCD_ERR_HIP;
+      if (hipEventCreateWithFlags(&ev_bwd[b], hipEventDisableTiming) != hipSuccess) return CMCD_ERR_HIP;
+    }
+    if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return CMCD_ERR_HIP;
+  }
   // bias1 rows are still in the forward workspace (lgcp_forward's prep)
   for (int64_t base = 0; base < n; base += kMP) {
     const int M = (int)((n - base) < kMP ? (n - base) : kMP);
@@ -875,39 +901,56 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
       if (hipMemsetAsync(gws + g.lamn, 0, sizeof(float) * 2 * ((kMP * (int64_t)D + 3) & ~3), stream) != hipSuccess) return CMCD_ERR_HIP;
       if (hipMemsetAsync(gws + g.gmu_acc, 0, sizeof(float) * 2 * ((kMP * (int64_t)D + 3) & ~3), stream) != hipSuccess) return CMCD_ERR_HIP;
     }
-    ActArgs act{};
-    act.mu0 = mu0; act.M = M; act.D = D; act.IN = IN; act.xm = ws + w.xm;
-    GemmArgs gm{};
-    gm.M = M;
-    for (int e = K; e >= 0; --e) {
+    if (hipEventRecord(ev_fork, stream) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess) return CMCD_ERR_HIP;
+
+    // forward recompute at z_e into buffer set e & 1, on stream st
+    auto forward_at = [&](int e, hipStream_t st) {
+      const LgcpFwdSet& f = g.fs[e & 1];
       const int ie = e < K ? e : K - 1;
       const float* xe = traj + ((int64_t)e * n + base) * D;
-      const int64_t row0 = (int64_t)e * n + base;
-      // ---- forward recompute at z_e
+      ActArgs act{};
+      act.mu0 = mu0; act.M = M; act.D = D; act.IN = IN; act.xm = gws + f.xm;
       act.x = xe; act.emb = params + lay.g_emb + (int64_t)ie * E;
       act.mode = 0;
-      hipLaunchKernelGGL(lgcp_act_kernel, dim3((M * D + 255) / 256), dim3(256), 0, stream, act);
+      hipLaunchKernelGGL(lgcp_act_kernel, dim3((M * D + 255) / 256), dim3(256), 0, st, act);
+      GemmArgs gm{};
+      gm.M = M;
       gm.Kdim = D;
-      gm.seg[0] = GemmSeg{ws + w.xm, kinv, ws + w.kr, D, D, D, D};
-      gm.seg[1] = GemmSeg{xe, params + lay.g_w1, ws + w.slab1, IN, D, IN, IN};
+      gm.seg[0] = GemmSeg{gws + f.xm, kinv, gws + f.kr, D, D, D, D};
+      gm.seg[1] = GemmSeg{xe, params + lay.g_w1, gws + f.slab1, IN, D, IN, IN};
       gm.nblk0 = cbD;
-      hipLaunchKernelGGL(lgcp_gemm_kernel, dim3(cbD + cbIN, kSplit), gblock, gemm_lds, stream, gm);
-      act.mode = 1; act.slab_a = ws + w.slab1; act.bias_a = ws + w.bias1 + (int64_t)e * IN;
-      act.sum_a = ws + w.pre1; act.u_prev = nullptr; act.u_out = ws + w.u1;
-      hipLaunchKernelGGL(lgcp_act_kernel, dim3((M * IN + 255) / 256), dim3(256), 0, stream, act);
+      hipLaunchKernelGGL(lgcp_gemm_kernel, dim3(cbD + cbIN, kSplit), gblock, gemm_lds, st, gm);
+      act.mode = 1; act.slab_a = gws + f.slab1; act.bias_a = ws + w.bias1 + (int64_t)e * IN;
+      act.sum_a = gws + f.pre1; act.u_prev = nullptr; act.u_out = gws + f.u1;
+      hipLaunchKernelGGL(lgcp_act_kernel, dim3((M * IN + 255) / 256), dim3(256), 0, st, act);
       gm.Kdim = IN;
-      gm.seg[0] = GemmSeg{ws + w.u1, params + lay.g_w2, ws + w.slab2, IN, IN, IN, IN};
+      gm.seg[0] = GemmSeg{gws + f.u1, params + lay.g_w2, gws + f.slab2, IN, IN, IN, IN};
       gm.nblk0 = cbIN;
-      hipLaunchKernelGGL(lgcp_gemm_kernel, dim3(cbIN, kSplit), gblock, gemm_lds, stream, gm);
-      act.mode = 2; act.slab_a = ws + w.slab2; act.bias_a = params + lay.g_b2;
-      act.sum_a = ws + w.pre2; act.u_prev = ws + w.u1; act.u_out = ws + w.u2;
-      hipLaunchKernelGGL(lgcp_act_kernel, dim3((M * IN + 255) / 256), dim3(256), 0, stream, act);
-      gm.seg[0] = GemmSeg{ws + w.u2, params + lay.g_w3, ws + w.sn, D, IN, D, D};
+      hipLaunchKernelGGL(lgcp_gemm_kernel, dim3(cbIN, kSplit), gblock, gemm_lds, st, gm);
+      act.mode = 2; act.slab_a = gws + f.slab2; act.bias_a = params + lay.g_b2;
+      act.sum_a = gws + f.pre2; act.u_prev = gws + f.u1; act.u_out = gws + f.u2;
+      hipLaunchKernelGGL(lgcp_act_kernel, dim3((M * IN + 255) / 256), dim3(256), 0, st, act);
+      gm.seg[0] = GemmSeg{gws + f.u2, params + lay.g_w3, gws + f.sn, D, IN, D, D};
       gm.nblk0 = cbD;
-      hipLaunchKernelGGL(lgcp_gemm_kernel, dim3(cbD, kSplit), gblock, gemm_lds, stream, gm);
+      hipLaunchKernelGGL(lgcp_gemm_kernel, dim3(cbD, kSplit), gblock, gemm_lds, st, gm);
+    };
+
+    forward_at(K, side);
+    if (hipEventRecord(ev_fwd[K & 1], side) != hipSuccess) return CMCD_ERR_HIP;
+    for (int e = K; e >= 0; --e) {
+      if (e > 0) {  // next evaluation's recompute: its buffer set was last read by the backward pass of e+1
+        if (e + 1 <= K && hipStreamWaitEvent(side, ev_bwd[(e - 1) & 1], 0) != hipSuccess) return CMCD_ERR_HIP;
+        forward_at(e - 1, side);
+        if (hipEventRecord(ev_fwd[(e - 1) & 1], side) != hipSuccess) return CMCD_ERR_HIP;
+      }
+      if (hipStreamWaitEvent(stream, ev_fwd[e & 1], 0) != hipSuccess) return CMCD_ERR_HIP;
+      const LgcpFwdSet& f = g.fs[e & 1];
+      const int64_t row0 = (int64_t)e * n + base;
+      GemmArgs gm{};
+      gm.M = M;
       // ---- adjoint step
       LgcpAdjArgs aa{};
-      aa.params = params; aa.tc = tc; aa.sched = ws + sw.sched; aa.traj = traj; aa.kr = ws + w.kr; aa.sn = ws + w.sn;
+      aa.params = params; aa.tc = tc; aa.sched = ws + sw.sched; aa.traj = traj; aa.kr = gws + f.kr; aa.sn = gws + f.sn;
       aa.b3 = params + lay.g_b3; aa.factor = params + lay.g_factor; aa.lamn = gws + g.lamn; aa.gE = gws + g.gE;
       aa.gprev = gws + g.gprev; aa.dO = gws + g.dO; aa.v = gws + g.v; aa.lam_part = gws + g.lam_part;
       aa.gmu_acc = gws + g.gmu_acc; aa.glam_acc = gws + g.glam_acc; aa.gbeta = gws + g.gbeta; aa.geps = gws + g.geps;
@@ -920,7 +963,7 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
       gm.nblk0 = cbIN;
       hipLaunchKernelGGL(lgcp_gemm_kernel, dim3(cbIN, kSplit), gblock, gemm_lds, stream, gm);
       LgcpActbArgs ab{};
-      ab.slab = gws + g.du2s; ab.pre = ws + w.pre2; ab.du_prev = nullptr; ab.u_src = ws + w.u2;
+      ab.slab = gws + g.du2s; ab.pre = gws + f.pre2; ab.du_prev = nullptr; ab.u_src = gws + f.u2;
       ab.du_out = gws + g.du2; ab.da_out = gws + g.da2; ab.da_big = gws + g.DA2; ab.u_big = gws + g.U2;
       ab.gb = gws + g.gb2; ab.row0 = row0; ab.M = M; ab.IN = IN; ab.mode = 2;
       hipLaunchKernelGGL(lgcp_actb_kernel, dim3((IN + 255) / 256, M), dim3(256), 0, stream, ab);
@@ -929,7 +972,7 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
       gm.seg[0] = GemmSeg{gws + g.da2, gws + g.wt2, gws + g.ts, IN, IN, IN, IN};
       gm.nblk0 = cbIN;
       hipLaunchKernelGGL(lgcp_gemm_kernel, dim3(cbIN, kSplit), gblock, gemm_lds, stream, gm);
-      ab.slab = gws + g.ts; ab.pre = ws + w.pre1; ab.du_prev = gws + g.du2; ab.u_src = ws + w.u1;
+      ab.slab = gws + g.ts; ab.pre = gws + f.pre1; ab.du_prev = gws + g.du2; ab.u_src = gws + f.u1;
       ab.du_out = gws + g.du1; ab.da_out = gws + g.da1; ab.da_big = gws + g.DA1; ab.u_big = gws + g.U1;
       ab.S = gws + g.S + (int64_t)e * IN; ab.S2 = gws + g.S2 + (int64_t)e * IN; ab.mode = 1;
       hipLaunchKernelGGL(lgcp_actb_kernel, dim3((IN + 255) / 256, M), dim3(256), 0, stream, ab);
@@ -948,6 +991,7 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
       la.gE = gws + g.gE; la.gmu_acc = gws + g.gmu_acc; la.glam_acc = gws + g.glam_acc; la.lay = lay; la.n = n;
       la.base = base; la.M = M; la.D = D; la.IN = IN; la.e = e; la.omega = omega;
       hipLaunchKernelGGL(lgcp_lam_finish_kernel, dim3((M * D + 255) / 256), dim3(256), 0, stream, la);
+      if (hipEventRecord(ev_bwd[e & 1], stream) != hipSuccess) return CMCD_ERR_HIP;
     }
     // q gradients of this pass: sum over its particles, accumulated into grad
     hipLaunchKernelGGL(lgcp_colsum_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, gws + g.gmu_acc, (int64_t)M, D, D,
