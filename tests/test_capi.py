@@ -106,3 +106,37 @@ def test_stats_merge_empty_rank_and_all_inf():
     assert merged[0] == 2 and abs(mean - 1.5) < 1e-15
     merged, mean, var, lnz = _lib.stats_merge([stats5(np.array([np.inf, np.inf]))], [2])
     assert merged[0] == 0 and lnz == -math.inf
+
+
+def test_gradient_and_optimiser_entry_points_validate_before_any_gpu_work(hip_lib):
+    """Workspace sizing and argument checks of the training entry points run on the host."""
+    lay = _lib.Layout(*([-1] * len(_lib.LAYOUT_FIELDS)))
+    # workspace sizes: the reparameterised gradient exists for CAIS_sn / ULA / ULA_sn, VarGrad for CAIS_var_sn
+    assert hip_lib.cmcd_bound_grad_workspace_bytes(C.byref(_desc()), 2000) > hip_lib.cmcd_workspace_bytes(C.byref(_desc()), 2000)
+    assert hip_lib.cmcd_bound_grad_workspace_bytes(C.byref(_desc(mode=1)), 2000) == 0
+    assert hip_lib.cmcd_bound_grad_workspace_bytes(C.byref(_desc(mode=2)), 2000) > 0
+    assert hip_lib.cmcd_bound_grad_workspace_bytes(C.byref(_desc(mode=3, arch=0, emb_dim=20, target=0)), 300) > 0
+    assert hip_lib.cmcd_bound_grad_workspace_bytes(C.byref(_desc(arch=0, emb_dim=20, target=3, dim=1600, nbridges=4)), 20) > 0
+    assert hip_lib.cmcd_grad_workspace_bytes(C.byref(_desc(mode=1)), 2000) > 0
+    assert hip_lib.cmcd_grad_workspace_bytes(C.byref(_desc(mode=1, arch=0, emb_dim=31)), 2000) == 0       # width 33: no instance
+    assert hip_lib.cmcd_mfvi_workspace_bytes(2, 2, 1000) > 0 and hip_lib.cmcd_mfvi_workspace_bytes(3, 1600, 20) > 0
+    assert hip_lib.cmcd_mfvi_workspace_bytes(1, 7, 100) == 0                                              # funnel d = 7
+    # null pointers / wrong modes are refused with a message
+    rc = hip_lib.cmcd_bound_grad(C.byref(_desc()), C.byref(lay), None, 16, None, 0, None, 0, 1.0, None, 0, None, None,
+                                 None, None, None)
+    assert rc == -1
+    rc = hip_lib.cmcd_bound_grad(C.byref(_desc(mode=1)), C.byref(lay), None, 16, None, 0, None, 0, 1.0, None, 0, None,
+                                 None, None, C.c_void_p(16), None)
+    assert rc == -2 and "MCD_CAIS_var_sn" in _lib.last_error()
+    rc = hip_lib.cmcd_bound_var_grad(C.byref(_desc()), C.byref(lay), C.c_void_p(16), 16, C.c_void_p(16), 0, None, 0,
+                                     C.c_void_p(16), C.c_void_p(16), 0, C.c_void_p(16), None)
+    assert rc == -2
+    rc = hip_lib.cmcd_mfvi_bound_grad(2, 2, 0, 2, None, 16, None, 4, None, 0, 1.0, None, 0, None, None, None, None, None)
+    assert rc == -1
+    rc = hip_lib.cmcd_adam_step(None, None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 5.0, 1, 1e-3, None, 0, None)
+    assert rc == -1
+    rng = (_lib.ProjectRange * 9)()
+    rc = hip_lib.cmcd_adam_step(C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), None, 10, 1e-3, 0.9, 0.999,
+                                1e-8, 5.0, 1, 1e-3, rng, 9, None)
+    assert rc == -1 and "8 projection ranges" in _lib.last_error()
+    assert C.sizeof(_lib.ProjectRange) == 32
