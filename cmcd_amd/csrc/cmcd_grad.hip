@@ -1190,6 +1190,7 @@ struct TailArgs {
   const float* gtab;
   const float* slabs;
   float* grad;         // [n_params]
+  float* tail;         // dds: [(K+1)][kTailRow] per-evaluation vectors of the time-coder tail
   cmcd_layout lay;
   WsLayout w;
   int64_t o_S, o_S2, o_gbeta, o_geps, o_gvd, o_gfac, slab_stride, n_params;
@@ -1330,18 +1331,21 @@ __global__ void grad_geffner_tail_kernel(TailArgs a) {
 }
 
 // dds tail: S[e][n] = d / d bias1[e][n] with bias1[e] = sb1 + tau(e) sw1[D:, :], tau(e) the time coder
-// (nn_dds.py:131-143,155-158).  One 64-thread block per e recomputes the time path and back-propagates;
-// per-e contributions are accumulated with float atomics (257 adders per address).
+// (nn_dds.py:131-143,155-158).  Two launches: (A) one 64-thread block per e recomputes the time path and
+// back-propagates S[e] through it, leaving its per-e vectors in a table; (B) one thread per parameter sums the
+// per-e outer products over e in a fixed order (no atomics: 4.3 M float atomics took 50 us, this takes ~15).
+constexpr int kTailRow = 448;   // per e: emb[128] | hh[64] | tau[64] | dtau[64] | dact[64] | dphase[64]
+
 __global__ __launch_bounds__(64) void grad_dds_tail_kernel(TailArgs a) {
-  __shared__ float emb[128], arg_s[64], ha[64], hh[64], tau[64], dtau[64], dh[64], dact[64], demb[128];
+  __shared__ float emb[128], ha[64], hh[64], dtau[64], dh[64], dact[64];
   const int j = threadIdx.x, t = blockIdx.x, D = a.D;
   const float* P = a.params;
   const float* S = a.gtab + a.o_S + (int64_t)t * 64;
+  float* row = a.tail + (int64_t)t * kTailRow;
   {
     const double step = (100.0 - 0.1) / 63.0;
     const float cj = (j == 63) ? 100.0f : (float)((double)j * step + 0.1);
     const float arg = cj * (float)t + P[a.lay.d_phase + j];
-    arg_s[j] = arg;
     emb[j] = sinf(arg);
     emb[64 + j] = cosf(arg);
   }
@@ -1353,40 +1357,71 @@ __global__ __launch_bounds__(64) void grad_dds_tail_kernel(TailArgs a) {
   __syncthreads();
   acc = P[a.lay.d_tb2 + j];
   for (int k = 0; k < 64; ++k) acc = fmaf(hh[k], P[a.lay.d_tw2 + k * 64 + j], acc);
-  tau[j] = acc;
-  __syncthreads();
-  // sb1, sw1[D:, :]
-  atomicAdd(a.grad + a.lay.d_sb1 + j, S[j]);
-  for (int k = 0; k < 64; ++k) atomicAdd(a.grad + a.lay.d_sw1 + (int64_t)(D + k) * 64 + j, tau[k] * S[j]);
+  const float tau = acc;
   // d tau_k = sum_n sw1[D+k][n] S[n]
   acc = 0.f;
   for (int n = 0; n < 64; ++n) acc = fmaf(P[a.lay.d_sw1 + (int64_t)(D + j) * 64 + n], S[n], acc);
   dtau[j] = acc;
   __syncthreads();
-  atomicAdd(a.grad + a.lay.d_tb2 + j, dtau[j]);
-  for (int k = 0; k < 64; ++k) atomicAdd(a.grad + a.lay.d_tw2 + k * 64 + j, hh[k] * dtau[j]);
   acc = 0.f;
   for (int n = 0; n < 64; ++n) acc = fmaf(P[a.lay.d_tw2 + j * 64 + n], dtau[n], acc);
   dh[j] = acc;
-  // exact gelu': Phi(x) + x phi(x)
-  {
+  {  // exact gelu': Phi(x) + x phi(x)
     const float x = ha[j];
     const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
     const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
     dact[j] = dh[j] * (cdf + x * pdf);
   }
   __syncthreads();
-  atomicAdd(a.grad + a.lay.d_tb1 + j, dact[j]);
-  for (int k = 0; k < 128; ++k) atomicAdd(a.grad + a.lay.d_tw1 + k * 64 + j, emb[k] * dact[j]);
+  float de[2];
   for (int q = 0; q < 2; ++q) {
     const int k = j + 64 * q;
     acc = 0.f;
     for (int n = 0; n < 64; ++n) acc = fmaf(P[a.lay.d_tw1 + k * 64 + n], dact[n], acc);
-    demb[k] = acc;
+    de[q] = acc;
   }
-  __syncthreads();
+  row[j] = emb[j];
+  row[64 + j] = emb[64 + j];
+  row[128 + j] = hh[j];
+  row[192 + j] = tau;
+  row[256 + j] = dtau[j];
+  row[320 + j] = dact[j];
   // emb = [sin(arg), cos(arg)], arg = c t + phase:  d phase_j = demb_j cos(arg_j) - demb_{64+j} sin(arg_j)
-  atomicAdd(a.grad + a.lay.d_phase + j, demb[j] * emb[64 + j] - demb[64 + j] * emb[j]);
+  row[384 + j] = de[0] * emb[64 + j] - de[1] * emb[j];
+}
+
+// (B) d sb1, d sw1[D:], d tb2, d tw2, d tb1, d tw1, d phase: 16 lanes per entry, lane l sums e = l, l+16, ...,
+// then a fixed butterfly (deterministic; a one-thread 257-long walk is latency-bound: 67 us)
+__global__ __launch_bounds__(256) void grad_dds_tail_sum_kernel(TailArgs a) {
+  const int sub = threadIdx.x & 15, D = a.D, E1 = a.K + 1;
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const float* T0 = a.tail;
+  const float* S = a.gtab + a.o_S;
+  // segments: [0,64) sb1 | 4096 sw1[D+k][j] | 64 tb2 | 4096 tw2 | 64 tb1 | 8192 tw1 | 64 phase
+  int o = i;
+  int64_t dst = -1;
+  int xa = -1, xb = -1;     // offsets inside the per-e row (xa < 0: factor 1);  xb < 0: second factor is S[e][-xb-1]
+  if (o < 64) { dst = a.lay.d_sb1 + o; xb = -(o + 1); }
+  else if ((o -= 64) < 4096) { dst = a.lay.d_sw1 + (int64_t)(D + (o >> 6)) * 64 + (o & 63); xa = 192 + (o >> 6); xb = -((o & 63) + 1); }
+  else if ((o -= 4096) < 64) { dst = a.lay.d_tb2 + o; xb = 256 + o; }
+  else if ((o -= 64) < 4096) { dst = a.lay.d_tw2 + o; xa = 128 + (o >> 6); xb = 256 + (o & 63); }
+  else if ((o -= 4096) < 64) { dst = a.lay.d_tb1 + o; xb = 320 + o; }
+  else if ((o -= 64) < 8192) { dst = a.lay.d_tw1 + o; xa = o >> 6; xb = 320 + (o & 63); }
+  else if ((o -= 8192) < 64) { dst = a.lay.d_phase + o; xb = 384 + o; }
+  float v = 0.f;
+  if (dst >= 0) {
+    for (int e = sub; e < E1; e += 16) {
+      const float* row = T0 + (int64_t)e * kTailRow;
+      const float fa = xa >= 0 ? row[xa] : 1.0f;
+      const float fb = xb >= 0 ? row[xb] : S[(int64_t)e * 64 + (-xb - 1)];
+      v = fmaf(fa, fb, v);
+    }
+  }
+  v += __shfl_xor(v, 8);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 1);
+  if (dst >= 0 && sub == 0) a.grad[dst] = v;
 }
 
 typedef void (*grad_fn)(GradArgs);
@@ -1460,6 +1495,8 @@ static void grad_offsets(const cmcd_desc& d, int HP, int64_t& o_S, int64_t& o_S2
   o_gfac = o; o += 4;
   total = o;
 }
+// the dds tail's per-evaluation table sits after the zero-initialised tables
+static int64_t grad_tail_floats(const cmcd_desc& d) { return d.arch == CMCD_ARCH_DDS ? (int64_t)(d.nbridges + 1) * 448 : 0; }
 
 static int grad_nslabs(int64_t n, int nw) {
   const int64_t nquads = (n + 16 * nw - 1) / (16 * nw);
@@ -1470,7 +1507,7 @@ int64_t grad_workspace_floats(const cmcd_desc& d, int HP, int64_t n) {
   int64_t oS, oS2, ob, oe, ov, of, tot;
   grad_offsets(d, HP, oS, oS2, ob, oe, ov, of, tot);
   const int64_t slab = (int64_t)HP * HP + HP * 16 + 4 * (2 * 16 * HP + 256 + 32);
-  return tot + slab * 256;   // up to one slab per workgroup of a full-chip launch (either path)
+  return tot + grad_tail_floats(d) + slab * 256;   // up to one slab per workgroup of a full-chip launch (either path)
 }
 
 // ws_fwd: the forward workspace as left by cmcd_bound_forward's prep on the SAME desc/params;
@@ -1492,7 +1529,7 @@ int grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, c
   const int64_t nitems = ntiles * (K + 1);
   const int64_t n_outer = (nitems + nw - 1) / nw;
   const int nslabs = item ? (int)(n_outer < 256 ? n_outer : 256) : grad_nslabs(n, nw);
-  ga.seeds = seeds; ga.params = params; ga.ws = ws_fwd; ga.omega = omega; ga.omega_scalar = omega_scalar; ga.traj = traj; ga.gtab = gws; ga.slabs = gws + tot;
+  ga.seeds = seeds; ga.params = params; ga.ws = ws_fwd; ga.omega = omega; ga.omega_scalar = omega_scalar; ga.traj = traj; ga.gtab = gws; ga.slabs = gws + tot + grad_tail_floats(d);
   ga.lay = lay; ga.w = w; ga.n = n; ga.K = K; ga.var_mode = d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0;
   ga.grad_clipping = d.grad_clipping; ga.nquads = (int)((n + 16 * nw - 1) / (16 * nw));
   ga.ula = d.mode == CMCD_MODE_ULA_SN ? 2 : 0;
@@ -1528,7 +1565,8 @@ int grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, c
   hipLaunchKernelGGL(fn, dim3(nslabs), dim3(64 * nw), lds_bytes, stream, ga);
 
   TailArgs ta{};
-  ta.params = params; ta.ws = ws_fwd; ta.gtab = gws; ta.slabs = gws + tot; ta.grad = grad; ta.lay = lay; ta.w = w;
+  ta.params = params; ta.ws = ws_fwd; ta.gtab = gws; ta.slabs = gws + tot + grad_tail_floats(d); ta.tail = gws + tot;
+  ta.grad = grad; ta.lay = lay; ta.w = w;
   ta.o_S = ga.o_S; ta.o_S2 = ga.o_S2; ta.o_gbeta = ga.o_gbeta; ta.o_geps = ga.o_geps; ta.o_gvd = ga.o_gvd;
   ta.o_gfac = ga.o_gfac; ta.slab_stride = ga.slab_stride; ta.n_params = n_params;
   ta.K = K; ta.D = D; ta.E = d.emb_dim; ta.IN = D + d.emb_dim; ta.HP = HP; ta.arch = d.arch; ta.nslabs = nslabs;
@@ -1539,7 +1577,10 @@ int grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, c
     hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((outs * 16 + 255) / 256)), dim3(256), 0, stream, ta);
   }
   hipLaunchKernelGGL(grad_sched_tail_kernel, dim3(1), dim3(256), 0, stream, ta);
-  if (d.arch == CMCD_ARCH_DDS) hipLaunchKernelGGL(grad_dds_tail_kernel, dim3(K + 1), dim3(64), 0, stream, ta);
+  if (d.arch == CMCD_ARCH_DDS) {
+    hipLaunchKernelGGL(grad_dds_tail_kernel, dim3(K + 1), dim3(64), 0, stream, ta);
+    hipLaunchKernelGGL(grad_dds_tail_sum_kernel, dim3(((64 + 4096 + 64 + 4096 + 64 + 8192 + 64) * 16 + 255) / 256), dim3(256), 0, stream, ta);
+  }
   else hipLaunchKernelGGL(grad_geffner_tail_kernel, dim3(64), dim3(256), 0, stream, ta);
   return hipGetLastError() == hipSuccess ? CMCD_OK : CMCD_ERR_HIP;
 }
