@@ -124,6 +124,8 @@ def main():
 
     name = args.config or synthetic.NORTH_STAR
     over = {"N": args.particles} if args.particles else {}
+    if "lgcp" in name:   # the 40 x 40 bin counts of the point set ship as a fixture
+        over["lgcp_counts"] = np.load(os.path.join(ROOT, "tests", "golden", "lgcp_bin_counts.npy"))
     b = synthetic.build(name, device=device, **over)
     cfg = b["cfg"]
     dim, K, mode, spec = b["params_fixed"]
@@ -169,7 +171,10 @@ def main():
     units_per_step = n * K * world
     value = units_per_step * args.steps / elapsed
     f_alg, f_survey = flops_per_particle_step(cfg, dim, spec.width)
-    kern_s = kern_ms / 1e3 / max(launches, 1)
+    if launches == 0:   # lgcp: a launch sequence, no single trajectory kernel — the whole call is the unit
+        kern_s, launches = elapsed / args.steps, args.steps
+    else:
+        kern_s = kern_ms / 1e3 / max(launches, 1)
     achieved = n * K * f_alg / kern_s / 1e12
     fin = parallel.finalize(stats, n * world)
 
@@ -189,6 +194,9 @@ def main():
     tiles = (n + 15) // 16
     coop = mcdbm.KERNEL_VARIANT == 2 or (mcdbm.KERNEL_VARIANT == 0 and tiles <= (256 if spec.width >= 128 else 512))
     kernel_name = "coop_kernel" if coop else "traj_kernel"
+
+    if cfg["model"] == "lgcp":
+        kernel_name = "lgcp launch sequence (skinny GEMMs + state kernels)"
 
     result = {
         "metric": "bridge-steps*particles/sec", "value": value, "unit": "bridge-steps*particles/s",
@@ -223,6 +231,14 @@ def main():
         result["saturated"] = {"particles": ns, "kernel_ms": ks * 1e3, "value": ns * K / ks,
                                "achieved": ns * K * f_alg / ks / 1e12,
                                "frac": ns * K * f_alg / ks / 1e12 / PEAK_FP32_TFLOPS}
+
+    if cfg["model"] == "lgcp":
+        # weight-bandwidth bound: every evaluation streams K^-1 and the three weight matrices
+        IN = dim + cfg["emb_dim"]
+        wbytes = 4.0 * (dim * dim + 2 * dim * IN + IN * IN) * (K + 1) * -(-n // 24)
+        result["roofline"].update({"bound": "hbm", "achieved": wbytes / kern_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                   "frac": wbytes / kern_s / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                                   "weight_bytes_per_call": wbytes})
 
     if rank == 0 and world == 1 and name == synthetic.NORTH_STAR:
         # value-and-gradient of the VarGrad loss on the same batch (boundmode MCD_CAIS_var_sn, same net/target)
