@@ -272,17 +272,14 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
     // per-bridge scalars {beta, eps, sigma, log sigma + log sqrt(2 pi), 1/(2 sigma^2)}.  VECTOR loads
     // (vmcnt) issued early: a scalar load would sit on lgkmcnt, which every LDS wait of the step drains,
     // exposing its full L2 latency.  MLP waves need row i (phase C(i) after barrier 2), ACC row i-1.
-    const int srow = is_acc ? (i > 0 ? i - 1 : 0) : (i < K ? i : K - 1);
+    const int srow = i < K ? i : K - 1;
     const f32x4 sc0 = *reinterpret_cast<const f32x4*>(sched_v + 8 * srow);
     const f32x4 sc1 = *reinterpret_cast<const f32x4*>(sched_v + 8 * srow + 4);
     f32x4 h = {0.f, 0.f, 0.f, 0.f};
     uint32_t g0 = 0, g1 = 0, h0 = 0, h1 = 0;
+    typename Target<TARGET, D>::State tst;
     // ------------------------------------------------------------------ interval 1
     if (is_mlp) {
-      if (wv == 0 && g == 0) {  // publish z_i for the TGT waves
-#pragma unroll
-        for (int j = 0; j < D; ++j) zbuf[c * ZP + j] = z[j];
-      }
       f32x4 pre = brow;
 #pragma unroll
       for (int j = 0; j < D; ++j) pre += z[j] * w1z[j];
@@ -303,6 +300,8 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
         for (int r = 0; r < 4; ++r) h[r] = u[r] + softplus(pre[r]);
       }
       *reinterpret_cast<f32x4*>(my_h) = h;
+    } else if (is_tgt) {
+      Target<TARGET, D>::template pass1<8>(z, sub8, lds_tgt, tst);   // distances / shift of z_i (own copy of z)
     } else if (is_rng && i + 1 < K) {
       uint32_t x0 = gb, x1 = 2 + gb;
       threefry2x32(k0, k1, x0, x1);            // (G, H) = split(gen) of bridge i+1
@@ -337,13 +336,9 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
         if (g == 0) part[(buf * 16 + c) * PT + wv * D + j] = pj;
       }
     } else if (is_tgt) {
-      // z_i from LDS; both passes here, while the SIMD partner (an MLP wave) sits in its MFMA chain
-      float zt[D], gp[D], lp = 0.f;
-#pragma unroll
-      for (int j = 0; j < D; ++j) zt[j] = zbuf[c * ZP + j];
-      typename Target<TARGET, D>::State tst;
-      Target<TARGET, D>::template pass1<8>(zt, sub8, lds_tgt, tst);
-      Target<TARGET, D>::template pass2<8>(zt, sub8, lds_tgt, tst, lp, gp);
+      // second pass only: its SIMD partner (an MLP wave) blocks the VALU during the 16 fp32 MFMAs
+      float gp[D], lp = 0.f;
+      Target<TARGET, D>::template pass2<8>(z, sub8, lds_tgt, tst, lp, gp);
       if (sub8 == 0) {
 #pragma unroll
         for (int j = 0; j < D; ++j) gpb[(buf * 16 + c) * GP + j] = gp[j];
@@ -353,18 +348,15 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
       if (i + 1 < K) normal_bits(g0, g1, h0, h1, buf ^ 1, true);
     } else {
       if (i < K) convert(buf);                       // noise of bridge i, read in phase C(i)
-      if (i > 0) phase_c(i - 1, true, sc0, sc1);     // shadow of the trajectory, one bridge late: w
     }
     STAMP(2);
     lds_barrier();
     STAMP(3);
-    // ------------------------------------------------------------------ phase C (MLP waves only)
-    if (is_mlp && i < K) phase_c(i, false, sc0, sc1);
+    // ------------------------------------------------------------------ phase C: MLP, TGT (own copies of z) and
+    // ACC (with the log-weight); ~45 instructions each, so the redundancy is cheaper than an LDS hand-over
+    if (is_acc) phase_c(i, true, sc0, sc1);          // i = K: closes step K-1 and picks up log p(z_K)
+    else if ((is_mlp || is_tgt) && i < K) phase_c(i, false, sc0, sc1);
     STAMP(4);
-  }
-  if (is_acc) {  // last evaluation: closes step K-1 and picks up log p(z_K)
-    const f32x4 dummy = {0.f, 0.f, 0.f, 0.f};
-    phase_c(K, true, dummy, dummy);
   }
 #ifdef CMCD_STAMPS
   if (blockIdx.x == 0 && lane == 0)
