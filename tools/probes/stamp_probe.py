@@ -8,12 +8,14 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-lib = "/tmp/libcmcd_hip_stamps.so"
+lib = os.path.join(ROOT, "gpurun_out", "libcmcd_hip_stamps.so")
+os.makedirs(os.path.dirname(lib), exist_ok=True)
 csrc = os.path.join(ROOT, "cmcd_amd", "csrc")
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                 "-DCMCD_STAMPS", "-I", os.path.join(ROOT, "include"), "-I", csrc, "-Wno-format-security",
                 "-o", lib, os.path.join(csrc, "cmcd_kernels.hip"), os.path.join(csrc, "cmcd_coop.hip"),
-                os.path.join(csrc, "cmcd_lgcp.hip"), os.path.join(csrc, "cmcd_grad.hip")], check=True)
+                os.path.join(csrc, "cmcd_lgcp.hip"), os.path.join(csrc, "cmcd_grad.hip"),
+                os.path.join(csrc, "cmcd_mfvi.hip"), os.path.join(csrc, "cmcd_opt.hip")], check=True)
 os.environ["CMCD_LIB_PATH"] = lib
 os.environ["CMCD_KERNEL_VARIANT"] = "2"
 import torch  # noqa: E402
