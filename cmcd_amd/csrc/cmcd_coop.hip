@@ -267,6 +267,8 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
   unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
 #endif
+  typename Target<TARGET, D>::Means tmeans;
+  if (is_tgt) Target<TARGET, D>::template load_means<8>(sub8, lds_tgt, tmeans);
   for (int i = 0; i <= K; ++i) {
     const int buf = i & 1;
     // per-bridge scalars {beta, eps, sigma, log sigma + log sqrt(2 pi), 1/(2 sigma^2)}.  VECTOR loads
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
       }
       *reinterpret_cast<f32x4*>(my_h) = h;
     } else if (is_tgt) {
-      Target<TARGET, D>::template pass1<8>(z, sub8, lds_tgt, tst);   // distances / shift of z_i (own copy of z)
+      Target<TARGET, D>::template pass1r<8>(z, sub8, lds_tgt, tmeans, tst);   // distances / shift of z_i (own z, means in registers)
     } else if (is_rng && i + 1 < K) {
       uint32_t x0 = gb, x1 = 2 + gb;
       threefry2x32(k0, k1, x0, x1);            // (G, H) = split(gen) of bridge i+1

@@ -284,6 +284,38 @@ struct Target<CMCD_TARGET_MANY_GMM, 2> {
     }
     st.dmin = dmin;
   }
+  // The cooperative kernel's target waves own the same components for the whole launch: their means stay in
+  // registers (loaded once), so the distance pass has no LDS read on the per-bridge critical path.
+  struct Means {
+    float mx[10], my[10];
+    bool fast;
+  };
+  template <int LP>
+  __device__ static __forceinline__ void load_means(int sub, const float* tc, Means& m) {
+    constexpr int kQ = kFastMix / LP;
+    const float2* mu = reinterpret_cast<const float2*>(tc + kLdsHeader);
+    m.fast = __float_as_int(tc[2]) == kFastMix;
+#pragma unroll
+    for (int q = 0; q < kQ; ++q) {
+      const float2 mk = m.fast ? mu[sub + LP * q] : float2{0.f, 0.f};
+      m.mx[q] = mk.x;
+      m.my[q] = mk.y;
+    }
+  }
+  template <int LP>
+  __device__ static __forceinline__ void pass1r(const float (&z)[2], int sub, const float* tc, const Means& m, State& st) {
+    constexpr int kQ = kFastMix / LP;
+    if (!m.fast) { pass1<LP>(z, sub, tc, st); return; }
+    float dmin = INFINITY;
+#pragma unroll
+    for (int q = 0; q < kQ; ++q) {
+      st.dx[q] = z[0] - m.mx[q];
+      st.dy[q] = z[1] - m.my[q];
+      st.d2[q] = fmaf(st.dx[q], st.dx[q], st.dy[q] * st.dy[q]);
+      dmin = fminf(dmin, st.d2[q]);
+    }
+    st.dmin = dmin;
+  }
   template <int LP>
   __device__ static __forceinline__ void pass2(const float (&z)[2], int sub, const float* tc, const State& st,
                                                float& logp, float (&grad)[2]) {
@@ -403,6 +435,11 @@ struct Target<CMCD_TARGET_GMM, 2> {
     gy = (ea * pa1 + eb * pb1 + ec * pc1) * is;
   }
   struct State {};
+  struct Means {};
+  template <int LP>
+  __device__ static __forceinline__ void load_means(int, const float*, Means&) {}
+  template <int LP>
+  __device__ static __forceinline__ void pass1r(const float (&)[2], int, const float*, const Means&, State&) {}
   template <int LP>
   __device__ static __forceinline__ void pass1(const float (&)[2], int, const float*, State&) {}
   template <int LP>
@@ -476,6 +513,11 @@ template <int D>
 struct Target<CMCD_TARGET_FUNNEL, D> {
   static constexpr int kLdsHeader = 0;
   struct State {};
+  struct Means {};
+  template <int LP>
+  __device__ static __forceinline__ void load_means(int, const float*, Means&) {}
+  template <int LP>
+  __device__ static __forceinline__ void pass1r(const float (&)[D], int, const float*, const Means&, State&) {}
   template <int LP>
   __device__ static __forceinline__ void pass1(const float (&)[D], int, const float*, State&) {}
   template <int LP>
