@@ -43,8 +43,8 @@ def logp_funnel(z):
             - 0.5 * torch.exp(-v) * (z[:, 1:] ** 2).sum(-1))
 
 
-def logp_many_gmm(z):
-    mu = torch.tensor(np.asarray(many_gmm_means(), np.float64), dtype=z.dtype)
+def logp_many_gmm(z, n_mixes=40, loc_scaling=40.0):
+    mu = torch.tensor(np.asarray(many_gmm_means(n_mixes, 2, loc_scaling), np.float64), dtype=z.dtype)
     s = math.log1p(math.exp(0.1))
     comp = (-0.5 * ((z[:, None, :] - mu) / s) ** 2 - math.log(s) - 0.5 * LOG_2PI).sum(-1)
     lp = torch.logsumexp(comp - math.log(mu.shape[0]), dim=1)

@@ -13,7 +13,7 @@ def oracle_target(cfg, lgcp_counts=None):
     if m == "funnel":
         return otg.Funnel(10)
     if m == "many_gmm":
-        return otg.ManyGmm()
+        return otg.ManyGmm(n_mixes=int(cfg.get("n_mixes", 40)), loc_scaling=float(cfg.get("loc_scaling", 40.0)))
     if m == "lgcp":
         return otg.Lgcp(lgcp_counts)
     raise KeyError(m)

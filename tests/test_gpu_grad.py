@@ -390,3 +390,29 @@ def test_sharded_grad_and_loss_without_a_process_group_is_the_plain_call(hip_lib
     g2, (l2, _) = plain(*args)
     assert torch.equal(l1, l2)
     assert float((g1 - g2).abs().max()) <= 1e-5 * float(g2.abs().max())
+
+
+@pytest.mark.parametrize("item", [0, 1])
+def test_gradient_with_a_17_component_mixture(hip_lib, monkeypatch, item):
+    """The generic component loop of the target's gradient + Hessian (n_mixes != 40)."""
+    from functools import partial
+    monkeypatch.setenv("CMCD_GRAD_ITEM", str(item))
+    b = synthetic.build("many_gmm_n2000_k256_dds", device="cuda", nbridges=6, n_mixes=17, init_sigma=15.0, init_eps=0.3)
+    seeds = synthetic.parity_seeds(80)
+    grad, (losses, z) = mcdbm.compute_bound_grad(torch.from_numpy(seeds).cuda(), b["params_flat"], b["unflatten"],
+                                                 b["params_fixed"], b["target"], eps_schedule=b["eps_schedule"],
+                                                 grad_clipping=b["grad_clipping"])
+    torch.cuda.synchronize()
+    dim, K, mode, spec = b["params_fixed"]
+    p = synthetic.oracle_params(b["unflatten"], b["params_flat"])
+    val, l_ref, _, g = ot.bound_and_grad(seeds, p, dim, K, mode, spec.arch, partial(ot.logp_many_gmm, n_mixes=17),
+                                         b["cfg"]["eps_schedule"], b["cfg"]["grad_clipping"])
+    assert np.isfinite(l_ref).all()
+    np.testing.assert_allclose(losses.cpu().numpy(), l_ref, rtol=2e-3, atol=2e-3)
+    off = b["unflatten"].offset("sn", "drift_net/~/linear_3", "w")
+    got = grad[off:off + 4096].double().cpu().numpy().reshape(64, 64)
+    ref = np.asarray(g["sn"]["s_w2"])
+    assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max()
+    for leaf in ("mean", "logdiag"):
+        off = b["unflatten"].offset("vd", leaf)
+        assert np.abs(grad[off:off + 2].double().cpu().numpy() - g["vd"][leaf]).max() <= 2e-3 * np.abs(g["vd"][leaf]).max()

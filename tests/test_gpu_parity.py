@@ -105,3 +105,19 @@ def test_sibling_overdamped_modes_match_oracle(hip_lib, variant, name, mode, n, 
     l_ref, z_ref = orc.compute_log_elbo_batch(seeds, p, dim, K, mode, arch, oracle_target(b["cfg"]), dtype=np.float64)
     rep = compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"{name} {mode}")
     print(name, mode, rep)
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("n_mixes", [7, 17, 64])
+def test_many_gmm_with_other_mixture_sizes(hip_lib, monkeypatch, n_mixes, variant):
+    """config.n_mixes != 40 takes the generic component loop (the 40-mode fast path keeps squared distances — in the
+    cooperative kernel also the means — in registers); 64 is the library's maximum."""
+    monkeypatch.setattr(mcdbm, "KERNEL_VARIANT", variant)
+    b = synthetic.build("many_gmm_n2000_k256_dds", device="cuda", nbridges=24, n_mixes=n_mixes, init_sigma=20.0)
+    seeds = synthetic.parity_seeds(333)
+    mean, (losses, z) = mcdbm.compute_bound(torch.from_numpy(seeds).cuda(), b["params_flat"], b["unflatten"],
+                                            b["params_fixed"], b["target"], eps_schedule=b["eps_schedule"],
+                                            grad_clipping=b["grad_clipping"])
+    torch.cuda.synchronize()
+    l_ref, z_ref = run_oracle(b, seeds, dtype=np.float64)
+    compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"n_mixes={n_mixes}")
