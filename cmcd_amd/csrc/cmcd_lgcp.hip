@@ -30,10 +30,10 @@
 namespace cmcd {
 
 constexpr int kMP = 24;      // particles per pass (rows of the skinny GEMM)
-constexpr int kGemmWaves = 16;
+constexpr int kGemmWaves = 8;
 constexpr int kChunk = 32;   // k rows staged per round
 
-constexpr int kSplit = 4;    // K split across workgroups (partial slabs, summed in fixed order downstream)
+constexpr int kSplit = 8;    // K split across workgroups (partial slabs, summed in fixed order downstream)
 
 struct GemmSeg {
   const float* A;      // [kMP][lda]  activations (already formed)
