@@ -302,36 +302,32 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
       }
 #pragma unroll
       for (int t = 0; t < T; ++t) a2[t] = *reinterpret_cast<const f32x4*>(lds_b2 + 16 * t + 4 * g);
-      // fragments streamed from L2 (WGLOBAL): the address arithmetic stays inside the loop (an opaque lane offset), or
+      // fragments (LDS, or L2 when WGLOBAL): the address arithmetic stays inside the loop (an opaque lane offset), or
       // the T*T loop-invariant 64-bit addresses are hoisted into registers and spilled (324 dwords for T = 9); the row
       // of fragments for ti+1 is requested before the MFMAs of ti so that the L2 latency hides behind them
-      f32x4 afn[WGLOBAL ? T : 1];
-      if (WGLOBAL) {
+      f32x4 afn[T];
+      {
         int lofs = lane * 4;
         asm volatile("" : "+v"(lofs));
 #pragma unroll
-        for (int to = 0; to < T; ++to) afn[WGLOBAL ? to : 0] = *reinterpret_cast<const f32x4*>(w2f + to * 256 + lofs);
+        for (int to = 0; to < T; ++to) afn[to] = *reinterpret_cast<const f32x4*>(w2f + to * 256 + lofs);
       }
 #pragma unroll
       for (int ti = 0; ti < T; ++ti) {
         asm volatile("" ::: "memory");
         int lofs = lane * 4;
-        if (WGLOBAL) asm volatile("" : "+v"(lofs));
-        f32x4 afc[WGLOBAL ? T : 1];
-        if (WGLOBAL) {
+        asm volatile("" : "+v"(lofs));
+        f32x4 afc[T];
 #pragma unroll
-          for (int to = 0; to < T; ++to) afc[WGLOBAL ? to : 0] = afn[WGLOBAL ? to : 0];
-          if (ti + 1 < T) {
+        for (int to = 0; to < T; ++to) afc[to] = afn[to];
+        if (ti + 1 < T) {
 #pragma unroll
-            for (int to = 0; to < T; ++to)
-              afn[WGLOBAL ? to : 0] = *reinterpret_cast<const f32x4*>(w2f + ((ti + 1) * T + to) * 256 + lofs);
-          }
+          for (int to = 0; to < T; ++to) afn[to] = *reinterpret_cast<const f32x4*>(w2f + ((ti + 1) * T + to) * 256 + lofs);
         }
 #pragma unroll
         for (int to = 0; to < T; ++to) {
-          const f32x4 af = WGLOBAL ? afc[WGLOBAL ? to : 0] : *reinterpret_cast<const f32x4*>(w2f + (ti * T + to) * 256 + lofs);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) a2[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r], u1[ti][r], a2[to], 0, 0, 0);
+          for (int r = 0; r < 4; ++r) a2[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(afc[to][r], u1[ti][r], a2[to], 0, 0, 0);
         }
       }
       float opre[D], sn[D];
@@ -573,33 +569,29 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
       f32x4 d1[T];
 #pragma unroll
       for (int tk = 0; tk < T; ++tk) d1[tk] = GEF ? a2[tk] : f32x4{0.f, 0.f, 0.f, 0.f};
-      f32x4 atn[WGLOBAL ? T : 1];
-      if (WGLOBAL) {
+      f32x4 atn[T];
+      {
         int lofs = lane * 4;
         asm volatile("" : "+v"(lofs));
 #pragma unroll
-        for (int tk = 0; tk < T; ++tk) atn[WGLOBAL ? tk : 0] = *reinterpret_cast<const f32x4*>(w2tf + (tk * T) * 256 + lofs);
+        for (int tk = 0; tk < T; ++tk) atn[tk] = *reinterpret_cast<const f32x4*>(w2tf + (tk * T) * 256 + lofs);
       }
 #pragma unroll
       for (int tn = 0; tn < T; ++tn) {
         asm volatile("" ::: "memory");
         int lofs = lane * 4;
-        if (WGLOBAL) asm volatile("" : "+v"(lofs));
-        f32x4 atc[WGLOBAL ? T : 1];
-        if (WGLOBAL) {
+        asm volatile("" : "+v"(lofs));
+        f32x4 atc[T];
 #pragma unroll
-          for (int tk = 0; tk < T; ++tk) atc[WGLOBAL ? tk : 0] = atn[WGLOBAL ? tk : 0];
-          if (tn + 1 < T) {
+        for (int tk = 0; tk < T; ++tk) atc[tk] = atn[tk];
+        if (tn + 1 < T) {
 #pragma unroll
-            for (int tk = 0; tk < T; ++tk)
-              atn[WGLOBAL ? tk : 0] = *reinterpret_cast<const f32x4*>(w2tf + (tk * T + tn + 1) * 256 + lofs);
-          }
+          for (int tk = 0; tk < T; ++tk) atn[tk] = *reinterpret_cast<const f32x4*>(w2tf + (tk * T + tn + 1) * 256 + lofs);
         }
 #pragma unroll
         for (int tk = 0; tk < T; ++tk) {
-          const f32x4 af = WGLOBAL ? atc[WGLOBAL ? tk : 0] : *reinterpret_cast<const f32x4*>(w2tf + (tk * T + tn) * 256 + lofs);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) d1[tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r], d2[tn][r], d1[tk], 0, 0, 0);
+          for (int r = 0; r < 4; ++r) d1[tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(atc[tk][r], d2[tn][r], d1[tk], 0, 0, 0);
         }
       }
       float jpart[D];  // BPTT: J_s(z_e)^T a_s, this lane's share of the hidden units
