@@ -163,3 +163,31 @@ def test_full_length_gradient_against_autograd(hip_lib, mode):
             worst = max(worst, float((a - r).abs().max()) / scale)
     print(mode, "cosine", cos, "worst leaf error / scale", worst)
     assert cos > 0.9999 and worst < 2e-2
+
+
+@pytest.mark.parametrize("mode", ["MCD_CAIS_sn", "MCD_CAIS_var_sn"])
+def test_work_item_and_whole_chain_gradients_agree_on_a_large_batch(hip_lib, monkeypatch, mode):
+    """N = 6000 (ragged last tile), K = 256: the two gradient paths are different kernels and launch sequences of the
+    same arithmetic; they must agree to float32 accumulation noise."""
+    b = synthetic.build("many_gmm_n2000_k256_dds", device="cuda", boundmode=mode, init_sigma=15.0)
+    seeds = torch.from_numpy(synthetic.throughput_seeds(6000 - 7, stream=3)).cuda()
+    fn = mcdbm.compute_bound_grad if mode == "MCD_CAIS_sn" else mcdbm.compute_log_var_grad
+    out = {}
+    for item in ("0", "1"):
+        monkeypatch.setenv("CMCD_GRAD_ITEM", item)
+        g, (l, z) = fn(seeds, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"],
+                       eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
+        torch.cuda.synchronize()
+        out[item] = (g.double().cpu(), l.cpu())
+    assert torch.equal(out["0"][1], out["1"][1])
+    fin = torch.isfinite(out["0"][1])
+    assert bool(fin.all()), "sigma = 15 keeps every particle inside the floor"
+    ga, gb = out["0"][0], out["1"][0]
+    cos = float((ga * gb).sum() / (ga.norm() * gb.norm()))
+    assert cos > 1 - 1e-8, cos
+    for path, (off, shape) in b["unflatten"].layout.items():
+        numel = max(1, int(np.prod(shape)))
+        a, r = ga[off:off + numel], gb[off:off + numel]
+        scale = float(r.abs().max())
+        if scale > 1e-9:
+            assert float((a - r).abs().max()) <= 2e-4 * scale, (path, float((a - r).abs().max()), scale)
