@@ -1465,6 +1465,8 @@ static grad_fn pick_grad_t(const cmcd_desc& d, int T) {
   if (d.arch == CMCD_ARCH_GEFFNER) {
     if (d.target == CMCD_TARGET_GMM && d.dim == 2 && T == 2) return grad_kernel<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER, 2, 2, 4, false, BPTT, ITEM>;
     if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 2) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 2, 4, false, BPTT, ITEM>;
+    if (d.target == CMCD_TARGET_GMM && d.dim == 2 && T == 4) return grad_kernel<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER, 2, 4, 4, false, BPTT, ITEM>;
+    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 4) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 4, 4, false, BPTT, ITEM>;
     if (!BPTT && d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 9) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 9, 3, true, false, ITEM>;
     if (d.target == CMCD_TARGET_FUNNEL && d.dim == 10 && T == 4) return grad_kernel<CMCD_TARGET_FUNNEL, CMCD_ARCH_GEFFNER, 10, 4, 4, false, BPTT, ITEM>;
   }
@@ -1485,6 +1487,8 @@ static jac_fn pick_jac(const cmcd_desc& d, int T) {
   if (d.arch == CMCD_ARCH_GEFFNER) {
     if (d.target == CMCD_TARGET_GMM && d.dim == 2 && T == 2) return bptt_jac_kernel<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER, 2, 2>;
     if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 2) return bptt_jac_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 2>;
+    if (d.target == CMCD_TARGET_GMM && d.dim == 2 && T == 4) return bptt_jac_kernel<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER, 2, 4>;
+    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 4) return bptt_jac_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 4>;
     if (d.target == CMCD_TARGET_FUNNEL && d.dim == 10 && T == 4) return bptt_jac_kernel<CMCD_TARGET_FUNNEL, CMCD_ARCH_GEFFNER, 10, 4>;
   }
   return nullptr;

@@ -65,6 +65,13 @@ static bool hidden_width(const cmcd_desc& d, int& HP) {
   if (d.arch == CMCD_ARCH_GEFFNER) {
     if (d.emb_dim < 1) return false;
     HP = ((d.dim + d.emb_dim + 15) / 16) * 16;
+    // Kernel instances exist for 2, 4 and 9 neuron tiles (the BASELINE widths 22 / 58 / 132); any other width runs
+    // on the next larger instance with zero-padded weights: a padded unit has no outgoing weight, so it cannot
+    // reach the output, and its gradient entries are never copied out.  (lgcp has its own path: any width.)
+    if (d.target != CMCD_TARGET_LGCP) {
+      const int T = HP / 16;
+      HP = 16 * (T <= 2 ? 2 : (T <= 4 ? 4 : (T <= 9 ? 9 : T)));
+    }
     return true;
   }
   return false;

@@ -1,0 +1,185 @@
+"""Command-line driver with the reference's flag surface: `python -m cmcd_amd.main --config.model many_gmm
+--config.boundmode MCD_CAIS_sn --config.N 2000 --config.nbridges 256 --noconfig.pretrain_mfvi ...` runs what
+`python main.py --config.model ...` runs in /root/reference/src (main.py:52-300), on the HIP path:
+
+  mean-field pre-training (config.pretrain_mfvi)  ->  mcdbm.initialize(vdparams=vdparams_init)  ->  opt.run
+  ->  opt.sample / log_final_losses (n_input_dist_seeds x n_samples)  [-> the same with the EMA parameters]
+
+Flag names, defaults and the `--config.x value` / `--config.x=value` / `--noconfig.x` forms follow
+/root/reference/src/configs/base.py:77-155 (ml_collections + absl).  Left out: W&B, plotting, W2 distances, the
+sweep tables that override lr / init_eps for the inference-gym targets.  Modes outside the overdamped family raise
+NotImplementedError exactly like the library.  Under torchrun the particles of every iteration are sharded over the
+ranks (parallel.make_sharded_grad_and_loss)."""
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def get_config():
+    """/root/reference/src/configs/base.py:77-155 (the fields this driver reads)."""
+    c = types.SimpleNamespace()
+    c.boundmode = "UHA"
+    c.model = "lorenz"
+    c.N = 5
+    c.nbridges = 8
+    c.lfsteps = 1
+    c.emb_dim = 20
+    c.nlayers = 3
+    c.init_eta = 0.0
+    c.init_eps = 1e-5
+    c.init_sigma = 1.0
+    c.pretrain_mfvi = True
+    c.train_vi = True
+    c.train_eps = True
+    c.train_betas = True
+    c.nn_arch = "geffner"
+    c.eps_schedule = ""
+    c.grad_clipping = False
+    c.mfvi_iters = 150000
+    c.mfvi_lr = 0.01
+    c.iters = 150000
+    c.lr = 0.0001
+    c.seed = 1
+    c.n_samples = 500
+    c.n_input_dist_seeds = 30
+    c.use_ema = False
+    c.funnel_d = 10
+    c.n_mixes = 40
+    c.loc_scaling = 40
+    c.file_path = os.path.join(os.getcwd(), "../pines.csv")
+    c.save_params = ""          # extra: path of a params.pkl to write (the reference logs it as a W&B artifact)
+    return c
+
+
+def parse_flags(argv, config):
+    """absl / ml_collections style: --config.name value | --config.name=value | --config.flag | --noconfig.flag"""
+    i = 0
+    while i < len(argv):
+        a = argv[i]
+        if a.startswith("--noconfig."):
+            name = a[len("--noconfig."):]
+            if not isinstance(getattr(config, name, None), bool):
+                raise SystemExit(f"--noconfig.{name}: not a boolean field")
+            setattr(config, name, False)
+            i += 1
+            continue
+        if not a.startswith("--config."):
+            raise SystemExit(f"unknown argument {a!r} (expected --config.<field> ...)")
+        name, eq, val = a[len("--config."):].partition("=")
+        if not hasattr(config, name):
+            raise SystemExit(f"unknown config field {name!r}")
+        cur = getattr(config, name)
+        if isinstance(cur, bool):
+            if eq:
+                setattr(config, name, val.lower() in ("1", "true", "yes"))
+            else:
+                setattr(config, name, True)
+            i += 1
+            continue
+        if not eq:
+            i += 1
+            if i >= len(argv):
+                raise SystemExit(f"--config.{name} needs a value")
+            val = argv[i]
+        setattr(config, name, type(cur)(val) if not isinstance(cur, str) else val)
+        i += 1
+    return config
+
+
+def main(config):
+    import torch.distributed as dist
+    from . import boundingmachine as bm
+    from . import mcdboundingmachine as mcdbm
+    from . import opt, parallel, utils
+    from .model_handler import load_model
+
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("cmcd_amd.main needs a ROCm GPU (no CPU fallback for the hot path)")
+    torch.cuda.set_device(local)
+    if "RANK" in os.environ and "MASTER_PORT" in os.environ:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    say = print if rank == 0 else (lambda *a, **k: None)
+    say({k: v for k, v in vars(config).items()})
+
+    if "lgcp" in config.model and not os.path.exists(config.file_path):
+        # the point set is reference content; its 40 x 40 bin counts ship as a test fixture
+        from .lgcp import load_model_lgcp
+        counts = np.load(os.path.join(ROOT, "tests", "golden", "lgcp_bin_counts.npy"))
+        res = load_model_lgcp(config.model, config, flat_bin_counts=counts)
+    else:
+        res = load_model(config.model, config)
+    log_prob_model, dim = res[0], res[1]
+
+    gen = torch.Generator().manual_seed(config.seed)                       # train_rng_key_gen
+    eval_gen = torch.Generator().manual_seed(config.seed + 1)              # eval_rng_key_gen
+    device = torch.device("cuda", local)
+
+    # Train initial variational distribution to maximize the ELBO            main.py:81-109
+    trainable = ("vd",)
+    params_flat, unflatten, params_fixed = bm.initialize(dim=dim, nbridges=0, trainable=trainable,
+                                                         init_sigma=config.init_sigma, device=device)
+    if config.pretrain_mfvi:
+        losses, params_flat, _ = opt.run(config, config.mfvi_lr, config.mfvi_iters, params_flat, unflatten, params_fixed,
+                                         log_prob_model, bm.grad_and_loss, trainable, gen, log_prefix="pretrain")
+        elbo_init = -float(np.mean(losses[-500:]))
+        say("Done training initial parameters, got ELBO %.2f." % elbo_init)
+    vdparams_init = {k: v.detach().cpu().clone() for k, v in unflatten(params_flat)[0]["vd"].items()}
+
+    if "MCD" not in config.boundmode:
+        raise NotImplementedError("Mode %s not implemented." % config.boundmode)       # UHA: outside this build
+    trainable = ("eta", "gamma")
+    if config.train_eps:
+        trainable += ("eps",)
+    if config.train_vi:
+        trainable += ("vd",)
+    if config.train_betas:
+        trainable += ("mgridref_y",)
+    say(f"Params being trained : {trainable}")
+    params_flat, unflatten, params_fixed = mcdbm.initialize(
+        dim=dim, nbridges=config.nbridges, vdparams=vdparams_init, eta=config.init_eta, eps=config.init_eps,
+        trainable=trainable, mode=config.boundmode, emb_dim=config.emb_dim, nlayers=config.nlayers,
+        nn_arch=config.nn_arch, device=device)
+    grad_and_loss, loss_fn = mcdbm.make_grad_and_loss(config.boundmode, eps_schedule=config.eps_schedule,
+                                                      grad_clipping=config.grad_clipping)
+    if world > 1:
+        grad_and_loss = parallel.make_sharded_grad_and_loss(config.boundmode, eps_schedule=config.eps_schedule,
+                                                            grad_clipping=config.grad_clipping)
+
+    t0 = time.time()
+    _, params_flat, ema_params = opt.run(config, config.lr, config.iters, params_flat, unflatten, params_fixed,
+                                         log_prob_model, grad_and_loss, trainable, gen, use_ema=config.use_ema)
+    torch.cuda.synchronize()
+    say("%d iterations in %.1f s" % (config.iters, time.time() - t0))
+
+    # Average over n_input_dist_seeds seeds, n_samples samples each, after training is done.   main.py:179-226
+    n = config.n_samples * config.n_input_dist_seeds
+    eval_seeds = torch.randint(1, 1000000, (n,), generator=eval_gen, dtype=torch.int32).to(device)
+    eval_losses, samples = utils.sample(config, config.n_samples, config.n_input_dist_seeds, params_flat, unflatten,
+                                        params_fixed, log_prob_model, loss_fn, eval_seeds, log_prefix="eval")
+    final_elbo, final_ln_Z = utils.log_final_losses(eval_losses.cpu())
+    say("Done training, got ELBO %.2f." % final_elbo)
+    say("Done training, got ln Z %.2f." % final_ln_Z)
+    if config.use_ema:
+        eval_losses_ema, _ = utils.sample(config, config.n_samples, config.n_input_dist_seeds, ema_params, unflatten,
+                                          params_fixed, log_prob_model, loss_fn, eval_seeds, log_prefix="eval")
+        e2, z2 = utils.log_final_losses(eval_losses_ema.cpu(), log_prefix="_ema")
+        say("With EMA, got ELBO %.2f." % e2)
+        say("With EMA, got ln Z %.2f." % z2)
+    if config.save_params and rank == 0:
+        utils.save_params(config.save_params, params_flat, unflatten)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    return final_elbo, final_ln_Z
+
+
+if __name__ == "__main__":
+    main(parse_flags(sys.argv[1:], get_config()))

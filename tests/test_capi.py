@@ -118,7 +118,8 @@ def test_gradient_and_optimiser_entry_points_validate_before_any_gpu_work(hip_li
     assert hip_lib.cmcd_bound_grad_workspace_bytes(C.byref(_desc(mode=3, arch=0, emb_dim=20, target=0)), 300) > 0
     assert hip_lib.cmcd_bound_grad_workspace_bytes(C.byref(_desc(arch=0, emb_dim=20, target=3, dim=1600, nbridges=4)), 20) > 0
     assert hip_lib.cmcd_grad_workspace_bytes(C.byref(_desc(mode=1)), 2000) > 0
-    assert hip_lib.cmcd_grad_workspace_bytes(C.byref(_desc(mode=1, arch=0, emb_dim=31)), 2000) == 0       # width 33: no instance
+    assert hip_lib.cmcd_grad_workspace_bytes(C.byref(_desc(mode=1, arch=0, emb_dim=31)), 2000) > 0        # width 33 runs padded to 64
+    assert hip_lib.cmcd_grad_workspace_bytes(C.byref(_desc(mode=1, arch=0, emb_dim=200)), 2000) == 0      # width 202 > 144: no instance
     assert hip_lib.cmcd_mfvi_workspace_bytes(2, 2, 1000) > 0 and hip_lib.cmcd_mfvi_workspace_bytes(3, 1600, 20) > 0
     assert hip_lib.cmcd_mfvi_workspace_bytes(1, 7, 100) == 0                                              # funnel d = 7
     # null pointers / wrong modes are refused with a message

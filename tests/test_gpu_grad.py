@@ -47,6 +47,8 @@ CASES = [
     ("funnel_n300_k64", 70, dict(boundmode="MCD_CAIS_var_sn", nbridges=6)),
     ("many_gmm_var_n16000_k256", 64, dict(nbridges=6, emb_dim=20)),
     ("many_gmm_var_n16000_k256", 80, dict(nbridges=5)),                  # 132-wide net (config 4), 3-wave groups
+    ("many_gmm_var_n16000_k256", 60, dict(nbridges=6, emb_dim=40)),      # the reference README's example width (42 -> padded to 64)
+    ("many_gmm_var_n16000_k256", 40, dict(nbridges=4, emb_dim=70)),      # width 72 -> padded to 144
 ]
 
 
@@ -107,6 +109,8 @@ BPTT_CASES = [
     ("gmm_n300_k8", 64, dict(nn_arch="dds", grad_clipping=True)),
     ("funnel_n300_k64", 70, dict(nbridges=6)),                                                # d = 10, geffner 58
     ("many_gmm_n2000_k256_dds", 64, dict(nbridges=6, nn_arch="geffner", emb_dim=20, init_sigma=15.0, init_eps=0.3)),
+    ("many_gmm_n2000_k256_dds", 48, dict(nbridges=5, nn_arch="geffner", emb_dim=40, init_sigma=15.0, init_eps=0.3)),   # width 42 -> 64
+    ("gmm_n300_k8", 50, dict(emb_dim=7)),                                                                              # width 9 -> 32
 ]
 
 

@@ -121,3 +121,20 @@ def test_many_gmm_with_other_mixture_sizes(hip_lib, monkeypatch, n_mixes, varian
     torch.cuda.synchronize()
     l_ref, z_ref = run_oracle(b, seeds, dtype=np.float64)
     compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"n_mixes={n_mixes}")
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("model,emb_dim", [("gmm", 5), ("many_gmm", 40), ("many_gmm", 70), ("funnel", 30)])
+def test_network_widths_between_the_instances_run_zero_padded(hip_lib, monkeypatch, model, emb_dim, variant):
+    """config.emb_dim is free in the reference (README: --config.emb_dim 40).  Widths without an instance of their
+    own (here 7, 42, 72 and 40) run on the next larger one with zero-padded weights: same numbers."""
+    monkeypatch.setattr(mcdbm, "KERNEL_VARIANT", variant)
+    name = {"gmm": "gmm_n300_k8", "many_gmm": "many_gmm_var_n16000_k256", "funnel": "funnel_n300_k64"}[model]
+    b = synthetic.build(name, device="cuda", emb_dim=emb_dim, nbridges=12, boundmode="MCD_CAIS_sn")
+    seeds = synthetic.parity_seeds(200)
+    mean, (losses, z) = mcdbm.compute_bound(torch.from_numpy(seeds).cuda(), b["params_flat"], b["unflatten"],
+                                            b["params_fixed"], b["target"], eps_schedule=b["eps_schedule"],
+                                            grad_clipping=b["grad_clipping"])
+    torch.cuda.synchronize()
+    l_ref, z_ref = run_oracle(b, seeds, dtype=np.float64)
+    compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"{model} emb_dim={emb_dim}")

@@ -108,3 +108,22 @@ def test_params_pickle_round_trip(tmp_path):
         d["vd"]["mean"] = np.zeros(3)
         with pytest.raises(ValueError):
             utils.load_params(d, flat, unflatten)
+
+
+def test_main_flag_surface_follows_the_reference():
+    """--config.x value / --config.x=value / --config.flag / --noconfig.flag (configs/base.py + absl)."""
+    from cmcd_amd import main as drv
+    c = drv.parse_flags(["--config.model", "many_gmm", "--config.boundmode=MCD_CAIS_var_sn", "--config.N", "300",
+                         "--config.nbridges=128", "--noconfig.pretrain_mfvi", "--config.init_sigma", "10",
+                         "--config.grad_clipping", "--config.init_eps", "0.65", "--config.emb_dim", "40",
+                         "--noconfig.train_eps", "--noconfig.train_vi"], drv.get_config())
+    assert (c.model, c.boundmode, c.N, c.nbridges, c.pretrain_mfvi, c.init_sigma, c.grad_clipping, c.init_eps, c.emb_dim,
+            c.train_eps, c.train_vi, c.train_betas) == ("many_gmm", "MCD_CAIS_var_sn", 300, 128, False, 10.0, True, 0.65,
+                                                        40, False, False, True)
+    d = drv.get_config()
+    assert (d.boundmode, d.N, d.nbridges, d.lr, d.mfvi_lr, d.iters, d.n_samples, d.n_input_dist_seeds, d.nn_arch) == (
+        "UHA", 5, 8, 1e-4, 0.01, 150000, 500, 30, "geffner")
+    with pytest.raises(SystemExit):
+        drv.parse_flags(["--config.nonsense", "1"], drv.get_config())
+    with pytest.raises(SystemExit):
+        drv.parse_flags(["--noconfig.N"], drv.get_config())
