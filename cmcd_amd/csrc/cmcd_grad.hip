@@ -1460,6 +1460,7 @@ static grad_fn pick_grad_t(const cmcd_desc& d, int T) {
   if (d.arch == CMCD_ARCH_DDS && T == 4) {
     if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_DDS, 2, 4, 4, false, BPTT, ITEM>;
     if (d.target == CMCD_TARGET_GMM && d.dim == 2) return grad_kernel<CMCD_TARGET_GMM, CMCD_ARCH_DDS, 2, 4, 4, false, BPTT, ITEM>;
+    if (d.target == CMCD_TARGET_FUNNEL && d.dim == 10) return grad_kernel<CMCD_TARGET_FUNNEL, CMCD_ARCH_DDS, 10, 4, 4, false, BPTT, ITEM>;
     return nullptr;
   }
   if (d.arch == CMCD_ARCH_GEFFNER) {
@@ -1467,7 +1468,8 @@ static grad_fn pick_grad_t(const cmcd_desc& d, int T) {
     if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 2) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 2, 4, false, BPTT, ITEM>;
     if (d.target == CMCD_TARGET_GMM && d.dim == 2 && T == 4) return grad_kernel<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER, 2, 4, 4, false, BPTT, ITEM>;
     if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 4) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 4, 4, false, BPTT, ITEM>;
-    if (!BPTT && d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 9) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 9, 3, true, false, ITEM>;
+    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 9) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 9, 3, true, BPTT, ITEM>;
+    if (d.target == CMCD_TARGET_GMM && d.dim == 2 && T == 9) return grad_kernel<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER, 2, 9, 3, true, BPTT, ITEM>;
     if (d.target == CMCD_TARGET_FUNNEL && d.dim == 10 && T == 4) return grad_kernel<CMCD_TARGET_FUNNEL, CMCD_ARCH_GEFFNER, 10, 4, 4, false, BPTT, ITEM>;
   }
   return nullptr;
@@ -1482,6 +1484,7 @@ static jac_fn pick_jac(const cmcd_desc& d, int T) {
   if (d.arch == CMCD_ARCH_DDS && T == 4) {
     if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2) return bptt_jac_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_DDS, 2, 4>;
     if (d.target == CMCD_TARGET_GMM && d.dim == 2) return bptt_jac_kernel<CMCD_TARGET_GMM, CMCD_ARCH_DDS, 2, 4>;
+    if (d.target == CMCD_TARGET_FUNNEL && d.dim == 10) return bptt_jac_kernel<CMCD_TARGET_FUNNEL, CMCD_ARCH_DDS, 10, 4>;
     return nullptr;
   }
   if (d.arch == CMCD_ARCH_GEFFNER) {
@@ -1489,6 +1492,8 @@ static jac_fn pick_jac(const cmcd_desc& d, int T) {
     if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 2) return bptt_jac_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 2>;
     if (d.target == CMCD_TARGET_GMM && d.dim == 2 && T == 4) return bptt_jac_kernel<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER, 2, 4>;
     if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 4) return bptt_jac_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 4>;
+    if (d.target == CMCD_TARGET_GMM && d.dim == 2 && T == 9) return bptt_jac_kernel<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER, 2, 9>;
+    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 9) return bptt_jac_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 9>;
     if (d.target == CMCD_TARGET_FUNNEL && d.dim == 10 && T == 4) return bptt_jac_kernel<CMCD_TARGET_FUNNEL, CMCD_ARCH_GEFFNER, 10, 4>;
   }
   return nullptr;

@@ -70,7 +70,9 @@ static bool hidden_width(const cmcd_desc& d, int& HP) {
     // reach the output, and its gradient entries are never copied out.  (lgcp has its own path: any width.)
     if (d.target != CMCD_TARGET_LGCP) {
       const int T = HP / 16;
-      HP = 16 * (T <= 2 ? 2 : (T <= 4 ? 4 : (T <= 9 ? 9 : T)));
+      // funnel (d = 10): its gradient kernels start at 4 tiles, and forward / gradient share one workspace layout
+      const int tmin = d.target == CMCD_TARGET_FUNNEL ? 4 : 2;
+      HP = 16 * (T <= tmin ? tmin : (T <= 4 ? 4 : (T <= 9 ? 9 : T)));
     }
     return true;
   }

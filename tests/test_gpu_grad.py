@@ -45,10 +45,13 @@ CASES = [
                                          init_eps=0.3)),
     ("gmm_n300_k8", 128, dict(boundmode="MCD_CAIS_var_sn", grad_clipping=True)),
     ("funnel_n300_k64", 70, dict(boundmode="MCD_CAIS_var_sn", nbridges=6)),
+    ("funnel_n300_k64", 40, dict(boundmode="MCD_CAIS_var_sn", nbridges=5, emb_dim=20)),          # the default emb_dim: width 30 -> 64
+    ("funnel_n300_k64", 40, dict(boundmode="MCD_CAIS_var_sn", nbridges=5, nn_arch="dds")),
     ("many_gmm_var_n16000_k256", 64, dict(nbridges=6, emb_dim=20)),
     ("many_gmm_var_n16000_k256", 80, dict(nbridges=5)),                  # 132-wide net (config 4), 3-wave groups
     ("many_gmm_var_n16000_k256", 60, dict(nbridges=6, emb_dim=40)),      # the reference README's example width (42 -> padded to 64)
     ("many_gmm_var_n16000_k256", 40, dict(nbridges=4, emb_dim=70)),      # width 72 -> padded to 144
+    ("gmm_n300_k8", 40, dict(boundmode="MCD_CAIS_var_sn", nbridges=4, emb_dim=90)),   # 9 tiles on gmm
 ]
 
 
@@ -108,9 +111,13 @@ BPTT_CASES = [
     ("gmm_n300_k8", 128, dict()),                                                             # geffner 22
     ("gmm_n300_k8", 64, dict(nn_arch="dds", grad_clipping=True)),
     ("funnel_n300_k64", 70, dict(nbridges=6)),                                                # d = 10, geffner 58
+    ("funnel_n300_k64", 40, dict(nbridges=5, emb_dim=20)),                                    # default emb_dim (width 30 -> 64)
+    ("funnel_n300_k64", 40, dict(nbridges=5, nn_arch="dds")),
     ("many_gmm_n2000_k256_dds", 64, dict(nbridges=6, nn_arch="geffner", emb_dim=20, init_sigma=15.0, init_eps=0.3)),
     ("many_gmm_n2000_k256_dds", 48, dict(nbridges=5, nn_arch="geffner", emb_dim=40, init_sigma=15.0, init_eps=0.3)),   # width 42 -> 64
     ("gmm_n300_k8", 50, dict(emb_dim=7)),                                                                              # width 9 -> 32
+    ("many_gmm_n2000_k256_dds", 40, dict(nbridges=4, nn_arch="geffner", emb_dim=100, init_sigma=15.0, init_eps=0.3)),  # width 102 -> 144
+    ("gmm_n300_k8", 40, dict(nbridges=4, emb_dim=130)),                                                                # 9 tiles, gmm
 ]
 
 
@@ -200,8 +207,8 @@ def test_training_with_the_reparameterised_gradient_raises_the_elbo(hip_lib):
 
 def test_unsupported_configurations_fail_loudly(hip_lib):
     seeds = torch.arange(1, 33, dtype=torch.int32).cuda()
-    b = synthetic.build("funnel_n300_k64", device="cuda", boundmode="MCD_CAIS_var_sn", nbridges=4, emb_dim=20)
-    with pytest.raises(NotImplementedError):                                          # width 30: no instance
+    b = synthetic.build("funnel_n300_k64", device="cuda", boundmode="MCD_CAIS_var_sn", nbridges=4, emb_dim=160)
+    with pytest.raises(NotImplementedError):                                          # width 170 > 144: no instance
         mcdbm.compute_log_var_grad(seeds, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"])
     b = synthetic.build("gmm_n300_k8", device="cuda")                                 # MCD_CAIS_sn
     with pytest.raises(NotImplementedError, match="Mode not implemented."):
@@ -209,7 +216,7 @@ def test_unsupported_configurations_fail_loudly(hip_lib):
     b = synthetic.build("gmm_n300_k8", device="cuda", boundmode="MCD_CAIS_var_sn")    # wrong mode for the full gradient
     with pytest.raises(NotImplementedError, match="Mode not implemented."):
         mcdbm.compute_bound_grad(seeds, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"])
-    b = synthetic.build("many_gmm_var_n16000_k256", device="cuda", boundmode="MCD_CAIS_sn", nbridges=4)   # width 132
+    b = synthetic.build("funnel_n300_k64", device="cuda", nbridges=4, emb_dim=100)                        # funnel beyond 4 tiles
     with pytest.raises(NotImplementedError):
         mcdbm.compute_bound_grad(seeds, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"])
 
