@@ -7,7 +7,7 @@
 
 Flag names, defaults and the `--config.x value` / `--config.x=value` / `--noconfig.x` forms follow
 /root/reference/src/configs/base.py:77-155 (ml_collections + absl).  Left out: W&B, plotting, W2 distances, the
-sweep tables that override lr / init_eps for the inference-gym targets.  Modes outside the overdamped family raise
+inference-gym rows of the lr table.  Modes outside the overdamped family raise
 NotImplementedError exactly like the library.  Under torchrun the particles of every iteration are sharded over the
 ranks (parallel.make_sharded_grad_and_loss)."""
 import os
@@ -55,6 +55,26 @@ def get_config():
     c.file_path = os.path.join(os.getcwd(), "../pines.csv")
     c.save_params = ""          # extra: path of a params.pkl to write (the reference logs it as a W&B artifact)
     return c
+
+
+# /root/reference/src/configs/base.py:5-75 (the entries of the models this build runs)
+LR_DICT = {"lgcp": {"MCD_CAIS_UHA_sn": 1e-3, "MCD_CAIS_sn": 1e-4, "MCD_U_a-lp-sn": 1e-3, "UHA": 1e-4, "MCD_ULA_sn": 1e-4,
+                    "MCD_ULA": 1e-4}}
+FUNNEL_EPS_DICT = {8: {"init_eps": 0.1, "lr": 0.01}, 16: {"init_eps": 0.1, "lr": 0.01}, 32: {"init_eps": 0.1, "lr": 0.005},
+                   64: {"init_eps": 0.1, "lr": 0.001}, 128: {"init_eps": 0.01, "lr": 0.01}, 256: {"init_eps": 0.01, "lr": 0.005}}
+
+
+def setup_config(config):
+    """/root/reference/src/utils.py:181-204: the tuned lr / init_eps that main.py writes over the flags
+    (funnel: by nbridges; lgcp: by boundmode; gmm / many_gmm: none; unknown keys: none)."""
+    try:
+        if config.model == "funnel":
+            config.init_eps, config.lr = FUNNEL_EPS_DICT[config.nbridges]["init_eps"], FUNNEL_EPS_DICT[config.nbridges]["lr"]
+        elif config.model not in ("many_gmm", "gmm"):
+            config.lr = LR_DICT[config.model][config.boundmode]
+    except KeyError:
+        print("LR not found for model %s and boundmode %s" % (config.model, config.boundmode))
+    return config
 
 
 def parse_flags(argv, config):
@@ -108,6 +128,7 @@ def main(config):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     say = print if rank == 0 else (lambda *a, **k: None)
+    setup_config(config)                                                   # main.py:64-66
     say({k: v for k, v in vars(config).items()})
 
     if "lgcp" in config.model and not os.path.exists(config.file_path):

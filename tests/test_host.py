@@ -127,3 +127,15 @@ def test_main_flag_surface_follows_the_reference():
         drv.parse_flags(["--config.nonsense", "1"], drv.get_config())
     with pytest.raises(SystemExit):
         drv.parse_flags(["--noconfig.N"], drv.get_config())
+
+
+def test_main_applies_the_tuned_lr_and_eps_tables():
+    from cmcd_amd import main as drv
+    c = drv.setup_config(drv.parse_flags(["--config.model", "funnel", "--config.nbridges", "32"], drv.get_config()))
+    assert (c.init_eps, c.lr) == (0.1, 0.005)
+    c = drv.setup_config(drv.parse_flags(["--config.model", "lgcp", "--config.boundmode", "MCD_CAIS_sn"], drv.get_config()))
+    assert c.lr == 1e-4
+    c = drv.setup_config(drv.parse_flags(["--config.model", "many_gmm", "--config.lr", "0.01"], drv.get_config()))
+    assert c.lr == 0.01
+    c = drv.setup_config(drv.parse_flags(["--config.model", "funnel", "--config.nbridges", "7"], drv.get_config()))
+    assert c.lr == 1e-4                                                     # KeyError branch: flags stand
