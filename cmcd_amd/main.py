@@ -6,8 +6,7 @@
   ->  opt.sample / log_final_losses (n_input_dist_seeds x n_samples)  [-> the same with the EMA parameters]
 
 Flag names, defaults and the `--config.x value` / `--config.x=value` / `--noconfig.x` forms follow
-/root/reference/src/configs/base.py:77-155 (ml_collections + absl).  Left out: W&B, plotting, W2 distances, the
-inference-gym rows of the lr table.  Modes outside the overdamped family raise
+/root/reference/src/configs/base.py:77-155 (ml_collections + absl).  Left out: W&B, plotting, the inference-gym rows of the lr table.  Modes outside the overdamped family raise
 NotImplementedError exactly like the library.  Under torchrun the particles of every iteration are sharded over the
 ranks (parallel.make_sharded_grad_and_loss)."""
 import os
@@ -48,7 +47,10 @@ def get_config():
     c.seed = 1
     c.n_samples = 500
     c.n_input_dist_seeds = 30
+    c.n_sinkhorn = 300      # read by nobody, like the reference (main.py passes n_samples)
     c.use_ema = False
+    c.funnel_sig = 3
+    c.funnel_clipy = 11
     c.funnel_d = 10
     c.n_mixes = 40
     c.loc_scaling = 40
@@ -139,6 +141,7 @@ def main(config):
     else:
         res = load_model(config.model, config)
     log_prob_model, dim = res[0], res[1]
+    sample_from_target_fn = res[2] if len(res) > 2 and config.model in ("funnel", "gmm", "many_gmm") else None   # TRACTABLE_DISTS
 
     gen = torch.Generator().manual_seed(config.seed)                       # train_rng_key_gen
     eval_gen = torch.Generator().manual_seed(config.seed + 1)              # eval_rng_key_gen
@@ -190,11 +193,21 @@ def main(config):
     say("Done training, got ELBO %.2f." % final_elbo)
     say("Done training, got ln Z %.2f." % final_ln_Z)
     if config.use_ema:
-        eval_losses_ema, _ = utils.sample(config, config.n_samples, config.n_input_dist_seeds, ema_params, unflatten,
+        eval_losses_ema, samples_ema = utils.sample(config, config.n_samples, config.n_input_dist_seeds, ema_params, unflatten,
                                           params_fixed, log_prob_model, loss_fn, eval_seeds, log_prefix="eval")
         e2, z2 = utils.log_final_losses(eval_losses_ema.cpu(), log_prefix="_ema")
         say("With EMA, got ELBO %.2f." % e2)
         say("With EMA, got ln Z %.2f." % z2)
+    if sample_from_target_fn is not None and config.model in ("funnel", "gmm") and rank == 0:   # main.py:248-271
+        tgt = torch.from_numpy(sample_from_target_fn(1, n)).to(device)
+        other = torch.from_numpy(sample_from_target_fn(2, n)).to(device)
+        clouds = [("", samples)] + ([("_ema", samples_ema)] if config.use_ema else [])
+        for prefix, cloud in clouds:
+            w2 = utils.calculate_W2_distances(cloud, tgt, other, config.n_samples, config.n_input_dist_seeds,
+                                              config.n_samples, log_prefix=prefix)
+            say("W2%s to the target %.4f (+- %.4f); between two target draws %.4f (+- %.4f)" % (
+                prefix, w2["w2_dist" + prefix], w2["w2_dist_std" + prefix], w2["self_w2_dist" + prefix],
+                w2["self_w2_dist_std" + prefix]))
     if config.save_params and rank == 0:
         utils.save_params(config.save_params, params_flat, unflatten)
     if dist.is_initialized():

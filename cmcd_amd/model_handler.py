@@ -63,15 +63,54 @@ def _no_sampler(*a, **k):
     raise NotImplementedError("sampling from the target is outside the CMCD hot path")
 
 
+# Exact samplers of the tractable targets (the third return value of the reference's load_model; main.py:185-190
+# draws target samples for the W2 metrics).  `rng` is an int seed or a numpy Generator: the reference's jax key
+# streams are not reproduced (these samples only feed a distance between point clouds).
+def _gen(rng):
+    return rng if isinstance(rng, np.random.Generator) else np.random.default_rng(int(rng))
+
+
+def _funnel_sampler(d, sig=3.0, clip_y=11.0):
+    def sample_data(rng, n_samples):
+        """/root/reference/src/model_handler.py:145-152 (including its exp(-y/2) scale)."""
+        g = _gen(rng)
+        y = np.clip(sig * g.standard_normal((n_samples, 1)), -clip_y, clip_y)
+        x = g.standard_normal((n_samples, d - 1)) * np.exp(-y / 2)
+        return np.concatenate((y, x), axis=1).astype(np.float32)
+    return sample_data
+
+
+def _gmm_sampler(rng, num_samples):
+    """/root/reference/src/model_handler.py:204-229: the 3-component mixture (not its flip-symmetrised density)."""
+    g = _gen(rng)
+    means = np.array([[3.0, 0.0], [-2.5, 0.0], [2.0, 3.0]])
+    covs = np.array([[[0.7, 0.0], [0.0, 0.05]], [[0.7, 0.0], [0.0, 0.05]], [[1.0, 0.95], [0.95, 1.0]]])
+    idx = g.integers(0, 3, num_samples)
+    chol = np.linalg.cholesky(covs)
+    e = g.standard_normal((num_samples, 2))
+    return (means[idx] + np.einsum("nij,nj->ni", chol[idx], e)).astype(np.float32)
+
+
+def _many_gmm_sampler(consts, n_mixes):
+    def sample(seed, sample_shape):
+        """distrax.MixtureSameFamily(Categorical(uniform), Normal(mean, scale)).sample (model_handler.py:283-284)."""
+        g = _gen(seed)
+        n = int(np.prod(sample_shape))
+        mean = np.asarray(consts[1:], np.float64).reshape(n_mixes, 2)
+        idx = g.integers(0, n_mixes, n)
+        return (mean[idx] + float(consts[0]) * g.standard_normal((n, 2))).astype(np.float32).reshape(tuple(sample_shape) + (2,))
+    return sample
+
+
 def load_model_funnel(model="funnel", config=None):
     """/root/reference/src/model_handler.py:124-154"""
     d = int(_cfg(config, "funnel_d", 10))
-    return Target("funnel", d), d, _no_sampler
+    return Target("funnel", d), d, _funnel_sampler(d, float(_cfg(config, "funnel_sig", 3)), float(_cfg(config, "funnel_clipy", 11)))
 
 
 def load_model_gmm(model="gmm", config=None):
     """/root/reference/src/model_handler.py:157-242"""
-    return Target("gmm", 2), 2, _no_sampler
+    return Target("gmm", 2), 2, _gmm_sampler
 
 
 def many_gmm_constants(n_mixes=40, loc_scaling=40.0, log_var_scaling=0.1, seed=0):
@@ -86,7 +125,8 @@ def load_model_manygmm(model="many_gmm", config=None):
     """/root/reference/src/model_handler.py:245-281"""
     n_mixes = int(_cfg(config, "n_mixes", 40))
     loc_scaling = float(_cfg(config, "loc_scaling", 40))
-    return Target("many_gmm", 2, many_gmm_constants(n_mixes, loc_scaling), n_mixes=n_mixes), 2, _no_sampler
+    consts = many_gmm_constants(n_mixes, loc_scaling)
+    return Target("many_gmm", 2, consts, n_mixes=n_mixes), 2, _many_gmm_sampler(consts, n_mixes)
 
 
 def load_model(model="many_gmm", config=None):

@@ -98,3 +98,43 @@ def load_params(path_or_dict, params_flat, unflatten):
             out[off:off + max(arr.size, 1)] = torch.from_numpy(arr.reshape(-1)).to(out.device)
     walk(params, ())
     return out
+
+
+def W2_distance(x, y, reg=0.01, num_iter_max=10000, stop_thr=1e-16):
+    """/root/reference/src/utils.py:207-216: entropic OT cost `ot.sinkhorn2(a, b, M / M.max(), reg)` between two equal-size
+    point clouds with uniform weights — the Sinkhorn-Knopp iteration of POT's default solver (POT itself is not in this
+    image), in float64 torch on the device of `x`: u <- a / (K v), v <- b / (K^T u), K = exp(-M / reg); stops when the
+    marginal violation drops below `stop_thr` (checked every 10 iterations) or after `num_iter_max` iterations."""
+    x = torch.as_tensor(x, dtype=torch.float64)
+    y = torch.as_tensor(y, dtype=torch.float64, device=x.device)
+    n = x.shape[0]
+    a = torch.full((n,), 1.0 / n, dtype=torch.float64, device=x.device)
+    b = a.clone()
+    M = torch.cdist(x, y) ** 2                      # ot.dist default: squared Euclidean
+    M = M / M.max()
+    Kmat = torch.exp(-M / reg)
+    u, v = torch.ones_like(a) / n, torch.ones_like(b) / n
+    for it in range(num_iter_max):
+        KtU = Kmat.t() @ u
+        v = b / KtU
+        u = a / (Kmat @ v)
+        if it % 10 == 0:
+            err = torch.linalg.norm(v * (Kmat.t() @ u) - b) ** 2
+            if float(err) < stop_thr:
+                break
+    P = u[:, None] * Kmat * v[None, :]
+    return float((P * M).sum())
+
+
+def calculate_W2_distances(samples, target_samples, other_target_samples, n_samples, n_input_dist_seeds, n_sinkhorn,
+                           log_prefix=""):
+    """/root/reference/src/utils.py:251-282, returning the four numbers it logs to W&B."""
+    import numpy as np
+    w2, self_w2 = [], []
+    assert n_sinkhorn <= n_samples
+    for i in range(n_input_dist_seeds):
+        sl = slice(i * n_samples, i * n_samples + n_sinkhorn)
+        w2.append(W2_distance(samples[sl], target_samples[sl]))
+        self_w2.append(W2_distance(target_samples[sl], other_target_samples[sl]))
+    return {f"w2_dist{log_prefix}": float(np.mean(w2)), f"w2_dist_std{log_prefix}": float(np.std(w2)),
+            f"self_w2_dist{log_prefix}": float(np.mean(self_w2)), f"self_w2_dist_std{log_prefix}": float(np.std(self_w2))}

@@ -139,3 +139,24 @@ def test_main_applies_the_tuned_lr_and_eps_tables():
     assert c.lr == 0.01
     c = drv.setup_config(drv.parse_flags(["--config.model", "funnel", "--config.nbridges", "7"], drv.get_config()))
     assert c.lr == 1e-4                                                     # KeyError branch: flags stand
+
+
+def test_target_samplers_and_the_sinkhorn_metric():
+    """load_model's third return value (exact samplers of the tractable targets) and utils.W2_distance: a cloud is
+    closer to a second draw of its own law than to a shifted copy; identical clouds are at (almost) zero."""
+    import types
+    from cmcd_amd import utils
+    from cmcd_amd.model_handler import load_model
+    for name, dim in (("gmm", 2), ("funnel", 10), ("many_gmm", 2)):
+        _, d, sampler = load_model(name, types.SimpleNamespace())
+        x = sampler(1, 400) if name != "many_gmm" else sampler(1, (400,))
+        assert x.shape == (400, dim) and np.isfinite(x).all()
+    _, _, sampler = load_model("gmm", types.SimpleNamespace())
+    a, b = sampler(1, 300), sampler(2, 300)
+    near = utils.W2_distance(a, b)
+    far = utils.W2_distance(a, b + np.array([4.0, 0.0], np.float32))
+    same = utils.W2_distance(a, a)
+    assert 0.0 <= same < near < far
+    out = utils.calculate_W2_distances(torch.from_numpy(np.concatenate([a, b])), torch.from_numpy(np.concatenate([b, a])),
+                                       torch.from_numpy(np.concatenate([a, b])[::-1].copy()), 300, 2, 200)
+    assert set(out) == {"w2_dist", "w2_dist_std", "self_w2_dist", "self_w2_dist_std"}
