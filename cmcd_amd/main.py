@@ -56,6 +56,17 @@ def get_config():
     c.loc_scaling = 40
     c.file_path = os.path.join(os.getcwd(), "../pines.csv")
     c.save_params = ""          # extra: path of a params.pkl to write (the reference logs it as a W&B artifact)
+    # fields of the reference's config this driver accepts so that its README command lines run unchanged, but whose
+    # only legal value here is the default (dds nets are 64-wide, the lgcp posterior is un-whitened, 40 mixtures
+    # unless n_mixes says otherwise) or that configure subsystems left out (NICE, W&B, the cluster launcher)
+    c.fully_connected_units = "[64, 64]"
+    c.use_whitened = False
+    c.gmm_easy_mode = False
+    c.id = -1
+    c.run_cluster = 0
+    c.im_size, c.alpha, c.n_bits, c.hidden_dim = 14, 0.05, 3, 1000
+    c.wandb = types.SimpleNamespace(log=True, project="final_cmcd", entity="shreyaspadhy", code_dir=os.getcwd(),
+                                    name="", log_artifact=True)
     return c
 
 
@@ -79,39 +90,64 @@ def setup_config(config):
     return config
 
 
+def _field(config, dotted):
+    """`wandb.name` -> (config.wandb, "name")"""
+    node, parts = config, dotted.split(".")
+    for part in parts[:-1]:
+        node = getattr(node, part, None)
+        if not isinstance(node, types.SimpleNamespace):
+            raise SystemExit(f"unknown config field {dotted!r}")
+    if not hasattr(node, parts[-1]) or isinstance(getattr(node, parts[-1]), types.SimpleNamespace):
+        raise SystemExit(f"unknown config field {dotted!r}")
+    return node, parts[-1]
+
+
 def parse_flags(argv, config):
-    """absl / ml_collections style: --config.name value | --config.name=value | --config.flag | --noconfig.flag"""
+    """absl / ml_collections style: --config.name value | --config.name=value | --config.flag | --noconfig.flag
+    (absl also takes a single leading dash; the reference's README uses it once)."""
     i = 0
     while i < len(argv):
         a = argv[i]
+        if a.startswith("-") and not a.startswith("--"):
+            a = "-" + a
         if a.startswith("--noconfig."):
-            name = a[len("--noconfig."):]
-            if not isinstance(getattr(config, name, None), bool):
-                raise SystemExit(f"--noconfig.{name}: not a boolean field")
-            setattr(config, name, False)
+            node, name = _field(config, a[len("--noconfig."):])
+            if not isinstance(getattr(node, name), bool):
+                raise SystemExit(f"{a}: not a boolean field")
+            setattr(node, name, False)
             i += 1
             continue
         if not a.startswith("--config."):
             raise SystemExit(f"unknown argument {a!r} (expected --config.<field> ...)")
-        name, eq, val = a[len("--config."):].partition("=")
-        if not hasattr(config, name):
-            raise SystemExit(f"unknown config field {name!r}")
-        cur = getattr(config, name)
+        dotted, eq, val = a[len("--config."):].partition("=")
+        node, name = _field(config, dotted)
+        cur = getattr(node, name)
         if isinstance(cur, bool):
             if eq:
-                setattr(config, name, val.lower() in ("1", "true", "yes"))
+                setattr(node, name, val.lower() in ("1", "true", "yes"))
             else:
-                setattr(config, name, True)
+                setattr(node, name, True)
             i += 1
             continue
         if not eq:
             i += 1
             if i >= len(argv):
-                raise SystemExit(f"--config.{name} needs a value")
+                raise SystemExit(f"--config.{dotted} needs a value")
             val = argv[i]
-        setattr(config, name, type(cur)(val) if not isinstance(cur, str) else val)
+        setattr(node, name, type(cur)(val) if not isinstance(cur, str) else val)
         i += 1
     return config
+
+
+def check_fixed_fields(config):
+    """The accepted-but-fixed fields: fail loudly rather than silently run something else."""
+    units = [int(u) for u in str(config.fully_connected_units).strip("[]() ").replace(" ", "").split(",") if u]
+    if config.nn_arch in ("dds", "dds_grad") and units != [64, 64]:
+        raise NotImplementedError(f"fully_connected_units={units}: the HIP path builds the dds net 64 wide")
+    if config.use_whitened:
+        raise NotImplementedError("use_whitened=True: the lgcp kernels evaluate the un-whitened posterior")
+    # gmm_easy_mode is read once while the reference builds its defaults (configs/base.py:137-143), so the flag changes
+    # nothing there either; wandb.* configure a logger this build replaces by stdout
 
 
 def main(config):
@@ -131,7 +167,8 @@ def main(config):
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     say = print if rank == 0 else (lambda *a, **k: None)
     setup_config(config)                                                   # main.py:64-66
-    say({k: v for k, v in vars(config).items()})
+    check_fixed_fields(config)
+    say({k: v for k, v in vars(config).items() if k != "wandb"})
 
     if "lgcp" in config.model and not os.path.exists(config.file_path):
         # the point set is reference content; its 40 x 40 bin counts ship as a test fixture

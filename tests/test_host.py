@@ -160,3 +160,27 @@ def test_target_samplers_and_the_sinkhorn_metric():
     out = utils.calculate_W2_distances(torch.from_numpy(np.concatenate([a, b])), torch.from_numpy(np.concatenate([b, a])),
                                        torch.from_numpy(np.concatenate([a, b])[::-1].copy()), 300, 2, 200)
     assert set(out) == {"w2_dist", "w2_dist_std", "self_w2_dist", "self_w2_dist_std"}
+
+
+def test_cli_takes_the_reference_readme_command_lines_verbatim():
+    """Every flag of the reference README's replicate commands parses (alpha, wandb.name, the single-dash
+    `-config.init_sigma`), nested fields land in the nested namespace, fixed fields are refused when changed."""
+    from cmcd_amd import main as cli
+    argv = ["--config.boundmode", "MCD_CAIS_sn", "--config.model", "funnel", "--config.N", "300", "--config.alpha", "0.05",
+            "--config.emb_dim", "48", "--config.init_eps", "0.1", "-config.init_sigma", "1", "--config.iters", "11000",
+            "--noconfig.pretrain_mfvi", "--config.train_vi", "--noconfig.train_eps", "--config.wandb.name",
+            "funnel replicate w/ cos_sq", "--config.lr", "0.01", "--config.n_samples", "2000", "--config.eps_schedule", "cos_sq"]
+    c = cli.parse_flags(argv, cli.get_config())
+    assert (c.model, c.N, c.emb_dim, c.init_sigma, c.iters, c.pretrain_mfvi, c.train_eps) == ("funnel", 300, 48, 1.0, 11000, False, False)
+    assert c.wandb.name == "funnel replicate w/ cos_sq" and c.alpha == 0.05 and c.n_samples == 2000
+    cli.check_fixed_fields(c)
+    c = cli.parse_flags(["--noconfig.wandb.log", "--config.use_whitened"], cli.get_config())
+    assert c.wandb.log is False
+    with pytest.raises(NotImplementedError):
+        cli.check_fixed_fields(c)
+    c = cli.parse_flags(["--config.nn_arch", "dds", "--config.fully_connected_units", "[128, 128]"], cli.get_config())
+    with pytest.raises(NotImplementedError):
+        cli.check_fixed_fields(c)
+    for bad in (["--config.wandb", "x"], ["--config.wandb.nope", "x"], ["--config.nope", "1"]):
+        with pytest.raises(SystemExit):
+            cli.parse_flags(bad, cli.get_config())
