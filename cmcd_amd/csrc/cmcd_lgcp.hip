@@ -29,9 +29,14 @@
 
 namespace cmcd {
 
-constexpr int kMP = 24;      // particles per pass (rows of the skinny GEMM)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kMP = 24;      // particles per pass (rows of the skinny GEMM; padded to the 32-row MFMA tile)
 constexpr int kGemmWaves = 8;
-constexpr int kChunk = 32;   // k rows staged per round
+constexpr int kQuarters = kGemmWaves / 2;   // k quarters of a round (x 2 column halves = the 8 waves)
+constexpr int kQLen = 52;                   // k rows per quarter per round (even: 32x32x2 takes two per MFMA)
+constexpr int kStage = kQuarters * kQLen;   // k rows staged per round (208 >= 1620 / 8)
+constexpr int kAsLd = 33;                   // LDS row pitch of the staged slice (odd: conflict-free writes)
 
 constexpr int kSplit = 8;    // K split across workgroups (partial slabs, summed in fixed order downstream)
 
@@ -40,70 +45,278 @@ struct GemmSeg {
   const float* W;      // [Kdim][ldw]
   float* out;          // [kSplit][kMP][ldo] partial slabs
   int N, lda, ldw, ldo;
+  float a_shift;       // the operand is A - a_shift (K^-1 (x - mu0) without a separate subtraction pass)
+};
+
+// Fused consumers ("epilogues"): the kSplit workgroups of one 64-column block publish their partial slabs, fence, and
+// bump the block's counter; the LAST one to arrive sums the slabs in fixed order (bitwise deterministic: which
+// workgroup does the summing does not change the arithmetic) and applies the consumer for its 64 columns.  That
+// removes the separate activation / state launches (5.7 us and 13 us of a 61 us evaluation) from the dependent chain.
+enum { EPI_NONE = 0, EPI_ACT = 1, EPI_STEP = 2 };
+
+struct ActEpi {          // u_out = u + softplus(bias + sum(slabs))      nn.py:45-50,68-69
+  const float* bias;     // [IN]
+  float* sum_out;        // [kMP][IN] summed pre-activation (kept for the backward pass)
+  const float* x;        // [kMP][D]   mode 1: u = [x; emb]
+  const float* emb;      // [E]
+  const float* u_prev;   // [kMP][IN]  mode 2: u = u1
+  float* u_out;          // [kMP][IN]
+  int D, IN, mode;
+};
+
+struct StepEpi {         // evaluation i at z_i: closes step i-1, opens step i (or, at i = K, collects log p(z_K))
+  const float* params;
+  const float* tc;           // {Kinv[d,d], counts[d], mu0, a, lognorm}
+  const float* sched;        // [K][8]
+  float* x;                  // [kMP][D]   current z (updated in place, own columns only)
+  float* xp;                 // [kMP][D]   previous z
+  float* xm;                 // [kMP][D]   z - mu0: the next evaluation's K^-1 operand
+  const float* kr;           // [kSplit][kMP][D]   partial slabs of K^-1 (x - mu0)   (previous launch)
+  const float* b3;           // [D]
+  const float* factor;       // factor_sn (device scalar)
+  uint32_t* gen;             // [kMP][2]      gen key of the chain (advanced by column block 0's extra wave)
+  uint32_t* gkey;            // [2][kMP][2]   G_i, parity-buffered by i: read [i & 1], written [(i + 1) & 1]
+  float* wslot;              // [ncb][kMP]    running sum over closed steps of (bk - fk) on this block's columns
+  float* fkslot;             // [ncb][kMP]    forward-kernel log-density of the open step on this block's columns
+  float* lpslot;             // [ncb][kMP]    log p(z_K) on this block's columns (i = K)
+  float* out_z;              // [M][D]
+  float* traj;               // optional [K+1][n_total][D]
+  int64_t n_total, base;
+  cmcd_layout lay;
+  int D, K, i, var_mode, grad_clipping;
 };
 
 struct GemmArgs {
   GemmSeg seg[2];
   int nblk0;           // column blocks of segment 0
   int M, Kdim;
+  int Kdim1;           // K extent of segment 1 when it differs from segment 0's (0: same)
+  int* counters;       // [gridDim.x] arrival counters, zero between launches (reset by the last arriver)
+  int epi_seg;         // segment the epilogue applies to (-1: all)
+  ActEpi act;
+  StepEpi step;
 };
 
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// (G, H) = split(gen); gen' = second(split(H))     mcd_cais.py:66-67,87
+__device__ __forceinline__ void lgcp_key_advance(uint32_t& k0, uint32_t& k1, uint32_t& G0, uint32_t& G1) {
+  uint32_t g0 = 0, h0 = 2, g1 = 1, h1 = 3;
+  threefry2x32(k0, k1, g0, h0);
+  threefry2x32(k0, k1, g1, h1);
+  uint32_t n0 = 0, n2 = 2, n1 = 1, n3 = 3;
+  threefry2x32(h0, h1, n0, n2);
+  threefry2x32(h0, h1, n1, n3);
+  G0 = g0; G1 = g1; k0 = n2; k1 = n3;
+}
+
+// the state update of lgcp_forward's evaluation i on columns [n0, n0 + 64) of all particles; sn slabs are this
+// launch's output (visible after the arrival protocol), everything else is from earlier launches
+__device__ __forceinline__ void lgcp_step_tile(const StepEpi& a, const float* sn_slabs, int M, int n0, int cb, int wv,
+                                               int lane) {
+  const int D = a.D, H = (D + 1) / 2, i = a.i;
+  const float* counts = a.tc + (int64_t)D * D;
+  const float mu0 = a.tc[(int64_t)D * D + D], pa = a.tc[(int64_t)D * D + D + 1];
+  const float clipv = a.var_mode ? 1e2f : 1e3f;
+  const bool clip_p = a.grad_clipping != 0, clip_q = clip_p && a.var_mode;
+  const bool last = i == a.K;
+  const float* sp = a.sched + 8 * (i > 0 ? i - 1 : 0);
+  const float pbeta = sp[0], peps = sp[1], pcst = sp[3], pinv2s2 = sp[4];
+  const float* sc = a.sched + 8 * (last ? a.K - 1 : i);
+  const float beta = sc[0], eps = sc[1], sig = sc[2], cst = sc[3], inv2s2 = sc[4];
+  const float fac = a.factor[0];
+  const int e = n0 + lane;
+  const bool ecol = e < D;
+  const float cnt = ecol ? counts[e] : 0.f, b3 = ecol ? a.b3[e] : 0.f;
+  const float mean = ecol ? a.params[a.lay.vd_mean + e] : 0.f;
+  const float sd = ecol ? expf(a.params[a.lay.vd_logdiag + e]) : 1.f;
+  const uint32_t* gk = a.gkey + (i & 1) * 2 * kMP;
+  for (int m = wv; m < kMP; m += kGemmWaves) {       // a wave = one particle x 64 columns
+    if (m >= M) break;
+    float bk_acc = 0.f, fk_acc = 0.f, lp_acc = 0.f;
+    if (ecol) {
+      const float z = a.x[m * D + e];
+      float kr = 0.f, s = b3;
+#pragma unroll
+      for (int ks = 0; ks < kSplit; ++ks) {            // fixed-order sums of the split-K slabs
+        kr += a.kr[((int64_t)ks * kMP + m) * D + e];
+        s += __hip_atomic_load(sn_slabs + ((int64_t)ks * kMP + m) * D + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      s *= fac;                                        // factor_sn (u2 W3 + b3)           nn.py:70
+      const float ez = expf(z);
+      float gp = -kr + cnt - pa * ez;                  // grad log p      model_handler.py:386-396
+      float gq = -(z - mean) / (sd * sd);
+      if (clip_p) gp = fminf(fmaxf(gp, -clipv), clipv);
+      if (clip_q) gq = fminf(fmaxf(gq, -clipv), clipv);
+      if (i > 0) {   // backward kernel of step i-1                           mcd_cais.py:71-86
+        const float ub = -1.0f * (pbeta * gp + (1.0f - pbeta) * gq);
+        const float bk = z - peps * ub + peps * s;
+        const float db = a.xp[m * D + e] - bk;
+        bk_acc = -(db * db) * pinv2s2 - pcst;
+      }
+      if (last) {    // log p(z_K)
+        lp_acc = -0.5f * (z - mu0) * kr + z * cnt - pa * ez;
+        a.out_z[(int64_t)m * D + e] = z;
+      } else {       // forward kernel of step i                              mcd_cais.py:52-67
+        // eps_i = normal(G_i, (D,)): element e is word (e >= H) of the block with counters (j, H + j), j = e mod H
+        const int j = e < H ? e : e - H;
+        uint32_t y0 = j, y1 = (H + j < D) ? H + j : 0;
+        threefry2x32(gk[2 * m], gk[2 * m + 1], y0, y1);
+        const float uf = -1.0f * (beta * gp + (1.0f - beta) * gq);
+        const float fk = z - eps * uf - eps * s;
+        const float zn = fk + sig * bits_to_normal(e < H ? y0 : y1);
+        const float df = zn - fk;
+        fk_acc = -(df * df) * inv2s2 - cst;
+        a.xp[m * D + e] = z;
+        a.x[m * D + e] = zn;
+        a.xm[m * D + e] = zn - mu0;
+        if (a.traj) a.traj[((int64_t)(i + 1) * a.n_total + a.base + m) * D + e] = zn;
+      }
+    }
+    const float bk_lp = wave_sum64(bk_acc), fk_lp = wave_sum64(fk_acc), lp = wave_sum64(lp_acc);
+    if (lane == 0) {
+      const int sl = cb * kMP + m;
+      if (i > 0) a.wslot[sl] += bk_lp - a.fkslot[sl];
+      if (!last) a.fkslot[sl] = fk_lp;
+      else a.lpslot[sl] = lp;
+    }
+  }
+}
+
 // out[ks][m][n] = sum_{k in slice ks, wave w} A[m][k] W[k][n]   (no bias: added when the slabs are summed)
-__global__ __launch_bounds__(64 * kGemmWaves) void lgcp_gemm_kernel(GemmArgs a) {
+template <int EPI>
+__global__ __launch_bounds__(64 * (kGemmWaves + (EPI == EPI_STEP ? 1 : 0))) void lgcp_gemm_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ int s_last;
   const int s = blockIdx.x < a.nblk0 ? 0 : 1;
   const GemmSeg sg = a.seg[s];
+  const int Kdim = (s && a.Kdim1) ? a.Kdim1 : a.Kdim;
   const int n0 = (blockIdx.x - (s ? a.nblk0 : 0)) * 64;
   const int ksplit = blockIdx.y;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  float* As = lds + wv * (kChunk * kMP);                             // wave-private [kChunk][kMP]
-  float* red = lds + kGemmWaves * kChunk * kMP;                      // [16][kMP][64]
-  const int kslice = (a.Kdim + kSplit - 1) / kSplit;
-  const int s_lo = ksplit * kslice, s_hi = min(a.Kdim, s_lo + kslice);
-  const int ks = (s_hi - s_lo + kGemmWaves - 1) / kGemmWaves;
-  const int k_lo = s_lo + wv * ks, k_hi = min(s_hi, k_lo + ks);
-  const int n = n0 + lane;
+  const bool worker = EPI != EPI_STEP || wv < kGemmWaves;            // EPI_STEP carries one extra wave (key chain)
+  float* As = lds;                                                   // [kStage][kAsLd]  A slice, k-major, particle-minor
+  float* red = lds + kStage * kAsLd;                                 // [kQuarters][kMP][64]
+  const int kslice = (Kdim + kSplit - 1) / kSplit;
+  const int s_lo = ksplit * kslice, s_hi = min(Kdim, s_lo + kslice);
+  const int half = wv & 1, q = wv >> 1;                              // wave = (32-column half, k quarter of the round)
+  const int l31 = lane & 31, l5 = lane >> 5;
+  const int n = n0 + 32 * half + l31;
   const bool ncol = n < sg.N;
 
-  float acc[kMP];
+  // rows 24..31 of the 32-row MFMA operand stay zero
+  for (int e = threadIdx.x; e < kStage * (32 - kMP); e += blockDim.x)
+    As[(e / (32 - kMP)) * kAsLd + kMP + e % (32 - kMP)] = 0.f;
+  f32x16 acc;
 #pragma unroll
-  for (int m = 0; m < kMP; ++m) acc[m] = 0.f;
-
-  for (int kc = k_lo; kc < k_hi; kc += kChunk) {
-    const int len = min(kChunk, k_hi - kc);
-    float wrow[kChunk];
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int r0 = s_lo; r0 < s_hi; r0 += kStage) {                     // one round for Kdim <= kSplit * kStage = 1664
+    // this wave's W rows of the round: 2 rows x 128 B per load, all in flight before anything waits
+    float wreg[kQLen / 2];
+    if (worker) {
 #pragma unroll
-    for (int kk = 0; kk < kChunk; ++kk)
-      wrow[kk] = (kk < len && ncol) ? sg.W[(int64_t)(kc + kk) * sg.ldw + n] : 0.f;
-    // stage A[:, kc:kc+len] into wave-private LDS, k-major: lane -> (m = e / 32, kk = e % 32), coalesced in k
-#pragma unroll
-    for (int e0 = 0; e0 < kChunk * kMP; e0 += 64) {
-      const int e = e0 + lane, m = e >> 5, kk = e & 31;
-      As[kk * kMP + m] = (m < a.M && kk < len) ? sg.A[(int64_t)m * sg.lda + kc + kk] : 0.f;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-#pragma unroll
-    for (int kk = 0; kk < kChunk; ++kk) {
-#pragma unroll
-      for (int m4 = 0; m4 < kMP / 4; ++m4) {
-        const f32x4 av = *reinterpret_cast<const f32x4*>(As + kk * kMP + 4 * m4);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[4 * m4 + q] = fmaf(av[q], wrow[kk], acc[4 * m4 + q]);
+      for (int j = 0; j < kQLen / 2; ++j) {
+        const int k = r0 + q * kQLen + 2 * j + l5;
+        wreg[j] = (k < s_hi && ncol) ? sg.W[(int64_t)k * sg.ldw + n] : 0.f;
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  }
+    // the workgroup stages A[:, r0 : r0 + kStage) once: coalesced along k, conflict-free LDS writes (odd row pitch)
+    if (r0 > s_lo) __syncthreads();
+    if (worker) {
 #pragma unroll
-  for (int m = 0; m < kMP; ++m) red[(wv * kMP + m) * 64 + lane] = acc[m];
+      for (int e0 = 0; e0 < kMP * kStage; e0 += 64 * kGemmWaves) {
+        const int e = e0 + threadIdx.x, m = e / kStage, kk = e - m * kStage;
+        if (e < kMP * kStage)
+          As[kk * kAsLd + m] = (m < a.M && r0 + kk < s_hi) ? sg.A[(int64_t)m * sg.lda + r0 + kk] - sg.a_shift : 0.f;
+      }
+    }
+    __syncthreads();
+    if (worker) {
+#pragma unroll
+      for (int j = 0; j < kQLen / 2; ++j) {
+        const float av = As[(q * kQLen + 2 * j + l5) * kAsLd + l31];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wreg[j], acc, 0, 0, 0);
+      }
+    }
+  }
+  if (worker) {
+    // D layout: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int m = (i & 3) + 8 * (i >> 2) + 4 * l5;
+      if (m < kMP) red[(q * kMP + m) * 64 + 32 * half + l31] = acc[i];
+    }
+  }
   __syncthreads();
   float* slab = sg.out + (int64_t)ksplit * kMP * sg.ldo;
-  for (int o = threadIdx.x; o < kMP * 64; o += blockDim.x) {
-    const int m = o >> 6, nl = o & 63;
-    if (m < a.M && n0 + nl < sg.N) {
-      float v = 0.f;
+  if (worker) {
+    for (int o = threadIdx.x; o < kMP * 64; o += 64 * kGemmWaves) {
+      const int m = o >> 6, nl = o & 63;
+      if (m < a.M && n0 + nl < sg.N) {
+        float v = 0.f;
 #pragma unroll
-      for (int w = 0; w < kGemmWaves; ++w) v += red[(w * kMP + m) * 64 + nl];  // fixed order
-      slab[(int64_t)m * sg.ldo + n0 + nl] = v;
+        for (int w = 0; w < kQuarters; ++w) v += red[(w * kMP + m) * 64 + nl];  // fixed order
+        // a consumed slab goes out as an agent-scope (write-through, sc1) store: the arrival protocol below then
+        // needs no L2 write-back fence (buffer_wbl2 per wave made the launch 4x longer)
+        if (EPI != EPI_NONE && (a.epi_seg < 0 || s == a.epi_seg))
+          __hip_atomic_store(slab + (int64_t)m * sg.ldo + n0 + nl, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else
+          slab[(int64_t)m * sg.ldo + n0 + nl] = v;
+      }
+    }
+  }
+  if (EPI == EPI_NONE) return;
+  if (a.epi_seg >= 0 && s != a.epi_seg) return;                       // uniform per workgroup
+
+  // ---- arrival protocol: the slab stores are complete at agent scope once vmcnt drains (the workgroup-scope
+  // release of __syncthreads waits for that); count; the last workgroup of the block reads the slabs back with
+  // agent-scope loads (never served from a stale L1 / remote-XCD L2 line) and consumes
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int old = __hip_atomic_fetch_add(a.counters + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = old == kSplit - 1;
+    if (s_last) a.counters[blockIdx.x] = 0;                           // ready for the next launch
+  }
+  __syncthreads();
+  if (!s_last) return;
+
+  if (EPI == EPI_ACT) {
+    const ActEpi& ac = a.act;
+    const int k = n0 + lane;
+    if (k < ac.IN) {
+      const float bias = ac.bias[k];
+      for (int m = wv; m < a.M; m += kGemmWaves) {
+        float pre = bias;
+#pragma unroll
+        for (int q = 0; q < kSplit; ++q)
+          pre += __hip_atomic_load(sg.out + ((int64_t)q * kMP + m) * sg.ldo + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int idx = m * ac.IN + k;
+        ac.sum_out[idx] = pre;
+        float u;
+        if (ac.mode == 1) u = k < ac.D ? ac.x[m * ac.D + k] : ac.emb[k - ac.D];   // u = [x; emb_i]      nn.py:68-69
+        else u = ac.u_prev[idx];
+        ac.u_out[idx] = u + softplus(pre);                                        // nn.py:45-50
+      }
+    }
+  } else if (EPI == EPI_STEP) {
+    const StepEpi& st = a.step;
+    const int cb = blockIdx.x;
+    if (wv < kGemmWaves) {
+      lgcp_step_tile(st, sg.out, a.M, n0, cb, wv, lane);
+    } else if (cb == 0 && st.i + 1 < st.K && lane < a.M) {
+      // the chain's key for evaluation i + 1 (a dependent integer chain of ~450 instructions: on its own wave it
+      // hides behind the state update of the eight others)
+      uint32_t k0 = st.gen[2 * lane], k1 = st.gen[2 * lane + 1], G0, G1;
+      lgcp_key_advance(k0, k1, G0, G1);
+      st.gen[2 * lane] = k0; st.gen[2 * lane + 1] = k1;
+      uint32_t* gk = st.gkey + ((st.i + 1) & 1) * 2 * kMP;
+      gk[2 * lane] = G0; gk[2 * lane + 1] = G1;
     }
   }
 }
@@ -183,6 +396,7 @@ struct LgcpStateArgs {
   float* out_z;              // [M][D]
   double* partials;          // [M][5]
   float* xm;                 // [kMP][D]   z - mu0 of the CURRENT z: the next GEMM's input (no separate launch)
+  uint32_t* gkey;            // [2][kMP][2] noise key of evaluation 0 (forward path only; nullptr: not needed)
   float* traj;               // optional [K+1][n_total][D]: z_0..z_K of every particle (reverse sweep of the gradient)
   int64_t n_total, base;     // trajectory row of particle p of this pass: base + p
   cmcd_layout lay;
@@ -238,114 +452,53 @@ __global__ __launch_bounds__(256) void lgcp_init_kernel(LgcpStateArgs a) {
     uint32_t g0 = 0, g2 = 2, g1 = 1, g3 = 3;
     threefry2x32(c0, c1, g0, g2);
     threefry2x32(c0, c1, g1, g3);       // gen = second(split(C)) = (g2, g3)
-    a.keys[2 * p] = g2;
-    a.keys[2 * p + 1] = g3;
+    uint32_t k0 = g2, k1 = g3;
+    if (a.gkey) {                        // G_0 for evaluation 0; the GEMM epilogue carries the chain from here
+      uint32_t G0, G1;
+      lgcp_key_advance(k0, k1, G0, G1);
+      a.gkey[2 * p] = G0;
+      a.gkey[2 * p + 1] = G1;
+    }
+    a.keys[2 * p] = k0;
+    a.keys[2 * p + 1] = k1;
   }
 }
 
-// evaluation i at z_i: closes step i-1, opens step i (or, at i = K, writes the outputs)
-__global__ __launch_bounds__(256) void lgcp_step_kernel(LgcpStateArgs a) {
-  __shared__ float sh[4];
-  const int p = blockIdx.x, D = a.D, H = (D + 1) / 2, i = a.i;
-  const float* counts = a.tc + (int64_t)D * D;
-  const float mu0 = a.tc[(int64_t)D * D + D], pa = a.tc[(int64_t)D * D + D + 1];
-  const float lognorm = a.tc[(int64_t)D * D + D + 2];
-  const float clipv = a.var_mode ? 1e2f : 1e3f;
-  const bool clip_p = a.grad_clipping != 0, clip_q = clip_p && a.var_mode;
-  const bool last = i == a.K;
-  const float* sp = a.sched + 8 * (i > 0 ? i - 1 : 0);
-  const float pbeta = sp[0], peps = sp[1], pcst = sp[3], pinv2s2 = sp[4];
-  const float* sc = a.sched + 8 * (last ? a.K - 1 : i);
-  const float beta = sc[0], eps = sc[1], sig = sc[2], cst = sc[3], inv2s2 = sc[4];
+// loss = -(w_0 + sum over column blocks of the closed steps' (bk - fk) + log p(z_K)); fixed summation order
+struct LgcpFinalArgs {
+  const float* w0;       // [kMP]  -log q(z_0)
+  const float* wslot;    // [ncb][kMP]
+  const float* lpslot;   // [ncb][kMP]
+  const float* tc;
+  float* out_loss;       // [M]
+  double* partials;      // [M][5]
+  int M, D, ncb;
+};
 
-  // (G, H) = split(gen); eps_i = normal(G, (D,)); gen' = second(split(H))   mcd_cais.py:66-67,87
-  const uint32_t k0 = a.keys[2 * p], k1 = a.keys[2 * p + 1];
-  uint32_t g0 = 0, h0 = 2, g1 = 1, h1 = 3;
-  threefry2x32(k0, k1, g0, h0);
-  threefry2x32(k0, k1, g1, h1);
-
-  float bk_acc = 0.f, fk_acc = 0.f, lp_acc = 0.f;
-  for (int j = threadIdx.x; j < H; j += blockDim.x) {
-    uint32_t y0 = j, y1 = (H + j < D) ? H + j : 0;
-    if (!last) threefry2x32(g0, g1, y0, y1);
-    const int idx[2] = {j, H + j};
-    const uint32_t bits[2] = {y0, y1};
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int e = idx[q];
-      if (e < D) {
-        const float z = a.x[p * D + e];
-        float kr = 0.f, s = a.b3[e];
-#pragma unroll
-        for (int ks = 0; ks < kSplit; ++ks) {   // fixed-order sum of the split-K slabs
-          kr += a.kr[((int64_t)ks * kMP + p) * D + e];
-          s += a.sn[((int64_t)ks * kMP + p) * D + e];
-        }
-        s *= a.factor[0];                       // factor_sn (u2 W3 + b3)           nn.py:70
-        const float ez = expf(z);
-        float gp = -kr + counts[e] - pa * ez;                                  // grad log p
-        const float mean = a.params[a.lay.vd_mean + e];
-        const float sd = expf(a.params[a.lay.vd_logdiag + e]);
-        float gq = -(z - mean) / (sd * sd);
-        if (clip_p) gp = fminf(fmaxf(gp, -clipv), clipv);
-        if (clip_q) gq = fminf(fmaxf(gq, -clipv), clipv);
-        if (i > 0) {   // backward kernel of step i-1                           mcd_cais.py:71-86
-          const float ub = -1.0f * (pbeta * gp + (1.0f - pbeta) * gq);
-          const float bk = z - peps * ub + peps * s;
-          const float db = a.xp[p * D + e] - bk;
-          bk_acc += -(db * db) * pinv2s2 - pcst;
-        }
-        if (last) {    // log p(z_K)                                            model_handler.py:386-396
-          lp_acc += -0.5f * (z - mu0) * kr + z * counts[e] - pa * ez;
-        } else {       // forward kernel of step i                              mcd_cais.py:52-67
-          const float uf = -1.0f * (beta * gp + (1.0f - beta) * gq);
-          const float fk = z - eps * uf - eps * s;
-          const float zn = fk + sig * bits_to_normal(bits[q]);
-          const float df = zn - fk;
-          fk_acc += -(df * df) * inv2s2 - cst;
-          a.xp[p * D + e] = z;
-          a.x[p * D + e] = zn;
-          a.xm[p * D + e] = zn - mu0;
-          if (a.traj) a.traj[((int64_t)(i + 1) * a.n_total + a.base + p) * D + e] = zn;
-        }
-      }
-    }
+__global__ void lgcp_final_kernel(LgcpFinalArgs a) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= a.M) return;
+  float w = a.w0[p], lp = 0.f;
+  for (int cb = 0; cb < a.ncb; ++cb) {
+    w += a.wslot[cb * kMP + p];
+    lp += a.lpslot[cb * kMP + p];
   }
-  const float bk_lp = block_sum_256(bk_acc, sh);
-  const float fk_lp = block_sum_256(fk_acc, sh);
-  const float lp = block_sum_256(lp_acc, sh);
-  if (threadIdx.x == 0) {
-    float w = a.w[p];
-    if (i > 0) w += bk_lp - a.fklp[p];
-    if (!last) {
-      a.fklp[p] = fk_lp;
-      uint32_t n0 = 0, n2 = 2, n1 = 1, n3 = 3;
-      threefry2x32(h0, h1, n0, n2);
-      threefry2x32(h0, h1, n1, n3);
-      a.keys[2 * p] = n2;
-      a.keys[2 * p + 1] = n3;
-      a.w[p] = w;
-    } else {
-      w += lp + lognorm;                        // + log p(z_K)   mcdboundingmachine.py:178
-      const float loss = -w;
-      a.out_loss[p] = loss;
-      double* o = a.partials + (int64_t)p * CMCD_NSTATS;
-      o[0] = isfinite(loss) ? 1.0 : 0.0;
-      o[1] = loss;
-      o[2] = (double)loss * (double)loss;
-      o[3] = -(double)loss;
-      o[4] = isfinite(loss) ? 1.0 : 0.0;
-    }
-  }
-  if (last)
-    for (int e = threadIdx.x; e < D; e += blockDim.x) a.out_z[(int64_t)p * D + e] = a.x[p * D + e];
+  w += lp + a.tc[(int64_t)a.D * a.D + a.D + 2];     // + log p(z_K)   mcdboundingmachine.py:178
+  const float loss = -w;
+  a.out_loss[p] = loss;
+  double* o = a.partials + (int64_t)p * CMCD_NSTATS;
+  o[0] = isfinite(loss) ? 1.0 : 0.0;
+  o[1] = loss;
+  o[2] = (double)loss * (double)loss;
+  o[3] = -(double)loss;
+  o[4] = isfinite(loss) ? 1.0 : 0.0;
 }
 
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 struct LgcpWs {
-  int64_t bias1, x, xp, xm, u1, u2, pre1, pre2, kr, slab1, slab2, sn, w, fklp, keys, partials, total;
+  int64_t bias1, x, xp, xm, u1, u2, pre1, pre2, kr, slab1, slab2, sn, w, fklp, keys, gkey, slots, counters, partials, total;
 };
 
 static LgcpWs lgcp_ws(const cmcd_desc& d, int64_t n, int64_t base) {
@@ -358,7 +511,9 @@ static LgcpWs lgcp_ws(const cmcd_desc& d, int64_t n, int64_t base) {
   w.u1 = take(kMP * IN); w.u2 = take(kMP * IN); w.pre1 = take(kMP * IN); w.pre2 = take(kMP * IN);
   w.kr = take(kSplit * kMP * D); w.slab1 = take(kSplit * kMP * IN); w.slab2 = take(kSplit * kMP * IN);
   w.sn = take(kSplit * kMP * D);
-  w.w = take(kMP); w.fklp = take(kMP); w.keys = take(2 * kMP);
+  w.w = take(kMP); w.fklp = take(kMP); w.keys = take(2 * kMP); w.gkey = take(4 * kMP);
+  w.slots = take(3 * ((D + 63) / 64) * kMP);             // wslot | fkslot | lpslot
+  w.counters = take(((D + 63) / 64) + ((IN + 63) / 64)); // int arrival counters of the widest launch
   o = (o + 1) & ~int64_t(1);
   w.partials = take(n * CMCD_NSTATS * 2);
   w.total = o;
@@ -366,6 +521,16 @@ static LgcpWs lgcp_ws(const cmcd_desc& d, int64_t n, int64_t base) {
 }
 
 int64_t lgcp_workspace_floats(const cmcd_desc& d, int64_t n, int64_t base) { return lgcp_ws(d, n, base).total; }
+
+static int lgcp_gemm_attrs() {
+  const int gemm_lds = int(size_t(kStage * kAsLd + kQuarters * kMP * 64) * 4);
+  const void* fns[3] = {reinterpret_cast<const void*>(lgcp_gemm_kernel<EPI_NONE>),
+                        reinterpret_cast<const void*>(lgcp_gemm_kernel<EPI_ACT>),
+                        reinterpret_cast<const void*>(lgcp_gemm_kernel<EPI_STEP>)};
+  for (const void* fn : fns)
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds) != hipSuccess) return -1;
+  return gemm_lds;
+}
 
 int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, const int32_t* seeds, int64_t n,
                  const float* params, const float* tc, float* ws, float* out_loss, float* out_z,
@@ -377,65 +542,64 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
     LgcpPrepArgs pa{params, ws + w.bias1, lay, D, E, K, IN};
     hipLaunchKernelGGL(lgcp_prep_kernel, dim3((IN + 255) / 256, K + 1), dim3(256), 0, stream, pa);
   }
-  const size_t gemm_lds = size_t(kGemmWaves * kChunk * kMP + kGemmWaves * kMP * 64) * 4;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lgcp_gemm_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds);
-  if (e != hipSuccess) return CMCD_ERR_HIP;
+  const int gemm_lds = lgcp_gemm_attrs();
+  if (gemm_lds < 0) return CMCD_ERR_HIP;
   const float* kinv = tc;
   double* partials = reinterpret_cast<double*>(ws + w.partials);
   *partials_out = partials;
-  // mu0 is a model constant, log(126) - 0.5 * 1.91 (model_handler.py:346); the step kernel reads the
-  // device copy in tc, the activation kernel takes it as a launch argument.
-  const float mu0 = 3.8812819069514780f;
-  const dim3 gblock(64 * kGemmWaves);
+  const dim3 gblock(64 * kGemmWaves), gblock_step(64 * (kGemmWaves + 1));
   const int cbD = (D + 63) / 64, cbIN = (IN + 63) / 64;
+  int* counters = reinterpret_cast<int*>(ws + w.counters);
+  if (hipMemsetAsync(counters, 0, sizeof(int) * (cbD + cbIN), stream) != hipSuccess) return CMCD_ERR_HIP;
 
   for (int64_t base = 0; base < n; base += kMP) {
     const int M = (int)((n - base) < kMP ? (n - base) : kMP);
+    if (hipMemsetAsync(ws + w.slots, 0, sizeof(float) * 3 * cbD * kMP, stream) != hipSuccess) return CMCD_ERR_HIP;
     LgcpStateArgs st{};
     st.seeds = seeds + base; st.params = params; st.tc = tc; st.sched = ws + sw.sched;
-    st.x = ws + w.x; st.xp = ws + w.xp; st.kr = ws + w.kr; st.sn = ws + w.sn;
-    st.b3 = params + lay.g_b3; st.factor = params + lay.g_factor;
+    st.x = ws + w.x; st.xp = ws + w.xp;
     st.w = ws + w.w; st.fklp = ws + w.fklp; st.keys = reinterpret_cast<uint32_t*>(ws + w.keys);
-    st.out_loss = out_loss + base; st.out_z = out_z + base * D; st.partials = partials + base * CMCD_NSTATS;
+    st.gkey = reinterpret_cast<uint32_t*>(ws + w.gkey);
     st.lay = lay; st.M = M; st.D = D; st.K = K;
     st.traj = traj; st.n_total = n; st.base = base; st.xm = ws + w.xm;
-    st.var_mode = d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0; st.grad_clipping = d.grad_clipping;
     hipLaunchKernelGGL(lgcp_init_kernel, dim3(M), dim3(256), 0, stream, st);
 
-    ActArgs act{};
-    act.x = ws + w.x; act.mu0 = mu0; act.M = M; act.D = D; act.IN = IN; act.xm = ws + w.xm;
     GemmArgs g{};
-    g.M = M;
+    g.M = M; g.counters = counters;
+    g.act.x = ws + w.x; g.act.D = D; g.act.IN = IN;
+    StepEpi& se = g.step;
+    se.params = params; se.tc = tc; se.sched = ws + sw.sched; se.x = ws + w.x; se.xp = ws + w.xp; se.xm = ws + w.xm;
+    se.kr = ws + w.kr; se.b3 = params + lay.g_b3; se.factor = params + lay.g_factor;
+    se.gen = reinterpret_cast<uint32_t*>(ws + w.keys); se.gkey = reinterpret_cast<uint32_t*>(ws + w.gkey);
+    se.wslot = ws + w.slots; se.fkslot = se.wslot + cbD * kMP; se.lpslot = se.fkslot + cbD * kMP;
+    se.out_z = out_z + base * D; se.traj = traj; se.n_total = n; se.base = base; se.lay = lay;
+    se.D = D; se.K = K; se.var_mode = d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0; se.grad_clipping = d.grad_clipping;
     for (int i = 0; i <= K; ++i) {
       const int ie = i < K ? i : K - 1;
-      act.emb = params + lay.g_emb + (int64_t)ie * E;
-      // A: [x - mu0] Kinv -> kr slabs  |  x W1[:D] -> pre1 slabs   (x - mu0 written by the init / step kernel)
-      g.Kdim = D;
+      // A: [x - mu0] Kinv -> kr slabs (summed by the state update two launches on)
+      //    x W1[:D] -> pre1 slabs -> u1 = [x; emb_i] + softplus(pre1 + bias1_i)            (fused consumer)
+      g.Kdim = D; g.Kdim1 = 0;
       g.seg[0] = GemmSeg{ws + w.xm, kinv, ws + w.kr, D, D, D, D};
       g.seg[1] = GemmSeg{ws + w.x, params + lay.g_w1, ws + w.slab1, IN, D, IN, IN};
-      g.nblk0 = cbD;
-      hipLaunchKernelGGL(lgcp_gemm_kernel, dim3(cbD + cbIN, kSplit), gblock, gemm_lds, stream, g);
-      // u1 = u + softplus(pre1 + bias1_i)
-      act.mode = 1; act.slab_a = ws + w.slab1; act.bias_a = ws + w.bias1 + (int64_t)i * IN;
-      act.sum_a = ws + w.pre1; act.u_prev = nullptr; act.u_out = ws + w.u1;
-      hipLaunchKernelGGL(lgcp_act_kernel, dim3((M * IN + 255) / 256), dim3(256), 0, stream, act);
-      // B: u1 W2 -> pre2 slabs
+      g.nblk0 = cbD; g.epi_seg = 1;
+      g.act.mode = 1; g.act.bias = ws + w.bias1 + (int64_t)i * IN; g.act.emb = params + lay.g_emb + (int64_t)ie * E;
+      g.act.sum_out = ws + w.pre1; g.act.u_prev = nullptr; g.act.u_out = ws + w.u1;
+      hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_ACT>, dim3(cbD + cbIN, kSplit), gblock, gemm_lds, stream, g);
+      // B: u1 W2 -> pre2 slabs -> u2 = u1 + softplus(pre2 + b2)
       g.Kdim = IN;
       g.seg[0] = GemmSeg{ws + w.u1, params + lay.g_w2, ws + w.slab2, IN, IN, IN, IN};
-      g.nblk0 = cbIN;
-      hipLaunchKernelGGL(lgcp_gemm_kernel, dim3(cbIN, kSplit), gblock, gemm_lds, stream, g);
-      // u2 = u1 + softplus(pre2 + b2)
-      act.mode = 2; act.slab_a = ws + w.slab2; act.bias_a = params + lay.g_b2;
-      act.sum_a = ws + w.pre2; act.u_prev = ws + w.u1; act.u_out = ws + w.u2;
-      hipLaunchKernelGGL(lgcp_act_kernel, dim3((M * IN + 255) / 256), dim3(256), 0, stream, act);
-      // C: u2 W3 -> sn slabs (bias and factor_sn applied in the step kernel)
+      g.nblk0 = cbIN; g.epi_seg = -1;
+      g.act.mode = 2; g.act.bias = params + lay.g_b2; g.act.sum_out = ws + w.pre2; g.act.u_prev = ws + w.u1;
+      g.act.u_out = ws + w.u2;
+      hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_ACT>, dim3(cbIN, kSplit), gblock, gemm_lds, stream, g);
+      // C: u2 W3 -> sn slabs -> state update of evaluation i on the block's columns
       g.seg[0] = GemmSeg{ws + w.u2, params + lay.g_w3, ws + w.sn, D, IN, D, D};
       g.nblk0 = cbD;
-      hipLaunchKernelGGL(lgcp_gemm_kernel, dim3(cbD, kSplit), gblock, gemm_lds, stream, g);
-      st.i = i;
-      hipLaunchKernelGGL(lgcp_step_kernel, dim3(M), dim3(256), 0, stream, st);
+      se.i = i;
+      hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_STEP>, dim3(cbD, kSplit), gblock_step, gemm_lds, stream, g);
     }
+    LgcpFinalArgs fa{ws + w.w, se.wslot, se.lpslot, tc, out_loss + base, partials + base * CMCD_NSTATS, M, D, cbD};
+    hipLaunchKernelGGL(lgcp_final_kernel, dim3(1), dim3(64), 0, stream, fa);
   }
   return hipGetLastError() == hipSuccess ? CMCD_OK : CMCD_ERR_HIP;
 }
@@ -519,10 +683,8 @@ int lgcp_mfvi(int D, int64_t o_mean, int64_t o_logdiag, const int32_t* seeds, in
   float* gbuf = with_grad ? ws + ogb : nullptr;
   *partials_out = partials;
   *gbuf_out = gbuf;
-  const size_t gemm_lds = size_t(kGemmWaves * kChunk * kMP + kGemmWaves * kMP * 64) * 4;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(lgcp_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)gemm_lds) != hipSuccess)
-    return CMCD_ERR_HIP;
+  const int gemm_lds = lgcp_gemm_attrs();
+  if (gemm_lds < 0) return CMCD_ERR_HIP;
   const float mu0 = 3.8812819069514780f;
   const int cbD = (D + 63) / 64;
   cmcd_layout lay{};
@@ -541,7 +703,7 @@ int lgcp_mfvi(int D, int64_t o_mean, int64_t o_logdiag, const int32_t* seeds, in
     g.M = M; g.Kdim = D;
     g.seg[0] = GemmSeg{ws + oxm, tc, ws + okr, D, D, D, D};
     g.nblk0 = cbD;
-    hipLaunchKernelGGL(lgcp_gemm_kernel, dim3(cbD, kSplit), dim3(64 * kGemmWaves), gemm_lds, stream, g);
+    hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_NONE>, dim3(cbD, kSplit), dim3(64 * kGemmWaves), gemm_lds, stream, g);
     LgcpMfviArgs fa{params, tc, ws + ox, ws + okr, ws + ow, out_loss + base, out_z + base * D,
                     partials + base * CMCD_NSTATS, gbuf ? gbuf + base * 2 * D : nullptr, o_mean, D};
     hipLaunchKernelGGL(lgcp_mfvi_finish_kernel, dim3(M), dim3(256), 0, stream, fa);
@@ -873,10 +1035,8 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
     hipLaunchKernelGGL(lgcp_transpose_kernel, dim3((D + 31) / 32, (IN + 31) / 32), tb, 0, stream, params + lay.g_w3,
                        gws + g.wt3, IN, D, D, IN);
   }
-  const size_t gemm_lds = size_t(kGemmWaves * kChunk * kMP + kGemmWaves * kMP * 64) * 4;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(lgcp_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)gemm_lds) != hipSuccess)
-    return CMCD_ERR_HIP;
+  const int gemm_lds = lgcp_gemm_attrs();
+  if (gemm_lds < 0) return CMCD_ERR_HIP;
   const float* kinv = tc;
   const float mu0 = 3.8812819069514780f;
   const dim3 gblock(64 * kGemmWaves);
@@ -919,20 +1079,20 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
       gm.seg[0] = GemmSeg{gws + f.xm, kinv, gws + f.kr, D, D, D, D};
       gm.seg[1] = GemmSeg{xe, params + lay.g_w1, gws + f.slab1, IN, D, IN, IN};
       gm.nblk0 = cbD;
-      hipLaunchKernelGGL(lgcp_gemm_kernel, dim3(cbD + cbIN, kSplit), gblock, gemm_lds, st, gm);
+      hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_NONE>, dim3(cbD + cbIN, kSplit), gblock, gemm_lds, st, gm);
       act.mode = 1; act.slab_a = gws + f.slab1; act.bias_a = ws + w.bias1 + (int64_t)e * IN;
       act.sum_a = gws + f.pre1; act.u_prev = nullptr; act.u_out = gws + f.u1;
       hipLaunchKernelGGL(lgcp_act_kernel, dim3((M * IN + 255) / 256), dim3(256), 0, st, act);
       gm.Kdim = IN;
       gm.seg[0] = GemmSeg{gws + f.u1, params + lay.g_w2, gws + f.slab2, IN, IN, IN, IN};
       gm.nblk0 = cbIN;
-      hipLaunchKernelGGL(lgcp_gemm_kernel, dim3(cbIN, kSplit), gblock, gemm_lds, st, gm);
+      hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_NONE>, dim3(cbIN, kSplit), gblock, gemm_lds, st, gm);
       act.mode = 2; act.slab_a = gws + f.slab2; act.bias_a = params + lay.g_b2;
       act.sum_a = gws + f.pre2; act.u_prev = gws + f.u1; act.u_out = gws + f.u2;
       hipLaunchKernelGGL(lgcp_act_kernel, dim3((M * IN + 255) / 256), dim3(256), 0, st, act);
       gm.seg[0] = GemmSeg{gws + f.u2, params + lay.g_w3, gws + f.sn, D, IN, D, D};
       gm.nblk0 = cbD;
-      hipLaunchKernelGGL(lgcp_gemm_kernel, dim3(cbD, kSplit), gblock, gemm_lds, st, gm);
+      hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_NONE>, dim3(cbD, kSplit), gblock, gemm_lds, st, gm);
     };
 
     forward_at(K, side);
@@ -961,7 +1121,7 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
       gm.Kdim = D;
       gm.seg[0] = GemmSeg{gws + g.dO, gws + g.wt3, gws + g.du2s, IN, D, IN, IN};
       gm.nblk0 = cbIN;
-      hipLaunchKernelGGL(lgcp_gemm_kernel, dim3(cbIN, kSplit), gblock, gemm_lds, stream, gm);
+      hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_NONE>, dim3(cbIN, kSplit), gblock, gemm_lds, stream, gm);
       LgcpActbArgs ab{};
       ab.slab = gws + g.du2s; ab.pre = gws + f.pre2; ab.du_prev = nullptr; ab.u_src = gws + f.u2;
       ab.du_out = gws + g.du2; ab.da_out = gws + g.da2; ab.da_big = gws + g.DA2; ab.u_big = gws + g.U2;
@@ -971,7 +1131,7 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
       gm.Kdim = IN;
       gm.seg[0] = GemmSeg{gws + g.da2, gws + g.wt2, gws + g.ts, IN, IN, IN, IN};
       gm.nblk0 = cbIN;
-      hipLaunchKernelGGL(lgcp_gemm_kernel, dim3(cbIN, kSplit), gblock, gemm_lds, stream, gm);
+      hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_NONE>, dim3(cbIN, kSplit), gblock, gemm_lds, stream, gm);
       ab.slab = gws + g.ts; ab.pre = gws + f.pre1; ab.du_prev = gws + g.du2; ab.u_src = gws + f.u1;
       ab.du_out = gws + g.du1; ab.da_out = gws + g.da1; ab.da_big = gws + g.DA1; ab.u_big = gws + g.U1;
       ab.S = gws + g.S + (int64_t)e * IN; ab.S2 = gws + g.S2 + (int64_t)e * IN; ab.mode = 1;
@@ -980,11 +1140,11 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
       gm.Kdim = IN;
       gm.seg[0] = GemmSeg{gws + g.da1, gws + g.wt1, gws + g.dxf, D, IN, IN, D};
       gm.nblk0 = cbD;
-      hipLaunchKernelGGL(lgcp_gemm_kernel, dim3(cbD, kSplit), gblock, gemm_lds, stream, gm);
+      hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_NONE>, dim3(cbD, kSplit), gblock, gemm_lds, stream, gm);
       gm.Kdim = D;
       gm.seg[0] = GemmSeg{gws + g.v, kinv, gws + g.hv, D, D, D, D};
       gm.nblk0 = cbD;
-      hipLaunchKernelGGL(lgcp_gemm_kernel, dim3(cbD, kSplit), gblock, gemm_lds, stream, gm);
+      hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_NONE>, dim3(cbD, kSplit), gblock, gemm_lds, stream, gm);
       LgcpLamArgs la{};
       la.params = params; la.tc = tc; la.traj = traj; la.dxf = gws + g.dxf; la.hv = gws + g.hv; la.du1 = gws + g.du1;
       la.v = gws + g.v; la.lam_part = gws + g.lam_part; la.gprev = gws + g.gprev; la.lamn = gws + g.lamn;
