@@ -753,9 +753,7 @@ struct LgcpAdjArgs {
   float* lam_part;           // [kMP][D]
   float* gmu_acc;            // [kMP][D] running d / d vd.mean per particle
   float* glam_acc;           // [kMP][D]
-  float* gbeta;              // [K]
-  float* geps;               // [K]
-  float* gfac;               // scalar
+  float* part;               // [K+1][n * nbx][8] per-workgroup partial sums {sb, se, r2, sb2, se2, gf} (no atomics)
   float* DObig;              // [(K+1) n][D]
   cmcd_layout lay;
   int64_t n, base;
@@ -765,7 +763,7 @@ struct LgcpAdjArgs {
 
 __global__ __launch_bounds__(256) void lgcp_adj_step_kernel(LgcpAdjArgs a) {
   __shared__ float sh[4];
-  const int p = blockIdx.x, D = a.D, e = a.e, K = a.K;
+  const int p = blockIdx.y, D = a.D, e = a.e, K = a.K;
   const float* counts = a.tc + (int64_t)D * D;
   const float pa = a.tc[(int64_t)D * D + D + 1];
   const float clipv = 1e3f;
@@ -778,7 +776,8 @@ __global__ __launch_bounds__(256) void lgcp_adj_step_kernel(LgcpAdjArgs a) {
   const float* zpv = a.traj + ((int64_t)(e > 0 ? e - 1 : 0) * a.n + a.base + p) * D;
   const float* znv = a.traj + ((int64_t)(e < K ? e + 1 : K) * a.n + a.base + p) * D;
   float sb = 0.f, se = 0.f, r2 = 0.f, sb2 = 0.f, se2 = 0.f, gf = 0.f;
-  for (int j = threadIdx.x; j < D; j += blockDim.x) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;     // one element per thread: a single memory round trip
+  if (j < D) {
     const float z = ze[j];
     float kr = 0.f, o = a.b3[j];
 #pragma unroll
@@ -826,17 +825,52 @@ __global__ __launch_bounds__(256) void lgcp_adj_step_kernel(LgcpAdjArgs a) {
   const float tsb = block_sum_256(sb, sh), tse = block_sum_256(se, sh), tr2 = block_sum_256(r2, sh);
   const float tsb2 = block_sum_256(sb2, sh), tse2 = block_sum_256(se2, sh), tgf = block_sum_256(gf, sh);
   if (threadIdx.x == 0) {
-    if (e > 0) {
-      const float inv2e = 0.5f / pe;
-      atomicAdd(a.gbeta + (e - 1), pe * tsb);
-      atomicAdd(a.geps + (e - 1), tse - om * tr2 * inv2e * inv2e);
-    }
-    if (e < K) {
-      atomicAdd(a.gbeta + e, ee * tsb2);
-      atomicAdd(a.geps + e, tse2);
-    }
-    atomicAdd(a.gfac, tgf);
+    float* o = a.part + (((int64_t)e * a.n + a.base + p) * gridDim.x + blockIdx.x) * 8;
+    o[0] = tsb; o[1] = tse; o[2] = tr2; o[3] = tsb2; o[4] = tse2; o[5] = tgf;
   }
+}
+
+// gbeta / geps / d factor_sn from the adjoint step's per-workgroup partials: one wave per evaluation e, fixed order
+struct LgcpAdjRedArgs {
+  const float* part;     // [K+1][slots][8]
+  const float* sched;
+  float* gbeta_lo;       // [K+1] contribution of evaluation e to entry e-1
+  float* geps_lo;
+  float* gbeta_hi;       // [K+1] contribution of evaluation e to entry e
+  float* geps_hi;
+  float* gfac_e;         // [K+1]
+  int K, slots;
+  float omega;
+};
+
+__global__ __launch_bounds__(64) void lgcp_adj_reduce_kernel(LgcpAdjRedArgs a) {
+  const int e = blockIdx.x, lane = threadIdx.x;
+  float t[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int sl = lane; sl < a.slots; sl += 64) {
+    const float* o = a.part + ((int64_t)e * a.slots + sl) * 8;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) t[q] += o[q];
+  }
+#pragma unroll
+  for (int q = 0; q < 6; ++q) t[q] = wave_sum64(t[q]);
+  if (lane == 0) {
+    const float pe = e > 0 ? a.sched[8 * (e - 1) + 1] : 1.f, ee = e < a.K ? a.sched[8 * e + 1] : 1.f;
+    const float inv2e = 0.5f / pe;
+    a.gbeta_lo[e] = e > 0 ? pe * t[0] : 0.f;
+    a.geps_lo[e] = e > 0 ? t[1] - a.omega * t[2] * inv2e * inv2e : 0.f;
+    a.gbeta_hi[e] = e < a.K ? ee * t[3] : 0.f;
+    a.geps_hi[e] = e < a.K ? t[4] : 0.f;
+    a.gfac_e[e] = t[5];
+  }
+}
+
+// gbeta[k] = hi[k] + lo[k + 1]  (two addends: order-free), same for geps
+__global__ void lgcp_adj_combine_kernel(const float* lo_b, const float* hi_b, const float* lo_e, const float* hi_e, float* gbeta,
+                                        float* geps, int K) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  gbeta[k] = hi_b[k] + lo_b[k + 1];
+  geps[k] = hi_e[k] + lo_e[k + 1];
 }
 
 // backward activations: one thread per (particle, hidden unit)
@@ -981,7 +1015,9 @@ struct LgcpGradWs {
   int64_t gmu_acc, glam_acc;                   // [kMP][D]
   int64_t U1, U2, DA1, DA2;                    // [(K+1) n][IN]
   int64_t DO;                                  // [(K+1) n][D]
-  int64_t S, S2, gbeta, geps, gfac, gb2;       // tables
+  int64_t S, S2, gbeta, geps, gfac, gb2;       // tables (gfac: [K+1] per-evaluation terms)
+  int64_t adjpart, gb_lo, ge_lo, gb_hi, ge_hi; // adjoint step partial sums and their per-evaluation reductions
+  int64_t counters;                            // arrival counters of the side stream's fused GEMMs (ints)
   int64_t zero_lo, zero_hi;                    // range to clear per call
   LgcpFwdSet fs[2];
   int64_t total;
@@ -1008,8 +1044,11 @@ static LgcpGradWs lgcp_grad_ws(const cmcd_desc& d, int64_t n) {
   w.lamn = take(kMP * D); w.gE = take(kMP * D);
   w.gmu_acc = take(kMP * D); w.glam_acc = take(kMP * D);
   w.S = take((K + 1) * IN); w.S2 = take((K + 1) * IN);
-  w.gbeta = take(K); w.geps = take(K); w.gfac = take(4); w.gb2 = take(IN);
+  w.gbeta = take(K); w.geps = take(K); w.gfac = take(K + 1); w.gb2 = take(IN);
+  w.counters = take((D + 63) / 64 + (IN + 63) / 64);
   w.zero_hi = o;
+  w.adjpart = take((K + 1) * n * ((D + 255) / 256) * 8);
+  w.gb_lo = take(K + 1); w.ge_lo = take(K + 1); w.gb_hi = take(K + 1); w.ge_hi = take(K + 1);
   w.total = o;
   return w;
 }
@@ -1063,33 +1102,29 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
     }
     if (hipEventRecord(ev_fork, stream) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess) return CMCD_ERR_HIP;
 
-    // forward recompute at z_e into buffer set e & 1, on stream st
+    // forward recompute at z_e into buffer set e & 1, on stream st: the forward path's three launches (activations
+    // fused into the GEMMs; the third has no consumer here: the adjoint step sums its slabs)
+    int* side_counters = reinterpret_cast<int*>(gws + g.counters);
     auto forward_at = [&](int e, hipStream_t st) {
       const LgcpFwdSet& f = g.fs[e & 1];
       const int ie = e < K ? e : K - 1;
       const float* xe = traj + ((int64_t)e * n + base) * D;
-      ActArgs act{};
-      act.mu0 = mu0; act.M = M; act.D = D; act.IN = IN; act.xm = gws + f.xm;
-      act.x = xe; act.emb = params + lay.g_emb + (int64_t)ie * E;
-      act.mode = 0;
-      hipLaunchKernelGGL(lgcp_act_kernel, dim3((M * D + 255) / 256), dim3(256), 0, st, act);
       GemmArgs gm{};
-      gm.M = M;
+      gm.M = M; gm.counters = side_counters;
+      gm.act.x = xe; gm.act.D = D; gm.act.IN = IN;
       gm.Kdim = D;
-      gm.seg[0] = GemmSeg{gws + f.xm, kinv, gws + f.kr, D, D, D, D};
+      gm.seg[0] = GemmSeg{xe, kinv, gws + f.kr, D, D, D, D, mu0};
       gm.seg[1] = GemmSeg{xe, params + lay.g_w1, gws + f.slab1, IN, D, IN, IN};
-      gm.nblk0 = cbD;
-      hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_NONE>, dim3(cbD + cbIN, kSplit), gblock, gemm_lds, st, gm);
-      act.mode = 1; act.slab_a = gws + f.slab1; act.bias_a = ws + w.bias1 + (int64_t)e * IN;
-      act.sum_a = gws + f.pre1; act.u_prev = nullptr; act.u_out = gws + f.u1;
-      hipLaunchKernelGGL(lgcp_act_kernel, dim3((M * IN + 255) / 256), dim3(256), 0, st, act);
+      gm.nblk0 = cbD; gm.epi_seg = 1;
+      gm.act.mode = 1; gm.act.bias = ws + w.bias1 + (int64_t)e * IN; gm.act.emb = params + lay.g_emb + (int64_t)ie * E;
+      gm.act.sum_out = gws + f.pre1; gm.act.u_prev = nullptr; gm.act.u_out = gws + f.u1;
+      hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_ACT>, dim3(cbD + cbIN, kSplit), gblock, gemm_lds, st, gm);
       gm.Kdim = IN;
       gm.seg[0] = GemmSeg{gws + f.u1, params + lay.g_w2, gws + f.slab2, IN, IN, IN, IN};
-      gm.nblk0 = cbIN;
-      hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_NONE>, dim3(cbIN, kSplit), gblock, gemm_lds, st, gm);
-      act.mode = 2; act.slab_a = gws + f.slab2; act.bias_a = params + lay.g_b2;
-      act.sum_a = gws + f.pre2; act.u_prev = gws + f.u1; act.u_out = gws + f.u2;
-      hipLaunchKernelGGL(lgcp_act_kernel, dim3((M * IN + 255) / 256), dim3(256), 0, st, act);
+      gm.nblk0 = cbIN; gm.epi_seg = -1;
+      gm.act.mode = 2; gm.act.bias = params + lay.g_b2; gm.act.sum_out = gws + f.pre2; gm.act.u_prev = gws + f.u1;
+      gm.act.u_out = gws + f.u2;
+      hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_ACT>, dim3(cbIN, kSplit), gblock, gemm_lds, st, gm);
       gm.seg[0] = GemmSeg{gws + f.u2, params + lay.g_w3, gws + f.sn, D, IN, D, D};
       gm.nblk0 = cbD;
       hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_NONE>, dim3(cbD, kSplit), gblock, gemm_lds, st, gm);
@@ -1113,10 +1148,10 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
       aa.params = params; aa.tc = tc; aa.sched = ws + sw.sched; aa.traj = traj; aa.kr = gws + f.kr; aa.sn = gws + f.sn;
       aa.b3 = params + lay.g_b3; aa.factor = params + lay.g_factor; aa.lamn = gws + g.lamn; aa.gE = gws + g.gE;
       aa.gprev = gws + g.gprev; aa.dO = gws + g.dO; aa.v = gws + g.v; aa.lam_part = gws + g.lam_part;
-      aa.gmu_acc = gws + g.gmu_acc; aa.glam_acc = gws + g.glam_acc; aa.gbeta = gws + g.gbeta; aa.geps = gws + g.geps;
-      aa.gfac = gws + g.gfac; aa.DObig = gws + g.DO; aa.lay = lay; aa.n = n; aa.base = base;
+      aa.gmu_acc = gws + g.gmu_acc; aa.glam_acc = gws + g.glam_acc; aa.part = gws + g.adjpart;
+      aa.DObig = gws + g.DO; aa.lay = lay; aa.n = n; aa.base = base;
       aa.M = M; aa.D = D; aa.K = K; aa.e = e; aa.grad_clipping = d.grad_clipping; aa.omega = omega;
-      hipLaunchKernelGGL(lgcp_adj_step_kernel, dim3(M), dim3(256), 0, stream, aa);
+      hipLaunchKernelGGL(lgcp_adj_step_kernel, dim3((D + 255) / 256, M), dim3(256), 0, stream, aa);
       // ---- net backward: d u2 = d o W3^T
       gm.Kdim = D;
       gm.seg[0] = GemmSeg{gws + g.dO, gws + g.wt3, gws + g.du2s, IN, D, IN, IN};
@@ -1137,14 +1172,12 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
       ab.S = gws + g.S + (int64_t)e * IN; ab.S2 = gws + g.S2 + (int64_t)e * IN; ab.mode = 1;
       hipLaunchKernelGGL(lgcp_actb_kernel, dim3((IN + 255) / 256, M), dim3(256), 0, stream, ab);
       // d x = d u1[:D] + d a1 W1[:D]^T   |   v K^-1
-      gm.Kdim = IN;
+      gm.Kdim = IN; gm.Kdim1 = D;                       // two independent products, one launch
       gm.seg[0] = GemmSeg{gws + g.da1, gws + g.wt1, gws + g.dxf, D, IN, IN, D};
+      gm.seg[1] = GemmSeg{gws + g.v, kinv, gws + g.hv, D, D, D, D};
       gm.nblk0 = cbD;
-      hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_NONE>, dim3(cbD, kSplit), gblock, gemm_lds, stream, gm);
-      gm.Kdim = D;
-      gm.seg[0] = GemmSeg{gws + g.v, kinv, gws + g.hv, D, D, D, D};
-      gm.nblk0 = cbD;
-      hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_NONE>, dim3(cbD, kSplit), gblock, gemm_lds, stream, gm);
+      hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_NONE>, dim3(2 * cbD, kSplit), gblock, gemm_lds, stream, gm);
+      gm.Kdim1 = 0;
       LgcpLamArgs la{};
       la.params = params; la.tc = tc; la.traj = traj; la.dxf = gws + g.dxf; la.hv = gws + g.hv; la.du1 = gws + g.du1;
       la.v = gws + g.v; la.lam_part = gws + g.lam_part; la.gprev = gws + g.gprev; la.lamn = gws + g.lamn;
@@ -1169,7 +1202,15 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
                      grad + lay.g_w1, R, D, IN, D, IN, IN);                                     // dW1[:D] = X^T dA1
   hipLaunchKernelGGL(lgcp_colsum_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, gws + g.DO, R, D, D, grad + lay.g_b3, 1.0f, 0);
   hipLaunchKernelGGL(lgcp_colsum_kernel, dim3((IN + 255) / 256), dim3(256), 0, stream, gws + g.gb2, (int64_t)1, IN, IN, grad + lay.g_b2, 1.0f, 0);
-  hipLaunchKernelGGL(lgcp_colsum_kernel, dim3(1), dim3(256), 0, stream, gws + g.gfac, (int64_t)1, 1, 1, grad + lay.g_factor, 1.0f, 0);
+  {
+    const int slots = (int)(n * ((D + 255) / 256));
+    LgcpAdjRedArgs ra{gws + g.adjpart, ws + sw.sched, gws + g.gb_lo, gws + g.ge_lo, gws + g.gb_hi, gws + g.ge_hi, gws + g.gfac,
+                      K, slots, omega};
+    hipLaunchKernelGGL(lgcp_adj_reduce_kernel, dim3(K + 1), dim3(64), 0, stream, ra);
+    hipLaunchKernelGGL(lgcp_adj_combine_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, gws + g.gb_lo, gws + g.gb_hi,
+                       gws + g.ge_lo, gws + g.ge_hi, gws + g.gbeta, gws + g.geps, K);
+  }
+  hipLaunchKernelGGL(lgcp_colsum_kernel, dim3(1), dim3(256), 0, stream, gws + g.gfac, (int64_t)(K + 1), 1, 1, grad + lay.g_factor, 1.0f, 0);
   int rc = launch_geffner_tails(d, lay, sw, params, gws, g.S, g.S2, g.gbeta, g.geps, IN, grad, stream_);
   if (rc != CMCD_OK) return rc;
   return hipGetLastError() == hipSuccess ? CMCD_OK : CMCD_ERR_HIP;
