@@ -106,12 +106,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback for the hot path)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # test hook (tests/test_gpu_bench.py): all ranks on device 0 over gloo, to exercise the N > 1 code path on a 1-GPU box
+    shared_gpu = os.environ.get("CMCD_BENCH_SHARED_GPU") == "1"
+    dev_index = 0 if shared_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ   # launched by torch.distributed.run
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from cmcd_amd import _lib, build, synthetic

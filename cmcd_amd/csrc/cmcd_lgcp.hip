@@ -68,7 +68,6 @@ struct StepEpi {         // evaluation i at z_i: closes step i-1, opens step i (
   const float* sched;        // [K][8]
   float* x;                  // [kMP][D]   current z (updated in place, own columns only)
   float* xp;                 // [kMP][D]   previous z
-  float* xm;                 // [kMP][D]   z - mu0: the next evaluation's K^-1 operand
   const float* kr;           // [kSplit][kMP][D]   partial slabs of K^-1 (x - mu0)   (previous launch)
   const float* b3;           // [D]
   const float* factor;       // factor_sn (device scalar)
@@ -171,7 +170,6 @@ __device__ __forceinline__ void lgcp_step_tile(const StepEpi& a, const float* sn
         fk_acc = -(df * df) * inv2s2 - cst;
         a.xp[m * D + e] = z;
         a.x[m * D + e] = zn;
-        a.xm[m * D + e] = zn - mu0;
         if (a.traj) a.traj[((int64_t)(i + 1) * a.n_total + a.base + m) * D + e] = zn;
       }
     }
@@ -320,40 +318,6 @@ __global__ __launch_bounds__(64 * (kGemmWaves + (EPI == EPI_STEP ? 1 : 0))) void
 }
 
 // ------------------------------------------------------------------------------------------
-// activation kernels: sum the split-K slabs in fixed order, add the bias, form the next GEMM's input
-// ------------------------------------------------------------------------------------------
-struct ActArgs {
-  const float* x;        // [kMP][D]
-  const float* emb;      // [E]
-  const float* slab_a;   // [kSplit][kMP][lda]  partials of the previous GEMM (segment a)
-  const float* bias_a;   // [IN] or nullptr
-  float* sum_a;          // [kMP][IN] summed pre-activation (kept: the next layer's residual needs it)
-  const float* u_prev;   // [kMP][IN] previous layer's u (act2 only)
-  float* u_out;          // [kMP][IN]
-  float* xm;             // [kMP][D]   x - mu0 (act0 only)
-  float mu0;
-  int M, D, IN, mode;    // mode 0: xm = x - mu0 ; 1: u1 = u + softplus(pre1) ; 2: u2 = u1 + softplus(pre2)
-};
-
-__global__ void lgcp_act_kernel(ActArgs a) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (a.mode == 0) {
-    if (idx < a.M * a.D) a.xm[idx] = a.x[idx] - a.mu0;
-    return;
-  }
-  if (idx >= a.M * a.IN) return;
-  const int m = idx / a.IN, k = idx - m * a.IN;
-  float pre = a.bias_a[k];
-#pragma unroll
-  for (int ks = 0; ks < kSplit; ++ks) pre += a.slab_a[((int64_t)ks * kMP + m) * a.IN + k];
-  a.sum_a[idx] = pre;
-  float u;
-  if (a.mode == 1) u = k < a.D ? a.x[m * a.D + k] : a.emb[k - a.D];   // u = [x; emb_i]      nn.py:68-69
-  else u = a.u_prev[idx];
-  a.u_out[idx] = u + softplus(pre);                                   // nn.py:45-50
-}
-
-// ------------------------------------------------------------------------------------------
 // per-bridge first-layer bias of the 1620-wide geffner net: b1 + emb[min(i, K-1)] W1[d:, :]
 // ------------------------------------------------------------------------------------------
 struct LgcpPrepArgs {
@@ -380,25 +344,14 @@ struct LgcpStateArgs {
   const int32_t* seeds;      // [M] (this pass)
   const float* params;
   const float* tc;           // {Kinv[d,d], counts[d], mu0, a, lognorm}
-  const float* sched;        // [K][8]
-  float* x;                  // [kMP][D]   current z
-  float* xp;                 // [kMP][D]   previous z
-  const float* kr;           // [kSplit][kMP][D]   partial slabs of K^-1 (x - mu0)
-  const float* sn;           // [kSplit][kMP][D]   partial slabs of u2 W3
-  const float* b3;           // [D]
-  const float* factor;       // factor_sn (device scalar)
-  float* w;                  // [kMP]
-  float* fklp;               // [kMP]
+  float* x;                  // [kMP][D]   z_0
+  float* w;                  // [kMP]      -log q(z_0)
   uint32_t* keys;            // [kMP][2]   gen key of the chain
-  float* out_loss;           // [M]
-  float* out_z;              // [M][D]
-  double* partials;          // [M][5]
-  float* xm;                 // [kMP][D]   z - mu0 of the CURRENT z: the next GEMM's input (no separate launch)
   uint32_t* gkey;            // [2][kMP][2] noise key of evaluation 0 (forward path only; nullptr: not needed)
   float* traj;               // optional [K+1][n_total][D]: z_0..z_K of every particle (reverse sweep of the gradient)
   int64_t n_total, base;     // trajectory row of particle p of this pass: base + p
   cmcd_layout lay;
-  int M, D, K, i, var_mode, grad_clipping;
+  int M, D;
 };
 
 __device__ __forceinline__ float block_sum_256(float v, float* sh) {
@@ -433,7 +386,6 @@ __global__ __launch_bounds__(256) void lgcp_init_kernel(LgcpStateArgs a) {
         const float sd = expf(a.params[a.lay.vd_logdiag + idx[q]]);
         const float z = sd * bits_to_normal(bits[q]) + mean;
         a.x[p * D + idx[q]] = z;
-        if (a.xm) a.xm[p * D + idx[q]] = z - a.tc[(int64_t)D * D + D];
         if (a.traj) a.traj[(a.base + p) * D + idx[q]] = z;
         const float dz = z - mean;
         acc += -(dz * dz) / (2.0f * sd * sd) - logf(sd) - kHalfLog2Pi;
@@ -443,7 +395,6 @@ __global__ __launch_bounds__(256) void lgcp_init_kernel(LgcpStateArgs a) {
   const float lq = block_sum_256(acc, sh);
   if (threadIdx.x == 0) {
     a.w[p] = -lq;
-    a.fklp[p] = 0.f;
     uint32_t c0 = 0, c2 = 2, c1 = 1, c3 = 3;
     threefry2x32(b0, b1, c0, c2);
     threefry2x32(b0, b1, c1, c3);       // C = (c0, c1)
@@ -496,7 +447,7 @@ __global__ void lgcp_final_kernel(LgcpFinalArgs a) {
 // host side
 // ------------------------------------------------------------------------------------------
 struct LgcpWs {
-  int64_t bias1, x, xp, xm, u1, u2, pre1, pre2, kr, slab1, slab2, sn, w, fklp, keys, gkey, slots, counters, partials, total;
+  int64_t bias1, x, xp, u1, u2, pre1, pre2, kr, slab1, slab2, sn, w, keys, gkey, slots, counters, partials, total;
 };
 
 static LgcpWs lgcp_ws(const cmcd_desc& d, int64_t n, int64_t base) {
@@ -505,11 +456,11 @@ static LgcpWs lgcp_ws(const cmcd_desc& d, int64_t n, int64_t base) {
   int64_t o = base;
   auto take = [&](int64_t cnt) { int64_t r = o; o += (cnt + 3) & ~int64_t(3); return r; };
   w.bias1 = take((K + 1) * IN);
-  w.x = take(kMP * D); w.xp = take(kMP * D); w.xm = take(kMP * D);
+  w.x = take(kMP * D); w.xp = take(kMP * D);
   w.u1 = take(kMP * IN); w.u2 = take(kMP * IN); w.pre1 = take(kMP * IN); w.pre2 = take(kMP * IN);
   w.kr = take(kSplit * kMP * D); w.slab1 = take(kSplit * kMP * IN); w.slab2 = take(kSplit * kMP * IN);
   w.sn = take(kSplit * kMP * D);
-  w.w = take(kMP); w.fklp = take(kMP); w.keys = take(2 * kMP); w.gkey = take(4 * kMP);
+  w.w = take(kMP); w.keys = take(2 * kMP); w.gkey = take(4 * kMP);
   w.slots = take(3 * ((D + 63) / 64) * kMP);             // wslot | fkslot | lpslot
   w.counters = take(((D + 63) / 64) + ((IN + 63) / 64)); // int arrival counters of the widest launch
   o = (o + 1) & ~int64_t(1);
@@ -545,6 +496,9 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
   const float* kinv = tc;
   double* partials = reinterpret_cast<double*>(ws + w.partials);
   *partials_out = partials;
+  // mu0 is a model constant, log(126) - 0.5 * 1.91 (model_handler.py:346); the state update reads the device copy in
+  // tc, the GEMM takes it as the operand shift
+  const float mu0 = 3.8812819069514780f;
   const dim3 gblock(64 * kGemmWaves), gblock_step(64 * (kGemmWaves + 1));
   const int cbD = (D + 63) / 64, cbIN = (IN + 63) / 64;
   int* counters = reinterpret_cast<int*>(ws + w.counters);
@@ -554,19 +508,18 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
     const int M = (int)((n - base) < kMP ? (n - base) : kMP);
     if (hipMemsetAsync(ws + w.slots, 0, sizeof(float) * 3 * cbD * kMP, stream) != hipSuccess) return CMCD_ERR_HIP;
     LgcpStateArgs st{};
-    st.seeds = seeds + base; st.params = params; st.tc = tc; st.sched = ws + sw.sched;
-    st.x = ws + w.x; st.xp = ws + w.xp;
-    st.w = ws + w.w; st.fklp = ws + w.fklp; st.keys = reinterpret_cast<uint32_t*>(ws + w.keys);
+    st.seeds = seeds + base; st.params = params; st.tc = tc; st.x = ws + w.x;
+    st.w = ws + w.w; st.keys = reinterpret_cast<uint32_t*>(ws + w.keys);
     st.gkey = reinterpret_cast<uint32_t*>(ws + w.gkey);
-    st.lay = lay; st.M = M; st.D = D; st.K = K;
-    st.traj = traj; st.n_total = n; st.base = base; st.xm = ws + w.xm;
+    st.lay = lay; st.M = M; st.D = D;
+    st.traj = traj; st.n_total = n; st.base = base;
     hipLaunchKernelGGL(lgcp_init_kernel, dim3(M), dim3(256), 0, stream, st);
 
     GemmArgs g{};
     g.M = M; g.counters = counters;
     g.act.x = ws + w.x; g.act.D = D; g.act.IN = IN;
     StepEpi& se = g.step;
-    se.params = params; se.tc = tc; se.sched = ws + sw.sched; se.x = ws + w.x; se.xp = ws + w.xp; se.xm = ws + w.xm;
+    se.params = params; se.tc = tc; se.sched = ws + sw.sched; se.x = ws + w.x; se.xp = ws + w.xp;
     se.kr = ws + w.kr; se.b3 = params + lay.g_b3; se.factor = params + lay.g_factor;
     se.gen = reinterpret_cast<uint32_t*>(ws + w.keys); se.gkey = reinterpret_cast<uint32_t*>(ws + w.gkey);
     se.wslot = ws + w.slots; se.fkslot = se.wslot + cbD * kMP; se.lpslot = se.fkslot + cbD * kMP;
@@ -577,7 +530,7 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
       // A: [x - mu0] Kinv -> kr slabs (summed by the state update two launches on)
       //    x W1[:D] -> pre1 slabs -> u1 = [x; emb_i] + softplus(pre1 + bias1_i)            (fused consumer)
       g.Kdim = D; g.Kdim1 = 0;
-      g.seg[0] = GemmSeg{ws + w.xm, kinv, ws + w.kr, D, D, D, D};
+      g.seg[0] = GemmSeg{ws + w.x, kinv, ws + w.kr, D, D, D, D, mu0};
       g.seg[1] = GemmSeg{ws + w.x, params + lay.g_w1, ws + w.slab1, IN, D, IN, IN};
       g.nblk0 = cbD; g.epi_seg = 1;
       g.act.mode = 1; g.act.bias = ws + w.bias1 + (int64_t)i * IN; g.act.emb = params + lay.g_emb + (int64_t)ie * E;
@@ -607,7 +560,7 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
 // Mean-field VI on the lgcp target (nbridges = 0; /root/reference/src/boundingmachine.py:73-111 with
 // /root/reference/src/main.py:82-109): z = mean + std e, loss = log q(z) - log p(z), and under the
 // reparameterisation d loss / d mean = -grad log p(z), d loss / d logdiag = -1 - grad log p(z) std e.
-// Per pass of <= kMP particles: init (z, -log q) -> x - mu0 -> one skinny GEMM with K^-1 -> finish.
+// Per pass of <= kMP particles: init (z, -log q) -> one skinny GEMM (z - mu0) K^-1 -> finish.
 // ------------------------------------------------------------------------------------------
 struct LgcpMfviArgs {
   const float* params;
@@ -660,8 +613,8 @@ __global__ __launch_bounds__(256) void lgcp_mfvi_finish_kernel(LgcpMfviArgs a) {
 int64_t lgcp_mfvi_workspace_floats(int D, int64_t n, bool with_grad) {
   int64_t o = 0;
   auto take = [&](int64_t cnt) { o += (cnt + 3) & ~int64_t(3); };
-  take(kMP * (int64_t)D); take(kMP * (int64_t)D); take(kSplit * kMP * (int64_t)D);
-  take(kMP); take(kMP); take(2 * kMP);
+  take(kMP * (int64_t)D); take(kSplit * kMP * (int64_t)D);
+  take(kMP); take(2 * kMP);
   take(n * CMCD_NSTATS * 2);
   if (with_grad) take(n * 2 * (int64_t)D);
   return o;
@@ -673,8 +626,8 @@ int lgcp_mfvi(int D, int64_t o_mean, int64_t o_logdiag, const int32_t* seeds, in
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   int64_t o = 0;
   auto take = [&](int64_t cnt) { int64_t r = o; o += (cnt + 3) & ~int64_t(3); return r; };
-  const int64_t ox = take(kMP * (int64_t)D), oxm = take(kMP * (int64_t)D), okr = take(kSplit * kMP * (int64_t)D);
-  const int64_t ow = take(kMP), ofk = take(kMP), okeys = take(2 * kMP);
+  const int64_t ox = take(kMP * (int64_t)D), okr = take(kSplit * kMP * (int64_t)D);
+  const int64_t ow = take(kMP), okeys = take(2 * kMP);
   const int64_t opart = take(n * CMCD_NSTATS * 2);
   const int64_t ogb = with_grad ? take(n * 2 * (int64_t)D) : 0;
   double* partials = reinterpret_cast<double*>(ws + opart);
@@ -691,15 +644,12 @@ int lgcp_mfvi(int D, int64_t o_mean, int64_t o_logdiag, const int32_t* seeds, in
     const int M = (int)((n - base) < kMP ? (n - base) : kMP);
     LgcpStateArgs st{};
     st.seeds = seeds + base; st.params = params; st.tc = tc; st.x = ws + ox;
-    st.w = ws + ow; st.fklp = ws + ofk; st.keys = reinterpret_cast<uint32_t*>(ws + okeys);
-    st.lay = lay; st.M = M; st.D = D; st.K = 0;
+    st.w = ws + ow; st.keys = reinterpret_cast<uint32_t*>(ws + okeys);
+    st.lay = lay; st.M = M; st.D = D;
     hipLaunchKernelGGL(lgcp_init_kernel, dim3(M), dim3(256), 0, stream, st);
-    ActArgs act{};
-    act.x = ws + ox; act.mu0 = mu0; act.M = M; act.D = D; act.IN = D; act.xm = ws + oxm; act.mode = 0;
-    hipLaunchKernelGGL(lgcp_act_kernel, dim3((M * D + 255) / 256), dim3(256), 0, stream, act);
     GemmArgs g{};
     g.M = M; g.Kdim = D;
-    g.seg[0] = GemmSeg{ws + oxm, tc, ws + okr, D, D, D, D};
+    g.seg[0] = GemmSeg{ws + ox, tc, ws + okr, D, D, D, D, mu0};
     g.nblk0 = cbD;
     hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_NONE>, dim3(cbD, kSplit), dim3(64 * kGemmWaves), gemm_lds, stream, g);
     LgcpMfviArgs fa{params, tc, ws + ox, ws + okr, ws + ow, out_loss + base, out_z + base * D,
@@ -1032,7 +982,7 @@ __global__ void lgcp_colsum_kernel(const float* __restrict__ A, int64_t R, int C
 // buffers of one forward recompute (two sets: evaluation e-1 is recomputed on a side stream while the backward
 // pass of evaluation e reads the other set)
 struct LgcpFwdSet {
-  int64_t xm, kr, slab1, pre1, u1, slab2, pre2, u2, sn;
+  int64_t kr, slab1, pre1, u1, slab2, pre2, u2, sn;
 };
 
 struct LgcpGradWs {
@@ -1065,7 +1015,7 @@ static LgcpGradWs lgcp_grad_ws(const cmcd_desc& d, int64_t n) {
   w.U1 = take(R * IN); w.U2 = take(R * IN); w.DA1 = take(R * IN); w.DA2 = take(R * IN); w.DO = take(R * D);
   for (int b = 0; b < 2; ++b) {
     LgcpFwdSet& f = w.fs[b];
-    f.xm = take(kMP * D); f.kr = take(kSplit * kMP * D); f.slab1 = take(kSplit * kMP * IN); f.pre1 = take(kMP * IN);
+    f.kr = take(kSplit * kMP * D); f.slab1 = take(kSplit * kMP * IN); f.pre1 = take(kMP * IN);
     f.u1 = take(kMP * IN); f.slab2 = take(kSplit * kMP * IN); f.pre2 = take(kMP * IN); f.u2 = take(kMP * IN);
     f.sn = take(kSplit * kMP * D);
   }
