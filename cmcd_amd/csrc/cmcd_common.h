@@ -58,8 +58,8 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
 // reverse sweep of the reparameterised gradient on the d = 1600 path (cmcd_lgcp.hip); traj as left by lgcp_forward
 int64_t lgcp_grad_workspace_floats(const cmcd_desc& d, int64_t n);
 int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, int64_t n, const float* params,
-              int64_t n_params, const float* tc, float* ws_fwd, const float* traj, float* gws, float omega, float* grad,
-              void* stream);
+              int64_t n_params, const float* tc, float* ws, const float* traj, float* gws, float omega,
+              const float* omega_vec, bool bptt, float* grad, void* stream);
 // cmcd_grad.hip: MCD_ULA (no network) reverse sweep
 bool ula_grad_available(const cmcd_desc& d);
 int64_t ula_grad_workspace_floats(const cmcd_desc& d, int64_t n);

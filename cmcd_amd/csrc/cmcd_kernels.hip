@@ -1067,7 +1067,7 @@ int cmcd_bound_grad(const cmcd_desc* desc, const cmcd_layout* lay, const int32_t
     rc = forward_impl(desc, lay, seeds, n, params, n_params, target_consts, n_target, workspace, fwd * 4, out_loss,
                       out_z, out_stats, traj, stream_);
     if (rc != CMCD_OK) return rc;
-    rc = lgcp_grad(d, *lay, lw, n, params, n_params, target_consts, ws, traj, ws + fwd, omega, grad, stream_);
+    rc = lgcp_grad(d, *lay, lw, n, params, n_params, target_consts, ws, traj, ws + fwd, omega, nullptr, true, grad, stream_);
     if (rc != CMCD_OK) return fail(rc, "lgcp gradient launch sequence failed%s");
     return CMCD_OK;
   }
@@ -1107,7 +1107,13 @@ int cmcd_bound_grad(const cmcd_desc* desc, const cmcd_layout* lay, const int32_t
 }
 
 int64_t cmcd_grad_workspace_bytes(const cmcd_desc* desc, int64_t n) {
-  if (check_desc(desc) != CMCD_OK || n < 1 || desc->target == CMCD_TARGET_LGCP) return 0;
+  if (check_desc(desc) != CMCD_OK || n < 1) return 0;
+  if (desc->target == CMCD_TARGET_LGCP) {   // launch-sequence forward + reverse sweep + the kept trajectory
+    WsLayout lw;
+    make_ws_lgcp(*desc, n, lw);
+    return (align4(lgcp_workspace_floats(*desc, n, lw.total_floats)) + align4(lgcp_grad_workspace_floats(*desc, n)) +
+            (int64_t)(desc->nbridges + 1) * n * desc->dim) * 4;
+  }
   WsLayout w;
   const int64_t nt = desc->target == CMCD_TARGET_MANY_GMM ? 1 + 2 * 64 : 0;
   if (!make_ws(*desc, n, nt, w)) return 0;
@@ -1139,8 +1145,24 @@ static int var_grad_impl(const cmcd_desc* desc, const cmcd_layout* lay, const in
   if (!lay || !seeds || !params || !omega || !workspace || !grad) return fail(CMCD_ERR_BAD_ARG, "null pointer argument%s");
   if (desc->mode != CMCD_MODE_CAIS_VAR_SN)
     return fail(CMCD_ERR_UNSUPPORTED, "the local (stop_gradient) gradient exists for MCD_CAIS_var_sn only%s");
-  if (desc->target == CMCD_TARGET_LGCP) return fail(CMCD_ERR_UNSUPPORTED, "no lgcp gradient%s");
   const cmcd_desc& d = *desc;
+  if (d.target == CMCD_TARGET_LGCP) {
+    // d = 1600: the reverse launch sequence of cmcd_lgcp.hip with z detached, on the trajectory cmcd_bound_var_forward left
+    if (!kept)
+      return fail(CMCD_ERR_UNSUPPORTED, "lgcp: call cmcd_bound_var_forward, then cmcd_bound_var_grad_kept on the same workspace%s");
+    WsLayout lw;
+    make_ws_lgcp(d, n, lw);
+    const int64_t fwd = align4(lgcp_workspace_floats(d, n, lw.total_floats));
+    const int64_t gfl = align4(lgcp_grad_workspace_floats(d, n));
+    const int64_t need = (fwd + gfl + (int64_t)(d.nbridges + 1) * n * d.dim) * 4;
+    if (workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15))
+      return fail(CMCD_ERR_WORKSPACE, "workspace too small or not 16-byte aligned (need %s%lld bytes)", "", need);
+    float* ws = static_cast<float*>(workspace);
+    rc = lgcp_grad(d, *lay, lw, n, params, n_params, target_consts, ws, ws + fwd + gfl, ws + fwd, 0.f, omega, false, grad,
+                   stream_);
+    if (rc != CMCD_OK) return fail(rc, "lgcp gradient launch sequence failed%s");
+    return CMCD_OK;
+  }
   int n_mix = 0;
   if (d.target == CMCD_TARGET_MANY_GMM) {
     if (!target_consts || n_target < 3 || (n_target - 1) % 2 != 0 || (n_target - 1) / 2 > 64)
@@ -1191,12 +1213,20 @@ int cmcd_bound_var_forward(const cmcd_desc* desc, const cmcd_layout* lay, const 
                            double* out_stats, void* stream_) {
   int rc = check_desc(desc);
   if (rc != CMCD_OK) return rc;
-  if (desc->mode != CMCD_MODE_CAIS_VAR_SN || desc->target == CMCD_TARGET_LGCP)
+  if (desc->mode != CMCD_MODE_CAIS_VAR_SN)
     return fail(CMCD_ERR_UNSUPPORTED, "the local (stop_gradient) gradient exists for MCD_CAIS_var_sn only%s");
   const int64_t need = cmcd_grad_workspace_bytes(desc, n);
   if (need <= 0) return CMCD_ERR_UNSUPPORTED;
   if (workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15))
     return fail(CMCD_ERR_WORKSPACE, "workspace too small or not 16-byte aligned (need %s%lld bytes)", "", need);
+  if (desc->target == CMCD_TARGET_LGCP) {
+    WsLayout lw;
+    make_ws_lgcp(*desc, n, lw);
+    const int64_t fwd = align4(lgcp_workspace_floats(*desc, n, lw.total_floats));
+    const int64_t gfl = align4(lgcp_grad_workspace_floats(*desc, n));
+    return forward_impl(desc, lay, seeds, n, params, n_params, target_consts, n_target, workspace, fwd * 4, out_loss,
+                        out_z, out_stats, static_cast<float*>(workspace) + fwd + gfl, stream_);
+  }
   WsLayout w;
   if (!make_ws(*desc, n, n_target, w)) return fail(CMCD_ERR_BAD_ARG, "bad descriptor%s");
   const int64_t fwd = align4(w.total_floats), gfl = align4(grad_workspace_floats(*desc, w.HP, n));

@@ -73,6 +73,7 @@ struct StepEpi {         // evaluation i at z_i: closes step i-1, opens step i (
   const float* factor;       // factor_sn (device scalar)
   uint32_t* gen;             // [kMP][2]      gen key of the chain (advanced by column block 0's extra wave)
   uint32_t* gkey;            // [2][kMP][2]   G_i, parity-buffered by i: read [i & 1], written [(i + 1) & 1]
+  uint32_t* gktab;           // [K][n_total][2] every G_i of every particle (the VarGrad sweep redraws the noise from it)
   float* wslot;              // [ncb][kMP]    running sum over closed steps of (bk - fk) on this block's columns
   float* fkslot;             // [ncb][kMP]    forward-kernel log-density of the open step on this block's columns
   float* lpslot;             // [ncb][kMP]    log p(z_K) on this block's columns (i = K)
@@ -313,6 +314,8 @@ __global__ __launch_bounds__(64 * (kGemmWaves + (EPI == EPI_STEP ? 1 : 0))) void
       st.gen[2 * lane] = k0; st.gen[2 * lane + 1] = k1;
       uint32_t* gk = st.gkey + ((st.i + 1) & 1) * 2 * kMP;
       gk[2 * lane] = G0; gk[2 * lane + 1] = G1;
+      uint32_t* gt = st.gktab + ((int64_t)(st.i + 1) * st.n_total + st.base + lane) * 2;
+      gt[0] = G0; gt[1] = G1;
     }
   }
 }
@@ -348,6 +351,7 @@ struct LgcpStateArgs {
   float* w;                  // [kMP]      -log q(z_0)
   uint32_t* keys;            // [kMP][2]   gen key of the chain
   uint32_t* gkey;            // [2][kMP][2] noise key of evaluation 0 (forward path only; nullptr: not needed)
+  uint32_t* gktab;           // [K][n_total][2] (forward path only)
   float* traj;               // optional [K+1][n_total][D]: z_0..z_K of every particle (reverse sweep of the gradient)
   int64_t n_total, base;     // trajectory row of particle p of this pass: base + p
   cmcd_layout lay;
@@ -407,6 +411,8 @@ __global__ __launch_bounds__(256) void lgcp_init_kernel(LgcpStateArgs a) {
       lgcp_key_advance(k0, k1, G0, G1);
       a.gkey[2 * p] = G0;
       a.gkey[2 * p + 1] = G1;
+      a.gktab[(a.base + p) * 2] = G0;
+      a.gktab[(a.base + p) * 2 + 1] = G1;
     }
     a.keys[2 * p] = k0;
     a.keys[2 * p + 1] = k1;
@@ -447,7 +453,7 @@ __global__ void lgcp_final_kernel(LgcpFinalArgs a) {
 // host side
 // ------------------------------------------------------------------------------------------
 struct LgcpWs {
-  int64_t bias1, x, xp, u1, u2, pre1, pre2, kr, slab1, slab2, sn, w, keys, gkey, slots, counters, partials, total;
+  int64_t bias1, x, xp, u1, u2, pre1, pre2, kr, slab1, slab2, sn, w, keys, gkey, gktab, slots, counters, partials, total;
 };
 
 static LgcpWs lgcp_ws(const cmcd_desc& d, int64_t n, int64_t base) {
@@ -460,7 +466,7 @@ static LgcpWs lgcp_ws(const cmcd_desc& d, int64_t n, int64_t base) {
   w.u1 = take(kMP * IN); w.u2 = take(kMP * IN); w.pre1 = take(kMP * IN); w.pre2 = take(kMP * IN);
   w.kr = take(kSplit * kMP * D); w.slab1 = take(kSplit * kMP * IN); w.slab2 = take(kSplit * kMP * IN);
   w.sn = take(kSplit * kMP * D);
-  w.w = take(kMP); w.keys = take(2 * kMP); w.gkey = take(4 * kMP);
+  w.w = take(kMP); w.keys = take(2 * kMP); w.gkey = take(4 * kMP); w.gktab = take(2 * K * n);
   w.slots = take(3 * ((D + 63) / 64) * kMP);             // wslot | fkslot | lpslot
   w.counters = take(((D + 63) / 64) + ((IN + 63) / 64)); // int arrival counters of the widest launch
   o = (o + 1) & ~int64_t(1);
@@ -510,7 +516,7 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
     LgcpStateArgs st{};
     st.seeds = seeds + base; st.params = params; st.tc = tc; st.x = ws + w.x;
     st.w = ws + w.w; st.keys = reinterpret_cast<uint32_t*>(ws + w.keys);
-    st.gkey = reinterpret_cast<uint32_t*>(ws + w.gkey);
+    st.gkey = reinterpret_cast<uint32_t*>(ws + w.gkey); st.gktab = reinterpret_cast<uint32_t*>(ws + w.gktab);
     st.lay = lay; st.M = M; st.D = D;
     st.traj = traj; st.n_total = n; st.base = base;
     hipLaunchKernelGGL(lgcp_init_kernel, dim3(M), dim3(256), 0, stream, st);
@@ -522,6 +528,7 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
     se.params = params; se.tc = tc; se.sched = ws + sw.sched; se.x = ws + w.x; se.xp = ws + w.xp;
     se.kr = ws + w.kr; se.b3 = params + lay.g_b3; se.factor = params + lay.g_factor;
     se.gen = reinterpret_cast<uint32_t*>(ws + w.keys); se.gkey = reinterpret_cast<uint32_t*>(ws + w.gkey);
+    se.gktab = reinterpret_cast<uint32_t*>(ws + w.gktab);
     se.wslot = ws + w.slots; se.fkslot = se.wslot + cbD * kMP; se.lpslot = se.fkslot + cbD * kMP;
     se.out_z = out_z + base * D; se.traj = traj; se.n_total = n; se.base = base; se.lay = lay;
     se.D = D; se.K = K; se.var_mode = d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0; se.grad_clipping = d.grad_clipping;
@@ -706,7 +713,11 @@ struct LgcpAdjArgs {
   cmcd_layout lay;
   int64_t n, base;
   int M, D, K, e, grad_clipping;
-  float omega;
+  float omega;               // weight of every particle's loss (reparameterised gradient of the mean)
+  const float* omega_vec;    // [n] VarGrad: weight of particle p's LOG-WEIGHT (cmcd_vargrad_weights), or nullptr
+  const uint32_t* gktab;     // [K][n][2] noise keys of the forward pass (VarGrad: z_{e+1} - mean = sigma eps_e, exactly)
+  int bptt;                  // 1: gradient through the trajectory (lambda recursion); 0: z detached (mcd_cais_var.py:59,79)
+  int var_mode;              // MCD_CAIS_var_sn: clip at 1e2 and clip grad log q too (mcd_cais_var.py:29-36)
 };
 
 __global__ __launch_bounds__(256) void lgcp_adj_step_kernel(LgcpAdjArgs a) {
@@ -714,9 +725,10 @@ __global__ __launch_bounds__(256) void lgcp_adj_step_kernel(LgcpAdjArgs a) {
   const int p = blockIdx.y, D = a.D, e = a.e, K = a.K;
   const float* counts = a.tc + (int64_t)D * D;
   const float pa = a.tc[(int64_t)D * D + D + 1];
-  const float clipv = 1e3f;
-  const bool clip_p = a.grad_clipping != 0;
-  const float om = a.omega;
+  const float clipv = a.var_mode ? 1e2f : 1e3f;
+  const bool clip_p = a.grad_clipping != 0, clip_q = clip_p && a.var_mode;
+  const bool bptt = a.bptt != 0;
+  const float om = a.omega_vec ? -a.omega_vec[a.base + p] : a.omega;      // weight of this particle's loss = -w
   const float pb = e > 0 ? a.sched[8 * (e - 1)] : 0.f, pe = e > 0 ? a.sched[8 * (e - 1) + 1] : 1.f;
   const float be = e < K ? a.sched[8 * e] : 0.f, ee = e < K ? a.sched[8 * e + 1] : 1.f;
   const float fac = a.factor[0];
@@ -740,35 +752,52 @@ __global__ __launch_bounds__(256) void lgcp_adj_step_kernel(LgcpAdjArgs a) {
     const float mean = a.params[a.lay.vd_mean + j];
     const float sd = expf(a.params[a.lay.vd_logdiag + j]);
     const float qiv = 1.0f / (sd * sd);
-    const float gq = -(z - mean) * qiv;
+    const float gqraw = -(z - mean) * qiv;
+    const float mq = (!clip_q || fabsf(gqraw) < clipv) ? 1.0f : 0.f;
+    const float gq = clip_q ? fminf(fmaxf(gqraw, -clipv), clipv) : gqraw;
     float a_s = 0.f, a_gp = 0.f, a_gq = 0.f, lam = 0.f, gpv = 0.f;
-    if (e > 0) {
+    if (e > 0) {   // backward kernel of step e-1: d loss / d (its mean) = -r / sigma^2
       const float ub = -1.0f * (pb * gp + (1.0f - pb) * gq);
-      const float bk = z - pe * ub + pe * s;
-      const float r = zpv[j] - bk;
+      // r = z_{e-1} - (z - pe ub + pe s), with the O(1) states subtracted first (exact in float32: they differ by a step)
+      const float r = (zpv[j] - z) + pe * (ub - s);
       gpv = -om * r * (0.5f / pe);
       a_s += pe * gpv; a_gp += pe * pb * gpv; a_gq += pe * (1.0f - pb) * gpv; lam += gpv;
-      sb += (gp - gq) * gpv; se += (s - ub) * gpv; r2 += r * r;
+      sb += (gp - gq) * gpv; se += (s - ub) * gpv; r2 += om * r * r;
     }
-    if (e < K) {
-      const float ln = a.lamn[p * D + j];
+    if (e < K) {   // forward kernel of step e
       const float uf = -1.0f * (be * gp + (1.0f - be) * gq);
-      const float fk = z - ee * uf - ee * s;
-      const float nsig = (znv[j] - fk) * (0.5f / ee);
-      a_s -= ee * ln; a_gp += ee * be * ln; a_gq += ee * (1.0f - be) * ln; lam += ln - a.gE[p * D + j];
-      sb2 += (gp - gq) * ln; se2 += (nsig - uf - s) * ln;
+      float df = (znv[j] - z) + ee * (uf + s);            // z_{e+1} - (z - ee uf - ee s), same ordering
+      if (!bptt) {
+        // the weights omega_p sum to zero and |df|^2 / (4 eps^2) is ~1e5 per particle: the float32 difference above loses
+        // the digits that survive the cancellation.  z_{e+1} = mean + sigma eps_e, so redraw eps_e (mcd_cais.py:66-67)
+        const int H = (D + 1) / 2, jj = j < H ? j : j - H;
+        const uint32_t* gk = a.gktab + ((int64_t)e * a.n + a.base + p) * 2;
+        uint32_t y0 = jj, y1 = (H + jj < D) ? H + jj : 0;
+        threefry2x32(gk[0], gk[1], y0, y1);
+        df = a.sched[8 * e + 2] * bits_to_normal(j < H ? y0 : y1);
+      }
+      const float nsig = df * (0.5f / ee);
+      // cotangent of the kernel's mean: lambda_{e+1} when z_{e+1} = mean + noise carries the gradient on; with z detached
+      // the density log N(z_{e+1}; mean, sigma) itself: d loss / d mean = +df / sigma^2
+      const float ln = bptt ? a.lamn[p * D + j] : om * nsig;
+      a_s -= ee * ln; a_gp += ee * be * ln; a_gq += ee * (1.0f - be) * ln;
+      if (bptt) lam += ln - a.gE[p * D + j];
+      sb2 += (gp - gq) * ln;
+      se2 += bptt ? (nsig - uf - s) * ln : (-uf - s) * ln + om * df * df * (0.25f / (ee * ee));
     }
     if (e == K) lam -= om * graw;
     if (e == 0) lam += om * gq;
-    a.gmu_acc[p * D + j] += a_gq * qiv;
-    a.glam_acc[p * D + j] += a_gq * (-2.0f * gq);
+    a.gmu_acc[p * D + j] += a_gq * mq * qiv;
+    a.glam_acc[p * D + j] += a_gq * mq * (-2.0f * gqraw) + ((!bptt && e == 0) ? -om : 0.f);   // z detached: d log q(z_0(theta)) / d logdiag = -1
     lam -= a_gq * qiv;
     gf += a_s * o;
-    a.gprev[p * D + j] = gpv;
     a.dO[p * D + j] = a_s * fac;
     a.DObig[((int64_t)e * a.n + a.base + p) * D + j] = a_s * fac;
-    a.v[p * D + j] = m * a_gp;
-    a.lam_part[p * D + j] = lam;
+    if (bptt) {
+      a.gprev[p * D + j] = gpv;
+      a.v[p * D + j] = m * a_gp;
+      a.lam_part[p * D + j] = lam;
+    }
   }
   const float tsb = block_sum_256(sb, sh), tse = block_sum_256(se, sh), tr2 = block_sum_256(r2, sh);
   const float tsb2 = block_sum_256(sb2, sh), tse2 = block_sum_256(se2, sh), tgf = block_sum_256(gf, sh);
@@ -788,7 +817,6 @@ struct LgcpAdjRedArgs {
   float* geps_hi;
   float* gfac_e;         // [K+1]
   int K, slots;
-  float omega;
 };
 
 __global__ __launch_bounds__(64) void lgcp_adj_reduce_kernel(LgcpAdjRedArgs a) {
@@ -805,7 +833,7 @@ __global__ __launch_bounds__(64) void lgcp_adj_reduce_kernel(LgcpAdjRedArgs a) {
     const float pe = e > 0 ? a.sched[8 * (e - 1) + 1] : 1.f, ee = e < a.K ? a.sched[8 * e + 1] : 1.f;
     const float inv2e = 0.5f / pe;
     a.gbeta_lo[e] = e > 0 ? pe * t[0] : 0.f;
-    a.geps_lo[e] = e > 0 ? t[1] - a.omega * t[2] * inv2e * inv2e : 0.f;
+    a.geps_lo[e] = e > 0 ? t[1] - t[2] * inv2e * inv2e : 0.f;            // t[2] = sum omega r^2
     a.gbeta_hi[e] = e < a.K ? ee * t[3] : 0.f;
     a.geps_hi[e] = e < a.K ? t[4] : 0.f;
     a.gfac_e[e] = t[5];
@@ -1035,8 +1063,8 @@ static LgcpGradWs lgcp_grad_ws(const cmcd_desc& d, int64_t n) {
 int64_t lgcp_grad_workspace_floats(const cmcd_desc& d, int64_t n) { return lgcp_grad_ws(d, n).total; }
 
 int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, int64_t n, const float* params,
-              int64_t n_params, const float* tc, float* ws, const float* traj, float* gws, float omega, float* grad,
-              void* stream_) {
+              int64_t n_params, const float* tc, float* ws, const float* traj, float* gws, float omega,
+              const float* omega_vec, bool bptt, float* grad, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const int D = d.dim, E = d.emb_dim, IN = D + E, K = d.nbridges;
   const LgcpWs w = lgcp_ws(d, n, sw.total_floats);
@@ -1130,6 +1158,7 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
       aa.gmu_acc = gws + g.gmu_acc; aa.glam_acc = gws + g.glam_acc; aa.part = gws + g.adjpart;
       aa.DObig = gws + g.DO; aa.lay = lay; aa.n = n; aa.base = base;
       aa.M = M; aa.D = D; aa.K = K; aa.e = e; aa.grad_clipping = d.grad_clipping; aa.omega = omega;
+      aa.omega_vec = omega_vec; aa.gktab = reinterpret_cast<const uint32_t*>(ws + w.gktab); aa.bptt = bptt ? 1 : 0; aa.var_mode = d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0;
       hipLaunchKernelGGL(lgcp_adj_step_kernel, dim3((D + 255) / 256, M), dim3(256), 0, stream, aa);
       // ---- net backward: d u2 = d o W3^T
       gm.Kdim = D;
@@ -1151,6 +1180,10 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
       ab.S = gws + g.S + (int64_t)e * IN; ab.S2 = gws + g.S2 + (int64_t)e * IN; ab.mode = 1;
       hipLaunchKernelGGL(lgcp_actb_kernel, dim3((IN + 255) / 256, M), dim3(256), 0, stream, ab);
       // d x = d u1[:D] + d a1 W1[:D]^T   |   v K^-1
+      if (!bptt) {   // z detached: no lambda, no Hessian product; this evaluation's buffers are free after actb
+        if (hipEventRecord(ev_bwd[e & 1], stream) != hipSuccess) return CMCD_ERR_HIP;
+        continue;
+      }
       gm.Kdim = IN; gm.Kdim1 = D;                       // two independent products, one launch
       gm.seg[0] = GemmSeg{gws + g.da1, gws + g.wt1, gws + g.dxf, D, IN, IN, D};
       gm.seg[1] = GemmSeg{gws + g.v, kinv, gws + g.hv, D, D, D, D};
@@ -1184,7 +1217,7 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
   {
     const int slots = (int)(n * ((D + 255) / 256));
     LgcpAdjRedArgs ra{gws + g.adjpart, ws + sw.sched, gws + g.gb_lo, gws + g.ge_lo, gws + g.gb_hi, gws + g.ge_hi, gws + g.gfac,
-                      K, slots, omega};
+                      K, slots};
     hipLaunchKernelGGL(lgcp_adj_reduce_kernel, dim3(K + 1), dim3(64), 0, stream, ra);
     hipLaunchKernelGGL(lgcp_adj_combine_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, gws + g.gb_lo, gws + g.gb_hi,
                        gws + g.ge_lo, gws + g.ge_hi, gws + g.gbeta, gws + g.geps, K);

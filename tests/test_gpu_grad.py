@@ -337,6 +337,49 @@ def test_lgcp_reparameterised_gradient_matches_autograd(hip_lib, n, K, clip):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("n,K,clip", [(6, 3, False), (27, 2, True)])
+def test_lgcp_vargrad_matches_autograd(hip_lib, n, K, clip):
+    """d = 1600 with MCD_CAIS_var_sn: the reverse launch sequence with z detached (no lambda recursion, no Hessian
+    product), per-particle weights from the statistics — against autograd of var(losses) through the float64
+    restatement with the reference's stop_gradient placement.  n = 27 spans two passes; clip = 1e2 on both scores."""
+    from helpers import lgcp_counts_fixture
+    counts = lgcp_counts_fixture()
+    b = synthetic.build("lgcp_n20_k128", device="cuda", lgcp_counts=counts, nbridges=K, N=n, grad_clipping=clip,
+                        init_eps=2e-3, boundmode="MCD_CAIS_var_sn")
+    assert b["params_fixed"][2] == "MCD_CAIS_var_sn"
+    seeds = synthetic.parity_seeds(n)
+    grad, (losses, z) = mcdbm.compute_log_var_grad(torch.from_numpy(seeds).cuda(), b["params_flat"], b["unflatten"],
+                                                   b["params_fixed"], b["target"], eps_schedule=b["eps_schedule"],
+                                                   grad_clipping=b["grad_clipping"])
+    torch.cuda.synchronize()
+    dim, _, mode, spec = b["params_fixed"]
+    p = synthetic.oracle_params(b["unflatten"], b["params_flat"])
+    val, l_ref, z_ref, g = ot.bound_and_grad(seeds, p, dim, K, mode, spec.arch, ot.make_logp_lgcp(counts),
+                                             b["cfg"]["eps_schedule"], clip)
+    np.testing.assert_allclose(losses.cpu().numpy(), l_ref, rtol=2e-4, atol=0.5)
+    un = b["unflatten"]
+    gh = grad.double().cpu().numpy()
+
+    def leaf(*path):
+        off, shape = un.layout[(0,) + path] if (0,) + path in un.layout else un.layout[(1,) + path]
+        return gh[off:off + max(1, int(np.prod(shape)))].reshape(shape)
+    (w1, b1), (w2, b2), (w3, b3) = [(("sn", "nn", i, 0), ("sn", "nn", i, 1)) for i in range(3)]
+    checks = {"vd.mean": (leaf("vd", "mean"), g["vd"]["mean"]), "vd.logdiag": (leaf("vd", "logdiag"), g["vd"]["logdiag"]),
+              "eps": (leaf("eps"), g["eps"]), "mgridref_y": (leaf("mgridref_y"), g["mgridref_y"]),
+              "W1": (leaf(*w1), g["sn"]["W1"]), "b1": (leaf(*b1), g["sn"]["b1"]), "W2": (leaf(*w2), g["sn"]["W2"]),
+              "b2": (leaf(*b2), g["sn"]["b2"]), "W3": (leaf(*w3), g["sn"]["W3"]), "b3": (leaf(*b3), g["sn"]["b3"]),
+              "emb": (leaf("sn", "emb"), g["sn"]["emb"]), "factor_sn": (leaf("sn", "factor_sn"), g["sn"]["factor_sn"])}
+    worst = {}
+    for name, (a, r) in checks.items():
+        r = np.asarray(r, np.float64).reshape(a.shape)
+        scale = max(np.abs(r).max(), 1e-12)
+        worst[name] = (float(np.abs(a - r).max() / scale), float(scale))
+    print({k: "%.1e (|ref| %.1e)" % v for k, v in worst.items()})
+    # float32 losses of size ~300 enter the weights 2 (l_p - mean) / n: the relative error of a weight is ~1e-4
+    bad = {k: v for k, v in worst.items() if v[0] > 5e-3 and v[1] > 1e-9}
+    assert not bad, bad
+
+
 ULA_CASES = [
     ("many_gmm_n2000_k256_dds", 70, dict(nbridges=6, init_sigma=15.0, init_eps=0.2)),
     ("gmm_n300_k8", 96, dict()),
