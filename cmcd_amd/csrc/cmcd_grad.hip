@@ -392,8 +392,8 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
 #pragma unroll
           for (int j = 0; j < D; ++j) {
             const float ub = -1.0f * (pb * gp[j] + (1.0f - pb) * gq[j]);
-            const float bk = z[j] - pe * ub + pe * sn[j];
-            const float r = zp[j] - bk;
+            // z_{e-1} - (z - pe ub + pe s) with the O(1) states subtracted first (exact in float32: one step apart)
+            const float r = (zp[j] - z[j]) + pe * (ub - sn[j]);
             gprev[j] = -om * r * inv2e;
             cot[j] += pe * gprev[j];
             a_gp[j] += pe * pb * gprev[j];
@@ -413,8 +413,7 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
 #pragma unroll
           for (int j = 0; j < D; ++j) {
             const float uf = -1.0f * (be * gp[j] + (1.0f - be) * gq[j]);
-            const float fk = z[j] - ee * uf - fsn * ee * sn[j];
-            const float nsig = (znext[j] - fk) * inv2e;        // n_e / sigma_e
+            const float nsig = ((znext[j] - z[j]) + ee * (uf + fsn * sn[j])) * inv2e;        // n_e / sigma_e
             cot[j] -= fsn * ee * lamn[j];
             a_gp[j] += ee * be * lamn[j];
             a_gq[j] += ee * (1.0f - be) * lamn[j];
@@ -458,8 +457,7 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
 #pragma unroll
         for (int j = 0; j < D; ++j) {
           const float ub = -1.0f * (pbeta * gp[j] + (1.0f - pbeta) * gq[j]);
-          const float bk = z[j] - peps * ub + peps * sn[j];
-          const float db = zp[j] - bk;
+          const float db = (zp[j] - z[j]) + peps * (ub - sn[j]);
           cot[j] += 0.5f * db;
           sb += db * (gp[j] - gq[j]);
           se += db * (sn[j] - ub);
@@ -519,7 +517,7 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
           const float uf = -1.0f * (beta * gp[j] + (1.0f - beta) * gq[j]);
           const float fk = z[j] - eps * uf - eps * sn[j];
           zn[j] = ITEM ? znext[j] : fk + sig * nz[j];
-          const float df = zn[j] - fk;
+          const float df = ITEM ? (znext[j] - z[j]) + eps * (uf + sn[j]) : sig * nz[j];
           cot[j] += 0.5f * df;
           sb += df * (gp[j] - gq[j]);
           se += df * (uf + sn[j]);
@@ -985,8 +983,7 @@ __global__ __launch_bounds__(256) void bptt_jac_kernel(JacArgs a) {
 #pragma unroll
       for (int j = 0; j < D; ++j) {
         const float ub = -1.0f * (pb * gp[j] + (1.0f - pb) * gq[j]);
-        const float bk = z[j] - pe * ub + pe * sn[j];
-        gprev[j] = -om * (zp[j] - bk) * inv2e;
+        gprev[j] = -om * ((zp[j] - z[j]) + pe * (ub - sn[j])) * inv2e;
       }
 #pragma unroll
       for (int j = 0; j < D; ++j) {
@@ -1154,8 +1151,7 @@ __global__ __launch_bounds__(256) void ula_grad_kernel(UlaGradArgs a) {
 #pragma unroll
       for (int j = 0; j < D; ++j) {
         const float uf = -1.0f * (be * gp[j] + (1.0f - be) * gq[j]);
-        const float fk = z[j] - ee * uf;
-        const float nsig = (znext[j] - fk) * inv2e;
+        const float nsig = ((znext[j] - z[j]) + ee * uf) * inv2e;
         a_gp[j] += ee * be * lamn[j];
         a_gq[j] += ee * (1.0f - be) * lamn[j];
         lam[j] += lamn[j] - gE[j];
