@@ -69,7 +69,7 @@ int ula_grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& 
 // cmcd_grad.hip: the particle-independent tails of a geffner net's gradient from the S / S2 / beta / eps tables
 int launch_geffner_tails(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, const float* params,
                          const float* gtab, int64_t o_S, int64_t o_S2, int64_t o_gbeta, int64_t o_geps, int HP,
-                         float* grad, void* stream);
+                         float* grad, void* stream, bool with_net = true);
 
 // mean-field VI on lgcp (cmcd_lgcp.hip) and the statistics merge launcher (cmcd_kernels.hip), used by cmcd_mfvi.hip
 int64_t lgcp_mfvi_workspace_floats(int D, int64_t n, bool with_grad);

@@ -1652,7 +1652,7 @@ int ula_grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& 
 
 int launch_geffner_tails(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, const float* params,
                          const float* gtab, int64_t o_S, int64_t o_S2, int64_t o_gbeta, int64_t o_geps, int HP,
-                         float* grad, void* stream_) {
+                         float* grad, void* stream_, bool with_net) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TailArgs ta{};
   ta.params = params; ta.gtab = gtab; ta.grad = grad; ta.lay = lay; ta.w = w;
@@ -1660,7 +1660,7 @@ int launch_geffner_tails(const cmcd_desc& d, const cmcd_layout& lay, const WsLay
   ta.K = d.nbridges; ta.D = d.dim; ta.E = d.emb_dim; ta.IN = d.dim + d.emb_dim; ta.HP = HP; ta.arch = d.arch;
   ta.eps_schedule = d.eps_schedule; ta.ngrid = d.ngrid;
   hipLaunchKernelGGL(grad_sched_tail_kernel, dim3(1), dim3(256), 0, stream, ta);
-  hipLaunchKernelGGL(grad_geffner_tail_kernel, dim3(256), dim3(256), 0, stream, ta);
+  if (with_net) hipLaunchKernelGGL(grad_geffner_tail_kernel, dim3(256), dim3(256), 0, stream, ta);
   return hipGetLastError() == hipSuccess ? CMCD_OK : CMCD_ERR_HIP;
 }
 

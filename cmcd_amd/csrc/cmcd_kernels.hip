@@ -813,8 +813,6 @@ static int check_desc(const cmcd_desc* d) {
     return fail(CMCD_ERR_UNSUPPORTED, "Mode not implemented.%s");
   if (d->mode == CMCD_MODE_ULA && d->arch != CMCD_ARCH_DDS)
     return fail(CMCD_ERR_BAD_ARG, "MCD_ULA has no network: pass arch = CMCD_ARCH_DDS as the placeholder%s");
-  if (d->target == CMCD_TARGET_LGCP && d->mode > CMCD_MODE_CAIS_VAR_SN)
-    return fail(CMCD_ERR_UNSUPPORTED, "lgcp runs the CAIS modes only%s");
   if (d->arch != CMCD_ARCH_DDS && d->arch != CMCD_ARCH_GEFFNER)
     return fail(CMCD_ERR_UNSUPPORTED, "nn_arch not implemented%s");
   if (d->nbridges < 1) return fail(CMCD_ERR_BAD_ARG, "nbridges must be >= 1%s");
@@ -824,7 +822,7 @@ static int check_desc(const cmcd_desc* d) {
   int HP;
   if (!hidden_width(*d, HP)) return fail(CMCD_ERR_BAD_ARG, "bad emb_dim%s");
   if (d->target == CMCD_TARGET_LGCP) {
-    if (d->arch != CMCD_ARCH_GEFFNER || d->dim < 4 || d->dim > 4096)
+    if ((d->arch != CMCD_ARCH_GEFFNER && d->mode != CMCD_MODE_ULA) || d->dim < 4 || d->dim > 4096)
       return fail(CMCD_ERR_UNSUPPORTED, "lgcp runs with the geffner net only%s");
     return CMCD_OK;
   }
@@ -916,10 +914,13 @@ static int forward_impl(const cmcd_desc* desc, const cmcd_layout* lay, const int
       return fail(CMCD_ERR_WORKSPACE, "workspace too small or not 16-byte aligned (need %s%lld bytes)", "", need);
     hipStream_t st = static_cast<hipStream_t>(stream_);
     float* wsf = static_cast<float*>(workspace);
-    SchedArgs sa{params, wsf, *lay, lw, (int32_t)K, d.ngrid, d.eps_schedule, -1, -1};
+    // the overdamped baselines: constant eps, no clipping (the reference's dispatcher passes neither, mcd_utils.py:35-58)
+    cmcd_desc dl = d;
+    if (d.mode == CMCD_MODE_ULA || d.mode == CMCD_MODE_ULA_SN) { dl.eps_schedule = CMCD_EPS_CONST; dl.grad_clipping = 0; }
+    SchedArgs sa{params, wsf, *lay, lw, (int32_t)K, d.ngrid, dl.eps_schedule, -1, -1};
     hipLaunchKernelGGL(prep_sched_kernel, dim3(1), dim3(256), 0, st, sa);
     double* partials = nullptr;
-    rc = lgcp_forward(d, *lay, lw, seeds, n, params, target_consts, wsf, out_loss, out_z, &partials, traj, stream_);
+    rc = lgcp_forward(dl, *lay, lw, seeds, n, params, target_consts, wsf, out_loss, out_z, &partials, traj, stream_);
     if (rc != CMCD_OK) return fail(rc, "lgcp launch sequence failed%s");
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, partials, (int32_t)n, out_stats);
     CMCD_HIP_CHECK(hipGetLastError());
@@ -1013,8 +1014,8 @@ int cmcd_bound_forward(const cmcd_desc* desc, const cmcd_layout* lay, const int3
 int64_t cmcd_bound_grad_workspace_bytes(const cmcd_desc* desc, int64_t n) {
   if (check_desc(desc) != CMCD_OK || n < 1) return 0;
   if (desc->target == CMCD_TARGET_LGCP) {
-    if (desc->mode != CMCD_MODE_CAIS_SN) {
-      fail(CMCD_ERR_UNSUPPORTED, "the reparameterised gradient exists for MCD_CAIS_sn only%s");
+    if (desc->mode == CMCD_MODE_CAIS_VAR_SN) {
+      fail(CMCD_ERR_UNSUPPORTED, "MCD_CAIS_var_sn: cmcd_grad_workspace_bytes / cmcd_bound_var_forward / cmcd_bound_var_grad_kept%s");
       return 0;
     }
     WsLayout lw;
@@ -1046,8 +1047,7 @@ int cmcd_bound_grad(const cmcd_desc* desc, const cmcd_layout* lay, const int32_t
   int rc = check_desc(desc);
   if (rc != CMCD_OK) return rc;
   if (!grad) return fail(CMCD_ERR_BAD_ARG, "null pointer argument%s");
-  if (desc->mode != CMCD_MODE_CAIS_SN &&
-      !((desc->mode == CMCD_MODE_ULA_SN || desc->mode == CMCD_MODE_ULA) && desc->target != CMCD_TARGET_LGCP))
+  if (desc->mode != CMCD_MODE_CAIS_SN && desc->mode != CMCD_MODE_ULA_SN && desc->mode != CMCD_MODE_ULA)
     return fail(CMCD_ERR_UNSUPPORTED, "the reparameterised gradient exists for MCD_CAIS_sn and MCD_ULA_sn (MCD_CAIS_var_sn: cmcd_bound_var_grad)%s");
   // MCD_ULA_sn: the reference's dispatcher passes neither eps_schedule nor grad_clipping (mcd_utils.py:35-58)
   cmcd_desc dd = *desc;

@@ -82,6 +82,8 @@ struct StepEpi {         // evaluation i at z_i: closes step i-1, opens step i (
   int64_t n_total, base;
   cmcd_layout lay;
   int D, K, i, var_mode, grad_clipping;
+  int ula;                   // 0: CAIS; 1: MCD_ULA (no network at all: the K^-1 product is this launch's own GEMM);
+                             // 2: MCD_ULA_sn (network in the backward kernel only)     mcd_over_orig.py:6-65
 };
 
 struct GemmArgs {
@@ -116,6 +118,8 @@ __device__ __forceinline__ void lgcp_key_advance(uint32_t& k0, uint32_t& k1, uin
 // launch's output (visible after the arrival protocol), everything else is from earlier launches
 __device__ __forceinline__ void lgcp_step_tile(const StepEpi& a, const float* sn_slabs, int M, int n0, int cb, int wv,
                                                int lane) {
+  const bool no_net = a.ula == 1;               // then sn_slabs are the K^-1 slabs of THIS launch (agent-scope reads)
+  const float fsn = a.ula ? 0.f : 1.f;          // the overdamped baselines have no network in the forward kernel
   const int D = a.D, H = (D + 1) / 2, i = a.i;
   const float* counts = a.tc + (int64_t)D * D;
   const float mu0 = a.tc[(int64_t)D * D + D], pa = a.tc[(int64_t)D * D + D + 1];
@@ -126,10 +130,10 @@ __device__ __forceinline__ void lgcp_step_tile(const StepEpi& a, const float* sn
   const float pbeta = sp[0], peps = sp[1], pcst = sp[3], pinv2s2 = sp[4];
   const float* sc = a.sched + 8 * (last ? a.K - 1 : i);
   const float beta = sc[0], eps = sc[1], sig = sc[2], cst = sc[3], inv2s2 = sc[4];
-  const float fac = a.factor[0];
+  const float fac = no_net ? 0.f : a.factor[0];
   const int e = n0 + lane;
   const bool ecol = e < D;
-  const float cnt = ecol ? counts[e] : 0.f, b3 = ecol ? a.b3[e] : 0.f;
+  const float cnt = ecol ? counts[e] : 0.f, b3 = (ecol && !no_net) ? a.b3[e] : 0.f;
   const float mean = ecol ? a.params[a.lay.vd_mean + e] : 0.f;
   const float sd = ecol ? expf(a.params[a.lay.vd_logdiag + e]) : 1.f;
   const uint32_t* gk = a.gkey + (i & 1) * 2 * kMP;
@@ -141,10 +145,11 @@ __device__ __forceinline__ void lgcp_step_tile(const StepEpi& a, const float* sn
       float kr = 0.f, s = b3;
 #pragma unroll
       for (int ks = 0; ks < kSplit; ++ks) {            // fixed-order sums of the split-K slabs
-        kr += a.kr[((int64_t)ks * kMP + m) * D + e];
-        s += __hip_atomic_load(sn_slabs + ((int64_t)ks * kMP + m) * D + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float own = __hip_atomic_load(sn_slabs + ((int64_t)ks * kMP + m) * D + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        kr += no_net ? own : a.kr[((int64_t)ks * kMP + m) * D + e];
+        s += no_net ? 0.f : own;
       }
-      s *= fac;                                        // factor_sn (u2 W3 + b3)           nn.py:70
+      s = no_net ? 0.f : s * fac;                      // factor_sn (u2 W3 + b3)           nn.py:70
       const float ez = expf(z);
       float gp = -kr + cnt - pa * ez;                  // grad log p      model_handler.py:386-396
       float gq = -(z - mean) / (sd * sd);
@@ -165,7 +170,7 @@ __device__ __forceinline__ void lgcp_step_tile(const StepEpi& a, const float* sn
         uint32_t y0 = j, y1 = (H + j < D) ? H + j : 0;
         threefry2x32(gk[2 * m], gk[2 * m + 1], y0, y1);
         const float uf = -1.0f * (beta * gp + (1.0f - beta) * gq);
-        const float fk = z - eps * uf - eps * s;
+        const float fk = z - eps * uf - fsn * eps * s;
         const float zn = fk + sig * bits_to_normal(e < H ? y0 : y1);
         const float df = zn - fk;
         fk_acc = -(df * df) * inv2s2 - cst;
@@ -493,7 +498,7 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const int D = d.dim, E = d.emb_dim, IN = D + E, K = d.nbridges;
   const LgcpWs w = lgcp_ws(d, n, sw.total_floats);
-  {
+  if (d.mode != CMCD_MODE_ULA) {   // MCD_ULA has no network leaves at all
     LgcpPrepArgs pa{params, ws + w.bias1, lay, D, E, K, IN};
     hipLaunchKernelGGL(lgcp_prep_kernel, dim3((IN + 255) / 256, K + 1), dim3(256), 0, stream, pa);
   }
@@ -532,15 +537,27 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
     se.wslot = ws + w.slots; se.fkslot = se.wslot + cbD * kMP; se.lpslot = se.fkslot + cbD * kMP;
     se.out_z = out_z + base * D; se.traj = traj; se.n_total = n; se.base = base; se.lay = lay;
     se.D = D; se.K = K; se.var_mode = d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0; se.grad_clipping = d.grad_clipping;
+    const int ula = d.mode == CMCD_MODE_ULA ? 1 : (d.mode == CMCD_MODE_ULA_SN ? 2 : 0);
+    se.ula = ula;
     for (int i = 0; i <= K; ++i) {
-      const int ie = i < K ? i : K - 1;
+      se.i = i;
+      if (ula == 1) {   // MCD_ULA: one launch per evaluation, [x - mu0] Kinv with the state update as its consumer
+        g.Kdim = D; g.Kdim1 = 0;
+        g.seg[0] = GemmSeg{ws + w.x, kinv, ws + w.kr, D, D, D, D, mu0};
+        g.nblk0 = cbD; g.epi_seg = -1;
+        hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_STEP>, dim3(cbD, kSplit), gblock_step, gemm_lds, stream, g);
+        continue;
+      }
+      // CAIS: s(z_i, i) serves both kernels; MCD_ULA_sn: s(z_i, i - 1) serves the backward kernel only
+      const int it = ula == 2 ? (i > 0 ? i - 1 : 0) : i;
+      const int ie = it < K ? it : K - 1;
       // A: [x - mu0] Kinv -> kr slabs (summed by the state update two launches on)
       //    x W1[:D] -> pre1 slabs -> u1 = [x; emb_i] + softplus(pre1 + bias1_i)            (fused consumer)
       g.Kdim = D; g.Kdim1 = 0;
       g.seg[0] = GemmSeg{ws + w.x, kinv, ws + w.kr, D, D, D, D, mu0};
       g.seg[1] = GemmSeg{ws + w.x, params + lay.g_w1, ws + w.slab1, IN, D, IN, IN};
       g.nblk0 = cbD; g.epi_seg = 1;
-      g.act.mode = 1; g.act.bias = ws + w.bias1 + (int64_t)i * IN; g.act.emb = params + lay.g_emb + (int64_t)ie * E;
+      g.act.mode = 1; g.act.bias = ws + w.bias1 + (int64_t)it * IN; g.act.emb = params + lay.g_emb + (int64_t)ie * E;
       g.act.sum_out = ws + w.pre1; g.act.u_prev = nullptr; g.act.u_out = ws + w.u1;
       hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_ACT>, dim3(cbD + cbIN, kSplit), gblock, gemm_lds, stream, g);
       // B: u1 W2 -> pre2 slabs -> u2 = u1 + softplus(pre2 + b2)
@@ -553,7 +570,6 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
       // C: u2 W3 -> sn slabs -> state update of evaluation i on the block's columns
       g.seg[0] = GemmSeg{ws + w.u2, params + lay.g_w3, ws + w.sn, D, IN, D, D};
       g.nblk0 = cbD;
-      se.i = i;
       hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_STEP>, dim3(cbD, kSplit), gblock_step, gemm_lds, stream, g);
     }
     LgcpFinalArgs fa{ws + w.w, se.wslot, se.lpslot, tc, out_loss + base, partials + base * CMCD_NSTATS, M, D, cbD};
@@ -716,6 +732,7 @@ struct LgcpAdjArgs {
   float omega;               // weight of every particle's loss (reparameterised gradient of the mean)
   const float* omega_vec;    // [n] VarGrad: weight of particle p's LOG-WEIGHT (cmcd_vargrad_weights), or nullptr
   const uint32_t* gktab;     // [K][n][2] noise keys of the forward pass (VarGrad: z_{e+1} - mean = sigma eps_e, exactly)
+  int ula;                   // 0: CAIS; 1: MCD_ULA (no network); 2: MCD_ULA_sn (network in the backward kernel only)
   int bptt;                  // 1: gradient through the trajectory (lambda recursion); 0: z detached (mcd_cais_var.py:59,79)
   int var_mode;              // MCD_CAIS_var_sn: clip at 1e2 and clip grad log q too (mcd_cais_var.py:29-36)
 };
@@ -731,7 +748,9 @@ __global__ __launch_bounds__(256) void lgcp_adj_step_kernel(LgcpAdjArgs a) {
   const float om = a.omega_vec ? -a.omega_vec[a.base + p] : a.omega;      // weight of this particle's loss = -w
   const float pb = e > 0 ? a.sched[8 * (e - 1)] : 0.f, pe = e > 0 ? a.sched[8 * (e - 1) + 1] : 1.f;
   const float be = e < K ? a.sched[8 * e] : 0.f, ee = e < K ? a.sched[8 * e + 1] : 1.f;
-  const float fac = a.factor[0];
+  const bool no_net = a.ula == 1;
+  const float fsn = a.ula ? 0.f : 1.f;
+  const float fac = no_net ? 0.f : a.factor[0];
   const float* ze = a.traj + ((int64_t)e * a.n + a.base + p) * D;
   const float* zpv = a.traj + ((int64_t)(e > 0 ? e - 1 : 0) * a.n + a.base + p) * D;
   const float* znv = a.traj + ((int64_t)(e < K ? e + 1 : K) * a.n + a.base + p) * D;
@@ -739,11 +758,11 @@ __global__ __launch_bounds__(256) void lgcp_adj_step_kernel(LgcpAdjArgs a) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;     // one element per thread: a single memory round trip
   if (j < D) {
     const float z = ze[j];
-    float kr = 0.f, o = a.b3[j];
+    float kr = 0.f, o = no_net ? 0.f : a.b3[j];
 #pragma unroll
     for (int ks = 0; ks < kSplit; ++ks) {
       kr += a.kr[((int64_t)ks * kMP + p) * D + j];
-      o += a.sn[((int64_t)ks * kMP + p) * D + j];
+      o += no_net ? 0.f : a.sn[((int64_t)ks * kMP + p) * D + j];
     }
     const float s = o * fac;
     const float graw = -kr + counts[j] - pa * expf(z);
@@ -766,7 +785,7 @@ __global__ __launch_bounds__(256) void lgcp_adj_step_kernel(LgcpAdjArgs a) {
     }
     if (e < K) {   // forward kernel of step e
       const float uf = -1.0f * (be * gp + (1.0f - be) * gq);
-      float df = (znv[j] - z) + ee * (uf + s);            // z_{e+1} - (z - ee uf - ee s), same ordering
+      float df = (znv[j] - z) + ee * (uf + fsn * s);      // z_{e+1} - (z - ee uf - ee s), same ordering
       if (!bptt) {
         // the weights omega_p sum to zero and |df|^2 / (4 eps^2) is ~1e5 per particle: the float32 difference above loses
         // the digits that survive the cancellation.  z_{e+1} = mean + sigma eps_e, so redraw eps_e (mcd_cais.py:66-67)
@@ -780,10 +799,10 @@ __global__ __launch_bounds__(256) void lgcp_adj_step_kernel(LgcpAdjArgs a) {
       // cotangent of the kernel's mean: lambda_{e+1} when z_{e+1} = mean + noise carries the gradient on; with z detached
       // the density log N(z_{e+1}; mean, sigma) itself: d loss / d mean = +df / sigma^2
       const float ln = bptt ? a.lamn[p * D + j] : om * nsig;
-      a_s -= ee * ln; a_gp += ee * be * ln; a_gq += ee * (1.0f - be) * ln;
+      a_s -= fsn * ee * ln; a_gp += ee * be * ln; a_gq += ee * (1.0f - be) * ln;
       if (bptt) lam += ln - a.gE[p * D + j];
       sb2 += (gp - gq) * ln;
-      se2 += bptt ? (nsig - uf - s) * ln : (-uf - s) * ln + om * df * df * (0.25f / (ee * ee));
+      se2 += bptt ? (nsig - uf - fsn * s) * ln : (-uf - fsn * s) * ln + om * df * df * (0.25f / (ee * ee));
     }
     if (e == K) lam -= om * graw;
     if (e == 0) lam += om * gq;
@@ -791,8 +810,10 @@ __global__ __launch_bounds__(256) void lgcp_adj_step_kernel(LgcpAdjArgs a) {
     a.glam_acc[p * D + j] += a_gq * mq * (-2.0f * gqraw) + ((!bptt && e == 0) ? -om : 0.f);   // z detached: d log q(z_0(theta)) / d logdiag = -1
     lam -= a_gq * qiv;
     gf += a_s * o;
-    a.dO[p * D + j] = a_s * fac;
-    a.DObig[((int64_t)e * a.n + a.base + p) * D + j] = a_s * fac;
+    if (!no_net) {
+      a.dO[p * D + j] = a_s * fac;
+      a.DObig[((int64_t)e * a.n + a.base + p) * D + j] = a_s * fac;
+    }
     if (bptt) {
       a.gprev[p * D + j] = gpv;
       a.v[p * D + j] = m * a_gp;
@@ -900,6 +921,7 @@ struct LgcpLamArgs {
   int64_t n, base;
   int M, D, IN, e;
   float omega;
+  int no_net;              // MCD_ULA: d x = 0 (no network to go back through)
 };
 
 __global__ void lgcp_lam_finish_kernel(LgcpLamArgs a) {
@@ -908,10 +930,10 @@ __global__ void lgcp_lam_finish_kernel(LgcpLamArgs a) {
   const int m = idx / a.D, j = idx - m * a.D, D = a.D;
   const float pa = a.tc[(int64_t)D * D + D + 1];
   const float z = a.traj[((int64_t)a.e * a.n + a.base + m) * D + j];
-  float dx = a.du1[m * a.IN + j], hv = 0.f;     // residual path: d x_j += d u1_j
+  float dx = a.no_net ? 0.f : a.du1[m * a.IN + j], hv = 0.f;     // residual path: d x_j += d u1_j
 #pragma unroll
   for (int ks = 0; ks < kSplit; ++ks) {
-    dx += a.dxf[((int64_t)ks * kMP + m) * D + j];
+    dx += a.no_net ? 0.f : a.dxf[((int64_t)ks * kMP + m) * D + j];
     hv += a.hv[((int64_t)ks * kMP + m) * D + j];
   }
   const float lam = a.lam_part[idx] + dx - hv - pa * expf(z) * a.v[idx];   // H_p v = -K^-1 v - a e^z v
@@ -1071,8 +1093,10 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
   const LgcpGradWs g = lgcp_grad_ws(d, n);
   if (hipMemsetAsync(grad, 0, sizeof(float) * n_params, stream) != hipSuccess) return CMCD_ERR_HIP;
   if (hipMemsetAsync(gws + g.zero_lo, 0, sizeof(float) * (g.zero_hi - g.zero_lo), stream) != hipSuccess) return CMCD_ERR_HIP;
+  const int ula = d.mode == CMCD_MODE_ULA ? 1 : (d.mode == CMCD_MODE_ULA_SN ? 2 : 0);
+  const bool net = ula != 1;
   // transposed weight copies: the backward GEMMs are then the forward kernel on W^T
-  {
+  if (net) {
     const dim3 tb(32, 8);
     hipLaunchKernelGGL(lgcp_transpose_kernel, dim3((IN + 31) / 32, (IN + 31) / 32), tb, 0, stream, params + lay.g_w1,
                        gws + g.wt1, IN, IN, IN, IN);
@@ -1114,16 +1138,22 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
     int* side_counters = reinterpret_cast<int*>(gws + g.counters);
     auto forward_at = [&](int e, hipStream_t st) {
       const LgcpFwdSet& f = g.fs[e & 1];
-      const int ie = e < K ? e : K - 1;
+      const int er = ula == 2 ? (e > 0 ? e - 1 : 0) : e;       // MCD_ULA_sn: s(z_e, e - 1)
+      const int ie = er < K ? er : K - 1;
       const float* xe = traj + ((int64_t)e * n + base) * D;
       GemmArgs gm{};
       gm.M = M; gm.counters = side_counters;
       gm.act.x = xe; gm.act.D = D; gm.act.IN = IN;
       gm.Kdim = D;
       gm.seg[0] = GemmSeg{xe, kinv, gws + f.kr, D, D, D, D, mu0};
+      if (!net) {   // MCD_ULA: the target's K^-1 product is all there is to recompute
+        gm.nblk0 = cbD;
+        hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_NONE>, dim3(cbD, kSplit), gblock, gemm_lds, st, gm);
+        return;
+      }
       gm.seg[1] = GemmSeg{xe, params + lay.g_w1, gws + f.slab1, IN, D, IN, IN};
       gm.nblk0 = cbD; gm.epi_seg = 1;
-      gm.act.mode = 1; gm.act.bias = ws + w.bias1 + (int64_t)e * IN; gm.act.emb = params + lay.g_emb + (int64_t)ie * E;
+      gm.act.mode = 1; gm.act.bias = ws + w.bias1 + (int64_t)er * IN; gm.act.emb = params + lay.g_emb + (int64_t)ie * E;
       gm.act.sum_out = gws + f.pre1; gm.act.u_prev = nullptr; gm.act.u_out = gws + f.u1;
       hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_ACT>, dim3(cbD + cbIN, kSplit), gblock, gemm_lds, st, gm);
       gm.Kdim = IN;
@@ -1158,8 +1188,22 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
       aa.gmu_acc = gws + g.gmu_acc; aa.glam_acc = gws + g.glam_acc; aa.part = gws + g.adjpart;
       aa.DObig = gws + g.DO; aa.lay = lay; aa.n = n; aa.base = base;
       aa.M = M; aa.D = D; aa.K = K; aa.e = e; aa.grad_clipping = d.grad_clipping; aa.omega = omega;
-      aa.omega_vec = omega_vec; aa.gktab = reinterpret_cast<const uint32_t*>(ws + w.gktab); aa.bptt = bptt ? 1 : 0; aa.var_mode = d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0;
+      aa.ula = ula; aa.omega_vec = omega_vec; aa.gktab = reinterpret_cast<const uint32_t*>(ws + w.gktab); aa.bptt = bptt ? 1 : 0; aa.var_mode = d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0;
       hipLaunchKernelGGL(lgcp_adj_step_kernel, dim3((D + 255) / 256, M), dim3(256), 0, stream, aa);
+      if (!net) {   // MCD_ULA: lambda_e = lam_part - H_p v, one GEMM
+        gm.Kdim = D; gm.Kdim1 = 0;
+        gm.seg[0] = GemmSeg{gws + g.v, kinv, gws + g.hv, D, D, D, D};
+        gm.nblk0 = cbD;
+        hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_NONE>, dim3(cbD, kSplit), gblock, gemm_lds, stream, gm);
+        LgcpLamArgs la{};
+        la.params = params; la.tc = tc; la.traj = traj; la.dxf = nullptr; la.hv = gws + g.hv; la.du1 = nullptr;
+        la.v = gws + g.v; la.lam_part = gws + g.lam_part; la.gprev = gws + g.gprev; la.lamn = gws + g.lamn;
+        la.gE = gws + g.gE; la.gmu_acc = gws + g.gmu_acc; la.glam_acc = gws + g.glam_acc; la.lay = lay; la.n = n;
+        la.base = base; la.M = M; la.D = D; la.IN = IN; la.e = e; la.omega = omega; la.no_net = 1;
+        hipLaunchKernelGGL(lgcp_lam_finish_kernel, dim3((M * D + 255) / 256), dim3(256), 0, stream, la);
+        if (hipEventRecord(ev_bwd[e & 1], stream) != hipSuccess) return CMCD_ERR_HIP;
+        continue;
+      }
       // ---- net backward: d u2 = d o W3^T
       gm.Kdim = D;
       gm.seg[0] = GemmSeg{gws + g.dO, gws + g.wt3, gws + g.du2s, IN, D, IN, IN};
@@ -1177,7 +1221,10 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
       hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_NONE>, dim3(cbIN, kSplit), gblock, gemm_lds, stream, gm);
       ab.slab = gws + g.ts; ab.pre = gws + f.pre1; ab.du_prev = gws + g.du2; ab.u_src = gws + f.u1;
       ab.du_out = gws + g.du1; ab.da_out = gws + g.da1; ab.da_big = gws + g.DA1; ab.u_big = gws + g.U1;
-      ab.S = gws + g.S + (int64_t)e * IN; ab.S2 = gws + g.S2 + (int64_t)e * IN; ab.mode = 1;
+      {
+        const int er = ula == 2 ? (e > 0 ? e - 1 : 0) : e;     // the time index the network saw at this evaluation
+        ab.S = gws + g.S + (int64_t)er * IN; ab.S2 = gws + g.S2 + (int64_t)er * IN; ab.mode = 1;
+      }
       hipLaunchKernelGGL(lgcp_actb_kernel, dim3((IN + 255) / 256, M), dim3(256), 0, stream, ab);
       // d x = d u1[:D] + d a1 W1[:D]^T   |   v K^-1
       if (!bptt) {   // z detached: no lambda, no Hessian product; this evaluation's buffers are free after actb
@@ -1206,6 +1253,7 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
   }
   // ---- deferred parameter contractions over all (K+1) n rows
   const int64_t R = (int64_t)(K + 1) * n;
+  if (net) {
   hipLaunchKernelGGL(lgcp_tn_gemm_kernel, dim3((IN + 127) / 128, (IN + 127) / 128, kTnSplit), dim3(256), 0, stream, gws + g.U1, gws + g.DA2,
                      grad + lay.g_w2, R, IN, IN, IN, IN, IN);                                   // dW2 = U1^T dA2
   hipLaunchKernelGGL(lgcp_tn_gemm_kernel, dim3((D + 127) / 128, (IN + 127) / 128, kTnSplit), dim3(256), 0, stream, gws + g.U2, gws + g.DO,
@@ -1214,6 +1262,7 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
                      grad + lay.g_w1, R, D, IN, D, IN, IN);                                     // dW1[:D] = X^T dA1
   hipLaunchKernelGGL(lgcp_colsum_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, gws + g.DO, R, D, D, grad + lay.g_b3, 1.0f, 0);
   hipLaunchKernelGGL(lgcp_colsum_kernel, dim3((IN + 255) / 256), dim3(256), 0, stream, gws + g.gb2, (int64_t)1, IN, IN, grad + lay.g_b2, 1.0f, 0);
+  }
   {
     const int slots = (int)(n * ((D + 255) / 256));
     LgcpAdjRedArgs ra{gws + g.adjpart, ws + sw.sched, gws + g.gb_lo, gws + g.ge_lo, gws + g.gb_hi, gws + g.ge_hi, gws + g.gfac,
@@ -1222,8 +1271,9 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
     hipLaunchKernelGGL(lgcp_adj_combine_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, gws + g.gb_lo, gws + g.gb_hi,
                        gws + g.ge_lo, gws + g.ge_hi, gws + g.gbeta, gws + g.geps, K);
   }
-  hipLaunchKernelGGL(lgcp_colsum_kernel, dim3(1), dim3(256), 0, stream, gws + g.gfac, (int64_t)(K + 1), 1, 1, grad + lay.g_factor, 1.0f, 0);
-  int rc = launch_geffner_tails(d, lay, sw, params, gws, g.S, g.S2, g.gbeta, g.geps, IN, grad, stream_);
+  if (net)
+    hipLaunchKernelGGL(lgcp_colsum_kernel, dim3(1), dim3(256), 0, stream, gws + g.gfac, (int64_t)(K + 1), 1, 1, grad + lay.g_factor, 1.0f, 0);
+  int rc = launch_geffner_tails(d, lay, sw, params, gws, g.S, g.S2, g.gbeta, g.geps, IN, grad, stream_, net);
   if (rc != CMCD_OK) return rc;
   return hipGetLastError() == hipSuccess ? CMCD_OK : CMCD_ERR_HIP;
 }

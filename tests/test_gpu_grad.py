@@ -432,6 +432,55 @@ def test_ula_gradient_matches_autograd(hip_lib, name, n, over):
         assert np.abs(got - ref).max() <= 2e-3 * max(np.abs(ref).max(), 1e-9), (path, got, ref)
 
 
+@pytest.mark.parametrize("mode,n,K", [("MCD_ULA_sn", 6, 3), ("MCD_ULA", 27, 3)])
+def test_lgcp_overdamped_baselines_match_autograd(hip_lib, mode, n, K):
+    """d = 1600 with the two overdamped baselines (mcd_over_orig.py): MCD_ULA_sn = network in the backward kernel only,
+    time index i; MCD_ULA = no network at all (one GEMM launch per evaluation forward, two per evaluation in the reverse
+    sweep).  Losses and every gradient leaf against autograd through the float64 restatement."""
+    from helpers import lgcp_counts_fixture
+    counts = lgcp_counts_fixture()
+    b = synthetic.build("lgcp_n20_k128", device="cuda", lgcp_counts=counts, nbridges=K, N=n, init_eps=2e-3, boundmode=mode)
+    seeds = synthetic.parity_seeds(n)
+    grad, (losses, z) = mcdbm.compute_bound_grad(torch.from_numpy(seeds).cuda(), b["params_flat"], b["unflatten"],
+                                                 b["params_fixed"], b["target"])
+    torch.cuda.synchronize()
+    dim, _, _, spec = b["params_fixed"]
+    un = b["unflatten"]
+    if mode == "MCD_ULA":
+        train, notrain = un(b["params_flat"].detach().cpu())
+        allp = {**train, **notrain}
+        f = lambda t: np.asarray(t.numpy(), np.float64)
+        p = {"vd": {k: f(v) for k, v in allp["vd"].items()}, "eps": f(allp["eps"]), "mgridref_y": f(allp["mgridref_y"]),
+             "gridref_x": f(allp["gridref_x"]), "target_x": f(allp["target_x"])}
+        arch = "geffner"
+    else:
+        p = synthetic.oracle_params(un, b["params_flat"])
+        arch = spec.arch
+    val, l_ref, z_ref, g = ot.bound_and_grad(seeds, p, dim, K, mode, arch, ot.make_logp_lgcp(counts), None, False)
+    np.testing.assert_allclose(losses.cpu().numpy(), l_ref, rtol=2e-4, atol=0.5)
+    np.testing.assert_allclose(z.cpu().numpy(), z_ref, rtol=0, atol=5e-4)
+    gh = grad.double().cpu().numpy()
+
+    def leaf(*path):
+        off, shape = un.layout[(0,) + path] if (0,) + path in un.layout else un.layout[(1,) + path]
+        return gh[off:off + max(1, int(np.prod(shape)))].reshape(shape)
+    checks = {"vd.mean": (leaf("vd", "mean"), g["vd"]["mean"]), "vd.logdiag": (leaf("vd", "logdiag"), g["vd"]["logdiag"]),
+              "eps": (leaf("eps"), g["eps"]), "mgridref_y": (leaf("mgridref_y"), g["mgridref_y"])}
+    if mode == "MCD_ULA_sn":
+        (w1, b1), (w2, b2), (w3, b3) = [(("sn", "nn", i, 0), ("sn", "nn", i, 1)) for i in range(3)]
+        checks.update({"W1": (leaf(*w1), g["sn"]["W1"]), "b1": (leaf(*b1), g["sn"]["b1"]), "W2": (leaf(*w2), g["sn"]["W2"]),
+                       "b2": (leaf(*b2), g["sn"]["b2"]), "W3": (leaf(*w3), g["sn"]["W3"]), "b3": (leaf(*b3), g["sn"]["b3"]),
+                       "emb": (leaf("sn", "emb"), g["sn"]["emb"]), "factor_sn": (leaf("sn", "factor_sn"), g["sn"]["factor_sn"])})
+    worst = {}
+    for name, (a, r) in checks.items():
+        r = np.asarray(r, np.float64).reshape(a.shape)
+        scale = max(np.abs(r).max(), 1e-12)
+        worst[name] = (float(np.abs(a - r).max() / scale), float(scale))
+    print({k: "%.1e (|ref| %.1e)" % v for k, v in worst.items()})
+    bad = {k: v for k, v in worst.items() if v[0] > 5e-3 and v[1] > 1e-9}
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("mode", ["MCD_CAIS_sn", "MCD_CAIS_var_sn"])
 def test_sharded_grad_and_loss_without_a_process_group_is_the_plain_call(hip_lib, mode):
     from cmcd_amd import parallel
