@@ -29,7 +29,8 @@ namespace cmcd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kMP = 24;      // particles per pass (rows of the skinny GEMM; padded to the 32-row MFMA tile)
+constexpr int kMP = 24;      // particles per pass (rows of the skinny GEMM, padded to the 32-row MFMA tile; 32 measured
+                             // 11 % slower at the named N = 20: staging and the consumers scale with kMP, the MFMAs do not)
 constexpr int kGemmWaves = 8;
 constexpr int kQuarters = kGemmWaves / 2;   // k quarters of a round (x 2 column halves = the 8 waves)
 constexpr int kQLen = 52;                   // k rows per quarter per round (even: 32x32x2 takes two per MFMA)
@@ -210,9 +211,10 @@ __global__ __launch_bounds__(64 * (kGemmWaves + (EPI == EPI_STEP ? 1 : 0))) void
   const int n = n0 + 32 * half + l31;
   const bool ncol = n < sg.N;
 
-  // rows 24..31 of the 32-row MFMA operand stay zero
-  for (int e = threadIdx.x; e < kStage * (32 - kMP); e += blockDim.x)
-    As[(e / (32 - kMP)) * kAsLd + kMP + e % (32 - kMP)] = 0.f;
+  if (kMP < 32) {
+    constexpr int kPad = kMP < 32 ? 32 - kMP : 1;
+    for (int e = threadIdx.x; e < kStage * kPad; e += blockDim.x) As[(e / kPad) * kAsLd + kMP + e % kPad] = 0.f;
+  }
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;

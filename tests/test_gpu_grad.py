@@ -296,10 +296,10 @@ def test_graph_replayed_training_equals_eager_training(hip_lib, mode):
     assert float((out[True][1] - flat.double().cpu()).abs().max()) > 1e-3      # and it did train
 
 
-@pytest.mark.parametrize("n,K,clip", [(5, 3, False), (27, 2, True)])
+@pytest.mark.parametrize("n,K,clip", [(5, 3, False), (37, 2, True)])
 def test_lgcp_reparameterised_gradient_matches_autograd(hip_lib, n, K, clip):
     """d = 1600 (config 5): launch-sequence reverse sweep + deferred A^T B parameter contractions vs autograd
-    through the float64 restatement.  n = 27 spans two passes of 24 particles."""
+    through the float64 restatement.  n = 37 spans two passes of 24 particles."""
     from helpers import lgcp_counts_fixture
     counts = lgcp_counts_fixture()
     b = synthetic.build("lgcp_n20_k128", device="cuda", lgcp_counts=counts, nbridges=K, N=n, grad_clipping=clip,
@@ -337,11 +337,11 @@ def test_lgcp_reparameterised_gradient_matches_autograd(hip_lib, n, K, clip):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("n,K,clip", [(6, 3, False), (27, 2, True)])
+@pytest.mark.parametrize("n,K,clip", [(6, 3, False), (37, 2, True)])
 def test_lgcp_vargrad_matches_autograd(hip_lib, n, K, clip):
     """d = 1600 with MCD_CAIS_var_sn: the reverse launch sequence with z detached (no lambda recursion, no Hessian
     product), per-particle weights from the statistics — against autograd of var(losses) through the float64
-    restatement with the reference's stop_gradient placement.  n = 27 spans two passes; clip = 1e2 on both scores."""
+    restatement with the reference's stop_gradient placement.  n = 37 spans two passes; clip = 1e2 on both scores."""
     from helpers import lgcp_counts_fixture
     counts = lgcp_counts_fixture()
     b = synthetic.build("lgcp_n20_k128", device="cuda", lgcp_counts=counts, nbridges=K, N=n, grad_clipping=clip,
@@ -432,7 +432,7 @@ def test_ula_gradient_matches_autograd(hip_lib, name, n, over):
         assert np.abs(got - ref).max() <= 2e-3 * max(np.abs(ref).max(), 1e-9), (path, got, ref)
 
 
-@pytest.mark.parametrize("mode,n,K", [("MCD_ULA_sn", 6, 3), ("MCD_ULA", 27, 3)])
+@pytest.mark.parametrize("mode,n,K", [("MCD_ULA_sn", 6, 3), ("MCD_ULA", 37, 3)])
 def test_lgcp_overdamped_baselines_match_autograd(hip_lib, mode, n, K):
     """d = 1600 with the two overdamped baselines (mcd_over_orig.py): MCD_ULA_sn = network in the backward kernel only,
     time index i; MCD_ULA = no network at all (one GEMM launch per evaluation forward, two per evaluation in the reverse
