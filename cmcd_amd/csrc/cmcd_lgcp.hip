@@ -51,7 +51,7 @@ struct GemmSeg {
 // bump the block's counter; the LAST one to arrive sums the slabs in fixed order (bitwise deterministic: which
 // workgroup does the summing does not change the arithmetic) and applies the consumer for its 64 columns.  That
 // removes the separate activation / state launches (5.7 us and 13 us of a 61 us evaluation) from the dependent chain.
-enum { EPI_NONE = 0, EPI_ACT = 1, EPI_STEP = 2 };
+enum { EPI_NONE = 0, EPI_ACT = 1, EPI_STEP = 2, EPI_STEP_NONET = 3 };   // NONET: MCD_ULA, the K^-1 slabs are this launch's own
 
 struct ActEpi {          // u_out = u + softplus(bias + sum(slabs))      nn.py:45-50,68-69
   const float* bias;     // [IN]
@@ -117,9 +117,10 @@ __device__ __forceinline__ void lgcp_key_advance(uint32_t& k0, uint32_t& k1, uin
 
 // the state update of lgcp_forward's evaluation i on columns [n0, n0 + 64) of all particles; sn slabs are this
 // launch's output (visible after the arrival protocol), everything else is from earlier launches
+template <bool NO_NET>   // NO_NET (MCD_ULA): `sn_slabs` are the K^-1 slabs of THIS launch, there is no network output
 __device__ __forceinline__ void lgcp_step_tile(const StepEpi& a, const float* sn_slabs, int M, int n0, int cb, int wv,
                                                int lane) {
-  const bool no_net = a.ula == 1;               // then sn_slabs are the K^-1 slabs of THIS launch (agent-scope reads)
+  constexpr bool no_net = NO_NET;               // compile-time: a run-time branch here split the 16 slab loads apart
   const float fsn = a.ula ? 0.f : 1.f;          // the overdamped baselines have no network in the forward kernel
   const int D = a.D, H = (D + 1) / 2, i = a.i;
   const float* counts = a.tc + (int64_t)D * D;
@@ -192,7 +193,7 @@ __device__ __forceinline__ void lgcp_step_tile(const StepEpi& a, const float* sn
 
 // out[ks][m][n] = sum_{k in slice ks, wave w} A[m][k] W[k][n]   (no bias: added when the slabs are summed)
 template <int EPI>
-__global__ __launch_bounds__(64 * (kGemmWaves + (EPI == EPI_STEP ? 1 : 0))) void lgcp_gemm_kernel(GemmArgs a) {
+__global__ __launch_bounds__(64 * (kGemmWaves + (EPI >= EPI_STEP ? 1 : 0))) void lgcp_gemm_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ int s_last;
   const int s = blockIdx.x < a.nblk0 ? 0 : 1;
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(64 * (kGemmWaves + (EPI == EPI_STEP ? 1 : 0))) void
   const int n0 = (blockIdx.x - (s ? a.nblk0 : 0)) * 64;
   const int ksplit = blockIdx.y;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const bool worker = EPI != EPI_STEP || wv < kGemmWaves;            // EPI_STEP carries one extra wave (key chain)
+  const bool worker = EPI < EPI_STEP || wv < kGemmWaves;             // EPI_STEP* carry one extra wave (key chain)
   float* As = lds;                                                   // [kStage][kAsLd]  A slice, k-major, particle-minor
   float* red = lds + kStage * kAsLd;                                 // [kQuarters][kMP][64]
   const int kslice = (Kdim + kSplit - 1) / kSplit;
@@ -308,11 +309,11 @@ __global__ __launch_bounds__(64 * (kGemmWaves + (EPI == EPI_STEP ? 1 : 0))) void
         ac.u_out[idx] = u + softplus(pre);                                        // nn.py:45-50
       }
     }
-  } else if (EPI == EPI_STEP) {
+  } else if (EPI >= EPI_STEP) {
     const StepEpi& st = a.step;
     const int cb = blockIdx.x;
     if (wv < kGemmWaves) {
-      lgcp_step_tile(st, sg.out, a.M, n0, cb, wv, lane);
+      lgcp_step_tile<EPI == EPI_STEP_NONET>(st, sg.out, a.M, n0, cb, wv, lane);
     } else if (cb == 0 && st.i + 1 < st.K && lane < a.M) {
       // the chain's key for evaluation i + 1 (a dependent integer chain of ~450 instructions: on its own wave it
       // hides behind the state update of the eight others)
@@ -486,9 +487,10 @@ int64_t lgcp_workspace_floats(const cmcd_desc& d, int64_t n, int64_t base) { ret
 
 static int lgcp_gemm_attrs() {
   const int gemm_lds = int(size_t(kStage * kAsLd + kQuarters * kMP * 64) * 4);
-  const void* fns[3] = {reinterpret_cast<const void*>(lgcp_gemm_kernel<EPI_NONE>),
+  const void* fns[4] = {reinterpret_cast<const void*>(lgcp_gemm_kernel<EPI_NONE>),
                         reinterpret_cast<const void*>(lgcp_gemm_kernel<EPI_ACT>),
-                        reinterpret_cast<const void*>(lgcp_gemm_kernel<EPI_STEP>)};
+                        reinterpret_cast<const void*>(lgcp_gemm_kernel<EPI_STEP>),
+                        reinterpret_cast<const void*>(lgcp_gemm_kernel<EPI_STEP_NONET>)};
   for (const void* fn : fns)
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds) != hipSuccess) return -1;
   return gemm_lds;
@@ -547,7 +549,7 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
         g.Kdim = D; g.Kdim1 = 0;
         g.seg[0] = GemmSeg{ws + w.x, kinv, ws + w.kr, D, D, D, D, mu0};
         g.nblk0 = cbD; g.epi_seg = -1;
-        hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_STEP>, dim3(cbD, kSplit), gblock_step, gemm_lds, stream, g);
+        hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_STEP_NONET>, dim3(cbD, kSplit), gblock_step, gemm_lds, stream, g);
         continue;
       }
       // CAIS: s(z_i, i) serves both kernels; MCD_ULA_sn: s(z_i, i - 1) serves the backward kernel only
