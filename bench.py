@@ -241,7 +241,7 @@ def main():
     if cfg["model"] == "lgcp":
         # weight-bandwidth bound: every evaluation streams K^-1 and the three weight matrices
         IN = dim + cfg["emb_dim"]
-        wbytes = 4.0 * (dim * dim + 2 * dim * IN + IN * IN) * (K + 1) * -(-n // 24)
+        wbytes = 4.0 * (dim * dim + 2 * dim * IN + IN * IN) * (K + 1) * -(-n // 32)
         result["roofline"].update({"bound": "hbm", "achieved": wbytes / kern_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                    "frac": wbytes / kern_s / 1e9 / PEAK_HBM_GBS, "traffic": None,
                                    "weight_bytes_per_call": wbytes})

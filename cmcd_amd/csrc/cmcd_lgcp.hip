@@ -9,9 +9,8 @@
 //   C: u2 W3 -> sn slabs -> state update: sn = factor_sn (sum(slabs) + b3); grad log p = -kr + counts - a e^x
 //      (model_handler.py:386-396, cp_utils.py:102-104); close step i-1, draw eps_i = normal(G_i, (1600,)),
 //      open step i; per-column-block partial log-weights (summed once at the end, fixed order).
-// The skinny GEMM ([<=24 particles] x [K] x [N]) is weight-bandwidth / latency bound: a workgroup owns 64
-// output columns of one of kSplit K-slices; it stages its <= 24 x 208 operand slice once in LDS (k-major,
-// padded to the 32-row MFMA tile), each of its 8 waves takes a 32-column half and a quarter of the slice on
+// The skinny GEMM ([<=32 particles] x [K] x [N]) is weight-bandwidth / latency bound: a workgroup owns 64
+// output columns of one of kSplit K-slices; it stages its <= 32 x 208 operand slice once in LDS (k-major), each of its 8 waves takes a 32-column half and a quarter of the slice on
 // v_mfma_f32_32x32x2_f32 (exact fp32; W rows read once, 2 x 128 B per load, all loads in flight before the first
 // wait), the 4 quarter tiles are summed through LDS and written as a partial slab.  The kSplit workgroups of a
 // column block count arrivals on a device counter; the last one sums the slabs in fixed order (bitwise
@@ -29,8 +28,7 @@ namespace cmcd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kMP = 24;      // particles per pass (rows of the skinny GEMM, padded to the 32-row MFMA tile; 32 measured
-                             // 11 % slower at the named N = 20: staging and the consumers scale with kMP, the MFMAs do not)
+constexpr int kMP = 32;      // particles per pass = the rows of the 32-row MFMA tile (same time per pass as 24 at N = 20)
 constexpr int kGemmWaves = 8;
 constexpr int kQuarters = kGemmWaves / 2;   // k quarters of a round (x 2 column halves = the 8 waves)
 constexpr int kQLen = 52;                   // k rows per quarter per round (even: 32x32x2 takes two per MFMA)
@@ -902,7 +900,7 @@ __global__ void lgcp_actb_kernel(LgcpActbArgs a) {
   a.da_out[m * a.IN + k] = da;
   a.da_big[(a.row0 + m) * a.IN + k] = da;
   a.u_big[(a.row0 + m) * a.IN + k] = a.u_src[m * a.IN + k];
-  // sums over the particles of the pass (<= 24 adders per address)
+  // sums over the particles of the pass (<= 32 adders per address)
   if (a.mode == 1) { atomicAdd(a.S + k, da); atomicAdd(a.S2 + k, du); }
   else atomicAdd(a.gb + k, da);
 }

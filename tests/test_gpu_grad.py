@@ -299,7 +299,7 @@ def test_graph_replayed_training_equals_eager_training(hip_lib, mode):
 @pytest.mark.parametrize("n,K,clip", [(5, 3, False), (37, 2, True)])
 def test_lgcp_reparameterised_gradient_matches_autograd(hip_lib, n, K, clip):
     """d = 1600 (config 5): launch-sequence reverse sweep + deferred A^T B parameter contractions vs autograd
-    through the float64 restatement.  n = 37 spans two passes of 24 particles."""
+    through the float64 restatement.  n = 37 spans two passes of 32 particles."""
     from helpers import lgcp_counts_fixture
     counts = lgcp_counts_fixture()
     b = synthetic.build("lgcp_n20_k128", device="cuda", lgcp_counts=counts, nbridges=K, N=n, grad_clipping=clip,

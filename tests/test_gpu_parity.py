@@ -53,7 +53,7 @@ def test_bound_matches_oracle(hip_lib, variant, name, n, over):
 
 @pytest.mark.parametrize("n,k", [(20, 8), (5, 3), (40, 2)])
 def test_lgcp_matches_oracle(hip_lib, n, k):
-    """d = 1600 (config 5): per-bridge GEMM path.  40 particles = two passes of the 24-row GEMM."""
+    """d = 1600 (config 5): per-bridge GEMM path.  40 particles = two passes of the 32-row GEMM."""
     import os
     counts = np.load(os.path.join(os.path.dirname(__file__), "golden", "lgcp_bin_counts.npy"))
     b = synthetic.build("lgcp_n20_k128", device="cuda", lgcp_counts=counts, nbridges=k)
