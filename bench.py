@@ -242,9 +242,19 @@ def main():
         # weight-bandwidth bound: every evaluation streams K^-1 and the three weight matrices
         IN = dim + cfg["emb_dim"]
         wbytes = 4.0 * (dim * dim + 2 * dim * IN + IN * IN) * (K + 1) * -(-n // 32)
+        # measured L2 <-> fabric bytes of the three GEMM launches of one evaluation (tools/probes/pmc_hbm_lgcp.sh: separate
+        # rocprofv3 --pmc passes, FETCH_SIZE doubled per the gfx950 note), x (K + 1) evaluations x passes — a constant of the
+        # named shape (N <= 32 per pass, K = 128, width 1620): weights + the operand slices every workgroup re-reads + slabs
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc", "lgcp_summary.json")))
+            if dim == 1600 and IN == 1620:
+                traffic = sum(v["hbm_bytes_per_launch"] for v in pm.values()) * (K + 1) * -(-n // 32)
+        except Exception:
+            pass
         result["roofline"].update({"bound": "hbm", "achieved": wbytes / kern_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                   "frac": wbytes / kern_s / 1e9 / PEAK_HBM_GBS, "traffic": None,
-                                   "weight_bytes_per_call": wbytes})
+                                   "frac": wbytes / kern_s / 1e9 / PEAK_HBM_GBS, "traffic": traffic,
+                                   "traffic_unit": "bytes/call (PMC)", "weight_bytes_per_call": wbytes})
 
     if rank == 0 and world == 1 and name == synthetic.NORTH_STAR:
         # value-and-gradient of the VarGrad loss on the same batch (boundmode MCD_CAIS_var_sn, same net/target)
