@@ -218,31 +218,37 @@ __global__ __launch_bounds__(64 * (kGemmWaves + (EPI >= EPI_STEP ? 1 : 0))) void
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   for (int r0 = s_lo; r0 < s_hi; r0 += kStage) {                     // one round for Kdim <= kSplit * kStage = 1664
-    // this wave's W rows of the round: 2 rows x 128 B per load, all in flight before anything waits
-    float wreg[kQLen / 2];
-    if (worker) {
-#pragma unroll
-      for (int j = 0; j < kQLen / 2; ++j) {
-        const int k = r0 + q * kQLen + 2 * j + l5;
-        wreg[j] = (k < s_hi && ncol) ? sg.W[(int64_t)k * sg.ldw + n] : 0.f;
-      }
-    }
-    // the workgroup stages A[:, r0 : r0 + kStage) once: coalesced along k, conflict-free LDS writes (odd row pitch)
+    // All loads of the round first — the operand slice (L2 / Infinity Cache resident: the previous launch wrote it), then
+    // this wave's 26 W row pairs (2 x 128 B per load, HBM) — so that the slice is staged while the weights are still in
+    // flight.  Clamped, unpredicated addresses (a predicated load gets its own branch and s_waitcnt): weight rows past the
+    // slice meet zero operand rows, columns past N are never stored.
+    constexpr int kIt = (kMP * kStage + 64 * kGemmWaves - 1) / (64 * kGemmWaves);
+    float wreg[kQLen / 2], av[kIt];
     if (r0 > s_lo) __syncthreads();
     if (worker) {
 #pragma unroll
-      for (int e0 = 0; e0 < kMP * kStage; e0 += 64 * kGemmWaves) {
-        const int e = e0 + threadIdx.x, m = e / kStage, kk = e - m * kStage;
-        if (e < kMP * kStage)
-          As[kk * kAsLd + m] = (m < a.M && r0 + kk < s_hi) ? sg.A[(int64_t)m * sg.lda + r0 + kk] - sg.a_shift : 0.f;
+      for (int it = 0; it < kIt; ++it) {
+        const int e = it * 64 * kGemmWaves + threadIdx.x, m = e / kStage, kk = e - m * kStage;
+        av[it] = sg.A[(int64_t)min(m, a.M - 1) * sg.lda + min(r0 + kk, s_hi - 1)];
+      }
+      const int nc = ncol ? n : sg.N - 1;
+#pragma unroll
+      for (int j = 0; j < kQLen / 2; ++j)
+        wreg[j] = sg.W[(int64_t)min(r0 + q * kQLen + 2 * j + l5, s_hi - 1) * sg.ldw + nc];
+      __builtin_amdgcn_sched_barrier(0);        // keep the selects below from being interleaved with (and waiting on) the loads
+#pragma unroll
+      for (int it = 0; it < kIt; ++it) {        // k-major, odd row pitch: conflict-free LDS writes
+        const int e = it * 64 * kGemmWaves + threadIdx.x, m = e / kStage, kk = e - m * kStage;
+        if (e < kMP * kStage) As[kk * kAsLd + m] = (m < a.M && r0 + kk < s_hi) ? av[it] - sg.a_shift : 0.f;
       }
     }
-    __syncthreads();
+    // workgroup barrier that publishes the LDS writes without draining the weight loads still in flight
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (worker) {
 #pragma unroll
       for (int j = 0; j < kQLen / 2; ++j) {
-        const float av = As[(q * kQLen + 2 * j + l5) * kAsLd + l31];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wreg[j], acc, 0, 0, 0);
+        const float aop = As[(q * kQLen + 2 * j + l5) * kAsLd + l31];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, wreg[j], acc, 0, 0, 0);
       }
     }
   }
