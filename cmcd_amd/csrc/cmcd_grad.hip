@@ -324,6 +324,9 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
 #pragma unroll
           for (int to = 0; to < T; ++to) afn[to] = *reinterpret_cast<const f32x4*>(w2f + ((ti + 1) * T + to) * 256 + lofs);
         }
+        // pin the requests above the MFMAs: left alone, the scheduler sinks each one down to its first use to shorten the
+        // live range, and every pair of fragments then waits out a full L2 round trip (s_waitcnt vmcnt(0) per 8 MFMAs)
+        if (WGLOBAL) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int to = 0; to < T; ++to) {
 #pragma unroll
@@ -586,6 +589,7 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
 #pragma unroll
           for (int tk = 0; tk < T; ++tk) atn[tk] = *reinterpret_cast<const f32x4*>(w2tf + (tk * T + tn + 1) * 256 + lofs);
         }
+        if (WGLOBAL) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int tk = 0; tk < T; ++tk) {
 #pragma unroll
