@@ -133,53 +133,83 @@ __device__ __forceinline__ void lgcp_step_tile(const StepEpi& a, const float* sn
   const float fac = no_net ? 0.f : a.factor[0];
   const int e = n0 + lane;
   const bool ecol = e < D;
-  const float cnt = ecol ? counts[e] : 0.f, b3 = (ecol && !no_net) ? a.b3[e] : 0.f;
-  const float mean = ecol ? a.params[a.lay.vd_mean + e] : 0.f;
-  const float sd = ecol ? expf(a.params[a.lay.vd_logdiag + e]) : 1.f;
+  const int ecl = min(e, D - 1);
+  const float cnt = counts[ecl], b3 = no_net ? 0.f : a.b3[ecl];
+  const float mean = a.params[a.lay.vd_mean + ecl];
+  const float sd = expf(a.params[a.lay.vd_logdiag + ecl]);
   const uint32_t* gk = a.gkey + (i & 1) * 2 * kMP;
-  for (int m = wv; m < kMP; m += kGemmWaves) {       // a wave = one particle x 64 columns
-    if (m >= M) break;
-    float bk_acc = 0.f, fk_acc = 0.f, lp_acc = 0.f;
-    if (ecol) {
-      const float z = a.x[m * D + e];
-      float kr = 0.f, s = b3;
+  // A wave = one particle x 64 columns, kMP / 8 particles per wave.  Every load of all of them first, from clamped
+  // (always valid) addresses: taken one particle at a time the stores of one would fence the loads of the next (three
+  // memory round trips in the tail), and a predicated load gets a branch and an s_waitcnt of its own.
+  constexpr int R = kMP / kGemmWaves;
+  const int ec = min(e, D - 1);
+  float zv[R], krv[R], sv[R], xpv[R];
+  uint32_t g0v[R], g1v[R];
 #pragma unroll
-      for (int ks = 0; ks < kSplit; ++ks) {            // fixed-order sums of the split-K slabs
-        const float own = __hip_atomic_load(sn_slabs + ((int64_t)ks * kMP + m) * D + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        kr += no_net ? own : a.kr[((int64_t)ks * kMP + m) * D + e];
-        s += no_net ? 0.f : own;
-      }
-      s = no_net ? 0.f : s * fac;                      // factor_sn (u2 W3 + b3)           nn.py:70
-      const float ez = expf(z);
-      float gp = -kr + cnt - pa * ez;                  // grad log p      model_handler.py:386-396
-      float gq = -(z - mean) / (sd * sd);
-      if (clip_p) gp = fminf(fmaxf(gp, -clipv), clipv);
-      if (clip_q) gq = fminf(fmaxf(gq, -clipv), clipv);
-      if (i > 0) {   // backward kernel of step i-1                           mcd_cais.py:71-86
-        const float ub = -1.0f * (pbeta * gp + (1.0f - pbeta) * gq);
-        const float bk = z - peps * ub + peps * s;
-        const float db = a.xp[m * D + e] - bk;
-        bk_acc = -(db * db) * pinv2s2 - pcst;
-      }
-      if (last) {    // log p(z_K)
-        lp_acc = -0.5f * (z - mu0) * kr + z * cnt - pa * ez;
-        a.out_z[(int64_t)m * D + e] = z;
-      } else {       // forward kernel of step i                              mcd_cais.py:52-67
-        // eps_i = normal(G_i, (D,)): element e is word (e >= H) of the block with counters (j, H + j), j = e mod H
-        const int j = e < H ? e : e - H;
-        uint32_t y0 = j, y1 = (H + j < D) ? H + j : 0;
-        threefry2x32(gk[2 * m], gk[2 * m + 1], y0, y1);
-        const float uf = -1.0f * (beta * gp + (1.0f - beta) * gq);
-        const float fk = z - eps * uf - fsn * eps * s;
-        const float zn = fk + sig * bits_to_normal(e < H ? y0 : y1);
-        const float df = zn - fk;
-        fk_acc = -(df * df) * inv2s2 - cst;
-        a.xp[m * D + e] = z;
-        a.x[m * D + e] = zn;
-        if (a.traj) a.traj[((int64_t)(i + 1) * a.n_total + a.base + m) * D + e] = zn;
+  for (int r = 0; r < R; ++r) {
+    const int mc = min(wv + kGemmWaves * r, M - 1);
+    zv[r] = a.x[mc * D + ec];
+    xpv[r] = a.xp[mc * D + ec];
+    g0v[r] = gk[2 * mc];
+    g1v[r] = gk[2 * mc + 1];
+    float kr = 0.f, sacc = b3;
+#pragma unroll
+    for (int ks = 0; ks < kSplit; ++ks) {              // fixed-order sums of the split-K slabs
+      const float own = __hip_atomic_load(sn_slabs + ((int64_t)ks * kMP + mc) * D + ec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      kr += no_net ? own : a.kr[((int64_t)ks * kMP + mc) * D + ec];
+      sacc += no_net ? 0.f : own;
+    }
+    krv[r] = kr;
+    sv[r] = no_net ? 0.f : sacc * fac;                 // factor_sn (u2 W3 + b3)           nn.py:70
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  float znv[R], bkv[R], fkv[R], lpv[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const float z = zv[r], kr = krv[r], sn = sv[r];
+    float bk_acc = 0.f, fk_acc = 0.f, lp_acc = 0.f, zn = 0.f;
+    znv[r] = 0.f; bkv[r] = 0.f; fkv[r] = 0.f; lpv[r] = 0.f;
+    if (wv + kGemmWaves * r >= M) continue;            // wave-uniform: no arithmetic for the clamped duplicates
+    const float ez = expf(z);
+    float gp = -kr + cnt - pa * ez;                    // grad log p      model_handler.py:386-396
+    float gq = -(z - mean) / (sd * sd);
+    if (clip_p) gp = fminf(fmaxf(gp, -clipv), clipv);
+    if (clip_q) gq = fminf(fmaxf(gq, -clipv), clipv);
+    if (i > 0) {   // backward kernel of step i-1                             mcd_cais.py:71-86
+      const float ub = -1.0f * (pbeta * gp + (1.0f - pbeta) * gq);
+      const float bk = z - peps * ub + peps * sn;
+      const float db = xpv[r] - bk;
+      bk_acc = -(db * db) * pinv2s2 - pcst;
+    }
+    if (last) {    // log p(z_K)
+      lp_acc = -0.5f * (z - mu0) * kr + z * cnt - pa * ez;
+    } else {       // forward kernel of step i                                mcd_cais.py:52-67
+      // eps_i = normal(G_i, (D,)): element e is word (e >= H) of the block with counters (j, H + j), j = e mod H
+      const int j = ec < H ? ec : ec - H;
+      uint32_t y0 = j, y1 = (H + j < D) ? H + j : 0;
+      threefry2x32(g0v[r], g1v[r], y0, y1);
+      const float uf = -1.0f * (beta * gp + (1.0f - beta) * gq);
+      const float fk = z - eps * uf - fsn * eps * sn;
+      zn = fk + sig * bits_to_normal(ec < H ? y0 : y1);
+      const float df = zn - fk;
+      fk_acc = -(df * df) * inv2s2 - cst;
+    }
+    znv[r] = zn; bkv[r] = ecol ? bk_acc : 0.f; fkv[r] = ecol ? fk_acc : 0.f; lpv[r] = ecol ? lp_acc : 0.f;   // clamped lanes: dropped
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int m = wv + kGemmWaves * r;
+    if (m >= M) continue;                              // wave-uniform
+    if (ecol) {
+      if (last) {
+        a.out_z[(int64_t)m * D + e] = zv[r];
+      } else {
+        a.xp[m * D + e] = zv[r];
+        a.x[m * D + e] = znv[r];
+        if (a.traj) a.traj[((int64_t)(i + 1) * a.n_total + a.base + m) * D + e] = znv[r];
       }
     }
-    const float bk_lp = wave_sum64(bk_acc), fk_lp = wave_sum64(fk_acc), lp = wave_sum64(lp_acc);
+    const float bk_lp = wave_sum64(bkv[r]), fk_lp = wave_sum64(fkv[r]), lp = wave_sum64(lpv[r]);
     if (lane == 0) {
       const int sl = cb * kMP + m;
       if (i > 0) a.wslot[sl] += bk_lp - a.fkslot[sl];
