@@ -327,20 +327,33 @@ __global__ __launch_bounds__(64 * (kGemmWaves + (EPI >= EPI_STEP ? 1 : 0))) void
 
   if (EPI == EPI_ACT) {
     const ActEpi& ac = a.act;
-    const int k = n0 + lane;
-    if (k < ac.IN) {
-      const float bias = ac.bias[k];
-      for (int m = wv; m < a.M; m += kGemmWaves) {
-        float pre = bias;
+    const int k = n0 + lane, kc = min(k, ac.IN - 1);
+    constexpr int R = kMP / kGemmWaves;
+    // all loads of the wave's particles first, clamped and unpredicated (see lgcp_step_tile)
+    const float bias = ac.bias[kc];
+    float pre[R], u[R];
 #pragma unroll
-        for (int q = 0; q < kSplit; ++q)
-          pre += __hip_atomic_load(sg.out + ((int64_t)q * kMP + m) * sg.ldo + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int idx = m * ac.IN + k;
-        ac.sum_out[idx] = pre;
-        float u;
-        if (ac.mode == 1) u = k < ac.D ? ac.x[m * ac.D + k] : ac.emb[k - ac.D];   // u = [x; emb_i]      nn.py:68-69
-        else u = ac.u_prev[idx];
-        ac.u_out[idx] = u + softplus(pre);                                        // nn.py:45-50
+    for (int r = 0; r < R; ++r) {
+      const int mc = min(wv + kGemmWaves * r, a.M - 1);
+      float p = bias;
+#pragma unroll
+      for (int q = 0; q < kSplit; ++q)
+        p += __hip_atomic_load(sg.out + ((int64_t)q * kMP + mc) * sg.ldo + kc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pre[r] = p;
+      if (ac.mode == 1) {                              // u = [x; emb_i]      nn.py:68-69
+        const float xv = ac.x[mc * ac.D + min(kc, ac.D - 1)], ev = ac.emb[max(kc - ac.D, 0)];
+        u[r] = kc < ac.D ? xv : ev;
+      } else {
+        u[r] = ac.u_prev[mc * ac.IN + kc];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int m = wv + kGemmWaves * r;
+      if (m < a.M && k < ac.IN) {
+        ac.sum_out[m * ac.IN + k] = pre[r];
+        ac.u_out[m * ac.IN + k] = u[r] + softplus(pre[r]);                        // nn.py:45-50
       }
     }
   } else if (EPI >= EPI_STEP) {
