@@ -789,7 +789,7 @@ struct LgcpAdjArgs {
 };
 
 __global__ __launch_bounds__(256) void lgcp_adj_step_kernel(LgcpAdjArgs a) {
-  __shared__ float sh[4];
+  __shared__ float sh6[24];
   const int p = blockIdx.y, D = a.D, e = a.e, K = a.K;
   const float* counts = a.tc + (int64_t)D * D;
   const float pa = a.tc[(int64_t)D * D + D + 1];
@@ -871,11 +871,17 @@ __global__ __launch_bounds__(256) void lgcp_adj_step_kernel(LgcpAdjArgs a) {
       a.lam_part[p * D + j] = lam;
     }
   }
-  const float tsb = block_sum_256(sb, sh), tse = block_sum_256(se, sh), tr2 = block_sum_256(r2, sh);
-  const float tsb2 = block_sum_256(sb2, sh), tse2 = block_sum_256(se2, sh), tgf = block_sum_256(gf, sh);
-  if (threadIdx.x == 0) {
+  // the six sums through LDS together: one barrier instead of twelve
+  float t6[6] = {sb, se, r2, sb2, se2, gf};
+#pragma unroll
+  for (int q = 0; q < 6; ++q) t6[q] = wave_sum64(t6[q]);
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int q = 0; q < 6; ++q) sh6[(threadIdx.x >> 6) * 6 + q] = t6[q];
+  __syncthreads();
+  if (threadIdx.x < 6) {
     float* o = a.part + (((int64_t)e * a.n + a.base + p) * gridDim.x + blockIdx.x) * 8;
-    o[0] = tsb; o[1] = tse; o[2] = tr2; o[3] = tsb2; o[4] = tse2; o[5] = tgf;
+    o[threadIdx.x] = sh6[threadIdx.x] + sh6[6 + threadIdx.x] + sh6[12 + threadIdx.x] + sh6[18 + threadIdx.x];
   }
 }
 
