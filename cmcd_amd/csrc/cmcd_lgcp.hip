@@ -49,7 +49,7 @@ struct GemmSeg {
 // bump the block's counter; the LAST one to arrive sums the slabs in fixed order (bitwise deterministic: which
 // workgroup does the summing does not change the arithmetic) and applies the consumer for its 64 columns.  That
 // removes the separate activation / state launches (5.7 us and 13 us of a 61 us evaluation) from the dependent chain.
-enum { EPI_NONE = 0, EPI_ACT = 1, EPI_STEP = 2, EPI_STEP_NONET = 3 };   // NONET: MCD_ULA, the K^-1 slabs are this launch's own
+enum { EPI_NONE = 0, EPI_ACT = 1, EPI_STEP = 2, EPI_STEP_NONET = 3, EPI_ACTB = 4 };   // NONET: MCD_ULA, the K^-1 slabs are this launch's own
 
 struct ActEpi {          // u_out = u + softplus(bias + sum(slabs))      nn.py:45-50,68-69
   const float* bias;     // [IN]
@@ -85,6 +85,22 @@ struct StepEpi {         // evaluation i at z_i: closes step i-1, opens step i (
                              // 2: MCD_ULA_sn (network in the backward kernel only)     mcd_over_orig.py:6-65
 };
 
+// backward activations (consumer of the two IN-wide backward GEMMs): d u = [d u_next +] sum(slabs), d a = d u sigmoid(pre)
+struct LgcpActbArgs {
+  const float* pre;        // [kMP][IN] pre-activation of this layer
+  const float* du_prev;    // [kMP][IN] (mode 1: d u2)
+  const float* u_src;      // [kMP][IN] this layer's input activation to keep (u2 for mode 2, u1 for mode 1)
+  float* du_out;           // [kMP][IN]
+  float* da_out;           // [kMP][IN]
+  float* da_big;           // [(K+1) n][IN]
+  float* u_big;            // [(K+1) n][IN]
+  float* S;                // mode 1: S[e][k]  = sum_m d a1   (row of the table)
+  float* S2;               // mode 1: S2[e][k] = sum_m d u1
+  float* gb;               // mode 2: d b2[k] += sum_m d a2
+  int64_t row0;            // e * n + base
+  int IN, mode;
+};
+
 struct GemmArgs {
   GemmSeg seg[2];
   int nblk0;           // column blocks of segment 0
@@ -94,6 +110,7 @@ struct GemmArgs {
   int epi_seg;         // segment the epilogue applies to (-1: all)
   ActEpi act;
   StepEpi step;
+  LgcpActbArgs actb;
 };
 
 __device__ __forceinline__ float wave_sum64(float v) {
@@ -221,7 +238,7 @@ __device__ __forceinline__ void lgcp_step_tile(const StepEpi& a, const float* sn
 
 // out[ks][m][n] = sum_{k in slice ks, wave w} A[m][k] W[k][n]   (no bias: added when the slabs are summed)
 template <int EPI>
-__global__ __launch_bounds__(64 * (kGemmWaves + (EPI >= EPI_STEP ? 1 : 0))) void lgcp_gemm_kernel(GemmArgs a) {
+__global__ __launch_bounds__(64 * (kGemmWaves + ((EPI == EPI_STEP || EPI == EPI_STEP_NONET) ? 1 : 0))) void lgcp_gemm_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ int s_last;
   const int s = blockIdx.x < a.nblk0 ? 0 : 1;
@@ -230,7 +247,7 @@ __global__ __launch_bounds__(64 * (kGemmWaves + (EPI >= EPI_STEP ? 1 : 0))) void
   const int n0 = (blockIdx.x - (s ? a.nblk0 : 0)) * 64;
   const int ksplit = blockIdx.y;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const bool worker = EPI < EPI_STEP || wv < kGemmWaves;             // EPI_STEP* carry one extra wave (key chain)
+  const bool worker = (EPI != EPI_STEP && EPI != EPI_STEP_NONET) || wv < kGemmWaves;   // EPI_STEP* carry one extra wave (key chain)
   float* As = lds;                                                   // [kStage][kAsLd]  A slice, k-major, particle-minor
   float* red = lds + kStage * kAsLd;                                 // [kQuarters][kMP][64]
   const int kslice = (Kdim + kSplit - 1) / kSplit;
@@ -356,7 +373,50 @@ __global__ __launch_bounds__(64 * (kGemmWaves + (EPI >= EPI_STEP ? 1 : 0))) void
         ac.u_out[m * ac.IN + k] = u[r] + softplus(pre[r]);                        // nn.py:45-50
       }
     }
-  } else if (EPI >= EPI_STEP) {
+  } else if (EPI == EPI_ACTB) {
+    const LgcpActbArgs& ab = a.actb;
+    const int k = n0 + lane, kc = min(k, ab.IN - 1);
+    constexpr int R = kMP / kGemmWaves;
+    float du[R], pr[R], us[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {                      // all loads first, clamped and unpredicated (see lgcp_step_tile)
+      const int mc = min(wv + kGemmWaves * r, a.M - 1);
+      float d = ab.mode == 1 ? ab.du_prev[mc * ab.IN + kc] : 0.f;      // uniform mode
+#pragma unroll
+      for (int q = 0; q < kSplit; ++q)
+        d += __hip_atomic_load(sg.out + ((int64_t)q * kMP + mc) * sg.ldo + kc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      du[r] = d;
+      pr[r] = ab.pre[mc * ab.IN + kc];
+      us[r] = ab.u_src[mc * ab.IN + kc];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float sda = 0.f, sdu = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int m = wv + kGemmWaves * r;
+      if (m < a.M && k < ab.IN) {
+        const float da = du[r] * sigmoid_fast(pr[r]);
+        ab.du_out[m * ab.IN + k] = du[r];
+        ab.da_out[m * ab.IN + k] = da;
+        ab.da_big[(ab.row0 + m) * ab.IN + k] = da;
+        ab.u_big[(ab.row0 + m) * ab.IN + k] = us[r];
+        sda += da; sdu += du[r];
+      }
+    }
+    // sums over the particles of the pass: through LDS across the 8 waves, then ONE writer per column (no atomics; the
+    // launches that touch a column's entry are ordered on the stream)
+    __syncthreads();                                   // the slab-summing pass above is done with `red`
+    red[(wv * 64 + lane) * 2] = sda;
+    red[(wv * 64 + lane) * 2 + 1] = sdu;
+    __syncthreads();
+    if (wv == 0 && k < ab.IN) {
+      float ta = 0.f, tu = 0.f;
+#pragma unroll
+      for (int w = 0; w < kGemmWaves; ++w) { ta += red[(w * 64 + lane) * 2]; tu += red[(w * 64 + lane) * 2 + 1]; }
+      if (ab.mode == 1) { ab.S[k] += ta; ab.S2[k] += tu; }
+      else ab.gb[k] += ta;
+    }
+  } else if (EPI == EPI_STEP || EPI == EPI_STEP_NONET) {
     const StepEpi& st = a.step;
     const int cb = blockIdx.x;
     if (wv < kGemmWaves) {
@@ -534,7 +594,8 @@ int64_t lgcp_workspace_floats(const cmcd_desc& d, int64_t n, int64_t base) { ret
 
 static int lgcp_gemm_attrs() {
   const int gemm_lds = int(size_t(kStage * kAsLd + kQuarters * kMP * 64) * 4);
-  const void* fns[4] = {reinterpret_cast<const void*>(lgcp_gemm_kernel<EPI_NONE>),
+  const void* fns[5] = {reinterpret_cast<const void*>(lgcp_gemm_kernel<EPI_ACTB>),
+                        reinterpret_cast<const void*>(lgcp_gemm_kernel<EPI_NONE>),
                         reinterpret_cast<const void*>(lgcp_gemm_kernel<EPI_ACT>),
                         reinterpret_cast<const void*>(lgcp_gemm_kernel<EPI_STEP>),
                         reinterpret_cast<const void*>(lgcp_gemm_kernel<EPI_STEP_NONET>)};
@@ -927,39 +988,6 @@ __global__ void lgcp_adj_combine_kernel(const float* lo_b, const float* hi_b, co
   geps[k] = hi_e[k] + lo_e[k + 1];
 }
 
-// backward activations: one thread per (particle, hidden unit)
-struct LgcpActbArgs {
-  const float* slab;       // [kSplit][kMP][IN] partials of the incoming GEMM
-  const float* pre;        // [kMP][IN] pre-activation of this layer
-  const float* du_prev;    // [kMP][IN] (mode 1: d u2)
-  const float* u_src;      // [kMP][IN] this layer's input activation to keep (u2 for mode 2, u1 for mode 1)
-  float* du_out;           // [kMP][IN]
-  float* da_out;           // [kMP][IN]
-  float* da_big;           // [(K+1) n][IN]
-  float* u_big;            // [(K+1) n][IN]
-  float* S;                // mode 1: S[e][k]  = sum_m d a1   (row of the table)
-  float* S2;               // mode 1: S2[e][k] = sum_m d u1
-  float* gb;               // mode 2: d b2[k] += sum_m d a2
-  int64_t row0;            // e * n + base
-  int M, IN, mode;
-};
-
-__global__ void lgcp_actb_kernel(LgcpActbArgs a) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
-  if (k >= a.IN) return;
-  float du = a.mode == 1 ? a.du_prev[m * a.IN + k] : 0.f;
-#pragma unroll
-  for (int ks = 0; ks < kSplit; ++ks) du += a.slab[((int64_t)ks * kMP + m) * a.IN + k];
-  const float da = du * sigmoid_fast(a.pre[m * a.IN + k]);
-  a.du_out[m * a.IN + k] = du;
-  a.da_out[m * a.IN + k] = da;
-  a.da_big[(a.row0 + m) * a.IN + k] = da;
-  a.u_big[(a.row0 + m) * a.IN + k] = a.u_src[m * a.IN + k];
-  // sums over the particles of the pass (<= 32 adders per address)
-  if (a.mode == 1) { atomicAdd(a.S + k, da); atomicAdd(a.S2 + k, du); }
-  else atomicAdd(a.gb + k, da);
-}
-
 struct LgcpLamArgs {
   const float* params;
   const float* tc;
@@ -1131,7 +1159,7 @@ static LgcpGradWs lgcp_grad_ws(const cmcd_desc& d, int64_t n) {
   w.gmu_acc = take(kMP * D); w.glam_acc = take(kMP * D);
   w.S = take((K + 1) * IN); w.S2 = take((K + 1) * IN);
   w.gbeta = take(K); w.geps = take(K); w.gfac = take(K + 1); w.gb2 = take(IN);
-  w.counters = take((D + 63) / 64 + (IN + 63) / 64);
+  w.counters = take(2 * ((D + 63) / 64 + (IN + 63) / 64));     // side stream's set | caller's stream's set
   w.zero_hi = o;
   w.adjpart = take((K + 1) * n * ((D + 255) / 256) * 8);
   w.gb_lo = take(K + 1); w.ge_lo = take(K + 1); w.gb_hi = take(K + 1); w.ge_hi = take(K + 1);
@@ -1193,6 +1221,7 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
     // forward recompute at z_e into buffer set e & 1, on stream st: the forward path's three launches (activations
     // fused into the GEMMs; the third has no consumer here: the adjoint step sums its slabs)
     int* side_counters = reinterpret_cast<int*>(gws + g.counters);
+    int* main_counters = side_counters + cbD + cbIN;
     auto forward_at = [&](int e, hipStream_t st) {
       const LgcpFwdSet& f = g.fs[e & 1];
       const int er = ula == 2 ? (e > 0 ? e - 1 : 0) : e;       // MCD_ULA_sn: s(z_e, e - 1)
@@ -1261,29 +1290,27 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
         if (hipEventRecord(ev_bwd[e & 1], stream) != hipSuccess) return CMCD_ERR_HIP;
         continue;
       }
-      // ---- net backward: d u2 = d o W3^T
+      // ---- net backward: d u2 = d o W3^T, then d a2 = d u2 sigmoid(pre2) as the GEMM's consumer
+      gm.counters = main_counters; gm.epi_seg = -1;
       gm.Kdim = D;
       gm.seg[0] = GemmSeg{gws + g.dO, gws + g.wt3, gws + g.du2s, IN, D, IN, IN};
       gm.nblk0 = cbIN;
-      hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_NONE>, dim3(cbIN, kSplit), gblock, gemm_lds, stream, gm);
-      LgcpActbArgs ab{};
-      ab.slab = gws + g.du2s; ab.pre = gws + f.pre2; ab.du_prev = nullptr; ab.u_src = gws + f.u2;
+      LgcpActbArgs& ab = gm.actb;
+      ab.pre = gws + f.pre2; ab.du_prev = nullptr; ab.u_src = gws + f.u2;
       ab.du_out = gws + g.du2; ab.da_out = gws + g.da2; ab.da_big = gws + g.DA2; ab.u_big = gws + g.U2;
-      ab.gb = gws + g.gb2; ab.row0 = row0; ab.M = M; ab.IN = IN; ab.mode = 2;
-      hipLaunchKernelGGL(lgcp_actb_kernel, dim3((IN + 255) / 256, M), dim3(256), 0, stream, ab);
-      // d u1 = d u2 + d a2 W2^T
+      ab.gb = gws + g.gb2; ab.row0 = row0; ab.IN = IN; ab.mode = 2;
+      hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_ACTB>, dim3(cbIN, kSplit), gblock, gemm_lds, stream, gm);
+      // d u1 = d u2 + d a2 W2^T, d a1 = d u1 sigmoid(pre1)
       gm.Kdim = IN;
       gm.seg[0] = GemmSeg{gws + g.da2, gws + g.wt2, gws + g.ts, IN, IN, IN, IN};
       gm.nblk0 = cbIN;
-      hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_NONE>, dim3(cbIN, kSplit), gblock, gemm_lds, stream, gm);
-      ab.slab = gws + g.ts; ab.pre = gws + f.pre1; ab.du_prev = gws + g.du2; ab.u_src = gws + f.u1;
+      ab.pre = gws + f.pre1; ab.du_prev = gws + g.du2; ab.u_src = gws + f.u1;
       ab.du_out = gws + g.du1; ab.da_out = gws + g.da1; ab.da_big = gws + g.DA1; ab.u_big = gws + g.U1;
       {
         const int er = ula == 2 ? (e > 0 ? e - 1 : 0) : e;     // the time index the network saw at this evaluation
         ab.S = gws + g.S + (int64_t)er * IN; ab.S2 = gws + g.S2 + (int64_t)er * IN; ab.mode = 1;
       }
-      hipLaunchKernelGGL(lgcp_actb_kernel, dim3((IN + 255) / 256, M), dim3(256), 0, stream, ab);
-      // d x = d u1[:D] + d a1 W1[:D]^T   |   v K^-1
+      hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_ACTB>, dim3(cbIN, kSplit), gblock, gemm_lds, stream, gm);
       if (!bptt) {   // z detached: no lambda, no Hessian product; this evaluation's buffers are free after actb
         if (hipEventRecord(ev_bwd[e & 1], stream) != hipSuccess) return CMCD_ERR_HIP;
         continue;
