@@ -101,6 +101,57 @@ struct LgcpActbArgs {
   int IN, mode;
 };
 
+struct LgcpAdjArgs {
+  const float* params;
+  const float* tc;
+  const float* sched;        // [K][8] {beta, eps, ...}
+  const float* traj;         // [K+1][n][D]
+  const float* kr;           // [kSplit][kMP][D]
+  const float* sn;           // [kSplit][kMP][D]
+  const float* b3;
+  const float* factor;
+  const float* lamn;         // [kMP][D] lambda_{e+1}
+  const float* gE;           // [kMP][D] g_e
+  float* gprev;              // [kMP][D] g_{e-1}
+  float* dO;                 // [kMP][D] cotangent of o = u2 W3 + b3
+  float* v;                  // [kMP][D] clipmask . a_gp
+  float* lam_part;           // [kMP][D]
+  float* gmu_acc;            // [kMP][D] running d / d vd.mean per particle
+  float* glam_acc;           // [kMP][D]
+  float* part;               // [K+1][n * nbx][8] per-workgroup partial sums {sb, se, r2, sb2, se2, gf} (no atomics)
+  float* DObig;              // [(K+1) n][D]
+  cmcd_layout lay;
+  int64_t n, base;
+  int M, D, K, e, grad_clipping;
+  float omega;               // weight of every particle's loss (reparameterised gradient of the mean)
+  const float* omega_vec;    // [n] VarGrad: weight of particle p's LOG-WEIGHT (cmcd_vargrad_weights), or nullptr
+  const uint32_t* gktab;     // [K][n][2] noise keys of the forward pass (VarGrad: z_{e+1} - mean = sigma eps_e, exactly)
+  int ula;                   // 0: CAIS; 1: MCD_ULA (no network); 2: MCD_ULA_sn (network in the backward kernel only)
+  int bptt;                  // 1: gradient through the trajectory (lambda recursion); 0: z detached (mcd_cais_var.py:59,79)
+  int var_mode;              // MCD_CAIS_var_sn: clip at 1e2 and clip grad log q too (mcd_cais_var.py:29-36)
+};
+
+struct LgcpLamArgs {
+  const float* params;
+  const float* tc;
+  const float* traj;
+  const float* dxf;        // [kSplit][kMP][D]   d a1 W1[:D]^T partials
+  const float* hv;         // [kSplit][kMP][D]   v K^-1 partials
+  const float* du1;        // [kMP][IN]
+  const float* v;          // [kMP][D]
+  const float* lam_part;   // [kMP][D]
+  const float* gprev;      // [kMP][D]
+  float* lamn;             // [kMP][D]
+  float* gE;               // [kMP][D]
+  float* gmu_acc;
+  float* glam_acc;
+  cmcd_layout lay;
+  int64_t n, base;
+  int M, D, IN, e;
+  float omega;
+  int no_net;              // MCD_ULA: d x = 0 (no network to go back through)
+};
+
 struct GemmArgs {
   GemmSeg seg[2];
   int nblk0;           // column blocks of segment 0
@@ -117,6 +168,142 @@ __device__ __forceinline__ float wave_sum64(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
+}
+
+// One element (particle p of the pass, column j < D) of the adjoint step at evaluation a.e; ln_in / ge_in are
+// lambda_{e+1}[p][j] and g_e[p][j] (reparameterised gradient only); t accumulates {sb, se, r2, sb2, se2, gf}.
+__device__ __forceinline__ void lgcp_adj_elem(const LgcpAdjArgs& a, int p, int j, float ln_in, float ge_in, float (&t)[6]) {
+  const int D = a.D, e = a.e, K = a.K;
+  const float* counts = a.tc + (int64_t)D * D;
+  const float pa = a.tc[(int64_t)D * D + D + 1];
+  const float clipv = a.var_mode ? 1e2f : 1e3f;
+  const bool clip_p = a.grad_clipping != 0, clip_q = clip_p && a.var_mode;
+  const bool bptt = a.bptt != 0;
+  const float om = a.omega_vec ? -a.omega_vec[a.base + p] : a.omega;      // weight of this particle's loss = -w
+  const float pb = e > 0 ? a.sched[8 * (e - 1)] : 0.f, pe = e > 0 ? a.sched[8 * (e - 1) + 1] : 1.f;
+  const float be = e < K ? a.sched[8 * e] : 0.f, ee = e < K ? a.sched[8 * e + 1] : 1.f;
+  const bool no_net = a.ula == 1;
+  const float fsn = a.ula ? 0.f : 1.f;
+  const float fac = no_net ? 0.f : a.factor[0];
+  const float* ze = a.traj + ((int64_t)e * a.n + a.base + p) * D;
+  const float* zpv = a.traj + ((int64_t)(e > 0 ? e - 1 : 0) * a.n + a.base + p) * D;
+  const float* znv = a.traj + ((int64_t)(e < K ? e + 1 : K) * a.n + a.base + p) * D;
+  {
+    const float z = ze[j];
+    float kr = 0.f, o = no_net ? 0.f : a.b3[j];
+#pragma unroll
+    for (int ks = 0; ks < kSplit; ++ks) {
+      kr += a.kr[((int64_t)ks * kMP + p) * D + j];
+      o += no_net ? 0.f : a.sn[((int64_t)ks * kMP + p) * D + j];
+    }
+    const float s = o * fac;
+    const float graw = -kr + counts[j] - pa * expf(z);
+    const float m = (!clip_p || fabsf(graw) < clipv) ? 1.0f : 0.f;
+    const float gp = clip_p ? fminf(fmaxf(graw, -clipv), clipv) : graw;
+    const float mean = a.params[a.lay.vd_mean + j];
+    const float sd = expf(a.params[a.lay.vd_logdiag + j]);
+    const float qiv = 1.0f / (sd * sd);
+    const float gqraw = -(z - mean) * qiv;
+    const float mq = (!clip_q || fabsf(gqraw) < clipv) ? 1.0f : 0.f;
+    const float gq = clip_q ? fminf(fmaxf(gqraw, -clipv), clipv) : gqraw;
+    float a_s = 0.f, a_gp = 0.f, a_gq = 0.f, lam = 0.f, gpv = 0.f;
+    if (e > 0) {   // backward kernel of step e-1: d loss / d (its mean) = -r / sigma^2
+      const float ub = -1.0f * (pb * gp + (1.0f - pb) * gq);
+      // r = z_{e-1} - (z - pe ub + pe s), with the O(1) states subtracted first (exact in float32: they differ by a step)
+      const float r = (zpv[j] - z) + pe * (ub - s);
+      gpv = -om * r * (0.5f / pe);
+      a_s += pe * gpv; a_gp += pe * pb * gpv; a_gq += pe * (1.0f - pb) * gpv; lam += gpv;
+      t[0] += (gp - gq) * gpv; t[1] += (s - ub) * gpv; t[2] += om * r * r;
+    }
+    if (e < K) {   // forward kernel of step e
+      const float uf = -1.0f * (be * gp + (1.0f - be) * gq);
+      float df = (znv[j] - z) + ee * (uf + fsn * s);      // z_{e+1} - (z - ee uf - ee s), same ordering
+      if (!bptt) {
+        // the weights omega_p sum to zero and |df|^2 / (4 eps^2) is ~1e5 per particle: the float32 difference above loses
+        // the digits that survive the cancellation.  z_{e+1} = mean + sigma eps_e, so redraw eps_e (mcd_cais.py:66-67)
+        const int H = (D + 1) / 2, jj = j < H ? j : j - H;
+        const uint32_t* gk = a.gktab + ((int64_t)e * a.n + a.base + p) * 2;
+        uint32_t y0 = jj, y1 = (H + jj < D) ? H + jj : 0;
+        threefry2x32(gk[0], gk[1], y0, y1);
+        df = a.sched[8 * e + 2] * bits_to_normal(j < H ? y0 : y1);
+      }
+      const float nsig = df * (0.5f / ee);
+      // cotangent of the kernel's mean: lambda_{e+1} when z_{e+1} = mean + noise carries the gradient on; with z detached
+      // the density log N(z_{e+1}; mean, sigma) itself: d loss / d mean = +df / sigma^2
+      const float ln = bptt ? ln_in : om * nsig;
+      a_s -= fsn * ee * ln; a_gp += ee * be * ln; a_gq += ee * (1.0f - be) * ln;
+      if (bptt) lam += ln - ge_in;
+      t[3] += (gp - gq) * ln;
+      t[4] += bptt ? (nsig - uf - fsn * s) * ln : (-uf - fsn * s) * ln + om * df * df * (0.25f / (ee * ee));
+    }
+    if (e == K) lam -= om * graw;
+    if (e == 0) lam += om * gq;
+    a.gmu_acc[p * D + j] += a_gq * mq * qiv;
+    a.glam_acc[p * D + j] += a_gq * mq * (-2.0f * gqraw) + ((!bptt && e == 0) ? -om : 0.f);   // z detached: d log q(z_0(theta)) / d logdiag = -1
+    lam -= a_gq * qiv;
+    t[5] += a_s * o;
+    if (!no_net) {
+      a.dO[p * D + j] = a_s * fac;
+      a.DObig[((int64_t)e * a.n + a.base + p) * D + j] = a_s * fac;
+    }
+    if (bptt) {
+      a.gprev[p * D + j] = gpv;
+      a.v[p * D + j] = m * a_gp;
+      a.lam_part[p * D + j] = lam;
+    }
+  }
+}
+
+// standalone launch: one wave per (64-column block, particle) — the slot layout of the fused consumer
+__global__ __launch_bounds__(64) void lgcp_adj_step_kernel(LgcpAdjArgs a) {
+  const int p = blockIdx.y, D = a.D, lane = threadIdx.x, j = blockIdx.x * 64 + lane;
+  float t[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (j < D) {
+    const bool live = a.bptt != 0 && a.e < a.K;
+    lgcp_adj_elem(a, p, j, live ? a.lamn[p * D + j] : 0.f, live ? a.gE[p * D + j] : 0.f, t);
+  }
+#pragma unroll
+  for (int q = 0; q < 6; ++q) t[q] = wave_sum64(t[q]);
+  if (lane == 0) {
+    float* o = a.part + (((int64_t)a.e * a.n + a.base + p) * gridDim.x + blockIdx.x) * 8;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) o[q] = t[q];
+  }
+}
+
+// lambda_e of element (m, j) from the summed products dx = d u1_j + (d a1 W1[:D]^T)_j and hv = (v K^-1)_j; also hands g_e on
+__device__ __forceinline__ void lgcp_lam_elem(const LgcpLamArgs& a, int m, int j, float dx, float hv, float& lam_out, float& ge_out) {
+  const int D = a.D, idx = m * D + j;
+  const float pa = a.tc[(int64_t)D * D + D + 1];
+  const float z = a.traj[((int64_t)a.e * a.n + a.base + m) * D + j];
+  const float lam = a.lam_part[idx] + dx - hv - pa * expf(z) * a.v[idx];   // H_p v = -K^-1 v - a e^z v
+  a.lamn[idx] = lam;
+  const float ge = a.gprev[idx];
+  a.gE[idx] = ge;
+  if (a.e == 0) {
+    const float mean = a.params[a.lay.vd_mean + j];
+    const float sd = expf(a.params[a.lay.vd_logdiag + j]);
+    const float qiv = 1.0f / (sd * sd), dz = z - mean;
+    const float gq = -dz * qiv;
+    a.gmu_acc[idx] += lam - a.omega * gq;
+    a.glam_acc[idx] += lam * dz + a.omega * (dz * dz * qiv - 1.0f);
+  }
+  lam_out = lam;
+  ge_out = ge;
+}
+
+__global__ void lgcp_lam_finish_kernel(LgcpLamArgs a) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.M * a.D) return;
+  const int m = idx / a.D, j = idx - m * a.D, D = a.D;
+  float dx = a.no_net ? 0.f : a.du1[m * a.IN + j], hv = 0.f;     // residual path: d x_j += d u1_j
+#pragma unroll
+  for (int ks = 0; ks < kSplit; ++ks) {
+    dx += a.no_net ? 0.f : a.dxf[((int64_t)ks * kMP + m) * D + j];
+    hv += a.hv[((int64_t)ks * kMP + m) * D + j];
+  }
+  float lam, ge;
+  lgcp_lam_elem(a, m, j, dx, hv, lam, ge);
 }
 
 // (G, H) = split(gen); gen' = second(split(H))     mcd_cais.py:66-67,87
@@ -819,133 +1006,6 @@ __global__ void lgcp_transpose_kernel(const float* __restrict__ src, float* __re
   }
 }
 
-struct LgcpAdjArgs {
-  const float* params;
-  const float* tc;
-  const float* sched;        // [K][8] {beta, eps, ...}
-  const float* traj;         // [K+1][n][D]
-  const float* kr;           // [kSplit][kMP][D]
-  const float* sn;           // [kSplit][kMP][D]
-  const float* b3;
-  const float* factor;
-  const float* lamn;         // [kMP][D] lambda_{e+1}
-  const float* gE;           // [kMP][D] g_e
-  float* gprev;              // [kMP][D] g_{e-1}
-  float* dO;                 // [kMP][D] cotangent of o = u2 W3 + b3
-  float* v;                  // [kMP][D] clipmask . a_gp
-  float* lam_part;           // [kMP][D]
-  float* gmu_acc;            // [kMP][D] running d / d vd.mean per particle
-  float* glam_acc;           // [kMP][D]
-  float* part;               // [K+1][n * nbx][8] per-workgroup partial sums {sb, se, r2, sb2, se2, gf} (no atomics)
-  float* DObig;              // [(K+1) n][D]
-  cmcd_layout lay;
-  int64_t n, base;
-  int M, D, K, e, grad_clipping;
-  float omega;               // weight of every particle's loss (reparameterised gradient of the mean)
-  const float* omega_vec;    // [n] VarGrad: weight of particle p's LOG-WEIGHT (cmcd_vargrad_weights), or nullptr
-  const uint32_t* gktab;     // [K][n][2] noise keys of the forward pass (VarGrad: z_{e+1} - mean = sigma eps_e, exactly)
-  int ula;                   // 0: CAIS; 1: MCD_ULA (no network); 2: MCD_ULA_sn (network in the backward kernel only)
-  int bptt;                  // 1: gradient through the trajectory (lambda recursion); 0: z detached (mcd_cais_var.py:59,79)
-  int var_mode;              // MCD_CAIS_var_sn: clip at 1e2 and clip grad log q too (mcd_cais_var.py:29-36)
-};
-
-__global__ __launch_bounds__(256) void lgcp_adj_step_kernel(LgcpAdjArgs a) {
-  __shared__ float sh6[24];
-  const int p = blockIdx.y, D = a.D, e = a.e, K = a.K;
-  const float* counts = a.tc + (int64_t)D * D;
-  const float pa = a.tc[(int64_t)D * D + D + 1];
-  const float clipv = a.var_mode ? 1e2f : 1e3f;
-  const bool clip_p = a.grad_clipping != 0, clip_q = clip_p && a.var_mode;
-  const bool bptt = a.bptt != 0;
-  const float om = a.omega_vec ? -a.omega_vec[a.base + p] : a.omega;      // weight of this particle's loss = -w
-  const float pb = e > 0 ? a.sched[8 * (e - 1)] : 0.f, pe = e > 0 ? a.sched[8 * (e - 1) + 1] : 1.f;
-  const float be = e < K ? a.sched[8 * e] : 0.f, ee = e < K ? a.sched[8 * e + 1] : 1.f;
-  const bool no_net = a.ula == 1;
-  const float fsn = a.ula ? 0.f : 1.f;
-  const float fac = no_net ? 0.f : a.factor[0];
-  const float* ze = a.traj + ((int64_t)e * a.n + a.base + p) * D;
-  const float* zpv = a.traj + ((int64_t)(e > 0 ? e - 1 : 0) * a.n + a.base + p) * D;
-  const float* znv = a.traj + ((int64_t)(e < K ? e + 1 : K) * a.n + a.base + p) * D;
-  float sb = 0.f, se = 0.f, r2 = 0.f, sb2 = 0.f, se2 = 0.f, gf = 0.f;
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;     // one element per thread: a single memory round trip
-  if (j < D) {
-    const float z = ze[j];
-    float kr = 0.f, o = no_net ? 0.f : a.b3[j];
-#pragma unroll
-    for (int ks = 0; ks < kSplit; ++ks) {
-      kr += a.kr[((int64_t)ks * kMP + p) * D + j];
-      o += no_net ? 0.f : a.sn[((int64_t)ks * kMP + p) * D + j];
-    }
-    const float s = o * fac;
-    const float graw = -kr + counts[j] - pa * expf(z);
-    const float m = (!clip_p || fabsf(graw) < clipv) ? 1.0f : 0.f;
-    const float gp = clip_p ? fminf(fmaxf(graw, -clipv), clipv) : graw;
-    const float mean = a.params[a.lay.vd_mean + j];
-    const float sd = expf(a.params[a.lay.vd_logdiag + j]);
-    const float qiv = 1.0f / (sd * sd);
-    const float gqraw = -(z - mean) * qiv;
-    const float mq = (!clip_q || fabsf(gqraw) < clipv) ? 1.0f : 0.f;
-    const float gq = clip_q ? fminf(fmaxf(gqraw, -clipv), clipv) : gqraw;
-    float a_s = 0.f, a_gp = 0.f, a_gq = 0.f, lam = 0.f, gpv = 0.f;
-    if (e > 0) {   // backward kernel of step e-1: d loss / d (its mean) = -r / sigma^2
-      const float ub = -1.0f * (pb * gp + (1.0f - pb) * gq);
-      // r = z_{e-1} - (z - pe ub + pe s), with the O(1) states subtracted first (exact in float32: they differ by a step)
-      const float r = (zpv[j] - z) + pe * (ub - s);
-      gpv = -om * r * (0.5f / pe);
-      a_s += pe * gpv; a_gp += pe * pb * gpv; a_gq += pe * (1.0f - pb) * gpv; lam += gpv;
-      sb += (gp - gq) * gpv; se += (s - ub) * gpv; r2 += om * r * r;
-    }
-    if (e < K) {   // forward kernel of step e
-      const float uf = -1.0f * (be * gp + (1.0f - be) * gq);
-      float df = (znv[j] - z) + ee * (uf + fsn * s);      // z_{e+1} - (z - ee uf - ee s), same ordering
-      if (!bptt) {
-        // the weights omega_p sum to zero and |df|^2 / (4 eps^2) is ~1e5 per particle: the float32 difference above loses
-        // the digits that survive the cancellation.  z_{e+1} = mean + sigma eps_e, so redraw eps_e (mcd_cais.py:66-67)
-        const int H = (D + 1) / 2, jj = j < H ? j : j - H;
-        const uint32_t* gk = a.gktab + ((int64_t)e * a.n + a.base + p) * 2;
-        uint32_t y0 = jj, y1 = (H + jj < D) ? H + jj : 0;
-        threefry2x32(gk[0], gk[1], y0, y1);
-        df = a.sched[8 * e + 2] * bits_to_normal(j < H ? y0 : y1);
-      }
-      const float nsig = df * (0.5f / ee);
-      // cotangent of the kernel's mean: lambda_{e+1} when z_{e+1} = mean + noise carries the gradient on; with z detached
-      // the density log N(z_{e+1}; mean, sigma) itself: d loss / d mean = +df / sigma^2
-      const float ln = bptt ? a.lamn[p * D + j] : om * nsig;
-      a_s -= fsn * ee * ln; a_gp += ee * be * ln; a_gq += ee * (1.0f - be) * ln;
-      if (bptt) lam += ln - a.gE[p * D + j];
-      sb2 += (gp - gq) * ln;
-      se2 += bptt ? (nsig - uf - fsn * s) * ln : (-uf - fsn * s) * ln + om * df * df * (0.25f / (ee * ee));
-    }
-    if (e == K) lam -= om * graw;
-    if (e == 0) lam += om * gq;
-    a.gmu_acc[p * D + j] += a_gq * mq * qiv;
-    a.glam_acc[p * D + j] += a_gq * mq * (-2.0f * gqraw) + ((!bptt && e == 0) ? -om : 0.f);   // z detached: d log q(z_0(theta)) / d logdiag = -1
-    lam -= a_gq * qiv;
-    gf += a_s * o;
-    if (!no_net) {
-      a.dO[p * D + j] = a_s * fac;
-      a.DObig[((int64_t)e * a.n + a.base + p) * D + j] = a_s * fac;
-    }
-    if (bptt) {
-      a.gprev[p * D + j] = gpv;
-      a.v[p * D + j] = m * a_gp;
-      a.lam_part[p * D + j] = lam;
-    }
-  }
-  // the six sums through LDS together: one barrier instead of twelve
-  float t6[6] = {sb, se, r2, sb2, se2, gf};
-#pragma unroll
-  for (int q = 0; q < 6; ++q) t6[q] = wave_sum64(t6[q]);
-  if ((threadIdx.x & 63) == 0)
-#pragma unroll
-    for (int q = 0; q < 6; ++q) sh6[(threadIdx.x >> 6) * 6 + q] = t6[q];
-  __syncthreads();
-  if (threadIdx.x < 6) {
-    float* o = a.part + (((int64_t)e * a.n + a.base + p) * gridDim.x + blockIdx.x) * 8;
-    o[threadIdx.x] = sh6[threadIdx.x] + sh6[6 + threadIdx.x] + sh6[12 + threadIdx.x] + sh6[18 + threadIdx.x];
-  }
-}
-
 // gbeta / geps / d factor_sn from the adjoint step's per-workgroup partials: one wave per evaluation e, fixed order
 struct LgcpAdjRedArgs {
   const float* part;     // [K+1][slots][8]
@@ -986,52 +1046,6 @@ __global__ void lgcp_adj_combine_kernel(const float* lo_b, const float* hi_b, co
   if (k >= K) return;
   gbeta[k] = hi_b[k] + lo_b[k + 1];
   geps[k] = hi_e[k] + lo_e[k + 1];
-}
-
-struct LgcpLamArgs {
-  const float* params;
-  const float* tc;
-  const float* traj;
-  const float* dxf;        // [kSplit][kMP][D]   d a1 W1[:D]^T partials
-  const float* hv;         // [kSplit][kMP][D]   v K^-1 partials
-  const float* du1;        // [kMP][IN]
-  const float* v;          // [kMP][D]
-  const float* lam_part;   // [kMP][D]
-  const float* gprev;      // [kMP][D]
-  float* lamn;             // [kMP][D]
-  float* gE;               // [kMP][D]
-  float* gmu_acc;
-  float* glam_acc;
-  cmcd_layout lay;
-  int64_t n, base;
-  int M, D, IN, e;
-  float omega;
-  int no_net;              // MCD_ULA: d x = 0 (no network to go back through)
-};
-
-__global__ void lgcp_lam_finish_kernel(LgcpLamArgs a) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= a.M * a.D) return;
-  const int m = idx / a.D, j = idx - m * a.D, D = a.D;
-  const float pa = a.tc[(int64_t)D * D + D + 1];
-  const float z = a.traj[((int64_t)a.e * a.n + a.base + m) * D + j];
-  float dx = a.no_net ? 0.f : a.du1[m * a.IN + j], hv = 0.f;     // residual path: d x_j += d u1_j
-#pragma unroll
-  for (int ks = 0; ks < kSplit; ++ks) {
-    dx += a.no_net ? 0.f : a.dxf[((int64_t)ks * kMP + m) * D + j];
-    hv += a.hv[((int64_t)ks * kMP + m) * D + j];
-  }
-  const float lam = a.lam_part[idx] + dx - hv - pa * expf(z) * a.v[idx];   // H_p v = -K^-1 v - a e^z v
-  a.lamn[idx] = lam;
-  a.gE[idx] = a.gprev[idx];
-  if (a.e == 0) {
-    const float mean = a.params[a.lay.vd_mean + j];
-    const float sd = expf(a.params[a.lay.vd_logdiag + j]);
-    const float qiv = 1.0f / (sd * sd), dz = z - mean;
-    const float gq = -dz * qiv;
-    a.gmu_acc[idx] += lam - a.omega * gq;
-    a.glam_acc[idx] += lam * dz + a.omega * (dz * dz * qiv - 1.0f);
-  }
 }
 
 // C[Ma][Nb] (ldc) += sum_r A[r][Ma]^T B[r][Nb]: contraction over the (K+1) n stored rows on the matrix cores.
@@ -1161,7 +1175,7 @@ static LgcpGradWs lgcp_grad_ws(const cmcd_desc& d, int64_t n) {
   w.gbeta = take(K); w.geps = take(K); w.gfac = take(K + 1); w.gb2 = take(IN);
   w.counters = take(2 * ((D + 63) / 64 + (IN + 63) / 64));     // side stream's set | caller's stream's set
   w.zero_hi = o;
-  w.adjpart = take((K + 1) * n * ((D + 255) / 256) * 8);
+  w.adjpart = take((K + 1) * n * ((D + 63) / 64) * 8);
   w.gb_lo = take(K + 1); w.ge_lo = take(K + 1); w.gb_hi = take(K + 1); w.ge_hi = take(K + 1);
   w.total = o;
   return w;
@@ -1275,7 +1289,7 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
       aa.DObig = gws + g.DO; aa.lay = lay; aa.n = n; aa.base = base;
       aa.M = M; aa.D = D; aa.K = K; aa.e = e; aa.grad_clipping = d.grad_clipping; aa.omega = omega;
       aa.ula = ula; aa.omega_vec = omega_vec; aa.gktab = reinterpret_cast<const uint32_t*>(ws + w.gktab); aa.bptt = bptt ? 1 : 0; aa.var_mode = d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0;
-      hipLaunchKernelGGL(lgcp_adj_step_kernel, dim3((D + 255) / 256, M), dim3(256), 0, stream, aa);
+      hipLaunchKernelGGL(lgcp_adj_step_kernel, dim3(cbD, M), dim3(64), 0, stream, aa);
       if (!net) {   // MCD_ULA: lambda_e = lam_part - H_p v, one GEMM
         gm.Kdim = D; gm.Kdim1 = 0;
         gm.seg[0] = GemmSeg{gws + g.v, kinv, gws + g.hv, D, D, D, D};
@@ -1348,7 +1362,7 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
   hipLaunchKernelGGL(lgcp_colsum_kernel, dim3((IN + 255) / 256), dim3(256), 0, stream, gws + g.gb2, (int64_t)1, IN, IN, grad + lay.g_b2, 1.0f, 0);
   }
   {
-    const int slots = (int)(n * ((D + 255) / 256));
+    const int slots = (int)(n * cbD);
     LgcpAdjRedArgs ra{gws + g.adjpart, ws + sw.sched, gws + g.gb_lo, gws + g.ge_lo, gws + g.gb_hi, gws + g.ge_hi, gws + g.gfac,
                       K, slots};
     hipLaunchKernelGGL(lgcp_adj_reduce_kernel, dim3(K + 1), dim3(64), 0, stream, ra);
