@@ -141,8 +141,9 @@ int cmcd_profile_collect(double* total_ms, int64_t* launches);
  *                         for multi-GPU) statistics; n_total = global particle count.
  *   cmcd_bound_var_grad   grad[n_params] (overwritten; zeros for leaves without gradient) =
  *                         sum_n omega_n d w_n / d params_flat.  Across ranks: all-reduce(sum) of grad.
- * MCD_CAIS_var_sn only; kernel instances exist for the BASELINE nets (dds 64; geffner 22 / 58 / 132),
- * CMCD_ERR_UNSUPPORTED otherwise. */
+ * MCD_CAIS_var_sn only; kernel instances exist for the BASELINE nets (dds 64; geffner widths up to 144 on the
+ * 2-d targets, 64 on funnel) and lgcp (geffner, any width: the launch-sequence reverse sweep with z detached —
+ * through cmcd_bound_var_forward + cmcd_bound_var_grad_kept only); CMCD_ERR_UNSUPPORTED otherwise. */
 int64_t cmcd_grad_workspace_bytes(const cmcd_desc* desc, int64_t n);
 int cmcd_vargrad_weights(const float* loss, const double* stats, int64_t n, int64_t n_total, float* omega,
                          void* stream);
@@ -169,9 +170,9 @@ int cmcd_bound_var_grad_kept(const cmcd_desc* desc, const cmcd_layout* layout, c
  * One call = forward (losses, z_K, statistics as cmcd_bound_forward; the trajectory z_0..z_K is kept in
  * the workspace) + reverse sweep.  grad[n_params] (overwritten) = omega * sum_n d loss_n / d params_flat;
  * omega = d value / d loss_n = 1 / N_total (across ranks: all-reduce(sum) of grad).
- * Also MCD_ULA_sn and MCD_ULA (/root/reference/src/mcd_over_orig.py; 2-d targets and funnel).
- * MCD_CAIS_sn with targets gmm / funnel / many_gmm and the BASELINE nets (dds 64; geffner 22 / 58), and lgcp
- * (geffner, any width: launch-sequence reverse sweep); CMCD_ERR_UNSUPPORTED otherwise (width 132 on the 2-d targets). */
+ * Also MCD_ULA_sn and MCD_ULA (/root/reference/src/mcd_over_orig.py), on every target.
+ * Targets gmm / funnel / many_gmm with the BASELINE nets (dds 64; geffner widths up to 144 on the 2-d targets,
+ * 64 on funnel), and lgcp (geffner, any width: launch-sequence reverse sweep); CMCD_ERR_UNSUPPORTED otherwise. */
 int64_t cmcd_bound_grad_workspace_bytes(const cmcd_desc* desc, int64_t n);
 int cmcd_bound_grad(const cmcd_desc* desc, const cmcd_layout* layout, const int32_t* seeds, int64_t n,
                     const float* params, int64_t n_params, const float* target_consts, int64_t n_target,
