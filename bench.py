@@ -155,14 +155,26 @@ def main():
         return mcdbm.bound_forward(s, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"],
                                    eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
 
-    # Multi-GPU: one RCCL all-gather of the 40-byte statistics vector + one merge kernel per step.
-    gathered = torch.zeros(world * parallel.NSTATS, dtype=torch.float64, device=device)
+    # Multi-GPU: one RCCL all-gather of the 40-byte statistics vector + one merge kernel per step.  The collective is
+    # latency-only (~20 us against a 340 us step), so it is taken off the launch stream: torch's process group runs it on
+    # its own stream (async_op=True) behind an event on the forward of step k, and the launch stream waits for it only
+    # after the forward of step k+1 has been enqueued — the statistics of step k are merged one step late, every step's
+    # all-gather and merge still run inside the timed region (the last one is drained before the closing barrier).
+    gathered = [torch.zeros(world * parallel.NSTATS, dtype=torch.float64, device=device) for _ in range(2)]
+    pending = []          # [(work, buffer, stats kept alive)] of the step whose all-gather is in flight
 
-    def step():
+    def drain():
+        work, buf, _ = pending.pop()
+        work.wait()
+        return parallel.merge_stats(buf.view(world, parallel.NSTATS))
+
+    def step(k):
         losses, z, stats = forward(seeds)
         if use_dist:
-            dist.all_gather_into_tensor(gathered, stats)
-            stats = parallel.merge_stats(gathered.view(world, parallel.NSTATS))
+            work = dist.all_gather_into_tensor(gathered[k & 1], stats, async_op=True)
+            merged = drain() if pending else None
+            pending.append((work, gathered[k & 1], stats))
+            stats = merged
         return losses, z, stats
 
     def barrier():
@@ -170,13 +182,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(k)
+    if pending:
+        drain()
     barrier()
     _lib.profile_enable(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        losses, z, stats = step()
+    for k in range(args.steps):
+        losses, z, stats = step(k)
+    if pending:
+        stats = drain()   # global statistics of the last step
     barrier()
     elapsed = time.perf_counter() - t0
     kern_ms, launches = _lib.profile_collect()
@@ -210,8 +226,11 @@ def main():
     # which trajectory kernel the library's auto-selection ran (cmcd_kernels.hip: cooperative up to 512 tiles,
     # 256 for nets wider than 128; CMCD_KERNEL_VARIANT pins it)
     tiles = (n + 15) // 16
-    coop = mcdbm.KERNEL_VARIANT == 2 or (mcdbm.KERNEL_VARIANT == 0 and tiles <= (256 if spec.width >= 128 else 512))
+    coop = mcdbm.KERNEL_VARIANT in (2, 3, 4) or (mcdbm.KERNEL_VARIANT == 0 and tiles <= (256 if spec.width >= 128 else 512))
     kernel_name = "coop_kernel" if coop else "traj_kernel"
+    if coop:   # 8-particle tiles (twice the workgroups) while each still gets a CU; instances exist for widths <= 64
+        half = mcdbm.KERNEL_VARIANT == 4 or (mcdbm.KERNEL_VARIANT != 3 and n <= 2048 and spec.width <= 64)
+        kernel_name += "<8-particle tiles>" if half else "<16-particle tiles>"
 
     if cfg["model"] == "lgcp":
         kernel_name = "lgcp launch sequence (skinny GEMMs + state kernels)"

@@ -47,7 +47,8 @@ struct TrajArgs {
 // cmcd_coop.hip: the CU-cooperative variant (one workgroup per 16-particle tile).
 // Returns nullptr-equivalent (false) when no instance exists for this (target, arch, dim, T).
 bool coop_available(const cmcd_desc& d, int T);
-int coop_launch(const cmcd_desc& d, const TrajArgs& ta, void* stream);
+bool coop_half_available(const cmcd_desc& d, int T);   // the 8-particle-tile instances (batches of <= 2048 particles)
+int coop_launch(const cmcd_desc& d, const TrajArgs& ta, bool half, void* stream);
 
 
 // cmcd_lgcp.hip: the d = 1600 path (per-bridge launch sequence)

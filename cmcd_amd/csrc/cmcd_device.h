@@ -203,16 +203,22 @@ __device__ __forceinline__ float group_max(float v) {
 __device__ __forceinline__ float xor8(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));
 }
+// rotation by 4 inside each 16-lane row (DPP row_ror:4)
+__device__ __forceinline__ float ror4(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));
+}
 // sum / max over the LP lanes that share a particle: LP = 4 -> lanes {c, c+16, c+32, c+48};
-// LP = 8 -> lanes {c8 + 8 s, s < 8}
+// LP = 8 -> lanes {c8 + 8 s, s < 8}; LP = 16 -> lanes {c4 + 4 s, s < 16}
 template <int LP>
 __device__ __forceinline__ float part_sum(float v) {
-  if (LP == 8) v += xor8(v);
+  if (LP >= 8) v += xor8(v);
+  if (LP == 16) v += ror4(v);
   return group_sum(v);
 }
 template <int LP>
 __device__ __forceinline__ float part_max(float v) {
-  if (LP == 8) v = fmaxf(v, xor8(v));
+  if (LP >= 8) v = fmaxf(v, xor8(v));
+  if (LP == 16) v = fmaxf(v, ror4(v));
   return group_max(v);
 }
 // sum over the 16 lanes of a row (the 16 particles of a tile, for a value held per particle), DPP only:
@@ -260,19 +266,22 @@ struct Target<CMCD_TARGET_MANY_GMM, 2> {
     float d2[10], dx[10], dy[10], dmin;
   };
   // `sub` in [0, LP): which share of the components this lane owns
+  // LP = 16 does not divide 40: the last slot of lanes sub >= 8 is empty (d2 = +inf -> weight exp2(-inf) = 0)
   template <int LP>
   __device__ static __forceinline__ void pass1(const float (&z)[2], int sub, const float* tc, State& st) {
-    constexpr int kQ = kFastMix / LP;
+    constexpr int kQ = (kFastMix + LP - 1) / LP;
+    constexpr bool kRagged = kFastMix % LP != 0;
     const int nm = __float_as_int(tc[2]);
     const float2* mu = reinterpret_cast<const float2*>(tc + kLdsHeader);
     float dmin = INFINITY;
     if (nm == kFastMix) {
 #pragma unroll
       for (int q = 0; q < kQ; ++q) {
-        const float2 mk = mu[sub + LP * q];
+        const bool has = !kRagged || sub + LP * q < kFastMix;
+        const float2 mk = has ? mu[sub + LP * q] : float2{0.f, 0.f};
         st.dx[q] = z[0] - mk.x;
         st.dy[q] = z[1] - mk.y;
-        st.d2[q] = fmaf(st.dx[q], st.dx[q], st.dy[q] * st.dy[q]);
+        st.d2[q] = has ? fmaf(st.dx[q], st.dx[q], st.dy[q] * st.dy[q]) : INFINITY;
         dmin = fminf(dmin, st.d2[q]);
       }
     } else {
@@ -292,26 +301,28 @@ struct Target<CMCD_TARGET_MANY_GMM, 2> {
   };
   template <int LP>
   __device__ static __forceinline__ void load_means(int sub, const float* tc, Means& m) {
-    constexpr int kQ = kFastMix / LP;
+    constexpr int kQ = (kFastMix + LP - 1) / LP;
     const float2* mu = reinterpret_cast<const float2*>(tc + kLdsHeader);
     m.fast = __float_as_int(tc[2]) == kFastMix;
 #pragma unroll
     for (int q = 0; q < kQ; ++q) {
-      const float2 mk = m.fast ? mu[sub + LP * q] : float2{0.f, 0.f};
+      const float2 mk = (m.fast && sub + LP * q < kFastMix) ? mu[sub + LP * q] : float2{0.f, 0.f};
       m.mx[q] = mk.x;
       m.my[q] = mk.y;
     }
   }
   template <int LP>
   __device__ static __forceinline__ void pass1r(const float (&z)[2], int sub, const float* tc, const Means& m, State& st) {
-    constexpr int kQ = kFastMix / LP;
+    constexpr int kQ = (kFastMix + LP - 1) / LP;
+    constexpr bool kRagged = kFastMix % LP != 0;
     if (!m.fast) { pass1<LP>(z, sub, tc, st); return; }
     float dmin = INFINITY;
 #pragma unroll
     for (int q = 0; q < kQ; ++q) {
       st.dx[q] = z[0] - m.mx[q];
       st.dy[q] = z[1] - m.my[q];
-      st.d2[q] = fmaf(st.dx[q], st.dx[q], st.dy[q] * st.dy[q]);
+      const float d2 = fmaf(st.dx[q], st.dx[q], st.dy[q] * st.dy[q]);
+      st.d2[q] = (!kRagged || sub + LP * q < kFastMix) ? d2 : INFINITY;
       dmin = fminf(dmin, st.d2[q]);
     }
     st.dmin = dmin;
@@ -319,7 +330,7 @@ struct Target<CMCD_TARGET_MANY_GMM, 2> {
   template <int LP>
   __device__ static __forceinline__ void pass2(const float (&z)[2], int sub, const float* tc, const State& st,
                                                float& logp, float (&grad)[2]) {
-    constexpr int kQ = kFastMix / LP;
+    constexpr int kQ = (kFastMix + LP - 1) / LP;
     const float inv_s = tc[0], c2 = tc[1], c0 = tc[3];
     const int nm = __float_as_int(tc[2]);
     const float2* mu = reinterpret_cast<const float2*>(tc + kLdsHeader);

@@ -123,7 +123,8 @@ static bool make_ws(const cmcd_desc& d, int64_t n, int64_t n_target, WsLayout& w
   w.tgt = o; o += w.tgt_floats;
   o = (o + 1) & ~int64_t(1);
   w.n_waves = int32_t((n + 15) / 16);
-  w.partials = o; o += int64_t(w.n_waves) * CMCD_NSTATS * 2;
+  // sized for the cooperative kernel's 8-particle tiles (twice the records of the 16-particle tiling)
+  w.partials = o; o += int64_t((n + 7) / 8) * CMCD_NSTATS * 2;
   w.total_floats = o;
   return true;
 }
@@ -941,11 +942,16 @@ static int forward_impl(const cmcd_desc* desc, const cmcd_layout* lay, const int
               (int32_t)K, d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0,
               (d.mode == CMCD_MODE_ULA || d.mode == CMCD_MODE_ULA_SN) ? 0 : d.grad_clipping, traj,
               d.mode == CMCD_MODE_ULA ? 1 : (d.mode == CMCD_MODE_ULA_SN ? 2 : 0)};
-  // Kernel variant (desc.reserved: 0 auto, 1 wave-per-tile, 2 CU-cooperative).  Auto: the
-  // cooperative kernel while the batch cannot fill the chip with one wave per tile.
+  // Kernel variant (desc.reserved: 0 auto, 1 wave-per-tile, 2 CU-cooperative, 3 cooperative on 16-particle tiles,
+  // 4 cooperative on 8-particle tiles).  Auto: the cooperative kernel while the batch cannot fill the chip with one
+  // wave per tile, on 8-particle tiles while those still get a CU each (n <= 8 x 256).
   const bool coop_ok = coop_available(d, w.T) && d.mode != CMCD_MODE_ULA;
-  bool use_coop = d.reserved == 2 ? coop_ok : (d.reserved == 1 ? false : (coop_ok && w.n_waves <= coop_max_tiles(d, w.T)));
-  if (d.reserved == 2 && !coop_ok) return fail(CMCD_ERR_UNSUPPORTED, "no cooperative kernel instance%s");
+  const bool forced = d.reserved >= 2 && d.reserved <= 4;
+  bool use_coop = forced ? coop_ok : (d.reserved == 1 ? false : (coop_ok && w.n_waves <= coop_max_tiles(d, w.T)));
+  if (forced && !coop_ok) return fail(CMCD_ERR_UNSUPPORTED, "no cooperative kernel instance%s");
+  const bool half_ok = coop_half_available(d, w.T);
+  if (d.reserved == 4 && !half_ok) return fail(CMCD_ERR_UNSUPPORTED, "no 8-particle-tile cooperative instance%s");
+  const bool half = d.reserved == 4 || (d.reserved != 3 && half_ok && n <= 8 * 256);
   if (use_coop) {
     const bool prof = g_prof.on && g_prof.used < ProfileState::kMax;
     if (prof) {
@@ -956,14 +962,14 @@ static int forward_impl(const cmcd_desc* desc, const cmcd_layout* lay, const int
       }
       CMCD_HIP_CHECK(hipEventRecord(g_prof.ev[g_prof.used][0], stream));
     }
-    rc = coop_launch(d, ta, stream);
+    rc = coop_launch(d, ta, half, stream);
     if (rc != CMCD_OK) return fail(rc, "cooperative launch failed%s");
     if (prof) {
       CMCD_HIP_CHECK(hipEventRecord(g_prof.ev[g_prof.used][1], stream));
       ++g_prof.used;
     }
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, stream,
-                       reinterpret_cast<const double*>(ws + w.partials), w.n_waves, out_stats);
+                       reinterpret_cast<const double*>(ws + w.partials), half ? int32_t((n + 7) / 8) : w.n_waves, out_stats);
     CMCD_HIP_CHECK(hipGetLastError());
     return CMCD_OK;
   }

@@ -157,7 +157,8 @@ def initialize(
 _workspaces = {}
 
 # Kernel variant handed to the library in cmcd_desc.reserved: 0 = auto (library heuristic),
-# 1 = wave-per-tile kernel, 2 = CU-cooperative kernel.  For tests / benchmarking only.
+# 1 = wave-per-tile kernel, 2 = CU-cooperative kernel (library picks the tile), 3 / 4 = cooperative on 16- / 8-particle
+# tiles.  For tests / benchmarking only.
 KERNEL_VARIANT = int(__import__("os").environ.get("CMCD_KERNEL_VARIANT", "0"))
 
 

@@ -22,7 +22,8 @@ CASES = [
 ]
 
 
-@pytest.fixture(params=[1, 2], ids=["wave_per_tile", "cooperative"])
+# 2 = cooperative with the library's tile choice (8-particle tiles up to 2048 particles), 3 = 16-particle tiles forced
+@pytest.fixture(params=[1, 2, 3], ids=["wave_per_tile", "cooperative", "cooperative_16"])
 def variant(request, monkeypatch):
     monkeypatch.setattr(mcdbm, "KERNEL_VARIANT", request.param)
     return request.param
@@ -77,7 +78,7 @@ def test_lgcp_matches_oracle(hip_lib, n, k):
 ])
 def test_sibling_overdamped_modes_match_oracle(hip_lib, variant, name, mode, n, over):
     """config.boundmode = MCD_ULA / MCD_ULA_sn (reference mcd_over_orig.py) on the same kernels."""
-    if mode == "MCD_ULA" and variant == 2:
+    if mode == "MCD_ULA" and variant >= 2:
         pytest.skip("MCD_ULA has no network: the cooperative (MLP-split) kernel does not apply")
     b = synthetic.build(name, device="cuda", boundmode=mode, **over)
     dim, K, _, spec = b["params_fixed"]
@@ -107,7 +108,7 @@ def test_sibling_overdamped_modes_match_oracle(hip_lib, variant, name, mode, n, 
     print(name, mode, rep)
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 @pytest.mark.parametrize("n_mixes", [7, 17, 64])
 def test_many_gmm_with_other_mixture_sizes(hip_lib, monkeypatch, n_mixes, variant):
     """config.n_mixes != 40 takes the generic component loop (the 40-mode fast path keeps squared distances — in the
@@ -123,7 +124,7 @@ def test_many_gmm_with_other_mixture_sizes(hip_lib, monkeypatch, n_mixes, varian
     compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"n_mixes={n_mixes}")
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 @pytest.mark.parametrize("model,emb_dim", [("gmm", 5), ("many_gmm", 40), ("many_gmm", 70), ("funnel", 30)])
 def test_network_widths_between_the_instances_run_zero_padded(hip_lib, monkeypatch, model, emb_dim, variant):
     """config.emb_dim is free in the reference (README: --config.emb_dim 40).  Widths without an instance of their

@@ -17,7 +17,7 @@ subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++
                 os.path.join(csrc, "cmcd_lgcp.hip"), os.path.join(csrc, "cmcd_grad.hip"),
                 os.path.join(csrc, "cmcd_mfvi.hip"), os.path.join(csrc, "cmcd_opt.hip")], check=True)
 os.environ["CMCD_LIB_PATH"] = lib
-os.environ["CMCD_KERNEL_VARIANT"] = "2"
+os.environ.setdefault("CMCD_KERNEL_VARIANT", "2")   # 3 / 4 pin the 16- / 8-particle tiling
 import torch  # noqa: E402
 from cmcd_amd import _lib, synthetic  # noqa: E402
 from cmcd_amd import mcdboundingmachine as mcdbm  # noqa: E402
