@@ -103,8 +103,9 @@ def _strict(o):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: 0.1 s of timed work — 20 steps (7 ms) end before the GPU's clocks have settled
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", default=None, help="name in cmcd_amd.synthetic.CONFIGS")
     ap.add_argument("--particles", type=int, default=None, help="override N per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -42,6 +42,7 @@ struct TrajArgs {
   int32_t K, var_mode, grad_clipping;
   float* traj;  // optional [K+1][n][D] trajectory z_0..z_K (the reparameterised gradient's reverse sweep reads it)
   int32_t ula;  // 0: CAIS; 1: MCD_ULA (no network); 2: MCD_ULA_sn (network in the backward kernel only, index i)
+  int32_t prio = 0;  // cooperative kernel: s_setprio level per role, 2 bits each {MLP, TGT, RNG, ACC} from bit 0
 };
 
 // cmcd_coop.hip: the CU-cooperative variant (one workgroup per 16-particle tile).

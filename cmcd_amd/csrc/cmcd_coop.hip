@@ -1,4 +1,5 @@
-// coop_kernel — the CU-cooperative trajectory kernel: ONE WORKGROUP per 16-particle tile.
+// coop_kernel — the CU-cooperative trajectory kernel: ONE WORKGROUP per 16-particle tile (8-particle tile for batches
+// of <= 2048 particles: template parameter HALF, described at the kernel).
 //
 // Why: the named workload (N = 2000, K = 256) is a 256-long dependent chain on only 125 tiles.  A
 // wave-per-tile kernel leaves 7/8 of the SIMDs idle and its per-bridge latency is one wave's
@@ -99,6 +100,13 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
   const int K = a.K;
 
   for (int i = threadIdx.x; i < a.w.tgt_floats; i += blockDim.x) lds_tgt[i] = a.ws[a.w.tgt + i];
+  // issue priority of this wave's role against its SIMD partner (s_setprio takes an immediate)
+  switch ((a.prio >> (is_mlp ? 0 : is_tgt ? 2 : is_rng ? 4 : 6)) & 3) {
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    case 3: __builtin_amdgcn_s_setprio(3); break;
+    default: break;
+  }
 
   // ---- per-role resident operands
   f32x4 afrag[T], w1z[D], w3t[D], b2v;
@@ -489,7 +497,22 @@ bool coop_available(const cmcd_desc& d, int T) { return pick(d, T, false) != nul
 bool coop_half_available(const cmcd_desc& d, int T) { return pick(d, T, true) != nullptr; }
 
 // half: 8-particle tiles (ceil(n / 8) workgroups, as many statistics records); else ta.w.n_waves 16-particle tiles
-int coop_launch(const cmcd_desc& d, const TrajArgs& ta, bool half, void* stream) {
+// Issue priority per role (s_setprio against the SIMD partner).  Measured with tools/probes/prio_sweep.py (interleaved
+// rounds, profiles/r01_o_prio_sweep*.txt): many_gmm N = 2000 — target waves one level above their MLP partners -2.1 % on
+// 8-particle tiles (-0.5 % on 16), ACC above its partner -0.6 %, RNG above its MLP partner +8 % (the MLP chain is the one
+// the barrier waits for on that SIMD); funnel d = 10, N = 300 on 8-particle tiles — ACC (ten deviates and the log-weight
+// of ten coordinates per bridge) above its partner -5.1 %, target waves up +4.2 %; on 16-particle tiles every raise is slower.
+static int g_coop_prio = -1;   // -1: the table below
+extern "C" void cmcd_debug_set_coop_prio(int prio) { g_coop_prio = prio; }   // tools/probes/prio_sweep.py
+static int default_prio(const cmcd_desc& d, bool half) {
+  if (d.target == CMCD_TARGET_MANY_GMM) return 1 << 2;
+  if (d.target == CMCD_TARGET_FUNNEL && half) return 1 << 6;
+  return 0;
+}
+
+int coop_launch(const cmcd_desc& d, const TrajArgs& ta_in, bool half, void* stream) {
+  TrajArgs ta = ta_in;
+  ta.prio = g_coop_prio >= 0 ? g_coop_prio : default_prio(d, half);
   const int T = ta.w.T, D = d.dim, Hh = (D + 1) / 2, NZ = 2 * Hh;
   const int GP = (D + 1 + 3) & ~3, PT = (T * D + 3) & ~3;
   coop_fn fn = pick(d, T, half);
