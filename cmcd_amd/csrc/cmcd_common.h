@@ -17,6 +17,7 @@ struct WsLayout {
   int64_t w1z;                     // [D][HP]
   int64_t w2;                      // [T][T][64][4]
   int64_t w2t;                     // [T][T][64][4]  A fragments of W2^T (gradient kernel)
+  int64_t w2q;                     // [T][HP/2][64]  A operands of the 4x4x1 MFMA (cooperative kernel, 8-particle tiles)
   int64_t b2;                      // [HP]
   int64_t w3t;                     // [D][HP]
   int64_t b3;                      // [16]  (b3[D] then factor)

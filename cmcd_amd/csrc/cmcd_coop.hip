@@ -91,12 +91,18 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
   // particles over the two waves, results written to both twin columns), everyone else 16 x 4
   constexpr int LPT = HALF ? 16 : 8;         // lanes per particle on the target waves
   const int sub8 = HALF ? (lane >> 2) : (lane >> 3);
-  const int c = is_tgt ? (HALF ? 4 * (wv - T) + (lane & 3) : 8 * (wv - T) + (lane & 7)) : (lane & 15);
+  // HALF MLP waves work in the lane order of v_mfma_f32_4x4x1 (16 blocks of 4 x 4): lane = qi + 4 ng + 16 pg + 32 kh —
+  // particle 4 pg + qi, neuron group ng (4 neurons of the wave's 16), half kh of the contraction
+  const int ng = (lane >> 2) & 3, kh = lane >> 5;
+  const int c = is_tgt ? (HALF ? 4 * (wv - T) + (lane & 3) : 8 * (wv - T) + (lane & 7))
+                       : ((HALF && is_mlp) ? (lane & 3) + 4 * ((lane >> 4) & 1) : (lane & 15));
   const int64_t tile = blockIdx.x;
   const int64_t p = tile * PPT + (HALF ? (c & 7) : c);
   const bool valid = p < a.n;
   const bool own = !HALF || c < 8;           // the column that writes its particle's outputs
-  const int hs = HALF ? ((lane >> 3) & 1) : 0;  // which neuron pair of the lane's four (MLP waves, HALF)
+  const int nb = HALF ? 16 * wv + 4 * ng + 2 * kh : 16 * wv + 4 * g;   // first of the lane's NR neurons (MLP waves)
+  constexpr int HQP = HP + 4;                // HALF: pitch of the [particle][neuron] activation buffer (bank spread)
+  constexpr int NQ = HALF ? HP / 2 : 1;      // HALF: 4x4x1 MFMA steps per bridge (two contraction halves side by side)
   const int K = a.K;
 
   for (int i = threadIdx.x; i < a.w.tgt_floats; i += blockDim.x) lds_tgt[i] = a.ws[a.w.tgt + i];
@@ -109,26 +115,30 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
   }
 
   // ---- per-role resident operands
-  f32x4 afrag[T], w1z[D], w3t[D], b2v;
-  if (is_mlp) {
+  f32x4 afrag[T], b2v = {0.f, 0.f, 0.f, 0.f};
+  float aq[NQ], b2p[NR];
+  float w1[D][NR], w3[D][NR];   // the lane's own neurons nb .. nb + NR - 1
 #pragma unroll
-    for (int ti = 0; ti < T; ++ti)
-      afrag[ti] = *reinterpret_cast<const f32x4*>(a.ws + a.w.w2 + ((ti * T + wv) * 64 + lane) * 4);
+  for (int r = 0; r < NR; ++r) b2p[r] = 0.f;
+  if (is_mlp) {
+    if (HALF) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) aq[q] = a.ws[a.w.w2q + (int64_t)(wv * NQ + q) * 64 + lane];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) b2p[r] = a.ws[a.w.b2 + nb + r];
+    } else {
+#pragma unroll
+      for (int ti = 0; ti < T; ++ti)
+        afrag[ti] = *reinterpret_cast<const f32x4*>(a.ws + a.w.w2 + ((ti * T + wv) * 64 + lane) * 4);
+      b2v = *reinterpret_cast<const f32x4*>(a.ws + a.w.b2 + 16 * wv + 4 * g);
+    }
 #pragma unroll
     for (int j = 0; j < D; ++j) {
-      w1z[j] = *reinterpret_cast<const f32x4*>(a.ws + a.w.w1z + j * HP + 16 * wv + 4 * g);
-      w3t[j] = *reinterpret_cast<const f32x4*>(a.ws + a.w.w3t + j * HP + 16 * wv + 4 * g);
-    }
-    b2v = *reinterpret_cast<const f32x4*>(a.ws + a.w.b2 + 16 * wv + 4 * g);
-  }
-  // the lane's own neurons: all four, or the pair hs
-  float w1[D][NR], w3[D][NR];
 #pragma unroll
-  for (int j = 0; j < D; ++j) {
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      w1[j][r] = HALF ? (hs ? w1z[j][2 + (r & 1)] : w1z[j][r & 1]) : w1z[j][r];
-      w3[j][r] = HALF ? (hs ? w3t[j][2 + (r & 1)] : w3t[j][r & 1]) : w3t[j][r];
+      for (int r = 0; r < NR; ++r) {
+        w1[j][r] = a.ws[a.w.w1z + j * HP + nb + r];
+        w3[j][r] = a.ws[a.w.w3t + j * HP + nb + r];
+      }
     }
   }
   float b3[D];
@@ -218,8 +228,8 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
   const float clipv = a.var_mode ? 1e2f : 1e3f;
   const bool clip_p = a.grad_clipping != 0;
   const bool clip_q = clip_p && a.var_mode;
-  const float* brow_ptr = a.ws + a.w.bias1 + 16 * wv + 4 * g + 2 * hs;
-  const float* urow_ptr = a.ws + a.w.utab + 16 * wv + 4 * g + 2 * hs;
+  const float* brow_ptr = a.ws + a.w.bias1 + nb;
+  const float* urow_ptr = a.ws + a.w.utab + nb;
   auto load_row = [&](const float* ptr) -> f32x4 {   // the lane's NR entries of a per-bridge row
     if (HALF) {
       const float2 t = *reinterpret_cast<const float2*>(ptr);
@@ -230,9 +240,9 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
   // per-lane copy of the (uniform) schedule pointer so that the loads are vector loads
   const float* sched_v = a.ws + a.w.sched + (lane & 0);
   asm volatile("" : "+v"(sched_v));
-  float* const my_h = hbuf + ((wv * 4 + g) * 16 + (lane & 15)) * 4 + 2 * hs;
-  float* const my_h2 = hbuf + ((wv * 4 + g) * 16 + ((lane & 15) ^ 8)) * 4 + 2 * hs;   // HALF: the twin column
-  const float* const rd_h = hbuf + (g * 16 + (lane & 15)) * 4;
+  // HALF: hbuf is [8 particles][HQP]; the lane writes its neuron pair, reads its particle's half kh of the neurons
+  float* const my_h = HALF ? hbuf + c * HQP + nb : hbuf + ((wv * 4 + g) * 16 + (lane & 15)) * 4;
+  const float* const rd_h = HALF ? hbuf + c * HQP + (HP / 2) * kh : hbuf + (g * 16 + (lane & 15)) * 4;
 
   float fk_lp = 0.f, peps = 0.f, pinv2s2 = 0.f, pcst = 0.f, logp = 0.f;
   f32x4 brow = {0.f, 0.f, 0.f, 0.f}, urow = {0.f, 0.f, 0.f, 0.f};
@@ -344,7 +354,7 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
         if (wv == 0) {  // the first D neurons of u are z itself (D <= 16)
 #pragma unroll
           for (int r = 0; r < NR; ++r) {
-            const int nidx = 4 * g + 2 * hs + r;
+            const int nidx = nb + r;   // wv == 0
 #pragma unroll
             for (int j = 0; j < D; ++j) u[r] = (nidx == j) ? z[j] : u[r];
           }
@@ -353,9 +363,7 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
         for (int r = 0; r < NR; ++r) h[r] = u[r] + softplus(pre[r]);
       }
       if (HALF) {
-        const float2 hv = {h[0], h[1]};
-        *reinterpret_cast<float2*>(my_h) = hv;
-        *reinterpret_cast<float2*>(my_h2) = hv;
+        *reinterpret_cast<float2*>(my_h) = float2{h[0], h[1]};
       } else {
         *reinterpret_cast<f32x4*>(my_h) = f32x4{h[0], h[1], h[NR - 2], h[NR - 1]};
       }
@@ -378,29 +386,60 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
       brow = load_row(brow_ptr + (int64_t)nrow * HP);
       if (ARCH == CMCD_ARCH_GEFFNER) urow = load_row(urow_ptr + (int64_t)nrow * HP);
       // layer 2: rows = my 16 output neurons, cols = particles, k = all HP inputs from LDS
-      f32x4 acc = b2v;
-#pragma unroll
-      for (int ti = 0; ti < T; ++ti) {
-        const f32x4 hb = *reinterpret_cast<const f32x4*>(rd_h + ti * 256);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ti][r], hb[r], acc, 0, 0, 0);
-      }
       float av[NR], h2[NR];
+      uint32_t r0h, r1h;
+      if (HALF) {
+        // 16 blocks of 4 neurons x 4 particles per instruction: block (ng, pg, kh) accumulates half kh of the
+        // contraction; no column of the product is wasted (the 16x16x4 shape would carry every particle twice)
+        // all LDS reads in flight before the first MFMA (one round trip, not one per group of four), and two
+        // accumulators (even / odd inputs): a 4x4x1 MFMA that reads its predecessor's result needs two wait states
+        constexpr int NQB = HALF ? NQ / 4 : 1;
+        f32x4 hb[NQB];
 #pragma unroll
-      for (int r = 0; r < NR; ++r) av[r] = HALF ? (hs ? acc[2 + (r & 1)] : acc[r & 1]) : acc[r];
+        for (int q = 0; q < NQB; ++q) hb[q] = *reinterpret_cast<const f32x4*>(rd_h + 4 * q);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < NQB; ++q) {
+          acc = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * q + 0], hb[q][0], acc, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * q + 1], hb[q][1], acc1, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * q + 2], hb[q][2], acc, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * q + 3], hb[q][3], acc1, 0, 0, 0);
+        }
+        acc += acc1;
+        // the two halves of the contraction sit in lanes l and l ^ 32; lane kh keeps neurons 2 kh + {0, 1} of its group
+        uint32_t r0, r1;
+        swap32(__float_as_uint(acc[0]), __float_as_uint(acc[2]), r0, r1);
+        av[0] = (__uint_as_float(r0) + __uint_as_float(r1)) + b2p[0];
+        swap32(__float_as_uint(acc[1]), __float_as_uint(acc[3]), r0, r1);
+        av[1] = (__uint_as_float(r0) + __uint_as_float(r1)) + b2p[1];
+      } else {
+        f32x4 acc = b2v;
+#pragma unroll
+        for (int ti = 0; ti < T; ++ti) {
+          const f32x4 hb = *reinterpret_cast<const f32x4*>(rd_h + ti * 256);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ti][r], hb[r], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) av[r] = acc[r & 3];
+      }
 #pragma unroll
       for (int r = 0; r < NR; ++r) h2[r] = (ARCH == CMCD_ARCH_DDS) ? gelu_fast(av[r]) : h[r] + softplus(av[r]);
 #pragma unroll
       for (int j = 0; j < D; ++j) {
-        float pj;
         if (HALF) {
-          pj = h2[0] * w3[j][0] + h2[1] * w3[j][1];
-          pj += xor8(pj);   // the twin column holds the other neuron pair of the same particle
+          float pj = h2[0] * w3[j][0] + h2[1] * w3[j][1];
+          pj += xor8(pj);   // over the 4 neuron groups (lane bits 2, 3) ...
+          pj += ror4(pj);
+          swap32(__float_as_uint(pj), __float_as_uint(pj), r0h, r1h);   // ... and the two halves (lane bit 5)
+          pj = __uint_as_float(r0h) + __uint_as_float(r1h);
+          if (ng == 0) part[(buf * 16 + c + 8 * kh) * PT + wv * D + j] = pj;   // both twin columns
         } else {
-          pj = h2[0] * w3[j][0] + h2[1] * w3[j][1] + h2[NR - 2] * w3[j][NR - 2] + h2[NR - 1] * w3[j][NR - 1];
+          float pj = h2[0] * w3[j][0] + h2[1] * w3[j][1] + h2[NR - 2] * w3[j][NR - 2] + h2[NR - 1] * w3[j][NR - 1];
+          pj = group_sum(pj);
+          if (g == 0) part[(buf * 16 + c) * PT + wv * D + j] = pj;
         }
-        pj = group_sum(pj);
-        if (g == 0) part[(buf * 16 + c) * PT + wv * D + j] = pj;
       }
     } else if (is_tgt) {
       // second pass only: its SIMD partner (an MLP wave) blocks the VALU during the 16 fp32 MFMAs
@@ -497,18 +536,15 @@ bool coop_available(const cmcd_desc& d, int T) { return pick(d, T, false) != nul
 bool coop_half_available(const cmcd_desc& d, int T) { return pick(d, T, true) != nullptr; }
 
 // half: 8-particle tiles (ceil(n / 8) workgroups, as many statistics records); else ta.w.n_waves 16-particle tiles
-// Issue priority per role (s_setprio against the SIMD partner).  Measured with tools/probes/prio_sweep.py (interleaved
-// rounds, profiles/r01_o_prio_sweep*.txt): many_gmm N = 2000 — target waves one level above their MLP partners -2.1 % on
-// 8-particle tiles (-0.5 % on 16), ACC above its partner -0.6 %, RNG above its MLP partner +8 % (the MLP chain is the one
-// the barrier waits for on that SIMD); funnel d = 10, N = 300 on 8-particle tiles — ACC (ten deviates and the log-weight
-// of ten coordinates per bridge) above its partner -5.1 %, target waves up +4.2 %; on 16-particle tiles every raise is slower.
+// Issue priority per role (s_setprio against the SIMD partner), tools/probes/prio_sweep.py, interleaved rounds
+// (profiles/r01_p_prio_sweep*.txt).  On 8-particle tiles with the 4x4x1 MFMA chain: target and ACC waves one level above
+// their MLP partners -0.5 % (many_gmm, N = 2000) / -2.4 % (funnel d = 10: ten deviates and ten log-weight terms per
+// bridge on ACC); RNG above its MLP partner +4 ... +8 % in every build (the MLP chain is what the barrier waits for on
+// that SIMD).  On 16-particle tiles no raise helps.  (Before the 4x4x1 chain the target waves were the long pole and
+// their raise alone gave -2.1 %: the table follows the balance, re-run the sweep after changing a role.)
 static int g_coop_prio = -1;   // -1: the table below
 extern "C" void cmcd_debug_set_coop_prio(int prio) { g_coop_prio = prio; }   // tools/probes/prio_sweep.py
-static int default_prio(const cmcd_desc& d, bool half) {
-  if (d.target == CMCD_TARGET_MANY_GMM) return 1 << 2;
-  if (d.target == CMCD_TARGET_FUNNEL && half) return 1 << 6;
-  return 0;
-}
+static int default_prio(const cmcd_desc&, bool half) { return half ? (1 << 2 | 1 << 6) : 0; }
 
 int coop_launch(const cmcd_desc& d, const TrajArgs& ta_in, bool half, void* stream) {
   TrajArgs ta = ta_in;
