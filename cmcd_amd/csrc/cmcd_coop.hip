@@ -26,6 +26,7 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <mutex>
 #include <set>
 #include <utility>
@@ -561,8 +562,13 @@ int coop_launch(const cmcd_desc& d, const TrajArgs& ta_in, bool half, void* stre
   // slower pair sets the kernel time: measured 0.316 vs 0.297 ms between 250 and 128 workgroups without this).
   size_t lds_claim = lds_bytes;
   int dev = 0, n_cu = 0;
-  if (hipGetDevice(&dev) == hipSuccess &&
-      hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && (int)tiles <= n_cu) {
+  static std::atomic<int> cu_count[64];   // per device, queried once (the attribute call costs microseconds per launch)
+  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+    n_cu = cu_count[dev].load(std::memory_order_relaxed);
+    if (n_cu == 0 && hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+      cu_count[dev].store(n_cu, std::memory_order_relaxed);
+  }
+  if (n_cu > 0 && (int)tiles <= n_cu) {
     constexpr size_t kExclusive = 84 * 1024;
     static std::mutex mu;
     static std::set<std::pair<const void*, int>> raised;
