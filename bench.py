@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--config", default=None, help="name in cmcd_amd.synthetic.CONFIGS")
     ap.add_argument("--particles", type=int, default=None, help="override N per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--forward-only", action="store_true",
+                    help="skip the vargrad / training_step legs (their trajectory-keeping forward launches would be averaged "
+                         "into the same kernel name by rocprofv3 --stats)")
     ap.add_argument("--cpu-particles", type=int, default=2000)
     ap.add_argument("--saturated", type=int, default=1 << 18,
                     help="also time a saturating batch of this many particles (0 = skip)")
@@ -292,7 +295,7 @@ def main():
                                    "frac": wbytes / kern_s / 1e9 / PEAK_HBM_GBS, "traffic": traffic,
                                    "traffic_unit": "bytes/call (PMC)", "weight_bytes_per_call": wbytes})
 
-    if rank == 0 and world == 1 and name == synthetic.NORTH_STAR:
+    if rank == 0 and world == 1 and name == synthetic.NORTH_STAR and not args.forward_only:
         # value-and-gradient of the VarGrad loss on the same batch (boundmode MCD_CAIS_var_sn, same net/target)
         try:
             bv = synthetic.build(name, device=device, boundmode="MCD_CAIS_var_sn", **over)

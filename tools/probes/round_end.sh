@@ -6,10 +6,10 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/$T
 python3 bench.py > gpurun_out/$T/bench.json 2> gpurun_out/$T/bench.err || exit 1
 rm -rf gpurun_out/$T/prof
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$T/prof -- python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline --saturated 0 > gpurun_out/$T/prof_bench.json 2> /dev/null || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$T/prof -- python3 bench.py --steps 300 --warmup 50 --no-cpu-baseline --saturated 0 --forward-only > gpurun_out/$T/prof_bench.json 2> /dev/null || exit 1
 cp $(find gpurun_out/$T/prof -name "*kernel_stats.csv" | head -1) gpurun_out/$T/kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/$T/pmc/$c -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --saturated 0 > /dev/null 2>&1 || exit 1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/$T/pmc/$c -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --saturated 0 --forward-only > /dev/null 2>&1 || exit 1
 done
 python3 - $T <<'PY'
 import glob, csv, collections, json, sys
