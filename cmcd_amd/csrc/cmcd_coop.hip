@@ -85,6 +85,9 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
   uint32_t* raw = reinterpret_cast<uint32_t*>(nzb + 2 * 16 * NZ);  // [2][16][NZ] raw bits
   float* lds_tgt = reinterpret_cast<float*>(raw + 2 * 16 * NZ);
 
+  // Role = hardware wave index: waves go to SIMD (index % 4), so every SIMD holds one MLP wave and one auxiliary wave.
+  // Measured alternative (profiles/r01_r_simd_map.txt): MLP waves paired on SIMDs 0 / 1 and the auxiliary waves on 2 / 3
+  // (no auxiliary wave ever blocked by an MFMA, but two MFMA chains per matrix pipe) is 6.7 % slower.
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63, g = lane >> 4;
   const bool is_mlp = wv < T, is_tgt = wv == T || wv == T + 1, is_rng = wv == T + 2, is_acc = wv == T + 3;
