@@ -35,7 +35,7 @@ buf = (C.c_ulonglong * 256)()
 L.cmcd_debug_read_stamps(buf)
 K = b["params_fixed"][1]
 names = ["int1 work", "wait bar1", "int2 work", "wait bar2", "phase C"]
-T = b["params_fixed"][3].width // 16 if b["params_fixed"][3].arch == "geffner" else 4
+T = (b["params_fixed"][3].width + 15) // 16 if b["params_fixed"][3].arch == "geffner" else 4
 print("cycles per bridge step, workgroup 0:")
 for wv in range(T + 4):
     row = [buf[wv * 16 + k] / (K + 1) for k in range(5)]
