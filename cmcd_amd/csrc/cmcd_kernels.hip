@@ -147,25 +147,42 @@ __device__ __forceinline__ void prep_sched_body(const SchedArgs& a) {
   const int G = a.ngrid;  // mgridref_y has G+1 entries
   if (threadIdx.x <= G) gm[threadIdx.x] = a.params[a.lay.mgridref_y + threadIdx.x];
   __syncthreads();
+  // gridref_y = concat([0], cumsum(m)/sum(m))       mcdboundingmachine.py:147-148.  The running sum stays sequential
+  // (same association as a serial cumsum) but runs in registers: all entries are read first, one thread adds them in
+  // order, and the G + 1 divisions and the grid abscissae are done by G + 2 threads in parallel (the serial version,
+  // ~100 dependent LDS reads and divisions on one thread, was the longest block of the prep launch).
   if (threadIdx.x == 0) {
-    // gridref_y = concat([0], cumsum(m)/sum(m))       mcdboundingmachine.py:147-148
-    float tot = 0.f;
-    for (int i = 0; i <= G; ++i) tot += gm[i];
+    float v[33];
+#pragma unroll
+    for (int i = 0; i < 33; ++i) v[i] = gm[i < G + 1 ? i : G];
     float run = 0.f;
-    gy[0] = 0.f;
-    for (int i = 0; i <= G; ++i) {
-      run += gm[i];
-      gy[i + 1] = run / tot;
+#pragma unroll
+    for (int i = 0; i < 33; ++i) {
+      if (i <= G) {
+        run += v[i];
+        gy[i + 1] = run;   // un-normalised
+      }
     }
-    for (int i = 0; i < G + 2; ++i) gx[i] = (float)i / (float)(G + 1);  // linspace(0,1,G+2)  :113
+    gy[0] = 0.f;
+    gm[39] = run;          // total (ngrid <= 32: slot 39 is free)
+  }
+  __syncthreads();
+  if (threadIdx.x < G + 2) {
+    const float tot = gm[39];
+    if (threadIdx.x >= 1) gy[threadIdx.x] = gy[threadIdx.x] / tot;
+    gx[threadIdx.x] = (float)threadIdx.x / (float)(G + 1);  // linspace(0,1,G+2)  :113
   }
   __syncthreads();
   const float eps0 = a.params[a.lay.eps];
   for (int i = threadIdx.x; i < a.K; i += blockDim.x) {
     // betas = interp(target_x, gridref_x, gridref_y)     :149, target_x = linspace(0,1,K+2)[1:-1]  :114
     const float x = (float)(i + 1) / (float)(a.K + 1);
-    int j = 1;
-    while (j < G + 1 && gx[j] <= x) ++j;  // searchsorted(side='right') clipped to [1, G+1]
+    // searchsorted(gx, x, side='right') clipped to [1, G+1]: gx is a uniform grid, so the answer is within one of
+    // floor(x (G+1)) + 1 — settle it with the exact comparisons instead of a linear scan through LDS
+    int j = (int)(x * (float)(G + 1)) + 1;
+    j = j < 1 ? 1 : (j > G + 1 ? G + 1 : j);
+    while (j > 1 && gx[j - 1] > x) --j;
+    while (j < G + 1 && gx[j] <= x) ++j;
     const float dx = gx[j] - gx[j - 1], df = gy[j] - gy[j - 1];
     a.ws[a.w.beta + i] = gy[j - 1] + ((x - gx[j - 1]) / dx) * df;
     // eps_i                                              mcd_cais.py:34-44,54-59
@@ -198,7 +215,7 @@ __device__ __forceinline__ void prep_sched_body(const SchedArgs& a) {
 __global__ void prep_sched_kernel(SchedArgs a) { prep_sched_body(a); }
 
 // ------------------------------------------------------------------------------------------
-// 2a. dds: time path -> per-bridge first-layer bias.  One 64-thread block per bridge index t.
+// 2a. dds: time path -> per-bridge first-layer bias.  One block (256 threads) per bridge index t.
 //     tau(t) = W_b gelu(W_a [sin(c t + phi), cos(c t + phi)] + b_a) + b_b   nn_dds.py:131-143,155-158
 //     bias1[t][n] = sb1[n] + sum_j tau_j * sw1[d + j][n]                    (concat at :159)
 // ------------------------------------------------------------------------------------------
@@ -210,13 +227,23 @@ struct DdsPrepArgs {
   int32_t D;
 };
 
-// `t` = bridge index; threads j >= 64 only take part in the barriers
+// `t` = bridge index.  256 threads: thread (q = tid >> 6, j = tid & 63) owns quarter q of each contraction for output j.
+// All weights a thread will need (32 + 16 + 16 values, independent of the data) are requested before the first
+// sin / cos, so the three dependent matrix-vector products pay ONE L2 round trip instead of three, and each runs
+// 32 / 16 / 16 dependent FMAs instead of 128 / 64 / 64; quarters are summed in fixed order (q = 0..3) through LDS.
 __device__ __forceinline__ void prep_dds_body(const DdsPrepArgs& a, int t) {
-  __shared__ float e[128], h[64], tau[64];
-  const int j = threadIdx.x;
-  const bool on = j < 64;
+  __shared__ float e[128], h[64], tau[64], red[4][64];
+  const int j = threadIdx.x & 63, q = threadIdx.x >> 6;
   const float* P = a.params;
-  if (on) {
+  float wa[32], wb[16], wc[16];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) wa[k] = P[a.lay.d_tw1 + (32 * q + k) * 64 + j];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) wb[k] = P[a.lay.d_tw2 + (16 * q + k) * 64 + j];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) wc[k] = P[a.lay.d_sw1 + (a.D + 16 * q + k) * 64 + j];
+  const float ba = P[a.lay.d_tb1 + j], bb = P[a.lay.d_tb2 + j], bc = P[a.lay.d_sb1 + j];
+  if (q == 0) {
     // timestep_coeff = linspace(0.1, 100, 64) (float32)   nn_dds.py:108
     const double step = (100.0 - 0.1) / 63.0;
     const float cj = (j == 63) ? 100.0f : (float)((double)j * step + 0.1);
@@ -226,23 +253,27 @@ __device__ __forceinline__ void prep_dds_body(const DdsPrepArgs& a, int t) {
   }
   __syncthreads();
   float acc = 0.f;
-  if (on) {
-    acc = P[a.lay.d_tb1 + j];
-    for (int k = 0; k < 128; ++k) acc = fmaf(e[k], P[a.lay.d_tw1 + k * 64 + j], acc);
-    h[j] = gelu_exact(acc);
-  }
+#pragma unroll
+  for (int k = 0; k < 32; ++k) acc = fmaf(e[32 * q + k], wa[k], acc);
+  red[q][j] = acc;
   __syncthreads();
-  if (on) {
-    acc = P[a.lay.d_tb2 + j];
-    for (int k = 0; k < 64; ++k) acc = fmaf(h[k], P[a.lay.d_tw2 + k * 64 + j], acc);
-    tau[j] = acc;
-  }
+  if (q == 0) h[j] = gelu_exact(ba + ((red[0][j] + red[1][j]) + (red[2][j] + red[3][j])));
   __syncthreads();
-  if (on) {
-    acc = P[a.lay.d_sb1 + j];
-    for (int k = 0; k < 64; ++k) acc = fmaf(tau[k], P[a.lay.d_sw1 + (a.D + k) * 64 + j], acc);
-    a.ws[a.w.bias1 + (int64_t)t * 64 + j] = acc;
-  }
+  acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc = fmaf(h[16 * q + k], wb[k], acc);
+  __syncthreads();   // red is reused
+  red[q][j] = acc;
+  __syncthreads();
+  if (q == 0) tau[j] = bb + ((red[0][j] + red[1][j]) + (red[2][j] + red[3][j]));
+  __syncthreads();
+  acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc = fmaf(tau[16 * q + k], wc[k], acc);
+  __syncthreads();
+  red[q][j] = acc;
+  __syncthreads();
+  if (q == 0) a.ws[a.w.bias1 + (int64_t)t * 64 + j] = bc + ((red[0][j] + red[1][j]) + (red[2][j] + red[3][j]));
 }
 
 // ------------------------------------------------------------------------------------------
