@@ -106,6 +106,7 @@ def main():
     # defaults: 0.1 s of timed work — 20 steps (7 ms) end before the GPU's clocks have settled
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--spinup", type=int, default=300, help="untimed launches before the warm-up steps (clock settling)")
     ap.add_argument("--config", default=None, help="name in cmcd_amd.synthetic.CONFIGS")
     ap.add_argument("--particles", type=int, default=None, help="override N per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -186,6 +187,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # device spin-up (untimed, before the W warm-up steps): ~0.1 s of launches so that the GPU's clocks have settled even
+    # when the caller asks for a handful of steps (20 steps = 6 ms read 0.305 ms per kernel against 0.267 ms settled)
+    for k in range(args.spinup):
+        step(k)
+    if pending:
+        drain()
     for k in range(args.warmup):
         step(k)
     if pending:
@@ -241,7 +248,7 @@ def main():
 
     result = {
         "metric": "bridge-steps*particles/sec", "value": value, "unit": "bridge-steps*particles/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup": args.spinup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": name, "model": cfg["model"], "boundmode": cfg["boundmode"],
