@@ -398,25 +398,17 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
         // all LDS reads in flight before the first MFMA (one round trip, not one per group of four), and two
         // accumulators (even / odd inputs): a 4x4x1 MFMA that reads its predecessor's result needs two wait states
         constexpr int NQB = HALF ? NQ / 4 : 1;
-        // The reads and their waits are written out by hand: the compiler drains the LDS queue completely
-        // (s_waitcnt lgkmcnt(0)) before the first use of any pending read, but LDS returns in order, so group q of the
-        // chain only needs the queue down to NQB - 1 - q entries.  Other LDS traffic of this wave around the sequence
-        // can only make these waits longer, never shorter (older entries retire first); there are no scalar loads in
-        // the bridge loop.  The "+v" operand ties each wait to the MFMAs that consume its data.
         f32x4 hb[NQB];
-        const uint32_t rd_addr = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)rd_h;
 #pragma unroll
-        for (int q = 0; q < NQB; ++q)
-          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(hb[q]) : "v"(rd_addr), "n"(16 * q));
+        for (int q = 0; q < NQB; ++q) hb[q] = *reinterpret_cast<const f32x4*>(rd_h + 4 * q);
+        __builtin_amdgcn_sched_barrier(0);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < NQB; ++q) {
-          asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(hb[q]) : "n"(NQB - 1 - q));
           acc = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * q + 0], hb[q][0], acc, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * q + 1], hb[q][1], acc1, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * q + 2], hb[q][2], acc, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * q + 3], hb[q][3], acc1, 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);   // keep group q's MFMAs above the wait of group q + 1
         }
         acc += acc1;
         // the two halves of the contraction sit in lanes l and l ^ 32; lane kh keeps neurons 2 kh + {0, 1} of its group
