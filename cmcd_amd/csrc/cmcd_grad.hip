@@ -1375,8 +1375,10 @@ __global__ __launch_bounds__(64) void grad_dds_tail_kernel(TailArgs a) {
   const float* S = a.gtab + a.o_S + (int64_t)t * 64;
   float* row = a.tail + (int64_t)t * kTailRow;
   {
-    const double step = (100.0 - 0.1) / 63.0;
-    const float cj = (j == 63) ? 100.0f : (float)((double)j * step + 0.1);
+    // timestep_coeff = jnp.linspace(0.1, 100, 64): float32 arithmetic, start (1 - s) + stop s with s = iota / 63, the
+    // end point appended exactly (nn_dds.py:108; `np` there is jax.numpy).  Unfused: XLA folds it as written.
+    const float sj = __fdiv_rn((float)j, 63.0f);
+    const float cj = (j == 63) ? 100.0f : __fadd_rn(__fmul_rn(0.1f, __fsub_rn(1.0f, sj)), __fmul_rn(100.0f, sj));
     const float arg = cj * (float)t + P[a.lay.d_phase + j];
     emb[j] = sinf(arg);
     emb[64 + j] = cosf(arg);

@@ -244,9 +244,10 @@ __device__ __forceinline__ void prep_dds_body(const DdsPrepArgs& a, int t) {
   for (int k = 0; k < 16; ++k) wc[k] = P[a.lay.d_sw1 + (a.D + 16 * q + k) * 64 + j];
   const float ba = P[a.lay.d_tb1 + j], bb = P[a.lay.d_tb2 + j], bc = P[a.lay.d_sb1 + j];
   if (q == 0) {
-    // timestep_coeff = linspace(0.1, 100, 64) (float32)   nn_dds.py:108
-    const double step = (100.0 - 0.1) / 63.0;
-    const float cj = (j == 63) ? 100.0f : (float)((double)j * step + 0.1);
+    // timestep_coeff = jnp.linspace(0.1, 100, 64): float32 arithmetic, start (1 - s) + stop s with s = iota / 63, the
+    // end point appended exactly (nn_dds.py:108; `np` there is jax.numpy).  Unfused: XLA folds it as written.
+    const float sj = __fdiv_rn((float)j, 63.0f);
+    const float cj = (j == 63) ? 100.0f : __fadd_rn(__fmul_rn(0.1f, __fsub_rn(1.0f, sj)), __fmul_rn(100.0f, sj));
     const float arg = cj * (float)t + P[a.lay.d_phase + j];
     e[j] = sinf(arg);
     e[64 + j] = cosf(arg);

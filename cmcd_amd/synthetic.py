@@ -40,29 +40,54 @@ def throughput_seeds(n, stream=0):
     return np.random.default_rng(stream).integers(1, 10 ** 6, n).astype(np.int32)
 
 
-def _fill_synthetic_sn(sn, arch, rng):
+# Parameter set used when build() is called without `dense=`: False = the measurement inputs of SURVEY.md section 8d
+# (biases, timestep_phase and the q mean zero, one sigma, uniform mgridref_y); True = every leaf non-trivial.  The parity
+# tests switch it through the `param_set` fixture of tests/conftest.py.
+DENSE_DEFAULT = False
+
+
+def _fill_synthetic_sn(sn, arch, rng, dense=False):
     """W ~ N(0, 1/fan_in), b = 0, last layer x0.1, factor_sn = 0.1, emb ~ 0.05 N(0,1): a network
     that actually moves the particles (the reference's zero-init last layer / factor_sn = 0 would
-    hide every MLP bug)."""
-    def dense(fan_in, fan_out, scale=1.0):
+    hide every MLP bug).  `dense`: additionally every bias ~ N(0, 0.1) (the output layer's too),
+    timestep_phase ~ U(0, 2 pi) and factor_sn = 0.17, so that a leaf the kernels dropped or folded
+    wrongly changes the result (/root/reference/src/nn_dds.py:111-127,155-164, src/nn.py:45-70)."""
+    def mat(fan_in, fan_out, scale=1.0):
         return torch.from_numpy((rng.standard_normal((fan_in, fan_out)) * scale / math.sqrt(fan_in)).astype(np.float32))
+
+    def bias(b):
+        if dense:
+            b.copy_(torch.from_numpy((0.1 * rng.standard_normal(tuple(b.shape))).astype(np.float32)))
+        else:
+            b.zero_()
 
     if arch == "geffner":
         for li, (w, b) in enumerate(sn["nn"]):
-            w.copy_(dense(w.shape[0], w.shape[1], 0.1 if li == 2 else 1.0))
-            b.zero_()
+            w.copy_(mat(w.shape[0], w.shape[1], 0.1 if li == 2 else 1.0))
+            bias(b)
         sn["emb"].copy_(torch.from_numpy((0.05 * rng.standard_normal(tuple(sn["emb"].shape))).astype(np.float32)))
-        sn["factor_sn"].fill_(0.1)
+        sn["factor_sn"].fill_(0.17 if dense else 0.1)
     else:
-        sn["drift_net"]["timestep_phase"].zero_()
+        ph = sn["drift_net"]["timestep_phase"]
+        if dense:
+            ph.copy_(torch.from_numpy(rng.uniform(0.0, 2.0 * math.pi, tuple(ph.shape)).astype(np.float32)))
+        else:
+            ph.zero_()
         for name in ("linear", "linear_1", "linear_2", "linear_3", "linear_zero"):
             mod = sn["drift_net/~/" + name]
-            mod["w"].copy_(dense(mod["w"].shape[0], mod["w"].shape[1], 0.1 if name == "linear_zero" else 1.0))
-            mod["b"].zero_()
+            mod["w"].copy_(mat(mod["w"].shape[0], mod["w"].shape[1], 0.1 if name == "linear_zero" else 1.0))
+            bias(mod["b"])
 
 
-def build(config_name=None, device=None, lgcp_counts=None, **overrides):
-    """-> dict(cfg, params_flat, unflatten, params_fixed, target, eps_schedule, grad_clipping)."""
+def build(config_name=None, device=None, lgcp_counts=None, dense=None, **overrides):
+    """-> dict(cfg, params_flat, unflatten, params_fixed, target, eps_schedule, grad_clipping).
+
+    dense=True: the all-leaves-non-trivial parameter set — biases, timestep_phase and factor_sn as in
+    `_fill_synthetic_sn`, q with a non-zero mean and a per-dimension logdiag (/root/reference/src/vardist/
+    diag_gauss.py:26-62) and random positive mgridref_y, i.e. a non-uniform beta grid (/root/reference/src/
+    mcdboundingmachine.py:146-149)."""
+    if dense is None:
+        dense = DENSE_DEFAULT
     cfg = dict(CONFIGS[config_name or NORTH_STAR])
     cfg.update(overrides)
     info = types.SimpleNamespace(**cfg)
@@ -75,13 +100,21 @@ def build(config_name=None, device=None, lgcp_counts=None, **overrides):
     if cfg["model"] == "lgcp":
         # stand-in for the MFVI-pretrained q: mean = mu_0
         vdparams["mean"] += math.log(126.0) - 0.955
+    mgridref_y = None
+    if dense:
+        rq = np.random.default_rng(7)
+        spread = 0.05 if cfg["model"] == "lgcp" else 0.2 * cfg["init_sigma"]
+        vdparams["mean"] += torch.from_numpy((spread * rq.standard_normal(dim)).astype(np.float32))
+        vdparams["logdiag"] += torch.from_numpy((0.15 * rq.standard_normal(dim)).astype(np.float32))
+        if cfg["nbridges"] >= 1:
+            mgridref_y = rq.uniform(0.5, 1.5, min(32, cfg["nbridges"]) + 1).astype(np.float32)
     flat, unflatten, fixed = mcdbm.initialize(
-        dim=dim, nbridges=cfg["nbridges"], vdparams=vdparams, eta=0.0, eps=cfg["init_eps"],
+        dim=dim, nbridges=cfg["nbridges"], vdparams=vdparams, eta=0.0, eps=cfg["init_eps"], mgridref_y=mgridref_y,
         trainable=("eta", "gamma", "eps", "vd", "mgridref_y"), mode=cfg["boundmode"],
         emb_dim=cfg["emb_dim"], nlayers=3, nn_arch=cfg["nn_arch"], device="cpu")
     train, _ = unflatten(flat)
     if "sn" in train:   # MCD_ULA keeps no network
-        _fill_synthetic_sn(train["sn"], cfg["nn_arch"], np.random.default_rng(1))
+        _fill_synthetic_sn(train["sn"], cfg["nn_arch"], np.random.default_rng(1), dense=dense)
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
     flat = flat.to(device)

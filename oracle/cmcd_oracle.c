@@ -161,7 +161,9 @@ static void dds_time_path(const Net* n, int t, float* tau) { /* nn_dds.py:131-14
   const float* P = n->P;
   float emb[128], h[64];
   for (int j = 0; j < 64; ++j) {
-    float c = (j == 63) ? 100.0f : (float)(0.1 + (double)j * ((100.0 - 0.1) / 63.0));
+    /* jnp.linspace(0.1, 100, 64) in float32: start (1 - s) + stop s, s = iota / 63, end point exact (nn_dds.py:108) */
+    float s = (float)j / 63.0f;
+    float c = (j == 63) ? 100.0f : 0.1f * (1.0f - s) + 100.0f * s;
     float arg = c * (float)t + P[n->lay->d_phase + j];
     emb[j] = (float)sin((double)arg);
     emb[64 + j] = (float)cos((double)arg);

@@ -82,10 +82,18 @@ def softplus(x):
     return np.logaddexp(x, x.dtype.type(0.0))
 
 
+def timestep_coeff():
+    """`np.linspace(start=0.1, stop=100, num=64)` of /root/reference/src/nn_dds.py:108 is jax.numpy's: float32
+    arithmetic, `start * (1 - step) + stop * step` with `step = iota(63) / 63`, the end point appended exactly."""
+    step = np.arange(63, dtype=np.float32) / np.float32(63)
+    out = np.float32(0.1) * (np.float32(1) - step) + np.float32(100) * step
+    return np.concatenate([out, np.array([100.0], np.float32)]).astype(np.float32)
+
+
 def dds_time_embedding(sn, t, dtype):
     """/root/reference/src/nn_dds.py:108,131-143,155-158.  t: integer bridge index."""
     dt = np.dtype(dtype).type
-    coeff = np.linspace(0.1, 100.0, 64).astype(np.float32)          # fp32 in the reference
+    coeff = timestep_coeff()
     arg = coeff * np.float32(t) + np.asarray(sn["timestep_phase"], np.float32).reshape(-1)
     arg = arg.astype(np.float32).astype(np.float64)                 # fp32-rounded argument
     emb = np.concatenate([np.sin(arg), np.cos(arg)]).astype(dtype)

@@ -17,6 +17,7 @@ import math
 import numpy as np
 import torch
 
+from . import cmcd_oracle as _np_oracle
 from . import prng
 from .targets import many_gmm_means
 
@@ -83,7 +84,7 @@ def gelu(x):
 
 
 def apply_dds(sn, z, t):
-    coeff = torch.tensor(np.linspace(0.1, 100.0, 64).astype(np.float32).astype(np.float64), dtype=z.dtype)
+    coeff = torch.tensor(_np_oracle.timestep_coeff().astype(np.float64), dtype=z.dtype)
     arg = coeff * float(t) + sn["timestep_phase"].reshape(-1)
     emb = torch.cat([torch.sin(arg), torch.cos(arg)])
     tau = gelu(emb @ sn["t_w1"] + sn["t_b1"]) @ sn["t_w2"] + sn["t_b2"]

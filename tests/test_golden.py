@@ -11,6 +11,7 @@ from helpers import run_oracle
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 CASES = ["gmm_k8", "funnel_k64", "many_gmm_dds_k256", "many_gmm_var_k32"]
+CASES += ["dense_" + c for c in CASES]
 
 
 def load_case(tag):

@@ -25,7 +25,7 @@ def _fwd(b, seeds):
     return out
 
 
-def test_north_star_full_batch_against_oracle(hip_lib):
+def test_north_star_full_batch_against_oracle(hip_lib, param_set):
     """config 3 at its named size (N = 2000, K = 256) vs the float32 reference-faithful oracle (~6 s)."""
     b = synthetic.build("many_gmm_n2000_k256_dds", device="cuda")
     seeds = synthetic.throughput_seeds(2000)
@@ -68,7 +68,7 @@ def test_determinism_and_batch_composition_invariance(hip_lib, monkeypatch, name
         assert np.quantile(rel, 0.99) < 5e-3
 
 
-def test_vargrad_config_full_batch_statistics(hip_lib):
+def test_vargrad_config_full_batch_statistics(hip_lib, param_set):
     """config 4 (N = 16000, K = 256, 132-wide net): the returned scalar is var(ddof=0) of the returned
     per-particle losses, statistics agree with torch reductions, and a 64-particle slice agrees with
     the float64 oracle."""
@@ -137,7 +137,7 @@ def test_error_paths_on_device(hip_lib):
 
 
 @pytest.mark.parametrize("mode", ["MCD_CAIS_sn", "MCD_CAIS_var_sn"])
-def test_full_length_gradient_against_autograd(hip_lib, mode):
+def test_full_length_gradient_against_autograd(hip_lib, param_set, mode):
     """The named chain length (K = 256, dds net, many_gmm, clipping on, cos_sq schedule) through both training
     gradients, 256 particles: float32 kernels vs float64 autograd through the restatement.  Over 256 steps the two
     precisions drift apart particle by particle, so the bar is on the aggregated gradient: cosine > 0.9999 and every

@@ -57,7 +57,7 @@ CASES = [
 
 @pytest.mark.parametrize("item", [0, 1])
 @pytest.mark.parametrize("name,n,over", CASES)
-def test_vargrad_matches_autograd(hip_lib, monkeypatch, name, n, over, item):
+def test_vargrad_matches_autograd(hip_lib, param_set, monkeypatch, name, n, over, item):
     """item = 1: the work-item path (trajectory stored, (tile, evaluation) pairs in parallel); 0: whole chains."""
     monkeypatch.setenv("CMCD_GRAD_ITEM", str(item))
     b = synthetic.build(name, device="cuda", **over)
@@ -123,7 +123,7 @@ BPTT_CASES = [
 
 @pytest.mark.parametrize("variant,item", [(1, 0), (2, 0), (1, 1), (2, 1), (3, 1)])
 @pytest.mark.parametrize("name,n,over", BPTT_CASES)
-def test_reparameterised_gradient_matches_autograd(hip_lib, monkeypatch, name, n, over, variant, item):
+def test_reparameterised_gradient_matches_autograd(hip_lib, param_set, monkeypatch, name, n, over, variant, item):
     """compute_bound_grad == jax.grad(compute_bound, 1): values from autograd through the float64 restatement
     with no detach (oracle/cmcd_oracle_torch.py).  Both forward kernel variants store the trajectory; item = 0 is
     the sequential reverse sweep, item = 1 the Jacobian + scan + work-item path for small batches."""
@@ -297,7 +297,7 @@ def test_graph_replayed_training_equals_eager_training(hip_lib, mode):
 
 
 @pytest.mark.parametrize("n,K,clip", [(5, 3, False), (37, 2, True)])
-def test_lgcp_reparameterised_gradient_matches_autograd(hip_lib, n, K, clip):
+def test_lgcp_reparameterised_gradient_matches_autograd(hip_lib, param_set, n, K, clip):
     """d = 1600 (config 5): launch-sequence reverse sweep + deferred A^T B parameter contractions vs autograd
     through the float64 restatement.  n = 37 spans two passes of 32 particles."""
     from helpers import lgcp_counts_fixture
@@ -338,7 +338,7 @@ def test_lgcp_reparameterised_gradient_matches_autograd(hip_lib, n, K, clip):
 
 
 @pytest.mark.parametrize("n,K,clip", [(6, 3, False), (37, 2, True)])
-def test_lgcp_vargrad_matches_autograd(hip_lib, n, K, clip):
+def test_lgcp_vargrad_matches_autograd(hip_lib, param_set, n, K, clip):
     """d = 1600 with MCD_CAIS_var_sn: the reverse launch sequence with z detached (no lambda recursion, no Hessian
     product), per-particle weights from the statistics — against autograd of var(losses) through the float64
     restatement with the reference's stop_gradient placement.  n = 37 spans two passes; clip = 1e2 on both scores."""
@@ -389,7 +389,7 @@ ULA_CASES = [
 
 @pytest.mark.parametrize("variant,item", [(1, 0), (2, 1), (1, 1)])
 @pytest.mark.parametrize("name,n,over", ULA_CASES)
-def test_ula_sn_gradient_matches_autograd(hip_lib, monkeypatch, name, n, over, variant, item):
+def test_ula_sn_gradient_matches_autograd(hip_lib, param_set, monkeypatch, name, n, over, variant, item):
     """MCD_ULA_sn (the "MCD" baseline, /root/reference/src/mcd_over_orig.py): network only in the backward kernel
     with index i, constant eps, no clipping — same reverse recursion, through both gradient paths."""
     monkeypatch.setattr(mcdbm, "KERNEL_VARIANT", variant)
@@ -407,7 +407,7 @@ def test_ula_sn_gradient_matches_autograd(hip_lib, monkeypatch, name, n, over, v
 
 
 @pytest.mark.parametrize("name,n,over", ULA_CASES)
-def test_ula_gradient_matches_autograd(hip_lib, name, n, over):
+def test_ula_gradient_matches_autograd(hip_lib, param_set, name, n, over):
     """MCD_ULA (no network): gradient w.r.t. eps, the schedule grid and q through the network-free reverse sweep."""
     b = synthetic.build(name, device="cuda", boundmode="MCD_ULA", **over)
     seeds = synthetic.parity_seeds(n)
@@ -433,7 +433,7 @@ def test_ula_gradient_matches_autograd(hip_lib, name, n, over):
 
 
 @pytest.mark.parametrize("mode,n,K", [("MCD_ULA_sn", 6, 3), ("MCD_ULA", 37, 3)])
-def test_lgcp_overdamped_baselines_match_autograd(hip_lib, mode, n, K):
+def test_lgcp_overdamped_baselines_match_autograd(hip_lib, param_set, mode, n, K):
     """d = 1600 with the two overdamped baselines (mcd_over_orig.py): MCD_ULA_sn = network in the backward kernel only,
     time index i; MCD_ULA = no network at all (one GEMM launch per evaluation forward, two per evaluation in the reverse
     sweep).  Losses and every gradient leaf against autograd through the float64 restatement."""
@@ -496,7 +496,7 @@ def test_sharded_grad_and_loss_without_a_process_group_is_the_plain_call(hip_lib
 
 
 @pytest.mark.parametrize("item", [0, 1])
-def test_gradient_with_a_17_component_mixture(hip_lib, monkeypatch, item):
+def test_gradient_with_a_17_component_mixture(hip_lib, param_set, monkeypatch, item):
     """The generic component loop of the target's gradient + Hessian (n_mixes != 40)."""
     from functools import partial
     monkeypatch.setenv("CMCD_GRAD_ITEM", str(item))

@@ -30,7 +30,7 @@ def variant(request, monkeypatch):
 
 
 @pytest.mark.parametrize("name,n,over", CASES)
-def test_bound_matches_oracle(hip_lib, variant, name, n, over):
+def test_bound_matches_oracle(hip_lib, param_set, variant, name, n, over):
     b = synthetic.build(name, device="cuda", **over)
     seeds = synthetic.parity_seeds(n)
     fn = mcdbm.compute_bound_var if "var" in b["cfg"]["boundmode"] else mcdbm.compute_bound
@@ -53,7 +53,7 @@ def test_bound_matches_oracle(hip_lib, variant, name, n, over):
 
 
 @pytest.mark.parametrize("n,k", [(20, 8), (5, 3), (40, 2)])
-def test_lgcp_matches_oracle(hip_lib, n, k):
+def test_lgcp_matches_oracle(hip_lib, param_set, n, k):
     """d = 1600 (config 5): per-bridge GEMM path.  40 particles = two passes of the 32-row GEMM."""
     import os
     counts = np.load(os.path.join(os.path.dirname(__file__), "golden", "lgcp_bin_counts.npy"))
@@ -76,7 +76,7 @@ def test_lgcp_matches_oracle(hip_lib, n, k):
     ("many_gmm_n2000_k256_dds", "MCD_ULA", 200, dict(nbridges=32, init_eps=0.3, init_sigma=15.0)),
     ("funnel_n300_k64", "MCD_ULA_sn", 100, dict(nbridges=16)),
 ])
-def test_sibling_overdamped_modes_match_oracle(hip_lib, variant, name, mode, n, over):
+def test_sibling_overdamped_modes_match_oracle(hip_lib, param_set, variant, name, mode, n, over):
     """config.boundmode = MCD_ULA / MCD_ULA_sn (reference mcd_over_orig.py) on the same kernels."""
     if mode == "MCD_ULA" and variant >= 2:
         pytest.skip("MCD_ULA has no network: the cooperative (MLP-split) kernel does not apply")
@@ -126,7 +126,7 @@ def test_many_gmm_with_other_mixture_sizes(hip_lib, monkeypatch, n_mixes, varian
 
 @pytest.mark.parametrize("variant", [1, 2, 3])
 @pytest.mark.parametrize("model,emb_dim", [("gmm", 5), ("many_gmm", 40), ("many_gmm", 70), ("funnel", 30)])
-def test_network_widths_between_the_instances_run_zero_padded(hip_lib, monkeypatch, model, emb_dim, variant):
+def test_network_widths_between_the_instances_run_zero_padded(hip_lib, param_set, monkeypatch, model, emb_dim, variant):
     """config.emb_dim is free in the reference (README: --config.emb_dim 40).  Widths without an instance of their
     own (here 7, 42, 72 and 40) run on the next larger one with zero-padded weights: same numbers."""
     monkeypatch.setattr(mcdbm, "KERNEL_VARIANT", variant)
@@ -139,3 +139,17 @@ def test_network_widths_between_the_instances_run_zero_padded(hip_lib, monkeypat
     torch.cuda.synchronize()
     l_ref, z_ref = run_oracle(b, seeds, dtype=np.float64)
     compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"{model} emb_dim={emb_dim}")
+
+
+@pytest.mark.parametrize("tag", ["gmm_k8", "funnel_k64", "many_gmm_dds_k256", "many_gmm_var_k32", "dense_gmm_k8",
+                                 "dense_funnel_k64", "dense_many_gmm_dds_k256", "dense_many_gmm_var_k32"])
+def test_bound_matches_committed_golden_vectors(hip_lib, variant, tag):
+    """The HIP path against tests/golden/oracle_*.npz (float64 restatement, tools/make_golden.py) — no oracle code runs."""
+    from test_golden import load_case
+    g, name, over = load_case(tag)
+    b = synthetic.build(name, device="cuda", **over)
+    fn = mcdbm.compute_bound_var if "var" in b["cfg"]["boundmode"] else mcdbm.compute_bound
+    _, (losses, z) = fn(torch.from_numpy(g["seeds"]).cuda(), b["params_flat"], b["unflatten"], b["params_fixed"],
+                        b["target"], eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
+    torch.cuda.synchronize()
+    compare_losses(losses.cpu().numpy(), g["loss"], z.cpu().numpy(), g["z"], tag=f"golden {tag}")

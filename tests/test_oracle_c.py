@@ -15,7 +15,7 @@ from helpers import compare_losses, run_c_oracle, run_oracle
     ("many_gmm_n2000_k256_dds", 40, dict(nbridges=8, eps_schedule="linear", init_eps=0.05)),
     ("many_gmm_var_n16000_k256", 32, dict(nbridges=8)),
 ])
-def test_c_oracle_matches_numpy_oracle(name, n, over):
+def test_c_oracle_matches_numpy_oracle(param_set, name, n, over):
     b = synthetic.build(name, device="cpu", **over)
     seeds = synthetic.parity_seeds(n)
     lc, zc = run_c_oracle(b, seeds)

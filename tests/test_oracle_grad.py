@@ -26,7 +26,7 @@ def _value(b, p, seeds, mode):
 
 
 @pytest.mark.parametrize("name,over", CASES)
-def test_forward_equals_numpy_oracle(name, over):
+def test_forward_equals_numpy_oracle(param_set, name, over):
     for mode in ("MCD_CAIS_sn", "MCD_CAIS_var_sn"):
         b = synthetic.build(name, device="cpu", boundmode=mode, **over)
         seeds = synthetic.parity_seeds(16)
@@ -52,7 +52,7 @@ def _directional_fd(b, p, seeds, mode, direction, h=1e-5):
 
 
 @pytest.mark.parametrize("name,over", CASES)
-def test_full_gradient_matches_finite_differences(name, over):
+def test_full_gradient_matches_finite_differences(param_set, name, over):
     """MCD_CAIS_sn: no stop_gradient, so autograd must equal the true derivative of the forward value."""
     b = synthetic.build(name, device="cpu", boundmode="MCD_CAIS_sn", grad_clipping=False, **over)
     seeds = synthetic.parity_seeds(12)

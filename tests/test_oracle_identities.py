@@ -141,3 +141,18 @@ def test_ula_modes_against_cais_and_longhand():
     w += tgt(x)[0]
     np.testing.assert_allclose(l_sn, -w, rtol=1e-9, atol=1e-9)
     assert np.abs(l_sn - l_ula).max() > 1e-4     # the network matters
+
+
+def test_dds_timestep_coefficients_follow_jnp_linspace():
+    """nn_dds.py:108 calls jax.numpy's linspace: float32 `start (1 - s) + stop s`, not NumPy's float64 `start + i step`
+    rounded afterwards.  The two differ in 31 of the 64 entries by up to 7.6e-6 (2e-3 rad of phase at t = 256)."""
+    from oracle import cmcd_oracle as orc
+    c = orc.timestep_coeff()
+    assert c.dtype == np.float32 and c.shape == (64,) and c[0] == np.float32(0.1) and c[-1] == np.float32(100.0)
+    i = np.arange(64, dtype=np.float64)
+    exact = 0.1 + i * (99.9 / 63.0)
+    assert np.abs(c - exact).max() < 1.6e-5            # a few float32 ulps at 100
+    assert (c != np.linspace(0.1, 100.0, 64).astype(np.float32)).sum() == 31
+    # hand-evaluated entries of the float32 formula
+    s1 = np.float32(1) / np.float32(63)
+    assert c[1] == np.float32(np.float32(np.float32(0.1) * np.float32(np.float32(1) - s1)) + np.float32(np.float32(100) * s1))

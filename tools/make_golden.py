@@ -27,6 +27,12 @@ CASES = {
     "funnel_k64": ("funnel_n300_k64", 32, {}),
     "many_gmm_dds_k256": ("many_gmm_n2000_k256_dds", 64, {}),
     "many_gmm_var_k32": ("many_gmm_var_n16000_k256", 32, dict(nbridges=32)),
+    # every parameter leaf non-trivial (synthetic.build(dense=True)): biases, timestep_phase, q mean / per-dimension
+    # logdiag, non-uniform mgridref_y, factor_sn
+    "dense_gmm_k8": ("gmm_n300_k8", 48, dict(dense=True)),
+    "dense_funnel_k64": ("funnel_n300_k64", 32, dict(dense=True)),
+    "dense_many_gmm_dds_k256": ("many_gmm_n2000_k256_dds", 64, dict(dense=True)),
+    "dense_many_gmm_var_k32": ("many_gmm_var_n16000_k256", 32, dict(nbridges=32, dense=True)),
 }
 
 
