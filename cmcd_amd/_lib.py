@@ -87,11 +87,12 @@ def lib():
         L.cmcd_adam_step.restype = C.c_int
         L.cmcd_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                      C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, C.c_float,
-                                     C.POINTER(ProjectRange), C.c_int32, C.c_void_p]
+                                     C.POINTER(ProjectRange), C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.cmcd_adam_step_dev.restype = C.c_int
         L.cmcd_adam_step_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                          C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_float,
-                                         C.POINTER(ProjectRange), C.c_int32, C.c_void_p]
+                                         C.POINTER(ProjectRange), C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
+                                         C.c_void_p]
         L.cmcd_stats_merge_device.restype = C.c_int
         L.cmcd_stats_merge_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.cmcd_profile_enable.restype = C.c_int

@@ -12,7 +12,7 @@ import torch
 
 from . import _lib
 from . import variationaldist as vd
-from .mcdboundingmachine import ravel_pytree, _workspaces
+from .mcdboundingmachine import ravel_pytree, _workspace
 
 
 def initialize(dim, vdparams=None, nbridges=0, lfsteps=1, eps=0.0, eta=0.5, mdparams=None, ngridb=32,
@@ -67,11 +67,7 @@ def _call(seeds, params_flat, unflatten, params_fixed, log_prob, want_grad, n_to
     nbytes = L.cmcd_mfvi_workspace_bytes(log_prob.target_id, dim, n)
     if nbytes <= 0:
         raise NotImplementedError(_lib.last_error() or "no mean-field kernel for this target")
-    key = str(device) + ":mfvi"
-    ws = _workspaces.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _workspaces[key] = ws
+    ws = _workspace(device, nbytes, "mfvi")
     consts = log_prob.consts_on(device)
     losses = torch.empty(n, dtype=torch.float32, device=device)
     z = torch.empty(n, dim, dtype=torch.float32, device=device)

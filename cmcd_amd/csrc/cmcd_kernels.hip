@@ -801,13 +801,17 @@ __global__ __launch_bounds__(256) void finalize_kernel(const double* partials, i
   }
 }
 
-// omega_n = d var(l, ddof=0) / d w_n = -(2 / N)(l_n - mean l), from the merged statistics {.., sum l, ..}
+// omega_n = d clip(var(l, ddof=0), +-1e7) / d w_n = -(2 / N)(l_n - mean l) from the merged statistics {.., sum l, sum l^2, ..};
+// zero where the clip of mcdboundingmachine.py:231 is active (jnp.clip passes no gradient outside its bounds); a NaN
+// variance (an infinite loss in the batch) gives NaN weights, as jax.grad does.
 __global__ void vargrad_weights_kernel(const float* loss, const double* stats, int64_t n, int64_t n_total,
                                        float* omega) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double mean = stats[1] / (double)n_total;
-  omega[i] = (float)(-2.0 / (double)n_total * ((double)loss[i] - mean));
+  const double var = stats[2] / (double)n_total - mean * mean;
+  const bool clipped = var > 1e7 || var < -1e7;
+  omega[i] = clipped ? 0.0f : (float)(-2.0 / (double)n_total * ((double)loss[i] - mean));
 }
 
 // ------------------------------------------------------------------------------------------

@@ -25,12 +25,34 @@ struct OptArgs {
   const int64_t* step_dev;                          // non-null: t = *step_dev + 1 (graph replay: the count lives on the device)
   int32_t n_ranges;
   cmcd_project_range ranges[8];
+  const float* losses;   // nullable: divergence guard on mean(losses)
+  int64_t n_losses;
+  int32_t* diverged;     // nullable, sticky
 };
 
 __global__ void adam_step_kernel(OptArgs a) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a.losses) {
+    // opt.py:122-124: `if np.isnan(jnp.mean(loss)): return` before the update.  mean is NaN iff a loss is NaN or both
+    // infinities occur.  Every block scans the (L2-resident) losses itself: no extra launch, no inter-block dependency.
+    // The block that sets the flag is not ordered against blocks that read it in the SAME launch, so the decision of
+    // this launch comes from the scan alone; the flag only carries it to later launches and to the host.
+    int bits = (a.diverged && __hip_atomic_load(a.diverged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ? 4 : 0;
+    for (int64_t k = threadIdx.x; k < a.n_losses; k += blockDim.x) {
+      const float l = a.losses[k];
+      bits |= (l != l) ? 4 : (l == INFINITY ? 1 : (l == -INFINITY ? 2 : 0));
+    }
+    const int any_nan = __syncthreads_or(bits & 4), pos = __syncthreads_or(bits & 1), neg = __syncthreads_or(bits & 2);
+    if (any_nan || (pos && neg)) {
+      if (a.diverged && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(a.diverged, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+  }
   if (i >= a.n) return;
-  const float g = fminf(fmaxf(a.grad[i], -a.clip), a.clip);
+  const float graw = a.grad[i];
+  // optax.clip = jnp.clip: +-inf is clipped, NaN passes through (and then poisons the parameter, as in the reference)
+  const float g = (graw == graw) ? fminf(fmaxf(graw, -a.clip), a.clip) : graw;
   const float m = a.b1 * a.mu[i] + (1.0f - a.b1) * g;
   const float v = a.b2 * a.nu[i] + (1.0f - a.b2) * g * g;
   a.mu[i] = m;
@@ -76,11 +98,14 @@ static int adam_launch(OptArgs& a, int64_t step, const cmcd_project_range* range
 // replayed: no launch argument changes between iterations.
 extern "C" int cmcd_adam_step_dev(float* params, const float* grad, float* mu, float* nu, float* ema, int64_t n,
                                   float lr, float b1, float b2, float eps, float clip, int64_t* step_counter,
-                                  float ema_step, const cmcd_project_range* ranges, int32_t n_ranges, void* stream) {
-  if (!params || !grad || !mu || !nu || !step_counter || n < 1) return fail_msg(CMCD_ERR_BAD_ARG, "bad argument");
+                                  float ema_step, const cmcd_project_range* ranges, int32_t n_ranges,
+                                  const float* losses, int64_t n_losses, int32_t* diverged, void* stream) {
+  if (!params || !grad || !mu || !nu || !step_counter || n < 1 || (losses && n_losses < 1))
+    return fail_msg(CMCD_ERR_BAD_ARG, "bad argument");
   OptArgs a{};
   a.params = params; a.grad = grad; a.mu = mu; a.nu = nu; a.ema = ema; a.n = n;
   a.lr = lr; a.b1 = b1; a.b2 = b2; a.eps = eps; a.clip = clip; a.ema_step = ema_step; a.step_dev = step_counter;
+  a.losses = losses; a.n_losses = n_losses; a.diverged = diverged;
   int rc = adam_launch(a, 1, ranges, n_ranges, stream);
   if (rc != CMCD_OK) return rc;
   hipLaunchKernelGGL(step_counter_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), step_counter);
@@ -89,10 +114,13 @@ extern "C" int cmcd_adam_step_dev(float* params, const float* grad, float* mu, f
 
 extern "C" int cmcd_adam_step(float* params, const float* grad, float* mu, float* nu, float* ema, int64_t n,
                               float lr, float b1, float b2, float eps, float clip, int64_t step, float ema_step,
-                              const cmcd_project_range* ranges, int32_t n_ranges, void* stream) {
-  if (!params || !grad || !mu || !nu || n < 1 || step < 1) return fail_msg(CMCD_ERR_BAD_ARG, "bad argument");
+                              const cmcd_project_range* ranges, int32_t n_ranges,
+                              const float* losses, int64_t n_losses, int32_t* diverged, void* stream) {
+  if (!params || !grad || !mu || !nu || n < 1 || step < 1 || (losses && n_losses < 1))
+    return fail_msg(CMCD_ERR_BAD_ARG, "bad argument");
   OptArgs a{};
   a.params = params; a.grad = grad; a.mu = mu; a.nu = nu; a.ema = ema; a.n = n;
   a.lr = lr; a.b1 = b1; a.b2 = b2; a.eps = eps; a.clip = clip; a.ema_step = ema_step; a.step_dev = nullptr;
+  a.losses = losses; a.n_losses = n_losses; a.diverged = diverged;
   return adam_launch(a, step, ranges, n_ranges, stream);
 }

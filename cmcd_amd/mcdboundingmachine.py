@@ -56,7 +56,7 @@ class Unflatten:
         self.size = off
 
     def __call__(self, params_flat):
-        leaves = {p: params_flat[o:o + max(1, _numel(s))].view(s) for p, (o, s) in self.layout.items()}
+        leaves = {p: params_flat[o:o + _numel(s)].reshape(s) for p, (o, s) in self.layout.items()}   # _numel(()) == 1
         return _rebuild(self._tree, leaves)
 
     def offset(self, *path):
@@ -162,8 +162,11 @@ _workspaces = {}
 KERNEL_VARIANT = int(__import__("os").environ.get("CMCD_KERNEL_VARIANT", "0"))
 
 
-def _workspace(device, nbytes):
-    key = str(device)
+def _workspace(device, nbytes, tag=""):
+    """Scratch buffer of one (device, HIP stream, purpose): calls enqueued on different streams of one device — from
+    one host thread or several — never share a workspace, so they may overlap on the GPU (include/cmcd_hip.h: the
+    library itself keeps nothing between calls).  Calls on the same stream are ordered and reuse the buffer."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0, tag)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
@@ -327,11 +330,7 @@ def compute_log_var_grad(seeds, params_flat, unflatten, params_fixed, log_prob, 
     nbytes = L.cmcd_grad_workspace_bytes(C.byref(desc), n)
     if nbytes <= 0:
         raise NotImplementedError(_lib.last_error() or "no gradient kernel for this configuration")
-    key = str(device) + ":grad"
-    ws = _workspaces.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _workspaces[key] = ws
+    ws = _workspace(device, nbytes, "grad")
     consts = log_prob.consts_on(device)
     cptr, cnum = (consts.data_ptr(), consts.numel()) if consts is not None else (None, 0)
     losses = torch.empty(n, dtype=torch.float32, device=device)
@@ -402,11 +401,7 @@ def compute_bound_grad(seeds, params_flat, unflatten, params_fixed, log_prob, ep
     nbytes = L.cmcd_bound_grad_workspace_bytes(C.byref(desc), n)
     if nbytes <= 0:
         raise NotImplementedError(_lib.last_error() or "no gradient kernel for this configuration")
-    key = str(device) + ":bptt"
-    ws = _workspaces.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _workspaces[key] = ws
+    ws = _workspace(device, nbytes, "bptt")
     consts = log_prob.consts_on(device)
     losses = torch.empty(n, dtype=torch.float32, device=device)
     z = torch.empty(n, dim, dtype=torch.float32, device=device)

@@ -69,9 +69,12 @@ class _FusedClipAdam(_ClipAdam):
     `cmcd_adam_step` on device tensors (the reference gets this fusion from jit; eager torch would issue ~15
     small kernels per iteration, which at 1 ms per training step is a third of the loop)."""
 
-    def step(self, params, grad, state, unflatten, trainable, ema=None, ema_step=0.001, device_counter=None):
+    def step(self, params, grad, state, unflatten, trainable, ema=None, ema_step=0.001, device_counter=None,
+             losses=None, diverged=None):
         """`device_counter`: int64 device scalar holding the number of completed steps — the graph-replay form
-        (`cmcd_adam_step_dev`), in which no launch argument changes from one iteration to the next."""
+        (`cmcd_adam_step_dev`), in which no launch argument changes from one iteration to the next.
+        `losses` / `diverged`: the reference's `if isnan(mean(loss)): return` (opt.py:122-124) evaluated inside the
+        launch — a step whose mean loss is NaN is skipped and sets the sticky int32 device flag `diverged`."""
         from . import _lib
         L = _lib.lib()
         ranges = state.get("ranges")
@@ -79,19 +82,22 @@ class _FusedClipAdam(_ClipAdam):
             rl = _project_ranges(unflatten, trainable)
             ranges = state["ranges"] = (_lib.ProjectRange * max(len(rl), 1))(*rl), len(rl)
         arr, cnt = ranges
+        lptr, ln = (losses.data_ptr(), losses.numel()) if losses is not None else (None, 0)
+        dptr = diverged.data_ptr() if diverged is not None else None
         if device_counter is not None:
             with torch.cuda.device(params.device):
                 _lib.check(L.cmcd_adam_step_dev(
                     params.data_ptr(), grad.data_ptr(), state["mu"].data_ptr(), state["nu"].data_ptr(),
                     ema.data_ptr() if ema is not None else None, params.numel(), self.lr, self.b1, self.b2, self.eps,
-                    5.0, device_counter.data_ptr(), ema_step, arr, cnt, torch.cuda.current_stream().cuda_stream))
+                    5.0, device_counter.data_ptr(), ema_step, arr, cnt, lptr, ln, dptr,
+                    torch.cuda.current_stream().cuda_stream))
             return
         state["count"] += 1
         with torch.cuda.device(params.device):
             _lib.check(L.cmcd_adam_step(
                 params.data_ptr(), grad.data_ptr(), state["mu"].data_ptr(), state["nu"].data_ptr(),
                 ema.data_ptr() if ema is not None else None, params.numel(), self.lr, self.b1, self.b2, self.eps,
-                5.0, state["count"], ema_step, arr, cnt, torch.cuda.current_stream().cuda_stream))
+                5.0, state["count"], ema_step, arr, cnt, lptr, ln, dptr, torch.cuda.current_stream().cuda_stream))
 
 
 def create_optimizer(step_size, b1=0.9, b2=0.999, eps=1e-8, trainable=None):
@@ -122,6 +128,12 @@ def run(info, lr, iters, params_flat, unflatten, params_fixed, log_prob_model, g
     n = info.N if hasattr(info, "N") else info["N"]
     every = max(iters // 1000, 1)
     fused = params_flat.is_cuda and params_flat.dtype == torch.float32 and params_flat.is_contiguous()
+    # the reference tests isnan(mean(loss)) on the host every iteration, before the update (opt.py:122-124).  Here the
+    # fused step makes that decision on the device (a NaN step is skipped and raises `diverged`), and the host polls the
+    # flag together with the logged loss every 0.1 % of the run and once at the end: same returned parameters — the
+    # last ones before the NaN loss — without a host sync per iteration.
+    diverged = torch.zeros(1, dtype=torch.int32, device=params_flat.device) if fused else None
+    guard = lambda l: l if (l.is_cuda and l.dtype == torch.float32 and l.is_contiguous()) else l.float().contiguous()
     if use_graph is None:
         import os
         use_graph = fused and os.environ.get("CMCD_TRAIN_GRAPH", "0") == "1"
@@ -145,47 +157,64 @@ def run(info, lr, iters, params_flat, unflatten, params_fixed, log_prob_model, g
                 try:
                     graph = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(graph):
-                        g_grad, (g_loss, _) = grad_and_loss(static_seeds, params_flat, unflatten, params_fixed,
-                                                            log_prob_model)
+                        g_grad, g_aux = grad_and_loss(static_seeds, params_flat, unflatten, params_fixed,
+                                                      log_prob_model)
+                        g_loss = g_aux[0] if len(g_aux) <= 2 else (g_aux[2][1:2] / float(n)).to(torch.float32)
                         optimizer.step(params_flat, g_grad, opt_state, unflatten, trainable,
-                                       ema=ema_params if use_ema else None, device_counter=counter)
+                                       ema=ema_params if use_ema else None, device_counter=counter,
+                                       losses=guard(g_loss), diverged=diverged)
                 except Exception as exc:   # capture refused (e.g. a gradient path that synchronises): stay eager
                     print(f"opt.run: graph capture unavailable ({exc}); running eagerly")
                     use_graph, graph = False, None
                 # capture does not execute: this iteration's replay follows like every other
             if graph is None:
-                grad, (loss, z) = grad_and_loss(seeds, params_flat, unflatten, params_fixed, log_prob_model)
+                grad, aux = grad_and_loss(seeds, params_flat, unflatten, params_fixed, log_prob_model)
+                loss = aux[0] if len(aux) <= 2 else (aux[2][1:2] / float(n)).to(torch.float32)
                 if i % every == 0:
                     mean_loss = float(loss.mean())
-                    if mean_loss != mean_loss:
+                    if mean_loss != mean_loss or int(diverged) != 0:
                         print("Diverged")
                         return losses, params_flat, ema_params
                     losses.append(mean_loss)
-                optimizer.step(params_flat, grad, opt_state, unflatten, trainable, ema=ema_params if use_ema else None)
+                optimizer.step(params_flat, grad, opt_state, unflatten, trainable, ema=ema_params if use_ema else None,
+                               losses=guard(loss), diverged=diverged)
                 continue
             static_seeds.copy_(seeds)
             graph.replay()
             opt_state["count"] += 1
             if i % every == 0:
                 mean_loss = float(g_loss.mean())
-                if mean_loss != mean_loss:
+                if mean_loss != mean_loss or int(diverged) != 0:
                     print("Diverged")
                     return losses, params_flat, ema_params
                 losses.append(mean_loss)
             continue
-        grad, (loss, z) = grad_and_loss(seeds, params_flat, unflatten, params_fixed, log_prob_model)
+        grad, aux = grad_and_loss(seeds, params_flat, unflatten, params_fixed, log_prob_model)
+        loss = aux[0]
+        if len(aux) > 2:
+            # particles sharded over ranks (parallel.make_sharded_grad_and_loss): `loss` is this rank's shard, aux[2]
+            # the merged statistics.  The guard and the logged value come from the GLOBAL sum of losses so that all
+            # ranks take the same decision.
+            loss = (aux[2][1:2] / float(n)).to(torch.float32)
         if i % every == 0:
             mean_loss = float(loss.mean())                   # the only host sync, every 0.1 % of the steps
-            if mean_loss != mean_loss:
+            if mean_loss != mean_loss or (diverged is not None and int(diverged) != 0):
                 print("Diverged")
                 return losses, params_flat, ema_params
             losses.append(mean_loss)
+        elif not fused:
+            if bool(torch.isnan(loss.mean())):               # eager path: the reference's per-iteration check
+                print("Diverged")
+                return losses, params_flat, ema_params
         if fused:
-            optimizer.step(params_flat, grad, opt_state, unflatten, trainable, ema=ema_params if use_ema else None)
+            optimizer.step(params_flat, grad, opt_state, unflatten, trainable, ema=ema_params if use_ema else None,
+                           losses=guard(loss), diverged=diverged)
         else:
             updates, opt_state = optimizer.update(grad, opt_state, params_flat)
             params_flat.add_(updates)
             project(params_flat, unflatten, trainable)
             if use_ema:
                 ema_params.mul_(1 - 0.001).add_(params_flat, alpha=0.001)   # optax.incremental_update(step_size=0.001)
+    if diverged is not None and int(diverged) != 0:
+        print("Diverged")
     return losses, params_flat, ema_params

@@ -17,10 +17,19 @@ NSTATS = 5
 
 
 def shard_range(n, world_size, rank):
-    """Contiguous block [lo, hi) of rank `rank`: ceil(n / world) per rank, last ranks may be short/empty."""
-    per = (n + world_size - 1) // world_size
-    lo = min(n, rank * per)
-    return lo, min(n, lo + per)
+    """Contiguous block [lo, hi) of rank `rank`, balanced: n // world particles per rank and one more on the first
+    n % world ranks, so a rank is empty only when there are fewer particles than ranks."""
+    per, extra = divmod(n, world_size)
+    lo = rank * per + min(rank, extra)
+    return lo, lo + per + (1 if rank < extra else 0)
+
+
+def _check_every_rank_has_particles(n, world):
+    """Evaluated identically on every rank BEFORE any collective is entered: a ValueError raised on the empty ranks
+    only would leave the others waiting in the all-gather / all-reduce."""
+    if n < world:
+        raise ValueError(f"fewer particles ({n}) than ranks ({world}): every rank needs at least one particle for the "
+                         "gradient")
 
 
 def empty_stats(device=None):
@@ -80,8 +89,11 @@ def sharded_bound(seeds_global, forward_fn, group=None):
     else:
         losses, z, stats = None, None, None
     if world > 1:
-        if stats is None:
-            stats = empty_stats(seeds_global.device if seeds_global.is_cuda else None)
+        if stats is None:   # forward only: an empty rank contributes the neutral element, on the device the collective uses
+            dev = seeds_global.device
+            if dist.get_backend(group) == "nccl" and not dev.type == "cuda":
+                dev = torch.device("cuda", torch.cuda.current_device())
+            stats = empty_stats(dev)
         rows = all_gather_stats(stats, group)
         stats = merge_stats(rows)
     out = dict(losses=losses, z=z, lo=lo, hi=hi, stats=stats)
@@ -102,8 +114,9 @@ def sharded_var_grad(seeds_global, forward_fn, grad_fn, group=None):
         world, rank = dist.get_world_size(group), dist.get_rank(group)
     n = int(seeds_global.shape[0])
     lo, hi = shard_range(n, world, rank)
+    _check_every_rank_has_particles(n, world)
     local = seeds_global[lo:hi]
-    losses, z, stats = forward_fn(local) if hi > lo else (None, None, empty_stats())
+    losses, z, stats = forward_fn(local)
     if world > 1:
         stats = merge_stats(all_gather_stats(stats, group))
     grad = grad_fn(local, losses, stats, n)
@@ -128,8 +141,7 @@ def sharded_bound_grad(seeds_global, value_and_grad_fn, group=None):
         world, rank = dist.get_world_size(group), dist.get_rank(group)
     n = int(seeds_global.shape[0])
     lo, hi = shard_range(n, world, rank)
-    if hi <= lo:
-        raise ValueError("fewer particles than ranks: every rank needs at least one particle for the gradient")
+    _check_every_rank_has_particles(n, world)
     grad, (losses, z), stats = value_and_grad_fn(seeds_global[lo:hi], n)
     if world > 1:
         stats = merge_stats(all_gather_stats(stats, group))
@@ -148,7 +160,10 @@ def make_sharded_grad_and_loss(boundmode, eps_schedule=None, grad_clipping=False
       VarGrad weights need: BASELINE's "RCCL log-w all-reduce") -> local gradient -> one all-reduce of grad_flat;
     * MCD_CAIS_sn / MCD_ULA_sn / MCD_ULA: weights 1 / N_total are known up front -> local value-and-gradient -> one
       all-reduce of grad_flat.
-    Returns (grad_flat, (local losses, local z)); with no process group it is the plain single-GPU call."""
+    Returns (grad_flat, (local losses, local z[, global statistics])); with no process group it is the plain single-GPU
+    call.  With more than one rank the third entry of the aux tuple is the MERGED 5-double statistics vector: `opt.run`
+    takes its divergence decision (isnan(mean loss), opt.py:122-124) and its logged loss from it, so that every rank
+    skips or applies the same update — the local shard's losses alone could be NaN on one rank only."""
     from . import mcdboundingmachine as mcdbm
 
     def grad_and_loss(seeds_global, params_flat, unflatten, params_fixed, log_prob):
@@ -156,18 +171,26 @@ def make_sharded_grad_and_loss(boundmode, eps_schedule=None, grad_clipping=False
         world, rank = (dist.get_world_size(group), dist.get_rank(group)) if on else (1, 0)
         n = int(seeds_global.shape[0])
         lo, hi = shard_range(n, world, rank)
-        if hi <= lo:
-            raise ValueError("fewer particles than ranks")
+        _check_every_rank_has_particles(n, world)
         local = seeds_global[lo:hi]
+        merged = {}
         if "var" in boundmode:
-            merge = (lambda st: merge_stats(all_gather_stats(st, group))) if world > 1 else None
+            def merge(st):
+                merged["stats"] = merge_stats(all_gather_stats(st, group))
+                return merged["stats"]
             grad, aux = mcdbm.compute_log_var_grad(local, params_flat, unflatten, params_fixed, log_prob,
                                                    eps_schedule=eps_schedule, grad_clipping=grad_clipping,
-                                                   n_total=n, stats_total=merge)
+                                                   n_total=n, stats_total=merge if world > 1 else None)
+        elif world > 1:
+            grad, aux, stats = mcdbm.compute_bound_grad(local, params_flat, unflatten, params_fixed, log_prob,
+                                                        eps_schedule=eps_schedule, grad_clipping=grad_clipping,
+                                                        n_total=n, return_stats=True)
+            merged["stats"] = merge_stats(all_gather_stats(stats, group))
         else:
             grad, aux = mcdbm.compute_bound_grad(local, params_flat, unflatten, params_fixed, log_prob,
                                                  eps_schedule=eps_schedule, grad_clipping=grad_clipping, n_total=n)
         if world > 1:
             dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=group)
+            return grad, (aux[0], aux[1], merged["stats"])
         return grad, aux
     return grad_and_loss

@@ -26,9 +26,14 @@
  *                             in a form that merges across ranks.
  *
  * Ownership: every pointer marked [device] is caller-owned device memory (e.g. the data_ptr() of
- * a contiguous torch tensor).  The library allocates nothing persistent, keeps no global state
- * and is re-entrant.  All work is enqueued asynchronously on `stream` (a hipStream_t, may be 0);
- * nothing in cmcd_bound_forward synchronises, so it can be captured into a hipGraph.
+ * a contiguous torch tensor).  The library allocates no device memory and keeps no state that a
+ * result depends on: what persists between calls is read-only or per host thread — cached device
+ * attributes (CU count, LDS opt-in, written once), the diagnostic wave-priority override of
+ * cmcd_coop.hip (read from the environment once), the thread-local error string and profile hook,
+ * and the lgcp gradient's thread-local side stream and events.  Calls are re-entrant as long as each
+ * concurrent call has its own `workspace` (two calls sharing a workspace must be ordered on one
+ * stream).  All work is enqueued asynchronously on `stream` (a hipStream_t, may be 0); nothing in
+ * cmcd_bound_forward synchronises, so it can be captured into a hipGraph.
  * Errors: 0 on success, negative cmcd_status otherwise; message via cmcd_last_error()
  * (thread-local).  Nothing throws across this boundary.
  */
@@ -41,7 +46,7 @@
 extern "C" {
 #endif
 
-#define CMCD_ABI_VERSION 1
+#define CMCD_ABI_VERSION 2   /* 2: cmcd_adam_step[_dev] take the divergence guard (losses, n_losses, diverged) */
 
 typedef enum cmcd_status {
   CMCD_OK = 0,
@@ -138,7 +143,8 @@ int cmcd_profile_collect(double* total_ms, int64_t* launches);
  * detach z, which makes the gradient local per bridge).  Two calls after a cmcd_bound_forward on the
  * same seeds / params:
  *   cmcd_vargrad_weights  omega[n] = d var / d w_n = -(2/N)(l_n - mean l) from loss[n] and the (merged,
- *                         for multi-GPU) statistics; n_total = global particle count.
+ *                         for multi-GPU) statistics; n_total = global particle count.  All zero while
+ *                         |var| > 1e7: the bound is clip(var, +-1e7) (mcdboundingmachine.py:231).
  *   cmcd_bound_var_grad   grad[n_params] (overwritten; zeros for leaves without gradient) =
  *                         sum_n omega_n d w_n / d params_flat.  Across ranks: all-reduce(sum) of grad.
  * MCD_CAIS_var_sn only; kernel instances exist for the BASELINE nets (dds 64; geffner widths up to 144 on the
@@ -198,7 +204,13 @@ int cmcd_mfvi_bound_grad(int32_t target, int32_t dim, int64_t off_vd_mean, int64
  * g = clip(grad, +-clip); Adam moments (optax.adam: bias correction 1 - b^step, eps outside the root);
  * params += -lr * m_hat / (sqrt(v_hat) + eps); projection of the listed ranges (opt.py:14-24);
  * optional ema = (1 - ema_step) ema + ema_step params (optax.incremental_update, opt.py:114-116).
- * step is the 1-based iteration count.  All pointers device, length n; ema may be NULL. */
+ * step is the 1-based iteration count.  All pointers device, length n; ema may be NULL.
+ * Non-finite input follows the reference: optax.clip passes a NaN gradient through (the parameter becomes NaN and the
+ * next loss trips the check), +-inf is clipped.  Divergence guard (opt.py:122-124 `if isnan(mean(loss)): return` BEFORE
+ * the update): with `losses` [n_losses] (device, nullable) the launch first decides whether mean(losses) is NaN — some
+ * loss is NaN, or +inf and -inf both occur — and if so leaves params / moments / ema untouched and sets *diverged = 1
+ * (device int32, sticky, nullable; once set every later guarded step is skipped too), so the caller may poll the flag
+ * at leisure and still gets back the last parameters the reference would have returned. */
 enum { CMCD_PROJECT_CLAMP = 0,      /* x -> min(max(x, lo), hi) */
        CMCD_PROJECT_RELU_FLOOR = 1  /* x -> relu(x - lo) + lo   (mgridref_y, opt.py:22-23) */ };
 typedef struct cmcd_project_range {
@@ -208,13 +220,15 @@ typedef struct cmcd_project_range {
 } cmcd_project_range;
 int cmcd_adam_step(float* params, const float* grad, float* mu, float* nu, float* ema, int64_t n,
                    float lr, float b1, float b2, float eps, float clip, int64_t step, float ema_step,
-                   const cmcd_project_range* ranges, int32_t n_ranges, void* stream);
+                   const cmcd_project_range* ranges, int32_t n_ranges,
+                   const float* losses, int64_t n_losses, int32_t* diverged, void* stream);
 /* The same step with the iteration count on the device (*step_counter = completed steps, int64, incremented by the
  * call): every launch argument is then constant across iterations, so a whole training iteration (gradient call
  * + this) can be captured once in a hipGraph and replayed (cmcd_amd.opt.run does, for launch-bound configs). */
 int cmcd_adam_step_dev(float* params, const float* grad, float* mu, float* nu, float* ema, int64_t n,
                        float lr, float b1, float b2, float eps, float clip, int64_t* step_counter, float ema_step,
-                       const cmcd_project_range* ranges, int32_t n_ranges, void* stream);
+                       const cmcd_project_range* ranges, int32_t n_ranges,
+                       const float* losses, int64_t n_losses, int32_t* diverged, void* stream);
 
 /* Device-side merge of `count` statistics vectors rows[count][5] (e.g. the result of an RCCL
  * all-gather of every rank's out_stats, in rank order) into out5[5], fixed order, one small kernel

@@ -25,7 +25,7 @@ def test_exports_every_declared_symbol(hip_lib):
             "cmcd_stats_merge", "cmcd_target_floats", "cmcd_profile_enable", "cmcd_profile_collect"} <= set(names)
     for n in names:
         assert hasattr(hip_lib, n), f"{n} declared in cmcd_hip.h but not exported"
-    assert hip_lib.cmcd_version() == 1
+    assert hip_lib.cmcd_version() == 2
 
 
 def _desc(**kw):
@@ -134,10 +134,11 @@ def test_gradient_and_optimiser_entry_points_validate_before_any_gpu_work(hip_li
     assert rc == -2
     rc = hip_lib.cmcd_mfvi_bound_grad(2, 2, 0, 2, None, 16, None, 4, None, 0, 1.0, None, 0, None, None, None, None, None)
     assert rc == -1
-    rc = hip_lib.cmcd_adam_step(None, None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 5.0, 1, 1e-3, None, 0, None)
+    rc = hip_lib.cmcd_adam_step(None, None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 5.0, 1, 1e-3, None, 0, None, 0,
+                                None, None)
     assert rc == -1
     rng = (_lib.ProjectRange * 9)()
     rc = hip_lib.cmcd_adam_step(C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), None, 10, 1e-3, 0.9, 0.999,
-                                1e-8, 5.0, 1, 1e-3, rng, 9, None)
+                                1e-8, 5.0, 1, 1e-3, rng, 9, None, 0, None, None)
     assert rc == -1 and "8 projection ranges" in _lib.last_error()
     assert C.sizeof(_lib.ProjectRange) == 32

@@ -274,6 +274,67 @@ def test_fused_optimiser_step_equals_the_eager_one(hip_lib):
     assert float(train["mgridref_y"].min()) >= 0.001
 
 
+def test_fused_optimiser_step_with_non_finite_input(hip_lib):
+    """optax.clip passes NaN through and clips +-inf (the eager torch.clamp does the same); a NaN mean loss skips the
+    update and raises the sticky device flag — /root/reference/src/opt.py:122-124 returns before the update."""
+    from cmcd_amd import opt
+    flat, unflatten, _ = mcdbm.initialize(dim=2, nbridges=4, eps=0.4, trainable=("eps", "mgridref_y"), mode="MCD_CAIS_sn",
+                                          nn_arch="geffner", emb_dim=4, device="cuda")
+    trainable = ("eps", "mgridref_y")
+    n = flat.numel()
+    grad = torch.randn(n, generator=torch.Generator().manual_seed(1)).cuda()
+    grad[3], grad[5], grad[7] = float("nan"), float("inf"), float("-inf")
+    pa, pb = flat.clone(), flat.clone()
+    fused, eager = opt.create_optimizer(0.05), opt._ClipAdam(0.05)
+    sa, sb = fused.init(pa), eager.init(pb)
+    fused.step(pa, grad, sa, unflatten, trainable)
+    upd, sb = eager.update(grad, sb, pb)
+    pb.add_(upd)
+    opt.project(pb, unflatten, trainable)
+    assert bool(torch.isnan(pa[3])) and bool(torch.isnan(pb[3]))
+    ok = torch.ones(n, dtype=torch.bool, device="cuda")
+    ok[3] = False
+    assert bool(torch.isfinite(pa[ok]).all()) and float((pa[ok] - pb[ok]).abs().max()) <= 1e-6
+    assert bool(torch.isnan(sa["mu"][3])) and float(sa["mu"][5]) == pytest.approx(0.5) and float(sa["mu"][7]) == pytest.approx(-0.5)
+    # the guard: a finite or +inf mean loss lets the step through, a NaN one does not and the flag stays up
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    g2 = torch.ones(n, device="cuda")
+    for losses, want_skip in ((torch.tensor([1.0, 2.0, float("inf")]), False), (torch.tensor([1.0, float("nan"), 2.0]), True),
+                              (torch.tensor([1.0, 2.0, 3.0]), True)):    # the last one: sticky
+        p = flat.clone()
+        st = fused.init(p)
+        fused.step(p, g2, st, unflatten, trainable, losses=losses.cuda(), diverged=flag)
+        assert torch.equal(p, flat) == want_skip and (int(flag) != 0) == want_skip
+        if want_skip:
+            assert float(st["mu"].abs().max()) == 0.0
+    flag.zero_()
+    p = flat.clone()
+    fused.step(p, g2, fused.init(p), unflatten, trainable, losses=torch.tensor([float("inf"), float("-inf")]).cuda(), diverged=flag)
+    assert torch.equal(p, flat) and int(flag) == 1          # inf - inf: the mean is NaN
+
+
+def test_opt_run_stops_at_a_nan_loss_with_the_last_finite_parameters(hip_lib):
+    """opt.run polls the divergence flag: a grad_and_loss that turns NaN at iteration 7 leaves the parameters of
+    iteration 6 (what /root/reference/src/opt.py:122-124 returns), however rarely the host looks."""
+    import types
+    from cmcd_amd import opt
+    flat, unflatten, fixed = mcdbm.initialize(dim=2, nbridges=4, eps=0.4, trainable=("eps",), mode="MCD_CAIS_sn",
+                                              nn_arch="geffner", emb_dim=4, device="cuda")
+    calls = {"n": 0, "snap": None}
+
+    def grad_and_loss(seeds, params_flat, *_):
+        calls["n"] += 1
+        loss = torch.ones(seeds.numel(), device="cuda")
+        if calls["n"] == 8:
+            calls["snap"] = params_flat.clone()
+        if calls["n"] >= 8:
+            loss[0] = float("nan")
+        return torch.full_like(params_flat, 0.3), (loss, None)
+    _, out, _ = opt.run(types.SimpleNamespace(N=16), 1e-2, 5000, flat, unflatten, fixed, None, grad_and_loss, ("eps",), 0)
+    assert calls["n"] < 5000 and calls["snap"] is not None and torch.equal(out, calls["snap"])
+    assert not torch.equal(out, flat)
+
+
 @pytest.mark.parametrize("mode", ["MCD_CAIS_sn", "MCD_CAIS_var_sn"])
 def test_graph_replayed_training_equals_eager_training(hip_lib, mode):
     """opt.run with the iteration captured in a HIP graph (static seed buffer, device-side Adam step count) ends

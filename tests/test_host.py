@@ -184,3 +184,14 @@ def test_cli_takes_the_reference_readme_command_lines_verbatim():
     for bad in (["--config.wandb", "x"], ["--config.wandb.nope", "x"], ["--config.nope", "1"]):
         with pytest.raises(SystemExit):
             cli.parse_flags(bad, cli.get_config())
+
+
+def test_unflatten_with_a_zero_size_leaf_in_the_middle():
+    """nbridges = 0 makes target_x an empty leaf (linspace(0, 1, 2)[1:-1]); with the default trainable it is not the
+    last one.  jax's ravel_pytree handles that; so must this one."""
+    from cmcd_amd import mcdboundingmachine as mcdbm
+    flat, unflatten, fixed = mcdbm.initialize(dim=2, nbridges=0, mode="MCD_ULA", device="cpu")
+    train, notrain = unflatten(flat)
+    assert notrain["target_x"].shape == (0,)
+    assert sum(int(np.prod(s)) if s else 1 for _, s in unflatten.layout.values()) == flat.numel()
+    assert float(train["eps"]) == pytest.approx(0.01) and notrain["vd"]["mean"].shape == (2,)

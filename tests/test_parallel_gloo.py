@@ -77,6 +77,34 @@ def test_shard_range_covers_everything():
         for w in (1, 2, 3, 8):
             r = [parallel.shard_range(n, w, k) for k in range(w)]
             assert r[0][0] == 0 and r[-1][1] == n and all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in r]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)     # balanced
+    assert all(hi > lo for lo, hi in (parallel.shard_range(9, 8, k) for k in range(8)))      # nobody empty at n >= world
+
+
+def _too_few_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    seeds = torch.arange(1, 2, dtype=torch.int32)              # one particle, two ranks
+    got = []
+    for fn in (lambda: parallel.sharded_bound_grad(seeds, lambda s, n: 1 / 0),
+               lambda: parallel.sharded_var_grad(seeds, lambda s: 1 / 0, lambda *a: 1 / 0)):
+        try:
+            fn()
+            got.append("no error")
+        except ValueError as e:
+            got.append(str(e))
+    out[rank] = got
+    dist.destroy_process_group()
+
+
+def test_fewer_particles_than_ranks_is_refused_on_every_rank():
+    """The check runs before any collective and gives the same answer on all ranks (a ValueError on the empty rank
+    alone would leave the other one waiting in the all-gather)."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_too_few_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert out[0] == out[1] and all("fewer particles" in m for m in out[0])
 
 
 def test_merge_stats_matches_c_abi():
