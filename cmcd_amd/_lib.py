@@ -95,6 +95,8 @@ def lib():
                                          C.c_void_p]
         L.cmcd_stats_merge_device.restype = C.c_int
         L.cmcd_stats_merge_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        L.cmcd_debug_capture_noise.restype = C.c_int
+        L.cmcd_debug_capture_noise.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.cmcd_profile_enable.restype = C.c_int
         L.cmcd_profile_enable.argtypes = [C.c_int]
         L.cmcd_profile_collect.restype = C.c_int

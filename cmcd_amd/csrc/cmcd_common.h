@@ -44,6 +44,11 @@ struct TrajArgs {
   float* traj;  // optional [K+1][n][D] trajectory z_0..z_K (the reparameterised gradient's reverse sweep reads it)
   int32_t ula;  // 0: CAIS; 1: MCD_ULA (no network); 2: MCD_ULA_sn (network in the backward kernel only, index i)
   int32_t prio = 0;  // cooperative kernel: s_setprio level per role, 2 bits each {MLP, TGT, RNG, ACC} from bit 0
+  // cmcd_debug_capture_noise (tests): the PRNG path of THIS launch, written next to the arithmetic that consumes it.
+  // Stage 0 = the draw of z_0, stage i + 1 = bridge i.  All nullable.
+  uint32_t* dbg_bits = nullptr;   // [K+1][n][D]  the random words that become the deviates (jax random_bits)
+  uint32_t* dbg_keys = nullptr;   // [K+1][n][2]  gen_0 .. gen_K: the chain key entering bridge i (mcd_cais.py:66,87,94)
+  float* dbg_noise = nullptr;     // [K+1][n][D]  the deviates (jax.random.normal)
 };
 
 // cmcd_coop.hip: the CU-cooperative variant (one workgroup per 16-particle tile).

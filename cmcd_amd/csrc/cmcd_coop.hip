@@ -163,7 +163,8 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
   const int gb = g & 1;
   uint32_t k0 = 0u, k1 = 0u;
   // normal(key, (D,)) bits: block j encrypts counters (j, Hh + j) -> words j and Hh + j; pad counter 0
-  auto normal_bits = [&](uint32_t nk0, uint32_t nk1, uint32_t hk0, uint32_t hk1, int buf, bool with_split) {
+  // `stage`: debug-capture index of the chain key this call derives (gen_stage), see TrajArgs::dbg_keys
+  auto normal_bits = [&](uint32_t nk0, uint32_t nk1, uint32_t hk0, uint32_t hk1, int buf, bool with_split, int stage) {
     constexpr int NB = 2 + Hh;
 #pragma unroll
     for (int b0 = with_split ? 0 : 2; b0 < NB; b0 += 4) {
@@ -173,7 +174,13 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
       uint32_t y0 = is_split ? b : jn;
       uint32_t y1 = is_split ? 2 + b : ((Hh + jn < D) ? Hh + jn : 0);
       threefry2x32(is_split ? hk0 : nk0, is_split ? hk1 : nk1, y0, y1);
-      if (with_split && b0 == 0) rows01(y1, k0, k1);  // gen = second(split(H))   mcd_cais.py:87
+      if (with_split && b0 == 0) {
+        rows01(y1, k0, k1);  // gen = second(split(H))   mcd_cais.py:87
+        if (a.dbg_keys && valid && own && g == 0) {
+          a.dbg_keys[((int64_t)stage * a.n + p) * 2] = k0;
+          a.dbg_keys[((int64_t)stage * a.n + p) * 2 + 1] = k1;
+        }
+      }
       if (jn >= 0 && jn < Hh) {
         raw[(buf * 16 + c) * NZ + jn] = y0;
         raw[(buf * 16 + c) * NZ + Hh + jn] = y1;
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
     uint32_t a0, a1, bb0, bb1;
     rows01(x0, a0, a1);
     rows01(x1, bb0, bb1);
-    normal_bits(a0, a1, 0u, 0u, 1, false);     // z0 noise = normal(A) -> raw[1]
+    normal_bits(a0, a1, 0u, 0u, 1, false, 0);  // z0 noise = normal(A) -> raw[1]
     x0 = gb; x1 = 2 + gb;
     threefry2x32(bb0, bb1, x0, x1);            // C = first(split(B))
     uint32_t c0, c1;
@@ -195,23 +202,35 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
     x0 = gb; x1 = 2 + gb;
     threefry2x32(c0, c1, x0, x1);              // gen = second(split(C))
     rows01(x1, k0, k1);
+    if (a.dbg_keys && valid && own && g == 0) {
+      a.dbg_keys[p * 2] = k0;
+      a.dbg_keys[p * 2 + 1] = k1;
+    }
     x0 = gb; x1 = 2 + gb;
     threefry2x32(k0, k1, x0, x1);              // (G, H) = split(gen)             mcd_cais.py:66
     uint32_t g0, g1, h0, h1;
     rows01(x0, g0, g1);
     rows01(x1, h0, h1);
-    normal_bits(g0, g1, h0, h1, 0, true);      // bridge 0 bits -> raw[0]
+    normal_bits(g0, g1, h0, h1, 0, true, 1);   // bridge 0 bits -> raw[0]
   }
   lds_barrier();
   // bits -> deviates, words dealt to the 4 rows of the wave
-  auto convert = [&](int buf) {
+  auto convert = [&](int buf, int stage) {
 #pragma unroll
     for (int q0 = 0; q0 < D; q0 += 4) {
       const int q = q0 + g;
-      if (q < D) nzb[(buf * 16 + c) * NZ + q] = bits_to_normal(raw[(buf * 16 + c) * NZ + q]);
+      if (q < D) {
+        const uint32_t bits = raw[(buf * 16 + c) * NZ + q];
+        const float dev = bits_to_normal(bits);
+        nzb[(buf * 16 + c) * NZ + q] = dev;
+        if (a.dbg_bits && valid && own) {
+          a.dbg_bits[((int64_t)stage * a.n + p) * D + q] = bits;
+          a.dbg_noise[((int64_t)stage * a.n + p) * D + q] = dev;
+        }
+      }
     }
   };
-  if (is_acc) convert(1);
+  if (is_acc) convert(1, 0);
   lds_barrier();
 
   // z0 = mean + std * normal(A, (D,)); w = -log q(z0)      diag_gauss.py:49-62, mcdboundingmachine.py:157
@@ -456,9 +475,9 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
         gpb[(buf * 16 + col) * GP + D] = lp;
       }
     } else if (is_rng) {
-      if (i + 1 < K) normal_bits(g0, g1, h0, h1, buf ^ 1, true);
+      if (i + 1 < K) normal_bits(g0, g1, h0, h1, buf ^ 1, true, i + 2);
     } else {
-      if (i < K) convert(buf);                       // noise of bridge i, read in phase C(i)
+      if (i < K) convert(buf, i + 1);                // noise of bridge i, read in phase C(i)
     }
     STAMP(2);
     lds_barrier();

@@ -42,6 +42,9 @@ struct ProfileState {
   int created = 0;
 };
 static thread_local ProfileState g_prof;
+// cmcd_debug_capture_noise: armed per host thread, consumed (and cleared) by the next forward call on that thread
+struct NoiseCapture { uint32_t* bits = nullptr; uint32_t* keys = nullptr; float* noise = nullptr; };
+static thread_local NoiseCapture g_capture;
 
 // Tiles (16 particles each) up to which the CU-cooperative kernel is preferred; measured crossovers on
 // MI355X (tools/probes/variant_sweep.py): dds/geffner T<=4 between 512 and 1024 tiles, the 132-wide
@@ -569,6 +572,14 @@ __global__ __launch_bounds__(512, (T > 4 || D > 4) ? 2 : 4) void traj_kernel(Tra
       const int j = j0 + g;  // block j encrypts (ctr[j], ctr[Hh + j]); pad counters are 0
       uint32_t y0 = j, y1 = (Hh + j < D) ? Hh + j : 0;
       threefry2x32(a0, a1, y0, y1);
+      if (a.dbg_bits && valid && j < Hh) {
+        a.dbg_bits[p * D + j] = y0;
+        a.dbg_noise[p * D + j] = bits_to_normal(y0);
+        if (Hh + j < D) {
+          a.dbg_bits[p * D + Hh + j] = y1;
+          a.dbg_noise[p * D + Hh + j] = bits_to_normal(y1);
+        }
+      }
       uint32_t r0[4], r1[4];
       rows0123(__float_as_uint(bits_to_normal(y0)), r0);
       rows0123(__float_as_uint(bits_to_normal(y1)), r1);
@@ -593,6 +604,10 @@ __global__ __launch_bounds__(512, (T > 4 || D > 4) ? 2 : 4) void traj_kernel(Tra
     x0 = gb; x1 = 2 + gb;
     threefry2x32(c0, c1, x0, x1);
     rows01(x1, k0, k1);
+    if (a.dbg_keys && valid && g == 0) {
+      a.dbg_keys[p * 2] = k0;
+      a.dbg_keys[p * 2 + 1] = k1;
+    }
   }
 
   // w = -log q(z0)                                       mcdboundingmachine.py:157
@@ -682,7 +697,22 @@ __global__ __launch_bounds__(512, (T > 4 || D > 4) ? 2 : 4) void traj_kernel(Tra
       uint32_t y0 = is_split ? b : jn;
       uint32_t y1 = is_split ? 2 + b : ((Hh + jn < D) ? Hh + jn : 0);
       if (!(CMCD_TRAJ_ABL & 8)) threefry2x32(is_split ? h0 : g0, is_split ? h1 : g1, y0, y1);
-      if (b0 == 0) rows01(y1, k0, k1);
+      if (b0 == 0) {
+        rows01(y1, k0, k1);
+        if (a.dbg_keys && valid && g == 0) {
+          a.dbg_keys[((int64_t)(i + 1) * a.n + p) * 2] = k0;
+          a.dbg_keys[((int64_t)(i + 1) * a.n + p) * 2 + 1] = k1;
+        }
+      }
+      if (a.dbg_bits && valid && jn >= 0 && jn < Hh) {
+        const int64_t o = ((int64_t)(i + 1) * a.n + p) * D;
+        a.dbg_bits[o + jn] = y0;
+        a.dbg_noise[o + jn] = bits_to_normal(y0);
+        if (Hh + jn < D) {
+          a.dbg_bits[o + Hh + jn] = y1;
+          a.dbg_noise[o + Hh + jn] = bits_to_normal(y1);
+        }
+      }
       uint32_t r0[4], r1[4];
       rows0123(__float_as_uint((CMCD_TRAJ_ABL & 8) ? __uint_as_float(y0) * 1e-9f : bits_to_normal(y0)), r0);
       rows0123(__float_as_uint((CMCD_TRAJ_ABL & 8) ? __uint_as_float(y1) * 1e-9f : bits_to_normal(y1)), r1);
@@ -946,8 +976,12 @@ static int forward_impl(const cmcd_desc* desc, const cmcd_layout* lay, const int
                         const float* params, int64_t n_params, const float* target_consts, int64_t n_target,
                         void* workspace, int64_t workspace_bytes, float* out_loss, float* out_z,
                         double* out_stats, float* traj, void* stream_) {
+  const NoiseCapture cap = g_capture;   // armed by cmcd_debug_capture_noise: this call consumes it, whatever happens
+  g_capture = NoiseCapture{};
   int rc = check_desc(desc);
   if (rc != CMCD_OK) return rc;
+  if ((cap.bits || cap.keys) && desc->target == CMCD_TARGET_LGCP)
+    return fail(CMCD_ERR_UNSUPPORTED, "cmcd_debug_capture_noise: trajectory kernels only (not the lgcp launch sequence)%s");
   if (!lay || !seeds || !params || !workspace || !out_loss || !out_z || !out_stats)
     return fail(CMCD_ERR_BAD_ARG, "null pointer argument%s");
   if (n < 1 || n > (int64_t)1 << 31) return fail(CMCD_ERR_BAD_ARG, "n out of range%s");
@@ -1013,6 +1047,7 @@ static int forward_impl(const cmcd_desc* desc, const cmcd_layout* lay, const int
               (int32_t)K, d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0,
               (d.mode == CMCD_MODE_ULA || d.mode == CMCD_MODE_ULA_SN) ? 0 : d.grad_clipping, traj,
               d.mode == CMCD_MODE_ULA ? 1 : (d.mode == CMCD_MODE_ULA_SN ? 2 : 0)};
+  ta.dbg_bits = cap.bits; ta.dbg_keys = cap.keys; ta.dbg_noise = cap.noise;
   // Kernel variant (desc.reserved: 0 auto, 1 wave-per-tile, 2 CU-cooperative, 3 cooperative on 16-particle tiles,
   // 4 cooperative on 8-particle tiles).  Auto: the cooperative kernel while the batch cannot fill the chip with one
   // wave per tile, on 8-particle tiles while those still get a CU each (n <= 8 x 256).
@@ -1077,6 +1112,12 @@ static int forward_impl(const cmcd_desc* desc, const cmcd_layout* lay, const int
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, stream,
                      reinterpret_cast<const double*>(ws + w.partials), w.n_waves, out_stats);
   CMCD_HIP_CHECK(hipGetLastError());
+  return CMCD_OK;
+}
+
+int cmcd_debug_capture_noise(uint32_t* bits, uint32_t* gen_keys, float* noise) {
+  if ((bits == nullptr) != (noise == nullptr)) return fail(CMCD_ERR_BAD_ARG, "bits and noise go together%s");
+  g_capture.bits = bits; g_capture.keys = gen_keys; g_capture.noise = noise;
   return CMCD_OK;
 }
 

@@ -138,6 +138,15 @@ int cmcd_bound_forward(const cmcd_desc* desc, const cmcd_layout* layout,
 int cmcd_profile_enable(int on);
 int cmcd_profile_collect(double* total_ms, int64_t* launches);
 
+/* Diagnostic (tests/test_gpu_prng.py): arm a capture of the PRNG path of the NEXT cmcd_bound_forward issued by this host
+ * thread (gmm / funnel / many_gmm; either trajectory kernel writes the words next to the arithmetic that consumes
+ * them; consumed and disarmed by that call).  [device] buffers, stage 0 = the draw of z_0, stage i + 1 = bridge i:
+ *   bits     uint32 [nbridges+1][n][dim]  the random words that become deviates (jax random_bits of normal(key, (dim,)))
+ *   gen_keys uint32 [nbridges+1][n][2]    the chain key entering bridge i, gen_0 .. gen_K (mcd_cais.py:66,87,94); nullable
+ *   noise    float  [nbridges+1][n][dim]  the deviates (jax.random.normal)
+ * Pass three NULLs to disarm. */
+int cmcd_debug_capture_noise(uint32_t* bits, uint32_t* gen_keys, float* noise);
+
 /* ---- VarGrad gradient ("compute_log_var_grad"): d/d params_flat of compute_bound_var
  * (/root/reference/src/main.py:161-176 takes jax.grad of it; /root/reference/src/mcd_cais_var.py:59,79
  * detach z, which makes the gradient local per bridge).  Two calls after a cmcd_bound_forward on the
