@@ -43,9 +43,18 @@ __device__ __forceinline__ void threefry2x32(uint32_t k0, uint32_t k1, uint32_t&
 
 // XLA's f32 erf_inv (Giles' single-precision polynomial), as used by jax.random.normal.
 __device__ __forceinline__ float erfinv_giles(float x) {
-  // w = -log(1 - x^2) = -ln2 * log2((1 - x)(1 + x)): both factors are exact near |x| = 1, one
-  // v_log_f32; absolute error of w < 1e-6, i.e. <= 2 ulp of the resulting normal deviate.
-  float w = -0.69314718055994530942f * __builtin_amdgcn_logf((1.0f - x) * (1.0f + x));
+  // w = -log1p(-x * x) with x * x ROUNDED to float32 first, as XLA evaluates it: for |x| near 1 the rounding of x^2
+  // moves 1 - x^2 by up to 2e-4 relative, i.e. the deviate by up to ~90 ulp against the mathematically better
+  // (1 - x)(1 + x) — the reference's numbers carry that rounding, so this does too (the subtraction 1 - t is exact
+  // for t >= 1/2 and costs < 0.3 ulp of the deviate below).  One v_log_f32; measured against the float32 restatement
+  // of XLA's formula over all 2^23 mantissas: <= 4 ulp (tests/test_gpu_prng.py holds every captured deviate to that).
+  float om;
+  {
+#pragma clang fp contract(off)   // hipcc contracts 1 - x * x into fma(-x, x, 1) — exactly the rounding XLA does NOT skip
+    const float t = x * x;
+    om = 1.0f - t;
+  }
+  float w = -0.69314718055994530942f * __builtin_amdgcn_logf(om);
   float p;
   if (w < 5.0f) {
     w = w - 2.5f;

@@ -249,8 +249,13 @@ __device__ __forceinline__ void prep_dds_body(const DdsPrepArgs& a, int t) {
   if (q == 0) {
     // timestep_coeff = jnp.linspace(0.1, 100, 64): float32 arithmetic, start (1 - s) + stop s with s = iota / 63, the
     // end point appended exactly (nn_dds.py:108; `np` there is jax.numpy).  Unfused: XLA folds it as written.
-    const float sj = __fdiv_rn((float)j, 63.0f);
-    const float cj = (j == 63) ? 100.0f : __fadd_rn(__fmul_rn(0.1f, __fsub_rn(1.0f, sj)), __fmul_rn(100.0f, sj));
+    float cj;
+    {
+#pragma clang fp contract(off)
+      const float sj = (float)j / 63.0f;
+      const float lo_part = 0.1f * (1.0f - sj), hi_part = 100.0f * sj;
+      cj = (j == 63) ? 100.0f : lo_part + hi_part;
+    }
     const float arg = cj * (float)t + P[a.lay.d_phase + j];
     e[j] = sinf(arg);
     e[64 + j] = cosf(arg);

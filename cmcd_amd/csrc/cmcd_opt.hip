@@ -66,7 +66,8 @@ __global__ void adam_step_kernel(OptArgs a) {
   float p = a.params[i] - a.lr * (m * c1) / (sqrtf(v * c2) + a.eps);
   for (int r = 0; r < a.n_ranges; ++r) {
     const cmcd_project_range q = a.ranges[r];
-    if (i >= q.offset && i < q.offset + q.length)
+    // jnp.clip / jax.nn.relu propagate NaN (fminf / fmaxf would return the bound and hide a diverged parameter)
+    if (i >= q.offset && i < q.offset + q.length && p == p)
       p = q.kind == CMCD_PROJECT_CLAMP ? fminf(fmaxf(p, q.lo), q.hi) : fmaxf(p - q.lo, 0.0f) + q.lo;
   }
   a.params[i] = p;

@@ -192,3 +192,41 @@ def test_work_item_and_whole_chain_gradients_agree_on_a_large_batch(hip_lib, mon
         scale = float(r.abs().max())
         if scale > 1e-9:
             assert float((a - r).abs().max()) <= 2e-4 * scale, (path, float((a - r).abs().max()), scale)
+
+
+@pytest.mark.parametrize("n,k,reps", [(20, 128, 200), (600, 8, 30)])
+def test_lgcp_repeat_calls_are_bitwise_identical(hip_lib, n, k, reps):
+    """Config 5 at its own size, the same call `reps` times: forward and both gradients must return bit-identical
+    results every time.  The d = 1600 launch sequence is the only path with inter-workgroup communication (8 K-slice
+    workgroups of a column block count arrivals on a device counter, the last one sums the partial slabs in fixed
+    order and runs the fused consumer, cmcd_lgcp.hip): a missing release / acquire would show up as a stale slab,
+    i.e. as a run-to-run difference."""
+    from helpers import lgcp_counts_fixture
+    b = synthetic.build("lgcp_n20_k128", device="cuda", lgcp_counts=lgcp_counts_fixture(), nbridges=k, N=n, dense=True)
+    seeds = torch.from_numpy(synthetic.throughput_seeds(n, stream=4)).cuda()
+    args = (b["params_flat"], b["unflatten"], b["params_fixed"], b["target"])
+    l0, z0, s0 = mcdbm.bound_forward(seeds, *args)
+    torch.cuda.synchronize()
+    assert torch.isfinite(l0).all()
+    for r in range(reps):
+        l, z, st = mcdbm.bound_forward(seeds, *args)
+        assert torch.equal(l, l0) and torch.equal(z, z0) and torch.equal(st, s0), f"forward repeat {r} differs"
+    g0, (lg0, _) = mcdbm.compute_bound_grad(seeds, *args)
+    torch.cuda.synchronize()
+    assert torch.equal(lg0, l0) and torch.isfinite(g0).all()
+    for r in range(max(reps // 4, 10)):
+        g, (lg, _) = mcdbm.compute_bound_grad(seeds, *args)
+        assert torch.equal(lg, l0) and torch.equal(g, g0), f"gradient repeat {r} differs"
+    # the VarGrad sweep of the same sequence
+    bv = synthetic.build("lgcp_n20_k128", device="cuda", lgcp_counts=lgcp_counts_fixture(), nbridges=k, N=n, dense=True,
+                         boundmode="MCD_CAIS_var_sn")
+    argv = (bv["params_flat"], bv["unflatten"], bv["params_fixed"], bv["target"])
+    v0, (lv0, _) = mcdbm.compute_log_var_grad(seeds, *argv)
+    for r in range(10):
+        v, (lv, _) = mcdbm.compute_log_var_grad(seeds, *argv)
+        assert torch.equal(lv, lv0) and torch.equal(v, v0), f"VarGrad repeat {r} differs"
+    # batch-composition invariance across GEMM passes: a particle's loss does not depend on its row / pass
+    if n > 64:
+        perm = torch.from_numpy(np.random.default_rng(1).permutation(n)).cuda()
+        lp, _, _ = mcdbm.bound_forward(seeds[perm], *args)
+        assert torch.equal(lp, l0[perm])

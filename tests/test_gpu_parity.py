@@ -52,9 +52,11 @@ def test_bound_matches_oracle(hip_lib, param_set, variant, name, n, over):
         assert not np.isfinite(float(val))
 
 
-@pytest.mark.parametrize("n,k", [(20, 8), (5, 3), (40, 2)])
+@pytest.mark.parametrize("n,k", [(20, 8), (5, 3), (40, 2), (20, 128), (600, 16)])
 def test_lgcp_matches_oracle(hip_lib, param_set, n, k):
-    """d = 1600 (config 5): per-bridge GEMM path.  40 particles = two passes of the 32-row GEMM."""
+    """d = 1600 (config 5): per-bridge GEMM path.  40 particles = two passes of the 32-row GEMM; (20, 128) is the
+    configuration's own size (BASELINE.json configs[4]), 600 particles the evaluation batch of the reference's lgcp
+    runs (n_samples 500-600 per seed group, /root/reference/README.md:63; 19 passes)."""
     import os
     counts = np.load(os.path.join(os.path.dirname(__file__), "golden", "lgcp_bin_counts.npy"))
     b = synthetic.build("lgcp_n20_k128", device="cuda", lgcp_counts=counts, nbridges=k)

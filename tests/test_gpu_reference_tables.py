@@ -34,7 +34,7 @@ def _run(model, k, seed):
             "--config.n_samples", str(hp["n_samples"]), "--config.nbridges", str(k), "--config.seed", str(seed)]
     if model == "funnel":   # README.md:53; init_eps / lr are overwritten from FUNNEL_EPS_DICT by setup_config
         argv += ["--config.init_eps", "0.1", "--config.lr", "0.01", "--config.eps_schedule", "cos_sq"]
-    else:                   # README.md:73 with the notebook table's init_sigma
+    else:                   # README.md:73
         argv += ["--config.init_eps", str(hp["init_eps"]), "--config.lr", str(hp["lr"])]
     return cli.main(cli.parse_flags(argv, cli.get_config()))
 
