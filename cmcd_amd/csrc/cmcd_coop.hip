@@ -84,6 +84,7 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
   float* nzb = gpb + 2 * 16 * GP;            // [2][16][NZ]    Gaussian noise
   uint32_t* raw = reinterpret_cast<uint32_t*>(nzb + 2 * 16 * NZ);  // [2][16][NZ] raw bits
   float* lds_tgt = reinterpret_cast<float*>(raw + 2 * 16 * NZ);
+  float* lds_sched = lds_tgt + a.w.tgt_floats;   // [K][8] the schedule table (tgt_floats is a multiple of 4)
 
   // Role = hardware wave index: waves go to SIMD (index % 4), so every SIMD holds one MLP wave and one auxiliary wave.
   // Measured alternative (profiles/r01_r_simd_map.txt): MLP waves paired on SIMDs 0 / 1 and the auxiliary waves on 2 / 3
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
   const int K = a.K;
 
   for (int i = threadIdx.x; i < a.w.tgt_floats; i += blockDim.x) lds_tgt[i] = a.ws[a.w.tgt + i];
+  for (int i = threadIdx.x; i < 8 * K; i += blockDim.x) lds_sched[i] = a.ws[a.w.sched + i];
   // issue priority of this wave's role against its SIMD partner (s_setprio takes an immediate)
   switch ((a.prio >> (is_mlp ? 0 : is_tgt ? 2 : is_rng ? 4 : 6)) & 3) {
     case 1: __builtin_amdgcn_s_setprio(1); break;
@@ -260,9 +262,6 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
     }
     return *reinterpret_cast<const f32x4*>(ptr);
   };
-  // per-lane copy of the (uniform) schedule pointer so that the loads are vector loads
-  const float* sched_v = a.ws + a.w.sched + (lane & 0);
-  asm volatile("" : "+v"(sched_v));
   // HALF: hbuf is [8 particles][HQP]; the lane writes its neuron pair, reads its particle's half kh of the neurons
   float* const my_h = HALF ? hbuf + c * HQP + nb : hbuf + ((wv * 4 + g) * 16 + (lane & 15)) * 4;
   const float* const rd_h = HALF ? hbuf + c * HQP + (HP / 2) * kh : hbuf + (g * 16 + (lane & 15)) * 4;
@@ -285,8 +284,16 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
   // v_med3_f32 against +-inf when clipping is off (no branch).
   const float cp = clip_p ? clipv : INFINITY, cq = clip_q ? clipv : INFINITY;
   float pA = 0.f, pB = 0.f;
-  auto phase_c = [&](int e, bool track_w, const f32x4& sc, const f32x4& sd) {
+  auto phase_c = [&](int e, bool track_w) {
     const int pb = e & 1;
+    // per-bridge scalars {beta, eps, sigma, log sigma + log sqrt(2 pi) | 1/(2 sigma^2), eps beta, eps (1 - beta), 0} from
+    // the LDS copy of the schedule table: two broadcast reads in the same batch as the exchange buffers below.  (r01
+    // fetched the row from L2 at the top of every iteration; the loaded registers were dead on some role paths, got
+    // re-used there, and the resulting hazard put `s_waitcnt vmcnt(0)` — a full L2 round trip — at the start of
+    // interval 1 of every wave and bridge.)
+    const int srow = e < K ? e : K - 1;
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(lds_sched + 8 * srow);
+    const f32x4 sd = *reinterpret_cast<const f32x4*>(lds_sched + 8 * srow + 4);
     const float eps = sc[1], sig = sc[2], cst = sc[3], inv2s2 = sd[0], cA = sd[1], cB = sd[2];
     float sn[D], gp[D], gq[D];
     {
@@ -347,12 +354,6 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
   if (is_tgt) Target<TARGET, D>::template load_means<LPT>(sub8, lds_tgt, tmeans);
   for (int i = 0; i <= K; ++i) {
     const int buf = i & 1;
-    // per-bridge scalars {beta, eps, sigma, log sigma + log sqrt(2 pi), 1/(2 sigma^2)}.  VECTOR loads
-    // (vmcnt) issued early: a scalar load would sit on lgkmcnt, which every LDS wait of the step drains,
-    // exposing its full L2 latency.  MLP waves need row i (phase C(i) after barrier 2), ACC row i-1.
-    const int srow = i < K ? i : K - 1;
-    const f32x4 sc0 = *reinterpret_cast<const f32x4*>(sched_v + 8 * srow);
-    const f32x4 sc1 = *reinterpret_cast<const f32x4*>(sched_v + 8 * srow + 4);
     float h[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) h[r] = 0.f;
@@ -484,8 +485,8 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
     STAMP(3);
     // ------------------------------------------------------------------ phase C: MLP, TGT (own copies of z) and
     // ACC (with the log-weight); ~45 instructions each, so the redundancy is cheaper than an LDS hand-over
-    if (is_acc) phase_c(i, true, sc0, sc1);          // i = K: closes step K-1 and picks up log p(z_K)
-    else if ((is_mlp || is_tgt) && i < K) phase_c(i, false, sc0, sc1);
+    if (is_acc) phase_c(i, true);                    // i = K: closes step K-1 and picks up log p(z_K)
+    else if ((is_mlp || is_tgt) && i < K) phase_c(i, false);
     STAMP(4);
   }
 #ifdef CMCD_STAMPS
@@ -555,8 +556,11 @@ extern "C" int cmcd_debug_read_stamps(unsigned long long* out) {
 }
 #endif
 
-bool coop_available(const cmcd_desc& d, int T) { return pick(d, T, false) != nullptr; }
-bool coop_half_available(const cmcd_desc& d, int T) { return pick(d, T, true) != nullptr; }
+// the schedule table rides in LDS (32 B per bridge) next to ~10 KB of exchange buffers
+static constexpr size_t kCoopMaxLds = 64 * 1024;
+bool coop_fits(const cmcd_desc& d) { return (size_t)d.nbridges * 32 + 16 * 1024 <= kCoopMaxLds; }
+bool coop_available(const cmcd_desc& d, int T) { return coop_fits(d) && pick(d, T, false) != nullptr; }
+bool coop_half_available(const cmcd_desc& d, int T) { return coop_fits(d) && pick(d, T, true) != nullptr; }
 
 // half: 8-particle tiles (ceil(n / 8) workgroups, as many statistics records); else ta.w.n_waves 16-particle tiles
 // Issue priority per role (s_setprio against the SIMD partner), tools/probes/prio_sweep.py, interleaved rounds
@@ -577,7 +581,9 @@ int coop_launch(const cmcd_desc& d, const TrajArgs& ta_in, bool half, void* stre
   coop_fn fn = pick(d, T, half);
   if (!fn) return CMCD_ERR_UNSUPPORTED;
   const int ZP = (D + 3) & ~3;
-  const size_t lds_bytes = size_t(16 * T * 16 + 2 * 16 * PT + 16 * ZP + 2 * 16 * GP + 2 * 16 * NZ + 2 * 16 * NZ + ta.w.tgt_floats) * 4;
+  const size_t lds_bytes = size_t(16 * T * 16 + 2 * 16 * PT + 16 * ZP + 2 * 16 * GP + 2 * 16 * NZ + 2 * 16 * NZ + ta.w.tgt_floats +
+                                  8 * (size_t)ta.K) * 4;
+  if (lds_bytes > kCoopMaxLds) return CMCD_ERR_UNSUPPORTED;   // callers check coop_fits() first
   const unsigned tiles = half ? unsigned((ta.n + 7) / 8) : (unsigned)ta.w.n_waves;
   // While there are no more workgroups than CUs, claim more than half of a CU's 160 KB of LDS: the dispatcher can
   // then never put two workgroups on one CU while another CU sits idle (two on a CU share its SIMDs and the
