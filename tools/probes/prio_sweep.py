@@ -30,11 +30,11 @@ def enc(mlp, tgt, rng, acc):
     return mlp | tgt << 2 | rng << 4 | acc << 6
 
 
-for variant in (4, 3):
+for variant in (4,):
     mcdbm.KERNEL_VARIANT = variant
     t(0, 50)   # clocks settle
-    cands = [(0, 0, 0, 0), (0, 1, 0, 0), (0, 3, 0, 0), (0, 1, 0, 1), (1, 1, 0, 1), (0, 2, 0, 1), (1, 2, 0, 1), (0, 0, 0, 1), (1, 0, 0, 0),
-             (0, 0, 1, 0)]
+    cands = [(0, 0, 0, 0), (0, 1, 0, 1), (1, 1, 0, 1), (1, 0, 0, 0), (1, 0, 0, 1), (2, 1, 0, 1), (0, 1, 0, 0), (0, 0, 0, 1), (0, 2, 0, 1),
+             (0, 1, 0, 2), (0, 2, 0, 2), (0, 0, 1, 0)]
     res = {c: [] for c in cands}
     for rnd in range(4):   # interleaved rounds: drift hits every candidate alike
         for c in cands:
