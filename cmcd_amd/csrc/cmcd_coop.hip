@@ -66,8 +66,11 @@ __device__ __forceinline__ void lds_barrier() {
 // the layer-3 products; both halves are written to both columns of the MFMA B operand, the layer-3 partial is
 // completed by one DPP row_ror:8 add.  A batch of <= 2048 particles then runs on twice the CUs (N = 2000: 250
 // workgroups instead of 125 on 256 CUs) with a shorter per-bridge chain on each.
-template <int TARGET, int ARCH, int D, int T, bool HALF>
-__global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
+// MERGE: the RNG and ACC roles share one wave (T + 3 waves per workgroup).  Used by the 9-tile (132-wide net) instance
+// on 8-particle tiles: twelve waves are three per SIMD = 168 registers each, which the 72 resident 4x4x1 operands of
+// an MLP wave need; and with 72 matrix instructions per MLP wave and bridge the key chain is no longer the long pole.
+template <int TARGET, int ARCH, int D, int T, bool HALF, bool MERGE = false>
+__global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajArgs a) {
   constexpr int HP = 16 * T;
   constexpr int PPT = HALF ? 8 : 16;         // particles per tile
   constexpr int NR = HALF ? 2 : 4;           // neurons per lane and 16-neuron tile (element-wise work)
@@ -91,7 +94,8 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
   // (no auxiliary wave ever blocked by an MFMA, but two MFMA chains per matrix pipe) is 6.7 % slower.
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63, g = lane >> 4;
-  const bool is_mlp = wv < T, is_tgt = wv == T || wv == T + 1, is_rng = wv == T + 2, is_acc = wv == T + 3;
+  const bool is_mlp = wv < T, is_tgt = wv == T || wv == T + 1, is_rng = wv == T + 2;
+  const bool is_acc = MERGE ? (wv == T + 2) : (wv == T + 3);
   // particle column of this lane: TGT waves hold 8 particles x 8 lanes (HALF: 4 particles x 16 lanes — the tile's 8
   // particles over the two waves, results written to both twin columns), everyone else 16 x 4
   constexpr int LPT = HALF ? 16 : 8;         // lanes per particle on the target waves
@@ -393,7 +397,7 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
       }
     } else if (is_tgt) {
       Target<TARGET, D>::template pass1r<LPT>(z, sub8, lds_tgt, tmeans, tst);   // distances / shift of z_i (own z, means in registers)
-    } else if (is_rng && i + 1 < K) {
+    } else if (is_rng && !MERGE && i + 1 < K) {
       uint32_t x0 = gb, x1 = 2 + gb;
       threefry2x32(k0, k1, x0, x1);            // (G, H) = split(gen) of bridge i+1
       rows01(x0, g0, g1);
@@ -418,17 +422,45 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
         // all LDS reads in flight before the first MFMA (one round trip, not one per group of four), and two
         // accumulators (even / odd inputs): a 4x4x1 MFMA that reads its predecessor's result needs two wait states
         constexpr int NQB = HALF ? NQ / 4 : 1;
-        f32x4 hb[NQB];
-#pragma unroll
-        for (int q = 0; q < NQB; ++q) hb[q] = *reinterpret_cast<const f32x4*>(rd_h + 4 * q);
-        __builtin_amdgcn_sched_barrier(0);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (NQB <= 8) {
+          f32x4 hb[NQB];
 #pragma unroll
-        for (int q = 0; q < NQB; ++q) {
-          acc = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * q + 0], hb[q][0], acc, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * q + 1], hb[q][1], acc1, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * q + 2], hb[q][2], acc, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * q + 3], hb[q][3], acc1, 0, 0, 0);
+          for (int q = 0; q < NQB; ++q) hb[q] = *reinterpret_cast<const f32x4*>(rd_h + 4 * q);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < NQB; ++q) {
+            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * q + 0], hb[q][0], acc, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * q + 1], hb[q][1], acc1, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * q + 2], hb[q][2], acc, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * q + 3], hb[q][3], acc1, 0, 0, 0);
+          }
+        } else {
+          // wide nets (9 tiles: 18 reads): the activations arrive in chunks of CH reads, chunk k + 1 requested before
+          // the matrix instructions of chunk k issue, so that the registers of one and a half chunks suffice
+          constexpr int CH = 3, NCH = NQB / CH;
+          static_assert(NQB % CH == 0, "chunking");
+          f32x4 hb[2][CH];
+#pragma unroll
+          for (int q = 0; q < CH; ++q) hb[0][q] = *reinterpret_cast<const f32x4*>(rd_h + 4 * q);
+#pragma unroll
+          for (int ch = 0; ch < NCH; ++ch) {
+            if (ch + 1 < NCH) {
+#pragma unroll
+              for (int q = 0; q < CH; ++q)
+                hb[(ch + 1) & 1][q] = *reinterpret_cast<const f32x4*>(rd_h + 4 * ((ch + 1) * CH + q));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+              const int qq = ch * CH + q;
+              acc = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * qq + 0], hb[ch & 1][q][0], acc, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * qq + 1], hb[ch & 1][q][1], acc1, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * qq + 2], hb[ch & 1][q][2], acc, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * qq + 3], hb[ch & 1][q][3], acc1, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
         acc += acc1;
         // the two halves of the contraction sit in lanes l and l ^ 32; lane kh keeps neurons 2 kh + {0, 1} of its group
@@ -476,7 +508,17 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
         gpb[(buf * 16 + col) * GP + D] = lp;
       }
     } else if (is_rng) {
+      // MERGE: nothing this wave produces is read before barrier 2 (the log-weight is its own, the bits and deviates are
+      // consumed in phase C), so its phase C runs straight into barrier 1 and the whole key-chain stage sits here — the
+      // MLP waves would otherwise wait at barrier 1 for a split they do not need (r02 stamps: 700 - 1100 cycles)
+      if (MERGE && i + 1 < K) {
+        uint32_t x0 = gb, x1 = 2 + gb;
+        threefry2x32(k0, k1, x0, x1);            // (G, H) = split(gen) of bridge i+1
+        rows01(x0, g0, g1);
+        rows01(x1, h0, h1);
+      }
       if (i + 1 < K) normal_bits(g0, g1, h0, h1, buf ^ 1, true, i + 2);
+      if (MERGE && i < K) convert(buf, i + 1);       // raw[buf] was written one iteration ago by this same wave
     } else {
       if (i < K) convert(buf, i + 1);                // noise of bridge i, read in phase C(i)
     }
@@ -524,30 +566,39 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_kernel(TrajArgs a) {
 }
 
 typedef void (*coop_fn)(TrajArgs);
+struct CoopInstance {
+  coop_fn fn = nullptr;
+  int waves = 0;   // per workgroup
+};
 
 template <int TARGET, int ARCH, int D>
-static coop_fn pick_T(int T, bool half) {
+static CoopInstance pick_T(int T, bool half) {
   switch (T) {
-    case 2: return half ? coop_kernel<TARGET, ARCH, D, 2, true> : coop_kernel<TARGET, ARCH, D, 2, false>;
-    case 4: return half ? coop_kernel<TARGET, ARCH, D, 4, true> : coop_kernel<TARGET, ARCH, D, 4, false>;
-    case 9: return half ? nullptr : coop_kernel<TARGET, ARCH, D, 9, false>;   // 132-wide net: full tiles only
-    default: return nullptr;
+    case 2: return {half ? coop_kernel<TARGET, ARCH, D, 2, true> : coop_kernel<TARGET, ARCH, D, 2, false>, 6};
+    case 4: return {half ? coop_kernel<TARGET, ARCH, D, 4, true> : coop_kernel<TARGET, ARCH, D, 4, false>, 8};
+    case 9:   // 132-wide net; the 2-d targets also on 8-particle tiles (merged RNG / ACC wave: 12 waves)
+      if (half) {
+        if constexpr (D == 2) return {coop_kernel<TARGET, ARCH, D, 9, true, true>, 12};
+        return {};
+      }
+      return {coop_kernel<TARGET, ARCH, D, 9, false>, 13};
+    default: return {};
   }
 }
 
-static coop_fn pick(const cmcd_desc& d, int T, bool half) {
+static CoopInstance pick(const cmcd_desc& d, int T, bool half) {
   const int arch = d.arch == CMCD_ARCH_DDS ? CMCD_ARCH_DDS : CMCD_ARCH_GEFFNER;
   if (arch == CMCD_ARCH_DDS) {
-    if (T != 4) return nullptr;
+    if (T != 4) return {};
     if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2) return pick_T<CMCD_TARGET_MANY_GMM, CMCD_ARCH_DDS, 2>(T, half);
     if (d.target == CMCD_TARGET_GMM && d.dim == 2) return pick_T<CMCD_TARGET_GMM, CMCD_ARCH_DDS, 2>(T, half);
     if (d.target == CMCD_TARGET_FUNNEL && d.dim == 10) return pick_T<CMCD_TARGET_FUNNEL, CMCD_ARCH_DDS, 10>(T, half);
-    return nullptr;
+    return {};
   }
   if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2) return pick_T<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2>(T, half);
   if (d.target == CMCD_TARGET_GMM && d.dim == 2) return pick_T<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER, 2>(T, half);
   if (d.target == CMCD_TARGET_FUNNEL && d.dim == 10) return pick_T<CMCD_TARGET_FUNNEL, CMCD_ARCH_GEFFNER, 10>(T, half);
-  return nullptr;
+  return {};
 }
 
 #ifdef CMCD_STAMPS
@@ -559,8 +610,8 @@ extern "C" int cmcd_debug_read_stamps(unsigned long long* out) {
 // the schedule table rides in LDS (32 B per bridge) next to ~10 KB of exchange buffers
 static constexpr size_t kCoopMaxLds = 64 * 1024;
 bool coop_fits(const cmcd_desc& d) { return (size_t)d.nbridges * 32 + 16 * 1024 <= kCoopMaxLds; }
-bool coop_available(const cmcd_desc& d, int T) { return coop_fits(d) && pick(d, T, false) != nullptr; }
-bool coop_half_available(const cmcd_desc& d, int T) { return coop_fits(d) && pick(d, T, true) != nullptr; }
+bool coop_available(const cmcd_desc& d, int T) { return coop_fits(d) && pick(d, T, false).fn != nullptr; }
+bool coop_half_available(const cmcd_desc& d, int T) { return coop_fits(d) && pick(d, T, true).fn != nullptr; }
 
 // half: 8-particle tiles (ceil(n / 8) workgroups, as many statistics records); else ta.w.n_waves 16-particle tiles
 // Issue priority per role (s_setprio against the SIMD partner), tools/probes/prio_sweep.py, interleaved rounds
@@ -578,7 +629,8 @@ int coop_launch(const cmcd_desc& d, const TrajArgs& ta_in, bool half, void* stre
   ta.prio = g_coop_prio >= 0 ? g_coop_prio : default_prio(d, half);
   const int T = ta.w.T, D = d.dim, Hh = (D + 1) / 2, NZ = 2 * Hh;
   const int GP = (D + 1 + 3) & ~3, PT = (T * D + 3) & ~3;
-  coop_fn fn = pick(d, T, half);
+  const CoopInstance inst = pick(d, T, half);
+  coop_fn fn = inst.fn;
   if (!fn) return CMCD_ERR_UNSUPPORTED;
   const int ZP = (D + 3) & ~3;
   const size_t lds_bytes = size_t(16 * T * 16 + 2 * 16 * PT + 16 * ZP + 2 * 16 * GP + 2 * 16 * NZ + 2 * 16 * NZ + ta.w.tgt_floats +
@@ -610,7 +662,7 @@ int coop_launch(const cmcd_desc& d, const TrajArgs& ta_in, bool half, void* stre
     }
     if (ok && lds_claim < kExclusive) lds_claim = kExclusive;
   }
-  hipLaunchKernelGGL(fn, dim3(tiles), dim3(64 * (T + 4)), lds_claim,
+  hipLaunchKernelGGL(fn, dim3(tiles), dim3(64 * inst.waves), lds_claim,
                      static_cast<hipStream_t>(stream), ta);
   return CMCD_OK;
 }

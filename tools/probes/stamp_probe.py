@@ -24,7 +24,7 @@ from cmcd_amd import mcdboundingmachine as mcdbm  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else synthetic.NORTH_STAR
 b = synthetic.build(name, device="cuda")
-n = b["cfg"]["N"]
+n = int(sys.argv[2]) if len(sys.argv) > 2 else b["cfg"]["N"]
 seeds = torch.from_numpy(synthetic.throughput_seeds(n)).cuda()
 for _ in range(3):
     mcdbm.bound_forward(seeds, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"],
@@ -37,8 +37,11 @@ K = b["params_fixed"][1]
 names = ["int1 work", "wait bar1", "int2 work", "wait bar2", "phase C"]
 T = (b["params_fixed"][3].width + 15) // 16 if b["params_fixed"][3].arch == "geffner" else 4
 print("cycles per bridge step, workgroup 0:")
-for wv in range(T + 4):
+nw = T + 4
+if buf[(T + 3) * 16] == 0 and buf[(T + 3) * 16 + 2] == 0:
+    nw = T + 3           # merged RNG / ACC wave (9-tile instance on 8-particle tiles)
+for wv in range(nw):
     row = [buf[wv * 16 + k] / (K + 1) for k in range(5)]
     fine = [buf[wv * 16 + k] / (K + 1) for k in range(5, 10)]
-    role = "MLP%d" % wv if wv < T else ["TGT0", "TGT1", "RNG", "ACC"][wv - T]
+    role = "MLP%d" % wv if wv < T else (["TGT0", "TGT1", "RNG", "ACC"] if nw == T + 4 else ["TGT0", "TGT1", "RNG+ACC"])[wv - T]
     print("%5s " % role + "  ".join("%s=%7.0f" % (nm, v) for nm, v in zip(names, row)) + "  total=%7.0f" % (sum(row) + sum(fine)) + "  | fine[L1,preMFMA,MFMA,act,C-reads]=" + " ".join("%5.0f" % v for v in fine))
