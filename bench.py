@@ -1,11 +1,18 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the CMCD annealed-Langevin bound on MI355X.
 
-A "step" is one `compute_bound` forward over one batch of synthetic particles (the hot path named
-by BASELINE.json: many_gmm, MCD_CAIS_sn, N=2000, nbridges=256, dds net).  Multi-GPU: one process per
-GPU (torch.distributed, backend nccl = RCCL); every rank runs the named batch on its own seeds
-(weak scaling) and one all-gather of the 5-number statistics vector per step merges the ELBO mean /
-ln Z across ranks.  Rank 0 prints ONE JSON line.
+A "step" is one `compute_bound` forward over one batch of synthetic particles.  N = 1: the hot path named by
+BASELINE.json (many_gmm, MCD_CAIS_sn, N=2000, nbridges=256, dds net).  N > 1: one process per GPU (torch.distributed,
+backend nccl = RCCL), particles sharded, one all-gather of the 5-number statistics vector per step merges the ELBO
+mean / ln Z across ranks; three legs are timed in the same job and reported under "legs":
+
+  weak                 the named batch (2000 particles) on every rank
+  strong_named         the named batch split over the ranks (2000 / N each) — north_star's "strong scaling", latency-bound
+  strong_sharded_cfg4  BASELINE.json configs[3]: many_gmm, MCD_CAIS_var_sn, 16000 particles x 132-wide net split over
+                       the ranks (the configuration BASELINE names for 8 GPUs) — the HEADLINE of an N > 1 line
+
+Each strong leg also times the un-split batch on rank 0's GPU alone inside the same job (`single_gpu_ms`), so the
+line carries its own strong-scaling ratio.  Rank 0 prints ONE JSON line.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
@@ -28,6 +35,31 @@ import torch.distributed as dist
 
 PEAK_FP32_TFLOPS = 157.3   # MI355X fp32 vector == fp32 MFMA peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
+CFG4 = "many_gmm_var_n16000_k256"
+
+
+def kernel_sources_sha():
+    """Identifies the kernel build a stored PMC figure belongs to: sha1 over the HIP sources of the trajectory kernels."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in ("cmcd_coop.hip", "cmcd_kernels.hip", "cmcd_device.h", "cmcd_common.h", "cmcd_lgcp.hip"):
+        with open(os.path.join(ROOT, "cmcd_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def stored_traffic(key):
+    """HBM bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of
+    this same command, tools/probes/pmc_hbm.sh) — bench.py cannot collect counters on itself.  The summary records the
+    sha of the kernel sources it was measured on; a figure from another build is reported as null, not as current."""
+    for rnd in ("r02_pmc", "r01_pmc"):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", rnd, "summary.json")))
+        except Exception:
+            continue
+        if pmc.get("kernel_sources_sha") == kernel_sources_sha() and key in pmc:
+            return pmc[key].get("hbm_bytes_per_launch"), rnd
+    return None, None
 
 
 def flops_per_particle_step(cfg, dim, width):
@@ -100,6 +132,121 @@ def _strict(o):
     return o
 
 
+class Leg:
+    """One workload of the job: `n_global` particles of a synthetic configuration, sharded contiguously over the ranks
+    (or `n_global` per rank when weak)."""
+
+    def __init__(self, name, cfg_name, n_global, weak, device, rank, world, over=None):
+        from cmcd_amd import mcdboundingmachine as mcdbm
+        from cmcd_amd import parallel, synthetic
+        self.name, self.cfg_name, self.weak, self.world, self.rank = name, cfg_name, weak, world, rank
+        self.b = synthetic.build(cfg_name, device=device, **(over or {}))
+        self.dim, self.K, self.mode, self.spec = self.b["params_fixed"]
+        if weak:
+            self.n_local, self.n_global = n_global, n_global * world
+            seeds_np = synthetic.throughput_seeds(n_global, stream=rank)
+        else:
+            lo, hi = parallel.shard_range(n_global, world, rank)
+            self.n_local, self.n_global = hi - lo, n_global
+            seeds_np = synthetic.throughput_seeds(n_global, stream=0)[lo:hi]     # every rank draws the same global vector
+        self.seeds_np = seeds_np
+        self.seeds = torch.from_numpy(seeds_np).to(device)       # resident in HBM before any timed region
+        self.full_seeds_np = synthetic.throughput_seeds(n_global, stream=0) if not weak else seeds_np
+        self._mcdbm = mcdbm
+
+    def forward(self, seeds=None):
+        b = self.b
+        return self._mcdbm.bound_forward(self.seeds if seeds is None else seeds, b["params_flat"], b["unflatten"],
+                                         b["params_fixed"], b["target"], eps_schedule=b["eps_schedule"],
+                                         grad_clipping=b["grad_clipping"])
+
+    def kernel_name(self, n):
+        mcdbm = self._mcdbm
+        if self.b["cfg"]["model"] == "lgcp":
+            return "lgcp launch sequence (skinny GEMMs + state kernels)"
+        wide = self.spec.width >= 128
+        tiles = (n + 15) // 16
+        coop = mcdbm.KERNEL_VARIANT in (2, 3, 4) or (mcdbm.KERNEL_VARIANT == 0 and tiles <= (256 if wide else 512))
+        if not coop:
+            return "traj_kernel"
+        half = mcdbm.KERNEL_VARIANT == 4 or (mcdbm.KERNEL_VARIANT != 3 and n <= 2048)
+        return "coop_kernel<%d-particle tiles%s>" % (8 if half else 16, ", 132-wide net" if wide else "")
+
+
+def time_leg(leg, steps, warmup, use_dist, device, world, sharded=True):
+    """W untimed + K timed forward steps of `leg` on this rank's shard: barrier + synchronize on both sides, MAX over ranks.
+    Multi-GPU: one RCCL all-gather of the 40-byte statistics vector + one merge kernel per step.  The collective is
+    latency-only (~20 us against a >= 240 us step), so it is taken off the launch stream: torch's process group runs it
+    on its own stream (async_op=True) behind an event on the forward of step k, and the launch stream waits for it only
+    after the forward of step k+1 has been enqueued — the statistics of step k are merged one step late, every step's
+    all-gather and merge still run inside the timed region (the last one is drained before the closing barrier)."""
+    from cmcd_amd import _lib, parallel
+    gathered = [torch.zeros(world * parallel.NSTATS, dtype=torch.float64, device=device) for _ in range(2)]
+    pending = []
+    gather = use_dist and sharded
+
+    def drain():
+        work, buf, _ = pending.pop()
+        work.wait()
+        return parallel.merge_stats(buf.view(world, parallel.NSTATS))
+
+    def step(k):
+        losses, z, stats = leg.forward()
+        if gather:
+            work = dist.all_gather_into_tensor(gathered[k & 1], stats, async_op=True)
+            merged = drain() if pending else None
+            pending.append((work, gathered[k & 1], stats))
+            stats = merged
+        return losses, z, stats
+
+    def barrier():
+        if use_dist and sharded:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(warmup):
+        step(k)
+    if pending:
+        drain()
+    barrier()
+    _lib.profile_enable(True)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        losses, z, stats = step(k)
+    if pending:
+        stats = drain()   # global statistics of the last step
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms, launches = _lib.profile_collect()
+    _lib.profile_enable(False)
+    if use_dist and sharded:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return dict(elapsed=elapsed, kern_ms=kern_ms, launches=launches, losses=losses, stats=stats)
+
+
+def leg_report(leg, t, steps):
+    """The per-leg object of the JSON line."""
+    from cmcd_amd import parallel
+    cfg = leg.b["cfg"]
+    units = leg.n_global * leg.K
+    f_alg, f_survey = flops_per_particle_step(cfg, leg.dim, leg.spec.width)
+    if t["launches"] == 0:
+        kern_s = t["elapsed"] / steps
+    else:
+        kern_s = t["kern_ms"] / 1e3 / t["launches"]
+    fin = parallel.finalize(t["stats"], leg.n_global)
+    var = float(fin["var"])
+    return {
+        "workload": leg.cfg_name, "scaling": "weak" if leg.weak else "strong", "global_particles": leg.n_global,
+        "particles_per_gpu": leg.n_local, "nbridges": leg.K, "value": units * steps / t["elapsed"],
+        "ms_per_step": t["elapsed"] / steps * 1e3, "kernel": leg.kernel_name(leg.n_local), "kernel_ms": kern_s * 1e3,
+        "kernel_frac_of_fp32_peak": leg.n_local * leg.K * f_alg / kern_s / 1e12 / PEAK_FP32_TFLOPS,
+        "elbo": float(-fin["mean"]), "ln_z": float(fin["ln_z"]), "loss_var": var, "n_finite": float(fin["n_finite"]),
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -113,6 +260,7 @@ def main():
     ap.add_argument("--forward-only", action="store_true",
                     help="skip the vargrad / training_step legs (their trajectory-keeping forward launches would be averaged "
                          "into the same kernel name by rocprofv3 --stats)")
+    ap.add_argument("--no-legs", action="store_true", help="N = 1: skip the strong_sharded_cfg4 leg (profiling runs)")
     ap.add_argument("--cpu-particles", type=int, default=2000)
     ap.add_argument("--saturated", type=int, default=1 << 18,
                     help="also time a saturating batch of this many particles (0 = skip)")
@@ -149,123 +297,128 @@ def main():
     over = {"N": args.particles} if args.particles else {}
     if "lgcp" in name:   # the 40 x 40 bin counts of the point set ship as a fixture
         over["lgcp_counts"] = np.load(os.path.join(ROOT, "tests", "golden", "lgcp_bin_counts.npy"))
-    b = synthetic.build(name, device=device, **over)
-    cfg = b["cfg"]
+    n_named = args.particles or synthetic.CONFIGS[name]["N"]
+    weak = Leg("weak", name, n_named, True, device, rank, world, over)
+    b, cfg = weak.b, weak.b["cfg"]
     dim, K, mode, spec = b["params_fixed"]
-    n = cfg["N"]
-    seeds_np = synthetic.throughput_seeds(n, stream=rank)
-    seeds = torch.from_numpy(seeds_np).to(device)  # resident in HBM before the timed region
-
-    def forward(s):
-        return mcdbm.bound_forward(s, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"],
-                                   eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
-
-    # Multi-GPU: one RCCL all-gather of the 40-byte statistics vector + one merge kernel per step.  The collective is
-    # latency-only (~20 us against a 340 us step), so it is taken off the launch stream: torch's process group runs it on
-    # its own stream (async_op=True) behind an event on the forward of step k, and the launch stream waits for it only
-    # after the forward of step k+1 has been enqueued — the statistics of step k are merged one step late, every step's
-    # all-gather and merge still run inside the timed region (the last one is drained before the closing barrier).
-    gathered = [torch.zeros(world * parallel.NSTATS, dtype=torch.float64, device=device) for _ in range(2)]
-    pending = []          # [(work, buffer, stats kept alive)] of the step whose all-gather is in flight
-
-    def drain():
-        work, buf, _ = pending.pop()
-        work.wait()
-        return parallel.merge_stats(buf.view(world, parallel.NSTATS))
-
-    def step(k):
-        losses, z, stats = forward(seeds)
-        if use_dist:
-            work = dist.all_gather_into_tensor(gathered[k & 1], stats, async_op=True)
-            merged = drain() if pending else None
-            pending.append((work, gathered[k & 1], stats))
-            stats = merged
-        return losses, z, stats
-
-    def barrier():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
+    n = weak.n_local
+    seeds_np, seeds = weak.seeds_np, weak.seeds
+    forward = weak.forward
 
     # device spin-up (untimed, before the W warm-up steps): ~0.1 s of launches so that the GPU's clocks have settled even
     # when the caller asks for a handful of steps (20 steps = 6 ms read 0.305 ms per kernel against 0.267 ms settled)
     for k in range(args.spinup):
-        step(k)
-    if pending:
-        drain()
-    for k in range(args.warmup):
-        step(k)
-    if pending:
-        drain()
-    barrier()
-    _lib.profile_enable(True)
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        losses, z, stats = step(k)
-    if pending:
-        stats = drain()   # global statistics of the last step
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kern_ms, launches = _lib.profile_collect()
-    _lib.profile_enable(False)
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        forward()
+    torch.cuda.synchronize()
 
-    units_per_step = n * K * world
-    value = units_per_step * args.steps / elapsed
-    f_alg, f_survey = flops_per_particle_step(cfg, dim, spec.width)
-    if launches == 0:   # lgcp: a launch sequence, no single trajectory kernel — the whole call is the unit
-        kern_s, launches = elapsed / args.steps, args.steps
-    else:
-        kern_s = kern_ms / 1e3 / max(launches, 1)
+    legs = {}
+    tw = time_leg(weak, args.steps, args.warmup, use_dist, device, world)
+    legs["weak"] = leg_report(weak, tw, args.steps)
+    elapsed, kern_ms, launches, losses, stats = tw["elapsed"], tw["kern_ms"], tw["launches"], tw["losses"], tw["stats"]
+    default_workload = name == synthetic.NORTH_STAR and not args.particles
+
+    head_leg, head_t = weak, tw
+    if default_workload and not args.no_legs:
+        # strong scaling on the named batch (2000 / N per rank) and on configs[3] (16000 x 132-wide net split over the ranks)
+        strong = Leg("strong_named", name, n_named, False, device, rank, world) if world > 1 else None
+        cfg4 = Leg("strong_sharded_cfg4", CFG4, synthetic.CONFIGS[CFG4]["N"], False, device, rank, world)
+        for leg in (strong, cfg4):
+            if leg is None:
+                continue
+            if leg.n_global < world:
+                raise SystemExit(f"{leg.name}: fewer particles than ranks")
+            t = time_leg(leg, args.steps, args.warmup, use_dist, device, world)
+            legs[leg.name] = leg_report(leg, t, args.steps)
+            if world > 1:
+                # the same job's single-GPU reference: rank 0 runs the UN-split batch alone, the others wait at the barrier
+                if rank == 0:
+                    full = Leg(leg.name + "_single", leg.cfg_name, leg.n_global, True, device, 0, 1)
+                    ts = time_leg(full, max(args.steps // 4, 3), max(args.warmup // 4, 1), False, device, 1, sharded=False)
+                    single_ms = ts["elapsed"] / max(args.steps // 4, 3) * 1e3
+                    legs[leg.name]["single_gpu_ms"] = single_ms
+                    legs[leg.name]["speedup_vs_single_gpu"] = single_ms / legs[leg.name]["ms_per_step"]
+                    del full
+                dist.barrier()
+            if leg is cfg4:
+                cfg4_t = t
+        if world == 1:
+            legs["strong_named"] = dict(legs["weak"], scaling="strong")      # N = 1: the same measurement
+        else:
+            head_leg, head_t = cfg4, cfg4_t
+        # configs[3]'s training step on its shard: VarGrad value + gradient, statistics all-gather ("RCCL log-w
+        # all-reduce") between forward and gradient, one all-reduce of grad_flat
+        try:
+            gl = parallel.make_sharded_grad_and_loss("MCD_CAIS_var_sn", eps_schedule=cfg4.b["eps_schedule"],
+                                                     grad_clipping=cfg4.b["grad_clipping"])
+            gs = torch.from_numpy(cfg4.full_seeds_np).to(device)
+            gargs = (gs, cfg4.b["params_flat"], cfg4.b["unflatten"], cfg4.b["params_fixed"], cfg4.b["target"])
+            reps = max(min(args.steps, 20) // 2, 2)
+            for _ in range(2):
+                gl(*gargs)
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            tg0 = time.perf_counter()
+            for _ in range(reps):
+                gl(*gargs)
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            tg = (time.perf_counter() - tg0) / reps
+            if use_dist:
+                tt = torch.tensor([tg], dtype=torch.float64, device=device)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                tg = float(tt.item())
+            legs["strong_sharded_cfg4"]["train_step_ms"] = tg * 1e3
+            legs["strong_sharded_cfg4"]["train_value"] = cfg4.n_global * cfg4.K / tg
+        except NotImplementedError as e:
+            legs["strong_sharded_cfg4"]["train_step_error"] = str(e)
+
+    # ---- headline: N = 1 the named batch; N > 1 strong scaling on configs[3]
+    hl = leg_report(head_leg, head_t, args.steps)
+    hcfg = head_leg.b["cfg"]
+    f_alg, f_survey = flops_per_particle_step(hcfg, head_leg.dim, head_leg.spec.width)
+    value, n, K, dim = hl["value"], head_leg.n_local, head_leg.K, head_leg.dim
+    kern_s = hl["kernel_ms"] / 1e3
     achieved = n * K * f_alg / kern_s / 1e12
-    fin = parallel.finalize(stats, n * world)
-
-    # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc
-    # passes of this same command; profiles/r01_pmc/summary.json) — a measured constant of the kernel,
-    # bench.py cannot collect counters on itself.
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc", "summary.json")))
-        if name == synthetic.NORTH_STAR and n == 2000:
-            traffic = pmc["coop_kernel"]["hbm_bytes_per_launch"]
-    except Exception:
-        pass
-
-    # which trajectory kernel the library's auto-selection ran (cmcd_kernels.hip: cooperative up to 512 tiles,
-    # 256 for nets wider than 128; CMCD_KERNEL_VARIANT pins it)
-    tiles = (n + 15) // 16
-    coop = mcdbm.KERNEL_VARIANT in (2, 3, 4) or (mcdbm.KERNEL_VARIANT == 0 and tiles <= (256 if spec.width >= 128 else 512))
-    kernel_name = "coop_kernel" if coop else "traj_kernel"
-    if coop:   # 8-particle tiles (twice the workgroups) while each still gets a CU; instances exist for widths <= 64
-        half = mcdbm.KERNEL_VARIANT == 4 or (mcdbm.KERNEL_VARIANT != 3 and n <= 2048 and spec.width <= 64)
-        kernel_name += "<8-particle tiles>" if half else "<16-particle tiles>"
-
-    if cfg["model"] == "lgcp":
-        kernel_name = "lgcp launch sequence (skinny GEMMs + state kernels)"
+    launches = head_t["launches"] or args.steps
+    traffic, traffic_src = (None, None)
+    if head_leg is weak and default_workload:
+        traffic, traffic_src = stored_traffic("coop_kernel")
+    elif head_leg is not weak:
+        traffic, traffic_src = stored_traffic("coop_kernel_t9_half")
 
     result = {
         "metric": "bridge-steps*particles/sec", "value": value, "unit": "bridge-steps*particles/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup": args.spinup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": hl["ms_per_step"], "higher_is_better": True, "scaling": hl["scaling"],
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": name, "model": cfg["model"], "boundmode": cfg["boundmode"],
-                   "particles_per_gpu": n, "nbridges": K, "nn_arch": cfg["nn_arch"], "dim": dim,
-                   "global_particles": n * world, "parallelism": f"particles sharded x{world}, stats all-gather"},
+        "config": {"workload": head_leg.cfg_name, "model": hcfg["model"], "boundmode": hcfg["boundmode"],
+                   "particles_per_gpu": n, "nbridges": K, "nn_arch": hcfg["nn_arch"], "dim": dim,
+                   "global_particles": head_leg.n_global,
+                   "parallelism": f"particles sharded x{world}, stats all-gather"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch (PMC)",
-                     "kernel": kernel_name, "kernel_ms": kern_s * 1e3, "launches": launches,
+                     "traffic_source": (f"profiles/{traffic_src}/summary.json (kernel sources {kernel_sources_sha()})"
+                                        if traffic is not None else "none for this kernel build"),
+                     "kernel": hl["kernel"], "kernel_ms": kern_s * 1e3, "launches": launches,
                      "flop_per_particle_step": f_alg, "flop_per_particle_step_survey": f_survey,
                      "achieved_survey_flops": n * K * f_survey / kern_s / 1e12,
                      "state_bytes_gbs": n * K * (8 * dim + 8) / kern_s / 1e9},
-        "elbo": float(-fin["mean"]), "ln_z": float(fin["ln_z"]), "n_finite": float(fin["n_finite"]),
+        "elbo": hl["elbo"], "ln_z": hl["ln_z"], "n_finite": hl["n_finite"],
+        "legs": legs,
     }
+    if world > 1:
+        result["scaling_note"] = ("headline = strong scaling on BASELINE configs[3] (16000 particles x 132-wide net split over the "
+                                  "ranks); legs.weak / legs.strong_named are the named batch; each strong leg carries the "
+                                  "same job's single-GPU time")
     # untrained net at init_sigma = 60: some particles leave float32 range exactly as in the reference (parity.inf_set_equal),
     # so the plain mean is -inf; the mean over this rank's finite particles is reported beside it
     lfin = losses[torch.isfinite(losses)]
     result["elbo_finite_particles"] = float(-lfin.double().mean()) if lfin.numel() else None
+    n, K, dim = weak.n_local, weak.K, weak.dim
+    f_alg, f_survey = flops_per_particle_step(cfg, dim, spec.width)
+    kern_s = legs["weak"]["kernel_ms"] / 1e3
 
     if rank == 0 and args.saturated and world == 1:
         ns = args.saturated
@@ -289,15 +442,18 @@ def main():
         IN = dim + cfg["emb_dim"]
         wbytes = 4.0 * (dim * dim + 2 * dim * IN + IN * IN) * (K + 1) * -(-n // 32)
         # measured L2 <-> fabric bytes of the three GEMM launches of one evaluation (tools/probes/pmc_hbm_lgcp.sh: separate
-        # rocprofv3 --pmc passes, FETCH_SIZE doubled per the gfx950 note), x (K + 1) evaluations x passes — a constant of the
-        # named shape (N <= 32 per pass, K = 128, width 1620): weights + the operand slices every workgroup re-reads + slabs
+        # rocprofv3 --pmc passes, FETCH_SIZE doubled per the gfx950 note), x (K + 1) evaluations x passes
         traffic = None
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc", "lgcp_summary.json")))
-            if dim == 1600 and IN == 1620:
-                traffic = sum(v["hbm_bytes_per_launch"] for v in pm.values()) * (K + 1) * -(-n // 32)
-        except Exception:
-            pass
+        for rnd in ("r02_pmc", "r01_pmc"):
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", rnd, "lgcp_summary.json")))
+            except Exception:
+                continue
+            if pm.get("kernel_sources_sha", None) in (None, kernel_sources_sha()) and rnd == "r02_pmc" or \
+               (rnd == "r01_pmc" and pm.get("kernel_sources_sha") == kernel_sources_sha()):
+                if dim == 1600 and IN == 1620:
+                    traffic = sum(v["hbm_bytes_per_launch"] for v in pm.values() if isinstance(v, dict)) * (K + 1) * -(-n // 32)
+                break
         result["roofline"].update({"bound": "hbm", "achieved": wbytes / kern_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                    "frac": wbytes / kern_s / 1e9 / PEAK_HBM_GBS, "traffic": traffic,
                                    "traffic_unit": "bytes/call (PMC)", "weight_bytes_per_call": wbytes})

@@ -286,6 +286,9 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
   // as fk = fma(eps beta, gp, fma(eps (1-beta), gq, fma(-eps, s, z))) with the two products precombined in
   // the schedule table: same value up to the last rounding, a third of the instructions.  Clips are
   // v_med3_f32 against +-inf when clipping is off (no branch).
+#ifdef CMCD_STAMPS
+  unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
+#endif
   const float cp = clip_p ? clipv : INFINITY, cq = clip_q ? clipv : INFINITY;
   float pA = 0.f, pB = 0.f;
   auto phase_c = [&](int e, bool track_w) {
@@ -319,6 +322,7 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
       }
       logp = gv[D];
     }
+    STAMP(9);   // exchange rows + schedule row read and combined
     if (track_w && e > 0) {  // backward kernel of step e-1: bk = z - eps ub + eps s, ub = -(beta gp + (1-beta) gq)
       float bk_lp = 0.f;
 #pragma unroll
@@ -351,7 +355,6 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
   };
 
 #ifdef CMCD_STAMPS
-  unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
 #endif
   typename Target<TARGET, D>::Means tmeans;
@@ -463,6 +466,7 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
           }
         }
         acc += acc1;
+        STAMP(7);   // activations read, matrix instructions done
         // the two halves of the contraction sit in lanes l and l ^ 32; lane kh keeps neurons 2 kh + {0, 1} of its group
         uint32_t r0, r1;
         swap32(__float_as_uint(acc[0]), __float_as_uint(acc[2]), r0, r1);
@@ -482,6 +486,7 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
       }
 #pragma unroll
       for (int r = 0; r < NR; ++r) h2[r] = (ARCH == CMCD_ARCH_DDS) ? gelu_fast(av[r]) : h[r] + softplus(av[r]);
+      STAMP(8);   // contraction halves folded, activation
 #pragma unroll
       for (int j = 0; j < D; ++j) {
         if (HALF) {

@@ -47,7 +47,7 @@ def test_determinism_and_batch_composition_invariance(hip_lib, monkeypatch, name
     b = synthetic.build(name, device="cuda")
     seeds = synthetic.throughput_seeds(n, stream=5)
     perm = np.random.default_rng(0).permutation(n)
-    for v in (1, 3, 4) if n <= 2048 else (1, 2):   # bitwise claims hold per kernel variant and tiling (auto-selection depends on batch size)
+    for v in (1, 3, 4) if n <= 2048 else (1, 3):   # bitwise claims hold per kernel variant and tiling (2 / auto pick the tiling by batch size)
         monkeypatch.setattr(mcdbm, "KERNEL_VARIANT", v)
         l1, z1, s1 = _fwd(b, seeds)
         l2, z2, s2 = _fwd(b, seeds)

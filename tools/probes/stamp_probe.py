@@ -34,7 +34,7 @@ L = _lib.lib()
 buf = (C.c_ulonglong * 256)()
 L.cmcd_debug_read_stamps(buf)
 K = b["params_fixed"][1]
-names = ["int1 work", "wait bar1", "int2 work", "wait bar2", "phase C"]
+names = ["int1 work", "wait bar1", "int2 tail", "wait bar2", "phaseC tail"]
 T = (b["params_fixed"][3].width + 15) // 16 if b["params_fixed"][3].arch == "geffner" else 4
 print("cycles per bridge step, workgroup 0:")
 nw = T + 4
@@ -44,4 +44,4 @@ for wv in range(nw):
     row = [buf[wv * 16 + k] / (K + 1) for k in range(5)]
     fine = [buf[wv * 16 + k] / (K + 1) for k in range(5, 10)]
     role = "MLP%d" % wv if wv < T else (["TGT0", "TGT1", "RNG", "ACC"] if nw == T + 4 else ["TGT0", "TGT1", "RNG+ACC"])[wv - T]
-    print("%5s " % role + "  ".join("%s=%7.0f" % (nm, v) for nm, v in zip(names, row)) + "  total=%7.0f" % (sum(row) + sum(fine)) + "  | fine[L1,preMFMA,MFMA,act,C-reads]=" + " ".join("%5.0f" % v for v in fine))
+    print("%5s " % role + "  ".join("%s=%7.0f" % (nm, v) for nm, v in zip(names, row)) + "  total=%7.0f" % (sum(row) + sum(fine)) + "  | [-, -, int2 reads+MFMA, int2 fold+act, phaseC rows]=" + " ".join("%5.0f" % v for v in fine))
