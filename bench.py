@@ -173,7 +173,7 @@ class Leg:
         return "coop_kernel<%d-particle tiles%s>" % (8 if half else 16, ", 132-wide net" if wide else "")
 
 
-def time_leg(leg, steps, warmup, use_dist, device, world, sharded=True):
+def time_leg(leg, steps, warmup, use_dist, device, world, sharded=True, spinup=0):
     """W untimed + K timed forward steps of `leg` on this rank's shard: barrier + synchronize on both sides, MAX over ranks.
     Multi-GPU: one RCCL all-gather of the 40-byte statistics vector + one merge kernel per step.  The collective is
     latency-only (~20 us against a >= 240 us step), so it is taken off the launch stream: torch's process group runs it
@@ -204,7 +204,9 @@ def time_leg(leg, steps, warmup, use_dist, device, world, sharded=True):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(warmup):
+    # device spin-up (untimed, in front of the W warm-up steps without a synchronisation in between): ~0.1 s of launches
+    # so that the GPU's clocks have settled even when the caller asks for a handful of steps (20 steps = 5 ms)
+    for k in range(spinup + warmup):
         step(k)
     if pending:
         drain()
@@ -305,14 +307,8 @@ def main():
     seeds_np, seeds = weak.seeds_np, weak.seeds
     forward = weak.forward
 
-    # device spin-up (untimed, before the W warm-up steps): ~0.1 s of launches so that the GPU's clocks have settled even
-    # when the caller asks for a handful of steps (20 steps = 6 ms read 0.305 ms per kernel against 0.267 ms settled)
-    for k in range(args.spinup):
-        forward()
-    torch.cuda.synchronize()
-
     legs = {}
-    tw = time_leg(weak, args.steps, args.warmup, use_dist, device, world)
+    tw = time_leg(weak, args.steps, args.warmup, use_dist, device, world, spinup=args.spinup)
     legs["weak"] = leg_report(weak, tw, args.steps)
     elapsed, kern_ms, launches, losses, stats = tw["elapsed"], tw["kern_ms"], tw["launches"], tw["losses"], tw["stats"]
     default_workload = name == synthetic.NORTH_STAR and not args.particles
@@ -327,7 +323,8 @@ def main():
                 continue
             if leg.n_global < world:
                 raise SystemExit(f"{leg.name}: fewer particles than ranks")
-            t = time_leg(leg, args.steps, args.warmup, use_dist, device, world)
+            t = time_leg(leg, args.steps, args.warmup, use_dist, device, world,
+                         spinup=args.spinup if leg.n_local <= 4096 else 0)    # short launches only: clock settling
             legs[leg.name] = leg_report(leg, t, args.steps)
             if world > 1:
                 # the same job's single-GPU reference: rank 0 runs the UN-split batch alone, the others wait at the barrier

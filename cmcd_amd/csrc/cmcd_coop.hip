@@ -87,7 +87,6 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
   float* nzb = gpb + 2 * 16 * GP;            // [2][16][NZ]    Gaussian noise
   uint32_t* raw = reinterpret_cast<uint32_t*>(nzb + 2 * 16 * NZ);  // [2][16][NZ] raw bits
   float* lds_tgt = reinterpret_cast<float*>(raw + 2 * 16 * NZ);
-  float* lds_sched = lds_tgt + a.w.tgt_floats;   // [K][8] the schedule table (tgt_floats is a multiple of 4)
 
   // Role = hardware wave index: waves go to SIMD (index % 4), so every SIMD holds one MLP wave and one auxiliary wave.
   // Measured alternative (profiles/r01_r_simd_map.txt): MLP waves paired on SIMDs 0 / 1 and the auxiliary waves on 2 / 3
@@ -115,7 +114,6 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
   const int K = a.K;
 
   for (int i = threadIdx.x; i < a.w.tgt_floats; i += blockDim.x) lds_tgt[i] = a.ws[a.w.tgt + i];
-  for (int i = threadIdx.x; i < 8 * K; i += blockDim.x) lds_sched[i] = a.ws[a.w.sched + i];
   // issue priority of this wave's role against its SIMD partner (s_setprio takes an immediate)
   switch ((a.prio >> (is_mlp ? 0 : is_tgt ? 2 : is_rng ? 4 : 6)) & 3) {
     case 1: __builtin_amdgcn_s_setprio(1); break;
@@ -291,16 +289,8 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
 #endif
   const float cp = clip_p ? clipv : INFINITY, cq = clip_q ? clipv : INFINITY;
   float pA = 0.f, pB = 0.f;
-  auto phase_c = [&](int e, bool track_w) {
+  auto phase_c = [&](int e, bool track_w, const f32x4& sc, const f32x4& sd) {
     const int pb = e & 1;
-    // per-bridge scalars {beta, eps, sigma, log sigma + log sqrt(2 pi) | 1/(2 sigma^2), eps beta, eps (1 - beta), 0} from
-    // the LDS copy of the schedule table: two broadcast reads in the same batch as the exchange buffers below.  (r01
-    // fetched the row from L2 at the top of every iteration; the loaded registers were dead on some role paths, got
-    // re-used there, and the resulting hazard put `s_waitcnt vmcnt(0)` — a full L2 round trip — at the start of
-    // interval 1 of every wave and bridge.)
-    const int srow = e < K ? e : K - 1;
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(lds_sched + 8 * srow);
-    const f32x4 sd = *reinterpret_cast<const f32x4*>(lds_sched + 8 * srow + 4);
     const float eps = sc[1], sig = sc[2], cst = sc[3], inv2s2 = sd[0], cA = sd[1], cB = sd[2];
     float sn[D], gp[D], gq[D];
     {
@@ -359,8 +349,20 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
 #endif
   typename Target<TARGET, D>::Means tmeans;
   if (is_tgt) Target<TARGET, D>::template load_means<LPT>(sub8, lds_tgt, tmeans);
+  // Per-bridge scalars {beta, eps, sigma, log sigma + log sqrt(2 pi) | 1/(2 sigma^2), eps beta, eps (1 - beta), 0}: row i is
+  // read by phase C(i) at the END of iteration i and requested at its top as a SCALAR load through the constant address
+  // space (the table is written by the prep launch, never by this kernel): eight SGPRs per wave, no LDS traffic in the
+  // burst behind barrier 2, and the request has a whole interval to complete before the first lgkmcnt wait (the LDS
+  // publication in front of barrier 1).  History: r01 fetched the row with vector loads whose registers were dead on
+  // some role paths, got re-used there, and the hazard put `s_waitcnt vmcnt(0)` — an L2 round trip — at the start of
+  // interval 1 of every wave (0.2676 ms); an LDS copy of the table removed that (0.2425 ms) at the price of two more
+  // 1 KB broadcast reads per wave in phase C.
+  typedef const __attribute__((address_space(4))) f32x4* const_f32x4_ptr;
+  const const_f32x4_ptr sched_c = (const_f32x4_ptr)(a.ws + a.w.sched);
   for (int i = 0; i <= K; ++i) {
     const int buf = i & 1;
+    const int srow = i < K ? i : K - 1;
+    const f32x4 sc = sched_c[2 * srow], sd = sched_c[2 * srow + 1];
     float h[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) h[r] = 0.f;
@@ -487,16 +489,27 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
 #pragma unroll
       for (int r = 0; r < NR; ++r) h2[r] = (ARCH == CMCD_ARCH_DDS) ? gelu_fast(av[r]) : h[r] + softplus(av[r]);
       STAMP(8);   // contraction halves folded, activation
+      if (HALF) {
+        // outputs in pairs (j, j + 1): ONE row swap leaves the lower half-wave with both contraction halves of output
+        // j and the upper half-wave with both of output j + 1 (swap32(a, b): r0 = [a_lo | b_lo], r1 = [a_hi | b_hi]),
+        // so the sum over the 4 neuron groups (lane bits 2, 3) runs once per pair instead of once per output
+        static_assert(D % 2 == 0, "8-particle tiles pair the outputs");
 #pragma unroll
-      for (int j = 0; j < D; ++j) {
-        if (HALF) {
-          float pj = h2[0] * w3[j][0] + h2[1] * w3[j][1];
-          pj += xor8(pj);   // over the 4 neuron groups (lane bits 2, 3) ...
+        for (int j = 0; j < D; j += 2) {
+          const float p0 = h2[0] * w3[j][0] + h2[1] * w3[j][1];
+          const float p1 = h2[0] * w3[j + 1][0] + h2[1] * w3[j + 1][1];
+          swap32(__float_as_uint(p0), __float_as_uint(p1), r0h, r1h);
+          float pj = __uint_as_float(r0h) + __uint_as_float(r1h);   // kh = 0: output j, kh = 1: output j + 1
+          pj += xor8(pj);
           pj += ror4(pj);
-          swap32(__float_as_uint(pj), __float_as_uint(pj), r0h, r1h);   // ... and the two halves (lane bit 5)
-          pj = __uint_as_float(r0h) + __uint_as_float(r1h);
-          if (ng == 0) part[(buf * 16 + c + 8 * kh) * PT + wv * D + j] = pj;   // both twin columns
-        } else {
+          if (ng == 0) {   // both twin columns
+            part[(buf * 16 + c) * PT + wv * D + j + kh] = pj;
+            part[(buf * 16 + c + 8) * PT + wv * D + j + kh] = pj;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
           float pj = h2[0] * w3[j][0] + h2[1] * w3[j][1] + h2[NR - 2] * w3[j][NR - 2] + h2[NR - 1] * w3[j][NR - 1];
           pj = group_sum(pj);
           if (g == 0) part[(buf * 16 + c) * PT + wv * D + j] = pj;
@@ -532,8 +545,8 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
     STAMP(3);
     // ------------------------------------------------------------------ phase C: MLP, TGT (own copies of z) and
     // ACC (with the log-weight); ~45 instructions each, so the redundancy is cheaper than an LDS hand-over
-    if (is_acc) phase_c(i, true);                    // i = K: closes step K-1 and picks up log p(z_K)
-    else if ((is_mlp || is_tgt) && i < K) phase_c(i, false);
+    if (is_acc) phase_c(i, true, sc, sd);            // i = K: closes step K-1 and picks up log p(z_K)
+    else if ((is_mlp || is_tgt) && i < K) phase_c(i, false, sc, sd);
     STAMP(4);
   }
 #ifdef CMCD_STAMPS
@@ -612,11 +625,8 @@ extern "C" int cmcd_debug_read_stamps(unsigned long long* out) {
 }
 #endif
 
-// the schedule table rides in LDS (32 B per bridge) next to ~10 KB of exchange buffers
-static constexpr size_t kCoopMaxLds = 64 * 1024;
-bool coop_fits(const cmcd_desc& d) { return (size_t)d.nbridges * 32 + 16 * 1024 <= kCoopMaxLds; }
-bool coop_available(const cmcd_desc& d, int T) { return coop_fits(d) && pick(d, T, false).fn != nullptr; }
-bool coop_half_available(const cmcd_desc& d, int T) { return coop_fits(d) && pick(d, T, true).fn != nullptr; }
+bool coop_available(const cmcd_desc& d, int T) { return pick(d, T, false).fn != nullptr; }
+bool coop_half_available(const cmcd_desc& d, int T) { return pick(d, T, true).fn != nullptr; }
 
 // half: 8-particle tiles (ceil(n / 8) workgroups, as many statistics records); else ta.w.n_waves 16-particle tiles
 // Issue priority per role (s_setprio against the SIMD partner), tools/probes/prio_sweep.py, interleaved rounds
@@ -638,9 +648,7 @@ int coop_launch(const cmcd_desc& d, const TrajArgs& ta_in, bool half, void* stre
   coop_fn fn = inst.fn;
   if (!fn) return CMCD_ERR_UNSUPPORTED;
   const int ZP = (D + 3) & ~3;
-  const size_t lds_bytes = size_t(16 * T * 16 + 2 * 16 * PT + 16 * ZP + 2 * 16 * GP + 2 * 16 * NZ + 2 * 16 * NZ + ta.w.tgt_floats +
-                                  8 * (size_t)ta.K) * 4;
-  if (lds_bytes > kCoopMaxLds) return CMCD_ERR_UNSUPPORTED;   // callers check coop_fits() first
+  const size_t lds_bytes = size_t(16 * T * 16 + 2 * 16 * PT + 16 * ZP + 2 * 16 * GP + 2 * 16 * NZ + 2 * 16 * NZ + ta.w.tgt_floats) * 4;
   const unsigned tiles = half ? unsigned((ta.n + 7) / 8) : (unsigned)ta.w.n_waves;
   // While there are no more workgroups than CUs, claim more than half of a CU's 160 KB of LDS: the dispatcher can
   // then never put two workgroups on one CU while another CU sits idle (two on a CU share its SIMDs and the
