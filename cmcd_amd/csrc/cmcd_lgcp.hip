@@ -754,25 +754,54 @@ __global__ void lgcp_final_kernel(LgcpFinalArgs a) {
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-struct LgcpWs {
-  int64_t bias1, x, xp, u1, u2, pre1, pre2, kr, slab1, slab2, sn, w, keys, gkey, gktab, slots, counters, partials, total;
+// Per-pass buffers (one "lane"): up to kLanes passes of <= kMP particles run concurrently, each on its own HIP stream
+// and buffer set (every launch of the sequence is latency-bound, so independent passes overlap almost freely).  Lane 0
+// is laid out exactly as the single-lane workspace always was (lgcp_grad reads bias1 / gktab at those offsets); the
+// other lanes' copies follow the statistics records.
+constexpr int kLanes = 4;
+struct LgcpLane {
+  int64_t x, xp, u1, u2, pre1, pre2, kr, slab1, slab2, sn, w, keys, gkey, slots, counters;
 };
+struct LgcpWs {
+  int64_t bias1, gktab, partials, total;
+  LgcpLane lane[kLanes];
+};
+
+static int lgcp_lanes(int64_t n) {
+  const int64_t passes = (n + kMP - 1) / kMP;
+  return (int)(passes < kLanes ? passes : kLanes);
+}
 
 static LgcpWs lgcp_ws(const cmcd_desc& d, int64_t n, int64_t base) {
   const int64_t D = d.dim, IN = D + d.emb_dim, K = d.nbridges;
   LgcpWs w;
   int64_t o = base;
   auto take = [&](int64_t cnt) { int64_t r = o; o += (cnt + 3) & ~int64_t(3); return r; };
+  auto take_lane_head = [&](LgcpLane& l) {
+    l.x = take(kMP * D); l.xp = take(kMP * D);
+    l.u1 = take(kMP * IN); l.u2 = take(kMP * IN); l.pre1 = take(kMP * IN); l.pre2 = take(kMP * IN);
+    l.kr = take(kSplit * kMP * D); l.slab1 = take(kSplit * kMP * IN); l.slab2 = take(kSplit * kMP * IN);
+    l.sn = take(kSplit * kMP * D);
+    l.w = take(kMP); l.keys = take(2 * kMP); l.gkey = take(4 * kMP);
+  };
+  auto take_lane_tail = [&](LgcpLane& l) {
+    l.slots = take(3 * ((D + 63) / 64) * kMP);             // wslot | fkslot | lpslot
+    l.counters = take(((D + 63) / 64) + ((IN + 63) / 64)); // int arrival counters of the widest launch
+  };
   w.bias1 = take((K + 1) * IN);
-  w.x = take(kMP * D); w.xp = take(kMP * D);
-  w.u1 = take(kMP * IN); w.u2 = take(kMP * IN); w.pre1 = take(kMP * IN); w.pre2 = take(kMP * IN);
-  w.kr = take(kSplit * kMP * D); w.slab1 = take(kSplit * kMP * IN); w.slab2 = take(kSplit * kMP * IN);
-  w.sn = take(kSplit * kMP * D);
-  w.w = take(kMP); w.keys = take(2 * kMP); w.gkey = take(4 * kMP); w.gktab = take(2 * K * n);
-  w.slots = take(3 * ((D + 63) / 64) * kMP);             // wslot | fkslot | lpslot
-  w.counters = take(((D + 63) / 64) + ((IN + 63) / 64)); // int arrival counters of the widest launch
+  take_lane_head(w.lane[0]);
+  w.gktab = take(2 * K * n);
+  take_lane_tail(w.lane[0]);
   o = (o + 1) & ~int64_t(1);
   w.partials = take(n * CMCD_NSTATS * 2);
+  for (int l = 1; l < kLanes; ++l) {
+    if (l < lgcp_lanes(n)) {
+      take_lane_head(w.lane[l]);
+      take_lane_tail(w.lane[l]);
+    } else {
+      w.lane[l] = w.lane[0];
+    }
+  }
   w.total = o;
   return w;
 }
@@ -811,68 +840,113 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
   const float mu0 = 3.8812819069514780f;
   const dim3 gblock(64 * kGemmWaves), gblock_step(64 * (kGemmWaves + 1));
   const int cbD = (D + 63) / 64, cbIN = (IN + 63) / 64;
-  int* counters = reinterpret_cast<int*>(ws + w.counters);
-  if (hipMemsetAsync(counters, 0, sizeof(int) * (cbD + cbIN), stream) != hipSuccess) return CMCD_ERR_HIP;
 
-  for (int64_t base = 0; base < n; base += kMP) {
-    const int M = (int)((n - base) < kMP ? (n - base) : kMP);
-    if (hipMemsetAsync(ws + w.slots, 0, sizeof(float) * 3 * cbD * kMP, stream) != hipSuccess) return CMCD_ERR_HIP;
-    LgcpStateArgs st{};
-    st.seeds = seeds + base; st.params = params; st.tc = tc; st.x = ws + w.x;
-    st.w = ws + w.w; st.keys = reinterpret_cast<uint32_t*>(ws + w.keys);
-    st.gkey = reinterpret_cast<uint32_t*>(ws + w.gkey); st.gktab = reinterpret_cast<uint32_t*>(ws + w.gktab);
-    st.lay = lay; st.M = M; st.D = D;
-    st.traj = traj; st.n_total = n; st.base = base;
-    hipLaunchKernelGGL(lgcp_init_kernel, dim3(M), dim3(256), 0, stream, st);
+  // Passes of <= kMP particles are independent chains of 3 (K + 1) latency-bound launches: up to kLanes of them run side
+  // by side, lane 0 on the caller's stream, the others on per-thread side streams forked from / joined to it by events
+  // (capturable in a graph, like the reverse sweep's two streams).  One pass (the named N = 20 batch): no side stream.
+  const int lanes = lgcp_lanes(n);
+  static thread_local hipStream_t side[kLanes] = {nullptr, nullptr, nullptr, nullptr};
+  static thread_local hipEvent_t ev_join[kLanes] = {nullptr, nullptr, nullptr, nullptr}, ev_fork = nullptr;
+  if (lanes > 1 && !ev_fork) {
+    for (int l = 1; l < kLanes; ++l) {
+      if (hipStreamCreateWithFlags(&side[l], hipStreamNonBlocking) != hipSuccess) return CMCD_ERR_HIP;
+      if (hipEventCreateWithFlags(&ev_join[l], hipEventDisableTiming) != hipSuccess) return CMCD_ERR_HIP;
+    }
+    if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return CMCD_ERR_HIP;
+  }
+  if (lanes > 1 && hipEventRecord(ev_fork, stream) != hipSuccess) return CMCD_ERR_HIP;   // behind the prep launch
 
-    GemmArgs g{};
-    g.M = M; g.counters = counters;
-    g.act.x = ws + w.x; g.act.D = D; g.act.IN = IN;
-    StepEpi& se = g.step;
-    se.params = params; se.tc = tc; se.sched = ws + sw.sched; se.x = ws + w.x; se.xp = ws + w.xp;
-    se.kr = ws + w.kr; se.b3 = params + lay.g_b3; se.factor = params + lay.g_factor;
-    se.gen = reinterpret_cast<uint32_t*>(ws + w.keys); se.gkey = reinterpret_cast<uint32_t*>(ws + w.gkey);
-    se.gktab = reinterpret_cast<uint32_t*>(ws + w.gktab);
-    se.wslot = ws + w.slots; se.fkslot = se.wslot + cbD * kMP; se.lpslot = se.fkslot + cbD * kMP;
-    se.out_z = out_z + base * D; se.traj = traj; se.n_total = n; se.base = base; se.lay = lay;
-    se.D = D; se.K = K; se.var_mode = d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0; se.grad_clipping = d.grad_clipping;
-    const int ula = d.mode == CMCD_MODE_ULA ? 1 : (d.mode == CMCD_MODE_ULA_SN ? 2 : 0);
-    se.ula = ula;
+  int* counters[kLanes];
+  for (int l = 0; l < lanes; ++l) {
+    hipStream_t st_l = l == 0 ? stream : side[l];
+    if (l > 0 && hipStreamWaitEvent(st_l, ev_fork, 0) != hipSuccess) return CMCD_ERR_HIP;
+    counters[l] = reinterpret_cast<int*>(ws + w.lane[l].counters);
+    if (hipMemsetAsync(counters[l], 0, sizeof(int) * (cbD + cbIN), st_l) != hipSuccess) return CMCD_ERR_HIP;
+  }
+  const int ula = d.mode == CMCD_MODE_ULA ? 1 : (d.mode == CMCD_MODE_ULA_SN ? 2 : 0);
+  // groups of `lanes` passes; inside a group the launches are enqueued evaluation by evaluation, round-robin over the
+  // lanes, so that the chains advance together (the same weights are in flight for all of them)
+  for (int64_t gbase = 0; gbase < n; gbase += (int64_t)lanes * kMP) {
+    GemmArgs g[kLanes];
+    int M[kLanes], live = 0;
+    for (int l = 0; l < lanes; ++l) {
+      const int64_t base = gbase + (int64_t)l * kMP;
+      if (base >= n) break;
+      ++live;
+      hipStream_t st_l = l == 0 ? stream : side[l];
+      const LgcpLane& wl = w.lane[l];
+      M[l] = (int)((n - base) < kMP ? (n - base) : kMP);
+      if (hipMemsetAsync(ws + wl.slots, 0, sizeof(float) * 3 * cbD * kMP, st_l) != hipSuccess) return CMCD_ERR_HIP;
+      LgcpStateArgs st{};
+      st.seeds = seeds + base; st.params = params; st.tc = tc; st.x = ws + wl.x;
+      st.w = ws + wl.w; st.keys = reinterpret_cast<uint32_t*>(ws + wl.keys);
+      st.gkey = reinterpret_cast<uint32_t*>(ws + wl.gkey); st.gktab = reinterpret_cast<uint32_t*>(ws + w.gktab);
+      st.lay = lay; st.M = M[l]; st.D = D;
+      st.traj = traj; st.n_total = n; st.base = base;
+      hipLaunchKernelGGL(lgcp_init_kernel, dim3(M[l]), dim3(256), 0, st_l, st);
+
+      g[l] = GemmArgs{};
+      g[l].M = M[l]; g[l].counters = counters[l];
+      g[l].act.x = ws + wl.x; g[l].act.D = D; g[l].act.IN = IN;
+      StepEpi& se = g[l].step;
+      se.params = params; se.tc = tc; se.sched = ws + sw.sched; se.x = ws + wl.x; se.xp = ws + wl.xp;
+      se.kr = ws + wl.kr; se.b3 = params + lay.g_b3; se.factor = params + lay.g_factor;
+      se.gen = reinterpret_cast<uint32_t*>(ws + wl.keys); se.gkey = reinterpret_cast<uint32_t*>(ws + wl.gkey);
+      se.gktab = reinterpret_cast<uint32_t*>(ws + w.gktab);
+      se.wslot = ws + wl.slots; se.fkslot = se.wslot + cbD * kMP; se.lpslot = se.fkslot + cbD * kMP;
+      se.out_z = out_z + base * D; se.traj = traj; se.n_total = n; se.base = base; se.lay = lay;
+      se.D = D; se.K = K; se.var_mode = d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0; se.grad_clipping = d.grad_clipping;
+      se.ula = ula;
+    }
     for (int i = 0; i <= K; ++i) {
-      se.i = i;
-      if (ula == 1) {   // MCD_ULA: one launch per evaluation, [x - mu0] Kinv with the state update as its consumer
-        g.Kdim = D; g.Kdim1 = 0;
-        g.seg[0] = GemmSeg{ws + w.x, kinv, ws + w.kr, D, D, D, D, mu0};
-        g.nblk0 = cbD; g.epi_seg = -1;
-        hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_STEP_NONET>, dim3(cbD, kSplit), gblock_step, gemm_lds, stream, g);
-        continue;
-      }
       // CAIS: s(z_i, i) serves both kernels; MCD_ULA_sn: s(z_i, i - 1) serves the backward kernel only
       const int it = ula == 2 ? (i > 0 ? i - 1 : 0) : i;
       const int ie = it < K ? it : K - 1;
-      // A: [x - mu0] Kinv -> kr slabs (summed by the state update two launches on)
-      //    x W1[:D] -> pre1 slabs -> u1 = [x; emb_i] + softplus(pre1 + bias1_i)            (fused consumer)
-      g.Kdim = D; g.Kdim1 = 0;
-      g.seg[0] = GemmSeg{ws + w.x, kinv, ws + w.kr, D, D, D, D, mu0};
-      g.seg[1] = GemmSeg{ws + w.x, params + lay.g_w1, ws + w.slab1, IN, D, IN, IN};
-      g.nblk0 = cbD; g.epi_seg = 1;
-      g.act.mode = 1; g.act.bias = ws + w.bias1 + (int64_t)it * IN; g.act.emb = params + lay.g_emb + (int64_t)ie * E;
-      g.act.sum_out = ws + w.pre1; g.act.u_prev = nullptr; g.act.u_out = ws + w.u1;
-      hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_ACT>, dim3(cbD + cbIN, kSplit), gblock, gemm_lds, stream, g);
-      // B: u1 W2 -> pre2 slabs -> u2 = u1 + softplus(pre2 + b2)
-      g.Kdim = IN;
-      g.seg[0] = GemmSeg{ws + w.u1, params + lay.g_w2, ws + w.slab2, IN, IN, IN, IN};
-      g.nblk0 = cbIN; g.epi_seg = -1;
-      g.act.mode = 2; g.act.bias = params + lay.g_b2; g.act.sum_out = ws + w.pre2; g.act.u_prev = ws + w.u1;
-      g.act.u_out = ws + w.u2;
-      hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_ACT>, dim3(cbIN, kSplit), gblock, gemm_lds, stream, g);
-      // C: u2 W3 -> sn slabs -> state update of evaluation i on the block's columns
-      g.seg[0] = GemmSeg{ws + w.u2, params + lay.g_w3, ws + w.sn, D, IN, D, D};
-      g.nblk0 = cbD;
-      hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_STEP>, dim3(cbD, kSplit), gblock_step, gemm_lds, stream, g);
+      for (int l = 0; l < live; ++l) {
+        hipStream_t st_l = l == 0 ? stream : side[l];
+        const LgcpLane& wl = w.lane[l];
+        GemmArgs& gl = g[l];
+        gl.step.i = i;
+        if (ula == 1) {   // MCD_ULA: one launch per evaluation, [x - mu0] Kinv with the state update as its consumer
+          gl.Kdim = D; gl.Kdim1 = 0;
+          gl.seg[0] = GemmSeg{ws + wl.x, kinv, ws + wl.kr, D, D, D, D, mu0};
+          gl.nblk0 = cbD; gl.epi_seg = -1;
+          hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_STEP_NONET>, dim3(cbD, kSplit), gblock_step, gemm_lds, st_l, gl);
+          continue;
+        }
+        // A: [x - mu0] Kinv -> kr slabs (summed by the state update two launches on)
+        //    x W1[:D] -> pre1 slabs -> u1 = [x; emb_i] + softplus(pre1 + bias1_i)            (fused consumer)
+        gl.Kdim = D; gl.Kdim1 = 0;
+        gl.seg[0] = GemmSeg{ws + wl.x, kinv, ws + wl.kr, D, D, D, D, mu0};
+        gl.seg[1] = GemmSeg{ws + wl.x, params + lay.g_w1, ws + wl.slab1, IN, D, IN, IN};
+        gl.nblk0 = cbD; gl.epi_seg = 1;
+        gl.act.mode = 1; gl.act.bias = ws + w.bias1 + (int64_t)it * IN; gl.act.emb = params + lay.g_emb + (int64_t)ie * E;
+        gl.act.sum_out = ws + wl.pre1; gl.act.u_prev = nullptr; gl.act.u_out = ws + wl.u1;
+        hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_ACT>, dim3(cbD + cbIN, kSplit), gblock, gemm_lds, st_l, gl);
+        // B: u1 W2 -> pre2 slabs -> u2 = u1 + softplus(pre2 + b2)
+        gl.Kdim = IN;
+        gl.seg[0] = GemmSeg{ws + wl.u1, params + lay.g_w2, ws + wl.slab2, IN, IN, IN, IN};
+        gl.nblk0 = cbIN; gl.epi_seg = -1;
+        gl.act.mode = 2; gl.act.bias = params + lay.g_b2; gl.act.sum_out = ws + wl.pre2; gl.act.u_prev = ws + wl.u1;
+        gl.act.u_out = ws + wl.u2;
+        hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_ACT>, dim3(cbIN, kSplit), gblock, gemm_lds, st_l, gl);
+        // C: u2 W3 -> sn slabs -> state update of evaluation i on the block's columns
+        gl.seg[0] = GemmSeg{ws + wl.u2, params + lay.g_w3, ws + wl.sn, D, IN, D, D};
+        gl.nblk0 = cbD;
+        hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_STEP>, dim3(cbD, kSplit), gblock_step, gemm_lds, st_l, gl);
+      }
     }
-    LgcpFinalArgs fa{ws + w.w, se.wslot, se.lpslot, tc, out_loss + base, partials + base * CMCD_NSTATS, M, D, cbD};
-    hipLaunchKernelGGL(lgcp_final_kernel, dim3(1), dim3(64), 0, stream, fa);
+    for (int l = 0; l < live; ++l) {
+      hipStream_t st_l = l == 0 ? stream : side[l];
+      const int64_t base = gbase + (int64_t)l * kMP;
+      const StepEpi& se = g[l].step;
+      LgcpFinalArgs fa{ws + w.lane[l].w, se.wslot, se.lpslot, tc, out_loss + base, partials + base * CMCD_NSTATS, M[l], D, cbD};
+      hipLaunchKernelGGL(lgcp_final_kernel, dim3(1), dim3(64), 0, st_l, fa);
+    }
+  }
+  for (int l = 1; l < lanes; ++l) {
+    if (hipEventRecord(ev_join[l], side[l]) != hipSuccess) return CMCD_ERR_HIP;
+    if (hipStreamWaitEvent(stream, ev_join[l], 0) != hipSuccess) return CMCD_ERR_HIP;
   }
   return hipGetLastError() == hipSuccess ? CMCD_OK : CMCD_ERR_HIP;
 }

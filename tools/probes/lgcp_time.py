@@ -6,7 +6,7 @@ from cmcd_amd import synthetic
 from cmcd_amd import mcdboundingmachine as mcdbm
 counts = np.load(os.path.join(ROOT, "tests", "golden", "lgcp_bin_counts.npy"))
 b = synthetic.build("lgcp_n20_k128", device="cuda", lgcp_counts=counts)
-for n in (20, 24, 48):
+for n in (20, 32, 64, 128, 600):
     seeds = torch.from_numpy(synthetic.throughput_seeds(n)).cuda()
     f = lambda: mcdbm.bound_forward(seeds, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"],
                                     eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
