@@ -51,3 +51,22 @@ def test_trained_bound_reproduces_the_reference_notebook_table(hip_lib, model, k
     assert abs(mean[1] - ref["ln_Z"]) <= max(3 * ref["ln_Z_std"], 3 * std[1]), (mean[1], ref["ln_Z"])
     # the targets are normalised (true ln Z = 0, Appendix A.6 of SURVEY.md) and the ELBO is a lower bound
     assert mean[0] < mean[1] + 0.02 and abs(mean[1]) < 0.5
+
+
+def test_lgcp_ula_baseline_reproduces_the_reference_notebook_table(hip_lib):
+    """lgcp (d = 1600), `MCD_ULA`, K = 8 with the README's lgcp flags (/root/reference/README.md:63: 20000 mean-field
+    iterations, 37500 training iterations, lr 1e-4; ~20 s on MI355X): the stored ELBO is 447.81 +- 0.39 (ipynb:3482);
+    the mean-field start is 391.3, so the 56-nat gain over 8 annealed steps is what is being checked.  The network modes
+    of the same table (MCD_ULA_sn 458.21, MCD_CAIS_sn 469.48) train for ~50 s each and are run by
+    tools/replicate_check.py (profiles/r02_o_*: 458.95 and 468.99)."""
+    ref = next(r for r in TABLES["lgcp"]["rows"] if r["boundmode"] == "MCD_ULA" and r["nbridges"] == 8)
+    hp = TABLES["lgcp"]["hparams"]
+    argv = ["--config.boundmode", "MCD_ULA", "--config.model", "lgcp", "--config.N", str(hp["N"]), "--config.emb_dim",
+            str(hp["emb_dim"]), "--config.init_eps", str(hp["init_eps"]), "--config.init_sigma", str(hp["init_sigma"]),
+            "--config.iters", str(hp["iters"]), "--config.pretrain_mfvi", "--config.mfvi_iters", str(hp["mfvi_iters"]),
+            "--config.train_vi", "--config.train_eps", "--config.lr", str(hp["lr"]), "--config.n_samples",
+            str(hp["n_samples"]), "--config.nbridges", "8", "--config.seed", "1"]
+    elbo, ln_z = cli.main(cli.parse_flags(argv, cli.get_config()))
+    print(f"lgcp MCD_ULA K=8: ELBO {elbo:.3f} (reference {ref['elbo']:.3f} +- {ref['elbo_std']:.3f}, ipynb:{ref['cite']}), ln Z {ln_z:.3f}")
+    assert abs(elbo - ref["elbo"]) <= 3 * ref["elbo_std"], (elbo, ref["elbo"])
+    assert ln_z > elbo
