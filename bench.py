@@ -166,7 +166,7 @@ class Leg:
             return "lgcp launch sequence (skinny GEMMs + state kernels)"
         wide = self.spec.width >= 128
         tiles = (n + 15) // 16
-        coop = mcdbm.KERNEL_VARIANT in (2, 3, 4) or (mcdbm.KERNEL_VARIANT == 0 and tiles <= (256 if wide else 512))
+        coop = mcdbm.KERNEL_VARIANT in (2, 3, 4) or (mcdbm.KERNEL_VARIANT == 0 and tiles <= 512)
         if not coop:
             return "traj_kernel"
         half = mcdbm.KERNEL_VARIANT == 4 or (mcdbm.KERNEL_VARIANT != 3 and n <= 2048)
@@ -441,16 +441,12 @@ def main():
         # measured L2 <-> fabric bytes of the three GEMM launches of one evaluation (tools/probes/pmc_hbm_lgcp.sh: separate
         # rocprofv3 --pmc passes, FETCH_SIZE doubled per the gfx950 note), x (K + 1) evaluations x passes
         traffic = None
-        for rnd in ("r02_pmc", "r01_pmc"):
-            try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", rnd, "lgcp_summary.json")))
-            except Exception:
-                continue
-            if pm.get("kernel_sources_sha", None) in (None, kernel_sources_sha()) and rnd == "r02_pmc" or \
-               (rnd == "r01_pmc" and pm.get("kernel_sources_sha") == kernel_sources_sha()):
-                if dim == 1600 and IN == 1620:
-                    traffic = sum(v["hbm_bytes_per_launch"] for v in pm.values() if isinstance(v, dict)) * (K + 1) * -(-n // 32)
-                break
+        try:   # only a summary measured on this build of the kernels counts (kernel_sources_sha)
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc", "lgcp_summary.json")))
+            if pm.get("kernel_sources_sha") == kernel_sources_sha() and dim == 1600 and IN == 1620:
+                traffic = sum(v["hbm_bytes_per_launch"] for v in pm.values() if isinstance(v, dict)) * (K + 1) * -(-n // 32)
+        except Exception:
+            pass
         result["roofline"].update({"bound": "hbm", "achieved": wbytes / kern_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                    "frac": wbytes / kern_s / 1e9 / PEAK_HBM_GBS, "traffic": traffic,
                                    "traffic_unit": "bytes/call (PMC)", "weight_bytes_per_call": wbytes})

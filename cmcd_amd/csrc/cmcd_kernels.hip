@@ -47,11 +47,12 @@ struct NoiseCapture { uint32_t* bits = nullptr; uint32_t* keys = nullptr; float*
 static thread_local NoiseCapture g_capture;
 
 // Tiles (16 particles each) up to which the CU-cooperative kernel is preferred; measured crossovers on
-// MI355X (tools/probes/variant_sweep.py): dds/geffner T<=4 between 512 and 1024 tiles, the 132-wide
-// net between 256 and 1000.
+// MI355X (tools/probes/variant_sweep.py, t9_variants.py): dds/geffner T<=4 between 512 and 1024 tiles; the 132-wide
+// net at ~600 (500 tiles: cooperative 1.85 ms against 2.27 ms one wave per tile; 1000 tiles: 3.69 against 2.28).
 static int coop_max_tiles(const cmcd_desc& d, int T) {
   (void)d;
-  return T >= 8 ? 256 : 512;
+  (void)T;
+  return 512;
 }
 static int fail(int code, const char* fmt, const char* a = "", long long b = 0) {
   snprintf(g_err, sizeof(g_err), fmt, a, b);
