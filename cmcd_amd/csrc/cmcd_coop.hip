@@ -441,28 +441,28 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
             acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * q + 3], hb[q][3], acc1, 0, 0, 0);
           }
         } else {
-          // wide nets (9 tiles: 18 reads): the activations arrive in chunks of CH reads, chunk k + 1 requested before
-          // the matrix instructions of chunk k issue, so that the registers of one and a half chunks suffice
-          constexpr int CH = 3, NCH = NQB / CH;
+          // wide nets (9 tiles: 18 reads): the activations arrive in chunks of CH reads.  Single-buffered: with three
+          // waves per SIMD the other waves' matrix instructions fill the LDS latency of a chunk, and the 72 resident
+          // operand registers leave no room for a second buffer (a spilled operand is reloaded from scratch INSIDE the
+          // chain: `s_waitcnt vmcnt(0)` between two matrix instructions, r02 ISA reading)
+#ifndef CMCD_T9_CH
+#define CMCD_T9_CH 3
+#endif
+          constexpr int CH = CMCD_T9_CH, NCH = NQB / CH;
           static_assert(NQB % CH == 0, "chunking");
-          f32x4 hb[2][CH];
-#pragma unroll
-          for (int q = 0; q < CH; ++q) hb[0][q] = *reinterpret_cast<const f32x4*>(rd_h + 4 * q);
 #pragma unroll
           for (int ch = 0; ch < NCH; ++ch) {
-            if (ch + 1 < NCH) {
+            f32x4 hb[CH];
 #pragma unroll
-              for (int q = 0; q < CH; ++q)
-                hb[(ch + 1) & 1][q] = *reinterpret_cast<const f32x4*>(rd_h + 4 * ((ch + 1) * CH + q));
-            }
+            for (int q = 0; q < CH; ++q) hb[q] = *reinterpret_cast<const f32x4*>(rd_h + 4 * (ch * CH + q));
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < CH; ++q) {
               const int qq = ch * CH + q;
-              acc = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * qq + 0], hb[ch & 1][q][0], acc, 0, 0, 0);
-              acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * qq + 1], hb[ch & 1][q][1], acc1, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * qq + 2], hb[ch & 1][q][2], acc, 0, 0, 0);
-              acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * qq + 3], hb[ch & 1][q][3], acc1, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * qq + 0], hb[q][0], acc, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * qq + 1], hb[q][1], acc1, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * qq + 2], hb[q][2], acc, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * qq + 3], hb[q][3], acc1, 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
           }
@@ -637,16 +637,22 @@ bool coop_half_available(const cmcd_desc& d, int T) { return pick(d, T, true).fn
 // their raise alone gave -2.1 %: the table follows the balance, re-run the sweep after changing a role.)
 static int g_coop_prio = -1;   // -1: the table below
 extern "C" void cmcd_debug_set_coop_prio(int prio) { g_coop_prio = prio; }   // tools/probes/prio_sweep.py
-static int default_prio(const cmcd_desc&, bool half) { return half ? (1 << 2 | 1 << 6) : 0; }
+// 12-wave instance (132-wide net, RNG + ACC merged): the merged wave's stream is the longest of the workgroup (three
+// Threefry passes, two deviates and the log-weight per bridge against two partners with 72 matrix instructions each);
+// target waves and the merged wave one level up: 0.4957 -> 0.4602 ms at N = 2000 (profiles/r02_t_prio_t9.txt)
+static int default_prio(const cmcd_desc&, bool half, int waves) {
+  if (!half) return 0;
+  return waves == 12 ? (1 << 2 | 1 << 4) : (1 << 2 | 1 << 6);
+}
 
 int coop_launch(const cmcd_desc& d, const TrajArgs& ta_in, bool half, void* stream) {
   TrajArgs ta = ta_in;
-  ta.prio = g_coop_prio >= 0 ? g_coop_prio : default_prio(d, half);
   const int T = ta.w.T, D = d.dim, Hh = (D + 1) / 2, NZ = 2 * Hh;
   const int GP = (D + 1 + 3) & ~3, PT = (T * D + 3) & ~3;
   const CoopInstance inst = pick(d, T, half);
   coop_fn fn = inst.fn;
   if (!fn) return CMCD_ERR_UNSUPPORTED;
+  ta.prio = g_coop_prio >= 0 ? g_coop_prio : default_prio(d, half, inst.waves);
   const int ZP = (D + 3) & ~3;
   const size_t lds_bytes = size_t(16 * T * 16 + 2 * 16 * PT + 16 * ZP + 2 * 16 * GP + 2 * 16 * NZ + 2 * 16 * NZ + ta.w.tgt_floats) * 4;
   const unsigned tiles = half ? unsigned((ta.n + 7) / 8) : (unsigned)ta.w.n_waves;

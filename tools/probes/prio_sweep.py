@@ -8,7 +8,7 @@ from cmcd_amd import mcdboundingmachine as mcdbm
 
 name = sys.argv[1] if len(sys.argv) > 1 else synthetic.NORTH_STAR
 b = synthetic.build(name, device="cuda")
-n = b["cfg"]["N"]
+n = int(sys.argv[2]) if len(sys.argv) > 2 else b["cfg"]["N"]
 seeds = torch.from_numpy(synthetic.throughput_seeds(n)).cuda()
 f = lambda: mcdbm.bound_forward(seeds, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"],
                                 eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
@@ -34,7 +34,7 @@ for variant in (4,):
     mcdbm.KERNEL_VARIANT = variant
     t(0, 50)   # clocks settle
     cands = [(0, 0, 0, 0), (0, 1, 0, 1), (1, 1, 0, 1), (1, 0, 0, 0), (1, 0, 0, 1), (2, 1, 0, 1), (0, 1, 0, 0), (0, 0, 0, 1), (0, 2, 0, 1),
-             (0, 1, 0, 2), (0, 2, 0, 2), (0, 0, 1, 0)]
+             (0, 1, 0, 2), (0, 2, 0, 2), (0, 0, 1, 0), (0, 1, 1, 0), (0, 1, 2, 0), (0, 0, 2, 0), (0, 1, 3, 0), (0, 2, 3, 0), (1, 2, 3, 0)]
     res = {c: [] for c in cands}
     for rnd in range(4):   # interleaved rounds: drift hits every candidate alike
         for c in cands:
