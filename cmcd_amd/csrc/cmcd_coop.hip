@@ -525,6 +525,22 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
         for (int j = 0; j < D; ++j) gpb[(buf * 16 + col) * GP + j] = gp[j];
         gpb[(buf * 16 + col) * GP + D] = lp;
       }
+      if (MERGE && i < K) {
+        // 12-wave instance: the merged RNG / ACC wave is the longest stream of the workgroup and the target waves wait
+        // ~1200 cycles at barrier 2, so the bits -> deviates conversion of bridge i (raw[buf], written one iteration
+        // ago) runs here: lane `sub` of a particle converts word `sub` and fills both twin columns
+        static_assert(!MERGE || (HALF && D <= 16), "the conversion is dealt to the 16 lanes of a particle");
+        if (sub8 < D) {
+          const uint32_t bits = raw[(buf * 16 + c) * NZ + sub8];
+          const float dev = bits_to_normal(bits);
+          nzb[(buf * 16 + c) * NZ + sub8] = dev;
+          nzb[(buf * 16 + c + 8) * NZ + sub8] = dev;
+          if (a.dbg_bits && valid) {
+            a.dbg_bits[((int64_t)(i + 1) * a.n + p) * D + sub8] = bits;
+            a.dbg_noise[((int64_t)(i + 1) * a.n + p) * D + sub8] = dev;
+          }
+        }
+      }
     } else if (is_rng) {
       // MERGE: nothing this wave produces is read before barrier 2 (the log-weight is its own, the bits and deviates are
       // consumed in phase C), so its phase C runs straight into barrier 1 and the whole key-chain stage sits here — the
@@ -535,8 +551,7 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
         rows01(x0, g0, g1);
         rows01(x1, h0, h1);
       }
-      if (i + 1 < K) normal_bits(g0, g1, h0, h1, buf ^ 1, true, i + 2);
-      if (MERGE && i < K) convert(buf, i + 1);       // raw[buf] was written one iteration ago by this same wave
+      if (i + 1 < K) normal_bits(g0, g1, h0, h1, buf ^ 1, true, i + 2);   // (MERGE: the target waves convert raw[buf])
     } else {
       if (i < K) convert(buf, i + 1);                // noise of bridge i, read in phase C(i)
     }

@@ -49,7 +49,8 @@ def ulp_distance(a, b):
 
 @pytest.mark.parametrize("variant", [1, 3, 4], ids=["wave_per_tile", "cooperative_16", "cooperative_8"])
 @pytest.mark.parametrize("name,n,K", [("many_gmm_n2000_k256_dds", 203, 40), ("funnel_n300_k64", 77, 9),
-                                      ("gmm_n300_k8", 33, 8), ("many_gmm_n2000_k256_dds", 2000, 256)])
+                                      ("gmm_n300_k8", 33, 8), ("many_gmm_n2000_k256_dds", 2000, 256),
+                                      ("many_gmm_var_n16000_k256", 100, 12)])   # 132-wide net: the 12-wave instance (variant 4)
 def test_key_chain_and_deviates_are_bit_exact(hip_lib, monkeypatch, variant, name, n, K):
     monkeypatch.setattr(mcdbm, "KERNEL_VARIANT", variant)
     b = synthetic.build(name, device="cuda", nbridges=K, dense=True)
