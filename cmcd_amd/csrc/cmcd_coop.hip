@@ -529,12 +529,12 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
         // 12-wave instance: the merged RNG / ACC wave is the longest stream of the workgroup and the target waves wait
         // ~1200 cycles at barrier 2, so the bits -> deviates conversion of bridge i (raw[buf], written one iteration
         // ago) runs here: lane `sub` of a particle converts word `sub` and fills both twin columns
-        static_assert(!MERGE || (HALF && D <= 16), "the conversion is dealt to the 16 lanes of a particle");
+        static_assert(!MERGE || D <= LPT, "the conversion is dealt to the lanes of a particle");
         if (sub8 < D) {
           const uint32_t bits = raw[(buf * 16 + c) * NZ + sub8];
           const float dev = bits_to_normal(bits);
           nzb[(buf * 16 + c) * NZ + sub8] = dev;
-          nzb[(buf * 16 + c + 8) * NZ + sub8] = dev;
+          if (HALF) nzb[(buf * 16 + c + 8) * NZ + sub8] = dev;
           if (a.dbg_bits && valid) {
             a.dbg_bits[((int64_t)(i + 1) * a.n + p) * D + sub8] = bits;
             a.dbg_noise[((int64_t)(i + 1) * a.n + p) * D + sub8] = dev;
@@ -614,7 +614,10 @@ static CoopInstance pick_T(int T, bool half) {
         if constexpr (D == 2) return {coop_kernel<TARGET, ARCH, D, 9, true, true>, 12};
         return {};
       }
-      return {coop_kernel<TARGET, ARCH, D, 9, false>, 13};
+      // 16-particle tiles: thirteen waves would be four per SIMD = 128 registers (76 spilled for many_gmm); the 2-d
+      // targets take the merged RNG / ACC wave here too
+      if constexpr (D == 2) return {coop_kernel<TARGET, ARCH, D, 9, false, true>, 12};
+      else return {coop_kernel<TARGET, ARCH, D, 9, false>, 13};
     default: return {};
   }
 }
@@ -656,8 +659,9 @@ extern "C" void cmcd_debug_set_coop_prio(int prio) { g_coop_prio = prio; }   // 
 // Threefry passes, two deviates and the log-weight per bridge against two partners with 72 matrix instructions each);
 // target waves and the merged wave one level up: 0.4957 -> 0.4602 ms at N = 2000 (profiles/r02_t_prio_t9.txt)
 static int default_prio(const cmcd_desc&, bool half, int waves) {
+  if (waves == 12) return 1 << 2 | 1 << 4;   // both tilings of the 12-wave instance (16-particle tiles: -1.6 %, r02_v)
   if (!half) return 0;
-  return waves == 12 ? (1 << 2 | 1 << 4) : (1 << 2 | 1 << 6);
+  return 1 << 2 | 1 << 6;
 }
 
 int coop_launch(const cmcd_desc& d, const TrajArgs& ta_in, bool half, void* stream) {

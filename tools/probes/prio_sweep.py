@@ -30,7 +30,7 @@ def enc(mlp, tgt, rng, acc):
     return mlp | tgt << 2 | rng << 4 | acc << 6
 
 
-for variant in (4,):
+for variant in ((int(sys.argv[3]),) if len(sys.argv) > 3 else (4,)):
     mcdbm.KERNEL_VARIANT = variant
     t(0, 50)   # clocks settle
     cands = [(0, 0, 0, 0), (0, 1, 0, 1), (1, 1, 0, 1), (1, 0, 0, 0), (1, 0, 0, 1), (2, 1, 0, 1), (0, 1, 0, 0), (0, 0, 0, 1), (0, 2, 0, 1),
