@@ -55,6 +55,31 @@ json.dump(out, open('gpurun_out/%s/pmc_summary.json' % T, 'w'), indent=1)
 print(json.dumps(out)[:1500])
 PY
 rm -rf $O/pmc
+# lgcp launch sequence: FETCH_SIZE / WRITE_SIZE per GEMM launch type (separate --pmc passes), with the kernel-source sha
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_lgcp/$c -- python3 bench.py --config lgcp_n20_k128 --steps 3 --warmup 1 --spinup 0 --no-cpu-baseline --saturated 0 --no-legs > /dev/null 2>&1 || echo "lgcp pass failed: $c"
+done
+python3 - $T <<'PY'
+import glob, csv, collections, json, sys, os
+sys.path.insert(0, os.getcwd())
+import bench
+T = sys.argv[1]
+acc = collections.defaultdict(list)
+for f in sorted(glob.glob('gpurun_out/%s/pmc_lgcp/*/*/*counter_collection.csv' % T)):
+    for r in csv.DictReader(open(f)):
+        if 'lgcp_gemm_kernel' in r['Kernel_Name']:
+            acc[(r['Kernel_Name'][:44], r.get('Grid_Size', r.get('Grid_Size_X', '?')), r['Counter_Name'])].append(float(r['Counter_Value']))
+out = {}
+for (k, g, c), v in sorted(acc.items()):
+    out.setdefault(k + ' grid ' + str(g), {})[c] = sum(v) / len(v)
+for k, d in out.items():
+    if 'FETCH_SIZE' in d and 'WRITE_SIZE' in d:
+        d['hbm_bytes_per_launch'] = (2 * d['FETCH_SIZE'] + d['WRITE_SIZE']) * 1024
+out['kernel_sources_sha'] = bench.kernel_sources_sha()
+json.dump(out, open('gpurun_out/%s/lgcp_pmc_summary.json' % T, 'w'), indent=1)
+print(json.dumps(out)[:800])
+PY
+rm -rf $O/pmc_lgcp
 for c in gmm_n300_k8 funnel_n300_k64 many_gmm_n2000_k256_dds many_gmm_var_n16000_k256 lgcp_n20_k128; do
   python3 bench.py --config $c --no-cpu-baseline --saturated 0 --no-legs 2>/dev/null | tail -1
 done > $O/all_configs.jsonl
