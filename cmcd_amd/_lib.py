@@ -3,6 +3,9 @@ missing or a call fails, this raises."""
 import ctypes as C
 import os
 
+import torch  # noqa: F401  (first: torch ships its own HIP runtime; loading libcmcd_hip.so before it would bring in /opt/rocm's
+#                            copy as a second runtime in the process, and launches through it fail with "no ROCm-capable device")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CMCD_LIB_PATH", os.path.join(_HERE, "libcmcd_hip.so"))  # override: diagnostic builds
 
