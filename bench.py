@@ -457,14 +457,14 @@ def main():
             bv = synthetic.build(name, device=device, boundmode="MCD_CAIS_var_sn", **over)
             gargs = (seeds, bv["params_flat"], bv["unflatten"], bv["params_fixed"], bv["target"])
             gkw = dict(eps_schedule=bv["eps_schedule"], grad_clipping=bv["grad_clipping"])
-            for _ in range(2):
+            for _ in range(10):
                 mcdbm.compute_log_var_grad(*gargs, **gkw)
             torch.cuda.synchronize()
             tg0 = time.perf_counter()
-            for _ in range(5):
+            for _ in range(40):
                 mcdbm.compute_log_var_grad(*gargs, **gkw)
             torch.cuda.synchronize()
-            tg = (time.perf_counter() - tg0) / 5
+            tg = (time.perf_counter() - tg0) / 40
             result["vargrad"] = {"ms_per_value_and_grad": tg * 1e3, "value": n * K / tg,
                                  "unit": "bridge-steps*particles/s (forward + backward)"}
         except NotImplementedError as e:
@@ -474,14 +474,14 @@ def main():
         try:
             gargs = (seeds, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"])
             gkw = dict(eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
-            for _ in range(2):
+            for _ in range(10):
                 mcdbm.compute_bound_grad(*gargs, **gkw)
             torch.cuda.synchronize()
             tg0 = time.perf_counter()
-            for _ in range(5):
+            for _ in range(40):
                 mcdbm.compute_bound_grad(*gargs, **gkw)
             torch.cuda.synchronize()
-            tg = (time.perf_counter() - tg0) / 5
+            tg = (time.perf_counter() - tg0) / 40
             result["training_step"] = {"ms_per_value_and_grad": tg * 1e3, "value": n * K / tg,
                                        "unit": "bridge-steps*particles/s (forward + reverse sweep)"}
         except NotImplementedError as e:

@@ -1227,7 +1227,7 @@ struct TailArgs {
 // Every entry of grad_flat that is a plain sum of slab entries: 16 lanes per output element, each lane a fixed
 // strided subset of the slabs (or of the (slab, wave) regions), then a fixed butterfly: deterministic, and
 // 256 slabs cost 16 loads per lane instead of a 256-long serial walk.
-__global__ __launch_bounds__(256) void grad_reduce_kernel(TailArgs a) {
+__device__ __forceinline__ void grad_reduce_body(const TailArgs& a, const unsigned bidx, const unsigned gdim) {
   const int HP = a.HP, D = a.D, IN = a.IN;
   const bool dds = a.arch == CMCD_ARCH_DDS;
   const int64_t o_w1 = dds ? a.lay.d_sw1 : a.lay.g_w1, o_w2 = dds ? a.lay.d_sw2 : a.lay.g_w2;
@@ -1235,7 +1235,7 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(TailArgs a) {
   const int64_t o_b3 = dds ? a.lay.d_sb3 : a.lay.g_b3;
   const int wid = dds ? 64 : IN;  // true width, row length of W1 / W2
   const int sub = threadIdx.x & 15;
-  int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  int64_t i = ((int64_t)bidx * blockDim.x + threadIdx.x) >> 4;
   const int64_t per = 2 * 16 * HP + 256 + 32, base = (int64_t)HP * HP + HP * 16;   // per-wave regions of a slab
   int64_t dst = -1, off = 0;
   bool perwave = false;
@@ -1276,7 +1276,7 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(TailArgs a) {
 }
 
 // d / d eps0 and d / d mgridref_y from the per-step tables (one 256-thread block, thread per bridge)
-__global__ __launch_bounds__(256) void grad_sched_tail_kernel(TailArgs a) {
+__device__ __forceinline__ void grad_sched_tail_body(const TailArgs& a, const unsigned bidx, const unsigned gdim) {
   __shared__ float gyg[40], gyv[40], red[256];
   const int K = a.K, G = a.ngrid;
   const float* gbeta = a.gtab + a.o_gbeta;
@@ -1329,12 +1329,12 @@ __global__ __launch_bounds__(256) void grad_sched_tail_kernel(TailArgs a) {
 // geffner tail: S[e][n] = d/d bias-table, S2[e][n] = sum_p d u1.   emb row of evaluation e is min(e, K-1).
 //   db1[n] = sum_e S[e][n];  dW1[D+j][n] = sum_e emb[ie][j] S[e][n];
 //   demb[i][j] = sum_{e: ie(e) = i} ( S2[e][D+j] + sum_n W1[D+j][n] S[e][n] )
-__global__ void grad_geffner_tail_kernel(TailArgs a) {
+__device__ __forceinline__ void grad_geffner_tail_body(const TailArgs& a, const unsigned bidx, const unsigned gdim) {
   const int K = a.K, D = a.D, E = a.E, IN = a.IN, HP = a.HP;
   const float* S = a.gtab + a.o_S;
   const float* S2 = a.gtab + a.o_S2;
   const float* P = a.params;
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t tid = (int64_t)bidx * blockDim.x + threadIdx.x, stride = (int64_t)gdim * blockDim.x;
   // db1 and dW1[D:, :]: 16 lanes per output, lane `part` sums the evaluations e = part, part + 16, ... and a fixed
   // butterfly adds the 16 partial sums (one thread per output walked all K + 1 evaluations serially — 257 dependent
   // L2 round trips: 0.23 ms of config 4's 2 ms training step at a 2000-particle shard)
@@ -1387,9 +1387,9 @@ static inline unsigned geffner_tail_blocks(const TailArgs& a) {
 // per-e outer products over e in a fixed order (no atomics: 4.3 M float atomics took 50 us, this takes ~15).
 constexpr int kTailRow = 448;   // per e: emb[128] | hh[64] | tau[64] | dtau[64] | dact[64] | dphase[64]
 
-__global__ __launch_bounds__(64) void grad_dds_tail_kernel(TailArgs a) {
+__device__ __forceinline__ void grad_dds_tail_body(const TailArgs& a, const unsigned bidx, const unsigned gdim) {
   __shared__ float emb[128], ha[64], hh[64], dtau[64], dh[64], dact[64];
-  const int j = threadIdx.x, t = blockIdx.x, D = a.D;
+  const int j = threadIdx.x, t = bidx, D = a.D;
   const float* P = a.params;
   const float* S = a.gtab + a.o_S + (int64_t)t * 64;
   float* row = a.tail + (int64_t)t * kTailRow;
@@ -1450,6 +1450,27 @@ __global__ __launch_bounds__(64) void grad_dds_tail_kernel(TailArgs a) {
 
 // (B) d sb1, d sw1[D:], d tb2, d tw2, d tb1, d tw1, d phase: 16 lanes per entry, lane l sums e = l, l+16, ...,
 // then a fixed butterfly (deterministic; a one-thread 257-long walk is latency-bound: 67 us)
+// thin launchers of the bodies above (the MCD_ULA and lgcp sweeps launch the schedule / geffner tails on their own)
+__global__ __launch_bounds__(256) void grad_sched_tail_kernel(TailArgs a) { grad_sched_tail_body(a, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(256) void grad_geffner_tail_kernel(TailArgs a) { grad_geffner_tail_body(a, blockIdx.x, gridDim.x); }
+
+// Everything behind the gradient kernel that only reads its tables and slabs, as ONE launch (r02: four dependent
+// 9 - 28 us launches were 10 % of the VarGrad step at N = 2000): blocks [0, n_reduce) the slab reduction, block n_reduce
+// the schedule tail, then either the K + 1 time-coder blocks of the dds tail (64 threads each; its fixed-order sum over
+// evaluations stays a second launch) or the geffner tail's blocks.  The groups write disjoint leaves of grad_flat.
+__global__ __launch_bounds__(256) void grad_tails_fused_kernel(TailArgs a, unsigned n_reduce, unsigned n_third) {
+  const unsigned b = blockIdx.x;
+  if (b < n_reduce) {
+    grad_reduce_body(a, b, n_reduce);
+  } else if (b == n_reduce) {
+    grad_sched_tail_body(a, 0, 1);
+  } else if (a.arch == CMCD_ARCH_DDS) {
+    if (threadIdx.x < 64) grad_dds_tail_body(a, b - n_reduce - 1, n_third);   // waves 1 - 3 leave: its barriers count wave 0 only
+  } else {
+    grad_geffner_tail_body(a, b - n_reduce - 1, n_third);
+  }
+}
+
 __global__ __launch_bounds__(256) void grad_dds_tail_sum_kernel(TailArgs a) {
   const int sub = threadIdx.x & 15, D = a.D, E1 = a.K + 1;
   const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
@@ -1641,14 +1662,17 @@ int grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, c
   {
     const int64_t wid = d.arch == CMCD_ARCH_DDS ? 64 : D + d.emb_dim;
     const int64_t outs = wid * wid + 2 * wid * D + wid + 3 * D + 1;
-    hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((outs * 16 + 255) / 256)), dim3(256), 0, stream, ta);
+    const unsigned n_reduce = (unsigned)((outs * 16 + 255) / 256);
+    // dds: reduction + schedule tail + the K + 1 time-coder blocks in one launch (65 -> 47 us of kernel time at N = 2000).
+    // geffner: reduction + schedule tail; its embedding tail stays a launch of its own (4096 light blocks behind the
+    // reduction's heavy ones in one grid measured 50 us against 24.5 + 17.9 apart)
+    const unsigned n_third = d.arch == CMCD_ARCH_DDS ? (unsigned)(K + 1) : 0u;
+    hipLaunchKernelGGL(grad_tails_fused_kernel, dim3(n_reduce + 1 + n_third), dim3(256), 0, stream, ta, n_reduce, n_third);
   }
-  hipLaunchKernelGGL(grad_sched_tail_kernel, dim3(1), dim3(256), 0, stream, ta);
-  if (d.arch == CMCD_ARCH_DDS) {
-    hipLaunchKernelGGL(grad_dds_tail_kernel, dim3(K + 1), dim3(64), 0, stream, ta);
+  if (d.arch == CMCD_ARCH_DDS)
     hipLaunchKernelGGL(grad_dds_tail_sum_kernel, dim3(((64 + 4096 + 64 + 4096 + 64 + 8192 + 64) * 16 + 255) / 256), dim3(256), 0, stream, ta);
-  }
-  else hipLaunchKernelGGL(grad_geffner_tail_kernel, dim3(geffner_tail_blocks(ta)), dim3(256), 0, stream, ta);
+  else
+    hipLaunchKernelGGL(grad_geffner_tail_kernel, dim3(geffner_tail_blocks(ta)), dim3(256), 0, stream, ta);
   return hipGetLastError() == hipSuccess ? CMCD_OK : CMCD_ERR_HIP;
 }
 
