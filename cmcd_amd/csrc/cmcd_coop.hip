@@ -76,14 +76,14 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
   constexpr int NR = HALF ? 2 : 4;           // neurons per lane and 16-neuron tile (element-wise work)
   constexpr int Hh = (D + 1) / 2;
   constexpr int NZ = 2 * Hh;                 // noise words per particle (>= D)
-  constexpr int GP = (D + 1 + 3) & ~3;       // grad log p [D], log p, padded to a float4 multiple
+  constexpr int GP = (2 * D + 1 + 3) & ~3;   // base [D] (state + score terms of the forward mean), grad log p [D], log p; padded
   constexpr int PT = (T * D + 3) & ~3;       // layer-3 partials per particle, padded
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* hbuf = lds;                         // [T][4][16][4]  layer-1 activations, MFMA-B order
   constexpr int ZP = (D + 3) & ~3;
   float* part = hbuf + HP * 16;              // [2][16][PT]    layer-3 partial sums, [c][v*D + j]
   float* zbuf = part + 2 * 16 * PT;          // [16][ZP]       z_i published by MLP wave 0
-  float* gpb = zbuf + 16 * ZP;               // [2][16][GP]    grad log p, log p
+  float* gpb = zbuf + 16 * ZP;               // [2][16][GP]    base, grad log p, log p
   float* nzb = gpb + 2 * 16 * GP;            // [2][16][NZ]    Gaussian noise
   uint32_t* raw = reinterpret_cast<uint32_t*>(nzb + 2 * 16 * NZ);  // [2][16][NZ] raw bits
   float* lds_tgt = reinterpret_cast<float*>(raw + 2 * 16 * NZ);
@@ -292,25 +292,44 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
   auto phase_c = [&](int e, bool track_w, const f32x4& sc, const f32x4& sd) {
     const int pb = e & 1;
     const float eps = sc[1], sig = sc[2], cst = sc[3], inv2s2 = sd[0], cA = sd[1], cB = sd[2];
-    float sn[D], gp[D], gq[D];
+    // base_j = z_j + eps beta clip(gp_j) + eps (1 - beta) clip(gq_j) arrives from the target waves (r02: they have the
+    // slack, the MLP waves are the critical path and need only s: 14 instead of 24 instructions here); the forward mean
+    // is fk = base - eps s, in the reference's own order (mcd_cais.py:61: z - eps uf - eps s).  Every wave reads the
+    // same base from LDS and forms the same sum over the same partials, so all copies of z stay bitwise equal.
+    float sn[D], gp[D], gq[D], base[D];
     {
-      float pt[PT], gv[GP];
+      float pt[PT];
 #pragma unroll
       for (int q = 0; q < PT; q += 4)
         *reinterpret_cast<f32x4*>(pt + q) = *reinterpret_cast<const f32x4*>(part + (pb * 16 + c) * PT + q);
+      if (track_w) {   // ACC: also the clipped scores (backward kernel of the previous step) and log p
+        float gv[GP];
 #pragma unroll
-      for (int q = 0; q < GP; q += 4)
-        *reinterpret_cast<f32x4*>(gv + q) = *reinterpret_cast<const f32x4*>(gpb + (pb * 16 + c) * GP + q);
+        for (int q = 0; q < GP; q += 4)
+          *reinterpret_cast<f32x4*>(gv + q) = *reinterpret_cast<const f32x4*>(gpb + (pb * 16 + c) * GP + q);
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          base[j] = gv[j];
+          gp[j] = __builtin_amdgcn_fmed3f(gv[D + j], -cp, cp);
+          gq[j] = __builtin_amdgcn_fmed3f((qmean[j] - z[j]) * qiv[j], -cq, cq);
+        }
+        logp = gv[2 * D];
+      } else {
+        constexpr int BQ = (D + 3) & ~3;
+        float bv[BQ];
+#pragma unroll
+        for (int q = 0; q < BQ; q += 4)
+          *reinterpret_cast<f32x4*>(bv + q) = *reinterpret_cast<const f32x4*>(gpb + (pb * 16 + c) * GP + q);
+#pragma unroll
+        for (int j = 0; j < D; ++j) { base[j] = bv[j]; gp[j] = 0.f; gq[j] = 0.f; }
+      }
 #pragma unroll
       for (int j = 0; j < D; ++j) {
         float o = b3[j];
 #pragma unroll
         for (int v = 0; v < T; ++v) o += pt[v * D + j];
         sn[j] = (ARCH == CMCD_ARCH_DDS) ? __builtin_amdgcn_fmed3f(o, -1e4f, 1e4f) : o * factor;
-        gp[j] = __builtin_amdgcn_fmed3f(gv[j], -cp, cp);
-        gq[j] = __builtin_amdgcn_fmed3f((qmean[j] - z[j]) * qiv[j], -cq, cq);
       }
-      logp = gv[D];
     }
     STAMP(9);   // exchange rows + schedule row read and combined
     if (track_w && e > 0) {  // backward kernel of step e-1: bk = z - eps ub + eps s, ub = -(beta gp + (1-beta) gq)
@@ -328,7 +347,7 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
     const float seps = a.ula ? 0.f : -eps;
 #pragma unroll
     for (int j = 0; j < D; ++j) {
-      const float fk = fmaf(cA, gp[j], fmaf(cB, gq[j], fmaf(seps, sn[j], z[j])));
+      const float fk = fmaf(seps, sn[j], base[j]);
       const float zn = fmaf(sig, nzb[(pb * 16 + c) * NZ + j], fk);
       if (track_w) {
         const float df = zn - fk;
@@ -521,9 +540,15 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
       Target<TARGET, D>::template pass2<LPT>(z, sub8, lds_tgt, tst, lp, gp);
       if (sub8 < (HALF ? 2 : 1)) {   // HALF: lane sub 1 (same totals) fills the twin column
         const int col = c + 8 * sub8;
+        const float cA = sd[1], cB = sd[2];   // eps_i beta_i, eps_i (1 - beta_i): the row phase C(i) uses
 #pragma unroll
-        for (int j = 0; j < D; ++j) gpb[(buf * 16 + col) * GP + j] = gp[j];
-        gpb[(buf * 16 + col) * GP + D] = lp;
+        for (int j = 0; j < D; ++j) {
+          const float gpc = __builtin_amdgcn_fmed3f(gp[j], -cp, cp);
+          const float gqc = __builtin_amdgcn_fmed3f((qmean[j] - z[j]) * qiv[j], -cq, cq);
+          gpb[(buf * 16 + col) * GP + j] = fmaf(cA, gpc, fmaf(cB, gqc, z[j]));
+          gpb[(buf * 16 + col) * GP + D + j] = gp[j];
+        }
+        gpb[(buf * 16 + col) * GP + 2 * D] = lp;
       }
       if (MERGE && i < K) {
         // 12-wave instance: the merged RNG / ACC wave is the longest stream of the workgroup and the target waves wait
@@ -667,7 +692,7 @@ static int default_prio(const cmcd_desc&, bool half, int waves) {
 int coop_launch(const cmcd_desc& d, const TrajArgs& ta_in, bool half, void* stream) {
   TrajArgs ta = ta_in;
   const int T = ta.w.T, D = d.dim, Hh = (D + 1) / 2, NZ = 2 * Hh;
-  const int GP = (D + 1 + 3) & ~3, PT = (T * D + 3) & ~3;
+  const int GP = (2 * D + 1 + 3) & ~3, PT = (T * D + 3) & ~3;
   const CoopInstance inst = pick(d, T, half);
   coop_fn fn = inst.fn;
   if (!fn) return CMCD_ERR_UNSUPPORTED;
