@@ -847,7 +847,10 @@ __global__ void vargrad_weights_kernel(const float* loss, const double* stats, i
   const double mean = stats[1] / (double)n_total;
   const double var = stats[2] / (double)n_total - mean * mean;
   const bool clipped = var > 1e7 || var < -1e7;
-  omega[i] = clipped ? 0.0f : (float)(-2.0 / (double)n_total * ((double)loss[i] - mean));
+  // NaN variance (inf - inf): reverse mode multiplies the zero cotangent of the clip into infinite / NaN partials, every
+  // entry of jax's gradient is NaN; the closed form alone would give +-inf for the finite losses, which Adam's clip
+  // would turn into full-size steps
+  omega[i] = (var != var) ? __builtin_nanf("") : (clipped ? 0.0f : (float)(-2.0 / (double)n_total * ((double)loss[i] - mean)));
 }
 
 // ------------------------------------------------------------------------------------------

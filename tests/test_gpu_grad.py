@@ -313,6 +313,32 @@ def test_fused_optimiser_step_with_non_finite_input(hip_lib):
     assert torch.equal(p, flat) and int(flag) == 1          # inf - inf: the mean is NaN
 
 
+def test_vargrad_weights_follow_the_variance_clip(hip_lib):
+    """compute_bound_var returns clip(var, +-1e7) (/root/reference/src/mcdboundingmachine.py:231): inside the clip
+    d var / d w_n = -(2 / N)(l_n - mean l); outside jnp.clip passes no gradient, so every weight is zero; a batch with an
+    infinite loss has var = NaN and NaN weights, as jax.grad gives."""
+    import ctypes as C
+    from cmcd_amd import _lib
+    from oracle import cmcd_oracle as orc
+
+    def weights(losses):
+        l = torch.tensor(losses, dtype=torch.float32, device="cuda")
+        stats = torch.tensor(orc.stats5(np.asarray(losses, np.float64)), dtype=torch.float64, device="cuda")
+        om = torch.empty_like(l)
+        _lib.check(hip_lib.cmcd_vargrad_weights(l.data_ptr(), stats.data_ptr(), l.numel(), l.numel(), om.data_ptr(), None))
+        torch.cuda.synchronize()
+        return om.cpu().numpy()
+    small = np.array([1.0, 2.0, 4.0, 9.0])
+    np.testing.assert_allclose(weights(small), -(2.0 / 4) * (small - small.mean()), rtol=1e-6)
+    big = np.array([0.0, 1.0e4, -1.0e4, 3.0])                 # var = 5e7 > 1e7
+    assert np.var(big) > 1e7 and not weights(big).any()
+    edge = np.array([0.0, 6.0e3, -6.0e3, 0.0])                # var = 1.8e7 > 1e7 as well; 4e3 -> 8e6 is inside
+    assert not weights(edge).any()
+    inside = np.array([0.0, 4.0e3, -4.0e3, 0.0])
+    np.testing.assert_allclose(weights(inside), -(2.0 / 4) * (inside - inside.mean()), rtol=1e-6)
+    assert np.isnan(weights(np.array([1.0, np.inf, 2.0, 3.0]))).all()
+
+
 def test_opt_run_stops_at_a_nan_loss_with_the_last_finite_parameters(hip_lib):
     """opt.run polls the divergence flag: a grad_and_loss that turns NaN at iteration 7 leaves the parameters of
     iteration 6 (what /root/reference/src/opt.py:122-124 returns), however rarely the host looks."""
