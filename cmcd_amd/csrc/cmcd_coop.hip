@@ -4,24 +4,29 @@
 // Why: the named workload (N = 2000, K = 256) is a 256-long dependent chain on only 125 tiles.  A
 // wave-per-tile kernel leaves 7/8 of the SIMDs idle and its per-bridge latency is one wave's
 // instruction issue (~1800 VALU instructions at ~4.5 cycles each; integer chains ~8.5).  Here the
-// tile's work is spread over T + 4 waves of one CU:
-//   waves 0..T-1  MLP: wave v owns hidden-neuron tile v (16 neurons): 4 first-layer neurons per lane,
-//                 its W2 A-fragments (resident in VGPRs for the whole launch), its MFMA accumulator, its
-//                 slice of the output dot product; advances z redundantly (needs it for layer 1);
-//   waves T, T+1  TGT: grad log p(z) for 8 particles each, 8 lanes per particle (z read from LDS);
+// tile's work is spread over T + 4 waves of one CU (T + 3 where RNG and ACC share a wave: MERGE, the 132-wide net):
+//   waves 0..T-1  MLP: wave v owns hidden-neuron tile v (16 neurons): its first-layer neurons, its W2 operands
+//                 (resident in VGPRs for the whole launch), its matrix accumulator, its slice of the output dot
+//                 product; keeps its own copy of z (needs it for layer 1);
+//   waves T, T+1  TGT: grad log p(z) for half of the tile's particles each (8, or 16 with HALF, lanes per particle),
+//                 own copy of z; also forms base = z + eps beta clip(gp) + eps (1 - beta) clip(gq), the part of the
+//                 forward mean that does not need the network;
 //   wave  T+2     RNG: the jax Threefry key chain, one bridge AHEAD, raw bits only (integer chain);
 //   wave  T+3     ACC: bits -> Gaussian deviates (Giles erfinv), and the only owner of the log-weight w
 //                 and of the outputs.
 // Per bridge evaluation i, two raw s_barriers (LDS visibility via s_waitcnt lgkmcnt(0) only):
-//   interval 1:  MLP only: phase C(i-1) (layer-3 partials, grad log p, noise -> z_i), publish z_i,
-//                layer 1 + activation -> hbuf.   (RNG: split(gen); TGT / ACC idle: VALU issue is a per-SIMD
-//                resource and they share SIMDs with the MLP waves)
+//   interval 1:  MLP: layer 1 + activation -> hbuf | TGT: distance pass of grad log p(z_i) | RNG: split(gen) of bridge i+1
 //   barrier 1
-//   interval 2:  MLP: layer 2 on the matrix cores from hbuf, activation, layer-3 partial -> part |
-//                TGT: both target passes -> gpb | RNG: split(H), normal bits -> raw |
-//                ACC: raw -> nzb, and phase C(i-1) again (one bridge late) for the log-weight
+//   interval 2:  MLP: layer 2 on the matrix cores from hbuf, activation, layer-3 partials -> part |
+//                TGT: exponential pass -> grad log p, log p, base -> gpb | RNG: split(H), normal bits -> raw |
+//                ACC: raw -> deviates -> nzb
 //   barrier 2
-// Same arithmetic as traj_kernel (cmcd_kernels.hip); reference lines are cited there.
+//   phase C(i):  every wave that keeps a z (MLP, TGT, ACC) reads the same exchange rows and forms
+//                s = clip(b3 + sum of partials), fk = base - eps s, z_{i+1} = fk + sigma eps_i — identical bits in
+//                every copy; ACC also closes step i-1 into the log-weight (mcd_cais.py:71-86).
+// The per-bridge schedule row arrives as a scalar load requested at the top of the iteration.
+// Same arithmetic as traj_kernel (cmcd_kernels.hip) up to the association of the forward mean; reference lines are
+// cited there.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -80,10 +85,8 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
   constexpr int PT = (T * D + 3) & ~3;       // layer-3 partials per particle, padded
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* hbuf = lds;                         // [T][4][16][4]  layer-1 activations, MFMA-B order
-  constexpr int ZP = (D + 3) & ~3;
   float* part = hbuf + HP * 16;              // [2][16][PT]    layer-3 partial sums, [c][v*D + j]
-  float* zbuf = part + 2 * 16 * PT;          // [16][ZP]       z_i published by MLP wave 0
-  float* gpb = zbuf + 16 * ZP;               // [2][16][GP]    base, grad log p, log p
+  float* gpb = part + 2 * 16 * PT;           // [2][16][GP]    base, grad log p, log p
   float* nzb = gpb + 2 * 16 * GP;            // [2][16][NZ]    Gaussian noise
   uint32_t* raw = reinterpret_cast<uint32_t*>(nzb + 2 * 16 * NZ);  // [2][16][NZ] raw bits
   float* lds_tgt = reinterpret_cast<float*>(raw + 2 * 16 * NZ);
@@ -275,15 +278,14 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
     if (ARCH == CMCD_ARCH_GEFFNER) urow = load_row(urow_ptr);
   }
 
-  // Phase C of evaluation e: s(z_e, e) from the layer-3 partials, grad log p, grad log q; [track_w: close
-  // step e-1 into the log-weight, mcd_cais.py:71-86]; open step e (forward kernel, mcd_cais.py:52-67) ->
-  // z_{e+1}.  VALU issue is a per-SIMD resource shared by co-resident waves (measured: the younger wave of
-  // a SIMD runs 2.2x slower while its partner issues), so only the waves that need z_{e+1} immediately (the
-  // MLP waves) run this after barrier 2; ACC repeats it one bridge later inside interval 2, for w.
-  // Arithmetic note: uf = -(beta gp + (1-beta) gq), fk = z - eps uf - eps s  (mcd_cais.py:52-61) is evaluated
-  // as fk = fma(eps beta, gp, fma(eps (1-beta), gq, fma(-eps, s, z))) with the two products precombined in
-  // the schedule table: same value up to the last rounding, a third of the instructions.  Clips are
-  // v_med3_f32 against +-inf when clipping is off (no branch).
+  // Phase C of evaluation e: s(z_e, e) from the layer-3 partials; [track_w: close step e-1 into the log-weight,
+  // mcd_cais.py:71-86]; open step e (forward kernel, mcd_cais.py:52-67) -> z_{e+1}.  Run right after barrier 2 by
+  // every wave that keeps a copy of z (MLP, TGT, ACC: ~15 instructions each, cheaper than an LDS hand-over of z and a
+  // third barrier); only ACC tracks w.
+  // Arithmetic note: uf = -(beta gp + (1-beta) gq), fk = z - eps uf - eps s  (mcd_cais.py:52-61) is evaluated as
+  // base = fma(eps beta, gp, fma(eps (1-beta), gq, z)) on the target waves (the two products precombined in the schedule
+  // table) and fk = fma(-eps, s, base) here: same value up to the last rounding.  Clips are v_med3_f32 against +-inf
+  // when clipping is off (no branch).
 #ifdef CMCD_STAMPS
   unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
 #endif
@@ -697,8 +699,7 @@ int coop_launch(const cmcd_desc& d, const TrajArgs& ta_in, bool half, void* stre
   coop_fn fn = inst.fn;
   if (!fn) return CMCD_ERR_UNSUPPORTED;
   ta.prio = g_coop_prio >= 0 ? g_coop_prio : default_prio(d, half, inst.waves);
-  const int ZP = (D + 3) & ~3;
-  const size_t lds_bytes = size_t(16 * T * 16 + 2 * 16 * PT + 16 * ZP + 2 * 16 * GP + 2 * 16 * NZ + 2 * 16 * NZ + ta.w.tgt_floats) * 4;
+  const size_t lds_bytes = size_t(16 * T * 16 + 2 * 16 * PT + 2 * 16 * GP + 2 * 16 * NZ + 2 * 16 * NZ + ta.w.tgt_floats) * 4;
   const unsigned tiles = half ? unsigned((ta.n + 7) / 8) : (unsigned)ta.w.n_waves;
   // While there are no more workgroups than CUs, claim more than half of a CU's 160 KB of LDS: the dispatcher can
   // then never put two workgroups on one CU while another CU sits idle (two on a CU share its SIMDs and the
