@@ -382,7 +382,7 @@ def main():
     traffic, traffic_src = (None, None)
     if head_leg is weak and default_workload:
         traffic, traffic_src = stored_traffic("coop_kernel")
-    elif head_leg is not weak:
+    elif head_leg is not weak and head_leg.n_local <= 2048:      # the 8-particle-tile instance of the 132-wide net
         traffic, traffic_src = stored_traffic("coop_kernel_t9_half")
 
     result = {
