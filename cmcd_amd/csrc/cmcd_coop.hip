@@ -34,6 +34,7 @@
 #include <atomic>
 #include <mutex>
 #include <set>
+#include <type_traits>
 #include <utility>
 
 #include "cmcd_common.h"
@@ -299,6 +300,14 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
     // is fk = base - eps s, in the reference's own order (mcd_cais.py:61: z - eps uf - eps s).  Every wave reads the
     // same base from LDS and forms the same sum over the same partials, so all copies of z stay bitwise equal.
     float sn[D], gp[D], gq[D], base[D];
+    // every exchange row this wave needs is requested before the first use: one LDS round trip, not two (the compiler
+    // left the noise and base reads behind the wait for the partials, ISA reading r02)
+    float nz[NZ];
+    if (e < K) {
+#pragma unroll
+      for (int q = 0; q < NZ; q += 2)
+        *reinterpret_cast<float2*>(nz + q) = *reinterpret_cast<const float2*>(nzb + (pb * 16 + c) * NZ + q);
+    }
     {
       float pt[PT];
 #pragma unroll
@@ -325,6 +334,7 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
 #pragma unroll
         for (int j = 0; j < D; ++j) { base[j] = bv[j]; gp[j] = 0.f; gq[j] = 0.f; }
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < D; ++j) {
         float o = b3[j];
@@ -350,7 +360,7 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
 #pragma unroll
     for (int j = 0; j < D; ++j) {
       const float fk = fmaf(seps, sn[j], base[j]);
-      const float zn = fmaf(sig, nzb[(pb * 16 + c) * NZ + j], fk);
+      const float zn = fmaf(sig, nz[j], fk);
       if (track_w) {
         const float df = zn - fk;
         fk_lp += -(df * df) * inv2s2 - cst;
@@ -378,219 +388,246 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
   // some role paths, got re-used there, and the hazard put `s_waitcnt vmcnt(0)` — an L2 round trip — at the start of
   // interval 1 of every wave (0.2676 ms); an LDS copy of the table removed that (0.2425 ms) at the price of two more
   // 1 KB broadcast reads per wave in phase C.
-  typedef const __attribute__((address_space(4))) f32x4* const_f32x4_ptr;
-  const const_f32x4_ptr sched_c = (const_f32x4_ptr)(a.ws + a.w.sched);
-  for (int i = 0; i <= K; ++i) {
-    const int buf = i & 1;
-    const int srow = i < K ? i : K - 1;
-    const f32x4 sc = sched_c[2 * srow], sd = sched_c[2 * srow + 1];
-    float h[NR];
-#pragma unroll
-    for (int r = 0; r < NR; ++r) h[r] = 0.f;
-    uint32_t g0 = 0, g1 = 0, h0 = 0, h1 = 0;
-    typename Target<TARGET, D>::State tst;
-    // ------------------------------------------------------------------ interval 1
-    if (is_mlp) {
-      float pre[NR];
-#pragma unroll
-      for (int r = 0; r < NR; ++r) {
-        pre[r] = brow[r];
-#pragma unroll
-        for (int j = 0; j < D; ++j) pre[r] += z[j] * w1[j][r];
+  const float* const sched_p = a.ws + a.w.sched;
+  // ONE LOOP PER ROLE (r02): the roles are wave-uniform, but as branches inside one shared loop body every role's
+  // loop-carried registers met at every merge point — the MLP waves executed ~40 `v_mov` phi copies and ~35 scalar
+  // branch instructions per bridge beside ~105 useful ones (ISA reading), and a lone wave issues one instruction per
+  // ~5 cycles whatever it is.  Each role now runs its own copy of the loop with the same barrier sequence (raw
+  // `s_barrier` counts arrivals, not program counters).
+  enum { kMLP = 0, kTGT = 1, kRNG = 2, kACC = 3, kRNGACC = 4 };
+  auto role_loop = [&](auto role_tag) {
+    constexpr int R = decltype(role_tag)::value;
+    constexpr bool r_mlp = R == kMLP, r_tgt = R == kTGT, r_rng = R == kRNG || R == kRNGACC, r_acc = R == kACC || R == kRNGACC;
+    for (int i = 0; i <= K; ++i) {
+      const int buf = i & 1;
+      const int srow = i < K ? i : K - 1;
+      // hand-issued s_load: the row is requested first thing in the iteration and is complete behind barrier 1's own
+      // `s_waitcnt lgkmcnt(0)`; the values pass THROUGH that barrier statement (in-out operands), so no use can be
+      // scheduled in front of it and the compiler, which does not see a pending scalar load, adds no wait of its own
+      f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sd = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (!r_rng || r_acc) {
+        const float* rowp = sched_p + __builtin_amdgcn_readfirstlane(8 * srow);   // scalar address whatever the allocator thinks of i
+        asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x10" : "=&s"(sc), "=&s"(sd) : "s"(rowp));
+        __builtin_amdgcn_sched_barrier(0);
       }
-      if (ARCH == CMCD_ARCH_DDS) {
+      float h[NR];
 #pragma unroll
-        for (int r = 0; r < NR; ++r) h[r] = gelu_fast(pre[r]);
-      } else {
-        float u[NR];
+      for (int r = 0; r < NR; ++r) h[r] = 0.f;
+      uint32_t g0 = 0, g1 = 0, h0 = 0, h1 = 0;
+      typename Target<TARGET, D>::State tst;
+      // ------------------------------------------------------------------ interval 1
+      if constexpr (r_mlp) {
+        float pre[NR];
 #pragma unroll
-        for (int r = 0; r < NR; ++r) u[r] = urow[r];
-        if (wv == 0) {  // the first D neurons of u are z itself (D <= 16)
+        for (int r = 0; r < NR; ++r) {
+          pre[r] = brow[r];
 #pragma unroll
-          for (int r = 0; r < NR; ++r) {
-            const int nidx = nb + r;   // wv == 0
-#pragma unroll
-            for (int j = 0; j < D; ++j) u[r] = (nidx == j) ? z[j] : u[r];
-          }
+          for (int j = 0; j < D; ++j) pre[r] += z[j] * w1[j][r];
         }
+        if (ARCH == CMCD_ARCH_DDS) {
 #pragma unroll
-        for (int r = 0; r < NR; ++r) h[r] = u[r] + softplus(pre[r]);
-      }
-      if (HALF) {
-        *reinterpret_cast<float2*>(my_h) = float2{h[0], h[1]};
-      } else {
-        *reinterpret_cast<f32x4*>(my_h) = f32x4{h[0], h[1], h[NR - 2], h[NR - 1]};
-      }
-    } else if (is_tgt) {
-      Target<TARGET, D>::template pass1r<LPT>(z, sub8, lds_tgt, tmeans, tst);   // distances / shift of z_i (own z, means in registers)
-    } else if (is_rng && !MERGE && i + 1 < K) {
-      uint32_t x0 = gb, x1 = 2 + gb;
-      threefry2x32(k0, k1, x0, x1);            // (G, H) = split(gen) of bridge i+1
-      rows01(x0, g0, g1);
-      rows01(x1, h0, h1);
-    }
-    STAMP(0);
-    lds_barrier();
-    STAMP(1);
-    // ------------------------------------------------------------------ interval 2
-    if (is_mlp) {
-      // prefetch the next evaluation's first-layer bias row (L2-resident); lands during the MFMAs.
-      // CAIS evaluates s(z_{i+1}, i+1); MCD_ULA_sn evaluates s(z_{i+1}, i) (mcd_over_orig.py:44).
-      const int nrow = (i < K ? i + 1 : K) - (a.ula == 2 ? 1 : 0);
-      brow = load_row(brow_ptr + (int64_t)nrow * HP);
-      if (ARCH == CMCD_ARCH_GEFFNER) urow = load_row(urow_ptr + (int64_t)nrow * HP);
-      // layer 2: rows = my 16 output neurons, cols = particles, k = all HP inputs from LDS
-      float av[NR], h2[NR];
-      uint32_t r0h, r1h;
-      if (HALF) {
-        // 16 blocks of 4 neurons x 4 particles per instruction: block (ng, pg, kh) accumulates half kh of the
-        // contraction; no column of the product is wasted (the 16x16x4 shape would carry every particle twice)
-        // all LDS reads in flight before the first MFMA (one round trip, not one per group of four), and two
-        // accumulators (even / odd inputs): a 4x4x1 MFMA that reads its predecessor's result needs two wait states
-        constexpr int NQB = HALF ? NQ / 4 : 1;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (NQB <= 8) {
-          f32x4 hb[NQB];
-#pragma unroll
-          for (int q = 0; q < NQB; ++q) hb[q] = *reinterpret_cast<const f32x4*>(rd_h + 4 * q);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int q = 0; q < NQB; ++q) {
-            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * q + 0], hb[q][0], acc, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * q + 1], hb[q][1], acc1, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * q + 2], hb[q][2], acc, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * q + 3], hb[q][3], acc1, 0, 0, 0);
-          }
+          for (int r = 0; r < NR; ++r) h[r] = gelu_fast(pre[r]);
         } else {
-          // wide nets (9 tiles: 18 reads): the activations arrive in chunks of CH reads.  Single-buffered: with three
-          // waves per SIMD the other waves' matrix instructions fill the LDS latency of a chunk, and the 72 resident
-          // operand registers leave no room for a second buffer (a spilled operand is reloaded from scratch INSIDE the
-          // chain: `s_waitcnt vmcnt(0)` between two matrix instructions, r02 ISA reading)
-#ifndef CMCD_T9_CH
-#define CMCD_T9_CH 3
-#endif
-          constexpr int CH = CMCD_T9_CH, NCH = NQB / CH;
-          static_assert(NQB % CH == 0, "chunking");
+          float u[NR];
 #pragma unroll
-          for (int ch = 0; ch < NCH; ++ch) {
-            f32x4 hb[CH];
+          for (int r = 0; r < NR; ++r) u[r] = urow[r];
+          if (wv == 0) {  // the first D neurons of u are z itself (D <= 16)
 #pragma unroll
-            for (int q = 0; q < CH; ++q) hb[q] = *reinterpret_cast<const f32x4*>(rd_h + 4 * (ch * CH + q));
-            __builtin_amdgcn_sched_barrier(0);
+            for (int r = 0; r < NR; ++r) {
+              const int nidx = nb + r;   // wv == 0
 #pragma unroll
-            for (int q = 0; q < CH; ++q) {
-              const int qq = ch * CH + q;
-              acc = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * qq + 0], hb[q][0], acc, 0, 0, 0);
-              acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * qq + 1], hb[q][1], acc1, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * qq + 2], hb[q][2], acc, 0, 0, 0);
-              acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * qq + 3], hb[q][3], acc1, 0, 0, 0);
+              for (int j = 0; j < D; ++j) u[r] = (nidx == j) ? z[j] : u[r];
             }
-            __builtin_amdgcn_sched_barrier(0);
           }
+#pragma unroll
+          for (int r = 0; r < NR; ++r) h[r] = u[r] + softplus(pre[r]);
         }
-        acc += acc1;
-        STAMP(7);   // activations read, matrix instructions done
-        // the two halves of the contraction sit in lanes l and l ^ 32; lane kh keeps neurons 2 kh + {0, 1} of its group
-        uint32_t r0, r1;
-        swap32(__float_as_uint(acc[0]), __float_as_uint(acc[2]), r0, r1);
-        av[0] = (__uint_as_float(r0) + __uint_as_float(r1)) + b2p[0];
-        swap32(__float_as_uint(acc[1]), __float_as_uint(acc[3]), r0, r1);
-        av[1] = (__uint_as_float(r0) + __uint_as_float(r1)) + b2p[1];
-      } else {
-        f32x4 acc = b2v;
-#pragma unroll
-        for (int ti = 0; ti < T; ++ti) {
-          const f32x4 hb = *reinterpret_cast<const f32x4*>(rd_h + ti * 256);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ti][r], hb[r], acc, 0, 0, 0);
+        if (HALF) {
+          *reinterpret_cast<float2*>(my_h) = float2{h[0], h[1]};
+        } else {
+          *reinterpret_cast<f32x4*>(my_h) = f32x4{h[0], h[1], h[NR - 2], h[NR - 1]};
         }
-#pragma unroll
-        for (int r = 0; r < NR; ++r) av[r] = acc[r & 3];
-      }
-#pragma unroll
-      for (int r = 0; r < NR; ++r) h2[r] = (ARCH == CMCD_ARCH_DDS) ? gelu_fast(av[r]) : h[r] + softplus(av[r]);
-      STAMP(8);   // contraction halves folded, activation
-      if (HALF) {
-        // outputs in pairs (j, j + 1): ONE row swap leaves the lower half-wave with both contraction halves of output
-        // j and the upper half-wave with both of output j + 1 (swap32(a, b): r0 = [a_lo | b_lo], r1 = [a_hi | b_hi]),
-        // so the sum over the 4 neuron groups (lane bits 2, 3) runs once per pair instead of once per output
-        static_assert(D % 2 == 0, "8-particle tiles pair the outputs");
-#pragma unroll
-        for (int j = 0; j < D; j += 2) {
-          const float p0 = h2[0] * w3[j][0] + h2[1] * w3[j][1];
-          const float p1 = h2[0] * w3[j + 1][0] + h2[1] * w3[j + 1][1];
-          swap32(__float_as_uint(p0), __float_as_uint(p1), r0h, r1h);
-          float pj = __uint_as_float(r0h) + __uint_as_float(r1h);   // kh = 0: output j, kh = 1: output j + 1
-          pj += xor8(pj);
-          pj += ror4(pj);
-          if (ng == 0) {   // both twin columns
-            part[(buf * 16 + c) * PT + wv * D + j + kh] = pj;
-            part[(buf * 16 + c + 8) * PT + wv * D + j + kh] = pj;
-          }
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-          float pj = h2[0] * w3[j][0] + h2[1] * w3[j][1] + h2[NR - 2] * w3[j][NR - 2] + h2[NR - 1] * w3[j][NR - 1];
-          pj = group_sum(pj);
-          if (g == 0) part[(buf * 16 + c) * PT + wv * D + j] = pj;
-        }
-      }
-    } else if (is_tgt) {
-      // second pass only: its SIMD partner (an MLP wave) blocks the VALU during the 16 fp32 MFMAs
-      float gp[D], lp = 0.f;
-      Target<TARGET, D>::template pass2<LPT>(z, sub8, lds_tgt, tst, lp, gp);
-      if (sub8 < (HALF ? 2 : 1)) {   // HALF: lane sub 1 (same totals) fills the twin column
-        const int col = c + 8 * sub8;
-        const float cA = sd[1], cB = sd[2];   // eps_i beta_i, eps_i (1 - beta_i): the row phase C(i) uses
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-          const float gpc = __builtin_amdgcn_fmed3f(gp[j], -cp, cp);
-          const float gqc = __builtin_amdgcn_fmed3f((qmean[j] - z[j]) * qiv[j], -cq, cq);
-          gpb[(buf * 16 + col) * GP + j] = fmaf(cA, gpc, fmaf(cB, gqc, z[j]));
-          gpb[(buf * 16 + col) * GP + D + j] = gp[j];
-        }
-        gpb[(buf * 16 + col) * GP + 2 * D] = lp;
-      }
-      if (MERGE && i < K) {
-        // 12-wave instance: the merged RNG / ACC wave is the longest stream of the workgroup and the target waves wait
-        // ~1200 cycles at barrier 2, so the bits -> deviates conversion of bridge i (raw[buf], written one iteration
-        // ago) runs here: lane `sub` of a particle converts word `sub` and fills both twin columns
-        static_assert(!MERGE || D <= LPT, "the conversion is dealt to the lanes of a particle");
-        if (sub8 < D) {
-          const uint32_t bits = raw[(buf * 16 + c) * NZ + sub8];
-          const float dev = bits_to_normal(bits);
-          nzb[(buf * 16 + c) * NZ + sub8] = dev;
-          if (HALF) nzb[(buf * 16 + c + 8) * NZ + sub8] = dev;
-          if (a.dbg_bits && valid) {
-            a.dbg_bits[((int64_t)(i + 1) * a.n + p) * D + sub8] = bits;
-            a.dbg_noise[((int64_t)(i + 1) * a.n + p) * D + sub8] = dev;
-          }
-        }
-      }
-    } else if (is_rng) {
-      // MERGE: nothing this wave produces is read before barrier 2 (the log-weight is its own, the bits and deviates are
-      // consumed in phase C), so its phase C runs straight into barrier 1 and the whole key-chain stage sits here — the
-      // MLP waves would otherwise wait at barrier 1 for a split they do not need (r02 stamps: 700 - 1100 cycles)
-      if (MERGE && i + 1 < K) {
+      } else if constexpr (r_tgt) {
+        Target<TARGET, D>::template pass1r<LPT>(z, sub8, lds_tgt, tmeans, tst);   // distances / shift of z_i (own z, means in registers)
+      } else if constexpr (r_rng && !MERGE) {
+       if (i + 1 < K) {
         uint32_t x0 = gb, x1 = 2 + gb;
         threefry2x32(k0, k1, x0, x1);            // (G, H) = split(gen) of bridge i+1
         rows01(x0, g0, g1);
         rows01(x1, h0, h1);
+       }
       }
-      if (i + 1 < K) normal_bits(g0, g1, h0, h1, buf ^ 1, true, i + 2);   // (MERGE: the target waves convert raw[buf])
-    } else {
-      if (i < K) convert(buf, i + 1);                // noise of bridge i, read in phase C(i)
+      STAMP(0);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+s"(sc), "+s"(sd)::"memory");   // barrier 1 (+ the schedule row)
+      STAMP(1);
+      // ------------------------------------------------------------------ interval 2
+      if constexpr (r_mlp) {
+        // prefetch the next evaluation's first-layer bias row (L2-resident); lands during the MFMAs.
+        // CAIS evaluates s(z_{i+1}, i+1); MCD_ULA_sn evaluates s(z_{i+1}, i) (mcd_over_orig.py:44).
+        const int nrow = (i < K ? i + 1 : K) - (a.ula == 2 ? 1 : 0);
+        brow = load_row(brow_ptr + (int64_t)nrow * HP);
+        if (ARCH == CMCD_ARCH_GEFFNER) urow = load_row(urow_ptr + (int64_t)nrow * HP);
+        // layer 2: rows = my 16 output neurons, cols = particles, k = all HP inputs from LDS
+        float av[NR], h2[NR];
+        uint32_t r0h, r1h;
+        if (HALF) {
+          // 16 blocks of 4 neurons x 4 particles per instruction: block (ng, pg, kh) accumulates half kh of the
+          // contraction; no column of the product is wasted (the 16x16x4 shape would carry every particle twice)
+          // all LDS reads in flight before the first MFMA (one round trip, not one per group of four), and two
+          // accumulators (even / odd inputs): a 4x4x1 MFMA that reads its predecessor's result needs two wait states
+          constexpr int NQB = HALF ? NQ / 4 : 1;
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (NQB <= 8) {
+            f32x4 hb[NQB];
+#pragma unroll
+            for (int q = 0; q < NQB; ++q) hb[q] = *reinterpret_cast<const f32x4*>(rd_h + 4 * q);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < NQB; ++q) {
+              acc = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * q + 0], hb[q][0], acc, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * q + 1], hb[q][1], acc1, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * q + 2], hb[q][2], acc, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * q + 3], hb[q][3], acc1, 0, 0, 0);
+            }
+          } else {
+            // wide nets (9 tiles: 18 reads): the activations arrive in chunks of CH reads.  Single-buffered: with three
+            // waves per SIMD the other waves' matrix instructions fill the LDS latency of a chunk, and the 72 resident
+            // operand registers leave no room for a second buffer (a spilled operand is reloaded from scratch INSIDE the
+            // chain: `s_waitcnt vmcnt(0)` between two matrix instructions, r02 ISA reading)
+#ifndef CMCD_T9_CH
+#define CMCD_T9_CH 3
+#endif
+            constexpr int CH = CMCD_T9_CH, NCH = NQB / CH;
+            static_assert(NQB % CH == 0, "chunking");
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+              f32x4 hb[CH];
+#pragma unroll
+              for (int q = 0; q < CH; ++q) hb[q] = *reinterpret_cast<const f32x4*>(rd_h + 4 * (ch * CH + q));
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int q = 0; q < CH; ++q) {
+                const int qq = ch * CH + q;
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * qq + 0], hb[q][0], acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * qq + 1], hb[q][1], acc1, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * qq + 2], hb[q][2], acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * qq + 3], hb[q][3], acc1, 0, 0, 0);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+          acc += acc1;
+          STAMP(7);   // activations read, matrix instructions done
+          // the two halves of the contraction sit in lanes l and l ^ 32; lane kh keeps neurons 2 kh + {0, 1} of its group
+          uint32_t r0, r1;
+          swap32(__float_as_uint(acc[0]), __float_as_uint(acc[2]), r0, r1);
+          av[0] = (__uint_as_float(r0) + __uint_as_float(r1)) + b2p[0];
+          swap32(__float_as_uint(acc[1]), __float_as_uint(acc[3]), r0, r1);
+          av[1] = (__uint_as_float(r0) + __uint_as_float(r1)) + b2p[1];
+        } else {
+          f32x4 acc = b2v;
+#pragma unroll
+          for (int ti = 0; ti < T; ++ti) {
+            const f32x4 hb = *reinterpret_cast<const f32x4*>(rd_h + ti * 256);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ti][r], hb[r], acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < NR; ++r) av[r] = acc[r & 3];
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) h2[r] = (ARCH == CMCD_ARCH_DDS) ? gelu_fast(av[r]) : h[r] + softplus(av[r]);
+        STAMP(8);   // contraction halves folded, activation
+        if (HALF) {
+          // outputs in pairs (j, j + 1): ONE row swap leaves the lower half-wave with both contraction halves of output
+          // j and the upper half-wave with both of output j + 1 (swap32(a, b): r0 = [a_lo | b_lo], r1 = [a_hi | b_hi]),
+          // so the sum over the 4 neuron groups (lane bits 2, 3) runs once per pair instead of once per output
+          static_assert(D % 2 == 0, "8-particle tiles pair the outputs");
+#pragma unroll
+          for (int j = 0; j < D; j += 2) {
+            const float p0 = h2[0] * w3[j][0] + h2[1] * w3[j][1];
+            const float p1 = h2[0] * w3[j + 1][0] + h2[1] * w3[j + 1][1];
+            swap32(__float_as_uint(p0), __float_as_uint(p1), r0h, r1h);
+            float pj = __uint_as_float(r0h) + __uint_as_float(r1h);   // kh = 0: output j, kh = 1: output j + 1
+            pj += xor8(pj);
+            pj += ror4(pj);
+            if (ng == 0) {   // both twin columns
+              part[(buf * 16 + c) * PT + wv * D + j + kh] = pj;
+              part[(buf * 16 + c + 8) * PT + wv * D + j + kh] = pj;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < D; ++j) {
+            float pj = h2[0] * w3[j][0] + h2[1] * w3[j][1] + h2[NR - 2] * w3[j][NR - 2] + h2[NR - 1] * w3[j][NR - 1];
+            pj = group_sum(pj);
+            if (g == 0) part[(buf * 16 + c) * PT + wv * D + j] = pj;
+          }
+        }
+      } else if constexpr (r_tgt) {
+        // second pass only: its SIMD partner (an MLP wave) blocks the VALU during the 16 fp32 MFMAs
+        float gp[D], lp = 0.f;
+        Target<TARGET, D>::template pass2<LPT>(z, sub8, lds_tgt, tst, lp, gp);
+        if (sub8 < (HALF ? 2 : 1)) {   // HALF: lane sub 1 (same totals) fills the twin column
+          const int col = c + 8 * sub8;
+          const float cA = sd[1], cB = sd[2];   // eps_i beta_i, eps_i (1 - beta_i): the row phase C(i) uses
+#pragma unroll
+          for (int j = 0; j < D; ++j) {
+            const float gpc = __builtin_amdgcn_fmed3f(gp[j], -cp, cp);
+            const float gqc = __builtin_amdgcn_fmed3f((qmean[j] - z[j]) * qiv[j], -cq, cq);
+            gpb[(buf * 16 + col) * GP + j] = fmaf(cA, gpc, fmaf(cB, gqc, z[j]));
+            gpb[(buf * 16 + col) * GP + D + j] = gp[j];
+          }
+          gpb[(buf * 16 + col) * GP + 2 * D] = lp;
+        }
+        if (MERGE && i < K) {
+          // 12-wave instance: the merged RNG / ACC wave is the longest stream of the workgroup and the target waves wait
+          // ~1200 cycles at barrier 2, so the bits -> deviates conversion of bridge i (raw[buf], written one iteration
+          // ago) runs here: lane `sub` of a particle converts word `sub` and fills both twin columns
+          static_assert(!MERGE || D <= LPT, "the conversion is dealt to the lanes of a particle");
+          if (sub8 < D) {
+            const uint32_t bits = raw[(buf * 16 + c) * NZ + sub8];
+            const float dev = bits_to_normal(bits);
+            nzb[(buf * 16 + c) * NZ + sub8] = dev;
+            if (HALF) nzb[(buf * 16 + c + 8) * NZ + sub8] = dev;
+            if (a.dbg_bits && valid) {
+              a.dbg_bits[((int64_t)(i + 1) * a.n + p) * D + sub8] = bits;
+              a.dbg_noise[((int64_t)(i + 1) * a.n + p) * D + sub8] = dev;
+            }
+          }
+        }
+      } else if constexpr (r_rng) {
+        // MERGE: nothing this wave produces is read before barrier 2 (the log-weight is its own, the bits and deviates are
+        // consumed in phase C), so its phase C runs straight into barrier 1 and the whole key-chain stage sits here — the
+        // MLP waves would otherwise wait at barrier 1 for a split they do not need (r02 stamps: 700 - 1100 cycles)
+        if (MERGE && i + 1 < K) {
+          uint32_t x0 = gb, x1 = 2 + gb;
+          threefry2x32(k0, k1, x0, x1);            // (G, H) = split(gen) of bridge i+1
+          rows01(x0, g0, g1);
+          rows01(x1, h0, h1);
+        }
+        if (i + 1 < K) normal_bits(g0, g1, h0, h1, buf ^ 1, true, i + 2);   // (MERGE: the target waves convert raw[buf])
+      } else {
+        if (i < K) convert(buf, i + 1);                // noise of bridge i, read in phase C(i)
+      }
+      STAMP(2);
+      lds_barrier();
+      STAMP(3);
+      // ------------------------------------------------------------------ phase C: MLP, TGT (own copies of z) and
+      // ACC (with the log-weight); ~45 instructions each, so the redundancy is cheaper than an LDS hand-over
+      if constexpr (r_acc) {
+        phase_c(i, true, sc, sd);            // i = K: closes step K-1 and picks up log p(z_K)
+      } else if constexpr (r_mlp || r_tgt) {
+        if (i < K) phase_c(i, false, sc, sd);
+      }
+      STAMP(4);
     }
-    STAMP(2);
-    lds_barrier();
-    STAMP(3);
-    // ------------------------------------------------------------------ phase C: MLP, TGT (own copies of z) and
-    // ACC (with the log-weight); ~45 instructions each, so the redundancy is cheaper than an LDS hand-over
-    if (is_acc) phase_c(i, true, sc, sd);            // i = K: closes step K-1 and picks up log p(z_K)
-    else if ((is_mlp || is_tgt) && i < K) phase_c(i, false, sc, sd);
-    STAMP(4);
-  }
+  };
+  if (is_mlp) role_loop(std::integral_constant<int, kMLP>{});
+  else if (is_tgt) role_loop(std::integral_constant<int, kTGT>{});
+  else if (MERGE) role_loop(std::integral_constant<int, kRNGACC>{});
+  else if (is_rng) role_loop(std::integral_constant<int, kRNG>{});
+  else role_loop(std::integral_constant<int, kACC>{});
 #ifdef CMCD_STAMPS
   if (blockIdx.x == 0 && lane == 0)
     for (int k = 0; k < 16; ++k) g_stamps[wv][k] = st_acc[k];
