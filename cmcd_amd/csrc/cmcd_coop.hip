@@ -103,11 +103,15 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
   // particles over the two waves, results written to both twin columns), everyone else 16 x 4
   constexpr int LPT = HALF ? 16 : 8;         // lanes per particle on the target waves
   const int sub8 = HALF ? (lane >> 2) : (lane >> 3);
-  // HALF MLP waves work in the lane order of v_mfma_f32_4x4x1 (16 blocks of 4 x 4): lane = qi + 4 ng + 16 pg + 32 kh —
-  // particle 4 pg + qi, neuron group ng (4 neurons of the wave's 16), half kh of the contraction
-  const int ng = (lane >> 2) & 3, kh = lane >> 5;
+  // HALF MLP waves work in the lane order of v_mfma_f32_4x4x1 (16 blocks of 4 x 4): lane = qi + 4 pg + 8 kh + 16 ng —
+  // particle 4 pg + qi, half kh of the contraction, neuron group ng (4 neurons of the wave's 16) = the 16-lane ROW of
+  // the wave.  The B operand (the layer-1 activations) does not depend on ng, and the instruction can take it from one
+  // row for all four (BLGP = 4 + row, tools/probes/blgp_probe.hip): each row fetches a quarter of the particle's
+  // activations from LDS instead of every lane fetching all of them (r02: 8 -> 2 ds_read_b128 per lane and bridge; the
+  // four MLP waves' reads were 256 of the bridge's ~1800 cycles of LDS pipe).
+  const int ng = lane >> 4, kh = (lane >> 3) & 1;
   const int c = is_tgt ? (HALF ? 4 * (wv - T) + (lane & 3) : 8 * (wv - T) + (lane & 7))
-                       : ((HALF && is_mlp) ? (lane & 3) + 4 * ((lane >> 4) & 1) : (lane & 15));
+                       : ((HALF && is_mlp) ? (lane & 7) : (lane & 15));
   const int64_t tile = blockIdx.x;
   const int64_t p = tile * PPT + (HALF ? (c & 7) : c);
   const bool valid = p < a.n;
@@ -115,6 +119,7 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
   const int nb = HALF ? 16 * wv + 4 * ng + 2 * kh : 16 * wv + 4 * g;   // first of the lane's NR neurons (MLP waves)
   constexpr int HQP = HP + 4;                // HALF: pitch of the [particle][neuron] activation buffer (bank spread)
   constexpr int NQ = HALF ? HP / 2 : 1;      // HALF: 4x4x1 MFMA steps per bridge (two contraction halves side by side)
+  constexpr int RSA = ((HP / 2 + 15) / 16) * 4;   // HALF: activations one row of an MLP wave fetches (quarter of a half, 16-B units)
   const int K = a.K;
 
   for (int i = threadIdx.x; i < a.w.tgt_floats; i += blockDim.x) lds_tgt[i] = a.ws[a.w.tgt + i];
@@ -270,7 +275,7 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
   };
   // HALF: hbuf is [8 particles][HQP]; the lane writes its neuron pair, reads its particle's half kh of the neurons
   float* const my_h = HALF ? hbuf + c * HQP + nb : hbuf + ((wv * 4 + g) * 16 + (lane & 15)) * 4;
-  const float* const rd_h = HALF ? hbuf + c * HQP + (HP / 2) * kh : hbuf + (g * 16 + (lane & 15)) * 4;
+  const float* const rd_h = HALF ? hbuf + c * HQP + (HP / 2) * kh + RSA * ng : hbuf + (g * 16 + (lane & 15)) * 4;
 
   float fk_lp = 0.f, peps = 0.f, pinv2s2 = 0.f, pcst = 0.f, logp = 0.f;
   f32x4 brow = {0.f, 0.f, 0.f, 0.f}, urow = {0.f, 0.f, 0.f, 0.f};
@@ -292,32 +297,47 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
 #endif
   const float cp = clip_p ? clipv : INFINITY, cq = clip_q ? clipv : INFINITY;
   float pA = 0.f, pB = 0.f;
-  auto phase_c = [&](int e, bool track_w, const f32x4& sc, const f32x4& sd) {
-    const int pb = e & 1;
+  auto phase_c = [&](int e, bool track_w, const f32x4& sc, const f32x4& sd, auto pb_tag) {
+    constexpr int pb = decltype(pb_tag)::value;   // = e & 1
     const float eps = sc[1], sig = sc[2], cst = sc[3], inv2s2 = sd[0], cA = sd[1], cB = sd[2];
     // base_j = z_j + eps beta clip(gp_j) + eps (1 - beta) clip(gq_j) arrives from the target waves (r02: they have the
     // slack, the MLP waves are the critical path and need only s: 14 instead of 24 instructions here); the forward mean
     // is fk = base - eps s, in the reference's own order (mcd_cais.py:61: z - eps uf - eps s).  Every wave reads the
     // same base from LDS and forms the same sum over the same partials, so all copies of z stay bitwise equal.
     float sn[D], gp[D], gq[D], base[D];
-    // every exchange row this wave needs is requested before the first use: one LDS round trip, not two (the compiler
-    // left the noise and base reads behind the wait for the partials, ISA reading r02)
-    float nz[NZ];
+    // Every exchange row this wave needs is requested before the first use: one LDS round trip, not two (the compiler
+    // left the noise and base reads behind the wait for the partials, ISA reading r02).  The empty asm statement takes
+    // every loaded register as an in-out operand: all requests are out, and have landed, before any arithmetic.
+    f32x2 nzv[NZ / 2];
+    f32x4 ptv[PT / 4];
+    constexpr int GQ = GP / 4, BQ4 = (D + 3) / 4;
+    f32x4 gvv[GQ];
     if (e < K) {
 #pragma unroll
-      for (int q = 0; q < NZ; q += 2)
-        *reinterpret_cast<float2*>(nz + q) = *reinterpret_cast<const float2*>(nzb + (pb * 16 + c) * NZ + q);
+      for (int q = 0; q < NZ / 2; ++q) nzv[q] = *reinterpret_cast<const f32x2*>(nzb + (pb * 16 + c) * NZ + 2 * q);
     }
+#pragma unroll
+    for (int q = 0; q < (track_w ? GQ : BQ4); ++q) gvv[q] = *reinterpret_cast<const f32x4*>(gpb + (pb * 16 + c) * GP + 4 * q);
+#pragma unroll
+    for (int q = 0; q < PT / 4; ++q) ptv[q] = *reinterpret_cast<const f32x4*>(part + (pb * 16 + c) * PT + 4 * q);
+    if (e < K) {
+#pragma unroll
+      for (int q = 0; q < NZ / 2; ++q) asm volatile("" : "+v"(nzv[q]));
+    }
+#pragma unroll
+    for (int q = 0; q < (track_w ? GQ : BQ4); ++q) asm volatile("" : "+v"(gvv[q]));
+#pragma unroll
+    for (int q = 0; q < PT / 4; ++q) asm volatile("" : "+v"(ptv[q]));
+    float nz[NZ];
+#pragma unroll
+    for (int q = 0; q < NZ; ++q) nz[q] = (e < K) ? nzv[q / 2][q % 2] : 0.f;
     {
-      float pt[PT];
+      float pt[PT], gv[GP];
 #pragma unroll
-      for (int q = 0; q < PT; q += 4)
-        *reinterpret_cast<f32x4*>(pt + q) = *reinterpret_cast<const f32x4*>(part + (pb * 16 + c) * PT + q);
+      for (int q = 0; q < PT; ++q) pt[q] = ptv[q / 4][q % 4];
+#pragma unroll
+      for (int q = 0; q < (track_w ? GP : 4 * BQ4); ++q) gv[q] = gvv[q / 4][q % 4];
       if (track_w) {   // ACC: also the clipped scores (backward kernel of the previous step) and log p
-        float gv[GP];
-#pragma unroll
-        for (int q = 0; q < GP; q += 4)
-          *reinterpret_cast<f32x4*>(gv + q) = *reinterpret_cast<const f32x4*>(gpb + (pb * 16 + c) * GP + q);
 #pragma unroll
         for (int j = 0; j < D; ++j) {
           base[j] = gv[j];
@@ -326,15 +346,9 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
         }
         logp = gv[2 * D];
       } else {
-        constexpr int BQ = (D + 3) & ~3;
-        float bv[BQ];
 #pragma unroll
-        for (int q = 0; q < BQ; q += 4)
-          *reinterpret_cast<f32x4*>(bv + q) = *reinterpret_cast<const f32x4*>(gpb + (pb * 16 + c) * GP + q);
-#pragma unroll
-        for (int j = 0; j < D; ++j) { base[j] = bv[j]; gp[j] = 0.f; gq[j] = 0.f; }
+        for (int j = 0; j < D; ++j) { base[j] = gv[j]; gp[j] = 0.f; gq[j] = 0.f; }
       }
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < D; ++j) {
         float o = b3[j];
@@ -394,12 +408,16 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
   // branch instructions per bridge beside ~105 useful ones (ISA reading), and a lone wave issues one instruction per
   // ~5 cycles whatever it is.  Each role now runs its own copy of the loop with the same barrier sequence (raw
   // `s_barrier` counts arrivals, not program counters).
-  enum { kMLP = 0, kTGT = 1, kRNG = 2, kACC = 3, kRNGACC = 4 };
+  enum { kMLP = 0, kTGT = 1, kRNG = 2, kACC = 3, kRNGACC = 4, kTGTF = 5 };   // kTGTF: target waves, register-resident mixture (Target::is_fast)
   auto role_loop = [&](auto role_tag) {
     constexpr int R = decltype(role_tag)::value;
-    constexpr bool r_mlp = R == kMLP, r_tgt = R == kTGT, r_rng = R == kRNG || R == kRNGACC, r_acc = R == kACC || R == kRNGACC;
-    for (int i = 0; i <= K; ++i) {
-      const int buf = i & 1;
+    constexpr bool r_mlp = R == kMLP, r_tgt = R == kTGT || R == kTGTF, r_tgtf = R == kTGTF;
+    constexpr bool r_rng = R == kRNG || R == kRNGACC, r_acc = R == kACC || R == kRNGACC;
+    // The body is instantiated for both parities of the evaluation index: every double-buffered exchange row is then at
+    // a compile-time offset from a loop-invariant address (immediate offset field of the LDS instruction) instead of
+    // two to four address instructions per access group and bridge.
+    auto body = [&](const int i, auto buf_tag) {
+      constexpr int buf = decltype(buf_tag)::value;
       const int srow = i < K ? i : K - 1;
       // hand-issued s_load: the row is requested first thing in the iteration and is complete behind barrier 1's own
       // `s_waitcnt lgkmcnt(0)`; the values pass THROUGH that barrier statement (in-out operands), so no use can be
@@ -448,7 +466,9 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
           *reinterpret_cast<f32x4*>(my_h) = f32x4{h[0], h[1], h[NR - 2], h[NR - 1]};
         }
       } else if constexpr (r_tgt) {
-        Target<TARGET, D>::template pass1r<LPT>(z, sub8, lds_tgt, tmeans, tst);   // distances / shift of z_i (own z, means in registers)
+        // distances / shift of z_i (own z, means in registers)
+        if constexpr (r_tgtf) Target<TARGET, D>::template pass1f<LPT>(z, sub8, tmeans, tst);
+        else Target<TARGET, D>::template pass1r<LPT>(z, sub8, lds_tgt, tmeans, tst);
       } else if constexpr (r_rng && !MERGE) {
        if (i + 1 < K) {
         uint32_t x0 = gb, x1 = 2 + gb;
@@ -465,65 +485,38 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
         // prefetch the next evaluation's first-layer bias row (L2-resident); lands during the MFMAs.
         // CAIS evaluates s(z_{i+1}, i+1); MCD_ULA_sn evaluates s(z_{i+1}, i) (mcd_over_orig.py:44).
         const int nrow = (i < K ? i + 1 : K) - (a.ula == 2 ? 1 : 0);
-        brow = load_row(brow_ptr + (int64_t)nrow * HP);
-        if (ARCH == CMCD_ARCH_GEFFNER) urow = load_row(urow_ptr + (int64_t)nrow * HP);
+        // (uniform row base + the lane's constant neuron offset: scalar address arithmetic, saddr form of the load)
+        brow = load_row(a.ws + a.w.bias1 + (int64_t)nrow * HP + nb);
+        if (ARCH == CMCD_ARCH_GEFFNER) urow = load_row(a.ws + a.w.utab + (int64_t)nrow * HP + nb);
         // layer 2: rows = my 16 output neurons, cols = particles, k = all HP inputs from LDS
         float av[NR], h2[NR];
-        uint32_t r0h, r1h;
         if (HALF) {
-          // 16 blocks of 4 neurons x 4 particles per instruction: block (ng, pg, kh) accumulates half kh of the
-          // contraction; no column of the product is wasted (the 16x16x4 shape would carry every particle twice)
-          // all LDS reads in flight before the first MFMA (one round trip, not one per group of four), and two
-          // accumulators (even / odd inputs): a 4x4x1 MFMA that reads its predecessor's result needs two wait states
-          constexpr int NQB = HALF ? NQ / 4 : 1;
+          // 16 blocks of 4 neurons x 4 particles per instruction: block (pg, kh, ng) accumulates half kh of the
+          // contraction; no column of the product is wasted (the 16x16x4 shape would carry every particle twice).
+          // Step s takes its activation from the row that fetched it (BLGP broadcast); all LDS reads are in flight
+          // before the first MFMA, and two accumulators (even / odd inputs): a 4x4x1 MFMA that reads its predecessor's
+          // result needs two wait states.  Same accumulation order as the every-lane-reads-everything layout of r01.
           f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-          if constexpr (NQB <= 8) {
-            f32x4 hb[NQB];
+          f32x4 hb[RSA / 4];
 #pragma unroll
-            for (int q = 0; q < NQB; ++q) hb[q] = *reinterpret_cast<const f32x4*>(rd_h + 4 * q);
-            __builtin_amdgcn_sched_barrier(0);
+          for (int q = 0; q < RSA / 4; ++q) hb[q] = *reinterpret_cast<const f32x4*>(rd_h + 4 * q);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int q = 0; q < NQB; ++q) {
-              acc = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * q + 0], hb[q][0], acc, 0, 0, 0);
-              acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * q + 1], hb[q][1], acc1, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * q + 2], hb[q][2], acc, 0, 0, 0);
-              acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * q + 3], hb[q][3], acc1, 0, 0, 0);
-            }
-          } else {
-            // wide nets (9 tiles: 18 reads): the activations arrive in chunks of CH reads.  Single-buffered: with three
-            // waves per SIMD the other waves' matrix instructions fill the LDS latency of a chunk, and the 72 resident
-            // operand registers leave no room for a second buffer (a spilled operand is reloaded from scratch INSIDE the
-            // chain: `s_waitcnt vmcnt(0)` between two matrix instructions, r02 ISA reading)
-#ifndef CMCD_T9_CH
-#define CMCD_T9_CH 3
-#endif
-            constexpr int CH = CMCD_T9_CH, NCH = NQB / CH;
-            static_assert(NQB % CH == 0, "chunking");
-#pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) {
-              f32x4 hb[CH];
-#pragma unroll
-              for (int q = 0; q < CH; ++q) hb[q] = *reinterpret_cast<const f32x4*>(rd_h + 4 * (ch * CH + q));
-              __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-              for (int q = 0; q < CH; ++q) {
-                const int qq = ch * CH + q;
-                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * qq + 0], hb[q][0], acc, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * qq + 1], hb[q][1], acc1, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * qq + 2], hb[q][2], acc, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[4 * qq + 3], hb[q][3], acc1, 0, 0, 0);
-              }
-              __builtin_amdgcn_sched_barrier(0);
-            }
+          for (int sq = 0; sq < NQ; ++sq) {
+            const int row = sq / RSA, t = sq % RSA;
+            const float bv = hb[t / 4][t % 4];
+            f32x4& ac = (sq & 1) ? acc1 : acc;
+            if (row == 0) ac = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[sq], bv, ac, 0, 0, 4);
+            else if (row == 1) ac = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[sq], bv, ac, 0, 0, 5);
+            else if (row == 2) ac = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[sq], bv, ac, 0, 0, 6);
+            else ac = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[sq], bv, ac, 0, 0, 7);
           }
           acc += acc1;
           STAMP(7);   // activations read, matrix instructions done
-          // the two halves of the contraction sit in lanes l and l ^ 32; lane kh keeps neurons 2 kh + {0, 1} of its group
-          uint32_t r0, r1;
-          swap32(__float_as_uint(acc[0]), __float_as_uint(acc[2]), r0, r1);
-          av[0] = (__uint_as_float(r0) + __uint_as_float(r1)) + b2p[0];
-          swap32(__float_as_uint(acc[1]), __float_as_uint(acc[3]), r0, r1);
-          av[1] = (__uint_as_float(r0) + __uint_as_float(r1)) + b2p[1];
+          // the two halves of the contraction sit in lanes l and l ^ 8; lane kh keeps neurons 2 kh + {0, 1} of its group:
+          // it adds its own half of those to the partner's (the partner's register of the pair, through DPP row_ror:8)
+          av[0] = ((kh ? acc[2] : acc[0]) + xor8(kh ? acc[0] : acc[2])) + b2p[0];
+          av[1] = ((kh ? acc[3] : acc[1]) + xor8(kh ? acc[1] : acc[3])) + b2p[1];
         } else {
           f32x4 acc = b2v;
 #pragma unroll
@@ -539,18 +532,16 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
         for (int r = 0; r < NR; ++r) h2[r] = (ARCH == CMCD_ARCH_DDS) ? gelu_fast(av[r]) : h[r] + softplus(av[r]);
         STAMP(8);   // contraction halves folded, activation
         if (HALF) {
-          // outputs in pairs (j, j + 1): ONE row swap leaves the lower half-wave with both contraction halves of output
-          // j and the upper half-wave with both of output j + 1 (swap32(a, b): r0 = [a_lo | b_lo], r1 = [a_hi | b_hi]),
-          // so the sum over the 4 neuron groups (lane bits 2, 3) runs once per pair instead of once per output
+          // outputs in pairs (j, j + 1): lane kh = 0 collects both contraction halves of output j, lane kh = 1 both of
+          // output j + 1 (own term + the partner's other term through DPP row_ror:8), so the sum over the 4 neuron groups
+          // (the rows of the wave) runs once per pair instead of once per output
           static_assert(D % 2 == 0, "8-particle tiles pair the outputs");
 #pragma unroll
           for (int j = 0; j < D; j += 2) {
             const float p0 = h2[0] * w3[j][0] + h2[1] * w3[j][1];
             const float p1 = h2[0] * w3[j + 1][0] + h2[1] * w3[j + 1][1];
-            swap32(__float_as_uint(p0), __float_as_uint(p1), r0h, r1h);
-            float pj = __uint_as_float(r0h) + __uint_as_float(r1h);   // kh = 0: output j, kh = 1: output j + 1
-            pj += xor8(pj);
-            pj += ror4(pj);
+            float pj = (kh ? p1 : p0) + xor8(kh ? p0 : p1);   // kh = 0: output j, kh = 1: output j + 1
+            pj = group_sum(pj);
             if (ng == 0) {   // both twin columns
               part[(buf * 16 + c) * PT + wv * D + j + kh] = pj;
               part[(buf * 16 + c + 8) * PT + wv * D + j + kh] = pj;
@@ -567,7 +558,8 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
       } else if constexpr (r_tgt) {
         // second pass only: its SIMD partner (an MLP wave) blocks the VALU during the 16 fp32 MFMAs
         float gp[D], lp = 0.f;
-        Target<TARGET, D>::template pass2<LPT>(z, sub8, lds_tgt, tst, lp, gp);
+        if constexpr (r_tgtf) Target<TARGET, D>::template pass2f<LPT>(z, sub8, tmeans, tst, lp, gp);
+        else Target<TARGET, D>::template pass2<LPT>(z, sub8, lds_tgt, tst, lp, gp);
         if (sub8 < (HALF ? 2 : 1)) {   // HALF: lane sub 1 (same totals) fills the twin column
           const int col = c + 8 * sub8;
           const float cA = sd[1], cB = sd[2];   // eps_i beta_i, eps_i (1 - beta_i): the row phase C(i) uses
@@ -616,15 +608,24 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
       // ------------------------------------------------------------------ phase C: MLP, TGT (own copies of z) and
       // ACC (with the log-weight); ~45 instructions each, so the redundancy is cheaper than an LDS hand-over
       if constexpr (r_acc) {
-        phase_c(i, true, sc, sd);            // i = K: closes step K-1 and picks up log p(z_K)
+        phase_c(i, true, sc, sd, buf_tag);            // i = K: closes step K-1 and picks up log p(z_K)
       } else if constexpr (r_mlp || r_tgt) {
-        if (i < K) phase_c(i, false, sc, sd);
+        if (i < K) phase_c(i, false, sc, sd, buf_tag);
       }
       STAMP(4);
+    };
+    for (int i = 0; i <= K; i += 2) {
+      body(i, std::integral_constant<int, 0>{});
+      if (i + 1 <= K) body(i + 1, std::integral_constant<int, 1>{});
     }
   };
   if (is_mlp) role_loop(std::integral_constant<int, kMLP>{});
-  else if (is_tgt) role_loop(std::integral_constant<int, kTGT>{});
+  else if (is_tgt) {
+    if (Target<TARGET, D>::kHasFast && __builtin_amdgcn_readfirstlane((int)Target<TARGET, D>::is_fast(tmeans)))
+      role_loop(std::integral_constant<int, kTGTF>{});
+    else
+      role_loop(std::integral_constant<int, kTGT>{});
+  }
   else if (MERGE) role_loop(std::integral_constant<int, kRNGACC>{});
   else if (is_rng) role_loop(std::integral_constant<int, kRNG>{});
   else role_loop(std::integral_constant<int, kACC>{});

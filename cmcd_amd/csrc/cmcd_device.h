@@ -9,6 +9,7 @@
 namespace cmcd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr float kHalfLog2Pi = 0.91893853320467274178f;
 constexpr float kLog2Pi = 1.8378770664093453f;
@@ -229,6 +230,21 @@ __device__ __forceinline__ float part_max(float v) {
   if (LP == 16) v = fmaxf(v, ror4(v));
   return group_max(v);
 }
+// minimum of a NON-NEGATIVE float (a squared distance, possibly +inf) over the LP lanes of a particle, taken on the bit
+// patterns as unsigned integers: same order, same result as fminf (a NaN pattern is larger than +inf and is ignored the
+// same way), but no canonicalising v_max x, x in front of every step (llvm.minnum quiets its inputs: 3 instructions per
+// butterfly stage instead of 1) and the DPP moves fold into the v_min_u32.
+template <int LP>
+__device__ __forceinline__ float part_min_nonneg(float v) {
+  uint32_t u = __float_as_uint(v);
+  if (LP >= 8) u = min(u, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u, 0x128, 0xf, 0xf, false));
+  if (LP == 16) u = min(u, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u, 0x124, 0xf, 0xf, false));
+  uint32_t a, b;
+  swap32(u, u, a, b);
+  u = min(a, b);
+  swap16(u, u, a, b);
+  return __uint_as_float(min(a, b));
+}
 // sum over the 16 lanes of a row (the 16 particles of a tile, for a value held per particle), DPP only:
 // quad butterflies then row rotations by 4 and 8.  Every lane of the row receives the total.
 __device__ __forceinline__ float row_sum16(float v) {
@@ -306,12 +322,16 @@ struct Target<CMCD_TARGET_MANY_GMM, 2> {
   struct Means {
     float mx[10], my[10];
     bool fast;
+    float inv_s, c2, c0;   // the header, for pass1f / pass2f
   };
+  static constexpr bool kHasFast = true;
+  __device__ static __forceinline__ bool is_fast(const Means& m) { return m.fast; }
   template <int LP>
   __device__ static __forceinline__ void load_means(int sub, const float* tc, Means& m) {
     constexpr int kQ = (kFastMix + LP - 1) / LP;
     const float2* mu = reinterpret_cast<const float2*>(tc + kLdsHeader);
     m.fast = __float_as_int(tc[2]) == kFastMix;
+    m.inv_s = tc[0]; m.c2 = tc[1]; m.c0 = tc[3];
 #pragma unroll
     for (int q = 0; q < kQ; ++q) {
       const float2 mk = (m.fast && sub + LP * q < kFastMix) ? mu[sub + LP * q] : float2{0.f, 0.f};
@@ -334,6 +354,48 @@ struct Target<CMCD_TARGET_MANY_GMM, 2> {
       dmin = fminf(dmin, st.d2[q]);
     }
     st.dmin = dmin;
+  }
+  // The cooperative kernel's target waves when n_mixes == 40 (decided once per launch): no per-bridge read of the
+  // header, no mixture-size branches; the same arithmetic as pass1r / pass2 (min over non-negative distances taken on
+  // the bit patterns: identical value).
+  template <int LP>
+  __device__ static __forceinline__ void pass1f(const float (&z)[2], int sub, const Means& m, State& st) {
+    constexpr int kQ = (kFastMix + LP - 1) / LP;
+    constexpr bool kRagged = kFastMix % LP != 0;
+    float dmin = INFINITY;
+#pragma unroll
+    for (int q = 0; q < kQ; ++q) {
+      st.dx[q] = z[0] - m.mx[q];
+      st.dy[q] = z[1] - m.my[q];
+      const float d2 = fmaf(st.dx[q], st.dx[q], st.dy[q] * st.dy[q]);
+      st.d2[q] = (!kRagged || sub + LP * q < kFastMix) ? d2 : INFINITY;
+      dmin = q == 0 ? st.d2[q] : fminf(dmin, st.d2[q]);
+    }
+    st.dmin = dmin;
+  }
+  template <int LP>
+  __device__ static __forceinline__ void pass2f(const float (&z)[2], int sub, const Means& m, const State& st,
+                                                float& logp, float (&grad)[2]) {
+    constexpr int kQ = (kFastMix + LP - 1) / LP;
+    const float inv_s = m.inv_s, c2 = m.c2, c0 = m.c0;
+    const float dmin = part_min_nonneg<LP>(st.dmin);
+    float s = 0.f, sx = 0.f, sy = 0.f;
+#pragma unroll
+    for (int q = 0; q < kQ; ++q) {
+      const float e = __builtin_amdgcn_exp2f(c2 * (st.d2[q] - dmin));
+      s += e;
+      sx = fmaf(e, st.dx[q], sx);
+      sy = fmaf(e, st.dy[q], sy);
+    }
+    s = part_sum<LP>(s);
+    sx = part_sum<LP>(sx);
+    sy = part_sum<LP>(sy);
+    const float lp = 0.69314718055994530942f * (fmaf(c2, dmin, c0) + __builtin_amdgcn_logf(s));
+    const bool valid = lp > -1e4f;  // model_handler.py:279-280
+    const float sc = -(inv_s * inv_s) * __builtin_amdgcn_rcpf(s);
+    logp = valid ? lp : -INFINITY;
+    grad[0] = valid ? sx * sc : 0.f;
+    grad[1] = valid ? sy * sc : 0.f;
   }
   template <int LP>
   __device__ static __forceinline__ void pass2(const float (&z)[2], int sub, const float* tc, const State& st,
@@ -457,6 +519,12 @@ struct Target<CMCD_TARGET_GMM, 2> {
   struct Means {};
   template <int LP>
   __device__ static __forceinline__ void load_means(int, const float*, Means&) {}
+  static constexpr bool kHasFast = false;
+  __device__ static __forceinline__ bool is_fast(const Means&) { return false; }
+  template <int LP>
+  __device__ static __forceinline__ void pass1f(const float (&)[2], int, const Means&, State&) {}
+  template <int LP>
+  __device__ static __forceinline__ void pass2f(const float (&)[2], int, const Means&, const State&, float&, float (&)[2]) {}
   template <int LP>
   __device__ static __forceinline__ void pass1r(const float (&)[2], int, const float*, const Means&, State&) {}
   template <int LP>
@@ -535,6 +603,12 @@ struct Target<CMCD_TARGET_FUNNEL, D> {
   struct Means {};
   template <int LP>
   __device__ static __forceinline__ void load_means(int, const float*, Means&) {}
+  static constexpr bool kHasFast = false;
+  __device__ static __forceinline__ bool is_fast(const Means&) { return false; }
+  template <int LP>
+  __device__ static __forceinline__ void pass1f(const float (&)[D], int, const Means&, State&) {}
+  template <int LP>
+  __device__ static __forceinline__ void pass2f(const float (&)[D], int, const Means&, const State&, float&, float (&)[D]) {}
   template <int LP>
   __device__ static __forceinline__ void pass1r(const float (&)[D], int, const float*, const Means&, State&) {}
   template <int LP>

@@ -345,12 +345,13 @@ __device__ __forceinline__ void pack_weights_body(const PackArgs& a, int vblock,
     const int krow = 16 * t_in + (lane & 15), ncon = 16 * t_out + 4 * (lane >> 4) + r;
     a.ws[a.w.w2t + idx] = (krow < a.IN && ncon < a.IN) ? P[a.o_w2 + (int64_t)krow * a.IN + ncon] : 0.f;
   }
-  // w2q[(wv * HP/2 + s) * 64 + lane] = W2[s + (HP/2) kh][16 wv + 4 ng + i], lane = i + 4 ng + 16 pg + 32 kh: the A
-  // operand of v_mfma_f32_4x4x1 step s — block (ng, pg, kh) multiplies 4 output neurons by 4 particles for input
-  // s of contraction half kh (the particle group pg sees the same weights)
+  // w2q[(wv * HP/2 + s) * 64 + lane] = W2[s + (HP/2) kh][16 wv + 4 ng + i], lane = i + 4 pg + 8 kh + 16 ng: the A
+  // operand of v_mfma_f32_4x4x1 step s — block (pg, kh, ng) multiplies 4 output neurons by 4 particles for input
+  // s of contraction half kh (the particle group pg sees the same weights; ng = the row of the wave, so that the
+  // activations can be broadcast from one row to all four by the instruction's B lane-group pattern)
   for (int64_t idx = tid; has_net && idx < 2 * (int64_t)HP * HP; idx += stride) {
     const int lane = idx & 63, rest = int(idx >> 6), sq = rest % (HP / 2), wvq = rest / (HP / 2);
-    const int kin = sq + (HP / 2) * (lane >> 5), nout = 16 * wvq + 4 * ((lane >> 2) & 3) + (lane & 3);
+    const int kin = sq + (HP / 2) * ((lane >> 3) & 1), nout = 16 * wvq + 4 * (lane >> 4) + (lane & 3);
     a.ws[a.w.w2q + idx] = (kin < a.IN && nout < a.IN) ? P[a.o_w2 + (int64_t)kin * a.IN + nout] : 0.f;
   }
   for (int64_t idx = tid; has_net && idx < (int64_t)a.D * HP; idx += stride) {
