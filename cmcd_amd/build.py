@@ -1,36 +1,75 @@
-"""Builds libcmcd_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Builds libcmcd_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+Each source is compiled to its own object (in parallel) and the objects are linked: per-file flags are possible and a
+rebuild after touching one kernel takes that file's compile time, not the sum."""
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libcmcd_hip.so")
 SOURCES = ["cmcd_kernels.hip", "cmcd_coop.hip", "cmcd_lgcp.hip", "cmcd_grad.hip", "cmcd_mfvi.hip", "cmcd_opt.hip"]
 HEADERS = ["cmcd_device.h", os.path.join(ROOT, "include", "cmcd_hip.h")]
+# Per-file flags.  cmcd_kernels.hip holds the wave-per-tile trajectory kernel, which is VALU-issue bound at 4 waves per
+# SIMD: there a packed fp32 instruction holds the pipe ~1.8x as long as a plain one and the SLP vectoriser pays v_mov
+# shuffles to form its operands (ISA reading r02: 126 v_pk_* + 4 v_mov per pair of mixture components), so it is off
+# for that file.  The cooperative kernel is issue-bound per wave (one instruction per ~5 cycles whatever it is) and
+# keeps the packed forms.
+EXTRA_FLAGS = {"cmcd_kernels.hip": ["-fno-slp-vectorize"]}
 
 
-def _stale():
-    if not os.path.exists(LIB):
+def _deps():
+    deps = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    deps.append(os.path.abspath(__file__))
+    return deps
+
+
+def _obj(src):
+    return os.path.join(OBJ, src.replace(".hip", ".o"))
+
+
+def _stale_obj(src):
+    o = _obj(src)
+    if not os.path.exists(o):
         return True
+    t = os.path.getmtime(o)
+    return any(os.path.getmtime(d) > t for d in _deps() + [os.path.join(CSRC, src)])
+
+
+def _lib_current():
+    if not os.path.exists(LIB):
+        return False
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
-    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return not any(os.path.getmtime(d) > t for d in _deps() + [os.path.join(CSRC, s) for s in SOURCES])
 
 
 def build(force=False, verbose=False):
-    if not force and not _stale():
-        return LIB
+    if not force and _lib_current():
+        return LIB          # (the objects need not exist: the GPU box receives the library, not build/)
+    os.makedirs(OBJ, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-           "-Wno-format-security", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+              "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-Wno-format-security"]
+    todo = [s for s in SOURCES if force or _stale_obj(s)]
+
+    def compile_one(src):
+        cmd = common + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", _obj(src)]
+        if verbose:
+            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+
+    if todo:
+        with ThreadPoolExecutor(max_workers=min(len(todo), int(os.environ.get("CMCD_BUILD_JOBS", "6")))) as ex:
+            list(ex.map(compile_one, todo))
+    objs = [_obj(s) for s in SOURCES]
+    if todo or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, check=True)
     return LIB
 
 

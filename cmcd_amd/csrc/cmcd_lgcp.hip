@@ -425,7 +425,7 @@ __device__ __forceinline__ void lgcp_step_tile(const StepEpi& a, const float* sn
 
 // out[ks][m][n] = sum_{k in slice ks, wave w} A[m][k] W[k][n]   (no bias: added when the slabs are summed)
 template <int EPI>
-__global__ __launch_bounds__(64 * (kGemmWaves + ((EPI == EPI_STEP || EPI == EPI_STEP_NONET) ? 1 : 0))) void lgcp_gemm_kernel(GemmArgs a) {
+__global__ __launch_bounds__(64 * (kGemmWaves + ((EPI == EPI_STEP || EPI == EPI_STEP_NONET) ? 1 : 0)), (EPI == EPI_STEP || EPI == EPI_STEP_NONET) ? 1 : 4) void lgcp_gemm_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ int s_last;
   const int s = blockIdx.x < a.nblk0 ? 0 : 1;
