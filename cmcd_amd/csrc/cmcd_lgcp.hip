@@ -914,22 +914,25 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
           hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_STEP_NONET>, dim3(cbD, kSplit), gblock_step, gemm_lds, st_l, gl);
           continue;
         }
-        // A: [x - mu0] Kinv -> kr slabs (summed by the state update two launches on)
-        //    x W1[:D] -> pre1 slabs -> u1 = [x; emb_i] + softplus(pre1 + bias1_i)            (fused consumer)
+        // A: x W1[:D] -> pre1 slabs -> u1 = [x; emb_i] + softplus(pre1 + bias1_i)            (fused consumer)
         gl.Kdim = D; gl.Kdim1 = 0;
-        gl.seg[0] = GemmSeg{ws + wl.x, kinv, ws + wl.kr, D, D, D, D, mu0};
-        gl.seg[1] = GemmSeg{ws + wl.x, params + lay.g_w1, ws + wl.slab1, IN, D, IN, IN};
-        gl.nblk0 = cbD; gl.epi_seg = 1;
+        gl.seg[0] = GemmSeg{ws + wl.x, params + lay.g_w1, ws + wl.slab1, IN, D, IN, IN};
+        gl.nblk0 = cbIN; gl.epi_seg = -1;
         gl.act.mode = 1; gl.act.bias = ws + w.bias1 + (int64_t)it * IN; gl.act.emb = params + lay.g_emb + (int64_t)ie * E;
         gl.act.sum_out = ws + wl.pre1; gl.act.u_prev = nullptr; gl.act.u_out = ws + wl.u1;
-        hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_ACT>, dim3(cbD + cbIN, kSplit), gblock, gemm_lds, st_l, gl);
-        // B: u1 W2 -> pre2 slabs -> u2 = u1 + softplus(pre2 + b2)
-        gl.Kdim = IN;
+        hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_ACT>, dim3(cbIN, kSplit), gblock, gemm_lds, st_l, gl);
+        // B: u1 W2 -> pre2 slabs -> u2 = u1 + softplus(pre2 + b2)                             (fused consumer)
+        //    [x - mu0] Kinv -> kr slabs (summed by the state update in launch C): this product needs only the state, so
+        //    it rides in the LIGHTEST launch of the three (r02: it used to double launch A's grid to 408 workgroups; the
+        //    GEMM kernel now fits two workgroups per CU, so B's 408 run side by side: A 15 -> ~10 us, B 9 -> ~11 us)
+        gl.Kdim = IN; gl.Kdim1 = D;
         gl.seg[0] = GemmSeg{ws + wl.u1, params + lay.g_w2, ws + wl.slab2, IN, IN, IN, IN};
-        gl.nblk0 = cbIN; gl.epi_seg = -1;
+        gl.seg[1] = GemmSeg{ws + wl.x, kinv, ws + wl.kr, D, D, D, D, mu0};
+        gl.nblk0 = cbIN; gl.epi_seg = 0;
         gl.act.mode = 2; gl.act.bias = params + lay.g_b2; gl.act.sum_out = ws + wl.pre2; gl.act.u_prev = ws + wl.u1;
         gl.act.u_out = ws + wl.u2;
-        hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_ACT>, dim3(cbIN, kSplit), gblock, gemm_lds, st_l, gl);
+        hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_ACT>, dim3(cbIN + cbD, kSplit), gblock, gemm_lds, st_l, gl);
+        gl.Kdim1 = 0;
         // C: u2 W3 -> sn slabs -> state update of evaluation i on the block's columns
         gl.seg[0] = GemmSeg{ws + wl.u2, params + lay.g_w3, ws + wl.sn, D, IN, D, D};
         gl.nblk0 = cbD;
