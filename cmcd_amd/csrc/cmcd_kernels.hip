@@ -637,7 +637,7 @@ __global__ __launch_bounds__(512, (T > 4 || D > 4) ? 2 : 4) void traj_kernel(Tra
   // forward kernel, :52-67) — the reference evaluates both twice.
   float zp[D];           // z_{i-1}
   float fk_lp = 0.f;     // log F_{i-1}(z_i | z_{i-1})
-  float pbeta = 0.f, peps = 0.f, pinv2s2 = 0.f, plogsig = 0.f;
+  float pbeta = 0.f, peps = 0.f, pinv2s2 = 0.f, pcst = 0.f;
   float logp = 0.f;
 #pragma unroll
   for (int j = 0; j < D; ++j) zp[j] = 0.f;
@@ -676,15 +676,16 @@ __global__ __launch_bounds__(512, (T > 4 || D > 4) ? 2 : 4) void traj_kernel(Tra
         const float ub = -1.0f * (pbeta * gp[j] + (1.0f - pbeta) * gq[j]);
         const float bk = z[j] - peps * ub + peps * sn[j];
         const float db = zp[j] - bk;
-        bk_lp += -(db * db) * pinv2s2 - plogsig - kHalfLog2Pi;  // log_prob_kernel, mcd_utils.py:19-21
+        bk_lp += -(db * db) * pinv2s2 - pcst;  // log_prob_kernel, mcd_utils.py:19-21 (pcst = log sigma + log sqrt(2 pi))
       }
       w += bk_lp - fk_lp;
     }
     if (i == K) break;
 
-    const float beta = a.ws[a.w.beta + i], eps = a.ws[a.w.eps + i];
-    const float sig = a.ws[a.w.sig + i], logsig = a.ws[a.w.logsig + i];
-    const float inv2s2 = 1.0f / (2.0f * sig * sig);
+    // the packed schedule row {beta, eps, sigma, log sigma + log sqrt(2 pi), 1 / (2 sigma^2), ...} of the prep launch
+    // (one scalar load; the division — ~10 VALU instructions per bridge on every lane — is done there once)
+    const float* scr = a.ws + a.w.sched + 8 * (int64_t)i;
+    const float beta = scr[0], eps = scr[1], sig = scr[2], cst = scr[3], inv2s2 = scr[4];
 
     // ---- noise: (G, H) = split(gen); eps_i = normal(G, (D,)); gen = second(split(H))
     //      mcd_cais.py:66-67,87
@@ -720,15 +721,29 @@ __global__ __launch_bounds__(512, (T > 4 || D > 4) ? 2 : 4) void traj_kernel(Tra
           a.dbg_noise[o + Hh + jn] = bits_to_normal(y1);
         }
       }
-      uint32_t r0[4], r1[4];
-      rows0123(__float_as_uint((CMCD_TRAJ_ABL & 8) ? __uint_as_float(y0) * 1e-9f : bits_to_normal(y0)), r0);
-      rows0123(__float_as_uint((CMCD_TRAJ_ABL & 8) ? __uint_as_float(y1) * 1e-9f : bits_to_normal(y1)), r1);
+      if (D == 2 && !(CMCD_TRAJ_ABL & 8)) {
+        // d = 2: the one normal block sits on row 2 with both words.  Word 1 moves to row 3 (one row swap), so that ONE
+        // bits -> deviate conversion serves both words (row 2 converts word 0, row 3 word 1; rows 0, 1 convert the split
+        // blocks' words, ignored) and one broadcast of the rows delivers them: a conversion (~18 instructions) and
+        // three row swaps less per evaluation than converting y0 and y1 on every row (r02).
+        uint32_t t0, t1;
+        swap16(y1, y1, t0, t1);                        // t0 = rows [y1(0) y1(0) y1(2) y1(2)]
+        const float dev = bits_to_normal(g == 3 ? t0 : y0);
+        uint32_t rr[4];
+        rows0123(__float_as_uint(dev), rr);
+        nz[0] = __uint_as_float(rr[2]);
+        nz[1] = __uint_as_float(rr[3]);
+      } else {
+        uint32_t r0[4], r1[4];
+        rows0123(__float_as_uint((CMCD_TRAJ_ABL & 8) ? __uint_as_float(y0) * 1e-9f : bits_to_normal(y0)), r0);
+        rows0123(__float_as_uint((CMCD_TRAJ_ABL & 8) ? __uint_as_float(y1) * 1e-9f : bits_to_normal(y1)), r1);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int jj = b0 + q - 2;
-        if (jj >= 0 && jj < Hh) {
-          nz[jj] = __uint_as_float(r0[q]);
-          nz[Hh + jj] = __uint_as_float(r1[q]);
+        for (int q = 0; q < 4; ++q) {
+          const int jj = b0 + q - 2;
+          if (jj >= 0 && jj < Hh) {
+            nz[jj] = __uint_as_float(r0[q]);
+            nz[Hh + jj] = __uint_as_float(r1[q]);
+          }
         }
       }
     }
@@ -741,7 +756,7 @@ __global__ __launch_bounds__(512, (T > 4 || D > 4) ? 2 : 4) void traj_kernel(Tra
       const float fk = z[j] - eps * uf - eps * (fsn * sn[j]);
       const float zn = fk + sig * nz[j];
       const float df = zn - fk;
-      fk_lp += -(df * df) * inv2s2 - logsig - kHalfLog2Pi;
+      fk_lp += -(df * df) * inv2s2 - cst;
       zp[j] = z[j];
       z[j] = zn;
     }
@@ -749,7 +764,7 @@ __global__ __launch_bounds__(512, (T > 4 || D > 4) ? 2 : 4) void traj_kernel(Tra
 #pragma unroll
       for (int j = 0; j < D; ++j) a.traj[((int64_t)(i + 1) * a.n + p) * D + j] = z[j];
     }
-    pbeta = beta; peps = eps; pinv2s2 = inv2s2; plogsig = logsig;
+    pbeta = beta; peps = eps; pinv2s2 = inv2s2; pcst = cst;
   }
   w += logp;  // + log p(z_K)   mcdboundingmachine.py:178
   const float loss = -w;
