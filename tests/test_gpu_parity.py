@@ -19,6 +19,8 @@ CASES = [
     ("many_gmm_var_n16000_k256", 128, dict(nbridges=64)),
     ("many_gmm_n2000_k256_dds", 64, dict(nbridges=8, eps_schedule="linear", init_eps=0.05)),
     ("gmm_n300_k8", 1, {}),                                       # a single particle
+    ("many_gmm_n2000_k256_dds", 9, dict(nbridges=4)),             # one 8-particle tile + 1 (twin-column tiling, r02 lane order)
+    ("many_gmm_var_n16000_k256", 2041, dict(nbridges=4)),         # the 132-wide net at the top of the 8-particle range, ragged
 ]
 
 
