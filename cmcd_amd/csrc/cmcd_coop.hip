@@ -24,6 +24,7 @@
 //   phase C(i):  every wave that keeps a z (MLP, TGT, ACC) reads the same exchange rows and forms
 //                s = clip(b3 + sum of partials), fk = base - eps s, z_{i+1} = fk + sigma eps_i — identical bits in
 //                every copy; ACC also closes step i-1 into the log-weight (mcd_cais.py:71-86).
+// Every role runs its OWN instantiation of the bridge loop (role_loop below) with this same barrier sequence.
 // The per-bridge schedule row arrives as a scalar load requested at the top of the iteration.
 // Same arithmetic as traj_kernel (cmcd_kernels.hip) up to the association of the forward mean; reference lines are
 // cited there.
@@ -65,13 +66,14 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// HALF: 8 particles per tile.  The tile keeps its 16 columns, columns c and c + 8 carry the SAME particle (same
-// seed, so every wave computes identical values in both), and the MLP waves split the element-wise work of a
-// particle's 4 neurons per lane between the two columns: lane (g, c < 8) owns neurons 4g + {0, 1}, lane (g, c + 8)
-// neurons 4g + {2, 3} — half the first-layer FMAs, half the activations (2 instead of 4 per layer and lane), half
-// the layer-3 products; both halves are written to both columns of the MFMA B operand, the layer-3 partial is
-// completed by one DPP row_ror:8 add.  A batch of <= 2048 particles then runs on twice the CUs (N = 2000: 250
-// workgroups instead of 125 on 256 CUs) with a shorter per-bridge chain on each.
+// HALF: 8 particles per tile.  The exchange rows keep 16 columns, columns c and c + 8 carry the SAME particle (same
+// seed, so the RNG / ACC / TGT waves compute identical values in both), and the MLP waves give every particle 8 lanes
+// instead of 4: lane (qi, pg, kh, ng) = particle 4 pg + qi, neurons 4 ng + 2 kh + {0, 1} of the wave's 16 — half the
+// first-layer FMAs, half the activations (2 instead of 4 per layer and lane), half the layer-3 products, and layer 2 on
+// the 4x4x1 matrix instruction (16 blocks of 4 neurons x 4 particles: no column wasted) with the activations broadcast
+// across the neuron groups by the instruction itself (described at the lane mapping below).  A batch of <= 2048
+// particles then runs on twice the CUs (N = 2000: 250 workgroups instead of 125 on 256 CUs) with a shorter per-bridge
+// chain on each.
 // MERGE: the RNG and ACC roles share one wave (T + 3 waves per workgroup).  Used by the 9-tile (132-wide net) instance
 // on 8-particle tiles: twelve waves are three per SIMD = 168 registers each, which the 72 resident 4x4x1 operands of
 // an MLP wave need; and with 72 matrix instructions per MLP wave and bridge the key chain is no longer the long pole.
