@@ -212,6 +212,10 @@ def time_leg(leg, steps, warmup, use_dist, device, world, sharded=True, spinup=0
         drain()
     barrier()
     _lib.profile_enable(True)
+    import gc
+    gc.collect()
+    gc_was = gc.isenabled()
+    gc.disable()          # a 20-step timed region is 4 ms: one collector pause on the launching thread would be 10 % of it
     t0 = time.perf_counter()
     for k in range(steps):
         losses, z, stats = step(k)
@@ -219,6 +223,8 @@ def time_leg(leg, steps, warmup, use_dist, device, world, sharded=True, spinup=0
         stats = drain()   # global statistics of the last step
     barrier()
     elapsed = time.perf_counter() - t0
+    if gc_was:
+        gc.enable()
     kern_ms, launches = _lib.profile_collect()
     _lib.profile_enable(False)
     if use_dist and sharded:
