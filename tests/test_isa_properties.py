@@ -1,0 +1,117 @@
+"""Code-generation properties of the hot kernels that the measured speed depends on ("second pass
+of round 2"), checked on the gfx950 ISA that hipcc emits — no GPU needed.  Each assertion names a regression that was
+worth several percent when it was found by reading the ISA:
+
+* the cooperative kernel runs ONE LOOP PER ROLE (the roles as branches inside a shared loop body cost the MLP waves ~40
+  phi copies and ~35 scalar branches per bridge);
+* every 4x4x1 matrix instruction of the 8-particle instance takes its B operand by row broadcast (`blgp:4..7`), i.e.
+  the layer-2 activations are fetched once per 16-lane row;
+* the per-bridge schedule row is the hand-issued `s_load` (not a compiler-scheduled load with its own wait);
+* the headline instance does not spill;
+* the wave-per-tile kernel keeps the erfinv tail inside a branch (the compiler flattens it back into straight-line
+  code unless its input passes through a volatile statement) and is built without the SLP vectoriser.
+"""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "cmcd_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+
+
+def _asm(tmp_path_factory, src, extra=()):
+    out = tmp_path_factory.mktemp("isa") / (src + ".s")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+           "--cuda-device-only", "-S", "-o", str(out), os.path.join(CSRC, src), *extra]
+    subprocess.run(cmd, check=True, capture_output=True)
+    return out.read_text().split("\n")
+
+
+def _kernel(lines, mangled_prefix):
+    start = next(i for i, l in enumerate(lines) if l.startswith(mangled_prefix) and l.rstrip().endswith(":") or
+                 (l.startswith(mangled_prefix) and ": " in l and "; @" in l))
+    end = next(i for i in range(start + 1, len(lines)) if lines[i].strip() == "s_endpgm")
+    tail = next(i for i in range(end, len(lines)) if lines[i].startswith("; ScratchSize:") or "ScratchSize" in lines[i])
+    return lines[start:end + 1], lines[end:tail + 1]
+
+
+@pytest.fixture(scope="module")
+def coop_asm(tmp_path_factory):
+    return _asm(tmp_path_factory, "cmcd_coop.hip")
+
+
+@pytest.fixture(scope="module")
+def traj_asm(tmp_path_factory):
+    from cmcd_amd import build
+    return _asm(tmp_path_factory, "cmcd_kernels.hip", build.EXTRA_FLAGS.get("cmcd_kernels.hip", []))
+
+
+# many_gmm (2), dds (1), D = 2, T = 4, 8-particle tiles, separate RNG / ACC waves: the kernel the named batch runs
+HEADLINE = "_ZN4cmcd11coop_kernelILi2ELi1ELi2ELi4ELb1ELb0EEEvNS_8TrajArgsE"
+
+
+def test_headline_kernel_has_one_bridge_loop_per_role(coop_asm):
+    body, _ = _kernel(coop_asm, HEADLINE)
+    # top-level loops that contain a workgroup barrier = bridge loops; roles: MLP, TGT (two flavours), RNG, ACC
+    loops, cur = [], None
+    for l in body:
+        if "Loop Header: Depth=1" in l:
+            cur = {"barriers": 0}
+            loops.append(cur)
+        elif cur is not None and l.strip() == "s_barrier":
+            cur["barriers"] += 1
+    bridge_loops = [lp for lp in loops if lp["barriers"] >= 2]
+    assert len(bridge_loops) >= 5, f"expected one bridge loop per role, found {len(bridge_loops)}"
+
+
+def test_headline_kernel_broadcasts_the_layer2_operand(coop_asm):
+    body, _ = _kernel(coop_asm, HEADLINE)
+    mfma = [l for l in body if "v_mfma_f32_4x4x1_16b_f32" in l]
+    assert len(mfma) >= 64          # 32 per bridge, two loop-body instantiations (even / odd evaluation)
+    assert all(re.search(r"blgp:[4-7]", l) for l in mfma), "a 4x4x1 matrix instruction without the row broadcast"
+    # per bridge body: the chain is fed by two 16-byte LDS reads per lane (it was eight)
+    idx = [i for i, l in enumerate(body) if "v_mfma_f32_4x4x1_16b_f32" in l]
+    first = idx[0]
+    window = body[max(0, first - 12):first]
+    assert sum("ds_read_b128" in l for l in window) == 2, window
+
+
+def test_headline_kernel_schedule_row_is_the_hand_issued_scalar_load(coop_asm):
+    body, _ = _kernel(coop_asm, HEADLINE)
+    hand = 0
+    for i, l in enumerate(body):
+        if "#ASMSTART" in l and "s_load_dwordx4" in body[i + 1] and "s_load_dwordx4" in body[i + 2]:
+            hand += 1
+    assert hand >= 4, "the per-bridge schedule row should be requested by inline asm in every role loop that reads it"
+
+
+def test_headline_kernel_does_not_spill(coop_asm):
+    _, meta = _kernel(coop_asm, HEADLINE)
+    scratch = next(l for l in meta if "ScratchSize" in l)
+    assert re.search(r"ScratchSize:\s*0\b", scratch), scratch
+
+
+def test_wave_per_tile_kernel_keeps_the_erfinv_tail_in_a_branch(traj_asm):
+    body, _ = _kernel(traj_asm, "_ZN4cmcd11traj_kernelILi2ELi1ELi2ELi4EEEvNS_8TrajArgsE")
+    marks = [i for i, l in enumerate(body) if "; erfinv tail" in l]
+    assert marks, "marker of the tail branch not found"
+    for i in marks:
+        # the IEEE square root of the tail must come AFTER the marker (inside the branch), not be hoisted above it
+        after = body[i:i + 12]
+        assert any("v_sqrt_f32" in l for l in after), "the tail's square root was hoisted out of its branch"
+    loop_start = max(i for i, l in enumerate(body) if "Loop Header: Depth=1" in l)
+    in_loop = body[loop_start:]
+    sqrt_in_loop = sum("v_sqrt_f32" in l for l in in_loop)
+    tails_in_loop = sum("; erfinv tail" in l for l in in_loop)
+    assert sqrt_in_loop == tails_in_loop, "a square root outside a tail branch in the bridge loop"
+
+
+def test_wave_per_tile_kernel_is_built_without_slp(traj_asm):
+    body, _ = _kernel(traj_asm, "_ZN4cmcd11traj_kernelILi2ELi1ELi2ELi4EEEvNS_8TrajArgsE")
+    packed = sum(1 for l in body if re.match(r"\s*v_pk_(fma|mul|add)_f32", l))
+    assert packed <= 40, f"{packed} packed fp32 instructions: is -fno-slp-vectorize still applied to cmcd_kernels.hip?"
