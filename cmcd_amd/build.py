@@ -12,14 +12,16 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libcmcd_hip.so")
-SOURCES = ["cmcd_kernels.hip", "cmcd_coop.hip", "cmcd_lgcp.hip", "cmcd_grad.hip", "cmcd_mfvi.hip", "cmcd_opt.hip"]
+SOURCES = ["cmcd_kernels.hip", "cmcd_coop.hip", "cmcd_lgcp.hip", "cmcd_grad.hip", "cmcd_bptt.hip", "cmcd_mfvi.hip", "cmcd_opt.hip"]
 HEADERS = ["cmcd_device.h", os.path.join(ROOT, "include", "cmcd_hip.h")]
 # Per-file flags.  cmcd_kernels.hip holds the wave-per-tile trajectory kernel, which is VALU-issue bound at 4 waves per
 # SIMD: there a packed fp32 instruction holds the pipe ~1.8x as long as a plain one and the SLP vectoriser pays v_mov
 # shuffles to form its operands (ISA reading r02: 126 v_pk_* + 4 v_mov per pair of mixture components), so it is off
 # for that file.  The cooperative kernel is issue-bound per wave (one instruction per ~5 cycles whatever it is) and
 # keeps the packed forms.
-EXTRA_FLAGS = {"cmcd_kernels.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"cmcd_kernels.hip": ["-fno-slp-vectorize"],
+               # Jacobian / scan kernels of the work-item reparameterised gradient: -11 % / -5 % without SLP (cmcd_bptt.hip)
+               "cmcd_bptt.hip": ["-fno-slp-vectorize"]}
 
 
 def _deps():
