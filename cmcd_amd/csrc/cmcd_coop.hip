@@ -93,6 +93,15 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
   float* nzb = gpb + 2 * 16 * GP;            // [2][16][NZ]    Gaussian noise
   uint32_t* raw = reinterpret_cast<uint32_t*>(nzb + 2 * 16 * NZ);  // [2][16][NZ] raw bits
   float* lds_tgt = reinterpret_cast<float*>(raw + 2 * 16 * NZ);
+  // PUBZ (d > 4: the funnel): phase C costs ~2 exchange rows per dimension and wave — at d = 10 eighteen LDS reads per
+  // lane on each of seven waves, ~1000 cycles of LDS pipe behind barrier 2.  There only the ACC wave forms z_{i+1}; it
+  // publishes the state and every other wave picks it up behind a third barrier (three 16-byte reads instead of 18):
+  // funnel, N = 300, K = 64: 0.1021 -> 0.0952 ms, bitwise identical.  (Splitting the publication over the ACC wave's four
+  // rows in front of its full update made it 0.1115 ms: the full update then runs into barrier 1, where this wave has
+  // no slack.)
+  constexpr bool PUBZ = D > 4;
+  constexpr int DP = (D + 3) & ~3;
+  float* const zpub = lds_tgt + a.w.tgt_floats;   // [16][DP], PUBZ only
 
   // Role = hardware wave index: waves go to SIMD (index % 4), so every SIMD holds one MLP wave and one auxiliary wave.
   // Measured alternative (profiles/r01_r_simd_map.txt): MLP waves paired on SIMDs 0 / 1 and the auxiliary waves on 2 / 3
@@ -360,6 +369,26 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
       }
     }
     STAMP(9);   // exchange rows + schedule row read and combined
+    // the new state first (PUBZ: published to the other waves before the log-weight bookkeeping of this wave)
+    const float seps = a.ula ? 0.f : -eps;
+    float fkv[D], znv[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      fkv[j] = fmaf(seps, sn[j], base[j]);
+      znv[j] = fmaf(sig, nz[j], fkv[j]);
+    }
+    if (PUBZ && track_w) {
+      if (e < K && g == 0) {
+#pragma unroll
+        for (int q = 0; q < DP; q += 4) {
+          f32x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = (q + r < D) ? znv[(q + r < D) ? q + r : 0] : 0.f;
+          *reinterpret_cast<f32x4*>(zpub + c * DP + q) = v;
+        }
+      }
+      lds_barrier();   // barrier 3 (every wave, every evaluation)
+    }
     if (track_w && e > 0) {  // backward kernel of step e-1: bk = z - eps ub + eps s, ub = -(beta gp + (1-beta) gq)
       float bk_lp = 0.f;
 #pragma unroll
@@ -372,17 +401,14 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
     }
     if (e == K) return;
     fk_lp = 0.f;
-    const float seps = a.ula ? 0.f : -eps;
 #pragma unroll
     for (int j = 0; j < D; ++j) {
-      const float fk = fmaf(seps, sn[j], base[j]);
-      const float zn = fmaf(sig, nz[j], fk);
       if (track_w) {
-        const float df = zn - fk;
+        const float df = znv[j] - fkv[j];
         fk_lp += -(df * df) * inv2s2 - cst;
         zp[j] = z[j];
       }
-      z[j] = zn;
+      z[j] = znv[j];
     }
     if (track_w && a.traj && valid && own && g == 0) {
 #pragma unroll
@@ -610,7 +636,20 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
       // ------------------------------------------------------------------ phase C: MLP, TGT (own copies of z) and
       // ACC (with the log-weight); ~45 instructions each, so the redundancy is cheaper than an LDS hand-over
       if constexpr (r_acc) {
-        phase_c(i, true, sc, sd, buf_tag);            // i = K: closes step K-1 and picks up log p(z_K)
+        phase_c(i, true, sc, sd, buf_tag);            // i = K: closes step K-1 and picks up log p(z_K); PUBZ: barrier 3 inside
+      } else if constexpr (PUBZ) {
+        lds_barrier();                                // barrier 3: z_{i+1} published by the ACC wave
+        if constexpr (r_mlp || r_tgt) {
+          if (i < K) {
+#pragma unroll
+            for (int q = 0; q < DP; q += 4) {
+              const f32x4 v = *reinterpret_cast<const f32x4*>(zpub + c * DP + q);
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (q + r < D) z[q + r] = v[r];
+            }
+          }
+        }
       } else if constexpr (r_mlp || r_tgt) {
         if (i < K) phase_c(i, false, sc, sd, buf_tag);
       }
@@ -739,7 +778,8 @@ int coop_launch(const cmcd_desc& d, const TrajArgs& ta_in, bool half, void* stre
   coop_fn fn = inst.fn;
   if (!fn) return CMCD_ERR_UNSUPPORTED;
   ta.prio = g_coop_prio >= 0 ? g_coop_prio : default_prio(d, half, inst.waves);
-  const size_t lds_bytes = size_t(16 * T * 16 + 2 * 16 * PT + 2 * 16 * GP + 2 * 16 * NZ + 2 * 16 * NZ + ta.w.tgt_floats) * 4;
+  const size_t lds_bytes = size_t(16 * T * 16 + 2 * 16 * PT + 2 * 16 * GP + 2 * 16 * NZ + 2 * 16 * NZ + ta.w.tgt_floats +
+                                 (D > 4 ? 16 * ((D + 3) & ~3) : 0)) * 4;   // + the published state (d > 4)
   const unsigned tiles = half ? unsigned((ta.n + 7) / 8) : (unsigned)ta.w.n_waves;
   // While there are no more workgroups than CUs, claim more than half of a CU's 160 KB of LDS: the dispatcher can
   // then never put two workgroups on one CU while another CU sits idle (two on a CU share its SIMDs and the
