@@ -4,8 +4,12 @@ tools/make_notebook_tables.py with the .ipynb line of every value).
 
 The reference's replicate command lines (/root/reference/README.md:53,73) are run flag for flag through
 cmcd_amd.main — HIP forward, reparameterised HIP gradient, fused Adam, 30 x n_samples evaluation — with three training
-seeds each; the seed-mean must agree with the stored value within max(3 sigma_notebook, 3 sigma_seeds), where
-sigma_notebook is the notebook's own spread over its 30 evaluation groups.  Not a bitwise pin (the initial weights and
+seeds each.  The stored value is ONE trained model of the reference (sigma_notebook = the spread of its 30 evaluation
+groups), so the difference between it and the mean of n training seeds of this build has variance
+sigma_notebook^2 + sigma_train^2 (1 + 1 / n); the test holds it to 3 of those sigmas, with sigma_train = the sample sigma
+of the n runs, floored for gmm by this build's measured 10-seed spread (the gmm runs are bimodal over training seeds:
+three seeds that share a mode have a sample sigma three times too small; tests/golden/reference_notebook_tables.json
+`train_seed_spread`, profiles/r02_gmm_training_seed_spread.txt).  Not a bitwise pin (the initial weights and
 the per-iteration particle seeds come from torch generators, not from jax's), but a wrong score network, schedule,
 target or gradient moves these numbers by many sigmas (the untrained bound is ELBO ~ -2.3 on funnel K = 8)."""
 import json
@@ -48,8 +52,12 @@ def test_trained_bound_reproduces_the_reference_notebook_table(hip_lib, model, k
     print(f"{model} K={k}: ELBO {mean[0]:.4f} +- {std[0]:.4f} (reference {ref['elbo']:.4f} +- {ref['elbo_std']:.4f}, "
           f"ipynb:{ref['cite']}), ln Z {mean[1]:.4f} +- {std[1]:.4f} (reference {ref['ln_Z']:.4f} +- {ref['ln_Z_std']:.4f}); "
           f"per seed {runs.tolist()}")
-    assert abs(mean[0] - ref["elbo"]) <= max(3 * ref["elbo_std"], 3 * std[0]), (mean[0], ref["elbo"])
-    assert abs(mean[1] - ref["ln_Z"]) <= max(3 * ref["ln_Z_std"], 3 * std[1]), (mean[1], ref["ln_Z"])
+    prior = TABLES[model].get("train_seed_spread", {})
+    n = len(SEEDS)
+    for q, key in ((0, "elbo"), (1, "ln_Z")):
+        s_train = max(std[q], prior.get(key + "_std", 0.0))
+        tol = 3.0 * np.sqrt(ref[key + "_std"] ** 2 + s_train ** 2 * (1.0 + 1.0 / n))
+        assert abs(mean[q] - ref[key]) <= tol, (key, mean[q], ref[key], tol)
     # the targets are normalised (true ln Z = 0, Appendix A.6 of SURVEY.md) and the ELBO is a lower bound
     assert mean[0] < mean[1] + 0.02 and abs(mean[1]) < 0.5
 
