@@ -498,6 +498,12 @@ struct Target<CMCD_TARGET_MANY_GMM, 2> {
   }
 };
 
+// exp / log on the hardware transcendentals (v_exp_f32 / v_log_f32, 1 ulp): exp(x) = 2^(x log2 e), log(x) = ln 2 log2(x).
+// The gmm target evaluates ten exponentials and three logarithms per evaluation; with the library routines (range
+// reduction, ~8 - 10 instructions each) its two target waves were the long pole of that configuration's bridge.
+__device__ __forceinline__ float exp_fast(float x) { return __builtin_amdgcn_exp2f(1.44269504088896340736f * x); }
+__device__ __forceinline__ float log_fast(float x) { return 0.69314718055994530942f * __builtin_amdgcn_logf(x); }
+
 // gmm: /root/reference/src/model_handler.py:157-200 (3 components, symmetrised by flip).
 template <>
 struct Target<CMCD_TARGET_GMM, 2> {
@@ -519,9 +525,9 @@ struct Target<CMCD_TARGET_GMM, 2> {
     const float pc0 = pc00 * d0 + pc01 * d1, pc1 = pc01 * d0 + pc00 * d1;
     const float lc = fmaf(-0.5f, d0 * pc0 + d1 * pc1, lcc);
     const float m = fmaxf(la, fmaxf(lb, lc));
-    const float ea = expf(la - m), eb = expf(lb - m), ec = expf(lc - m);
+    const float ea = exp_fast(la - m), eb = exp_fast(lb - m), ec = exp_fast(lc - m);
     const float s = ea + eb + ec;
-    f = m + logf(s);
+    f = m + log_fast(s);
     const float is = -1.0f / s;
     gx = (ea * pa0 + eb * pb0 + ec * pc0) * is;
     gy = (ea * pa1 + eb * pb1 + ec * pc1) * is;
@@ -551,9 +557,9 @@ struct Target<CMCD_TARGET_GMM, 2> {
     raw(z[0], z[1], fa, gax, gay);
     raw(z[1], z[0], fb, gbx, gby);  // log_density(flip(x)), model_handler.py:192-195
     const float m = fmaxf(fa, fb);
-    const float lse = m + logf(expf(fa - m) + expf(fb - m));
+    const float lse = m + log_fast(exp_fast(fa - m) + exp_fast(fb - m));
     logp = lse - 0.69314718055994530942f;
-    const float wa = expf(fa - lse), wb = expf(fb - lse);
+    const float wa = exp_fast(fa - lse), wb = exp_fast(fb - lse);
     grad[0] = wa * gax + wb * gby;  // un-flip the second gradient
     grad[1] = wa * gay + wb * gbx;
   }
@@ -573,9 +579,9 @@ struct Target<CMCD_TARGET_GMM, 2> {
     const float pc0 = pc00 * d0 + pc01 * d1, pc1 = pc01 * d0 + pc00 * d1;
     const float lc = fmaf(-0.5f, d0 * pc0 + d1 * pc1, lcc);
     const float m = fmaxf(la, fmaxf(lb, lc));
-    const float ea = expf(la - m), eb = expf(lb - m), ec = expf(lc - m);
+    const float ea = exp_fast(la - m), eb = exp_fast(lb - m), ec = exp_fast(lc - m);
     const float s = ea + eb + ec;
-    f = m + logf(s);
+    f = m + log_fast(s);
     const float rs = 1.0f / s;
     const float ra = ea * rs, rb = eb * rs, rc = ec * rs;
     gx = -(ra * pa0 + rb * pb0 + rc * pc0);
@@ -591,9 +597,9 @@ struct Target<CMCD_TARGET_GMM, 2> {
     raw2(z[0], z[1], fa, gax, gay, Ma);
     raw2(z[1], z[0], fb, gbx, gby, Mb);
     const float m = fmaxf(fa, fb);
-    const float lse = m + logf(expf(fa - m) + expf(fb - m));
+    const float lse = m + log_fast(exp_fast(fa - m) + exp_fast(fb - m));
     logp = lse - 0.69314718055994530942f;
-    const float wa = expf(fa - lse), wb = expf(fb - lse);
+    const float wa = exp_fast(fa - lse), wb = exp_fast(fb - lse);
     grad[0] = wa * gax + wb * gby;
     grad[1] = wa * gay + wb * gbx;
     H[0] = wa * Ma[0] + wb * Mb[2] - grad[0] * grad[0];
