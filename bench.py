@@ -166,7 +166,12 @@ class Leg:
             return "lgcp launch sequence (skinny GEMMs + state kernels)"
         wide = self.spec.width >= 128
         tiles = (n + 15) // 16
-        coop = mcdbm.KERNEL_VARIANT in (2, 3, 4) or (mcdbm.KERNEL_VARIANT == 0 and tiles <= 512)
+        cfg = self.b["cfg"]
+        # the library's selection rule (cmcd_kernels.hip: coop_max_tiles)
+        lim = 512
+        if cfg["model"] == "many_gmm":
+            lim = 1536 if cfg["nn_arch"] == "dds" else (768 if wide else 512)
+        coop = mcdbm.KERNEL_VARIANT in (2, 3, 4) or (mcdbm.KERNEL_VARIANT == 0 and tiles <= lim)
         if not coop:
             return "traj_kernel"
         half = mcdbm.KERNEL_VARIANT == 4 or (mcdbm.KERNEL_VARIANT != 3 and n <= 2048)

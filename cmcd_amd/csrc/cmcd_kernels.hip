@@ -49,9 +49,16 @@ static thread_local NoiseCapture g_capture;
 // Tiles (16 particles each) up to which the CU-cooperative kernel is preferred; measured crossovers on
 // MI355X (tools/probes/variant_sweep.py, t9_variants.py): dds/geffner T<=4 between 512 and 1024 tiles; the 132-wide
 // net at ~600 (500 tiles: cooperative 1.85 ms against 2.27 ms one wave per tile; 1000 tiles: 3.69 against 2.28).
+// r02, after the cooperative kernel's per-bridge time dropped by a sixth (tools/probes/variant_crossover.py,
+// profiles/r02_s2e_variant_crossover.txt; the cooperative time is ceil(tiles / 256 CUs) rounds of one workgroup per CU):
+//   dds net, 40-mode mixture:     cooperative wins through 6 rounds (1536 tiles: 1.13 against 1.34 ms; 2048: 1.42 / 1.34)
+//   132-wide net, 40-mode mixture: through 3 rounds (768 tiles: 1.91 against 2.31 ms; 813: 2.53 / 2.29)
+//   funnel / gmm on the narrow geffner nets: 512 tiles still (768: 0.373 / 0.314 ms and 0.0257 / 0.0246 ms)
 static int coop_max_tiles(const cmcd_desc& d, int T) {
-  (void)d;
-  (void)T;
+  if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2) {
+    if (d.arch == CMCD_ARCH_DDS) return 1536;
+    if (T == 9) return 768;
+  }
   return 512;
 }
 static int fail(int code, const char* fmt, const char* a = "", long long b = 0) {
