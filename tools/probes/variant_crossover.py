@@ -23,7 +23,9 @@ def time_cfg(name, n, variant, reps=20):
     return ms / cnt
 
 
-for name, sizes in [("funnel_n300_k64", [8192, 12288, 16384, 24576]), ("gmm_n300_k8", [8192, 12288, 16384, 24576])]:
+for name, sizes in [("many_gmm_n2000_k256_dds", [4096, 6144, 8192, 10240, 12288, 16384, 24576, 32768, 40960, 49152, 65536, 98304]),
+                    ("many_gmm_var_n16000_k256", [4096, 8192, 12288, 13000, 14000, 16000]),
+                    ("funnel_n300_k64", [8192, 12288, 16384, 24576]), ("gmm_n300_k8", [8192, 12288, 16384, 24576])]:
     K = synthetic.CONFIGS[name]["nbridges"]
     for n in sizes:
         t1, t3 = time_cfg(name, n, 1), time_cfg(name, n, 3)
