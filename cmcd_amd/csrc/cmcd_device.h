@@ -108,10 +108,9 @@ __device__ __forceinline__ float bits_to_normal(uint32_t b) {
 // Evaluated as max(x,0) - |x|/2 * erfc(|x|/sqrt 2) with erfc(s/sqrt 2) = 2^(-s R(s)), R a polynomial
 // (tools/fit_activations.py): one v_exp_f32, no branch, no cancellation for x < 0.
 __device__ __forceinline__ float gelu_fast(float x) {
-  // degree 5 (r02; tools/fit_activations.py): max abs error 3.9e-7 against float64 (rms 9e-8) where the degree-9 fit
-  // kept for the derivative below reaches 2.4e-7 — the float32 rounding of the result itself — for four FMAs fewer on
-  // the one function that is half of the forward kernels' VALU instructions.  The parity bar is 1e-3 on the batch
-  // statistics, observed 1e-5.
+  // degree 5 (r02; tools/fit_activations.py): max abs error 3.9e-7 against float64 (rms 9e-8) where the degree-9 fit of
+  // r01 reaches 2.4e-7 — the float32 rounding of the result itself — for four FMAs fewer on the one function that is a
+  // third of the forward kernels' VALU instructions.  The parity bar is 1e-3 on the batch statistics, observed 1e-5.
   const float ax = fabsf(x);
   const float s = fminf(ax, 6.0f);
   float r = -2.386156740e-05f;
@@ -124,42 +123,30 @@ __device__ __forceinline__ float gelu_fast(float x) {
   const float he = __builtin_amdgcn_exp2f(fmaf(-s, r, -1.0f));
   return fmaf(-ax, he, fmaxf(x, 0.0f));
 }
-// d gelu / dx = Phi(x) + x phi(x), Phi from the same erfc polynomial as gelu_fast.
-__device__ __forceinline__ float gelu_grad_fast(float x) {
-  const float ax = fabsf(x);
+// d gelu / dx = Phi(x) + x phi(x), Phi from the same erfc polynomial as gelu_fast (r02: degree 5 here too — the
+// derivative's max abs error is 2.5e-7 against 8e-8 with the degree-9 fit, both at the float32 rounding of a quantity of
+// order one, and the value the gradient kernels recompute is now bit for bit the forward kernels' activation).
+__device__ __forceinline__ float gelu_erfc_half(float ax) {   // erfc(|x| / sqrt 2) / 2
   const float s = fminf(ax, 6.0f);
-  float r = 5.626459558e-08f;
-  r = fmaf(r, s, -1.389874702e-06f);
-  r = fmaf(r, s, 1.521236383e-05f);
-  r = fmaf(r, s, -9.455732447e-05f);
-  r = fmaf(r, s, 3.240720773e-04f);
-  r = fmaf(r, s, -6.315276129e-05f);
-  r = fmaf(r, s, -6.896958595e-03f);
-  r = fmaf(r, s, 5.242151140e-02f);
-  r = fmaf(r, s, 4.592238824e-01f);
-  r = fmaf(r, s, 1.151104120e+00f);
-  const float he = 0.5f * __builtin_amdgcn_exp2f(-(s * r));           // erfc(|x|/sqrt2) / 2
+  float r = -2.386156740e-05f;
+  r = fmaf(r, s, 6.893407597e-04f);
+  r = fmaf(r, s, -7.823501478e-03f);
+  r = fmaf(r, s, 5.302766042e-02f);
+  r = fmaf(r, s, 4.590415202e-01f);
+  r = fmaf(r, s, 1.151121845e+00f);
+  return __builtin_amdgcn_exp2f(fmaf(-s, r, -1.0f));
+}
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+  const float he = gelu_erfc_half(fabsf(x));
   const float cdf = x >= 0.f ? 1.0f - he : he;
   const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);
   return fmaf(x, pdf, cdf);
 }
 // gelu and its derivative from ONE evaluation of the erfc polynomial and exponential (the gradient kernels need
-// both at every hidden unit; computed separately they cost 17 + 25 instructions, together 24)
+// both at every hidden unit): 19 instructions (24 with the degree-9 fit of r01)
 __device__ __forceinline__ float gelu_fast_both(float x, float& dg) {
   const float ax = fabsf(x);
-  const float s = fminf(ax, 6.0f);
-  float r = 5.626459558e-08f;
-  r = fmaf(r, s, -1.389874702e-06f);
-  r = fmaf(r, s, 1.521236383e-05f);
-  r = fmaf(r, s, -9.455732447e-05f);
-  r = fmaf(r, s, 3.240720773e-04f);
-  r = fmaf(r, s, -6.315276129e-05f);
-  r = fmaf(r, s, -6.896958595e-03f);
-  r = fmaf(r, s, 5.242151140e-02f);
-  r = fmaf(r, s, 4.592238824e-01f);
-  r = fmaf(r, s, 1.151104120e+00f);
-  const float e = __builtin_amdgcn_exp2f(-(s * r));                      // erfc(|x| / sqrt2)
-  const float he = 0.5f * e;
+  const float he = gelu_erfc_half(ax);
   const float cdf = x >= 0.f ? 1.0f - he : he;
   const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);
   dg = fmaf(x, pdf, cdf);
