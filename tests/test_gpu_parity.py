@@ -21,6 +21,7 @@ CASES = [
     ("gmm_n300_k8", 1, {}),                                       # a single particle
     ("many_gmm_n2000_k256_dds", 9, dict(nbridges=4)),             # one 8-particle tile + 1 (twin-column tiling, r02 lane order)
     ("many_gmm_var_n16000_k256", 2041, dict(nbridges=4)),         # the 132-wide net at the top of the 8-particle range, ragged
+    ("funnel_n300_k64", 40, dict(emb_dim=122, nbridges=6)),       # d = 10 on the 132-wide net: the 13-wave cooperative instance
 ]
 
 
