@@ -94,8 +94,15 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
   float* lds_b3 = lds_b2 + HP;            // 16
   float* lds_tgt = lds_b3 + 16;           // tgt_floats
   float* stage = lds_tgt + a.w.tgt_floats;
-  constexpr int STG = (5 * HP + 32) * 16 + (D + 1) * HP;  // per tile: u1T, u2T, da2T, da1T, du1T [HP][16]; z1, doT [16][16];
-                                                          // then accZ1 [D][HP], accB2 [HP] (wave-private sums over evaluations)
+  // per tile: u1T, u2T, da2T [HP][16] (read by the other waves of the workgroup); da1T, du1T (read by this wave only);
+  // z1, doT [16][16]; then accZ1 [D][HP], accB2 [HP] (wave-private sums over evaluations).
+  // TILE_LOCAL (the 132-wide net, r02): da1 / du1 are consumed by this wave's own products right where they are formed,
+  // 16 hidden units at a time through two 1 KB buffers, instead of being staged whole (2 x 9 KB per wave): 50 -> 33.5 KB
+  // of staging per wave, so FOUR waves fit a CU's LDS instead of three (the fourth SIMD used to idle).
+  constexpr bool TILE_LOCAL = T > 4;
+  constexpr int OWNBUF = TILE_LOCAL ? 256 : HP * 16;
+  constexpr int OFF_DOT = 3 * HP * 16 + 2 * OWNBUF + 256;
+  constexpr int STG = 3 * HP * 16 + 2 * OWNBUF + 512 + (D + 1) * HP;
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(a.ws + a.w.w1z);
     f32x4* dst = reinterpret_cast<f32x4*>(lds_w1z);
@@ -120,8 +127,8 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
   float* u2T = u1T + HP * 16;
   float* da2T = u2T + HP * 16;
   float* da1T = da2T + HP * 16;
-  float* du1T = da1T + HP * 16;
-  float* z1T = du1T + HP * 16;            // rows 0..D-1 = z_j, row D = 1, rest 0
+  float* du1T = da1T + OWNBUF;
+  float* z1T = du1T + OWNBUF;             // rows 0..D-1 = z_j, row D = 1, rest 0
   float* doT = z1T + 256;                 // rows 0..D-1 = d o_j, rest 0
   float* accZ1 = doT + 256;               // [D][HP]  dW1[j][n], j < D
   float* accB2 = accZ1 + D * HP;          // [HP]     db2[n]
@@ -604,6 +611,24 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
       float jpart[D];  // BPTT: J_s(z_e)^T a_s, this lane's share of the hidden units
 #pragma unroll
       for (int j = 0; j < D; ++j) jpart[j] = 0.f;
+      float za_own[4] = {0.f, 0.f, 0.f, 0.f};
+      if (TILE_LOCAL) {   // the small tiles first: this wave's own products below need z1
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = 4 * g + r;
+          float zv = 0.f, dv = 0.f;
+#pragma unroll
+          for (int j = 0; j < D; ++j) {
+            zv = (f == j) ? z[j] : zv;
+            dv = (f == j) ? dob[j] : dv;
+          }
+          if (f == D) zv = 1.0f;
+          z1T[wb[r]] = zv;
+          doT[wb[r]] = dv;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) za_own[s] = z1T[rb[s]];
+      }
 #pragma unroll
       for (int t = 0; t < T; ++t) {
         f32x4 pre1;
@@ -616,7 +641,7 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int o = wb[r] + 256 * t;
+          const int o = wb[r] + (TILE_LOCAL ? 0 : 256 * t);
           if (GEF) du1T[o] = d1[t][r];
           if (BPTT && !ITEM && GEF && 16 * t < D) {  // residual path of the first block: d x_j += d u1_j
 #pragma unroll
@@ -631,6 +656,26 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
           for (int j = 0; j < D; ++j) {
             const f32x4 wv4 = *reinterpret_cast<const f32x4*>(lds_w1z + j * HP + 16 * t + 4 * g);
             jpart[j] += d1[t][0] * wv4[0] + d1[t][1] * wv4[1] + d1[t][2] * wv4[2] + d1[t][3] * wv4[3];
+          }
+        }
+        if (TILE_LOCAL) {
+          // this wave's own outer products for tile t, straight from the two 1 KB buffers just written (same wave: the
+          // LDS queue is in order, no barrier): dW1 / bias-table row (d a1), residual table (d u1)
+          f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, s2acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(za_own[s4], da1T[rb[s4]], sacc, 0, 0, 0);
+            if (GEF) s2acc = __builtin_amdgcn_mfma_f32_16x16x4f32(za_own[s4], du1T[rb[s4]], s2acc, 0, 0, 0);
+          }
+          asm volatile("" ::: "memory");   // the next tile's stores stay behind these reads
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 4 * g + r;
+            if (row < D) atomicAdd(accZ1 + row * HP + 16 * t + c, sacc[r]);
+            if (row == D) {
+              atomicAdd(gS + erow * HP + 16 * t + c, sacc[r]);
+              if (GEF) atomicAdd(gS2 + erow * HP + 16 * t + c, s2acc[r]);
+            }
           }
         }
       }
@@ -649,6 +694,7 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
         }
       }
       // ---------------------------------------------------------------- stage the two small tiles
+      if (!TILE_LOCAL) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int f = 4 * g + r;
@@ -662,6 +708,7 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
         z1T[wb[r]] = zv;
         doT[wb[r]] = dv;
       }
+      }
       __syncthreads();
       // ---------------------------------------------------------------- outer products over particles
       {
@@ -673,24 +720,28 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
           f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, s2acc = {0.f, 0.f, 0.f, 0.f}, bacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
-            const float b1v = da1T[rb[s] + 256 * t];
             const float b2v = da2T[rb[s] + 256 * t];
-            sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(za[s], b1v, sacc, 0, 0, 0);
             bacc = __builtin_amdgcn_mfma_f32_16x16x4f32(za[s], b2v, bacc, 0, 0, 0);
-            if (GEF) {
-              const float b3v = du1T[rb[s] + 256 * t];
-              s2acc = __builtin_amdgcn_mfma_f32_16x16x4f32(za[s], b3v, s2acc, 0, 0, 0);
+            if (!TILE_LOCAL) {
+              const float b1v = da1T[rb[s] + 256 * t];
+              sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(za[s], b1v, sacc, 0, 0, 0);
+              if (GEF) {
+                const float b3v = du1T[rb[s] + 256 * t];
+                s2acc = __builtin_amdgcn_mfma_f32_16x16x4f32(za[s], b3v, s2acc, 0, 0, 0);
+              }
             }
           }
           // C rows are the features of z1 = [z_0 .. z_{D-1}, 1, 0 ...]: lane (g, c), register r <-> row 4 g + r
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = 4 * g + r;
-            if (row < D) atomicAdd(accZ1 + row * HP + 16 * t + c, sacc[r]);            // dW1[row][n] += z_row . d a1[n]
+            if (!TILE_LOCAL && row < D) atomicAdd(accZ1 + row * HP + 16 * t + c, sacc[r]);   // dW1[row][n] += z_row . d a1[n]
             if (row == D) {
               atomicAdd(accB2 + 16 * t + c, bacc[r]);                                  // db2[n] += sum_p d a2
-              atomicAdd(gS + erow * HP + 16 * t + c, sacc[r]);                        // d / d bias-table row used
-              if (GEF) atomicAdd(gS2 + erow * HP + 16 * t + c, s2acc[r]);
+              if (!TILE_LOCAL) {
+                atomicAdd(gS + erow * HP + 16 * t + c, sacc[r]);                      // d / d bias-table row used
+                if (GEF) atomicAdd(gS2 + erow * HP + 16 * t + c, s2acc[r]);
+              }
             }
           }
         }
@@ -718,7 +769,7 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
                                                                   gW2[k][to], 0, 0, 0);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
-              gW3[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(x2[s], base[5 * HP * 16 + 256 + rb[s]], gW3[k], 0, 0, 0);
+              gW3[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(x2[s], base[OFF_DOT + rb[s]], gW3[k], 0, 0, 0);
           }
         }
       }
@@ -1198,7 +1249,7 @@ __global__ __launch_bounds__(256) void grad_dds_tail_sum_kernel(TailArgs a) {
 
 typedef void (*grad_fn)(GradArgs);
 
-static int grad_nw(int T) { return T > 4 ? 3 : 4; }
+static int grad_nw(int T) { (void)T; return 4; }   // (r02: the 132-wide net too — its staging shrank to 33.5 KB per wave)
 
 template <bool BPTT, bool ITEM>
 static grad_fn pick_grad_t(const cmcd_desc& d, int T) {
@@ -1213,8 +1264,8 @@ static grad_fn pick_grad_t(const cmcd_desc& d, int T) {
     if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 2) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 2, 4, false, BPTT, ITEM>;
     if (d.target == CMCD_TARGET_GMM && d.dim == 2 && T == 4) return grad_kernel<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER, 2, 4, 4, false, BPTT, ITEM>;
     if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 4) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 4, 4, false, BPTT, ITEM>;
-    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 9) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 9, 3, true, BPTT, ITEM>;
-    if (d.target == CMCD_TARGET_GMM && d.dim == 2 && T == 9) return grad_kernel<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER, 2, 9, 3, true, BPTT, ITEM>;
+    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 9) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 9, 4, true, BPTT, ITEM>;
+    if (d.target == CMCD_TARGET_GMM && d.dim == 2 && T == 9) return grad_kernel<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER, 2, 9, 4, true, BPTT, ITEM>;
     if (d.target == CMCD_TARGET_FUNNEL && d.dim == 10 && T == 4) return grad_kernel<CMCD_TARGET_FUNNEL, CMCD_ARCH_GEFFNER, 10, 4, 4, false, BPTT, ITEM>;
   }
   return nullptr;
@@ -1308,7 +1359,8 @@ int grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, c
     ga.lam = lam;
   }
 
-  const size_t lds_bytes = size_t((w.T > 4 ? 0 : 2 * HP * HP) + 2 * D * HP + HP + 16 + w.tgt_floats + nw * ((5 * HP + 32) * 16 + (D + 1) * HP)) * 4;
+  const size_t stg = w.T > 4 ? size_t(3 * HP * 16 + 2 * 256 + 512 + (D + 1) * HP) : size_t((5 * HP + 32) * 16 + (D + 1) * HP);
+  const size_t lds_bytes = size_t((w.T > 4 ? 0 : 2 * HP * HP) + 2 * D * HP + HP + 16 + w.tgt_floats + nw * stg) * 4;
   if (lds_bytes > 160 * 1024) return CMCD_ERR_UNSUPPORTED;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)lds_bytes) != hipSuccess)
