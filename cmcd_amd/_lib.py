@@ -9,7 +9,7 @@ import torch  # noqa: F401  (first: torch ships its own HIP runtime; loading lib
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CMCD_LIB_PATH", os.path.join(_HERE, "libcmcd_hip.so"))  # override: diagnostic builds
 
-MODE = {"MCD_CAIS_sn": 0, "MCD_CAIS_var_sn": 1, "MCD_ULA": 2, "MCD_ULA_sn": 3}
+MODE = {"MCD_CAIS_sn": 0, "MCD_CAIS_var_sn": 1, "MCD_ULA": 2, "MCD_ULA_sn": 3, "MCD_CAIS_UHA_sn": 4}
 ARCH = {"geffner": 0, "dds": 1}
 TARGET = {"gmm": 0, "funnel": 1, "many_gmm": 2, "lgcp": 3}
 EPS_SCHEDULE = {None: 0, "": 0, "none": 0, "linear": 1, "cos_sq": 2}
@@ -23,7 +23,7 @@ class Desc(C.Structure):
 
 
 LAYOUT_FIELDS = (
-    "vd_mean", "vd_logdiag", "eps", "mgridref_y",
+    "vd_mean", "vd_logdiag", "eps", "mgridref_y", "gamma",
     "g_emb", "g_factor", "g_w1", "g_b1", "g_w2", "g_b2", "g_w3", "g_b3",
     "d_phase", "d_tw1", "d_tb1", "d_tw2", "d_tb2", "d_sw1", "d_sb1", "d_sw2", "d_sb2", "d_sw3", "d_sb3")
 

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libcmcd_hip.so")
-SOURCES = ["cmcd_kernels.hip", "cmcd_coop.hip", "cmcd_lgcp.hip", "cmcd_grad.hip", "cmcd_bptt.hip", "cmcd_mfvi.hip", "cmcd_opt.hip"]
+SOURCES = ["cmcd_kernels.hip", "cmcd_uha.hip", "cmcd_coop.hip", "cmcd_lgcp.hip", "cmcd_grad.hip", "cmcd_bptt.hip", "cmcd_mfvi.hip", "cmcd_opt.hip"]
 HEADERS = ["cmcd_device.h", os.path.join(ROOT, "include", "cmcd_hip.h")]
 # Per-file flags.  cmcd_kernels.hip holds the wave-per-tile trajectory kernel, which is VALU-issue bound at 4 waves per
 # SIMD: there a packed fp32 instruction holds the pipe ~1.8x as long as a plain one and the SLP vectoriser pays v_mov
@@ -20,6 +20,7 @@ HEADERS = ["cmcd_device.h", os.path.join(ROOT, "include", "cmcd_hip.h")]
 # for that file.  The cooperative kernel is issue-bound per wave (one instruction per ~5 cycles whatever it is) and
 # keeps the packed forms.
 EXTRA_FLAGS = {"cmcd_kernels.hip": ["-fno-slp-vectorize"],
+               "cmcd_uha.hip": ["-fno-slp-vectorize"],   # same wave-per-tile mapping as cmcd_kernels.hip
                # Jacobian / scan kernels of the work-item reparameterised gradient: -11 % / -5 % without SLP (cmcd_bptt.hip)
                "cmcd_bptt.hip": ["-fno-slp-vectorize"]}
 

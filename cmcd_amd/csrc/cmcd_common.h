@@ -58,6 +58,13 @@ bool coop_half_available(const cmcd_desc& d, int T);   // the 8-particle-tile in
 int coop_launch(const cmcd_desc& d, const TrajArgs& ta, bool half, void* stream);
 
 
+// cmcd_uha.hip: MCD_CAIS_UHA_sn (2nd-order CMCD) on the wave-per-tile mapping.  The kept trajectory is
+// [3 K + 2][n][dim]: z_0..z_K, rho_0..rho_K, rho'_0..rho'_{K-1}.
+int net_in_dim(const cmcd_desc& d);                    // dim, or 2 dim when the network takes concat(z, rho)
+bool uha_available(const cmcd_desc& d, int T);
+int64_t uha_traj_floats(const cmcd_desc& d, int64_t n);
+int uha_forward_launch(const cmcd_desc& d, const TrajArgs& ta, void* stream);
+
 // cmcd_lgcp.hip: the d = 1600 path (per-bridge launch sequence)
 int64_t lgcp_workspace_floats(const cmcd_desc& d, int64_t n, int64_t base);
 int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, const int32_t* seeds, int64_t n,

@@ -68,6 +68,7 @@ static int fail(int code, const char* fmt, const char* a = "", long long b = 0) 
 
 static inline int64_t align4(int64_t x) { return (x + 3) & ~int64_t(3); }
 
+int net_in_dim(const cmcd_desc& d);
 static bool hidden_width(const cmcd_desc& d, int& HP) {
   if (d.arch == CMCD_ARCH_DDS) {
     HP = 64;
@@ -75,7 +76,14 @@ static bool hidden_width(const cmcd_desc& d, int& HP) {
   }
   if (d.arch == CMCD_ARCH_GEFFNER) {
     if (d.emb_dim < 1) return false;
-    HP = ((d.dim + d.emb_dim + 15) / 16) * 16;
+    HP = ((net_in_dim(d) + d.emb_dim + 15) / 16) * 16;
+    if (d.mode == CMCD_MODE_CAIS_UHA_SN && d.target != CMCD_TARGET_LGCP) {
+      // 2nd-order CMCD has its own kernels (cmcd_uha.hip): instances of 2, 4, 5 and 9 neuron tiles (gmm 2*2+20 = 24,
+      // funnel 2*10+48 = 68, the 40-mode mixture 2*2+130 = 134), other widths zero-padded to the next one
+      const int T = HP / 16;
+      HP = 16 * (T <= 2 ? 2 : (T <= 4 ? 4 : (T <= 5 ? 5 : (T <= 9 ? 9 : T))));
+      return true;
+    }
     // Kernel instances exist for 2, 4 and 9 neuron tiles (the BASELINE widths 22 / 58 / 132); any other width runs
     // on the next larger instance with zero-padded weights: a padded unit has no outgoing weight, so it cannot
     // reach the output, and its gradient entries are never copied out.  (lgcp has its own path: any width.)
@@ -89,6 +97,10 @@ static bool hidden_width(const cmcd_desc& d, int& HP) {
   }
   return false;
 }
+
+// width of the state part of the network input: z, or concat(z, rho) for the momentum mode (rho_dim = dim,
+// /root/reference/src/mcdboundingmachine.py:82-98)
+int net_in_dim(const cmcd_desc& d) { return d.mode == CMCD_MODE_CAIS_UHA_SN ? 2 * d.dim : d.dim; }
 
 static int64_t target_lds_floats(const cmcd_desc& d, int64_t n_target) {
   if (d.target == CMCD_TARGET_MANY_GMM) return 4 + (n_target - 1);  // header + means
@@ -124,7 +136,7 @@ static bool make_ws(const cmcd_desc& d, int64_t n, int64_t n_target, WsLayout& w
   w.sched = o; o += 8 * K;
   w.bias1 = o; o += (K + 1) * HP;
   if (d.arch == CMCD_ARCH_GEFFNER) { w.utab = o; o += (K + 1) * HP; } else { w.utab = w.bias1; }
-  w.w1z = o; o += D * HP;
+  w.w1z = o; o += int64_t(net_in_dim(d)) * HP;
   w.w2 = o; o += int64_t(HP) * HP;
   w.w2t = o; o += int64_t(HP) * HP;
   w.w2q = o; o += 2 * int64_t(HP) * HP;
@@ -333,7 +345,8 @@ struct PackArgs {
   float* ws;
   WsLayout w;
   int64_t o_w1, o_w2, o_b2, o_w3, o_b3, o_factor;  // offsets in params (factor: -1 -> 1.0)
-  int32_t D, IN;                                   // true hidden width
+  int32_t D, IN;                                   // state inputs of the net (z, or [z; rho]); true hidden width
+  int32_t DO;                                      // outputs of the net (= dim)
   int32_t target, n_mix;
 };
 
@@ -364,12 +377,15 @@ __device__ __forceinline__ void pack_weights_body(const PackArgs& a, int vblock,
   for (int64_t idx = tid; has_net && idx < (int64_t)a.D * HP; idx += stride) {
     const int j = int(idx / HP), n = int(idx % HP);
     a.ws[a.w.w1z + idx] = n < a.IN ? P[a.o_w1 + (int64_t)j * a.IN + n] : 0.f;
-    a.ws[a.w.w3t + idx] = n < a.IN ? P[a.o_w3 + (int64_t)n * a.D + j] : 0.f;
+  }
+  for (int64_t idx = tid; has_net && idx < (int64_t)a.DO * HP; idx += stride) {
+    const int j = int(idx / HP), n = int(idx % HP);
+    a.ws[a.w.w3t + idx] = n < a.IN ? P[a.o_w3 + (int64_t)n * a.DO + j] : 0.f;
   }
   for (int64_t idx = tid; has_net && idx < HP; idx += stride) a.ws[a.w.b2 + idx] = idx < a.IN ? P[a.o_b2 + idx] : 0.f;
   for (int64_t idx = tid; idx < 16; idx += stride) {
     float v = 0.f;
-    if (has_net && idx < a.D) v = P[a.o_b3 + idx];
+    if (has_net && idx < a.DO) v = P[a.o_b3 + idx];
     if (idx == 15) v = a.o_factor >= 0 ? P[a.o_factor] : 1.0f;
     a.ws[a.w.b3 + idx] = v;
   }
@@ -908,13 +924,16 @@ static traj_fn pick_kernel(const cmcd_desc& d, int T) {
 static void launch_prep(const cmcd_desc& d, const cmcd_layout& layr, const WsLayout& w, const float* params,
                         const float* target_consts, int n_mix, float* ws, hipStream_t stream) {
   const cmcd_layout* lay = &layr;
-  const int64_t K = d.nbridges, D = d.dim, E = d.emb_dim, IN = D + E;
+  // D here = the state inputs of the network: z, or concat(z, rho) for the momentum mode
+  const int64_t K = d.nbridges, D = net_in_dim(d), E = d.emb_dim, IN = D + E;
   PrepArgs pa{};
   const bool ula_mode = d.mode == CMCD_MODE_ULA || d.mode == CMCD_MODE_ULA_SN;
-  pa.sched = SchedArgs{params, ws, *lay, w, (int32_t)K, d.ngrid, ula_mode ? CMCD_EPS_CONST : d.eps_schedule, -1, -1};
+  // MCD_CAIS_UHA_sn: the cos^2 schedule is part of the function body (mcd_under_lp_a_cais.py:33-40,48)
+  const int sched = ula_mode ? CMCD_EPS_CONST : (d.mode == CMCD_MODE_CAIS_UHA_SN ? CMCD_EPS_COS_SQ : d.eps_schedule);
+  pa.sched = SchedArgs{params, ws, *lay, w, (int32_t)K, d.ngrid, sched, -1, -1};
   PackArgs& pk = pa.pack;
   pk.params = params; pk.tgt = target_consts; pk.ws = ws; pk.w = w;
-  pk.D = (int32_t)D; pk.target = d.target; pk.n_mix = n_mix;
+  pk.D = (int32_t)D; pk.DO = d.dim; pk.target = d.target; pk.n_mix = n_mix;
   if (d.mode == CMCD_MODE_ULA) {
     pk.o_w1 = pk.o_w2 = pk.o_b2 = pk.o_w3 = pk.o_b3 = pk.o_factor = -1; pk.IN = 0;
   } else if (d.arch == CMCD_ARCH_DDS) {
@@ -943,7 +962,7 @@ int launch_finalize(const double* partials, int32_t count, double* out5, void* s
 
 static int check_desc(const cmcd_desc* d) {
   if (!d) return fail(CMCD_ERR_BAD_ARG, "null desc%s");
-  if (d->mode < CMCD_MODE_CAIS_SN || d->mode > CMCD_MODE_ULA_SN)
+  if (d->mode < CMCD_MODE_CAIS_SN || d->mode > CMCD_MODE_CAIS_UHA_SN)
     return fail(CMCD_ERR_UNSUPPORTED, "Mode not implemented.%s");
   if (d->mode == CMCD_MODE_ULA && d->arch != CMCD_ARCH_DDS)
     return fail(CMCD_ERR_BAD_ARG, "MCD_ULA has no network: pass arch = CMCD_ARCH_DDS as the placeholder%s");
@@ -958,6 +977,13 @@ static int check_desc(const cmcd_desc* d) {
   if (d->target == CMCD_TARGET_LGCP) {
     if ((d->arch != CMCD_ARCH_GEFFNER && d->mode != CMCD_MODE_ULA) || d->dim < 4 || d->dim > 4096)
       return fail(CMCD_ERR_UNSUPPORTED, "lgcp runs with the geffner net only%s");
+    if (d->mode == CMCD_MODE_CAIS_UHA_SN)
+      return fail(CMCD_ERR_UNSUPPORTED, "MCD_CAIS_UHA_sn on lgcp: not built yet%s");
+    return CMCD_OK;
+  }
+  if (d->mode == CMCD_MODE_CAIS_UHA_SN) {
+    if (!uha_available(*d, HP / 16))
+      return fail(CMCD_ERR_UNSUPPORTED, "no MCD_CAIS_UHA_sn kernel instance for this (target, dim, arch, width=%s%lld)", "", HP);
     return CMCD_OK;
   }
   if (!pick_kernel(*d, HP / 16))
@@ -1018,12 +1044,13 @@ static int forward_impl(const cmcd_desc* desc, const cmcd_layout* lay, const int
     return fail(CMCD_ERR_BAD_ARG, "null pointer argument%s");
   if (n < 1 || n > (int64_t)1 << 31) return fail(CMCD_ERR_BAD_ARG, "n out of range%s");
   const cmcd_desc& d = *desc;
-  const int64_t K = d.nbridges, D = d.dim, E = d.emb_dim, IN = D + E;
+  const int64_t K = d.nbridges, D = d.dim, E = d.emb_dim, DIN = net_in_dim(d), IN = DIN + E;
+  const bool uha = d.mode == CMCD_MODE_CAIS_UHA_SN;
 
   // every leaf this configuration reads must lie inside params_flat
   auto need = [&](int64_t off, int64_t len) { return off >= 0 && off + len <= n_params; };
   bool ok = need(lay->vd_mean, D) && need(lay->vd_logdiag, D) && need(lay->eps, 1) &&
-            need(lay->mgridref_y, d.ngrid + 1);
+            need(lay->mgridref_y, d.ngrid + 1) && (!uha || need(lay->gamma, 1));
   if (d.mode == CMCD_MODE_ULA) {
     // no network leaves
   } else if (d.arch == CMCD_ARCH_GEFFNER)
@@ -1032,7 +1059,7 @@ static int forward_impl(const cmcd_desc* desc, const cmcd_layout* lay, const int
          need(lay->g_b3, D);
   else
     ok = ok && need(lay->d_phase, 64) && need(lay->d_tw1, 128 * 64) && need(lay->d_tb1, 64) &&
-         need(lay->d_tw2, 64 * 64) && need(lay->d_tb2, 64) && need(lay->d_sw1, (D + 64) * 64) &&
+         need(lay->d_tw2, 64 * 64) && need(lay->d_tb2, 64) && need(lay->d_sw1, (DIN + 64) * 64) &&
          need(lay->d_sb1, 64) && need(lay->d_sw2, 64 * 64) && need(lay->d_sb2, 64) &&
          need(lay->d_sw3, 64 * D) && need(lay->d_sb3, D);
   if (!ok) return fail(CMCD_ERR_BAD_ARG, "layout offset missing or outside params_flat%s");
@@ -1074,6 +1101,18 @@ static int forward_impl(const cmcd_desc* desc, const cmcd_layout* lay, const int
   float* ws = static_cast<float*>(workspace);
 
   launch_prep(d, *lay, w, params, target_consts, n_mix, ws, stream);
+
+  if (uha) {   // 2nd-order CMCD: its own trajectory kernel (cmcd_uha.hip), same prep tables and statistics merge
+    TrajArgs tu{seeds, params, ws, reinterpret_cast<double*>(ws + w.partials), out_loss, out_z, *lay, w, n,
+                (int32_t)K, 0, 1, traj, 0};
+    tu.dbg_bits = cap.bits; tu.dbg_keys = cap.keys; tu.dbg_noise = cap.noise;
+    rc = uha_forward_launch(d, tu, stream);
+    if (rc != CMCD_OK) return fail(rc, "MCD_CAIS_UHA_sn launch failed%s");
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, stream,
+                       reinterpret_cast<const double*>(ws + w.partials), w.n_waves, out_stats);
+    CMCD_HIP_CHECK(hipGetLastError());
+    return CMCD_OK;
+  }
 
   TrajArgs ta{seeds, params, ws, reinterpret_cast<double*>(ws + w.partials), out_loss, out_z, *lay, w, n,
               (int32_t)K, d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0,

@@ -15,7 +15,7 @@ from . import variationaldist as vd
 from .nn import ScoreNet, initialize_network
 
 _SN_MODES = ["MCD_ULA_sn", "MCD_U_e-lp-sna", "MCD_U_a-lp-sna", "MCD_CAIS_sn", "MCD_CAIS_var_sn"]
-_SUPPORTED = ("MCD_CAIS_sn", "MCD_CAIS_var_sn", "MCD_ULA", "MCD_ULA_sn")
+_SUPPORTED = ("MCD_CAIS_sn", "MCD_CAIS_var_sn", "MCD_ULA", "MCD_ULA_sn", "MCD_CAIS_UHA_sn")
 
 
 # --------------------------------------------------------------------------- ravel_pytree
@@ -131,8 +131,14 @@ def initialize(
             dim, emb_dim, nbridges, nlayers=nlayers, nn_arch=nn_arch,
             fully_connected_units=fully_connected_units)
         params_train["sn"] = init_fun_sn(seed, None)[1]
-    elif mode in ["MCD_U_a-lp-sn", "MCD_U_ea-lp-sn", "MCD_U_a-nv-sn", "MCD_CAIS_UHA_sn"]:
-        raise NotImplementedError("Mode not implemented.")  # momentum modes: outside the hot path
+    elif mode == "MCD_CAIS_UHA_sn":
+        # score network with rho_dim = dim: its input is concat(z, rho)   (:82-98)
+        init_fun_sn, apply_fun_sn = initialize_network(
+            dim, emb_dim, nbridges, rho_dim=dim, nlayers=nlayers, nn_arch=nn_arch,
+            fully_connected_units=fully_connected_units)
+        params_train["sn"] = init_fun_sn(seed, None)[1]
+    elif mode in ["MCD_U_a-lp-sn", "MCD_U_ea-lp-sn", "MCD_U_a-nv-sn"]:
+        raise NotImplementedError("Mode not implemented.")  # the other momentum modes: outside the hot path
     else:
         apply_fun_sn = None
 
@@ -189,7 +195,7 @@ def _build_layout(unflatten, spec):
     lay = _lib.Layout(*([-1] * len(_lib.LAYOUT_FIELDS)))
     o = unflatten.offset
     lay.vd_mean, lay.vd_logdiag = o("vd", "mean"), o("vd", "logdiag")
-    lay.eps, lay.mgridref_y = o("eps"), o("mgridref_y")
+    lay.eps, lay.mgridref_y, lay.gamma = o("eps"), o("mgridref_y"), o("gamma")
     if spec.arch == "geffner":
         lay.g_emb, lay.g_factor = o("sn", "emb"), o("sn", "factor_sn")
         lay.g_w1, lay.g_b1 = o("sn", "nn", 0, 0), o("sn", "nn", 0, 1)

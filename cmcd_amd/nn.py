@@ -15,8 +15,10 @@ import math
 
 import torch
 
-ScoreNet = collections.namedtuple("ScoreNet", ["arch", "x_dim", "emb_dim", "nbridges", "width"])
-ScoreNet.__doc__ = "Static description of apply_fun_sn (the 4th entry of params_fixed)."
+ScoreNet = collections.namedtuple("ScoreNet", ["arch", "x_dim", "emb_dim", "nbridges", "width", "rho_dim"],
+                                  defaults=(0,))
+ScoreNet.__doc__ = ("Static description of apply_fun_sn (the 4th entry of params_fixed).  rho_dim = x_dim for the "
+                    "momentum modes (network input concat(z, rho), /root/reference/src/mcdboundingmachine.py:82-98), else 0.")
 
 DDS_WIDTH = 64  # PISNet overwrites fully_connected_units with [64, 64]  (nn_dds.py:95)
 
@@ -40,10 +42,10 @@ def initialize_embedding(gen, nbridges, emb_dim, factor=0.05):
 
 def initialize_mcd_network(x_dim, emb_dim, nbridges, rho_dim=0, nlayers=4):
     """/root/reference/src/nn.py:42-72 (nlayers is ignored there as well)."""
-    if rho_dim:
-        raise NotImplementedError("Mode not implemented.")
-    in_dim = x_dim + emb_dim
-    spec = ScoreNet("geffner", x_dim, emb_dim, nbridges, in_dim)
+    if rho_dim not in (0, x_dim):
+        raise NotImplementedError("rho_dim must be 0 or x_dim")   # the reference only ever passes dim (mcdboundingmachine.py:92)
+    in_dim = x_dim + rho_dim + emb_dim                                # nn.py:43
+    spec = ScoreNet("geffner", x_dim, emb_dim, nbridges, in_dim, rho_dim)
 
     def init_fun(seed, input_shape=None):
         gen = torch.Generator().manual_seed(int(seed))
@@ -61,10 +63,10 @@ def initialize_mcd_network(x_dim, emb_dim, nbridges, rho_dim=0, nlayers=4):
 
 def initialize_pis_network(x_dim, fully_connected_units=None, rho_dim=0):
     """/root/reference/src/nn_dds.py:55-70,91-127 — always 64 wide."""
-    if rho_dim:
-        raise NotImplementedError("Mode not implemented.")
+    if rho_dim not in (0, x_dim):
+        raise NotImplementedError("rho_dim must be 0 or x_dim")
     h = DDS_WIDTH
-    spec = ScoreNet("dds", x_dim, h, 0, h)
+    spec = ScoreNet("dds", x_dim, h, 0, h, rho_dim)
 
     def _linear(gen, fan_in, fan_out):
         # haiku Linear: w ~ TruncatedNormal(1/sqrt(fan_in)), b = 0
@@ -77,7 +79,7 @@ def initialize_pis_network(x_dim, fully_connected_units=None, rho_dim=0):
             "drift_net": {"timestep_phase": torch.zeros(1, h, dtype=torch.float32)},
             "drift_net/~/linear": _linear(gen, 2 * h, h),
             "drift_net/~/linear_1": _linear(gen, h, h),
-            "drift_net/~/linear_2": _linear(gen, x_dim + h, h),
+            "drift_net/~/linear_2": _linear(gen, x_dim + rho_dim + h, h),   # concat(x, t_net) with x = [z; rho]
             "drift_net/~/linear_3": _linear(gen, h, h),
             # LinearZero (nn_dds.py:179-192)
             "drift_net/~/linear_zero": {"b": torch.zeros(x_dim, dtype=torch.float32),

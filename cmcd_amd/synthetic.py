@@ -110,6 +110,7 @@ def build(config_name=None, device=None, lgcp_counts=None, dense=None, **overrid
             mgridref_y = rq.uniform(0.5, 1.5, min(32, cfg["nbridges"]) + 1).astype(np.float32)
     flat, unflatten, fixed = mcdbm.initialize(
         dim=dim, nbridges=cfg["nbridges"], vdparams=vdparams, eta=0.0, eps=cfg["init_eps"], mgridref_y=mgridref_y,
+        gamma=cfg.get("init_gamma", 10.0),
         trainable=("eta", "gamma", "eps", "vd", "mgridref_y"), mode=cfg["boundmode"],
         emb_dim=cfg["emb_dim"], nlayers=3, nn_arch=cfg["nn_arch"], device="cpu")
     train, _ = unflatten(flat)
@@ -128,7 +129,7 @@ def oracle_params(unflatten, params_flat):
     train, notrain = unflatten(params_flat.detach().cpu())
     allp = {**train, **notrain}
     f = lambda t: np.asarray(t.numpy(), np.float64)
-    out = {"vd": {k: f(v) for k, v in allp["vd"].items()}, "eps": f(allp["eps"]),
+    out = {"vd": {k: f(v) for k, v in allp["vd"].items()}, "eps": f(allp["eps"]), "gamma": f(allp["gamma"]),
            "mgridref_y": f(allp["mgridref_y"]), "gridref_x": f(allp["gridref_x"]), "target_x": f(allp["target_x"])}
     sn = allp["sn"]
     if "nn" in sn:

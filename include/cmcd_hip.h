@@ -46,7 +46,8 @@
 extern "C" {
 #endif
 
-#define CMCD_ABI_VERSION 2   /* 2: cmcd_adam_step[_dev] take the divergence guard (losses, n_losses, diverged) */
+#define CMCD_ABI_VERSION 3   /* 2: cmcd_adam_step[_dev] take the divergence guard (losses, n_losses, diverged)
+                                3: CMCD_MODE_CAIS_UHA_SN, cmcd_layout.gamma */
 
 typedef enum cmcd_status {
   CMCD_OK = 0,
@@ -61,7 +62,13 @@ typedef enum cmcd_status {
  * /root/reference/src/mcd_over_orig.py:6-65) exist here; every other value is CMCD_ERR_UNSUPPORTED
  * ("Mode not implemented.").  MCD_ULA has no network: pass arch = CMCD_ARCH_DDS and network layout
  * offsets of -1; eps_schedule / grad_clipping are ignored for both ULA modes, as in the reference. */
-enum { CMCD_MODE_CAIS_SN = 0, CMCD_MODE_CAIS_VAR_SN = 1, CMCD_MODE_ULA = 2, CMCD_MODE_ULA_SN = 3 };
+enum { CMCD_MODE_CAIS_SN = 0, CMCD_MODE_CAIS_VAR_SN = 1, CMCD_MODE_ULA = 2, CMCD_MODE_ULA_SN = 3,
+       /* 2nd-order CMCD (/root/reference/src/mcd_under_lp_a_cais.py:6-115 via mcd_utils.py:174-188): state (z, rho), the
+        * score network takes concat(z, rho) (built with rho_dim = dim, mcdboundingmachine.py:82-98: geffner width
+        * 2 dim + emb_dim, dds first layer [2 dim + 64, 64]), eta_aux = gamma * eps, one leap-frog step per bridge.  The
+        * function body fixes the cos^2 step-size schedule and the 1e2 clip of grad log p: eps_schedule / grad_clipping
+        * of the descriptor are ignored for this mode. */
+       CMCD_MODE_CAIS_UHA_SN = 4 };
 /* config.nn_arch (/root/reference/src/nn.py:21-39) */
 enum { CMCD_ARCH_GEFFNER = 0, CMCD_ARCH_DDS = 1 };
 /* config.model routing (/root/reference/src/model_handler.py:30-43) */
@@ -88,6 +95,8 @@ typedef struct cmcd_layout {
   int64_t vd_mean, vd_logdiag;           /* [dim] each  (vardist/diag_gauss.py:6-7)       */
   int64_t eps;                           /* scalar                                        */
   int64_t mgridref_y;                    /* [ngrid+1]                                     */
+  int64_t gamma;                         /* scalar friction (MCD_CAIS_UHA_sn: eta_aux = gamma * eps,
+                                            /root/reference/src/mcd_under_lp_a_cais.py:50); -1 otherwise   */
   /* geffner (/root/reference/src/nn.py:42-72), in = dim + emb_dim */
   int64_t g_emb;                         /* [nbridges, emb_dim]                           */
   int64_t g_factor;                      /* scalar factor_sn                              */

@@ -13,9 +13,9 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        src = os.path.join(HERE, "cmcd_oracle.c")
-        if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
-            subprocess.run(["make", "-s", "-C", HERE], check=True)
+        deps = [os.path.join(HERE, "cmcd_oracle.c"), os.path.join(HERE, "..", "include", "cmcd_hip.h")]
+        if not os.path.exists(LIB) or any(os.path.exists(d) and os.path.getmtime(LIB) < os.path.getmtime(d) for d in deps):
+            subprocess.run(["make", "-s", "-C", HERE], check=True)   # (the shared structs live in the header)
         _lib = C.CDLL(LIB)
         _lib.cmcd_oracle_threads.restype = C.c_int
         _lib.cmcd_oracle_bound.restype = C.c_int

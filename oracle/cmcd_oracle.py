@@ -1,4 +1,5 @@
-"""CPU restatement of the CMCD ``MCD_CAIS_sn`` / ``MCD_CAIS_var_sn`` bound.
+"""CPU restatement of the CMCD ``MCD_CAIS_sn`` / ``MCD_CAIS_var_sn`` bound (and the sibling modes
+``MCD_ULA``, ``MCD_ULA_sn``, ``MCD_CAIS_UHA_sn``).
 
 TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  PARITY UNPINNED: the
 reference cannot be imported here and holds no tests; this file follows the
@@ -10,6 +11,7 @@ float32/uint32 in both (oracle/prng.py).
 
 Parameter dict (same keys as cmcd_amd's ``unflatten`` output):
   vd: {mean[d], logdiag[d]}; eps: scalar; mgridref_y[G+1]; gridref_x[G+2]; target_x[K]
+  gamma: scalar (``MCD_CAIS_UHA_sn`` only; that mode's nets take [z; rho]: s_w1[2d+64,64], in = 2d + e)
   sn (dds):     timestep_phase[1,64], t_w1[128,64], t_b1[64], t_w2[64,64], t_b2[64],
                 s_w1[d+64,64], s_b1[64], s_w2[64,64], s_b2[64], s_w3[64,d], s_b3[d]
   sn (geffner): emb[K,e], factor_sn, W1[in,in], b1[in], W2[in,in], b2[in], W3[in,d], b3[d]
@@ -26,7 +28,7 @@ except Exception:  # pragma: no cover
 from . import prng
 
 LOG_2PI = 1.8378770664093453
-MODES = ("MCD_CAIS_sn", "MCD_CAIS_var_sn", "MCD_ULA", "MCD_ULA_sn")
+MODES = ("MCD_CAIS_sn", "MCD_CAIS_var_sn", "MCD_ULA", "MCD_ULA_sn", "MCD_CAIS_UHA_sn")
 
 
 # --------------------------------------------------------------------------- schedules
@@ -153,6 +155,8 @@ def compute_log_elbo_batch(seeds, params, dim, nbridges, mode, arch, target,
     """
     if mode not in MODES:
         raise NotImplementedError("Mode not implemented.")
+    if mode == "MCD_CAIS_UHA_sn":
+        return compute_log_elbo_batch_uha(seeds, params, dim, nbridges, arch, target, dtype=dtype)
     dt = np.dtype(dtype).type
     p = cast_params(params, dtype)
     vd, sn = p["vd"], p.get("sn")
@@ -213,6 +217,60 @@ def compute_log_elbo_batch(seeds, params, dim, nbridges, mode, arch, target,
         carried = (g_n, s_n)
     logp, _ = target(z)
     w = w + logp
+    return (dt(-1.0) * w).astype(dtype), z.astype(dtype)
+
+
+def compute_log_elbo_batch_uha(seeds, params, dim, nbridges, arch, target, dtype=np.float32):
+    """``MCD_CAIS_UHA_sn`` — second-order (underdamped) CMCD.  /root/reference/src/mcdboundingmachine.py:126-179 with
+    the evolve loop of /root/reference/src/mcd_under_lp_a_cais.py:6-115: state (z, rho), score network on
+    ``concat(z, rho)`` with the SAME time index i in the forward and the backward kernel (:51-54,77-80), momentum
+    refresh with ``eta_aux = gamma * eps`` (:50), one leap-frog step (:59-66), the cos^2 step-size schedule always on
+    (:33-40,48) and ``grad log p`` always clipped at 1e2 (``stable=True``, :23-30,46,64) — the function takes neither
+    ``eps_schedule`` nor ``grad_clipping``.  (The reference's dispatcher passes both keywords,
+    /root/reference/src/mcd_utils.py:174-188, which this signature would reject; the body is what is restated.)
+    Network built with ``rho_dim = dim`` (/root/reference/src/mcdboundingmachine.py:82-98, src/nn.py:42-43,
+    src/nn_dds.py:55-56): geffner input width 2 d + emb_dim, dds first layer [2 d + 64, 64]; output width d.
+    Returns (loss[N], z[N, dim]) in ``dtype``."""
+    dt = np.dtype(dtype).type
+    p = cast_params(params, dtype)
+    vd, sn = p["vd"], p["sn"]
+    seeds = np.asarray(seeds)
+    e0, rho0, noise = prng.particle_noise_uha(seeds, dim, nbridges)
+    betas = betas_from_grid(p["mgridref_y"], p["gridref_x"], p["target_x"], dtype)
+    eps_tab = eps_table(p["eps"], nbridges, "cos_sq", dtype)          # :33-40,48
+    gamma = dt(p["gamma"])
+    clip = dt(1e2)
+
+    z = q_sample(vd, e0.astype(dtype))
+    w = -q_log_prob(vd, z)                                            # mcdboundingmachine.py:157
+    rho = rho0.astype(dtype)                                          # :93
+    zero = np.zeros_like(rho)
+    w = w - log_prob_kernel(rho, zero, dt(1.0))                       # :96-97
+
+    def grad_u(zz, beta):                                             # :23-30
+        _, gp = target(zz)
+        gq = q_grad(vd, zz)
+        return dt(-1.0) * (beta * np.clip(gp, -clip, clip) + (dt(1.0) - beta) * gq)
+
+    for i in range(nbridges):
+        beta, eps = betas[i], eps_tab[i]
+        uf = grad_u(z, beta)                                          # :46
+        eta_aux = gamma * eps                                         # :50
+        s_old = apply_sn(arch, sn, np.concatenate([z, rho], 1), i, dtype)
+        fk_rho_mean = rho * (dt(1.0) - eta_aux) - dt(2.0) * eta_aux * s_old          # :52-54
+        scale = np.sqrt(dt(2.0) * eta_aux)                            # :56
+        rho_prime = fk_rho_mean + scale * noise[:, i, :].astype(dtype)               # :58-59
+        rho_pp = rho_prime - eps * uf / dt(2.0)                       # :62
+        z_new = z + eps * rho_pp                                      # :63
+        ub = grad_u(z_new, beta)                                      # :65
+        rho_new = rho_pp - eps * ub / dt(2.0)                         # :67
+        s_new = apply_sn(arch, sn, np.concatenate([z, rho_prime], 1), i, dtype)      # :77-80: old z, new momentum
+        bk_rho_mean = rho_prime * (dt(1.0) - eta_aux) + dt(2.0) * eta_aux * s_new
+        w = w + (log_prob_kernel(rho, bk_rho_mean, scale) - log_prob_kernel(rho_prime, fk_rho_mean, scale))  # :83-88
+        z, rho = z_new, rho_new
+    w = w + log_prob_kernel(rho, zero, dt(1.0))                       # :112
+    logp, _ = target(z)
+    w = w + logp                                                      # mcdboundingmachine.py:178
     return (dt(-1.0) * w).astype(dtype), z.astype(dtype)
 
 

@@ -134,6 +134,8 @@ def to_torch(params, requires_grad=True):
 
 def losses(seeds, p, dim, nbridges, mode, arch, target_name, eps_schedule=None, grad_clipping=False):
     """Per-particle losses [N] (float64), differentiable wrt the leaves of `p`."""
+    if mode == "MCD_CAIS_UHA_sn":
+        return losses_uha(seeds, p, dim, nbridges, arch, target_name)
     var_mode = mode == "MCD_CAIS_var_sn"
     # MCD_ULA / MCD_ULA_sn (/root/reference/src/mcd_over_orig.py:6-65 via mcd_utils.py:35-58): constant eps, no
     # clipping, no network in the forward kernel; the backward kernel's network (ULA_sn only) takes index i
@@ -186,6 +188,57 @@ def losses(seeds, p, dim, nbridges, mode, arch, target_name, eps_schedule=None, 
             bk = z_new - eps * ub + eps * apply(sn, z_new, i if ula else i + 1)
         w = w + log_kernel(z, bk, scale) - log_kernel(z_new, fk, scale)
         z = z_new
+    w = w + logp_fn(z)
+    return -w, z
+
+
+def losses_uha(seeds, p, dim, nbridges, arch, target_name):
+    """``MCD_CAIS_UHA_sn`` (/root/reference/src/mcd_under_lp_a_cais.py:6-115 under mcdboundingmachine.py:126-179), no
+    stop_gradient anywhere: the gradient is the full reparameterised one through (z, rho).  Same statement as
+    oracle/cmcd_oracle.py:compute_log_elbo_batch_uha (cos^2 schedule always on, clip 1e2 on grad log p only, both
+    network calls at time index i on concat(z, rho) / concat(z, rho'))."""
+    logp_fn = TARGETS[target_name] if isinstance(target_name, str) else target_name
+    e0, rho0, noise = prng.particle_noise_uha(np.asarray(seeds), dim, nbridges)
+    e0 = torch.tensor(e0.astype(np.float64))
+    rho = torch.tensor(rho0.astype(np.float64))
+    noise = torch.tensor(noise.astype(np.float64))
+    vd, sn = p["vd"], p["sn"]
+    std = torch.exp(vd["logdiag"])
+    betas = betas_from_grid(p["mgridref_y"], nbridges)
+    eps_tab = eps_table(p["eps"], nbridges, "cos_sq")
+    gamma = p["gamma"]
+    apply = apply_dds if arch == "dds" else apply_geffner
+
+    def log_q(z):
+        return (-((z - vd["mean"]) ** 2) / (2 * std * std) - torch.log(std) - 0.5 * LOG_2PI).sum(-1)
+
+    def log_kernel(x, mean, scale):
+        return (-((x - mean) ** 2) / (2 * scale * scale) - torch.log(scale) - 0.5 * LOG_2PI).sum(-1)
+
+    def grad_u(z, beta):
+        gq = -(z - vd["mean"]) / (std * std)
+        gp = torch.clamp(grad_logp(logp_fn, z, create_graph=True), -1e2, 1e2)
+        return -1.0 * (beta * gp + (1.0 - beta) * gq)
+
+    one = torch.ones((), dtype=torch.float64)
+    z = std * e0 + vd["mean"]
+    w = -log_q(z)
+    w = w - log_kernel(rho, torch.zeros_like(rho), one)
+    for i in range(nbridges):
+        beta, eps = betas[i], eps_tab[i]
+        uf = grad_u(z, beta)
+        eta_aux = gamma * eps
+        fk = rho * (1.0 - eta_aux) - 2.0 * eta_aux * apply(sn, torch.cat([z, rho], 1), i)
+        scale = torch.sqrt(2.0 * eta_aux)
+        rho_prime = fk + scale * noise[:, i, :]
+        rho_pp = rho_prime - eps * uf / 2.0
+        z_new = z + eps * rho_pp
+        ub = grad_u(z_new, beta)
+        rho_new = rho_pp - eps * ub / 2.0
+        bk = rho_prime * (1.0 - eta_aux) + 2.0 * eta_aux * apply(sn, torch.cat([z, rho_prime], 1), i)
+        w = w + log_kernel(rho, bk, scale) - log_kernel(rho_prime, fk, scale)
+        z, rho = z_new, rho_new
+    w = w + log_kernel(rho, torch.zeros_like(rho), one)
     w = w + logp_fn(z)
     return -w, z
 

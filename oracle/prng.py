@@ -144,3 +144,28 @@ def particle_noise(seeds, dim, nbridges):
         out[:, i, :] = normal(g, dim)
         _, gen = split(h)                 # mcd_cais.py:87
     return eps0, out
+
+
+def particle_noise_uha(seeds, dim, nbridges):
+    """Key chain of one particle under ``MCD_CAIS_UHA_sn`` (vectorised over seeds).
+
+    /root/reference/src/mcdboundingmachine.py:151-162 hands ``C = first(split(B))`` to evolve;
+    /root/reference/src/mcd_under_lp_a_cais.py:92-93 draws the initial momentum from
+    ``first(split(C))``, :100 takes ``gen = second(split(second(split(C))))``, and every step
+    draws its momentum-refresh noise from ``first(split(gen))`` (:55) and moves on to
+    ``second(split(second(split(gen))))`` (:84).  Returns
+    (eps0 float32[N, dim], rho0 float32[N, dim], eps float32[N, nbridges, dim]).
+    """
+    k0 = prng_key(seeds)
+    a, b = split(k0)                      # rng_key, rng_key_gen
+    eps0 = normal(a, dim)                 # vd.sample_rep
+    c, _ = split(b)                       # key handed to evolve
+    r, gen = split(c)                     # mcd_under_lp_a_cais.py:92
+    rho0 = normal(r, dim)                 # :93
+    _, gen = split(gen)                   # :100
+    out = np.zeros((k0.shape[0], nbridges, dim), np.float32)
+    for i in range(nbridges):
+        g, h = split(gen)                 # :55
+        out[:, i, :] = normal(g, dim)     # :56 sample_kernel
+        _, gen = split(h)                 # :84
+    return eps0, rho0, out

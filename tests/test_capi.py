@@ -25,7 +25,7 @@ def test_exports_every_declared_symbol(hip_lib):
             "cmcd_stats_merge", "cmcd_target_floats", "cmcd_profile_enable", "cmcd_profile_collect"} <= set(names)
     for n in names:
         assert hasattr(hip_lib, n), f"{n} declared in cmcd_hip.h but not exported"
-    assert hip_lib.cmcd_version() == 2
+    assert hip_lib.cmcd_version() == 3
 
 
 def _desc(**kw):
@@ -37,7 +37,7 @@ def _desc(**kw):
 
 def test_struct_sizes_match_header():
     assert C.sizeof(_lib.Desc) == 40
-    assert C.sizeof(_lib.Layout) == 8 * len(_lib.LAYOUT_FIELDS) == 8 * 23
+    assert C.sizeof(_lib.Layout) == 8 * len(_lib.LAYOUT_FIELDS) == 8 * 24
 
 
 def test_workspace_bytes_and_plugin_switch(hip_lib):
@@ -52,6 +52,10 @@ def test_workspace_bytes_and_plugin_switch(hip_lib):
     assert hip_lib.cmcd_workspace_bytes(C.byref(_desc(mode=2)), 2000) > 0          # MCD_ULA (arch placeholder dds)
     assert hip_lib.cmcd_workspace_bytes(C.byref(_desc(mode=3, arch=0, emb_dim=20, target=0)), 300) > 0   # MCD_ULA_sn
     assert hip_lib.cmcd_workspace_bytes(C.byref(_desc(mode=2, arch=0, emb_dim=20)), 300) == 0
+    # MCD_CAIS_UHA_sn (2nd-order CMCD): network on concat(z, rho) -> geffner width 2 dim + emb_dim
+    assert hip_lib.cmcd_workspace_bytes(C.byref(_desc(mode=4)), 2000) > 0
+    assert hip_lib.cmcd_workspace_bytes(C.byref(_desc(mode=4, arch=0, emb_dim=48, target=1, dim=10)), 300) > \
+        hip_lib.cmcd_workspace_bytes(C.byref(_desc(mode=0, arch=0, emb_dim=48, target=1, dim=10)), 300)
     assert hip_lib.cmcd_workspace_bytes(C.byref(_desc(arch=5)), 2000) == 0
     assert hip_lib.cmcd_workspace_bytes(C.byref(_desc(nbridges=0)), 2000) == 0
     assert hip_lib.cmcd_workspace_bytes(C.byref(_desc(arch=0, emb_dim=20, target=0)), 300) > 0

@@ -1,0 +1,101 @@
+"""`config.boundmode = "MCD_CAIS_UHA_sn"` (2nd-order CMCD, /root/reference/src/mcd_under_lp_a_cais.py:6-115): the HIP path
+against the float64 restatement on identical seeds and parameters, through the C ABI; its key chain bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+from cmcd_amd import _lib
+from cmcd_amd import mcdboundingmachine as mcdbm
+from cmcd_amd import synthetic
+from oracle import prng
+
+from helpers import compare_losses, run_oracle
+from test_gpu_prng import ulp_distance
+
+pytestmark = pytest.mark.gpu
+MODE = "MCD_CAIS_UHA_sn"
+
+FWD_CASES = [
+    ("gmm_n300_k8", 300, {}),                                                              # geffner 2*2+20 = 24: 2 tiles
+    ("funnel_n300_k64", 300, dict(init_eps=0.05, init_gamma=4.0)),                         # geffner 2*10+48 = 68: 5 tiles
+    ("many_gmm_n2000_k256_dds", 256, dict(init_eps=0.2, init_gamma=2.0, init_sigma=15.0)),  # dds, first layer [68, 64]
+    ("many_gmm_n2000_k256_dds", 100, dict(nbridges=16, init_eps=0.2, init_sigma=15.0)),    # ragged: 6 tiles + 4
+    ("many_gmm_var_n16000_k256", 128, dict(nbridges=32, init_eps=0.1, init_gamma=3.0)),    # geffner 2*2+130 = 134: 9 tiles
+    ("many_gmm_n2000_k256_dds", 2000, dict(init_eps=0.2, init_gamma=2.0)),                 # sigma_0 = 60: floored particles (+inf)
+    ("gmm_n300_k8", 1, {}),                                                                # a single particle
+    ("gmm_n300_k8", 200, dict(emb_dim=40, nbridges=12)),                                   # width 44 zero-padded to 64
+    ("funnel_n300_k64", 40, dict(emb_dim=100, nbridges=6, init_eps=0.05)),                 # d = 10 on 120 -> 144 wide
+    ("gmm_n300_k8", 1500, dict(nbridges=3, nn_arch="dds")),                                # many tiles, 4-wave workgroups
+    ("funnel_n300_k64", 64, dict(nbridges=5, nn_arch="dds", init_eps=0.05)),               # d = 10, dds first layer [84, 64]
+]
+
+
+@pytest.mark.parametrize("name,n,over", FWD_CASES)
+def test_bound_matches_oracle(hip_lib, param_set, name, n, over):
+    b = synthetic.build(name, device="cuda", boundmode=MODE, **over)
+    seeds = synthetic.parity_seeds(n)
+    mean, (losses, z) = mcdbm.compute_bound(torch.from_numpy(seeds).cuda(), b["params_flat"], b["unflatten"],
+                                            b["params_fixed"], b["target"], eps_schedule=b["eps_schedule"],
+                                            grad_clipping=b["grad_clipping"])
+    torch.cuda.synchronize()
+    l_ref, z_ref = run_oracle(b, seeds, dtype=np.float64)
+    rep = compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"UHA {name} n={n}")
+    print(name, n, over, rep)
+    want = np.mean(losses.double().cpu().numpy())
+    if np.isfinite(want):
+        assert abs(float(mean) - want) <= 1e-5 * max(1.0, abs(want))
+    else:
+        assert not np.isfinite(float(mean))
+
+
+def test_descriptor_schedule_and_clip_are_ignored(hip_lib):
+    """The function body fixes cos^2 and the 1e2 clip (:33-40,23-30): whatever the partial args say, same numbers."""
+    seeds = torch.from_numpy(synthetic.parity_seeds(96)).cuda()
+    b = synthetic.build("gmm_n300_k8", device="cuda", boundmode=MODE)
+    ref = None
+    for sched, clip in (("", False), ("linear", True), ("cos_sq", False)):
+        _, (l, _) = mcdbm.compute_bound(seeds, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"],
+                                        eps_schedule=sched, grad_clipping=clip)
+        ref = l if ref is None else ref
+        assert torch.equal(l, ref)
+
+
+def oracle_chain_uha(seeds, dim, K):
+    """-> bits uint32 [K+2, N, dim], gen keys uint32 [K+1, N, 2], deviates float32 [K+2, N, dim]; stage 0 = z_0,
+    stage 1 = rho_0 (mcd_under_lp_a_cais.py:92-93), stage i + 2 = bridge i (:55-56)."""
+    k0 = prng.prng_key(seeds)
+    a, b = prng.split(k0)
+    bits, keys, dev = [prng.random_bits(a, dim)], [], [prng.normal(a, dim)]
+    c, _ = prng.split(b)
+    r, gp = prng.split(c)
+    bits.append(prng.random_bits(r, dim))
+    dev.append(prng.normal(r, dim))
+    _, gen = prng.split(gp)
+    keys.append(gen)
+    for _ in range(K):
+        g, h = prng.split(gen)
+        bits.append(prng.random_bits(g, dim))
+        dev.append(prng.normal(g, dim))
+        _, gen = prng.split(h)
+        keys.append(gen)
+    return np.stack(bits), np.stack(keys), np.stack(dev)
+
+
+@pytest.mark.parametrize("name,n,K", [("many_gmm_n2000_k256_dds", 203, 40), ("funnel_n300_k64", 77, 9),
+                                      ("gmm_n300_k8", 2000, 64)])
+def test_key_chain_and_deviates_are_bit_exact(hip_lib, name, n, K):
+    b = synthetic.build(name, device="cuda", boundmode=MODE, nbridges=K, init_eps=0.02, dense=True)
+    dim = b["params_fixed"][0]
+    seeds = np.random.default_rng(3).integers(1, 10 ** 6, n).astype(np.int32)
+    seeds[:2] = (1, 999999)
+    bits = torch.zeros(K + 2, n, dim, dtype=torch.int32, device="cuda")
+    keys = torch.zeros(K + 1, n, 2, dtype=torch.int32, device="cuda")
+    noise = torch.zeros(K + 2, n, dim, dtype=torch.float32, device="cuda")
+    _lib.check(hip_lib.cmcd_debug_capture_noise(bits.data_ptr(), keys.data_ptr(), noise.data_ptr()))
+    mcdbm.bound_forward(torch.from_numpy(seeds).cuda(), b["params_flat"], b["unflatten"], b["params_fixed"], b["target"])
+    torch.cuda.synchronize()
+    rb, rk, rd = oracle_chain_uha(seeds, dim, K)
+    assert np.array_equal(keys.cpu().numpy().view(np.uint32), rk), "Threefry split chain differs from jax's"
+    assert np.array_equal(bits.cpu().numpy().view(np.uint32), rb), "random_bits of the normal draws differ from jax's"
+    d = ulp_distance(noise.cpu().numpy(), rd)
+    assert d.max() <= 4, f"deviates differ by up to {d.max()} ulp"

@@ -78,7 +78,10 @@ def test_no_cpu_fallback_and_plugin_errors():
     with pytest.raises(TypeError):
         mcdbm.compute_bound(seeds, b["params_flat"], b["unflatten"], b["params_fixed"], lambda z: z.sum())
     with pytest.raises(NotImplementedError):
-        mcdbm.initialize(dim=2, nbridges=8, mode="MCD_CAIS_UHA_sn", device="cpu")
+        mcdbm.initialize(dim=2, nbridges=8, mode="MCD_U_a-lp-sn", device="cpu")     # the other momentum modes stay out
+    # 2nd-order CMCD is a plugin value: its network is built with rho_dim = dim (mcdboundingmachine.py:82-98)
+    _, un, fixed = mcdbm.initialize(dim=2, nbridges=8, mode="MCD_CAIS_UHA_sn", nn_arch="geffner", emb_dim=20, device="cpu")
+    assert fixed[3].rho_dim == 2 and un.shape("sn", "nn", 0, 0) == (24, 24)
 
 
 def test_synthetic_configs_resolve():
