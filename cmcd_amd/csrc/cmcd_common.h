@@ -64,6 +64,16 @@ int net_in_dim(const cmcd_desc& d);                    // dim, or 2 dim when the
 bool uha_available(const cmcd_desc& d, int T);
 int64_t uha_traj_floats(const cmcd_desc& d, int64_t n);
 int uha_forward_launch(const cmcd_desc& d, const TrajArgs& ta, void* stream);
+// reparameterised gradient: reverse sweep over the kept trajectory
+bool uha_grad_available(const cmcd_desc& d, int T);
+int64_t uha_grad_workspace_floats(const cmcd_desc& d, int HP, int64_t n);
+int uha_grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, int64_t n, const float* params,
+                    int64_t n_params, const float* ws_fwd, const float* traj, float* gws, float omega, float* grad,
+                    void* stream);
+// cmcd_grad.hip: schedule + network tails for a network with `din` state inputs
+int launch_net_tails(const cmcd_desc& d, int din, int eps_schedule, const cmcd_layout& lay, const WsLayout& w,
+                     const float* params, const float* gtab, int64_t o_S, int64_t o_S2, int64_t o_gbeta, int64_t o_geps,
+                     int HP, float* dds_tail, float* grad, void* stream);
 
 // cmcd_lgcp.hip: the d = 1600 path (per-bridge launch sequence)
 int64_t lgcp_workspace_floats(const cmcd_desc& d, int64_t n, int64_t base);

@@ -1424,6 +1424,31 @@ int ula_grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& 
   return hipGetLastError() == hipSuccess ? CMCD_OK : CMCD_ERR_HIP;
 }
 
+__global__ __launch_bounds__(64) void grad_dds_tail_kernel(TailArgs a) { grad_dds_tail_body(a, blockIdx.x, gridDim.x); }
+
+// The particle-independent tails for a network whose state inputs are `din` wide (din = 2 dim for the momentum mode's
+// concat(z, rho); cmcd_uha.hip): schedule tail (d eps0, d mgridref_y from the per-bridge tables), then the embedding
+// table / W1[din:] / b1 (geffner) or the time coder (dds; `dds_tail` = (K + 1) * 448 floats of scratch).
+int launch_net_tails(const cmcd_desc& d, int din, int eps_schedule, const cmcd_layout& lay, const WsLayout& w,
+                     const float* params, const float* gtab, int64_t o_S, int64_t o_S2, int64_t o_gbeta, int64_t o_geps,
+                     int HP, float* dds_tail, float* grad, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TailArgs ta{};
+  ta.params = params; ta.gtab = gtab; ta.grad = grad; ta.lay = lay; ta.w = w; ta.tail = dds_tail;
+  ta.o_S = o_S; ta.o_S2 = o_S2; ta.o_gbeta = o_gbeta; ta.o_geps = o_geps;
+  ta.K = d.nbridges; ta.D = din; ta.E = d.emb_dim; ta.IN = din + d.emb_dim; ta.HP = HP; ta.arch = d.arch;
+  ta.eps_schedule = eps_schedule; ta.ngrid = d.ngrid;
+  hipLaunchKernelGGL(grad_sched_tail_kernel, dim3(1), dim3(256), 0, stream, ta);
+  if (d.arch == CMCD_ARCH_DDS) {
+    if (!dds_tail) return CMCD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(grad_dds_tail_kernel, dim3((unsigned)(d.nbridges + 1)), dim3(64), 0, stream, ta);
+    hipLaunchKernelGGL(grad_dds_tail_sum_kernel, dim3(((64 + 4096 + 64 + 4096 + 64 + 8192 + 64) * 16 + 255) / 256), dim3(256), 0, stream, ta);
+  } else {
+    hipLaunchKernelGGL(grad_geffner_tail_kernel, dim3(geffner_tail_blocks(ta)), dim3(256), 0, stream, ta);
+  }
+  return hipGetLastError() == hipSuccess ? CMCD_OK : CMCD_ERR_HIP;
+}
+
 int launch_geffner_tails(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, const float* params,
                          const float* gtab, int64_t o_S, int64_t o_S2, int64_t o_gbeta, int64_t o_geps, int HP,
                          float* grad, void* stream_, bool with_net) {

@@ -1220,6 +1220,10 @@ int64_t cmcd_bound_grad_workspace_bytes(const cmcd_desc* desc, int64_t n) {
     return (align4(w.total_floats) + align4(ula_grad_workspace_floats(*desc, n)) +
             (int64_t)(desc->nbridges + 1) * n * desc->dim) * 4;
   }
+  if (desc->mode == CMCD_MODE_CAIS_UHA_SN) {
+    if (!uha_grad_available(*desc, w.T)) { fail(CMCD_ERR_UNSUPPORTED, "no MCD_CAIS_UHA_sn gradient instance for this (target, dim, arch, width)%s"); return 0; }
+    return (align4(w.total_floats) + align4(uha_grad_workspace_floats(*desc, w.HP, n)) + uha_traj_floats(*desc, n)) * 4;
+  }
   if ((desc->mode != CMCD_MODE_CAIS_SN && desc->mode != CMCD_MODE_ULA_SN) || !bptt_available(*desc, w.T)) {
     fail(CMCD_ERR_UNSUPPORTED, "no reparameterised-gradient kernel instance for this (mode, target, dim, arch, width)%s");
     return 0;
@@ -1236,8 +1240,9 @@ int cmcd_bound_grad(const cmcd_desc* desc, const cmcd_layout* lay, const int32_t
   int rc = check_desc(desc);
   if (rc != CMCD_OK) return rc;
   if (!grad) return fail(CMCD_ERR_BAD_ARG, "null pointer argument%s");
-  if (desc->mode != CMCD_MODE_CAIS_SN && desc->mode != CMCD_MODE_ULA_SN && desc->mode != CMCD_MODE_ULA)
-    return fail(CMCD_ERR_UNSUPPORTED, "the reparameterised gradient exists for MCD_CAIS_sn and MCD_ULA_sn (MCD_CAIS_var_sn: cmcd_bound_var_grad)%s");
+  if (desc->mode != CMCD_MODE_CAIS_SN && desc->mode != CMCD_MODE_ULA_SN && desc->mode != CMCD_MODE_ULA &&
+      desc->mode != CMCD_MODE_CAIS_UHA_SN)
+    return fail(CMCD_ERR_UNSUPPORTED, "the reparameterised gradient exists for MCD_CAIS_sn, MCD_CAIS_UHA_sn and MCD_ULA[_sn] (MCD_CAIS_var_sn: cmcd_bound_var_grad)%s");
   // MCD_ULA_sn: the reference's dispatcher passes neither eps_schedule nor grad_clipping (mcd_utils.py:35-58)
   cmcd_desc dd = *desc;
   if (dd.mode == CMCD_MODE_ULA_SN || dd.mode == CMCD_MODE_ULA) { dd.eps_schedule = CMCD_EPS_CONST; dd.grad_clipping = 0; }
@@ -1274,6 +1279,21 @@ int cmcd_bound_grad(const cmcd_desc* desc, const cmcd_layout* lay, const int32_t
                       out_z, out_stats, traj, stream_);
     if (rc != CMCD_OK) return rc;
     rc = ula_grad_launch(d, *lay, w, n, params, n_params, ws, traj, ws + fwd, omega, grad, stream_);
+    if (rc != CMCD_OK) return fail(rc, "gradient launch failed%s");
+    return CMCD_OK;
+  }
+  if (d.mode == CMCD_MODE_CAIS_UHA_SN) {   // 2nd-order CMCD: forward with (z, rho, rho') kept + its reverse sweep (cmcd_uha.hip)
+    if (!uha_grad_available(d, w.T)) return fail(CMCD_ERR_UNSUPPORTED, "no MCD_CAIS_UHA_sn gradient instance for this (target, dim, arch, width)%s");
+    const int64_t fwd = align4(w.total_floats), gfl = align4(uha_grad_workspace_floats(d, w.HP, n));
+    const int64_t need = (fwd + gfl + uha_traj_floats(d, n)) * 4;
+    if (workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15))
+      return fail(CMCD_ERR_WORKSPACE, "workspace too small or not 16-byte aligned (need %s%lld bytes)", "", need);
+    float* ws = static_cast<float*>(workspace);
+    float* traj = ws + fwd + gfl;
+    rc = forward_impl(desc, lay, seeds, n, params, n_params, target_consts, n_target, workspace, fwd * 4, out_loss,
+                      out_z, out_stats, traj, stream_);
+    if (rc != CMCD_OK) return rc;
+    rc = uha_grad_launch(d, *lay, w, n, params, n_params, ws, traj, ws + fwd, omega, grad, stream_);
     if (rc != CMCD_OK) return fail(rc, "gradient launch failed%s");
     return CMCD_OK;
   }

@@ -431,4 +431,743 @@ int uha_forward_launch(const cmcd_desc& d, const TrajArgs& ta, void* stream_) {
   return hipGetLastError() == hipSuccess ? CMCD_OK : CMCD_ERR_HIP;
 }
 
+// =============================================================================================================
+// The reparameterised gradient of MCD_CAIS_UHA_sn: d / d params_flat of L = omega sum_n loss_n, i.e. what
+// jax.grad(compute_bound, 1) (/root/reference/src/main.py:174-176) back-propagates through
+// /root/reference/src/mcd_under_lp_a_cais.py:42-88 — no stop_gradient anywhere in this mode.
+//
+// The forward launch keeps (z_e, rho_e) for e = 0..K and rho'_i for i = 0..K-1.  One wave per 16-particle tile walks the
+// bridges in reverse with the adjoints lz = dL/dz_e, lr = dL/drho_e in registers.  With r = rho - m_b,
+// g_b = dL/dm_b = -omega r / (2 eta) (w_i = -|r|^2 / (4 eta) + |n_i|^2 / 2: the two log sigma terms cancel and n_i is
+// the raw deviate):
+//
+//   point e (one target gradient + Hessian at z_e serves ub of bridge e-1 and uf of bridge e):
+//     adj_ub = -eps_{e-1}/2 lr,  adj_uf = -eps_e/2 arpp_e           (arpp_e = dL/drho''_e, carried from bridge e)
+//     a_gp = -beta_{e-1} adj_ub - beta_e adj_uf,  a_gq likewise with 1 - beta
+//     lz += H_p(z_e) (clipmask . a_gp) - a_gq / std_q^2  [- omega grad log p(z_K) at e = K, + omega grad log q(z_0) at e = 0]
+//   bridge i = e-1:
+//     arpp = lr + eps lz;   arp = arpp + (1 - eta) g_b;   cot(s2) = 2 eta g_b;   (dz, drho') = J_s([z; rho'])^T cot
+//     lz += dz;  arp += drho';   cot(s1) = -2 eta arp;   (dz, drho) = J_s([z; rho])^T cot
+//     lz += dz;  lr = (1 - eta) arp - g_b + drho
+//     dL/d eta = (2 s2 - rho').g_b - omega |r|^2 / (4 eta^2) + ((rho' - m_f) / (2 eta) - rho - 2 s1).arp
+//     dL/d eps_i = rho''.lz - (ub.lr + uf.arpp) / 2 + gamma dL/d eta;   dL/d gamma += eps_i dL/d eta
+//     dL/d beta_i = -(gpc - gq)(z_{i+1}).adj_ub - (gpc - gq)(z_i).adj_uf
+//
+// Mapping and parameter contractions as in cmcd_grad.hip: 4-wave workgroups, wave q on its own tile; every contraction
+// over particles is an fp32 MFMA outer product of [feature][particle] tiles staged in LDS (XOR-swizzled); the dW2 / dW3
+// accumulator row tiles are dealt to the waves; bias-like sums (first-layer bias-table row, residual row, b2) are DPP row
+// sums.  Per-workgroup slabs + a fixed-order reduce write grad_flat; the particle-independent tails (time coder /
+// embedding table / schedules) are cmcd_grad.hip's, fed with the same S / S2 / beta / eps tables.
+// =============================================================================================================
+struct UhaGradArgs {
+  const float* params;
+  const float* ws;        // forward workspace (prep tables + packed weights)
+  const float* traj;      // [3K+2][n][D] as left by uha_traj_kernel
+  float* gtab;            // zeroed: S [(K+1)][HP], S2 [(K+1)][HP], gbeta [K4], geps [K4]
+  float* slabs;
+  cmcd_layout lay;
+  WsLayout w;
+  int64_t n;
+  int32_t K, nquads;
+  float omega;
+  int64_t o_S, o_S2, o_gbeta, o_geps, slab_stride;
+};
+
+__device__ __forceinline__ int uha_sw(int f, int p) { return f * 16 + (p ^ (f & 15)); }
+
+template <int TARGET, int ARCH, int D, int T, int NW, bool WGLOBAL>
+__global__ __launch_bounds__(64 * NW) void uha_grad_kernel(UhaGradArgs a) {
+  constexpr int HP = 16 * T;
+  constexpr int DIN = 2 * D;
+  constexpr int XT = (DIN + 15) / 16;          // 16-row tiles of the staged network input
+  constexpr bool GEF = ARCH == CMCD_ARCH_GEFFNER;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int WLDS = WGLOBAL ? 0 : 2 * HP * HP;
+  float* lds_w2 = lds;                     // HP*HP   forward A fragments   (absent when WGLOBAL)
+  float* lds_w2t = lds + HP * HP;          // HP*HP   A fragments of W2^T
+  float* lds_w1z = lds + WLDS;             // DIN*HP
+  float* lds_w3t = lds_w1z + DIN * HP;     // D*HP
+  float* lds_b2 = lds_w3t + D * HP;        // HP
+  float* lds_b3 = lds_b2 + HP;             // 16
+  float* lds_tgt = lds_b3 + 16;            // tgt_floats
+  float* stage = lds_tgt + a.w.tgt_floats;
+  // per wave: u1T, u2T, da2T [HP][16] and doT [16][16] (read by every wave of the workgroup); da1T, du1T [16][16] and
+  // xT [XT*16][16] (this wave only); accZ1 [DIN][HP], accB2 [HP] (wave-private sums over evaluations)
+  constexpr int OFF_DOT = 3 * HP * 16;
+  constexpr int OFF_DA1 = OFF_DOT + 256;
+  constexpr int OFF_DU1 = OFF_DA1 + 256;
+  constexpr int OFF_X = OFF_DU1 + 256;
+  constexpr int OFF_ACC = OFF_X + XT * 256;
+  constexpr int STG = OFF_ACC + (DIN + 1) * HP;
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.ws + a.w.w1z);
+    f32x4* dst = reinterpret_cast<f32x4*>(lds_w1z);
+    for (int i = threadIdx.x; i < DIN * HP / 4; i += blockDim.x) dst[i] = src[i];
+    if (!WGLOBAL) {
+      src = reinterpret_cast<const f32x4*>(a.ws + a.w.w2);   // w2 and w2t are adjacent in the workspace
+      dst = reinterpret_cast<f32x4*>(lds_w2);
+      for (int i = threadIdx.x; i < 2 * HP * HP / 4; i += blockDim.x) dst[i] = src[i];
+    }
+    src = reinterpret_cast<const f32x4*>(a.ws + a.w.w3t);
+    dst = reinterpret_cast<f32x4*>(lds_w3t);
+    for (int i = threadIdx.x; i < D * HP / 4; i += blockDim.x) dst[i] = src[i];
+    for (int i = threadIdx.x; i < HP; i += blockDim.x) lds_b2[i] = a.ws[a.w.b2 + i];
+    for (int i = threadIdx.x; i < 16; i += blockDim.x) lds_b3[i] = a.ws[a.w.b3 + i];
+    for (int i = threadIdx.x; i < a.w.tgt_floats; i += blockDim.x) lds_tgt[i] = a.ws[a.w.tgt + i];
+  }
+  __syncthreads();
+
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  float* my = stage + wv * STG;
+  float* u1T = my;
+  float* u2T = my + HP * 16;
+  float* da2T = my + 2 * HP * 16;
+  float* doT = my + OFF_DOT;
+  float* da1T = my + OFF_DA1;
+  float* du1T = my + OFF_DU1;
+  float* xT = my + OFF_X;
+  float* accZ1 = my + OFF_ACC;             // [DIN][HP]
+  float* accB2 = accZ1 + DIN * HP;         // [HP]
+  for (int i = lane; i < (DIN + 1) * HP; i += 64) accZ1[i] = 0.f;
+  const int K = a.K;
+  const float factor = lds_b3[15];
+  int wb[4], rb[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    wb[r] = (4 * g + r) * 16 + (c ^ (4 * g + r));   // write base of register r:  feature 16 t + 4 g + r, particle c
+    rb[r] = c * 16 + ((4 * r + g) ^ c);             // read base of k-step r:     feature 16 t + c, particle 4 r + g
+  }
+  const float* w2f = WGLOBAL ? a.ws + a.w.w2 : lds_w2;
+  const float* w2tf = WGLOBAL ? a.ws + a.w.w2t : lds_w2t;
+
+  float qmean[D], qiv[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    qmean[j] = a.params[a.lay.vd_mean + j];
+    const float sd = expf(a.params[a.lay.vd_logdiag + j]);
+    qiv[j] = 1.0f / (sd * sd);
+  }
+  const float gamma = a.params[a.lay.gamma];
+  constexpr float clipv = 1e2f;
+  const float* bias1 = a.ws + a.w.bias1;
+  const float* utab = a.ws + a.w.utab;
+  float* gS = a.gtab + a.o_S;
+  float* gS2 = a.gtab + a.o_S2;
+  const float* tz = a.traj;
+  const float* trho = a.traj + (int64_t)(K + 1) * a.n * D;
+  const float* trhop = a.traj + (int64_t)(2 * K + 2) * a.n * D;
+
+  // persistent accumulators (C layout: lane (g, c), register r <-> row 16 tile + 4 g + r, column 16 tile' + c)
+  constexpr int OWN = (T + NW - 1) / NW;   // dW2 / dW3 row tiles owned by this wave: ti = wv + NW k < T
+  f32x4 gW2[OWN][T], gW3[OWN];
+#pragma unroll
+  for (int k = 0; k < OWN; ++k) {
+    gW3[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < T; ++t) gW2[k][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  float gfac = 0.f, ggam = 0.f, gmu[D], glam[D], gb3[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) { gmu[j] = 0.f; glam[j] = 0.f; gb3[j] = 0.f; }
+
+  for (int64_t quad = blockIdx.x; quad < a.nquads; quad += gridDim.x) {
+    const int64_t tile = quad * NW + wv;
+    const int64_t p = tile * 16 + c;
+    const bool valid = p < a.n;
+    const int64_t pc = valid ? p : a.n - 1;
+    const float om = valid ? a.omega : 0.f;
+
+    float lz[D], lr[D], arpp_c[D];   // dL/dz_e, dL/drho_e; dL/drho''_e of the bridge already walked (its uf side is pending)
+    float znext[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      lz[j] = 0.f;
+      lr[j] = om * trho[((int64_t)K * a.n + pc) * D + j];    // + log N(rho_K; 0, 1):  dL/drho_K = omega rho_K
+      arpp_c[j] = 0.f;
+      znext[j] = 0.f;
+    }
+
+    for (int e = K; e >= 0; --e) {
+      asm volatile("" ::: "memory");   // LDS contents are loop-invariant: keep the weights in LDS, not in hoisted registers
+      // ---------------------------------------------------------------- point e
+      float z[D], gp[D], gq[D], gpraw[D], logp;
+      constexpr int HN = Target<TARGET, D>::HN;
+      float hs[HN];
+#pragma unroll
+      for (int j = 0; j < D; ++j) z[j] = tz[((int64_t)e * a.n + pc) * D + j];
+      Target<TARGET, D>::eval_hess(z, g, lds_tgt, logp, gp, hs);
+      float a_gp[D], a_gq[D];
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        gq[j] = -(z[j] - qmean[j]) * qiv[j];
+        gpraw[j] = gp[j];
+        gp[j] = fminf(fmaxf(gp[j], -clipv), clipv);
+        a_gp[j] = 0.f;
+        a_gq[j] = 0.f;
+      }
+      if (e >= 1) {   // ub of bridge e - 1:  rho_e = rho'' - eps ub / 2
+        const float be = a.ws[a.w.beta + e - 1], ee = a.ws[a.w.eps + e - 1];
+        float sb = 0.f, se = 0.f;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          const float adj = -0.5f * ee * lr[j];
+          const float ub = -1.0f * (be * gp[j] + (1.0f - be) * gq[j]);
+          a_gp[j] -= be * adj;
+          a_gq[j] -= (1.0f - be) * adj;
+          sb -= (gp[j] - gq[j]) * adj;
+          se -= 0.5f * ub * lr[j];
+        }
+        const float tb = row_sum16(sb), te = row_sum16(se);
+        if (lane == 0) {
+          atomicAdd(a.gtab + a.o_gbeta + (e - 1), tb);
+          atomicAdd(a.gtab + a.o_geps + (e - 1), te);
+        }
+      }
+      if (e <= K - 1) {   // uf of bridge e:  rho'' = rho' - eps uf / 2
+        const float be = a.ws[a.w.beta + e], ee = a.ws[a.w.eps + e];
+        float sb = 0.f, se = 0.f;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          const float adj = -0.5f * ee * arpp_c[j];
+          const float uf = -1.0f * (be * gp[j] + (1.0f - be) * gq[j]);
+          a_gp[j] -= be * adj;
+          a_gq[j] -= (1.0f - be) * adj;
+          sb -= (gp[j] - gq[j]) * adj;
+          se -= 0.5f * uf * arpp_c[j];
+        }
+        const float tb = row_sum16(sb), te = row_sum16(se);
+        if (lane == 0) {
+          atomicAdd(a.gtab + a.o_gbeta + e, tb);
+          atomicAdd(a.gtab + a.o_geps + e, te);
+        }
+      }
+      {
+        float v[D], hv[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          if (e == K) lz[j] -= om * gpraw[j];                    // + log p(z_K), unclipped   mcdboundingmachine.py:178
+          if (e == 0) lz[j] += om * gq[j];                       // - log q(z_0) in w  ->  + omega log q in L
+          v[j] = fabsf(gpraw[j]) < clipv ? a_gp[j] : 0.f;        // jnp.clip passes no gradient outside its bounds
+          gmu[j] += a_gq[j] * qiv[j];
+          glam[j] += a_gq[j] * (-2.0f * gq[j]);
+        }
+        Target<TARGET, D>::hvp(hs, z, v, hv);
+#pragma unroll
+        for (int j = 0; j < D; ++j) lz[j] += hv[j] - a_gq[j] * qiv[j];   // H_q = -diag(1 / std^2)
+      }
+      if (e == 0) {   // z_0 = mean + std e0 and the explicit parameters of log q(z_0)
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          const float dz = z[j] - qmean[j];
+          gmu[j] += lz[j] - om * gq[j];
+          glam[j] += lz[j] * dz + om * (dz * dz * qiv[j] - 1.0f);
+        }
+        break;
+      }
+#pragma unroll
+      for (int j = 0; j < D; ++j) znext[j] = z[j];
+
+      // ---------------------------------------------------------------- bridge i = e - 1
+      const int i = e - 1;
+      const float eps = a.ws[a.w.eps + i];
+      const float eta = gamma * eps, ome = 1.0f - eta, inv2eta = 0.5f / eta;
+      float rho[D], rhop[D], arp[D], gb[D], lrn[D];
+      float geta = 0.f, gepsd = 0.f;
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        z[j] = tz[((int64_t)i * a.n + pc) * D + j];
+        rho[j] = trho[((int64_t)i * a.n + pc) * D + j];
+        rhop[j] = trhop[((int64_t)i * a.n + pc) * D + j];
+        arp[j] = lr[j] + eps * lz[j];                            // dL/drho'' = dL/drho'
+        arpp_c[j] = arp[j];
+        gepsd += ((znext[j] - z[j]) / eps) * lz[j];              // z' = z + eps rho''
+        gb[j] = 0.f;
+        lrn[j] = 0.f;
+      }
+      const int64_t erow = i;
+      const float* brow = bias1 + erow * HP;
+
+      for (int pass = 0; pass < 2; ++pass) {   // pass 0: s2 = s([z; rho'], i) (backward kernel); pass 1: s1 = s([z; rho], i)
+        asm volatile("" ::: "memory");
+        float rin[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) rin[j] = pass == 0 ? rhop[j] : rho[j];
+        // ------------------------------------------------------------ forward (keeps the activation derivatives)
+        constexpr bool KEEP_A1 = T <= 4;
+        f32x4 a1[KEEP_A1 ? T : 1], u1[T], a2[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          f32x4 pre = *reinterpret_cast<const f32x4*>(brow + 16 * t + 4 * g);
+#pragma unroll
+          for (int j = 0; j < D; ++j) {
+            pre += z[j] * *reinterpret_cast<const f32x4*>(lds_w1z + j * HP + 16 * t + 4 * g);
+            pre += rin[j] * *reinterpret_cast<const f32x4*>(lds_w1z + (D + j) * HP + 16 * t + 4 * g);
+          }
+          f32x4 dact = {0.f, 0.f, 0.f, 0.f};
+          if (!GEF) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float dv = 0.f;
+              u1[t][r] = KEEP_A1 ? gelu_fast_both(pre[r], dv) : gelu_fast(pre[r]);
+              dact[r] = dv;
+            }
+          } else {
+            f32x4 u = *reinterpret_cast<const f32x4*>(utab + erow * HP + 16 * t + 4 * g);
+            if (16 * t < DIN) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int nidx = 16 * t + 4 * g + r;
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                  if (j >= 16 * t && j < 16 * t + 16) u[r] = (nidx == j) ? z[j] : u[r];
+                  if (D + j >= 16 * t && D + j < 16 * t + 16) u[r] = (nidx == D + j) ? rin[j] : u[r];
+                }
+              }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float dv = 0.f;
+              u1[t][r] = u[r] + (KEEP_A1 ? softplus_both(pre[r], dv) : softplus(pre[r]));
+              dact[r] = dv;
+            }
+          }
+          if (KEEP_A1) a1[KEEP_A1 ? t : 0] = dact;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) u1T[wb[r] + 256 * t] = u1[t][r];
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) a2[t] = *reinterpret_cast<const f32x4*>(lds_b2 + 16 * t + 4 * g);
+        {
+          f32x4 afn[T];
+          {
+            int lofs = lane * 4;
+            asm volatile("" : "+v"(lofs));
+#pragma unroll
+            for (int to = 0; to < T; ++to) afn[to] = *reinterpret_cast<const f32x4*>(w2f + to * 256 + lofs);
+          }
+#pragma unroll
+          for (int ti = 0; ti < T; ++ti) {
+            asm volatile("" ::: "memory");
+            int lofs = lane * 4;
+            asm volatile("" : "+v"(lofs));
+            f32x4 afc[T];
+#pragma unroll
+            for (int to = 0; to < T; ++to) afc[to] = afn[to];
+            if (ti + 1 < T) {
+#pragma unroll
+              for (int to = 0; to < T; ++to) afn[to] = *reinterpret_cast<const f32x4*>(w2f + ((ti + 1) * T + to) * 256 + lofs);
+            }
+            if (WGLOBAL) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int to = 0; to < T; ++to) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) a2[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(afc[to][r], u1[ti][r], a2[to], 0, 0, 0);
+            }
+          }
+        }
+        float opre[D], sn[D];
+        {
+          float part[D];
+#pragma unroll
+          for (int j = 0; j < D; ++j) part[j] = 0.f;
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            f32x4 u2t;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float dact2;
+              u2t[r] = GEF ? u1[t][r] + softplus_both(a2[t][r], dact2) : gelu_fast_both(a2[t][r], dact2);
+              a2[t][r] = dact2;
+              u2T[wb[r] + 256 * t] = u2t[r];
+            }
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+              const f32x4 wv4 = *reinterpret_cast<const f32x4*>(lds_w3t + j * HP + 16 * t + 4 * g);
+              part[j] += u2t[0] * wv4[0] + u2t[1] * wv4[1] + u2t[2] * wv4[2] + u2t[3] * wv4[3];
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < D; ++j) {
+            opre[j] = group_sum(part[j]) + lds_b3[j];
+            sn[j] = GEF ? opre[j] * factor : fminf(fmaxf(opre[j], -1e4f), 1e4f);
+          }
+        }
+        // ------------------------------------------------------------ cotangent of this evaluation
+        float cot[D];
+        if (pass == 0) {
+          float r2 = 0.f;
+#pragma unroll
+          for (int j = 0; j < D; ++j) {
+            const float mb = rhop[j] * ome + 2.0f * eta * sn[j];
+            const float r = rho[j] - mb;
+            gb[j] = -om * r * inv2eta;                            // dL/dm_b
+            arp[j] += ome * gb[j];
+            cot[j] = 2.0f * eta * gb[j];
+            geta += (2.0f * sn[j] - rhop[j]) * gb[j];
+            r2 += r * r;
+          }
+          geta -= om * r2 * inv2eta * inv2eta;
+        } else {
+#pragma unroll
+          for (int j = 0; j < D; ++j) {
+            const float mf = rho[j] * ome - 2.0f * eta * sn[j];
+            cot[j] = -2.0f * eta * arp[j];
+            geta += ((rhop[j] - mf) * inv2eta - rho[j] - 2.0f * sn[j]) * arp[j];   // sigma n / sigma^2 = (rho' - m_f) / (2 eta)
+            lrn[j] = ome * arp[j] - gb[j];
+          }
+        }
+        // ------------------------------------------------------------ MLP backward
+        asm volatile("" ::: "memory");
+        float dob[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          if (GEF) {
+            dob[j] = cot[j] * factor;
+            if (g == 0) gfac += cot[j] * opre[j];
+          } else {
+            dob[j] = fabsf(opre[j]) < 1e4f ? cot[j] : 0.f;
+          }
+          if (g == 0) gb3[j] += dob[j];
+        }
+        f32x4 d2[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          f32x4 du2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < D; ++j) du2 += dob[j] * *reinterpret_cast<const f32x4*>(lds_w3t + j * HP + 16 * t + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            d2[t][r] = du2[r] * a2[t][r];
+            da2T[wb[r] + 256 * t] = d2[t][r];
+            const float s = row_sum16(d2[t][r]);                  // db2[n] += sum over the tile's particles
+            if (c == 0) accB2[16 * t + 4 * g + r] += s;
+          }
+          if (GEF) a2[t] = du2;  // keep d u2 (residual path)
+        }
+        f32x4 d1[T];
+#pragma unroll
+        for (int tk = 0; tk < T; ++tk) d1[tk] = GEF ? a2[tk] : f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+          f32x4 atn[T];
+          {
+            int lofs = lane * 4;
+            asm volatile("" : "+v"(lofs));
+#pragma unroll
+            for (int tk = 0; tk < T; ++tk) atn[tk] = *reinterpret_cast<const f32x4*>(w2tf + (tk * T) * 256 + lofs);
+          }
+#pragma unroll
+          for (int tn = 0; tn < T; ++tn) {
+            asm volatile("" ::: "memory");
+            int lofs = lane * 4;
+            asm volatile("" : "+v"(lofs));
+            f32x4 atc[T];
+#pragma unroll
+            for (int tk = 0; tk < T; ++tk) atc[tk] = atn[tk];
+            if (tn + 1 < T) {
+#pragma unroll
+              for (int tk = 0; tk < T; ++tk) atn[tk] = *reinterpret_cast<const f32x4*>(w2tf + (tk * T + tn + 1) * 256 + lofs);
+            }
+            if (WGLOBAL) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tk = 0; tk < T; ++tk) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) d1[tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(atc[tk][r], d2[tn][r], d1[tk], 0, 0, 0);
+            }
+          }
+        }
+        // the two small tiles: network input [z; rin] and d o
+#pragma unroll
+        for (int xt = 0; xt < XT; ++xt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int f = 16 * xt + 4 * g + r;
+            float xv = 0.f;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+              xv = (f == j) ? z[j] : xv;
+              xv = (f == D + j) ? rin[j] : xv;
+            }
+            xT[wb[r] + 256 * xt] = xv;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = 4 * g + r;
+          float dv = 0.f;
+#pragma unroll
+          for (int j = 0; j < D; ++j) dv = (f == j) ? dob[j] : dv;
+          doT[wb[r]] = dv;
+        }
+        float xa_own[XT][4];
+#pragma unroll
+        for (int xt = 0; xt < XT; ++xt)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) xa_own[xt][s] = xT[rb[s] + 256 * xt];
+        float jpart[DIN];   // J_s^T cot, this lane's share of the hidden units
+#pragma unroll
+        for (int j = 0; j < DIN; ++j) jpart[j] = 0.f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          f32x4 pre1;
+          if (KEEP_A1) {
+            pre1 = a1[KEEP_A1 ? t : 0];
+          } else {
+            pre1 = *reinterpret_cast<const f32x4*>(brow + 16 * t + 4 * g);
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+              pre1 += z[j] * *reinterpret_cast<const f32x4*>(lds_w1z + j * HP + 16 * t + 4 * g);
+              pre1 += rin[j] * *reinterpret_cast<const f32x4*>(lds_w1z + (D + j) * HP + 16 * t + 4 * g);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (GEF) {
+              du1T[wb[r]] = d1[t][r];
+              const float s2v = row_sum16(d1[t][r]);              // residual row: sum_p d u1  (-> d emb)
+              if (c == 0) atomicAdd(gS2 + erow * HP + 16 * t + 4 * g + r, s2v);
+              if (16 * t < DIN) {                                 // residual path of the first block: d x_j += d u1_j
+#pragma unroll
+                for (int j = 0; j < DIN; ++j)
+                  if (j >= 16 * t && j < 16 * t + 16) jpart[j] += (16 * t + 4 * g + r == j) ? d1[t][r] : 0.f;
+              }
+            }
+            d1[t][r] *= KEEP_A1 ? pre1[r] : (GEF ? sigmoid_fast(pre1[r]) : gelu_grad_fast(pre1[r]));
+            da1T[wb[r]] = d1[t][r];
+            const float s1v = row_sum16(d1[t][r]);                // d / d bias-table row i
+            if (c == 0) atomicAdd(gS + erow * HP + 16 * t + 4 * g + r, s1v);
+          }
+#pragma unroll
+          for (int j = 0; j < DIN; ++j) {
+            const f32x4 wv4 = *reinterpret_cast<const f32x4*>(lds_w1z + j * HP + 16 * t + 4 * g);
+            jpart[j] += d1[t][0] * wv4[0] + d1[t][1] * wv4[1] + d1[t][2] * wv4[2] + d1[t][3] * wv4[3];
+          }
+          // this wave's own outer products for tile t (same wave: the LDS queue is in order, no barrier): dW1[:2d]
+#pragma unroll
+          for (int xt = 0; xt < XT; ++xt) {
+            f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa_own[xt][s4], da1T[rb[s4]], sacc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = 16 * xt + 4 * g + r;
+              if (row < DIN) accZ1[row * HP + 16 * t + c] += sacc[r];
+            }
+          }
+          asm volatile("" ::: "memory");   // the next tile's stores stay behind these reads
+        }
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          lz[j] += group_sum(jpart[j]);
+          const float dr = group_sum(jpart[D + j]);
+          if (pass == 0) arp[j] += dr; else lrn[j] += dr;
+        }
+        __syncthreads();
+        // ------------------------------------------------------------ outer products over particles (all tiles of the workgroup)
+#pragma unroll
+        for (int k = 0; k < OWN; ++k) {
+          const int ti = wv + NW * k;
+          if (ti < T) {
+#pragma unroll
+            for (int q = 0; q < NW; ++q) {
+              const float* base = stage + q * STG;
+              float xa[4], x2[4];
+#pragma unroll
+              for (int s = 0; s < 4; ++s) {
+                xa[s] = base[rb[s] + 256 * ti];                 // u1T
+                x2[s] = base[HP * 16 + rb[s] + 256 * ti];       // u2T
+              }
+#pragma unroll
+              for (int to = 0; to < T; ++to)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                  gW2[k][to] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], base[2 * HP * 16 + rb[s] + 256 * to], gW2[k][to], 0, 0, 0);
+#pragma unroll
+              for (int s = 0; s < 4; ++s) gW3[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(x2[s], base[OFF_DOT + rb[s]], gW3[k], 0, 0, 0);
+            }
+          }
+        }
+        __syncthreads();
+      }
+#pragma unroll
+      for (int j = 0; j < D; ++j) lr[j] = lrn[j];
+      {
+        ggam += eps * geta;
+        const float te = row_sum16(gepsd + gamma * geta);
+        if (lane == 0) atomicAdd(a.gtab + a.o_geps + i, te);
+      }
+    }
+  }
+
+  // ---------------------------------------------------------------- write the workgroup slab
+  // layout: dW2 [HP][HP] | dW3 [HP][16] | per wave: dW1x [DIN][HP], db2 [HP], scalars [64]: gfac, ggam, gmu[D], glam[D], gb3[D]
+  float* slab = a.slabs + (int64_t)blockIdx.x * a.slab_stride;
+#pragma unroll
+  for (int k = 0; k < OWN; ++k) {
+    const int ti = wv + NW * k;
+    if (ti < T) {
+#pragma unroll
+      for (int to = 0; to < T; ++to)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[(16 * ti + 4 * g + r) * HP + 16 * to + c] = gW2[k][to][r];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) slab[HP * HP + (16 * ti + 4 * g + r) * 16 + c] = gW3[k][r];
+    }
+  }
+  float* pw = slab + HP * HP + HP * 16 + wv * ((DIN + 1) * HP + 64);
+  for (int i = lane; i < (DIN + 1) * HP; i += 64) pw[i] = accZ1[i];   // dW1x rows, then db2
+  {
+    float* sc = pw + (DIN + 1) * HP;
+    const float tf = row_sum16(gfac), tg = row_sum16(g == 0 ? ggam : 0.f);
+    if (lane == 0) { sc[0] = tf; sc[1] = tg; }
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const float tm = row_sum16(gmu[j]), tl = row_sum16(glam[j]), t3 = row_sum16(gb3[j]);
+      if (lane == 0) { sc[2 + j] = tm; sc[2 + D + j] = tl; sc[2 + 2 * D + j] = t3; }
+    }
+  }
+}
+
+// fixed-order sum of the slabs into grad_flat: one thread per output entry
+struct UhaReduceArgs {
+  const float* slabs;
+  float* grad;
+  cmcd_layout lay;
+  int64_t slab_stride;
+  int32_t nslabs, nw, HP, D, wid, arch;
+};
+
+__global__ __launch_bounds__(256) void uha_reduce_kernel(UhaReduceArgs a) {
+  const int HP = a.HP, D = a.D, DIN = 2 * D, wid = a.wid;
+  const bool dds = a.arch == CMCD_ARCH_DDS;
+  const int64_t o_w1 = dds ? a.lay.d_sw1 : a.lay.g_w1, o_w2 = dds ? a.lay.d_sw2 : a.lay.g_w2;
+  const int64_t o_b2 = dds ? a.lay.d_sb2 : a.lay.g_b2, o_w3 = dds ? a.lay.d_sw3 : a.lay.g_w3;
+  const int64_t o_b3 = dds ? a.lay.d_sb3 : a.lay.g_b3;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t per = (int64_t)(DIN + 1) * HP + 64, base = (int64_t)HP * HP + HP * 16;
+  int64_t dst = -1, off = 0;
+  bool perwave = false;
+  if (i < (int64_t)wid * wid) {                                   // dW2[k][n]
+    dst = o_w2 + i; off = (i / wid) * HP + (i % wid);
+  } else if ((i -= (int64_t)wid * wid) < (int64_t)wid * D) {      // dW3[n][j]
+    dst = o_w3 + i; off = (int64_t)HP * HP + (i / D) * 16 + (i % D);
+  } else if ((i -= (int64_t)wid * D) < (int64_t)DIN * wid) {      // dW1[j][n], j < 2 D ([z; rho] rows)
+    dst = o_w1 + i; off = (i / wid) * HP + (i % wid); perwave = true;
+  } else if ((i -= (int64_t)DIN * wid) < wid) {                   // db2
+    dst = o_b2 + i; off = (int64_t)DIN * HP + i; perwave = true;
+  } else if ((i -= wid) < D) {                                    // db3
+    dst = o_b3 + i; off = (int64_t)(DIN + 1) * HP + 2 + 2 * D + i; perwave = true;
+  } else if ((i -= D) < D) {                                      // d vd.mean
+    dst = a.lay.vd_mean + i; off = (int64_t)(DIN + 1) * HP + 2 + i; perwave = true;
+  } else if ((i -= D) < D) {                                      // d vd.logdiag
+    dst = a.lay.vd_logdiag + i; off = (int64_t)(DIN + 1) * HP + 2 + D + i; perwave = true;
+  } else if ((i -= D) < 1) {                                      // d gamma
+    dst = a.lay.gamma; off = (int64_t)(DIN + 1) * HP + 1; perwave = true;
+  } else if ((i -= 1) < 1 && !dds) {                              // d factor_sn
+    dst = a.lay.g_factor; off = (int64_t)(DIN + 1) * HP; perwave = true;
+  }
+  if (dst < 0) return;
+  float v = 0.f;
+  if (!perwave) {
+    for (int sl = 0; sl < a.nslabs; ++sl) v += a.slabs[(int64_t)sl * a.slab_stride + off];
+  } else {
+    for (int sl = 0; sl < a.nslabs; ++sl)
+      for (int q = 0; q < a.nw; ++q) v += a.slabs[(int64_t)sl * a.slab_stride + base + q * per + off];
+  }
+  a.grad[dst] = v;
+}
+
+typedef void (*uha_grad_fn)(UhaGradArgs);
+constexpr int kUhaNW = 4;
+
+template <int TARGET, int ARCH, int D>
+static uha_grad_fn uha_grad_pick_T(int T) {
+  switch (T) {
+    case 2: return uha_grad_kernel<TARGET, ARCH, D, 2, kUhaNW, false>;
+    case 4: return uha_grad_kernel<TARGET, ARCH, D, 4, kUhaNW, false>;
+    case 5: return uha_grad_kernel<TARGET, ARCH, D, 5, kUhaNW, true>;
+    case 9: return uha_grad_kernel<TARGET, ARCH, D, 9, kUhaNW, true>;
+    default: return nullptr;
+  }
+}
+
+static uha_grad_fn uha_grad_pick(const cmcd_desc& d, int T) {
+  if (d.arch == CMCD_ARCH_DDS) {
+    if (T != 4) return nullptr;
+    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2) return uha_grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_DDS, 2, 4, kUhaNW, false>;
+    if (d.target == CMCD_TARGET_GMM && d.dim == 2) return uha_grad_kernel<CMCD_TARGET_GMM, CMCD_ARCH_DDS, 2, 4, kUhaNW, false>;
+    if (d.target == CMCD_TARGET_FUNNEL && d.dim == 10) return uha_grad_kernel<CMCD_TARGET_FUNNEL, CMCD_ARCH_DDS, 10, 4, kUhaNW, false>;
+    return nullptr;
+  }
+  if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2) return uha_grad_pick_T<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2>(T);
+  if (d.target == CMCD_TARGET_GMM && d.dim == 2) return uha_grad_pick_T<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER, 2>(T);
+  if (d.target == CMCD_TARGET_FUNNEL && d.dim == 10) return uha_grad_pick_T<CMCD_TARGET_FUNNEL, CMCD_ARCH_GEFFNER, 10>(T);
+  return nullptr;
+}
+
+bool uha_grad_available(const cmcd_desc& d, int T) { return uha_grad_pick(d, T) != nullptr; }
+
+static void uha_grad_offsets(const cmcd_desc& d, int HP, int64_t& o_S, int64_t& o_S2, int64_t& o_gbeta, int64_t& o_geps,
+                             int64_t& total) {
+  const int64_t K = d.nbridges, K4 = (K + 3) & ~int64_t(3);
+  int64_t o = 0;
+  o_S = o; o += (K + 1) * HP;
+  o_S2 = o; o += (K + 1) * HP;
+  o_gbeta = o; o += K4;
+  o_geps = o; o += K4;
+  total = o;
+}
+static int64_t uha_slab_floats(const cmcd_desc& d, int HP) {
+  return (int64_t)HP * HP + HP * 16 + kUhaNW * ((int64_t)(2 * d.dim + 1) * HP + 64);
+}
+static int64_t uha_dds_tail_floats(const cmcd_desc& d) { return d.arch == CMCD_ARCH_DDS ? (int64_t)(d.nbridges + 1) * 448 : 0; }
+
+int64_t uha_grad_workspace_floats(const cmcd_desc& d, int HP, int64_t n) {
+  int64_t oS, oS2, ob, oe, tot;
+  uha_grad_offsets(d, HP, oS, oS2, ob, oe, tot);
+  return tot + uha_dds_tail_floats(d) + uha_slab_floats(d, HP) * 256;
+}
+
+// ws_fwd / traj as left by the forward launch on the SAME desc / params; gws: uha_grad_workspace_floats; grad: [n_params],
+// fully overwritten (zeros for the leaves the loss does not reach).
+int uha_grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, int64_t n, const float* params,
+                    int64_t n_params, const float* ws_fwd, const float* traj, float* gws, float omega, float* grad,
+                    void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  uha_grad_fn fn = uha_grad_pick(d, w.T);
+  if (!fn || !traj) return CMCD_ERR_UNSUPPORTED;
+  const int D = d.dim, HP = w.HP, K = d.nbridges, DIN = 2 * D, XT = (DIN + 15) / 16;
+  UhaGradArgs ga{};
+  int64_t tot;
+  uha_grad_offsets(d, HP, ga.o_S, ga.o_S2, ga.o_gbeta, ga.o_geps, tot);
+  const int nw = kUhaNW;
+  const int64_t nquads = (n + 16 * nw - 1) / (16 * nw);
+  const int nslabs = (int)(nquads < 256 ? nquads : 256);
+  float* tailbuf = gws + tot;
+  float* slabs = tailbuf + uha_dds_tail_floats(d);
+  ga.params = params; ga.ws = ws_fwd; ga.traj = traj; ga.gtab = gws; ga.slabs = slabs; ga.lay = lay; ga.w = w; ga.n = n;
+  ga.K = K; ga.nquads = (int)nquads; ga.omega = omega; ga.slab_stride = uha_slab_floats(d, HP);
+  if (hipMemsetAsync(gws, 0, sizeof(float) * tot, stream) != hipSuccess) return CMCD_ERR_HIP;
+  if (hipMemsetAsync(grad, 0, sizeof(float) * n_params, stream) != hipSuccess) return CMCD_ERR_HIP;
+  const bool wglobal = w.T > 4;
+  const size_t stg = size_t(3 * HP * 16 + 3 * 256 + XT * 256 + (DIN + 1) * HP);
+  const size_t lds_bytes = size_t((wglobal ? 0 : 2 * HP * HP) + DIN * HP + D * HP + HP + 16 + w.tgt_floats + nw * stg) * 4;
+  if (lds_bytes > 160 * 1024) return CMCD_ERR_UNSUPPORTED;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)lds_bytes) != hipSuccess)
+    return CMCD_ERR_HIP;
+  hipLaunchKernelGGL(fn, dim3(nslabs), dim3(64 * nw), lds_bytes, stream, ga);
+
+  UhaReduceArgs ra{};
+  ra.slabs = slabs; ra.grad = grad; ra.lay = lay; ra.slab_stride = ga.slab_stride; ra.nslabs = nslabs; ra.nw = nw;
+  ra.HP = HP; ra.D = D; ra.wid = d.arch == CMCD_ARCH_DDS ? 64 : DIN + d.emb_dim; ra.arch = d.arch;
+  const int64_t outs = (int64_t)ra.wid * ra.wid + (int64_t)ra.wid * D + (int64_t)DIN * ra.wid + ra.wid + 3 * D + 2;
+  hipLaunchKernelGGL(uha_reduce_kernel, dim3((unsigned)((outs + 255) / 256)), dim3(256), 0, stream, ra);
+  // the particle-independent tails: schedules (cos^2 always), time coder / embedding table with the network's state
+  // inputs = 2 dim wide
+  const int rc = launch_net_tails(d, DIN, CMCD_EPS_COS_SQ, lay, w, params, gws, ga.o_S, ga.o_S2, ga.o_gbeta, ga.o_geps, HP,
+                                  tailbuf, grad, stream_);
+  if (rc != CMCD_OK) return rc;
+  return hipGetLastError() == hipSuccess ? CMCD_OK : CMCD_ERR_HIP;
+}
+
 }  // namespace cmcd

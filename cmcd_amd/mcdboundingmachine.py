@@ -377,7 +377,8 @@ def compute_bound_grad(seeds, params_flat, unflatten, params_fixed, log_prob, ep
     Returns (grad_flat, (losses, z)) [+ stats with return_stats]; multi-GPU: pass the global particle count
     as `n_total` and all-reduce the returned gradient."""
     dim, nbridges, mode, spec = params_fixed
-    if mode not in ("MCD_CAIS_sn", "MCD_ULA_sn", "MCD_ULA"):   # the two overdamped baselines take the same call
+    # the two overdamped baselines and 2nd-order CMCD (no stop_gradient either) take the same call
+    if mode not in ("MCD_CAIS_sn", "MCD_ULA_sn", "MCD_ULA", "MCD_CAIS_UHA_sn"):
         raise NotImplementedError("Mode not implemented.")
     if mode == "MCD_ULA":
         spec = ScoreNet("dds", dim, 64, 0, 64)   # placeholder: MCD_ULA has no network (apply_fun_sn is None)

@@ -24,6 +24,8 @@ def oracle_grad_flat(b, seeds):
     t = lambda a: torch.as_tensor(np.asarray(a))
     allp["vd"]["mean"].copy_(t(g["vd"]["mean"])); allp["vd"]["logdiag"].copy_(t(g["vd"]["logdiag"]))
     allp["eps"].copy_(t(g["eps"])); allp["mgridref_y"].copy_(t(g["mgridref_y"]))
+    if "gamma" in g:   # MCD_CAIS_UHA_sn's friction (zero gradient in every other mode)
+        allp["gamma"].copy_(t(g["gamma"]))
     sn, gs = allp["sn"], g["sn"]
     if "nn" in sn:
         (w1, b1), (w2, b2), (w3, b3) = sn["nn"]

@@ -99,3 +99,63 @@ def test_key_chain_and_deviates_are_bit_exact(hip_lib, name, n, K):
     assert np.array_equal(bits.cpu().numpy().view(np.uint32), rb), "random_bits of the normal draws differ from jax's"
     d = ulp_distance(noise.cpu().numpy(), rd)
     assert d.max() <= 4, f"deviates differ by up to {d.max()} ulp"
+
+
+# ---------------------------------------------------------------------------------------------- gradient
+GRAD_CASES = [
+    ("gmm_n300_k8", 128, {}),                                                               # geffner 24 (2 tiles)
+    ("gmm_n300_k8", 64, dict(nn_arch="dds", init_gamma=3.0)),                               # dds on d = 2
+    ("many_gmm_n2000_k256_dds", 96, dict(nbridges=8, init_eps=0.2, init_gamma=2.0, init_sigma=15.0)),
+    ("many_gmm_n2000_k256_dds", 40, dict(nbridges=24, init_eps=0.1, init_gamma=3.0, init_sigma=15.0)),   # longer chain
+    ("funnel_n300_k64", 70, dict(nbridges=6, init_eps=0.05, init_gamma=4.0)),               # d = 10, geffner 68 (5 tiles)
+    ("funnel_n300_k64", 40, dict(nbridges=5, nn_arch="dds", init_eps=0.05)),                # d = 10: two input tiles
+    ("funnel_n300_k64", 40, dict(nbridges=4, emb_dim=20, init_eps=0.05)),                   # width 40 -> 64
+    ("many_gmm_var_n16000_k256", 80, dict(nbridges=5, init_eps=0.1, init_gamma=3.0)),       # geffner 134 (9 tiles)
+    ("gmm_n300_k8", 50, dict(emb_dim=40, nbridges=5)),                                      # width 44 -> 64
+    ("gmm_n300_k8", 300, dict(nbridges=3)),                                                 # 19 tiles: five workgroups, ragged
+]
+
+
+@pytest.mark.parametrize("name,n,over", GRAD_CASES)
+def test_reparameterised_gradient_matches_autograd(hip_lib, param_set, name, n, over):
+    """jax.grad(compute_bound, 1) (/root/reference/src/main.py:174-176) through mcd_under_lp_a_cais.py:42-88: every leaf of
+    params_flat (network, eps, gamma, q, mgridref_y) against torch-autograd through the float64 restatement."""
+    from test_gpu_grad import _compare, oracle_grad_flat
+    b = synthetic.build(name, device="cuda", boundmode=MODE, **over)
+    seeds = synthetic.parity_seeds(n)
+    grad, (losses, z) = mcdbm.compute_bound_grad(torch.from_numpy(seeds).cuda(), b["params_flat"], b["unflatten"],
+                                                 b["params_fixed"], b["target"], eps_schedule=b["eps_schedule"],
+                                                 grad_clipping=b["grad_clipping"])
+    torch.cuda.synchronize()
+    val, l_ref, g_ref = oracle_grad_flat(b, seeds)
+    assert np.isfinite(l_ref).all(), "pick a case without +inf particles for the gradient check"
+    np.testing.assert_allclose(losses.double().cpu().numpy(), l_ref, rtol=2e-3, atol=2e-3)
+    _compare(name, over, b["unflatten"], grad.double().cpu(), g_ref)
+    assert float(g_ref[b["unflatten"].offset("gamma")].abs()) > 0     # the friction is a trained leaf in this mode
+
+
+def test_gradient_shards_add_up(hip_lib):
+    """Multi-GPU contract: shards called with the global particle count sum to the single-call gradient."""
+    b = synthetic.build("gmm_n300_k8", device="cuda", boundmode=MODE, dense=True)
+    seeds = torch.from_numpy(synthetic.parity_seeds(200)).cuda()
+    args = (b["params_flat"], b["unflatten"], b["params_fixed"], b["target"])
+    g_all, _ = mcdbm.compute_bound_grad(seeds, *args)
+    g_a, _ = mcdbm.compute_bound_grad(seeds[:120], *args, n_total=200)
+    g_b, _ = mcdbm.compute_bound_grad(seeds[120:], *args, n_total=200)
+    torch.testing.assert_close(g_a + g_b, g_all, rtol=2e-4, atol=2e-6 * float(g_all.abs().max()))
+
+
+def test_training_lowers_the_loss(hip_lib):
+    """opt.run on the 2nd-order mode: Adam on the HIP gradient lowers the mean loss on fresh seeds."""
+    from cmcd_amd import opt
+    import types
+    b = synthetic.build("funnel_n300_k64", device="cuda", boundmode=MODE, nbridges=8, init_eps=0.05, init_gamma=4.0)
+    grad_and_loss, loss_fn = mcdbm.make_grad_and_loss(MODE)
+    ev = torch.from_numpy(synthetic.throughput_seeds(2000, stream=9)).cuda()
+    before = float(loss_fn(ev, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"])[0])
+    trainable = ("eta", "gamma", "eps", "vd", "mgridref_y")
+    _, out, _ = opt.run(types.SimpleNamespace(N=300), 1e-3, 600, b["params_flat"].clone(), b["unflatten"], b["params_fixed"],
+                        b["target"], grad_and_loss, trainable, 0)
+    after = float(loss_fn(ev, out, b["unflatten"], b["params_fixed"], b["target"])[0])
+    print("UHA funnel K=8 mean loss", before, "->", after)
+    assert after < before - 0.2
