@@ -977,8 +977,6 @@ static int check_desc(const cmcd_desc* d) {
   if (d->target == CMCD_TARGET_LGCP) {
     if ((d->arch != CMCD_ARCH_GEFFNER && d->mode != CMCD_MODE_ULA) || d->dim < 4 || d->dim > 4096)
       return fail(CMCD_ERR_UNSUPPORTED, "lgcp runs with the geffner net only%s");
-    if (d->mode == CMCD_MODE_CAIS_UHA_SN)
-      return fail(CMCD_ERR_UNSUPPORTED, "MCD_CAIS_UHA_sn on lgcp: not built yet%s");
     return CMCD_OK;
   }
   if (d->mode == CMCD_MODE_CAIS_UHA_SN) {
@@ -1082,6 +1080,7 @@ static int forward_impl(const cmcd_desc* desc, const cmcd_layout* lay, const int
     // the overdamped baselines: constant eps, no clipping (the reference's dispatcher passes neither, mcd_utils.py:35-58)
     cmcd_desc dl = d;
     if (d.mode == CMCD_MODE_ULA || d.mode == CMCD_MODE_ULA_SN) { dl.eps_schedule = CMCD_EPS_CONST; dl.grad_clipping = 0; }
+    if (uha) { dl.eps_schedule = CMCD_EPS_COS_SQ; dl.grad_clipping = 1; }   // fixed by the function body (mcd_under_lp_a_cais.py:23-48)
     SchedArgs sa{params, wsf, *lay, lw, (int32_t)K, d.ngrid, dl.eps_schedule, -1, -1};
     hipLaunchKernelGGL(prep_sched_kernel, dim3(1), dim3(256), 0, st, sa);
     double* partials = nullptr;

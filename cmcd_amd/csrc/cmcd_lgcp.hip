@@ -806,7 +806,17 @@ static LgcpWs lgcp_ws(const cmcd_desc& d, int64_t n, int64_t base) {
   return w;
 }
 
-int64_t lgcp_workspace_floats(const cmcd_desc& d, int64_t n, int64_t base) { return lgcp_ws(d, n, base).total; }
+struct LgcpUhaWs;
+static LgcpUhaWs lgcp_uha_ws(const cmcd_desc& d, int64_t n, int64_t base);
+static int64_t lgcp_uha_ws_total(const cmcd_desc& d, int64_t n, int64_t base);
+static int lgcp_uha_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, const int32_t* seeds, int64_t n,
+                            const float* params, const float* tc, float* ws, float* out_loss, float* out_z,
+                            double** partials_out, float* traj, hipStream_t stream);
+
+int64_t lgcp_workspace_floats(const cmcd_desc& d, int64_t n, int64_t base) {
+  if (d.mode == CMCD_MODE_CAIS_UHA_SN) return lgcp_uha_ws_total(d, n, base);
+  return lgcp_ws(d, n, base).total;
+}
 
 static int lgcp_gemm_attrs() {
   const int gemm_lds = int(size_t(kStage * kAsLd + kQuarters * kMP * 64) * 4);
@@ -824,6 +834,8 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
                  const float* params, const float* tc, float* ws, float* out_loss, float* out_z,
                  double** partials_out, float* traj, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (d.mode == CMCD_MODE_CAIS_UHA_SN)
+    return lgcp_uha_forward(d, lay, sw, seeds, n, params, tc, ws, out_loss, out_z, partials_out, traj, stream);
   const int D = d.dim, E = d.emb_dim, IN = D + E, K = d.nbridges;
   const LgcpWs w = lgcp_ws(d, n, sw.total_floats);
   if (d.mode != CMCD_MODE_ULA) {   // MCD_ULA has no network leaves at all
@@ -1450,6 +1462,325 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
     hipLaunchKernelGGL(lgcp_colsum_kernel, dim3(1), dim3(256), 0, stream, gws + g.gfac, (int64_t)(K + 1), 1, 1, grad + lay.g_factor, 1.0f, 0);
   int rc = launch_geffner_tails(d, lay, sw, params, gws, g.S, g.S2, g.gbeta, g.geps, IN, grad, stream_, net);
   if (rc != CMCD_OK) return rc;
+  return hipGetLastError() == hipSuccess ? CMCD_OK : CMCD_ERR_HIP;
+}
+
+// =============================================================================================================
+// MCD_CAIS_UHA_sn on the lgcp path (d = 1600, geffner net of width 2 d + emb_dim = 3220 on concat(z, rho)):
+// /root/reference/src/mcd_under_lp_a_cais.py:42-112 as a launch sequence.  One evaluation of the network touches
+// W1[:2d] 41.2 MB + W2 41.5 MB + W3 20.6 MB, a bridge needs two of them (momentum rho and rho', same z, same index)
+// plus K^-1 (10.2 MB) once: 8 launches per bridge on the skinny-GEMM kernel above —
+//   L1  [z; rho] W1[:2d]  -> u1 = [z; rho; emb_i] + softplus(. + bias1_i)          (fused consumer)
+//   L2  u1 W2             -> u2 = u1 + softplus(. + b2)                             (fused consumer)
+//   L3  u2 W3             -> s1 slabs
+//   F1  m_f, rho' = m_f + sqrt(2 eta) n_i, rho'' = rho' - eps uf / 2, z' = z + eps rho''      (element-wise, one workgroup per particle)
+//   L4  [z; rho'] W1[:2d] -> u1  |  (z' - mu0) K^-1 -> kr slabs of z'  (second segment: z' does not depend on s2)
+//   L5, L6 as L2, L3      -> s2 slabs
+//   F2  m_b, log-weight increment, ub(z'), rho_new, key chain; at the last bridge log N(rho_K; 0, 1) + log p(z_K)
+// Passes of <= 32 particles run one after the other on the caller's stream.
+// =============================================================================================================
+struct LgcpUhaWs {
+  int64_t bias1;                                   // [K+1][IN]
+  int64_t zr, zrp, zn, rpp;                        // [kMP][2D], [kMP][2D], [kMP][D], [kMP][D]
+  int64_t u1, u2, pre1, pre2;                      // [kMP][IN]
+  int64_t slab1, slab2, sn, kr;                    // [kSplit][kMP][IN] x2, [kSplit][kMP][D] x2
+  int64_t w, fk, keys, gkey, counters, partials, total;
+};
+
+static LgcpUhaWs lgcp_uha_ws(const cmcd_desc& d, int64_t n, int64_t base) {
+  const int64_t D = d.dim, IN = 2 * D + d.emb_dim, K = d.nbridges;
+  LgcpUhaWs w;
+  int64_t o = base;
+  auto take = [&](int64_t cnt) { int64_t r = o; o += (cnt + 3) & ~int64_t(3); return r; };
+  w.bias1 = take((K + 1) * IN);
+  w.zr = take(kMP * 2 * D); w.zrp = take(kMP * 2 * D); w.zn = take(kMP * D); w.rpp = take(kMP * D);
+  w.u1 = take(kMP * IN); w.u2 = take(kMP * IN); w.pre1 = take(kMP * IN); w.pre2 = take(kMP * IN);
+  w.slab1 = take(kSplit * kMP * IN); w.slab2 = take(kSplit * kMP * IN);
+  w.sn = take(kSplit * kMP * D); w.kr = take(kSplit * kMP * D);
+  w.w = take(kMP); w.fk = take(kMP); w.keys = take(2 * kMP); w.gkey = take(2 * kMP);
+  w.counters = take(((D + 63) / 64) + ((IN + 63) / 64));
+  o = (o + 1) & ~int64_t(1);
+  w.partials = take(n * CMCD_NSTATS * 2);
+  w.total = o;
+  return w;
+}
+
+struct LgcpUhaStepArgs {
+  const int32_t* seeds;      // [M] (this pass; init only)
+  const float* params;
+  const float* tc;           // {Kinv[d,d], counts[d], mu0, a, lognorm}
+  const float* sched;        // [K][8] {beta, eps, ...}: cos^2 schedule (the prep launch is given CMCD_EPS_COS_SQ)
+  float* zr;                 // [kMP][2D]  [z | rho]
+  float* zrp;                // [kMP][2D]  [z | rho']
+  float* zn;                 // [kMP][D]   z'
+  float* rpp;                // [kMP][D]   rho''
+  const float* kr;           // [kSplit][kMP][D]  K^-1 (z - mu0) slabs: of z in F1, of z' in F2
+  const float* sn;           // [kSplit][kMP][D]  u2 W3 slabs
+  float* w;                  // [kMP] running log-weight
+  float* fk;                 // [kMP] forward-kernel log-density of the open bridge
+  uint32_t* gen;             // [kMP][2] chain key
+  uint32_t* gkey;            // [kMP][2] G_i: key of this bridge's momentum-refresh noise
+  float* out_loss;           // [M]
+  float* out_z;              // [M][D]
+  double* partials;          // [M][5]
+  float* traj;               // optional [3K+2][n_total][D]: z_0..z_K | rho_0..rho_K | rho'_0..rho'_{K-1}
+  int64_t n_total, base;
+  cmcd_layout lay;
+  int M, D, K, i;
+};
+
+// z0 = mean + std normal(A); rho0 = normal(R); w = -log q(z0) - log N(rho0; 0, 1); gen_0, G_0
+// (mcdboundingmachine.py:151-162, mcd_under_lp_a_cais.py:92-100)
+__global__ __launch_bounds__(256) void lgcp_uha_init_kernel(LgcpUhaStepArgs a) {
+  __shared__ float sh[4];
+  __shared__ uint32_t rk[2];
+  const int p = blockIdx.x, D = a.D, H = (D + 1) / 2, K = a.K;
+  const uint32_t seed = (uint32_t)a.seeds[p];
+  uint32_t s0 = 0, s1 = 2, t0 = 1, t1 = 3;
+  threefry2x32(0u, seed, s0, s1);
+  threefry2x32(0u, seed, t0, t1);
+  const uint32_t a0 = s0, a1 = t0, b0 = s1, b1 = t1;   // A = (out0, out1), B = (out2, out3)
+  if (threadIdx.x == 0) {
+    uint32_t c0 = 0, c2 = 2, c1 = 1, c3 = 3;
+    threefry2x32(b0, b1, c0, c2);
+    threefry2x32(b0, b1, c1, c3);       // C = first(split(B)) = (c0, c1): the key handed to evolve
+    uint32_t r0 = 0, g0 = 2, r1 = 1, g1 = 3;
+    threefry2x32(c0, c1, r0, g0);
+    threefry2x32(c0, c1, r1, g1);       // R = (r0, r1), G' = (g0, g1)                   :92
+    rk[0] = r0; rk[1] = r1;
+    uint32_t n0 = 0, n2 = 2, n1 = 1, n3 = 3;
+    threefry2x32(g0, g1, n0, n2);
+    threefry2x32(g0, g1, n1, n3);       // gen_0 = second(split(G')) = (n2, n3)          :100
+    uint32_t k0 = n2, k1 = n3, G0, G1;
+    lgcp_key_advance(k0, k1, G0, G1);   // G_0 and gen_1                                 :55,84
+    a.gkey[2 * p] = G0; a.gkey[2 * p + 1] = G1;
+    a.gen[2 * p] = k0; a.gen[2 * p + 1] = k1;
+  }
+  __syncthreads();
+  const uint32_t r0 = rk[0], r1 = rk[1];
+  float acc = 0.f;
+  for (int j = threadIdx.x; j < H; j += blockDim.x) {
+    uint32_t y0 = j, y1 = (H + j < D) ? H + j : 0;
+    uint32_t q0 = y0, q1 = y1;
+    threefry2x32(a0, a1, y0, y1);
+    threefry2x32(r0, r1, q0, q1);
+    const int idx[2] = {j, H + j};
+    const uint32_t bz[2] = {y0, y1}, br[2] = {q0, q1};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (idx[q] < D) {
+        const float mean = a.params[a.lay.vd_mean + idx[q]];
+        const float sd = expf(a.params[a.lay.vd_logdiag + idx[q]]);
+        const float z = sd * bits_to_normal(bz[q]) + mean;
+        const float rho = bits_to_normal(br[q]);
+        a.zr[p * 2 * D + idx[q]] = z;
+        a.zr[p * 2 * D + D + idx[q]] = rho;
+        if (a.traj) {
+          a.traj[(a.base + p) * D + idx[q]] = z;
+          a.traj[((int64_t)(K + 1) * a.n_total + a.base + p) * D + idx[q]] = rho;
+        }
+        const float dz = z - mean;
+        acc += -(dz * dz) / (2.0f * sd * sd) - logf(sd) - kHalfLog2Pi;   // log q(z0)
+        acc += -(rho * rho) * 0.5f - kHalfLog2Pi;                         // log N(rho0; 0, 1)
+      }
+    }
+  }
+  const float lq = block_sum_256(acc, sh);
+  if (threadIdx.x == 0) a.w[p] = -lq;
+}
+
+// F1 (see the header above)
+__global__ __launch_bounds__(256) void lgcp_uha_mid_kernel(LgcpUhaStepArgs a) {
+  __shared__ float sh[4];
+  const int p = blockIdx.x, D = a.D, H = (D + 1) / 2, K = a.K, i = a.i;
+  const float* counts = a.tc + (int64_t)D * D;
+  const float pa = a.tc[(int64_t)D * D + D + 1];
+  const float beta = a.sched[8 * i], eps = a.sched[8 * i + 1];
+  const float gamma = a.params[a.lay.gamma];
+  const float eta = gamma * eps, ome = 1.0f - eta, sig = sqrtf(2.0f * eta);
+  const float inv2s2 = 1.0f / (2.0f * sig * sig), cst = logf(sig) + kHalfLog2Pi;
+  const float fac = a.params[a.lay.g_factor];
+  const uint32_t g0 = a.gkey[2 * p], g1 = a.gkey[2 * p + 1];
+  float fk_acc = 0.f;
+  for (int e = threadIdx.x; e < D; e += blockDim.x) {
+    const float z = a.zr[p * 2 * D + e], rho = a.zr[p * 2 * D + D + e];
+    float kr = 0.f, o = a.params[a.lay.g_b3 + e];
+#pragma unroll
+    for (int ks = 0; ks < kSplit; ++ks) {
+      kr += a.kr[((int64_t)ks * kMP + p) * D + e];
+      o += a.sn[((int64_t)ks * kMP + p) * D + e];
+    }
+    const float s1 = o * fac;
+    const float mean = a.params[a.lay.vd_mean + e];
+    const float sd = expf(a.params[a.lay.vd_logdiag + e]);
+    float gp = -kr + counts[e] - pa * expf(z);
+    gp = fminf(fmaxf(gp, -1e2f), 1e2f);                      // gradU(z, beta, clip=1e2)          :23-30
+    const float gq = -(z - mean) / (sd * sd);
+    const float uf = -1.0f * (beta * gp + (1.0f - beta) * gq);
+    const float mf = rho * ome - 2.0f * eta * s1;             // :52-54
+    const int j = e < H ? e : e - H;
+    uint32_t y0 = j, y1 = (H + j < D) ? H + j : 0;
+    threefry2x32(g0, g1, y0, y1);
+    const float rhop = mf + sig * bits_to_normal(e < H ? y0 : y1);   // :58-59
+    const float df = rhop - mf;
+    fk_acc += -(df * df) * inv2s2 - cst;
+    const float rpp = rhop - eps * uf / 2.0f;                 // :62
+    a.zrp[p * 2 * D + e] = z;
+    a.zrp[p * 2 * D + D + e] = rhop;
+    a.zn[p * D + e] = z + eps * rpp;                          // :63
+    a.rpp[p * D + e] = rpp;
+    if (a.traj) a.traj[((int64_t)(2 * K + 2 + i) * a.n_total + a.base + p) * D + e] = rhop;
+  }
+  const float fk = block_sum_256(fk_acc, sh);
+  if (threadIdx.x == 0) a.fk[p] = fk;
+}
+
+// F2 (see the header above)
+__global__ __launch_bounds__(256) void lgcp_uha_close_kernel(LgcpUhaStepArgs a) {
+  __shared__ float sh[4];
+  const int p = blockIdx.x, D = a.D, K = a.K, i = a.i;
+  const bool last = i == K - 1;
+  const float* counts = a.tc + (int64_t)D * D;
+  const float mu0 = a.tc[(int64_t)D * D + D], pa = a.tc[(int64_t)D * D + D + 1], lognorm = a.tc[(int64_t)D * D + D + 2];
+  const float beta = a.sched[8 * i], eps = a.sched[8 * i + 1];
+  const float gamma = a.params[a.lay.gamma];
+  const float eta = gamma * eps, ome = 1.0f - eta, sig = sqrtf(2.0f * eta);
+  const float inv2s2 = 1.0f / (2.0f * sig * sig), cst = logf(sig) + kHalfLog2Pi;
+  const float fac = a.params[a.lay.g_factor];
+  if (threadIdx.x == 0 && !last) {   // the key chain for bridge i + 1                  :55,84
+    uint32_t k0 = a.gen[2 * p], k1 = a.gen[2 * p + 1], G0, G1;
+    lgcp_key_advance(k0, k1, G0, G1);
+    a.gen[2 * p] = k0; a.gen[2 * p + 1] = k1;
+    a.gkey[2 * p] = G0; a.gkey[2 * p + 1] = G1;
+  }
+  float bk_acc = 0.f, lp_acc = 0.f, lr_acc = 0.f;
+  for (int e = threadIdx.x; e < D; e += blockDim.x) {
+    const float rho = a.zr[p * 2 * D + D + e], rhop = a.zrp[p * 2 * D + D + e];
+    const float zn = a.zn[p * D + e], rpp = a.rpp[p * D + e];
+    float kr = 0.f, o = a.params[a.lay.g_b3 + e];
+#pragma unroll
+    for (int ks = 0; ks < kSplit; ++ks) {
+      kr += a.kr[((int64_t)ks * kMP + p) * D + e];
+      o += a.sn[((int64_t)ks * kMP + p) * D + e];
+    }
+    const float s2 = o * fac;
+    const float mb = rhop * ome + 2.0f * eta * s2;            // :77-80
+    const float db = rho - mb;
+    bk_acc += -(db * db) * inv2s2 - cst;                      // :84
+    const float mean = a.params[a.lay.vd_mean + e];
+    const float sd = expf(a.params[a.lay.vd_logdiag + e]);
+    const float ez = expf(zn);
+    const float graw = -kr + counts[e] - pa * ez;
+    const float gp = fminf(fmaxf(graw, -1e2f), 1e2f);
+    const float gq = -(zn - mean) / (sd * sd);
+    const float ub = -1.0f * (beta * gp + (1.0f - beta) * gq);   // :65
+    const float rnew = rpp - eps * ub / 2.0f;                 // :67
+    a.zr[p * 2 * D + e] = zn;
+    a.zr[p * 2 * D + D + e] = rnew;
+    if (a.traj) {
+      a.traj[((int64_t)(i + 1) * a.n_total + a.base + p) * D + e] = zn;
+      a.traj[((int64_t)(K + 2 + i) * a.n_total + a.base + p) * D + e] = rnew;
+    }
+    if (last) {
+      lp_acc += -0.5f * (zn - mu0) * kr + zn * counts[e] - pa * ez;
+      lr_acc += -(rnew * rnew) * 0.5f - kHalfLog2Pi;
+      a.out_z[(int64_t)p * D + e] = zn;
+    }
+  }
+  const float bk = block_sum_256(bk_acc, sh);
+  const float lp = block_sum_256(lp_acc, sh);
+  const float lr = block_sum_256(lr_acc, sh);
+  if (threadIdx.x == 0) {
+    float w = a.w[p] + (bk - a.fk[p]);                        // :88
+    a.w[p] = w;
+    if (last) {
+      w += lr;                                                // + log N(rho_K; 0, 1)   :112
+      w += lp + lognorm;                                      // + log p(z_K)           mcdboundingmachine.py:178
+      const float loss = -w;
+      a.out_loss[p] = loss;
+      double* o = a.partials + (int64_t)p * CMCD_NSTATS;
+      o[0] = isfinite(loss) ? 1.0 : 0.0;
+      o[1] = loss;
+      o[2] = (double)loss * (double)loss;
+      o[3] = -(double)loss;
+      o[4] = isfinite(loss) ? 1.0 : 0.0;
+    }
+  }
+}
+
+// the network on [zin | .] (lda = 2 D) at time index i: L1, L2, L3 of the header; `extra` (nullable): a second segment
+// of the first launch, (extra - mu0) K^-1 -> kr slabs
+static void lgcp_uha_net(const cmcd_desc& d, const cmcd_layout& lay, const float* params, const float* kinv, int M, int i,
+                         const float* zin, const float* bias1, float* slab1, float* pre1, float* u1, float* slab2, float* pre2,
+                         float* u2, float* sn, const float* extra, float* kr, int* counters, int gemm_lds, hipStream_t st) {
+  const int D = d.dim, E = d.emb_dim, IN = 2 * D + E;
+  const int cbD = (D + 63) / 64, cbIN = (IN + 63) / 64;
+  const float mu0 = 3.8812819069514780f;
+  const dim3 gblock(64 * kGemmWaves);
+  GemmArgs g{};
+  g.M = M; g.counters = counters;
+  g.act.x = zin; g.act.D = 2 * D; g.act.IN = IN;
+  g.Kdim = 2 * D; g.Kdim1 = extra ? D : 0;
+  g.seg[0] = GemmSeg{zin, params + lay.g_w1, slab1, IN, 2 * D, IN, IN};
+  if (extra) g.seg[1] = GemmSeg{extra, kinv, kr, D, D, D, D, mu0};
+  g.nblk0 = cbIN; g.epi_seg = extra ? 0 : -1;
+  g.act.mode = 1; g.act.bias = bias1 + (int64_t)i * IN; g.act.emb = params + lay.g_emb + (int64_t)i * E;
+  g.act.sum_out = pre1; g.act.u_prev = nullptr; g.act.u_out = u1;
+  hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_ACT>, dim3(cbIN + (extra ? cbD : 0), kSplit), gblock, gemm_lds, st, g);
+  g.Kdim = IN; g.Kdim1 = 0; g.epi_seg = -1;
+  g.seg[0] = GemmSeg{u1, params + lay.g_w2, slab2, IN, IN, IN, IN};
+  g.nblk0 = cbIN;
+  g.act.mode = 2; g.act.bias = params + lay.g_b2; g.act.sum_out = pre2; g.act.u_prev = u1; g.act.u_out = u2;
+  hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_ACT>, dim3(cbIN, kSplit), gblock, gemm_lds, st, g);
+  g.seg[0] = GemmSeg{u2, params + lay.g_w3, sn, D, IN, D, D};
+  g.nblk0 = cbD;
+  hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_NONE>, dim3(cbD, kSplit), gblock, gemm_lds, st, g);
+}
+
+static int64_t lgcp_uha_ws_total(const cmcd_desc& d, int64_t n, int64_t base) { return lgcp_uha_ws(d, n, base).total; }
+
+static int lgcp_uha_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, const int32_t* seeds, int64_t n,
+                            const float* params, const float* tc, float* ws, float* out_loss, float* out_z,
+                            double** partials_out, float* traj, hipStream_t stream) {
+  const int D = d.dim, E = d.emb_dim, IN = 2 * D + E, K = d.nbridges;
+  const LgcpUhaWs w = lgcp_uha_ws(d, n, sw.total_floats);
+  LgcpPrepArgs pa{params, ws + w.bias1, lay, 2 * D, E, K, IN};   // bias1_i = b1 + emb_i W1[2d:, :]
+  hipLaunchKernelGGL(lgcp_prep_kernel, dim3((IN + 255) / 256, K + 1), dim3(256), 0, stream, pa);
+  const int gemm_lds = lgcp_gemm_attrs();
+  if (gemm_lds < 0) return CMCD_ERR_HIP;
+  double* partials = reinterpret_cast<double*>(ws + w.partials);
+  *partials_out = partials;
+  const float mu0 = 3.8812819069514780f;
+  const int cbD = (D + 63) / 64, cbIN = (IN + 63) / 64;
+  int* counters = reinterpret_cast<int*>(ws + w.counters);
+  if (hipMemsetAsync(counters, 0, sizeof(int) * (cbD + cbIN), stream) != hipSuccess) return CMCD_ERR_HIP;
+  for (int64_t base = 0; base < n; base += kMP) {
+    const int M = (int)((n - base) < kMP ? (n - base) : kMP);
+    LgcpUhaStepArgs sa{};
+    sa.seeds = seeds + base; sa.params = params; sa.tc = tc; sa.sched = ws + sw.sched;
+    sa.zr = ws + w.zr; sa.zrp = ws + w.zrp; sa.zn = ws + w.zn; sa.rpp = ws + w.rpp; sa.kr = ws + w.kr; sa.sn = ws + w.sn;
+    sa.w = ws + w.w; sa.fk = ws + w.fk; sa.gen = reinterpret_cast<uint32_t*>(ws + w.keys);
+    sa.gkey = reinterpret_cast<uint32_t*>(ws + w.gkey);
+    sa.out_loss = out_loss + base; sa.out_z = out_z + base * D; sa.partials = partials + base * CMCD_NSTATS;
+    sa.traj = traj; sa.n_total = n; sa.base = base; sa.lay = lay; sa.M = M; sa.D = D; sa.K = K; sa.i = 0;
+    hipLaunchKernelGGL(lgcp_uha_init_kernel, dim3(M), dim3(256), 0, stream, sa);
+    {   // K^-1 (z_0 - mu0)
+      GemmArgs g{};
+      g.M = M; g.Kdim = D; g.counters = counters;
+      g.seg[0] = GemmSeg{ws + w.zr, tc, ws + w.kr, D, 2 * D, D, D, mu0};
+      g.nblk0 = cbD;
+      hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_NONE>, dim3(cbD, kSplit), dim3(64 * kGemmWaves), gemm_lds, stream, g);
+    }
+    for (int i = 0; i < K; ++i) {
+      sa.i = i;
+      lgcp_uha_net(d, lay, params, tc, M, i, ws + w.zr, ws + w.bias1, ws + w.slab1, ws + w.pre1, ws + w.u1, ws + w.slab2,
+                   ws + w.pre2, ws + w.u2, ws + w.sn, nullptr, nullptr, counters, gemm_lds, stream);
+      hipLaunchKernelGGL(lgcp_uha_mid_kernel, dim3(M), dim3(256), 0, stream, sa);
+      lgcp_uha_net(d, lay, params, tc, M, i, ws + w.zrp, ws + w.bias1, ws + w.slab1, ws + w.pre1, ws + w.u1, ws + w.slab2,
+                   ws + w.pre2, ws + w.u2, ws + w.sn, ws + w.zn, ws + w.kr, counters, gemm_lds, stream);
+      hipLaunchKernelGGL(lgcp_uha_close_kernel, dim3(M), dim3(256), 0, stream, sa);
+    }
+  }
   return hipGetLastError() == hipSuccess ? CMCD_OK : CMCD_ERR_HIP;
 }
 

@@ -159,3 +159,23 @@ def test_training_lowers_the_loss(hip_lib):
     after = float(loss_fn(ev, out, b["unflatten"], b["params_fixed"], b["target"])[0])
     print("UHA funnel K=8 mean loss", before, "->", after)
     assert after < before - 0.2
+
+
+# ---------------------------------------------------------------------------------------------- lgcp (d = 1600)
+@pytest.mark.parametrize("n,k", [(20, 8), (5, 3), (40, 2), (20, 32)])
+def test_lgcp_matches_oracle(hip_lib, param_set, n, k):
+    """d = 1600, geffner net on concat(z, rho): width 2 * 1600 + 20 = 3220 (the reference's lgcp runs of this mode,
+    /root/reference/src/notebooks/plotting_rebuttal.ipynb:3538-3548).  40 particles = two passes of the 32-row GEMM."""
+    from helpers import lgcp_counts_fixture
+    counts = lgcp_counts_fixture()
+    b = synthetic.build("lgcp_n20_k128", device="cuda", lgcp_counts=counts, boundmode=MODE, nbridges=k, init_eps=0.02,
+                        init_gamma=5.0)
+    assert b["params_fixed"][3].width == 3220
+    seeds = synthetic.parity_seeds(n)
+    val, (losses, z) = mcdbm.compute_bound(torch.from_numpy(seeds).cuda(), b["params_flat"], b["unflatten"],
+                                           b["params_fixed"], b["target"])
+    torch.cuda.synchronize()
+    l_ref, z_ref = run_oracle(b, seeds, dtype=np.float64, lgcp_counts=counts)
+    rep = compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"UHA lgcp n={n} k={k}")
+    print("UHA lgcp", n, k, rep, "mean loss", float(val), l_ref.mean())
+    assert abs(float(val) - losses.double().mean().item()) <= 1e-5 * abs(l_ref.mean())
