@@ -102,6 +102,11 @@ static bool hidden_width(const cmcd_desc& d, int& HP) {
 // /root/reference/src/mcdboundingmachine.py:82-98)
 int net_in_dim(const cmcd_desc& d) { return d.mode == CMCD_MODE_CAIS_UHA_SN ? 2 * d.dim : d.dim; }
 
+// floats of the trajectory a gradient call keeps: z_0..z_K, plus rho_0..rho_K and rho'_0..rho'_{K-1} for the momentum mode
+static int64_t kept_traj_floats(const cmcd_desc& d, int64_t n) {
+  return (int64_t)(d.mode == CMCD_MODE_CAIS_UHA_SN ? 3 * d.nbridges + 2 : d.nbridges + 1) * n * d.dim;
+}
+
 static int64_t target_lds_floats(const cmcd_desc& d, int64_t n_target) {
   if (d.target == CMCD_TARGET_MANY_GMM) return 4 + (n_target - 1);  // header + means
   return 0;
@@ -1209,7 +1214,7 @@ int64_t cmcd_bound_grad_workspace_bytes(const cmcd_desc* desc, int64_t n) {
     WsLayout lw;
     make_ws_lgcp(*desc, n, lw);
     return (align4(lgcp_workspace_floats(*desc, n, lw.total_floats)) + align4(lgcp_grad_workspace_floats(*desc, n)) +
-            (int64_t)(desc->nbridges + 1) * n * desc->dim) * 4;
+            kept_traj_floats(*desc, n)) * 4;
   }
   WsLayout w;
   const int64_t nt = desc->target == CMCD_TARGET_MANY_GMM ? 1 + 2 * 64 : 0;
@@ -1252,7 +1257,7 @@ int cmcd_bound_grad(const cmcd_desc* desc, const cmcd_layout* lay, const int32_t
     make_ws_lgcp(d, n, lw);
     const int64_t fwd = align4(lgcp_workspace_floats(d, n, lw.total_floats));
     const int64_t gfl = align4(lgcp_grad_workspace_floats(d, n));
-    const int64_t need = (fwd + gfl + (int64_t)(d.nbridges + 1) * n * d.dim) * 4;
+    const int64_t need = (fwd + gfl + kept_traj_floats(d, n)) * 4;
     if (workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15))
       return fail(CMCD_ERR_WORKSPACE, "workspace too small or not 16-byte aligned (need %s%lld bytes)", "", need);
     float* ws = static_cast<float*>(workspace);
@@ -1320,7 +1325,7 @@ int64_t cmcd_grad_workspace_bytes(const cmcd_desc* desc, int64_t n) {
     WsLayout lw;
     make_ws_lgcp(*desc, n, lw);
     return (align4(lgcp_workspace_floats(*desc, n, lw.total_floats)) + align4(lgcp_grad_workspace_floats(*desc, n)) +
-            (int64_t)(desc->nbridges + 1) * n * desc->dim) * 4;
+            kept_traj_floats(*desc, n)) * 4;
   }
   WsLayout w;
   const int64_t nt = desc->target == CMCD_TARGET_MANY_GMM ? 1 + 2 * 64 : 0;

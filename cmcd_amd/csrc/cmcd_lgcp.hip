@@ -1270,12 +1270,24 @@ static LgcpGradWs lgcp_grad_ws(const cmcd_desc& d, int64_t n) {
   return w;
 }
 
-int64_t lgcp_grad_workspace_floats(const cmcd_desc& d, int64_t n) { return lgcp_grad_ws(d, n).total; }
+static int64_t lgcp_uha_grad_ws_total(const cmcd_desc& d, int64_t n);
+static int lgcp_uha_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, int64_t n, const float* params,
+                         int64_t n_params, const float* tc, float* ws, const float* traj, float* gws, float omega,
+                         float* grad, hipStream_t stream);
+
+int64_t lgcp_grad_workspace_floats(const cmcd_desc& d, int64_t n) {
+  if (d.mode == CMCD_MODE_CAIS_UHA_SN) return lgcp_uha_grad_ws_total(d, n);
+  return lgcp_grad_ws(d, n).total;
+}
 
 int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, int64_t n, const float* params,
               int64_t n_params, const float* tc, float* ws, const float* traj, float* gws, float omega,
               const float* omega_vec, bool bptt, float* grad, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (d.mode == CMCD_MODE_CAIS_UHA_SN) {
+    if (!bptt || omega_vec) return CMCD_ERR_UNSUPPORTED;   // the mode has no stop_gradient variant
+    return lgcp_uha_grad(d, lay, sw, n, params, n_params, tc, ws, traj, gws, omega, grad, stream);
+  }
   const int D = d.dim, E = d.emb_dim, IN = D + E, K = d.nbridges;
   const LgcpWs w = lgcp_ws(d, n, sw.total_floats);
   const LgcpGradWs g = lgcp_grad_ws(d, n);
@@ -1781,6 +1793,450 @@ static int lgcp_uha_forward(const cmcd_desc& d, const cmcd_layout& lay, const Ws
       hipLaunchKernelGGL(lgcp_uha_close_kernel, dim3(M), dim3(256), 0, stream, sa);
     }
   }
+  return hipGetLastError() == hipSuccess ? CMCD_OK : CMCD_ERR_HIP;
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// Reparameterised gradient of MCD_CAIS_UHA_sn on the lgcp path: the reverse recursion of cmcd_uha.hip (header there)
+// as a launch sequence.  Per point e = K..0: element-wise point kernel (cotangents of ub / uf, clip mask, q gradients)
+// + one GEMM for H_p v = -K^-1 v - a e^z v; per bridge i = e - 1: recompute both network evaluations at the kept
+// (z_i, rho_i, rho'_i), back-propagate s2 then s1 (their cotangents are chained through d rho') through three skinny
+// GEMMs each against transposed weight copies.  The O(width^2) parameter gradients are deferred: every evaluation's
+// (input, u1, u2, d a1, d a2, d o) rows are kept and contracted at the end by A^T B products (inner dimension 2 K n).
+// -------------------------------------------------------------------------------------------------------------
+struct LgcpUhaFwdSet { int64_t zin, slab1, pre1, u1, slab2, pre2, u2, sn; };
+
+struct LgcpUhaGradWs {
+  int64_t wt1, wt2, wt3;                        // W1[:2D]^T [IN][2D], W2^T [IN][IN], W3^T [D][IN]
+  LgcpUhaFwdSet fs[2];                          // evaluation A = s([z; rho]), B = s([z; rho'])
+  int64_t kr, hv;                               // [kSplit][kMP][D]
+  int64_t v, dO, arp, gb, lrn, arppc;           // [kMP][D]
+  int64_t du2s, ts;                             // [kSplit][kMP][IN]
+  int64_t du2, du1, da2, da1;                   // [kMP][IN]
+  int64_t dxf;                                  // [kSplit][kMP][2D]
+  int64_t XIN, U1, U2, DA1, DA2, DO;            // [2 K n][2D | IN | IN | IN | IN | D]
+  int64_t zero_lo, zero_hi;
+  int64_t lz, lr, gmu_acc, glam_acc;            // [kMP][D]
+  int64_t geta, gepsd;                          // [kMP]
+  int64_t S, S2, gb2, gbeta, geps, counters;
+  int64_t sc;                                   // [(K+1)][n][8]
+  int64_t total;
+};
+
+static LgcpUhaGradWs lgcp_uha_grad_ws(const cmcd_desc& d, int64_t n) {
+  const int64_t D = d.dim, IN = 2 * D + d.emb_dim, K = d.nbridges, R = 2 * K * n;
+  LgcpUhaGradWs w;
+  int64_t o = 0;
+  auto take = [&](int64_t cnt) { int64_t r = o; o += (cnt + 3) & ~int64_t(3); return r; };
+  w.wt1 = take(IN * 2 * D); w.wt2 = take(IN * IN); w.wt3 = take(D * IN);
+  for (int b = 0; b < 2; ++b) {
+    LgcpUhaFwdSet& f = w.fs[b];
+    f.zin = take(kMP * 2 * D); f.slab1 = take(kSplit * kMP * IN); f.pre1 = take(kMP * IN); f.u1 = take(kMP * IN);
+    f.slab2 = take(kSplit * kMP * IN); f.pre2 = take(kMP * IN); f.u2 = take(kMP * IN); f.sn = take(kSplit * kMP * D);
+  }
+  w.kr = take(kSplit * kMP * D); w.hv = take(kSplit * kMP * D);
+  w.v = take(kMP * D); w.dO = take(kMP * D); w.arp = take(kMP * D); w.gb = take(kMP * D); w.lrn = take(kMP * D);
+  w.arppc = take(kMP * D);
+  w.du2s = take(kSplit * kMP * IN); w.ts = take(kSplit * kMP * IN);
+  w.du2 = take(kMP * IN); w.du1 = take(kMP * IN); w.da2 = take(kMP * IN); w.da1 = take(kMP * IN);
+  w.dxf = take(kSplit * kMP * 2 * D);
+  w.XIN = take(R * 2 * D); w.U1 = take(R * IN); w.U2 = take(R * IN); w.DA1 = take(R * IN); w.DA2 = take(R * IN); w.DO = take(R * D);
+  w.zero_lo = o;
+  w.lz = take(kMP * D); w.lr = take(kMP * D); w.gmu_acc = take(kMP * D); w.glam_acc = take(kMP * D);
+  w.geta = take(kMP); w.gepsd = take(kMP);
+  w.S = take((K + 1) * IN); w.S2 = take((K + 1) * IN); w.gb2 = take(IN); w.gbeta = take(K); w.geps = take(K);
+  w.counters = take(((D + 63) / 64) + ((IN + 63) / 64));
+  w.sc = take((K + 1) * n * 8);
+  w.zero_hi = o;
+  w.total = o;
+  return w;
+}
+
+struct LgcpUhaAdjArgs {
+  const float* params;
+  const float* tc;
+  const float* sched;
+  const float* traj;         // [3K+2][n][D]
+  const float* kr;           // [kSplit][kMP][D]  K^-1 (z_e - mu0)
+  const float* hv;           // [kSplit][kMP][D]  v K^-1
+  const float* snA;          // [kSplit][kMP][D]  u2 W3 slabs of evaluation A / B
+  const float* snB;
+  const float* du1;          // [kMP][IN]  d u1 of the evaluation just back-propagated (residual path)
+  const float* dxf;          // [kSplit][kMP][2D]  d a1 W1[:2D]^T
+  float* zinA;               // [kMP][2D]
+  float* zinB;
+  float* XIN;                // [2 K n][2D]
+  float* lz;                 // [kMP][D] dL/dz_e
+  float* lr;                 // [kMP][D] dL/drho_e
+  float* arppc;              // [kMP][D] dL/drho''_e of the bridge walked last
+  float* arp;
+  float* gb;
+  float* lrn;
+  float* v;
+  float* dO;
+  float* DObig;              // [2 K n][D]
+  float* gmu_acc;
+  float* glam_acc;
+  float* geta;               // [kMP]
+  float* gepsd;              // [kMP]
+  float* sc;                 // [(K+1)][n][8]
+  cmcd_layout lay;
+  int64_t n, base;
+  int M, D, IN, K, e;        // e: the point (point kernel) or e = i + 1 for the bridge kernels of bridge i
+  float omega;
+};
+
+// [z_i | rho_i] and [z_i | rho'_i]: the operands of the recomputed network evaluations; also rows 2 i, 2 i + 1 of XIN
+__global__ void lgcp_uha_gather_kernel(LgcpUhaAdjArgs a) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x, D = a.D, K = a.K, i = a.e - 1;
+  if (idx >= a.M * D) return;
+  const int m = idx / D, j = idx - m * D;
+  const int64_t pr = a.base + m;
+  const float z = a.traj[((int64_t)i * a.n + pr) * D + j];
+  const float rho = a.traj[((int64_t)(K + 1 + i) * a.n + pr) * D + j];
+  const float rhop = a.traj[((int64_t)(2 * K + 2 + i) * a.n + pr) * D + j];
+  a.zinA[m * 2 * D + j] = z; a.zinA[m * 2 * D + D + j] = rho;
+  a.zinB[m * 2 * D + j] = z; a.zinB[m * 2 * D + D + j] = rhop;
+  float* xa = a.XIN + ((int64_t)(2 * i) * a.n + pr) * 2 * D;
+  float* xb = a.XIN + ((int64_t)(2 * i + 1) * a.n + pr) * 2 * D;
+  xa[j] = z; xa[D + j] = rho;
+  xb[j] = z; xb[D + j] = rhop;
+}
+
+// point e: cotangents of ub (bridge e - 1) and uf (bridge e) at z_e, v = clipmask . a_gp for the Hessian product, q gradients
+__global__ __launch_bounds__(256) void lgcp_uha_adj_point_kernel(LgcpUhaAdjArgs a) {
+  __shared__ float sh[4];
+  const int p = blockIdx.x, D = a.D, K = a.K, e = a.e;
+  const int64_t pr = a.base + p;
+  const float* counts = a.tc + (int64_t)D * D;
+  const float pa = a.tc[(int64_t)D * D + D + 1];
+  const float om = a.omega;
+  const float bl = e >= 1 ? a.sched[8 * (e - 1)] : 0.f, el = e >= 1 ? a.sched[8 * (e - 1) + 1] : 0.f;
+  const float bh = e < K ? a.sched[8 * e] : 0.f, eh = e < K ? a.sched[8 * e + 1] : 0.f;
+  float sbl = 0.f, sel = 0.f, sbh = 0.f, seh = 0.f;
+  for (int j = threadIdx.x; j < D; j += blockDim.x) {
+    const float z = a.traj[((int64_t)e * a.n + pr) * D + j];
+    float kr = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < kSplit; ++ks) kr += a.kr[((int64_t)ks * kMP + p) * D + j];
+    const float graw = -kr + counts[j] - pa * expf(z);
+    const float gp = fminf(fmaxf(graw, -1e2f), 1e2f);
+    const float msk = fabsf(graw) < 1e2f ? 1.0f : 0.f;
+    const float mean = a.params[a.lay.vd_mean + j];
+    const float sd = expf(a.params[a.lay.vd_logdiag + j]);
+    const float qiv = 1.0f / (sd * sd);
+    const float gq = -(z - mean) * qiv;
+    float lz = e == K ? 0.f : a.lz[p * D + j];
+    float lr = e == K ? om * a.traj[((int64_t)(2 * K + 1) * a.n + pr) * D + j] : a.lr[p * D + j];   // dL/drho_K = omega rho_K
+    if (e == K) a.lr[p * D + j] = lr;
+    float a_gp = 0.f, a_gq = 0.f;
+    if (e >= 1) {
+      const float adj = -0.5f * el * lr;
+      const float ub = -1.0f * (bl * gp + (1.0f - bl) * gq);
+      a_gp -= bl * adj; a_gq -= (1.0f - bl) * adj;
+      sbl -= (gp - gq) * adj;
+      sel -= 0.5f * ub * lr;
+    }
+    if (e < K) {
+      const float ar = a.arppc[p * D + j];
+      const float adj = -0.5f * eh * ar;
+      const float uf = -1.0f * (bh * gp + (1.0f - bh) * gq);
+      a_gp -= bh * adj; a_gq -= (1.0f - bh) * adj;
+      sbh -= (gp - gq) * adj;
+      seh -= 0.5f * uf * ar;
+    }
+    if (e == K) lz -= om * graw;
+    if (e == 0) lz += om * gq;
+    lz -= a_gq * qiv;
+    a.gmu_acc[p * D + j] += a_gq * qiv;
+    a.glam_acc[p * D + j] += a_gq * (-2.0f * gq);
+    a.v[p * D + j] = msk * a_gp;
+    a.lz[p * D + j] = lz;
+  }
+  sbl = block_sum_256(sbl, sh); sel = block_sum_256(sel, sh); sbh = block_sum_256(sbh, sh); seh = block_sum_256(seh, sh);
+  if (threadIdx.x == 0) {
+    float* o = a.sc + ((int64_t)e * a.n + pr) * 8;
+    o[0] = sbl; o[1] = sel; o[2] = sbh; o[3] = seh;
+  }
+}
+
+// bridge i = e - 1, first half: finish lz_e with the Hessian product, leap-frog adjoints, g_b and the cotangent of s2
+__global__ __launch_bounds__(256) void lgcp_uha_adj_b_kernel(LgcpUhaAdjArgs a) {
+  __shared__ float sh[4];
+  const int p = blockIdx.x, D = a.D, K = a.K, e = a.e, i = e - 1;
+  const int64_t pr = a.base + p;
+  const float pa = a.tc[(int64_t)D * D + D + 1];
+  const float om = a.omega;
+  const float eps = a.sched[8 * i + 1];
+  const float gamma = a.params[a.lay.gamma];
+  const float eta = gamma * eps, ome = 1.0f - eta, inv2eta = 0.5f / eta;
+  const float fac = a.params[a.lay.g_factor];
+  float geta = 0.f, gepsd = 0.f, gfac = 0.f;
+  for (int j = threadIdx.x; j < D; j += blockDim.x) {
+    const float ze = a.traj[((int64_t)e * a.n + pr) * D + j];
+    const float z = a.traj[((int64_t)i * a.n + pr) * D + j];
+    const float rho = a.traj[((int64_t)(K + 1 + i) * a.n + pr) * D + j];
+    const float rhop = a.traj[((int64_t)(2 * K + 2 + i) * a.n + pr) * D + j];
+    float hv = 0.f, o = a.params[a.lay.g_b3 + j];
+#pragma unroll
+    for (int ks = 0; ks < kSplit; ++ks) {
+      hv += a.hv[((int64_t)ks * kMP + p) * D + j];
+      o += a.snB[((int64_t)ks * kMP + p) * D + j];
+    }
+    const float lz = a.lz[p * D + j] - hv - pa * expf(ze) * a.v[p * D + j];     // H_p v = -K^-1 v - a e^z v
+    a.lz[p * D + j] = lz;
+    const float arpp = a.lr[p * D + j] + eps * lz;
+    a.arppc[p * D + j] = arpp;
+    gepsd += ((ze - z) / eps) * lz;
+    const float s2 = o * fac;
+    const float mb = rhop * ome + 2.0f * eta * s2;
+    const float r = rho - mb;
+    const float gb = -om * r * inv2eta;
+    a.gb[p * D + j] = gb;
+    a.arp[p * D + j] = arpp + ome * gb;
+    const float cot = 2.0f * eta * gb;
+    geta += (2.0f * s2 - rhop) * gb - om * r * r * inv2eta * inv2eta;
+    gfac += cot * o;
+    a.dO[p * D + j] = cot * fac;
+    a.DObig[((int64_t)(2 * i + 1) * a.n + pr) * D + j] = cot * fac;
+  }
+  geta = block_sum_256(geta, sh); gepsd = block_sum_256(gepsd, sh); gfac = block_sum_256(gfac, sh);
+  if (threadIdx.x == 0) {
+    a.geta[p] = geta; a.gepsd[p] = gepsd;
+    a.sc[((int64_t)i * a.n + pr) * 8 + 6] = gfac;
+  }
+}
+
+// bridge i, second half: d [z; rho'] of s2 arrives; cotangent of s1
+__global__ __launch_bounds__(256) void lgcp_uha_adj_a_kernel(LgcpUhaAdjArgs a) {
+  __shared__ float sh[4];
+  const int p = blockIdx.x, D = a.D, K = a.K, i = a.e - 1, IN = a.IN;
+  const int64_t pr = a.base + p;
+  const float eps = a.sched[8 * i + 1];
+  const float gamma = a.params[a.lay.gamma];
+  const float eta = gamma * eps, ome = 1.0f - eta, inv2eta = 0.5f / eta;
+  const float fac = a.params[a.lay.g_factor];
+  float geta = 0.f, gfac = 0.f;
+  for (int j = threadIdx.x; j < D; j += blockDim.x) {
+    const float rho = a.traj[((int64_t)(K + 1 + i) * a.n + pr) * D + j];
+    const float rhop = a.traj[((int64_t)(2 * K + 2 + i) * a.n + pr) * D + j];
+    float dz = a.du1[p * IN + j], dr = a.du1[p * IN + D + j], o = a.params[a.lay.g_b3 + j];   // residual path: d x += d u1[:2D]
+#pragma unroll
+    for (int ks = 0; ks < kSplit; ++ks) {
+      dz += a.dxf[((int64_t)ks * kMP + p) * 2 * D + j];
+      dr += a.dxf[((int64_t)ks * kMP + p) * 2 * D + D + j];
+      o += a.snA[((int64_t)ks * kMP + p) * D + j];
+    }
+    a.lz[p * D + j] += dz;
+    const float arp = a.arp[p * D + j] + dr;
+    const float s1 = o * fac;
+    const float mf = rho * ome - 2.0f * eta * s1;
+    const float cot = -2.0f * eta * arp;
+    geta += ((rhop - mf) * inv2eta - rho - 2.0f * s1) * arp;
+    a.lrn[p * D + j] = ome * arp - a.gb[p * D + j];
+    gfac += cot * o;
+    a.dO[p * D + j] = cot * fac;
+    a.DObig[((int64_t)(2 * i) * a.n + pr) * D + j] = cot * fac;
+  }
+  geta = block_sum_256(geta, sh); gfac = block_sum_256(gfac, sh);
+  if (threadIdx.x == 0) {
+    a.geta[p] += geta;
+    a.sc[((int64_t)i * a.n + pr) * 8 + 7] = gfac;
+  }
+}
+
+// bridge i, end: d [z; rho] of s1 arrives -> (lz, lr) of point i (its Hessian part follows in the point kernel)
+__global__ __launch_bounds__(256) void lgcp_uha_adj_fin_kernel(LgcpUhaAdjArgs a) {
+  const int p = blockIdx.x, D = a.D, i = a.e - 1, IN = a.IN;
+  const int64_t pr = a.base + p;
+  for (int j = threadIdx.x; j < D; j += blockDim.x) {
+    float dz = a.du1[p * IN + j], dr = a.du1[p * IN + D + j];
+#pragma unroll
+    for (int ks = 0; ks < kSplit; ++ks) {
+      dz += a.dxf[((int64_t)ks * kMP + p) * 2 * D + j];
+      dr += a.dxf[((int64_t)ks * kMP + p) * 2 * D + D + j];
+    }
+    a.lz[p * D + j] += dz;
+    a.lr[p * D + j] = a.lrn[p * D + j] + dr;
+  }
+  if (threadIdx.x == 0) {
+    const float eps = a.sched[8 * i + 1], gamma = a.params[a.lay.gamma];
+    float* o = a.sc + ((int64_t)i * a.n + pr) * 8;
+    o[4] = a.gepsd[p] + gamma * a.geta[p];      // d / d eps_i (leap-frog + eta = gamma eps)
+    o[5] = eps * a.geta[p];                     // d / d gamma
+  }
+}
+
+// point 0, after its Hessian product: z_0 = mean + std e0 and the explicit parameters of log q(z_0)
+__global__ __launch_bounds__(256) void lgcp_uha_adj_z0_kernel(LgcpUhaAdjArgs a) {
+  const int p = blockIdx.x, D = a.D;
+  const int64_t pr = a.base + p;
+  const float pa = a.tc[(int64_t)D * D + D + 1];
+  for (int j = threadIdx.x; j < D; j += blockDim.x) {
+    const float z = a.traj[pr * D + j];
+    float hv = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < kSplit; ++ks) hv += a.hv[((int64_t)ks * kMP + p) * D + j];
+    const float lz = a.lz[p * D + j] - hv - pa * expf(z) * a.v[p * D + j];
+    const float mean = a.params[a.lay.vd_mean + j];
+    const float sd = expf(a.params[a.lay.vd_logdiag + j]);
+    const float qiv = 1.0f / (sd * sd), dz = z - mean, gq = -dz * qiv;
+    a.gmu_acc[p * D + j] += lz - a.omega * gq;
+    a.glam_acc[p * D + j] += lz * dz + a.omega * (dz * dz * qiv - 1.0f);
+  }
+}
+
+// gbeta / geps tables, d gamma, d factor_sn from the per-(point, particle) records; fixed order
+__global__ __launch_bounds__(256) void lgcp_uha_scal_reduce_kernel(const float* sc, int64_t n, int K, float* gbeta, float* geps,
+                                                                   float* grad_gamma, float* grad_factor) {
+  __shared__ float sh[4];
+  const int k = blockIdx.x;   // k < K: bridge k;  k == K: the two scalars
+  if (k < K) {
+    float b = 0.f, e = 0.f;
+    for (int64_t p = threadIdx.x; p < n; p += blockDim.x) {
+      const float* lo = sc + ((int64_t)(k + 1) * n + p) * 8;   // point k + 1: ub side of bridge k
+      const float* hi = sc + ((int64_t)k * n + p) * 8;         // point k: uf side; bridge k's own records
+      b += lo[0] + hi[2];
+      e += lo[1] + hi[3] + hi[4];
+    }
+    b = block_sum_256(b, sh); e = block_sum_256(e, sh);
+    if (threadIdx.x == 0) { gbeta[k] = b; geps[k] = e; }
+  } else {
+    float g = 0.f, f = 0.f;
+    for (int64_t t = threadIdx.x; t < (int64_t)K * n; t += blockDim.x) {
+      const float* r = sc + t * 8;
+      g += r[5];
+      f += r[6] + r[7];
+    }
+    g = block_sum_256(g, sh); f = block_sum_256(f, sh);
+    if (threadIdx.x == 0) { *grad_gamma = g; *grad_factor = f; }
+  }
+}
+
+static int64_t lgcp_uha_grad_ws_total(const cmcd_desc& d, int64_t n) { return lgcp_uha_grad_ws(d, n).total; }
+
+static int lgcp_uha_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, int64_t n, const float* params,
+                         int64_t n_params, const float* tc, float* ws, const float* traj, float* gws, float omega,
+                         float* grad, hipStream_t stream) {
+  const int D = d.dim, E = d.emb_dim, IN = 2 * D + E, K = d.nbridges;
+  const LgcpUhaWs w = lgcp_uha_ws(d, n, sw.total_floats);
+  const LgcpUhaGradWs g = lgcp_uha_grad_ws(d, n);
+  if (hipMemsetAsync(grad, 0, sizeof(float) * n_params, stream) != hipSuccess) return CMCD_ERR_HIP;
+  if (hipMemsetAsync(gws + g.zero_lo, 0, sizeof(float) * (g.zero_hi - g.zero_lo), stream) != hipSuccess) return CMCD_ERR_HIP;
+  {
+    const dim3 tb(32, 8);
+    hipLaunchKernelGGL(lgcp_transpose_kernel, dim3((IN + 31) / 32, (2 * D + 31) / 32), tb, 0, stream, params + lay.g_w1,
+                       gws + g.wt1, 2 * D, IN, IN, 2 * D);
+    hipLaunchKernelGGL(lgcp_transpose_kernel, dim3((IN + 31) / 32, (IN + 31) / 32), tb, 0, stream, params + lay.g_w2,
+                       gws + g.wt2, IN, IN, IN, IN);
+    hipLaunchKernelGGL(lgcp_transpose_kernel, dim3((D + 31) / 32, (IN + 31) / 32), tb, 0, stream, params + lay.g_w3,
+                       gws + g.wt3, IN, D, D, IN);
+  }
+  const int gemm_lds = lgcp_gemm_attrs();
+  if (gemm_lds < 0) return CMCD_ERR_HIP;
+  const float* kinv = tc;
+  const float mu0 = 3.8812819069514780f;
+  const dim3 gblock(64 * kGemmWaves);
+  const int cbD = (D + 63) / 64, cbIN = (IN + 63) / 64, cb2D = (2 * D + 63) / 64;
+  int* counters = reinterpret_cast<int*>(gws + g.counters);
+  const float* bias1 = ws + w.bias1;    // still in the forward workspace (lgcp_uha_forward's prep)
+
+  for (int64_t base = 0; base < n; base += kMP) {
+    const int M = (int)((n - base) < kMP ? (n - base) : kMP);
+    if (base > 0) {   // per-pass accumulators start from zero (lz / lr are initialised at point K)
+      if (hipMemsetAsync(gws + g.gmu_acc, 0, sizeof(float) * 2 * ((kMP * (int64_t)D + 3) & ~3), stream) != hipSuccess) return CMCD_ERR_HIP;
+    }
+    LgcpUhaAdjArgs aa{};
+    aa.params = params; aa.tc = tc; aa.sched = ws + sw.sched; aa.traj = traj; aa.kr = gws + g.kr; aa.hv = gws + g.hv;
+    aa.snA = gws + g.fs[0].sn; aa.snB = gws + g.fs[1].sn; aa.du1 = gws + g.du1; aa.dxf = gws + g.dxf;
+    aa.zinA = gws + g.fs[0].zin; aa.zinB = gws + g.fs[1].zin; aa.XIN = gws + g.XIN;
+    aa.lz = gws + g.lz; aa.lr = gws + g.lr; aa.arppc = gws + g.arppc; aa.arp = gws + g.arp; aa.gb = gws + g.gb;
+    aa.lrn = gws + g.lrn; aa.v = gws + g.v; aa.dO = gws + g.dO; aa.DObig = gws + g.DO; aa.gmu_acc = gws + g.gmu_acc;
+    aa.glam_acc = gws + g.glam_acc; aa.geta = gws + g.geta; aa.gepsd = gws + g.gepsd; aa.sc = gws + g.sc;
+    aa.lay = lay; aa.n = n; aa.base = base; aa.M = M; aa.D = D; aa.IN = IN; aa.K = K; aa.omega = omega;
+
+    auto kr_at = [&](int e) {   // K^-1 (z_e - mu0)
+      GemmArgs gm{};
+      gm.M = M; gm.Kdim = D; gm.counters = counters;
+      gm.seg[0] = GemmSeg{traj + ((int64_t)e * n + base) * D, kinv, gws + g.kr, D, D, D, D, mu0};
+      gm.nblk0 = cbD;
+      hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_NONE>, dim3(cbD, kSplit), gblock, gemm_lds, stream, gm);
+    };
+    // back-propagation of one network evaluation (buffer set f, table row `row`, time index i) from the cotangent in dO:
+    // leaves d u1 (residual path) and the d a1 W1[:2D]^T slabs
+    auto net_backward = [&](const LgcpUhaFwdSet& f, int64_t row, int i) {
+      GemmArgs gm{};
+      gm.M = M; gm.counters = counters; gm.epi_seg = -1;
+      gm.Kdim = D;
+      gm.seg[0] = GemmSeg{gws + g.dO, gws + g.wt3, gws + g.du2s, IN, D, IN, IN};
+      gm.nblk0 = cbIN;
+      LgcpActbArgs& ab = gm.actb;
+      ab.pre = gws + f.pre2; ab.du_prev = nullptr; ab.u_src = gws + f.u2;
+      ab.du_out = gws + g.du2; ab.da_out = gws + g.da2; ab.da_big = gws + g.DA2; ab.u_big = gws + g.U2;
+      ab.gb = gws + g.gb2; ab.row0 = row; ab.IN = IN; ab.mode = 2;
+      hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_ACTB>, dim3(cbIN, kSplit), gblock, gemm_lds, stream, gm);
+      gm.Kdim = IN;
+      gm.seg[0] = GemmSeg{gws + g.da2, gws + g.wt2, gws + g.ts, IN, IN, IN, IN};
+      ab.pre = gws + f.pre1; ab.du_prev = gws + g.du2; ab.u_src = gws + f.u1;
+      ab.du_out = gws + g.du1; ab.da_out = gws + g.da1; ab.da_big = gws + g.DA1; ab.u_big = gws + g.U1;
+      ab.S = gws + g.S + (int64_t)i * IN; ab.S2 = gws + g.S2 + (int64_t)i * IN; ab.mode = 1;
+      hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_ACTB>, dim3(cbIN, kSplit), gblock, gemm_lds, stream, gm);
+      gm.seg[0] = GemmSeg{gws + g.da1, gws + g.wt1, gws + g.dxf, 2 * D, IN, 2 * D, 2 * D};
+      gm.nblk0 = cb2D;
+      hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_NONE>, dim3(cb2D, kSplit), gblock, gemm_lds, stream, gm);
+    };
+    auto hv_product = [&]() {
+      GemmArgs gm{};
+      gm.M = M; gm.Kdim = D; gm.counters = counters;
+      gm.seg[0] = GemmSeg{gws + g.v, kinv, gws + g.hv, D, D, D, D};
+      gm.nblk0 = cbD;
+      hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_NONE>, dim3(cbD, kSplit), gblock, gemm_lds, stream, gm);
+    };
+
+    kr_at(K);
+    for (int e = K; e >= 1; --e) {
+      const int i = e - 1;
+      aa.e = e;
+      hipLaunchKernelGGL(lgcp_uha_adj_point_kernel, dim3(M), dim3(256), 0, stream, aa);
+      hv_product();
+      hipLaunchKernelGGL(lgcp_uha_gather_kernel, dim3((M * D + 255) / 256), dim3(256), 0, stream, aa);
+      const LgcpUhaFwdSet& fa = g.fs[0];
+      const LgcpUhaFwdSet& fb = g.fs[1];
+      lgcp_uha_net(d, lay, params, kinv, M, i, gws + fa.zin, bias1, gws + fa.slab1, gws + fa.pre1, gws + fa.u1, gws + fa.slab2,
+                   gws + fa.pre2, gws + fa.u2, gws + fa.sn, nullptr, nullptr, counters, gemm_lds, stream);
+      lgcp_uha_net(d, lay, params, kinv, M, i, gws + fb.zin, bias1, gws + fb.slab1, gws + fb.pre1, gws + fb.u1, gws + fb.slab2,
+                   gws + fb.pre2, gws + fb.u2, gws + fb.sn, nullptr, nullptr, counters, gemm_lds, stream);
+      hipLaunchKernelGGL(lgcp_uha_adj_b_kernel, dim3(M), dim3(256), 0, stream, aa);
+      net_backward(fb, (int64_t)(2 * i + 1) * n + base, i);
+      hipLaunchKernelGGL(lgcp_uha_adj_a_kernel, dim3(M), dim3(256), 0, stream, aa);
+      net_backward(fa, (int64_t)(2 * i) * n + base, i);
+      hipLaunchKernelGGL(lgcp_uha_adj_fin_kernel, dim3(M), dim3(256), 0, stream, aa);
+      kr_at(i);
+    }
+    aa.e = 0;
+    hipLaunchKernelGGL(lgcp_uha_adj_point_kernel, dim3(M), dim3(256), 0, stream, aa);
+    hv_product();
+    hipLaunchKernelGGL(lgcp_uha_adj_z0_kernel, dim3(M), dim3(256), 0, stream, aa);
+    hipLaunchKernelGGL(lgcp_colsum_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, gws + g.gmu_acc, (int64_t)M, D, D,
+                       grad + lay.vd_mean, 1.0f, 1);
+    hipLaunchKernelGGL(lgcp_colsum_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, gws + g.glam_acc, (int64_t)M, D, D,
+                       grad + lay.vd_logdiag, 1.0f, 1);
+  }
+  // ---- deferred parameter contractions over all 2 K n rows
+  const int64_t R = (int64_t)2 * K * n;
+  hipLaunchKernelGGL(lgcp_tn_gemm_kernel, dim3((IN + 127) / 128, (IN + 127) / 128, kTnSplit), dim3(256), 0, stream, gws + g.U1, gws + g.DA2,
+                     grad + lay.g_w2, R, IN, IN, IN, IN, IN);                                   // dW2 = U1^T dA2
+  hipLaunchKernelGGL(lgcp_tn_gemm_kernel, dim3((D + 127) / 128, (IN + 127) / 128, kTnSplit), dim3(256), 0, stream, gws + g.U2, gws + g.DO,
+                     grad + lay.g_w3, R, IN, D, IN, D, D);                                      // dW3 = U2^T dO
+  hipLaunchKernelGGL(lgcp_tn_gemm_kernel, dim3((IN + 127) / 128, (2 * D + 127) / 128, kTnSplit), dim3(256), 0, stream, gws + g.XIN, gws + g.DA1,
+                     grad + lay.g_w1, R, 2 * D, IN, 2 * D, IN, IN);                             // dW1[:2D] = [z; rho]^T dA1
+  hipLaunchKernelGGL(lgcp_colsum_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, gws + g.DO, R, D, D, grad + lay.g_b3, 1.0f, 0);
+  hipLaunchKernelGGL(lgcp_colsum_kernel, dim3((IN + 255) / 256), dim3(256), 0, stream, gws + g.gb2, (int64_t)1, IN, IN, grad + lay.g_b2, 1.0f, 0);
+  hipLaunchKernelGGL(lgcp_uha_scal_reduce_kernel, dim3(K + 1), dim3(256), 0, stream, gws + g.sc, n, K, gws + g.gbeta, gws + g.geps,
+                     grad + lay.gamma, grad + lay.g_factor);
+  // schedule (cos^2), embedding table, W1[2d:], b1 from the S / S2 / beta / eps tables
+  int rc = launch_net_tails(d, 2 * D, CMCD_EPS_COS_SQ, lay, sw, params, gws, g.S, g.S2, g.gbeta, g.geps, IN, nullptr, grad, stream);
+  if (rc != CMCD_OK) return rc;
   return hipGetLastError() == hipSuccess ? CMCD_OK : CMCD_ERR_HIP;
 }
 

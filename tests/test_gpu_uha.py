@@ -179,3 +179,44 @@ def test_lgcp_matches_oracle(hip_lib, param_set, n, k):
     rep = compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"UHA lgcp n={n} k={k}")
     print("UHA lgcp", n, k, rep, "mean loss", float(val), l_ref.mean())
     assert abs(float(val) - losses.double().mean().item()) <= 1e-5 * abs(l_ref.mean())
+
+
+@pytest.mark.parametrize("n,K", [(5, 3), (37, 2)])
+def test_lgcp_gradient_matches_autograd(hip_lib, param_set, n, K):
+    """d = 1600: the reverse launch sequence (both network evaluations of every bridge recomputed and back-propagated,
+    deferred A^T B parameter contractions over 2 K n rows) vs autograd through the float64 restatement.  n = 37 spans two
+    passes of 32 particles."""
+    from helpers import lgcp_counts_fixture
+    from oracle import cmcd_oracle_torch as ot
+    counts = lgcp_counts_fixture()
+    b = synthetic.build("lgcp_n20_k128", device="cuda", lgcp_counts=counts, boundmode=MODE, nbridges=K, N=n, init_eps=0.02,
+                        init_gamma=5.0)
+    seeds = synthetic.parity_seeds(n)
+    grad, (losses, z) = mcdbm.compute_bound_grad(torch.from_numpy(seeds).cuda(), b["params_flat"], b["unflatten"],
+                                                 b["params_fixed"], b["target"])
+    torch.cuda.synchronize()
+    dim, _, mode, spec = b["params_fixed"]
+    p = synthetic.oracle_params(b["unflatten"], b["params_flat"])
+    val, l_ref, z_ref, g = ot.bound_and_grad(seeds, p, dim, K, mode, spec.arch, ot.make_logp_lgcp(counts))
+    np.testing.assert_allclose(losses.cpu().numpy(), l_ref, rtol=2e-4, atol=0.5)
+    un = b["unflatten"]
+    gh = grad.double().cpu().numpy()
+
+    def leaf(*path):
+        off, shape = un.layout[(0,) + path] if (0,) + path in un.layout else un.layout[(1,) + path]
+        return gh[off:off + max(1, int(np.prod(shape)))].reshape(shape)
+    (w1, b1), (w2, b2), (w3, b3) = [(("sn", "nn", i, 0), ("sn", "nn", i, 1)) for i in range(3)]
+    checks = {"vd.mean": (leaf("vd", "mean"), g["vd"]["mean"]), "vd.logdiag": (leaf("vd", "logdiag"), g["vd"]["logdiag"]),
+              "eps": (leaf("eps"), g["eps"]), "gamma": (leaf("gamma"), g["gamma"]),
+              "mgridref_y": (leaf("mgridref_y"), g["mgridref_y"]),
+              "W1": (leaf(*w1), g["sn"]["W1"]), "b1": (leaf(*b1), g["sn"]["b1"]), "W2": (leaf(*w2), g["sn"]["W2"]),
+              "b2": (leaf(*b2), g["sn"]["b2"]), "W3": (leaf(*w3), g["sn"]["W3"]), "b3": (leaf(*b3), g["sn"]["b3"]),
+              "emb": (leaf("sn", "emb"), g["sn"]["emb"]), "factor_sn": (leaf("sn", "factor_sn"), g["sn"]["factor_sn"])}
+    worst = {}
+    for name, (a, r) in checks.items():
+        r = np.asarray(r, np.float64).reshape(a.shape)
+        scale = max(np.abs(r).max(), 1e-12)
+        worst[name] = (float(np.abs(a - r).max() / scale), float(scale))
+    print({k: "%.1e (|ref| %.1e)" % v for k, v in worst.items()})
+    bad = {k: v for k, v in worst.items() if v[0] > 5e-3 and v[1] > 1e-9}
+    assert not bad, bad
