@@ -1,18 +1,24 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the CMCD annealed-Langevin bound on MI355X.
 
-A "step" is one `compute_bound` forward over one batch of synthetic particles.  N = 1: the hot path named by
-BASELINE.json (many_gmm, MCD_CAIS_sn, N=2000, nbridges=256, dds net).  N > 1: one process per GPU (torch.distributed,
-backend nccl = RCCL), particles sharded, one all-gather of the 5-number statistics vector per step merges the ELBO
-mean / ln Z across ranks; three legs are timed in the same job and reported under "legs":
+A "step" is one `compute_bound` forward over one batch of synthetic particles.  The HEADLINE (`value`, `config`,
+`roofline`) is the same workload at every N: the hot path named by BASELINE.json (many_gmm, MCD_CAIS_sn, N=2000,
+nbridges=256, dds net) with 2000 particles PER GPU ("scaling": "weak"), so a driver-built 1 -> 8 curve divides like by
+like.  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), particles sharded, one all-gather of the
+5-number statistics vector per step merges the ELBO mean / ln Z across ranks; in the headline every step's all-gather
+and merge COMPLETE (in stream order) before the next step's forward — what a `compute_bound` call returning the merged
+scalar costs.  Further legs are timed in the same job and reported under "legs":
 
-  weak                 the named batch (2000 particles) on every rank
+  weak                 the headline measurement
+  weak_pipelined       the same with the all-gather issued async and merged one step late (its latency hidden behind
+                       the next forward): the rate of an evaluation loop that does not consume each scalar at once
   strong_named         the named batch split over the ranks (2000 / N each) — north_star's "strong scaling", latency-bound
   strong_sharded_cfg4  BASELINE.json configs[3]: many_gmm, MCD_CAIS_var_sn, 16000 particles x 132-wide net split over
-                       the ranks (the configuration BASELINE names for 8 GPUs) — the HEADLINE of an N > 1 line
+                       the ranks (the configuration BASELINE names for 8 GPUs), with its sharded VarGrad training step
 
-Each strong leg also times the un-split batch on rank 0's GPU alone inside the same job (`single_gpu_ms`), so the
-line carries its own strong-scaling ratio.  Rank 0 prints ONE JSON line.
+Each strong leg also times the un-split batch on rank 0's GPU alone inside the same job (`single_gpu_ms`,
+`speedup_vs_single_gpu`), so the line carries its own strong-scaling ratios; `collective` holds the measured latency of
+the statistics all-gather + merge.  Rank 0 prints ONE JSON line.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
@@ -52,7 +58,7 @@ def stored_traffic(key):
     """HBM bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of
     this same command, tools/probes/pmc_hbm.sh) — bench.py cannot collect counters on itself.  The summary records the
     sha of the kernel sources it was measured on; a figure from another build is reported as null, not as current."""
-    for rnd in ("r02_pmc", "r01_pmc"):
+    for rnd in ("r03_pmc", "r02_pmc", "r01_pmc"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", rnd, "summary.json")))
         except Exception:
@@ -160,28 +166,18 @@ class Leg:
                                          b["params_fixed"], b["target"], eps_schedule=b["eps_schedule"],
                                          grad_clipping=b["grad_clipping"])
 
-    def kernel_name(self, n):
-        mcdbm = self._mcdbm
-        if self.b["cfg"]["model"] == "lgcp":
-            return "lgcp launch sequence (skinny GEMMs + state kernels)"
-        wide = self.spec.width >= 128
-        tiles = (n + 15) // 16
-        cfg = self.b["cfg"]
-        # the library's selection rule (cmcd_kernels.hip: coop_max_tiles)
-        lim = 512
-        if cfg["model"] == "many_gmm":
-            lim = 1536 if cfg["nn_arch"] == "dds" else (768 if wide else 512)
-        coop = mcdbm.KERNEL_VARIANT in (2, 3, 4) or (mcdbm.KERNEL_VARIANT == 0 and tiles <= lim)
-        if not coop:
-            return "traj_kernel"
-        half = mcdbm.KERNEL_VARIANT == 4 or (mcdbm.KERNEL_VARIANT != 3 and n <= 2048)
-        return "coop_kernel<%d-particle tiles%s>" % (8 if half else 16, ", 132-wide net" if wide else "")
+    def kernel_name(self):
+        """What the library launched for this leg's last forward (cmcd_last_kernel_name): not re-derived here."""
+        from cmcd_amd import _lib
+        return _lib.last_kernel_name()
 
 
-def time_leg(leg, steps, warmup, use_dist, device, world, sharded=True, spinup=0):
+def time_leg(leg, steps, warmup, use_dist, device, world, sharded=True, spinup=0, pipelined=False):
     """W untimed + K timed forward steps of `leg` on this rank's shard: barrier + synchronize on both sides, MAX over ranks.
-    Multi-GPU: one RCCL all-gather of the 40-byte statistics vector + one merge kernel per step.  The collective is
-    latency-only (~20 us against a >= 240 us step), so it is taken off the launch stream: torch's process group runs it
+    Multi-GPU: one RCCL all-gather of the 40-byte statistics vector + one merge kernel per step.
+    pipelined=False (the headline): the all-gather and the merge of step k are enqueued behind its forward and complete, in
+    stream order, before the forward of step k + 1 — the cost of a call that returns the merged scalar.
+    pipelined=True: the collective is latency-only, so it is taken off the launch stream: torch's process group runs it
     on its own stream (async_op=True) behind an event on the forward of step k, and the launch stream waits for it only
     after the forward of step k+1 has been enqueued — the statistics of step k are merged one step late, every step's
     all-gather and merge still run inside the timed region (the last one is drained before the closing barrier)."""
@@ -197,7 +193,10 @@ def time_leg(leg, steps, warmup, use_dist, device, world, sharded=True, spinup=0
 
     def step(k):
         losses, z, stats = leg.forward()
-        if gather:
+        if gather and not pipelined:
+            dist.all_gather_into_tensor(gathered[0], stats)      # same stream order as the forward: done before step k + 1
+            stats = parallel.merge_stats(gathered[0].view(world, parallel.NSTATS))
+        elif gather:
             work = dist.all_gather_into_tensor(gathered[k & 1], stats, async_op=True)
             merged = drain() if pending else None
             pending.append((work, gathered[k & 1], stats))
@@ -236,7 +235,7 @@ def time_leg(leg, steps, warmup, use_dist, device, world, sharded=True, spinup=0
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    return dict(elapsed=elapsed, kern_ms=kern_ms, launches=launches, losses=losses, stats=stats)
+    return dict(elapsed=elapsed, kern_ms=kern_ms, launches=launches, losses=losses, stats=stats, kernel=_lib.last_kernel_name())
 
 
 def leg_report(leg, t, steps):
@@ -254,7 +253,7 @@ def leg_report(leg, t, steps):
     return {
         "workload": leg.cfg_name, "scaling": "weak" if leg.weak else "strong", "global_particles": leg.n_global,
         "particles_per_gpu": leg.n_local, "nbridges": leg.K, "value": units * steps / t["elapsed"],
-        "ms_per_step": t["elapsed"] / steps * 1e3, "kernel": leg.kernel_name(leg.n_local), "kernel_ms": kern_s * 1e3,
+        "ms_per_step": t["elapsed"] / steps * 1e3, "kernel": t.get("kernel") or leg.kernel_name(), "kernel_ms": kern_s * 1e3,
         "kernel_frac_of_fp32_peak": leg.n_local * leg.K * f_alg / kern_s / 1e12 / PEAK_FP32_TFLOPS,
         "elbo": float(-fin["mean"]), "ln_z": float(fin["ln_z"]), "loss_var": var, "n_finite": float(fin["n_finite"]),
     }
@@ -266,7 +265,11 @@ def main():
     # defaults: 0.1 s of timed work — 20 steps (7 ms) end before the GPU's clocks have settled
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--spinup", type=int, default=300, help="untimed launches before the warm-up steps (clock settling)")
+    ap.add_argument("--spinup", type=int, default=-1,
+                    help="untimed launches before the warm-up steps (clock settling); -1 = as many as fill --spinup-seconds")
+    ap.add_argument("--spinup-seconds", type=float, default=0.35,
+                    help="device time of the untimed spin-up: a count-based spin-up (300 launches = 0.07 s) left the clocks "
+                         "of a fresh box unsettled for a 20-step run (r02: 0.202 ms against 0.191 ms for 300 steps)")
     ap.add_argument("--config", default=None, help="name in cmcd_amd.synthetic.CONFIGS")
     ap.add_argument("--particles", type=int, default=None, help="override N per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -319,12 +322,49 @@ def main():
     forward = weak.forward
 
     legs = {}
+    if args.spinup < 0:
+        # time-based spin-up: a first synchronised batch gives the step time, the spin-up is then that many launches
+        for _ in range(10):
+            forward()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(40):
+            forward()
+        torch.cuda.synchronize()
+        est = max((time.perf_counter() - t0) / 40, 1e-5)
+        args.spinup = int(min(max(args.spinup_seconds / est, 50), 5000))
     tw = time_leg(weak, args.steps, args.warmup, use_dist, device, world, spinup=args.spinup)
     legs["weak"] = leg_report(weak, tw, args.steps)
     elapsed, kern_ms, launches, losses, stats = tw["elapsed"], tw["kern_ms"], tw["launches"], tw["losses"], tw["stats"]
     default_workload = name == synthetic.NORTH_STAR and not args.particles
 
     head_leg, head_t = weak, tw
+    collective = None
+    if world > 1:
+        # the same batch with the statistics all-gather taken off the critical path (merged one step late)
+        tp = time_leg(weak, args.steps, args.warmup, use_dist, device, world, spinup=0, pipelined=True)
+        legs["weak_pipelined"] = leg_report(weak, tp, args.steps)
+        # the collective alone: all-gather of the 5 doubles + merge kernel, back to back on the launch stream, HIP events
+        buf = torch.zeros(world * parallel.NSTATS, dtype=torch.float64, device=device)
+        st5 = tw["stats"].clone()
+        for _ in range(20):
+            dist.all_gather_into_tensor(buf, st5)
+            parallel.merge_stats(buf.view(world, parallel.NSTATS))
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 200
+        dist.barrier()
+        e0.record()
+        for _ in range(reps):
+            dist.all_gather_into_tensor(buf, st5)
+            parallel.merge_stats(buf.view(world, parallel.NSTATS))
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / reps * 1e3
+        tt = torch.tensor([us], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        collective = {"what": "all_gather_into_tensor of 5 float64 per rank + fixed-order merge kernel, stream-ordered",
+                      "backend": dist.get_backend(), "us_per_call": float(tt.item()), "bytes_per_rank": 40}
     if default_workload and not args.no_legs:
         # strong scaling on the named batch (2000 / N per rank) and on configs[3] (16000 x 132-wide net split over the ranks)
         strong = Leg("strong_named", name, n_named, False, device, rank, world) if world > 1 else None
@@ -351,8 +391,6 @@ def main():
                 cfg4_t = t
         if world == 1:
             legs["strong_named"] = dict(legs["weak"], scaling="strong")      # N = 1: the same measurement
-        else:
-            head_leg, head_t = cfg4, cfg4_t
         # configs[3]'s training step on its shard: VarGrad value + gradient, statistics all-gather ("RCCL log-w
         # all-reduce") between forward and gradient, one all-reduce of grad_flat
         try:
@@ -382,8 +420,8 @@ def main():
         except NotImplementedError as e:
             legs["strong_sharded_cfg4"]["train_step_error"] = str(e)
 
-    # ---- headline: N = 1 the named batch; N > 1 strong scaling on configs[3]
-    hl = leg_report(head_leg, head_t, args.steps)
+    # ---- headline: the named batch per GPU at every N (weak scaling; the collective completes inside every step)
+    hl = legs["weak"]
     hcfg = head_leg.b["cfg"]
     f_alg, f_survey = flops_per_particle_step(hcfg, head_leg.dim, head_leg.spec.width)
     value, n, K, dim = hl["value"], head_leg.n_local, head_leg.K, head_leg.dim
@@ -393,8 +431,6 @@ def main():
     traffic, traffic_src = (None, None)
     if head_leg is weak and default_workload:
         traffic, traffic_src = stored_traffic("coop_kernel")
-    elif head_leg is not weak and head_leg.n_local <= 2048:      # the 8-particle-tile instance of the 132-wide net
-        traffic, traffic_src = stored_traffic("coop_kernel_t9_half")
 
     result = {
         "metric": "bridge-steps*particles/sec", "value": value, "unit": "bridge-steps*particles/s",
@@ -417,9 +453,11 @@ def main():
         "legs": legs,
     }
     if world > 1:
-        result["scaling_note"] = ("headline = strong scaling on BASELINE configs[3] (16000 particles x 132-wide net split over the "
-                                  "ranks); legs.weak / legs.strong_named are the named batch; each strong leg carries the "
-                                  "same job's single-GPU time")
+        result["collective"] = collective
+        result["scaling_note"] = ("headline = the named batch (2000 particles) per GPU, statistics all-gather + merge completed "
+                                  "inside every step; legs.weak_pipelined hides the collective behind the next forward; "
+                                  "legs.strong_named / legs.strong_sharded_cfg4 split ONE batch over the ranks and carry the same "
+                                  "job's single-GPU time (speedup_vs_single_gpu)")
     # untrained net at init_sigma = 60: some particles leave float32 range exactly as in the reference (parity.inf_set_equal),
     # so the plain mean is -inf; the mean over this rank's finite particles is reported beside it
     lfin = losses[torch.isfinite(losses)]

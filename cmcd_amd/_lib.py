@@ -100,6 +100,9 @@ def lib():
         L.cmcd_stats_merge_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.cmcd_debug_capture_noise.restype = C.c_int
         L.cmcd_debug_capture_noise.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cmcd_debug_grad_item.restype = C.c_int
+        L.cmcd_debug_grad_item.argtypes = [C.c_int]
+        L.cmcd_last_kernel_name.restype = C.c_char_p
         L.cmcd_profile_enable.restype = C.c_int
         L.cmcd_profile_enable.argtypes = [C.c_int]
         L.cmcd_profile_collect.restype = C.c_int
@@ -132,6 +135,24 @@ def stats_merge(stats_rows, n_per):
     out3 = (C.c_double * 3)()
     check(lib().cmcd_stats_merge(flat, ns, cnt, merged, out3))
     return list(merged), out3[0], out3[1], out3[2]
+
+
+_grad_item_sent = None
+
+
+def sync_grad_item_override():
+    """Forwards CMCD_GRAD_ITEM (unset / "0" / "1"; tests and tools/probes) to the library when it changed since the
+    last gradient call of this process: the library reads no environment on its per-call path."""
+    global _grad_item_sent
+    want = os.environ.get("CMCD_GRAD_ITEM")
+    if want != _grad_item_sent:
+        check(lib().cmcd_debug_grad_item(-1 if want is None else int(want != "0")))
+        _grad_item_sent = want
+
+
+def last_kernel_name():
+    """The trajectory kernel (or launch sequence) the last forward call of this thread enqueued."""
+    return lib().cmcd_last_kernel_name().decode()
 
 
 def profile_enable(on=True):

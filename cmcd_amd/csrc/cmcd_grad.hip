@@ -1131,6 +1131,15 @@ static inline unsigned geffner_tail_blocks(const TailArgs& a) {
 // per-e outer products over e in a fixed order (no atomics: 4.3 M float atomics took 50 us, this takes ~15).
 constexpr int kTailRow = 448;   // per e: emb[128] | hh[64] | tau[64] | dtau[64] | dact[64] | dphase[64]
 
+// ONE wave runs this body (64 threads): its LDS hand-overs need no workgroup barrier — the LDS queue of a wave is in
+// order — only a compiler / counter fence.  (r02 called it from the first wave of a 256-thread block with
+// __syncthreads() inside: a barrier not reached by every thread of the block is undefined behaviour.)
+__device__ __forceinline__ void tail_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): every LDS write of this wave has landed
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __device__ __forceinline__ void grad_dds_tail_body(const TailArgs& a, const unsigned bidx, const unsigned gdim) {
   __shared__ float emb[128], ha[64], hh[64], dtau[64], dh[64], dact[64];
   const int j = threadIdx.x, t = bidx, D = a.D;
@@ -1151,12 +1160,12 @@ __device__ __forceinline__ void grad_dds_tail_body(const TailArgs& a, const unsi
     emb[j] = sinf(arg);
     emb[64 + j] = cosf(arg);
   }
-  __syncthreads();
+  tail_wave_sync();
   float acc = P[a.lay.d_tb1 + j];
   for (int k = 0; k < 128; ++k) acc = fmaf(emb[k], P[a.lay.d_tw1 + k * 64 + j], acc);
   ha[j] = acc;
   hh[j] = gelu_exact(acc);
-  __syncthreads();
+  tail_wave_sync();
   acc = P[a.lay.d_tb2 + j];
   for (int k = 0; k < 64; ++k) acc = fmaf(hh[k], P[a.lay.d_tw2 + k * 64 + j], acc);
   const float tau = acc;
@@ -1164,7 +1173,7 @@ __device__ __forceinline__ void grad_dds_tail_body(const TailArgs& a, const unsi
   acc = 0.f;
   for (int n = 0; n < 64; ++n) acc = fmaf(P[a.lay.d_sw1 + (int64_t)(D + j) * 64 + n], S[n], acc);
   dtau[j] = acc;
-  __syncthreads();
+  tail_wave_sync();
   acc = 0.f;
   for (int n = 0; n < 64; ++n) acc = fmaf(P[a.lay.d_tw2 + j * 64 + n], dtau[n], acc);
   dh[j] = acc;
@@ -1174,7 +1183,7 @@ __device__ __forceinline__ void grad_dds_tail_body(const TailArgs& a, const unsi
     const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
     dact[j] = dh[j] * (cdf + x * pdf);
   }
-  __syncthreads();
+  tail_wave_sync();
   float de[2];
   for (int q = 0; q < 2; ++q) {
     const int k = j + 64 * q;
@@ -1209,7 +1218,7 @@ __global__ __launch_bounds__(256) void grad_tails_fused_kernel(TailArgs a, unsig
   } else if (b == n_reduce) {
     grad_sched_tail_body(a, 0, 1);
   } else if (a.arch == CMCD_ARCH_DDS) {
-    if (threadIdx.x < 64) grad_dds_tail_body(a, b - n_reduce - 1, n_third);   // waves 1 - 3 leave: its barriers count wave 0 only
+    if (threadIdx.x < 64) grad_dds_tail_body(a, b - n_reduce - 1, n_third);   // wave 0 only; the body synchronises at wave level
   } else {
     grad_geffner_tail_body(a, b - n_reduce - 1, n_third);
   }
@@ -1278,10 +1287,14 @@ static grad_fn pick_grad(const cmcd_desc& d, int T, bool bptt, bool item = false
 bool grad_available(const cmcd_desc& d, int T) { return pick_grad(d, T, false) != nullptr; }
 bool bptt_available(const cmcd_desc& d, int T) { return pick_grad(d, T, true) != nullptr; }
 
-// Work-item (small-batch) path: worthwhile while whole-chain waves cannot fill the chip.  CMCD_GRAD_ITEM=0/1 overrides.
+// Work-item (small-batch) path: worthwhile while whole-chain waves cannot fill the chip.  cmcd_debug_grad_item(0 / 1)
+// pins it process-wide (tests and probes run every case through both paths; the Python binding forwards
+// CMCD_GRAD_ITEM from the environment), -1 returns to the measured rule.  No getenv on the per-call path.
+static int grad_item_override = -1;   // process-wide (diagnostic)
+void set_grad_item_override(int v) { grad_item_override = v; }
 bool grad_item_mode(const cmcd_desc& d, int T, int64_t n) {
   if (pick_grad(d, T, false, true) == nullptr) return false;
-  if (const char* e = getenv("CMCD_GRAD_ITEM")) return atoi(e) != 0;
+  if (grad_item_override >= 0) return grad_item_override != 0;
   // measured crossover on MI355X (tools/probes/grad_item_sweep.py, dds net, K = 256): ~11k particles for the
   // reparameterised gradient (it pays the Jacobian pass), ~17k for the local one
   // the 132-wide net (3-wave workgroups, fragments from L2) is faster item-wise at every size measured (N = 2000:

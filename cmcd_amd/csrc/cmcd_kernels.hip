@@ -30,6 +30,7 @@
 namespace cmcd {
 
 static thread_local char g_err[512] = "";
+static thread_local char g_kernel_name[96] = "";   // cmcd_last_kernel_name
 
 // Optional in-library timing of the trajectory kernel: when enabled, every cmcd_bound_forward
 // brackets its traj_kernel launch with a hipEvent pair on the caller's stream (bench.py reads
@@ -1002,6 +1003,7 @@ extern "C" {
 
 int cmcd_version(void) { return CMCD_ABI_VERSION; }
 const char* cmcd_last_error(void) { return g_err; }
+const char* cmcd_last_kernel_name(void) { return g_kernel_name; }
 
 int64_t cmcd_target_floats(const cmcd_desc* desc, int32_t n_mixes) {
   if (!desc) return -1;
@@ -1089,6 +1091,7 @@ static int forward_impl(const cmcd_desc* desc, const cmcd_layout* lay, const int
     SchedArgs sa{params, wsf, *lay, lw, (int32_t)K, d.ngrid, dl.eps_schedule, -1, -1};
     hipLaunchKernelGGL(prep_sched_kernel, dim3(1), dim3(256), 0, st, sa);
     double* partials = nullptr;
+    snprintf(g_kernel_name, sizeof(g_kernel_name), "lgcp launch sequence (skinny GEMMs + state kernels)");
     rc = lgcp_forward(dl, *lay, lw, seeds, n, params, target_consts, wsf, out_loss, out_z, &partials, traj, stream_);
     if (rc != CMCD_OK) return fail(rc, "lgcp launch sequence failed%s");
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, partials, (int32_t)n, out_stats);
@@ -1110,6 +1113,7 @@ static int forward_impl(const cmcd_desc* desc, const cmcd_layout* lay, const int
     TrajArgs tu{seeds, params, ws, reinterpret_cast<double*>(ws + w.partials), out_loss, out_z, *lay, w, n,
                 (int32_t)K, 0, 1, traj, 0};
     tu.dbg_bits = cap.bits; tu.dbg_keys = cap.keys; tu.dbg_noise = cap.noise;
+    snprintf(g_kernel_name, sizeof(g_kernel_name), "uha_traj_kernel");
     rc = uha_forward_launch(d, tu, stream);
     if (rc != CMCD_OK) return fail(rc, "MCD_CAIS_UHA_sn launch failed%s");
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, stream,
@@ -1143,6 +1147,8 @@ static int forward_impl(const cmcd_desc* desc, const cmcd_layout* lay, const int
       }
       CMCD_HIP_CHECK(hipEventRecord(g_prof.ev[g_prof.used][0], stream));
     }
+    snprintf(g_kernel_name, sizeof(g_kernel_name), "coop_kernel<%d-particle tiles%s>", half ? 8 : 16,
+             w.T == 9 ? ", 132-wide net" : "");
     rc = coop_launch(d, ta, half, stream);
     if (rc != CMCD_OK) return fail(rc, "cooperative launch failed%s");
     if (prof) {
@@ -1179,6 +1185,7 @@ static int forward_impl(const cmcd_desc* desc, const cmcd_layout* lay, const int
     }
     CMCD_HIP_CHECK(hipEventRecord(g_prof.ev[g_prof.used][0], stream));
   }
+  snprintf(g_kernel_name, sizeof(g_kernel_name), "traj_kernel");
   hipLaunchKernelGGL(fn, dim3(blocks), dim3(64 * nw), lds_bytes, stream, ta);
   if (prof) {
     CMCD_HIP_CHECK(hipEventRecord(g_prof.ev[g_prof.used][1], stream));
@@ -1460,6 +1467,12 @@ int cmcd_stats_merge_device(const double* rows, int32_t count, double* out5, voi
   if (!rows || !out5 || count < 1) return fail(CMCD_ERR_BAD_ARG, "null pointer argument%s");
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream_), rows, count, out5);
   CMCD_HIP_CHECK(hipGetLastError());
+  return CMCD_OK;
+}
+
+int cmcd_debug_grad_item(int mode) {
+  if (mode < -1 || mode > 1) return fail(CMCD_ERR_BAD_ARG, "mode must be -1, 0 or 1%s");
+  set_grad_item_override(mode);
   return CMCD_OK;
 }
 

@@ -857,8 +857,16 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
   // by side, lane 0 on the caller's stream, the others on per-thread side streams forked from / joined to it by events
   // (capturable in a graph, like the reverse sweep's two streams).  One pass (the named N = 20 batch): no side stream.
   const int lanes = lgcp_lanes(n);
-  static thread_local hipStream_t side[kLanes] = {nullptr, nullptr, nullptr, nullptr};
-  static thread_local hipEvent_t ev_join[kLanes] = {nullptr, nullptr, nullptr, nullptr}, ev_fork = nullptr;
+  // side streams and events belong to ONE device: keyed by the current device (a host thread may drive several GPUs)
+  struct SideSet { hipStream_t side[kLanes]; hipEvent_t ev_join[kLanes]; hipEvent_t ev_fork; };
+  constexpr int kMaxDev = 16;
+  static thread_local SideSet sets[kMaxDev] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return CMCD_ERR_HIP;
+  SideSet& ss = sets[dev];
+  hipStream_t* side = ss.side;
+  hipEvent_t* ev_join = ss.ev_join;
+  hipEvent_t& ev_fork = ss.ev_fork;
   if (lanes > 1 && !ev_fork) {
     for (int l = 1; l < kLanes; ++l) {
       if (hipStreamCreateWithFlags(&side[l], hipStreamNonBlocking) != hipSuccess) return CMCD_ERR_HIP;
@@ -867,13 +875,29 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
     if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return CMCD_ERR_HIP;
   }
   if (lanes > 1 && hipEventRecord(ev_fork, stream) != hipSuccess) return CMCD_ERR_HIP;   // behind the prep launch
+  // from here on the side streams are forked from the caller's stream: every exit joins them again (an un-joined fork
+  // would invalidate a graph capture and leave work of this call running behind the caller's back)
+  bool forked[kLanes] = {false, false, false, false};
+  auto join_all = [&]() {
+    bool ok = true;
+    for (int l = 1; l < lanes; ++l) {
+      if (!forked[l]) continue;
+      ok = hipEventRecord(ev_join[l], side[l]) == hipSuccess && ok;
+      ok = hipStreamWaitEvent(stream, ev_join[l], 0) == hipSuccess && ok;
+    }
+    return ok;
+  };
+  auto bail = [&]() { join_all(); return (int)CMCD_ERR_HIP; };
 
   int* counters[kLanes];
   for (int l = 0; l < lanes; ++l) {
     hipStream_t st_l = l == 0 ? stream : side[l];
-    if (l > 0 && hipStreamWaitEvent(st_l, ev_fork, 0) != hipSuccess) return CMCD_ERR_HIP;
+    if (l > 0) {
+      if (hipStreamWaitEvent(st_l, ev_fork, 0) != hipSuccess) return bail();
+      forked[l] = true;
+    }
     counters[l] = reinterpret_cast<int*>(ws + w.lane[l].counters);
-    if (hipMemsetAsync(counters[l], 0, sizeof(int) * (cbD + cbIN), st_l) != hipSuccess) return CMCD_ERR_HIP;
+    if (hipMemsetAsync(counters[l], 0, sizeof(int) * (cbD + cbIN), st_l) != hipSuccess) return bail();
   }
   const int ula = d.mode == CMCD_MODE_ULA ? 1 : (d.mode == CMCD_MODE_ULA_SN ? 2 : 0);
   // groups of `lanes` passes; inside a group the launches are enqueued evaluation by evaluation, round-robin over the
@@ -888,7 +912,7 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
       hipStream_t st_l = l == 0 ? stream : side[l];
       const LgcpLane& wl = w.lane[l];
       M[l] = (int)((n - base) < kMP ? (n - base) : kMP);
-      if (hipMemsetAsync(ws + wl.slots, 0, sizeof(float) * 3 * cbD * kMP, st_l) != hipSuccess) return CMCD_ERR_HIP;
+      if (hipMemsetAsync(ws + wl.slots, 0, sizeof(float) * 3 * cbD * kMP, st_l) != hipSuccess) return bail();
       LgcpStateArgs st{};
       st.seeds = seeds + base; st.params = params; st.tc = tc; st.x = ws + wl.x;
       st.w = ws + wl.w; st.keys = reinterpret_cast<uint32_t*>(ws + wl.keys);
@@ -959,10 +983,7 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
       hipLaunchKernelGGL(lgcp_final_kernel, dim3(1), dim3(64), 0, st_l, fa);
     }
   }
-  for (int l = 1; l < lanes; ++l) {
-    if (hipEventRecord(ev_join[l], side[l]) != hipSuccess) return CMCD_ERR_HIP;
-    if (hipStreamWaitEvent(stream, ev_join[l], 0) != hipSuccess) return CMCD_ERR_HIP;
-  }
+  if (!join_all()) return CMCD_ERR_HIP;
   return hipGetLastError() == hipSuccess ? CMCD_OK : CMCD_ERR_HIP;
 }
 
@@ -1314,8 +1335,15 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
   // Two streams: the forward recompute of evaluation e-1 (side stream, its own buffer set) overlaps the adjoint /
   // backward launches of evaluation e (caller's stream).  Every kernel here is launch-latency-bound, so the two
   // chains run side by side; events order the hand-overs (fork / join, capturable in a graph).
-  static thread_local hipStream_t side = nullptr;
-  static thread_local hipEvent_t ev_fwd[2] = {nullptr, nullptr}, ev_bwd[2] = {nullptr, nullptr}, ev_fork = nullptr;
+  struct GradSide { hipStream_t side; hipEvent_t ev_fwd[2], ev_bwd[2], ev_fork; };
+  constexpr int kMaxDev = 16;
+  static thread_local GradSide gsets[kMaxDev] = {};   // keyed by device, like the forward's side streams
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return CMCD_ERR_HIP;
+  hipStream_t& side = gsets[dev].side;
+  hipEvent_t* ev_fwd = gsets[dev].ev_fwd;
+  hipEvent_t* ev_bwd = gsets[dev].ev_bwd;
+  hipEvent_t& ev_fork = gsets[dev].ev_fork;
   if (!side) {
     if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) return CMCD_ERR_HIP;
     for (int b = 0; b < 2; ++b) {

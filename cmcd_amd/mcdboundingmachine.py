@@ -161,6 +161,7 @@ def initialize(
 
 # --------------------------------------------------------------------------- the HIP call
 _workspaces = {}
+_WORKSPACE_CACHE = 16    # (device, stream, purpose) entries kept; beyond that the least recently used buffer is released
 
 # Kernel variant handed to the library in cmcd_desc.reserved: 0 = auto (library heuristic),
 # 1 = wave-per-tile kernel, 2 = CU-cooperative kernel (library picks the tile), 3 / 4 = cooperative on 16- / 8-particle
@@ -172,11 +173,18 @@ def _workspace(device, nbytes, tag=""):
     """Scratch buffer of one (device, HIP stream, purpose): calls enqueued on different streams of one device — from
     one host thread or several — never share a workspace, so they may overlap on the GPU (include/cmcd_hip.h: the
     library itself keeps nothing between calls).  Calls on the same stream are ordered and reuse the buffer."""
+    capturing = torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing()
+    if capturing:
+        # inside torch.cuda.graph(): the buffer must come from (and stay with) the graph's private pool, so it is neither
+        # taken from the cache nor put into it — an eager call that later runs on a recycled stream handle never sees it
+        return torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
     key = (str(device), torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0, tag)
-    ws = _workspaces.get(key)
+    ws = _workspaces.pop(key, None)          # re-inserted below: the dict is ordered by last use
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-        _workspaces[key] = ws
+    _workspaces[key] = ws
+    while len(_workspaces) > _WORKSPACE_CACHE:     # least recently used first: streams that died, one-off streams
+        _workspaces.pop(next(iter(_workspaces)))
     return ws
 
 
@@ -333,6 +341,7 @@ def compute_log_var_grad(seeds, params_flat, unflatten, params_fixed, log_prob, 
                      eps_schedule=_lib.EPS_SCHEDULE[eps_schedule], grad_clipping=int(bool(grad_clipping)),
                      ngrid=unflatten.shape("mgridref_y")[0] - 1, reserved=KERNEL_VARIANT)
     lay = _layout(unflatten, spec)
+    _lib.sync_grad_item_override()
     nbytes = L.cmcd_grad_workspace_bytes(C.byref(desc), n)
     if nbytes <= 0:
         raise NotImplementedError(_lib.last_error() or "no gradient kernel for this configuration")
@@ -405,6 +414,7 @@ def compute_bound_grad(seeds, params_flat, unflatten, params_fixed, log_prob, ep
                      eps_schedule=_lib.EPS_SCHEDULE[eps_schedule], grad_clipping=int(bool(grad_clipping)),
                      ngrid=unflatten.shape("mgridref_y")[0] - 1, reserved=KERNEL_VARIANT)
     lay = _layout(unflatten, spec) if mode != "MCD_ULA" else _layout_no_net(unflatten)
+    _lib.sync_grad_item_override()
     nbytes = L.cmcd_bound_grad_workspace_bytes(C.byref(desc), n)
     if nbytes <= 0:
         raise NotImplementedError(_lib.last_error() or "no gradient kernel for this configuration")

@@ -140,6 +140,16 @@ int cmcd_bound_forward(const cmcd_desc* desc, const cmcd_layout* layout,
                        float* out_loss, float* out_z, double* out_stats,
                        void* stream);
 
+/* ---- Measurement and diagnostic hooks: NOT part of the product path.  Nothing a result depends on goes through them;
+ * they exist for bench.py (kernel time, kernel name) and the PRNG parity test, are per host thread, and a deployment can
+ * leave them unbound.  (The CMCD_COOP_PRIO / CMCD_GRAD_ITEM environment overrides are read once per process, for the
+ * probes under tools/probes only.) */
+
+/* Name of the trajectory kernel (or launch sequence) the last cmcd_bound_forward of this host thread enqueued, e.g.
+ * "coop_kernel<8-particle tiles>", "traj_kernel", "uha_traj_kernel", "lgcp launch sequence"; "" before the first call.
+ * bench.py reports it instead of re-deriving the library's selection rule. */
+const char* cmcd_last_kernel_name(void);
+
 /* Measurement hook (bench.py): while enabled (per host thread), every cmcd_bound_forward records a
  * hipEvent pair around its trajectory-kernel launch on the caller's stream.
  * cmcd_profile_collect synchronises those events, returns the summed kernel time and the number of
@@ -153,8 +163,15 @@ int cmcd_profile_collect(double* total_ms, int64_t* launches);
  *   bits     uint32 [nbridges+1][n][dim]  the random words that become deviates (jax random_bits of normal(key, (dim,)))
  *   gen_keys uint32 [nbridges+1][n][2]    the chain key entering bridge i, gen_0 .. gen_K (mcd_cais.py:66,87,94); nullable
  *   noise    float  [nbridges+1][n][dim]  the deviates (jax.random.normal)
+ * MCD_CAIS_UHA_sn has one more draw in front of the loop (the initial momentum, mcd_under_lp_a_cais.py:92-93): bits / noise
+ * are [nbridges+2][n][dim] with stage 1 = rho_0 and stage i + 2 = bridge i; gen_keys stays [nbridges+1][n][2].
  * Pass three NULLs to disarm. */
 int cmcd_debug_capture_noise(uint32_t* bits, uint32_t* gen_keys, float* noise);
+
+/* Diagnostic: pin the gradient calls of this process to whole chains (0) or to the work-item path (1); -1 returns to
+ * the measured batch-size rule.  (Tests and tools/probes run every case through both; the Python binding forwards the
+ * CMCD_GRAD_ITEM environment variable through this call, the library itself reads no environment per call.) */
+int cmcd_debug_grad_item(int mode);
 
 /* ---- VarGrad gradient ("compute_log_var_grad"): d/d params_flat of compute_bound_var
  * (/root/reference/src/main.py:161-176 takes jax.grad of it; /root/reference/src/mcd_cais_var.py:59,79

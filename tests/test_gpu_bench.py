@@ -47,14 +47,19 @@ def test_bench_two_ranks_share_the_gpu(hip_lib):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     r = _line(out.stdout)
-    # N > 1: the headline is strong scaling on BASELINE configs[3] (16000 particles x 132-wide net split over the ranks)
-    assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["config"]["workload"] == "many_gmm_var_n16000_k256"
-    assert r["config"]["global_particles"] == 16000 and r["config"]["particles_per_gpu"] == 8000 and r["value"] > 1e6
+    # the headline is ONE workload at every N: the named batch per GPU (weak scaling), collective inside every step
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["config"]["workload"] == "many_gmm_n2000_k256_dds"
+    assert r["config"]["global_particles"] == 4000 and r["config"]["particles_per_gpu"] == 2000 and r["value"] > 1e6
+    assert r["collective"]["us_per_call"] > 0 and r["collective"]["bytes_per_rank"] == 40
     legs = r["legs"]
+    assert set(legs) == {"weak", "weak_pipelined", "strong_named", "strong_sharded_cfg4"}
+    assert legs["weak"]["value"] == pytest.approx(r["value"]) and legs["weak_pipelined"]["global_particles"] == 4000
     # whole-job units: both ranks' particles counted
     # (two processes time-slice one GPU and gather over gloo through the host here: the rates themselves mean nothing)
     assert legs["weak"]["global_particles"] == 4000 and legs["weak"]["particles_per_gpu"] == 2000
     assert legs["strong_named"]["global_particles"] == 2000 and legs["strong_named"]["particles_per_gpu"] == 1000
     for k in ("strong_named", "strong_sharded_cfg4"):
         assert legs[k]["single_gpu_ms"] > 0 and legs[k]["speedup_vs_single_gpu"] > 0
-    assert legs["strong_sharded_cfg4"]["value"] == pytest.approx(r["value"]) and legs["strong_sharded_cfg4"]["train_step_ms"] > 0
+    assert legs["strong_sharded_cfg4"]["global_particles"] == 16000 and legs["strong_sharded_cfg4"]["particles_per_gpu"] == 8000
+    assert legs["strong_sharded_cfg4"]["train_step_ms"] > 0
+    assert r["roofline"]["kernel"].startswith("coop_kernel<8-particle tiles")       # asked of the library, not re-derived

@@ -2,7 +2,8 @@
 for and prints this build's numbers next to the stored ones (the GPU test tests/test_gpu_reference_tables.py asserts a
 25-second subset; this tool is for the long rows — lgcp trains for minutes).
 
-usage (GPU box): python tools/replicate_check.py lgcp:MCD_CAIS_sn:8 lgcp:MCD_ULA_sn:8 funnel:MCD_CAIS_sn:256 [--seeds 1,2,3]"""
+usage (GPU box): python tools/replicate_check.py lgcp:MCD_CAIS_sn:8 lgcp:MCD_ULA_sn:8 funnel:MCD_CAIS_sn:256 [--seeds 1,2,3]
+                 (--seeds=1,2,3 works too; --iters N overrides the row's iteration count for a quick look)"""
 import json
 import os
 import sys
@@ -17,8 +18,12 @@ from cmcd_amd import main as cli  # noqa: E402
 TABLES = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_notebook_tables.json")))
 
 
-def run(model, mode, k, seed):
-    hp = TABLES[model]["hparams"]
+def run(model, mode, k, seed, ref=None, iters=None):
+    hp = dict(TABLES[model]["hparams"])
+    if ref and "lr" in ref:      # a row with its own learning rate (LR_DICT of /root/reference/src/configs/base.py:5-63)
+        hp["lr"] = ref["lr"]
+    if iters:
+        hp["iters"] = iters
     argv = ["--config.boundmode", mode, "--config.model", model, "--config.N", str(hp["N"]), "--config.emb_dim",
             str(hp["emb_dim"]), "--config.init_sigma", str(hp["init_sigma"]), "--config.iters", str(hp["iters"]),
             "--config.n_samples", str(hp["n_samples"]), "--config.nbridges", str(k), "--config.seed", str(seed),
@@ -33,17 +38,19 @@ def run(model, mode, k, seed):
 
 
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    seeds = (1,)
-    for a in sys.argv[1:]:
-        if a.startswith("--seeds"):
-            seeds = tuple(int(s) for s in a.split("=")[1].split(","))
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("rows", nargs="+", help="model:boundmode:nbridges")
+    ap.add_argument("--seeds", default="1", help="comma-separated training seeds")
+    ap.add_argument("--iters", type=int, default=None)
+    ns = ap.parse_args()
+    args, seeds = ns.rows, tuple(int(s) for s in ns.seeds.split(","))
     for spec in args:
         model, mode, k = spec.split(":")
         k = int(k)
         ref = next(r for r in TABLES[model]["rows"] if r["nbridges"] == k and r.get("boundmode", "MCD_CAIS_sn") == mode)
         t0 = time.time()
-        runs = np.array([run(model, mode, k, s) for s in seeds])
+        runs = np.array([run(model, mode, k, s, ref, ns.iters) for s in seeds])
         line = dict(model=model, boundmode=mode, nbridges=k, seeds=list(seeds), elbo=runs[:, 0].tolist(), ln_Z=runs[:, 1].tolist(),
                     elbo_mean=float(runs[:, 0].mean()), reference_elbo=ref["elbo"], reference_elbo_std=ref["elbo_std"],
                     reference_ln_Z=ref.get("ln_Z"), cite=ref["cite"], wall_s=round(time.time() - t0, 1))
