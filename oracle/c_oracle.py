@@ -26,6 +26,10 @@ def threads():
     return lib().cmcd_oracle_threads()
 
 
+def set_threads(n):
+    lib().cmcd_oracle_set_threads(C.c_int(int(n)))
+
+
 def bound(desc, layout, seeds, params_flat, target_consts):
     """desc/layout: the ctypes structs of cmcd_amd._lib (same ABI structs); arrays: NumPy, host.
     -> (loss[n] f32, z[n, dim] f32)"""

@@ -242,6 +242,14 @@ int cmcd_oracle_threads(void) {
 #endif
 }
 
+void cmcd_oracle_set_threads(int n) {   /* bench.py's one-thread line */
+#ifdef _OPENMP
+  if (n >= 1) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 /* Host pointers everywhere.  Returns 0, or -2 for unsupported (lgcp, widths > 256). */
 int cmcd_oracle_bound(const cmcd_desc* desc, const cmcd_layout* lay, const int32_t* seeds, int64_t n,
                       const float* P, const float* target_consts, int64_t n_target, float* out_loss,

@@ -1,0 +1,136 @@
+"""Trains a model with the ORACLE (torch float64 autograd through the restatement, on the CPU) instead of the HIP path, with
+the same driver flow, optimiser, initial parameters and per-iteration particle seeds as `python -m cmcd_amd.main`:
+
+    python tools/oracle_train.py funnel 8 --seed 1           # README flags of the row, 11000 iterations, ~10 minutes of CPU
+
+Purpose (test infrastructure, like tools/make_golden.py): (i) the first pin of the ORACLE itself to a number the
+reference holds — the stored notebook tables (tests/golden/reference_notebook_tables.json) — and (ii) to tell an
+optimiser / initialisation offset from a forward / gradient discrepancy: the HIP run of the same flags sits +0.05 above the
+reference's funnel K = 8 ELBO with a seed spread of 0.006; if the oracle-trained model lands on the
+same value the HIP kernels are not the cause.  The result is appended to tests/golden/oracle_trained_rows.json (read by
+tests/test_oracle_trained_rows.py).  Only the funnel / gmm rows are small enough for the CPU."""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from cmcd_amd import main as cli  # noqa: E402
+from cmcd_amd import boundingmachine as bm  # noqa: E402
+from cmcd_amd import mcdboundingmachine as mcdbm  # noqa: E402
+from cmcd_amd import opt, synthetic  # noqa: E402
+from cmcd_amd.model_handler import load_model  # noqa: E402
+from oracle import cmcd_oracle as orc  # noqa: E402
+from oracle import cmcd_oracle_torch as ot  # noqa: E402
+from helpers import oracle_target  # noqa: E402
+
+TABLES = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_notebook_tables.json")))
+OUT = os.path.join(ROOT, "tests", "golden", "oracle_trained_rows.json")
+
+
+def grads_to_flat(unflatten, g, numel):
+    """The oracle's gradient dict re-assembled in params_flat order (float32)."""
+    flat = torch.zeros(numel, dtype=torch.float64)
+    train, notrain = unflatten(flat)
+    allp = {**train, **notrain}
+    t = lambda a: torch.as_tensor(np.asarray(a))
+    allp["vd"]["mean"].copy_(t(g["vd"]["mean"])); allp["vd"]["logdiag"].copy_(t(g["vd"]["logdiag"]))
+    allp["eps"].copy_(t(g["eps"])); allp["mgridref_y"].copy_(t(g["mgridref_y"])); allp["gamma"].copy_(t(g["gamma"]))
+    sn, gs = allp["sn"], g["sn"]
+    if "nn" in sn:
+        (w1, b1), (w2, b2), (w3, b3) = sn["nn"]
+        for dst, k in ((w1, "W1"), (b1, "b1"), (w2, "W2"), (b2, "b2"), (w3, "W3"), (b3, "b3")):
+            dst.copy_(t(gs[k]))
+        sn["emb"].copy_(t(gs["emb"])); sn["factor_sn"].copy_(t(gs["factor_sn"]))
+    else:
+        m = lambda n: sn["drift_net/~/" + n]
+        sn["drift_net"]["timestep_phase"].copy_(t(gs["timestep_phase"]))
+        for mod, (wk, bk) in (("linear", ("t_w1", "t_b1")), ("linear_1", ("t_w2", "t_b2")), ("linear_2", ("s_w1", "s_b1")),
+                              ("linear_3", ("s_w2", "s_b2")), ("linear_zero", ("s_w3", "s_b3"))):
+            m(mod)["w"].copy_(t(gs[wk])); m(mod)["b"].copy_(t(gs[bk]))
+    return flat.to(torch.float32)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("model", choices=["funnel", "gmm"])
+    ap.add_argument("nbridges", type=int)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--iters", type=int, default=None)
+    ap.add_argument("--boundmode", default="MCD_CAIS_sn")
+    ap.add_argument("--threads", type=int, default=4)
+    ns = ap.parse_args()
+    torch.set_num_threads(ns.threads)
+    hp = TABLES[ns.model]["hparams"]
+    argv = ["--config.boundmode", ns.boundmode, "--config.model", ns.model, "--config.N", str(hp["N"]),
+            "--config.emb_dim", str(hp["emb_dim"]), "--config.init_sigma", str(hp["init_sigma"]),
+            "--config.iters", str(ns.iters or hp["iters"]), "--noconfig.pretrain_mfvi", "--config.train_vi",
+            "--noconfig.train_eps", "--config.n_samples", str(hp["n_samples"]), "--config.nbridges", str(ns.nbridges),
+            "--config.seed", str(ns.seed)]
+    if ns.model == "funnel":
+        argv += ["--config.init_eps", "0.1", "--config.lr", "0.01", "--config.eps_schedule", "cos_sq"]
+    else:
+        argv += ["--config.init_eps", str(hp["init_eps"]), "--config.lr", str(hp["lr"])]
+    config = cli.setup_config(cli.parse_flags(argv, cli.get_config()))
+
+    # the driver flow of cmcd_amd.main (= /root/reference/src/main.py:69-226), on the CPU with the oracle's gradient
+    log_prob_model, dim = load_model(config.model, config)[:2]
+    gen = torch.Generator().manual_seed(config.seed)
+    eval_gen = torch.Generator().manual_seed(config.seed + 1)
+    params_flat, unflatten, params_fixed = bm.initialize(dim=dim, nbridges=0, trainable=("vd",),
+                                                         init_sigma=config.init_sigma, device="cpu")
+    vdparams_init = {k: v.detach().cpu().clone() for k, v in unflatten(params_flat)[0]["vd"].items()}
+    trainable = ("eta", "gamma") + (("eps",) if config.train_eps else ()) + (("vd",) if config.train_vi else ()) + \
+                (("mgridref_y",) if config.train_betas else ())
+    params_flat, unflatten, params_fixed = mcdbm.initialize(
+        dim=dim, nbridges=config.nbridges, vdparams=vdparams_init, eta=config.init_eta, eps=config.init_eps,
+        trainable=trainable, mode=config.boundmode, emb_dim=config.emb_dim, nlayers=config.nlayers,
+        nn_arch=config.nn_arch, device="cpu")
+    _, K, mode, spec = params_fixed
+    n_train = min(off for path, (off, _) in unflatten.layout.items() if path[0] == 1)
+
+    def grad_and_loss(seeds, pf, un, fixed, target):
+        p = synthetic.oracle_params(un, pf)
+        _, losses, z, g = ot.bound_and_grad(seeds.numpy(), p, dim, K, mode, spec.arch, config.model, config.eps_schedule,
+                                            config.grad_clipping)
+        flat = grads_to_flat(un, g, pf.numel())
+        flat[n_train:] = 0            # params_notrain = stop_gradient(params_notrain)   mcdboundingmachine.py:142
+        return flat, (torch.from_numpy(losses.astype(np.float32)), torch.from_numpy(z.astype(np.float32)))
+
+    t0 = time.time()
+    losses, params_flat, _ = opt.run(config, config.lr, config.iters, params_flat, unflatten, params_fixed, log_prob_model,
+                                     grad_and_loss, trainable, gen)
+    train_s = time.time() - t0
+    n = config.n_samples * config.n_input_dist_seeds
+    eval_seeds = torch.randint(1, 1000000, (n,), generator=eval_gen, dtype=torch.int32).numpy()
+    p = synthetic.oracle_params(unflatten, params_flat)
+    cfg = dict(model=config.model)
+    l_eval, _ = orc.compute_log_elbo_batch(eval_seeds, p, dim, K, mode, spec.arch, oracle_target(cfg),
+                                           eps_schedule=config.eps_schedule, grad_clipping=config.grad_clipping,
+                                           dtype=np.float64, reuse=True)
+    elbo, elbo_std, lnz, lnz_std = orc.log_final_losses(l_eval.reshape(config.n_input_dist_seeds, config.n_samples))
+    ref = next(r for r in TABLES[ns.model]["rows"] if r["nbridges"] == ns.nbridges and r.get("boundmode", "MCD_CAIS_sn") == ns.boundmode)
+    rec = dict(model=ns.model, boundmode=ns.boundmode, nbridges=ns.nbridges, seed=ns.seed, iters=config.iters, lr=config.lr,
+               init_eps=config.init_eps, elbo=float(elbo), elbo_group_std=float(elbo_std), ln_Z=float(lnz),
+               ln_Z_group_std=float(lnz_std), reference_elbo=ref["elbo"], reference_elbo_std=ref["elbo_std"],
+               reference_ln_Z=ref.get("ln_Z"), reference_cite=ref["cite"], last_training_losses=[float(x) for x in losses[-5:]],
+               train_seconds=round(train_s, 1),
+               how="tools/oracle_train.py: torch float64 autograd through oracle/cmcd_oracle_torch.py on the CPU, "
+                   "cmcd_amd.opt.run (eager clip + Adam), evaluation 30 x n_samples through oracle/cmcd_oracle.py float64")
+    print("ORACLE_TRAINED", json.dumps(rec), flush=True)
+    rows = json.load(open(OUT)) if os.path.exists(OUT) else []
+    rows = [r for r in rows if (r["model"], r["boundmode"], r["nbridges"], r["seed"], r["iters"]) !=
+            (rec["model"], rec["boundmode"], rec["nbridges"], rec["seed"], rec["iters"])] + [rec]
+    json.dump(rows, open(OUT, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

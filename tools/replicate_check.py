@@ -18,12 +18,14 @@ from cmcd_amd import main as cli  # noqa: E402
 TABLES = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_notebook_tables.json")))
 
 
-def run(model, mode, k, seed, ref=None, iters=None):
+def run(model, mode, k, seed, ref=None, iters=None, init_eps=None):
     hp = dict(TABLES[model]["hparams"])
     if ref and "lr" in ref:      # a row with its own learning rate (LR_DICT of /root/reference/src/configs/base.py:5-63)
         hp["lr"] = ref["lr"]
     if iters:
         hp["iters"] = iters
+    if init_eps is not None:
+        hp["init_eps"] = init_eps
     argv = ["--config.boundmode", mode, "--config.model", model, "--config.N", str(hp["N"]), "--config.emb_dim",
             str(hp["emb_dim"]), "--config.init_sigma", str(hp["init_sigma"]), "--config.iters", str(hp["iters"]),
             "--config.n_samples", str(hp["n_samples"]), "--config.nbridges", str(k), "--config.seed", str(seed),
@@ -43,6 +45,7 @@ def main():
     ap.add_argument("rows", nargs="+", help="model:boundmode:nbridges")
     ap.add_argument("--seeds", default="1", help="comma-separated training seeds")
     ap.add_argument("--iters", type=int, default=None)
+    ap.add_argument("--init_eps", type=float, default=None, help="override the row's init_eps (rows whose flags the reference does not hold)")
     ns = ap.parse_args()
     args, seeds = ns.rows, tuple(int(s) for s in ns.seeds.split(","))
     for spec in args:
@@ -50,10 +53,11 @@ def main():
         k = int(k)
         ref = next(r for r in TABLES[model]["rows"] if r["nbridges"] == k and r.get("boundmode", "MCD_CAIS_sn") == mode)
         t0 = time.time()
-        runs = np.array([run(model, mode, k, s, ref, ns.iters) for s in seeds])
+        runs = np.array([run(model, mode, k, s, ref, ns.iters, ns.init_eps) for s in seeds])
         line = dict(model=model, boundmode=mode, nbridges=k, seeds=list(seeds), elbo=runs[:, 0].tolist(), ln_Z=runs[:, 1].tolist(),
                     elbo_mean=float(runs[:, 0].mean()), reference_elbo=ref["elbo"], reference_elbo_std=ref["elbo_std"],
-                    reference_ln_Z=ref.get("ln_Z"), cite=ref["cite"], wall_s=round(time.time() - t0, 1))
+                    reference_ln_Z=ref.get("ln_Z"), cite=ref["cite"], wall_s=round(time.time() - t0, 1), init_eps=ns.init_eps,
+                    iters=ns.iters)
         print("REPLICATE", json.dumps(line), flush=True)
 
 
