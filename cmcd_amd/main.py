@@ -6,8 +6,8 @@
   ->  opt.sample / log_final_losses (n_input_dist_seeds x n_samples)  [-> the same with the EMA parameters]
 
 Flag names, defaults and the `--config.x value` / `--config.x=value` / `--noconfig.x` forms follow
-/root/reference/src/configs/base.py:77-155 (ml_collections + absl).  Left out: W&B, plotting, the inference-gym rows of the lr table.  Modes outside the overdamped family raise
-NotImplementedError exactly like the library.  Under torchrun the particles of every iteration are sharded over the
+/root/reference/src/configs/base.py:77-155 (ml_collections + absl).  Left out: W&B, plotting, the inference-gym rows of the lr table.  Modes outside the overdamped family and 2nd-order
+CMCD (`MCD_CAIS_UHA_sn`) raise NotImplementedError exactly like the library.  Under torchrun the particles of every iteration are sharded over the
 ranks (parallel.make_sharded_grad_and_loss)."""
 import os
 import sys
@@ -56,6 +56,8 @@ def get_config():
     c.loc_scaling = 40
     c.file_path = os.path.join(os.getcwd(), "../pines.csv")
     c.save_params = ""          # extra: path of a params.pkl to write (the reference logs it as a W&B artifact)
+    c.init_gamma = 10.0         # extra: the reference has no such flag — mcdbm.initialize's default gamma = 10.0 is what
+    #                             its main.py always uses (main.py:148-159); only MCD_CAIS_UHA_sn reads gamma
     c.compute_w2 = True         # extra: --noconfig.compute_w2 skips the Sinkhorn W2 block of main.py:248-271 (test harness)
     # fields of the reference's config this driver accepts so that its README command lines run unchanged, but whose
     # only legal value here is the default (dds nets are 64-wide, the lgcp posterior is un-whitened, 40 mixtures
@@ -208,7 +210,7 @@ def main(config):
     say(f"Params being trained : {trainable}")
     params_flat, unflatten, params_fixed = mcdbm.initialize(
         dim=dim, nbridges=config.nbridges, vdparams=vdparams_init, eta=config.init_eta, eps=config.init_eps,
-        trainable=trainable, mode=config.boundmode, emb_dim=config.emb_dim, nlayers=config.nlayers,
+        gamma=config.init_gamma, trainable=trainable, mode=config.boundmode, emb_dim=config.emb_dim, nlayers=config.nlayers,
         nn_arch=config.nn_arch, device=device)
     grad_and_loss, loss_fn = mcdbm.make_grad_and_loss(config.boundmode, eps_schedule=config.eps_schedule,
                                                       grad_clipping=config.grad_clipping)

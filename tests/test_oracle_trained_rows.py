@@ -1,0 +1,26 @@
+"""The first pin of the ORACLE itself to numbers the reference holds: tests/golden/oracle_trained_rows.json records models
+trained entirely by the restatements (tools/oracle_train.py: torch float64 autograd through oracle/cmcd_oracle_torch.py,
+the eager clip + Adam loop of cmcd_amd/opt.py, evaluation through oracle/cmcd_oracle.py float64; no HIP code runs) with the
+reference README's flags, next to the values the reference stores in its notebook
+(tests/golden/reference_notebook_tables.json).  A wrong kernel mean, scale, schedule, network or target in the restatement
+moves the trained ELBO / ln Z by many sigmas (the untrained funnel bound is ELBO -2.3).
+
+It also settles where the HIP path's +0.05 ELBO offset on funnel K = 8 comes from: the
+oracle-trained model sits at the SAME value as the HIP-trained ones (-1.004 vs -1.010 +- 0.006), so the offset belongs to
+the optimiser / initialisation (the README itself says the paper's runs used a hand-written Adam), not to the kernels."""
+import json
+import os
+
+import pytest
+
+ROWS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_trained_rows.json")))
+
+
+@pytest.mark.parametrize("row", [r for r in ROWS if r["iters"] >= 11000], ids=lambda r: f"{r['model']}_k{r['nbridges']}_seed{r['seed']}")
+def test_oracle_trained_model_reaches_the_reference_notebook_row(row):
+    # ln Z: the reference's own spread over its 30 evaluation groups is the only sigma it holds (0.15 for funnel K = 8)
+    assert abs(row["ln_Z"] - row["reference_ln_Z"]) <= 0.15, (row["ln_Z"], row["reference_ln_Z"])
+    # ELBO: one training run of this build against one of the reference: 3 notebook sigmas (the measured gap is 2.4)
+    assert abs(row["elbo"] - row["reference_elbo"]) <= 3.0 * row["reference_elbo_std"], (row["elbo"], row["reference_elbo"])
+    # the bound is a bound, and training got there (first logged loss of an untrained funnel model is ~2.3)
+    assert row["elbo"] < row["ln_Z"] and max(row["last_training_losses"]) < 1.3
