@@ -1,5 +1,5 @@
 /*
- * cmcd_oracle.c — plain-C restatement of CMCD's MCD_CAIS_sn / MCD_CAIS_var_sn bound.
+ * cmcd_oracle.c — plain-C restatement of CMCD's MCD_CAIS_sn / MCD_CAIS_var_sn / MCD_CAIS_UHA_sn bounds.
  * TEST INFRASTRUCTURE ONLY: linked/loaded solely by tests/, __graft_entry__.smoke() and the
  * cpu_baseline leg of bench.py.  PARITY UNPINNED (the reference is JAX-only, cannot be imported in
  * the build container and ships no tests); pinned by the same PRNG known answers and identities as
@@ -148,7 +148,8 @@ static float target_eval(const Target* t, const float* z, float* g) {
 
 /* ---- score networks */
 typedef struct {
-  int arch, d, e, in, K;
+  int arch, d, e, in, K;   /* d: output width (= dim); in: geffner width = din + e */
+  int din;                 /* state inputs: dim, or 2 dim for concat(z, rho) (MCD_CAIS_UHA_sn, mcdboundingmachine.py:82-98) */
   const float* P;
   const cmcd_layout* lay;
   float* tau; /* dds: [K+1][64] time-path output */
@@ -182,11 +183,11 @@ static void dds_time_path(const Net* n, int t, float* tau) { /* nn_dds.py:131-14
 static void net_apply(const Net* n, const float* z, int idx, float* out) {
   const float* P = n->P;
   const cmcd_layout* L = n->lay;
-  float u[MAXW], v[MAXW];
+  float u[MAXW + 64], v[MAXW + 64];
   if (n->arch == CMCD_ARCH_DDS) { /* nn_dds.py:159-162 */
-    const int in = n->d + 64;
-    for (int j = 0; j < n->d; ++j) u[j] = z[j];
-    memcpy(u + n->d, n->tau + (size_t)idx * 64, 64 * sizeof(float));
+    const int in = n->din + 64;
+    for (int j = 0; j < n->din; ++j) u[j] = z[j];
+    memcpy(u + n->din, n->tau + (size_t)idx * 64, 64 * sizeof(float));
     for (int j = 0; j < 64; ++j) {
       float a = P[L->d_sb1 + j];
       for (int k = 0; k < in; ++k) a += u[k] * P[L->d_sw1 + k * 64 + j];
@@ -206,8 +207,8 @@ static void net_apply(const Net* n, const float* z, int idx, float* out) {
   }
   /* geffner, nn.py:42-72; index clamps like a JAX gather */
   const int in = n->in, ie = idx < n->K ? idx : n->K - 1;
-  for (int j = 0; j < n->d; ++j) u[j] = z[j];
-  for (int j = 0; j < n->e; ++j) u[n->d + j] = P[L->g_emb + (size_t)ie * n->e + j];
+  for (int j = 0; j < n->din; ++j) u[j] = z[j];
+  for (int j = 0; j < n->e; ++j) u[n->din + j] = P[L->g_emb + (size_t)ie * n->e + j];
   const int64_t W[2] = {L->g_w1, L->g_w2}, B[2] = {L->g_b1, L->g_b2};
   for (int l = 0; l < 2; ++l) {
     for (int j = 0; j < in; ++j) {
@@ -256,8 +257,10 @@ int cmcd_oracle_bound(const cmcd_desc* desc, const cmcd_layout* lay, const int32
                       float* out_z) {
   const int d = desc->dim, K = desc->nbridges;
   if (desc->target == CMCD_TARGET_LGCP || d > MAXD) return -2;
-  if (desc->mode != CMCD_MODE_CAIS_SN && desc->mode != CMCD_MODE_CAIS_VAR_SN) return -2;
-  Net net = {desc->arch, d, desc->emb_dim, d + desc->emb_dim, K, P, lay, NULL};
+  const int uha = desc->mode == CMCD_MODE_CAIS_UHA_SN;
+  if (desc->mode != CMCD_MODE_CAIS_SN && desc->mode != CMCD_MODE_CAIS_VAR_SN && !uha) return -2;
+  const int din = uha ? 2 * d : d;
+  Net net = {desc->arch, d, desc->emb_dim, din + desc->emb_dim, K, din, P, lay, NULL};
   if (desc->arch == CMCD_ARCH_GEFFNER && net.in > MAXW) return -2;
   Target tgt = {desc->target, d, desc->target == CMCD_TARGET_MANY_GMM ? (int)((n_target - 1) / 2) : 0, target_consts};
 
@@ -277,7 +280,7 @@ int cmcd_oracle_bound(const cmcd_desc* desc, const cmcd_layout* lay, const int32
       while (j < G + 1 && (float)j / (float)(G + 1) <= x) ++j;
       float x0 = (float)(j - 1) / (float)(G + 1), x1 = (float)j / (float)(G + 1);
       beta[i] = gy[j - 1] + (x - x0) / (x1 - x0) * (gy[j] - gy[j - 1]);
-      if (desc->eps_schedule == CMCD_EPS_COS_SQ) {
+      if (desc->eps_schedule == CMCD_EPS_COS_SQ || uha) {   /* the 2nd-order mode's body fixes cos^2 (mcd_under_lp_a_cais.py:33-48) */
         float c = cosf(((float)i / (float)K + 0.008f) / 1.008f * 0.5f * 3.14159265358979323846f);
         epsv[i] = eps0 * c * c;
       } else if (desc->eps_schedule == CMCD_EPS_LINEAR) {
@@ -308,6 +311,54 @@ int cmcd_oracle_bound(const cmcd_desc* desc, const cmcd_layout* lay, const int32
       w -= -(dz * dz) / (2.0f * sd[j] * sd[j]) - logf(sd[j]) - HALF_LOG_2PI;
     }
     split(b, c, tmp);
+    if (uha) {
+      /* MCD_CAIS_UHA_sn: /root/reference/src/mcd_under_lp_a_cais.py:42-112 — state (z, rho), both network calls on
+       * concat(z, rho) / concat(z, rho') at index i, eta_aux = gamma eps, one leap-frog step, clip 1e2 on grad log p only */
+      float rho[MAXD], rhop[MAXD], rpp[MAXD], x[2 * MAXD], mf[MAXD], mb[MAXD], zero[MAXD], uf[MAXD];
+      uint32_t rk[2], gp2[2];
+      const float gamma = P[lay->gamma];
+      for (int j = 0; j < d; ++j) zero[j] = 0.f;
+      split(c, rk, gp2);                    /* :92 */
+      normal(rk, d, rho);                   /* :93 */
+      w -= log_prob_kernel(rho, zero, 1.0f, d);   /* :96-97 */
+      split(gp2, tmp, gen);                 /* :100 */
+      for (int i = 0; i < K; ++i) {
+        const float be = beta[i], eps = epsv[i], eta = gamma * eps, scale = sqrtf(2.0f * eta);
+        target_eval(&tgt, z, gp);
+        for (int j = 0; j < d; ++j) {
+          float gq = -(z[j] - mean[j]) / (sd[j] * sd[j]), g = fminf(fmaxf(gp[j], -1e2f), 1e2f);
+          uf[j] = -1.0f * (be * g + (1.0f - be) * gq);                  /* :23-30,46 */
+          x[j] = z[j]; x[d + j] = rho[j];
+        }
+        net_apply(&net, x, i, s);
+        for (int j = 0; j < d; ++j) mf[j] = rho[j] * (1.0f - eta) - 2.0f * eta * s[j];   /* :52-54 */
+        uint32_t gk[2], hk[2];
+        split(gen, gk, hk);                 /* :55 */
+        normal(gk, d, noise);
+        for (int j = 0; j < d; ++j) {
+          rhop[j] = mf[j] + scale * noise[j];                           /* :58-59 */
+          rpp[j] = rhop[j] - eps * uf[j] / 2.0f;                        /* :62 */
+          zn[j] = z[j] + eps * rpp[j];                                  /* :63 */
+          x[d + j] = rhop[j];                                           /* :77: old z, new momentum */
+        }
+        net_apply(&net, x, i, s);
+        for (int j = 0; j < d; ++j) mb[j] = rhop[j] * (1.0f - eta) + 2.0f * eta * s[j];  /* :78-80 */
+        w += log_prob_kernel(rho, mb, scale, d) - log_prob_kernel(rhop, mf, scale, d);   /* :83-88 */
+        target_eval(&tgt, zn, gp);
+        for (int j = 0; j < d; ++j) {
+          float gq = -(zn[j] - mean[j]) / (sd[j] * sd[j]), g = fminf(fmaxf(gp[j], -1e2f), 1e2f);
+          float ub = -1.0f * (be * g + (1.0f - be) * gq);               /* :65 */
+          rho[j] = rpp[j] - eps * ub / 2.0f;                            /* :67 */
+        }
+        split(hk, tmp, gen);                /* :84 */
+        memcpy(z, zn, sizeof(float) * d);
+      }
+      w += log_prob_kernel(rho, zero, 1.0f, d);   /* :112 */
+      w += target_eval(&tgt, z, gp);
+      out_loss[p] = -w;
+      memcpy(out_z + p * d, z, sizeof(float) * d);
+      continue;
+    }
     split(c, tmp, gen); /* mcd_cais.py:94 */
     for (int i = 0; i < K; ++i) {
       const float be = beta[i], eps = epsv[i], scale = sqrtf(2.0f * eps);

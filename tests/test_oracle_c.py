@@ -14,6 +14,10 @@ from helpers import compare_losses, run_c_oracle, run_oracle
     ("many_gmm_n2000_k256_dds", 96, dict(nbridges=32)),
     ("many_gmm_n2000_k256_dds", 40, dict(nbridges=8, eps_schedule="linear", init_eps=0.05)),
     ("many_gmm_var_n16000_k256", 32, dict(nbridges=8)),
+    # 2nd-order CMCD (mcd_under_lp_a_cais.py): network on concat(z, rho), three restatements
+    ("gmm_n300_k8", 64, dict(boundmode="MCD_CAIS_UHA_sn")),
+    ("funnel_n300_k64", 48, dict(boundmode="MCD_CAIS_UHA_sn", nbridges=8, init_eps=0.05, init_gamma=4.0)),
+    ("many_gmm_n2000_k256_dds", 64, dict(boundmode="MCD_CAIS_UHA_sn", nbridges=16, init_eps=0.2, init_gamma=2.0, init_sigma=15.0)),
 ])
 def test_c_oracle_matches_numpy_oracle(param_set, name, n, over):
     b = synthetic.build(name, device="cpu", **over)
