@@ -93,7 +93,14 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
   float* lds_b2 = lds_w3t + D * HP;       // HP
   float* lds_b3 = lds_b2 + HP;            // 16
   float* lds_tgt = lds_b3 + 16;           // tgt_floats
-  float* stage = lds_tgt + a.w.tgt_floats;
+  // WSHARE (the 132-wide net, r03): the four waves of a workgroup walk the SAME W2 / W2^T fragment rows (each for its own
+  // work item), so a row (T fragments x 1 KB) is fetched from L2 ONCE per workgroup — wave q fetches fragments q, q + 4,
+  // q + 8 — and handed round through a double-buffered LDS row: a quarter of the L2 traffic (r02: 166 KB per work item
+  // and wave, 5.3 GB per launch at N = 2000, the matrix chain waiting on an L2 round trip per row).
+  constexpr bool WSHARE = WGLOBAL && NW == 4;
+  constexpr int WSH_FLOATS = WSHARE ? 2 * T * 256 : 0;
+  float* wsh = lds_tgt + a.w.tgt_floats;             // [2][T][64 lanes][4]
+  float* stage = wsh + WSH_FLOATS;
   // per tile: u1T, u2T, da2T [HP][16] (read by the other waves of the workgroup); da1T, du1T (read by this wave only);
   // z1, doT [16][16]; then accZ1 [D][HP], accB2 [HP] (wave-private sums over evaluations).
   // TILE_LOCAL (the 132-wide net, r02): da1 / du1 are consumed by this wave's own products right where they are formed,
@@ -317,6 +324,45 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
       // fragments (LDS, or L2 when WGLOBAL): the address arithmetic stays inside the loop (an opaque lane offset), or
       // the T*T loop-invariant 64-bit addresses are hoisted into registers and spilled (324 dwords for T = 9); the row
       // of fragments for ti+1 is requested before the MFMAs of ti so that the L2 latency hides behind them
+      if constexpr (WSHARE) {
+        constexpr int SHR = (T + NW - 1) / NW;
+        f32x4 nxt[SHR];
+        auto fetch = [&](int row) {
+          int lofs = lane * 4;
+          asm volatile("" : "+v"(lofs));
+#pragma unroll
+          for (int k = 0; k < SHR; ++k) {
+            const int to = wv + NW * k;
+            if (to < T) nxt[k] = *reinterpret_cast<const f32x4*>(w2f + (row * T + to) * 256 + lofs);
+          }
+        };
+        auto publish = [&](int bufi) {
+#pragma unroll
+          for (int k = 0; k < SHR; ++k) {
+            const int to = wv + NW * k;
+            if (to < T) *reinterpret_cast<f32x4*>(wsh + (bufi * T + to) * 256 + lane * 4) = nxt[k];
+          }
+        };
+        fetch(0);
+        publish(0);
+        __syncthreads();
+#pragma unroll
+        for (int ti = 0; ti < T; ++ti) {
+          asm volatile("" ::: "memory");
+          if (ti + 1 < T) fetch(ti + 1);            // the next row's L2 requests ride behind this row's matrix instructions
+          f32x4 afc[T];
+#pragma unroll
+          for (int to = 0; to < T; ++to) afc[to] = *reinterpret_cast<const f32x4*>(wsh + ((ti & 1) * T + to) * 256 + lane * 4);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int to = 0; to < T; ++to) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a2[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(afc[to][r], u1[ti][r], a2[to], 0, 0, 0);
+          }
+          if (ti + 1 < T) publish((ti + 1) & 1);
+          __syncthreads();                          // row ti consumed by every wave, row ti + 1 visible
+        }
+      } else {
       f32x4 afn[T];
       {
         int lofs = lane * 4;
@@ -344,6 +390,7 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) a2[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(afc[to][r], u1[ti][r], a2[to], 0, 0, 0);
         }
+      }
       }
       float opre[D], sn[D];
       {
@@ -582,6 +629,45 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
       f32x4 d1[T];
 #pragma unroll
       for (int tk = 0; tk < T; ++tk) d1[tk] = GEF ? a2[tk] : f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (WSHARE) {
+        constexpr int SHR = (T + NW - 1) / NW;
+        f32x4 nxt[SHR];
+        auto fetch = [&](int tn) {                  // fragments (tk, tn) for this wave's tk
+          int lofs = lane * 4;
+          asm volatile("" : "+v"(lofs));
+#pragma unroll
+          for (int k = 0; k < SHR; ++k) {
+            const int tk = wv + NW * k;
+            if (tk < T) nxt[k] = *reinterpret_cast<const f32x4*>(w2tf + (tk * T + tn) * 256 + lofs);
+          }
+        };
+        auto publish = [&](int bufi) {
+#pragma unroll
+          for (int k = 0; k < SHR; ++k) {
+            const int tk = wv + NW * k;
+            if (tk < T) *reinterpret_cast<f32x4*>(wsh + (bufi * T + tk) * 256 + lane * 4) = nxt[k];
+          }
+        };
+        fetch(0);
+        publish(0);
+        __syncthreads();
+#pragma unroll
+        for (int tn = 0; tn < T; ++tn) {
+          asm volatile("" ::: "memory");
+          if (tn + 1 < T) fetch(tn + 1);
+          f32x4 atc[T];
+#pragma unroll
+          for (int tk = 0; tk < T; ++tk) atc[tk] = *reinterpret_cast<const f32x4*>(wsh + ((tn & 1) * T + tk) * 256 + lane * 4);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int tk = 0; tk < T; ++tk) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d1[tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(atc[tk][r], d2[tn][r], d1[tk], 0, 0, 0);
+          }
+          if (tn + 1 < T) publish((tn + 1) & 1);
+          __syncthreads();
+        }
+      } else {
       f32x4 atn[T];
       {
         int lofs = lane * 4;
@@ -607,6 +693,7 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) d1[tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(atc[tk][r], d2[tn][r], d1[tk], 0, 0, 0);
         }
+      }
       }
       float jpart[D];  // BPTT: J_s(z_e)^T a_s, this lane's share of the hidden units
 #pragma unroll
@@ -1373,7 +1460,8 @@ int grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, c
   }
 
   const size_t stg = w.T > 4 ? size_t(3 * HP * 16 + 2 * 256 + 512 + (D + 1) * HP) : size_t((5 * HP + 32) * 16 + (D + 1) * HP);
-  const size_t lds_bytes = size_t((w.T > 4 ? 0 : 2 * HP * HP) + 2 * D * HP + HP + 16 + w.tgt_floats + nw * stg) * 4;
+  const size_t wsh = (w.T > 4 && nw == 4) ? size_t(2 * w.T * 256) : 0;   // the shared fragment rows of the 132-wide net
+  const size_t lds_bytes = size_t((w.T > 4 ? 0 : 2 * HP * HP) + 2 * D * HP + HP + 16 + w.tgt_floats + wsh + nw * stg) * 4;
   if (lds_bytes > 160 * 1024) return CMCD_ERR_UNSUPPORTED;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)lds_bytes) != hipSuccess)

@@ -202,6 +202,9 @@ def run(info, lr, iters, params_flat, unflatten, params_fixed, log_prob_model, g
                 print("Diverged")
                 return losses, params_flat, ema_params
             losses.append(mean_loss)
+            if iters >= 20000 and i % (every * 50) == 0:     # long runs: a sign of life every 5 % (stderr)
+                import sys
+                print(f"[opt.run {log_prefix}] iteration {i} / {iters}: mean loss {mean_loss:.4f}", file=sys.stderr, flush=True)
         elif not fused:
             if bool(torch.isnan(loss.mean())):               # eager path: the reference's per-iteration check
                 print("Diverged")
