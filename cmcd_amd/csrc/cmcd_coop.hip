@@ -525,6 +525,9 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
           // before the first MFMA, and two accumulators (even / odd inputs): a 4x4x1 MFMA that reads its predecessor's
           // result needs two wait states.  Same accumulation order as the every-lane-reads-everything layout of r01.
           f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#ifdef CMCD_COOP_ACC4   // probe (r03, rejected: 0.1930 -> 0.2011 ms): four independent accumulator chains instead of two
+          f32x4 acc2 = {0.f, 0.f, 0.f, 0.f}, acc3 = {0.f, 0.f, 0.f, 0.f};
+#endif
           f32x4 hb[RSA / 4];
 #pragma unroll
           for (int q = 0; q < RSA / 4; ++q) hb[q] = *reinterpret_cast<const f32x4*>(rd_h + 4 * q);
@@ -533,13 +536,21 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
           for (int sq = 0; sq < NQ; ++sq) {
             const int row = sq / RSA, t = sq % RSA;
             const float bv = hb[t / 4][t % 4];
+#ifdef CMCD_COOP_ACC4
+            f32x4& ac = (sq & 3) == 0 ? acc : ((sq & 3) == 1 ? acc1 : ((sq & 3) == 2 ? acc2 : acc3));
+#else
             f32x4& ac = (sq & 1) ? acc1 : acc;
+#endif
             if (row == 0) ac = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[sq], bv, ac, 0, 0, 4);
             else if (row == 1) ac = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[sq], bv, ac, 0, 0, 5);
             else if (row == 2) ac = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[sq], bv, ac, 0, 0, 6);
             else ac = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[sq], bv, ac, 0, 0, 7);
           }
+#ifdef CMCD_COOP_ACC4
+          acc = (acc + acc2) + (acc1 + acc3);
+#else
           acc += acc1;
+#endif
           STAMP(7);   // activations read, matrix instructions done
           // the two halves of the contraction sit in lanes l and l ^ 8; lane kh keeps neurons 2 kh + {0, 1} of its group:
           // it adds its own half of those to the partner's (the partner's register of the pair, through DPP row_ror:8)

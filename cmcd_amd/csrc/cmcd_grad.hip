@@ -93,11 +93,14 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
   float* lds_b2 = lds_w3t + D * HP;       // HP
   float* lds_b3 = lds_b2 + HP;            // 16
   float* lds_tgt = lds_b3 + 16;           // tgt_floats
-  // WSHARE (the 132-wide net, r03): the four waves of a workgroup walk the SAME W2 / W2^T fragment rows (each for its own
-  // work item), so a row (T fragments x 1 KB) is fetched from L2 ONCE per workgroup — wave q fetches fragments q, q + 4,
-  // q + 8 — and handed round through a double-buffered LDS row: a quarter of the L2 traffic (r02: 166 KB per work item
-  // and wave, 5.3 GB per launch at N = 2000, the matrix chain waiting on an L2 round trip per row).
-  constexpr bool WSHARE = WGLOBAL && NW == 4;
+  // WSHARE (the 132-wide net, r03, MEASURED AND REJECTED — kept compiled out as the record of the experiment): the four
+  // waves of a workgroup walk the SAME W2 / W2^T fragment rows (each for its own work item), so a row (T fragments x 1 KB)
+  // can be fetched from L2 ONCE per workgroup — wave q fetches fragments q, q + 4, q + 8 — and handed round through a
+  // double-buffered LDS row: a quarter of the L2 traffic (r02: 166 KB per work item and wave).  On MI355X the kernel went
+  // from 1.099 to 1.587 ms at 2000 particles (profiles/r03_wshare_rejected_kernel_stats.csv): the 20 extra workgroup
+  // barriers per work item put the four waves in lockstep, so no wave's matrix chain covers another's load latency any
+  // more — the L2 stream was not the bound, the overlap between the waves was the asset.
+  constexpr bool WSHARE = false;   // measured and rejected (r03): see the note below
   constexpr int WSH_FLOATS = WSHARE ? 2 * T * 256 : 0;
   float* wsh = lds_tgt + a.w.tgt_floats;             // [2][T][64 lanes][4]
   float* stage = wsh + WSH_FLOATS;
@@ -1460,7 +1463,7 @@ int grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, c
   }
 
   const size_t stg = w.T > 4 ? size_t(3 * HP * 16 + 2 * 256 + 512 + (D + 1) * HP) : size_t((5 * HP + 32) * 16 + (D + 1) * HP);
-  const size_t wsh = (w.T > 4 && nw == 4) ? size_t(2 * w.T * 256) : 0;   // the shared fragment rows of the 132-wide net
+  const size_t wsh = 0;   // (the shared fragment rows of the rejected WSHARE experiment would need 2 * T * 256 floats)
   const size_t lds_bytes = size_t((w.T > 4 ? 0 : 2 * HP * HP) + 2 * D * HP + HP + 16 + w.tgt_floats + wsh + nw * stg) * 4;
   if (lds_bytes > 160 * 1024) return CMCD_ERR_UNSUPPORTED;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
