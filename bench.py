@@ -323,6 +323,9 @@ def main():
     ap.add_argument("--saturated", type=int, default=1 << 18,
                     help="also time a saturating batch of this many particles (0 = skip)")
     args = ap.parse_args()
+    if os.environ.get("CMCD_BENCH_TRACE_AFTER"):     # diagnostics: dump every thread's stack if the run is still going then
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["CMCD_BENCH_TRACE_AFTER"]), exit=True)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -375,6 +378,10 @@ def main():
         torch.cuda.synchronize()
         est = max((time.perf_counter() - t0) / 40, 1e-5)
         args.spinup = int(min(max(args.spinup_seconds / est, 50), 5000))
+        if use_dist:    # every rank must issue the SAME number of steps (each carries a collective): take the largest count
+            cnt = torch.tensor([args.spinup], dtype=torch.int64, device=device)
+            dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
+            args.spinup = int(cnt.item())
     tw = time_leg(weak, args.steps, args.warmup, use_dist, device, world, spinup=args.spinup)
     legs["weak"] = leg_report(weak, tw, args.steps)
     elapsed, kern_ms, launches, losses, stats = tw["elapsed"], tw["kern_ms"], tw["launches"], tw["losses"], tw["stats"]

@@ -27,6 +27,7 @@ FWD_CASES = [
     ("funnel_n300_k64", 40, dict(emb_dim=100, nbridges=6, init_eps=0.05)),                 # d = 10 on 120 -> 144 wide
     ("gmm_n300_k8", 1500, dict(nbridges=3, nn_arch="dds")),                                # many tiles, 4-wave workgroups
     ("funnel_n300_k64", 64, dict(nbridges=5, nn_arch="dds", init_eps=0.05)),               # d = 10, dds first layer [84, 64]
+    ("gmm_n300_k8", 33, dict(nbridges=1)),                                                 # a single bridge
 ]
 
 
@@ -113,6 +114,7 @@ GRAD_CASES = [
     ("many_gmm_var_n16000_k256", 80, dict(nbridges=5, init_eps=0.1, init_gamma=3.0)),       # geffner 134 (9 tiles)
     ("gmm_n300_k8", 50, dict(emb_dim=40, nbridges=5)),                                      # width 44 -> 64
     ("gmm_n300_k8", 300, dict(nbridges=3)),                                                 # 19 tiles: five workgroups, ragged
+    ("gmm_n300_k8", 20, dict(nbridges=1, nn_arch="dds")),                                   # a single bridge
 ]
 
 
