@@ -135,23 +135,28 @@ def cpu_baseline(built, seeds_np, losses_hip, max_particles, min_seconds=8.0):
         dim, _, mode, spec = built["params_fixed"]
         cfg = built["cfg"]
         params_np = synthetic.oracle_params(built["unflatten"], built["params_flat"])
-        mk = lambda m: torch_port.Prepared(seeds_np[:m], params_np, dim, K, mode, spec.arch, cfg["model"], oracle_target(cfg),
-                                           cfg["eps_schedule"], cfg["grad_clipping"])
-        probe = mk(min(n, 64))
+        prep = torch_port.Prepared(seeds_np[:n], params_np, dim, K, mode, spec.arch, cfg["model"], oracle_target(cfg),
+                                   cfg["eps_schedule"], cfg["grad_clipping"])
         ncpu, was = os.cpu_count() or 1, torch.get_num_threads()
         for tag, nt, reuse in (("torch_cpu_all_cores", ncpu, False), ("torch_cpu_all_cores_reuse", ncpu, True),
                                ("torch_cpu_1_thread", 1, False)):
             torch.set_num_threads(nt)
-            torch_port.run(probe, reuse=reuse)                      # warm-up + rate estimate on a 64-particle probe
+            # bounded samples: a 4-bridge probe of 64 particles gives the rate, the timed sample is then the largest
+            # (particles x bridges) prefix of the same batch that fits ~3 s at that rate (128 threads on small matrices can
+            # be SLOWER than one: the sample must not be sized for the fast case)
+            pm, pk = min(n, 16), min(K, 2)
+            torch_port.run(prep, reuse=reuse, max_bridges=1, max_particles=pm)
             t1 = time.perf_counter()
-            torch_port.run(probe, reuse=reuse)
-            per_particle = (time.perf_counter() - t1) / min(n, 64)
-            m = int(min(n, max(64, 4.0 / max(per_particle, 1e-9))))  # a sample of about 4 s at the probe's rate (or less)
-            prep = probe if m <= 64 else mk(m)
+            torch_port.run(prep, reuse=reuse, max_bridges=pk, max_particles=pm)
+            per_step = max((time.perf_counter() - t1) / (pm * pk), 1e-9)     # seconds per particle-bridge-step
+            budget = 3.0 / per_step                                        # particle-steps that fit the budget
+            sm = int(min(n, max(pm, budget / K))) if budget >= pm * K else pm
+            sk = int(min(K, max(pk, budget / sm)))
             t1 = time.perf_counter()
-            torch_port.run(prep, reuse=reuse)
-            lines[tag] = {"value": min(m, n) * K / (time.perf_counter() - t1), "cores": nt,
-                          "sample": f"1 call of {min(m, n)} particles x {K} bridges, float32, PRNG streams drawn outside the timed call"}
+            torch_port.run(prep, reuse=reuse, max_bridges=sk, max_particles=sm)
+            lines[tag] = {"value": sm * sk / (time.perf_counter() - t1), "cores": nt,
+                          "sample": f"{sm} particles x the first {sk} of {K} bridges in one call, float32, PRNG streams drawn "
+                                    f"outside the timed call"}
         torch.set_num_threads(was)
     except NotImplementedError as e:
         lines["torch_cpu"] = {"error": str(e)}

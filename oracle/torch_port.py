@@ -93,9 +93,11 @@ def _net(p, z, i):
 
 
 @torch.no_grad()
-def run(p, reuse=False):
+def run(p, reuse=False, max_bridges=None, max_particles=None):
     """-> (loss[N], z[N, dim]) float32.  reuse=False: two network and two gradient evaluations per bridge as the
-    reference executes them; reuse=True: one of each (the backward evaluation opens the next bridge)."""
+    reference executes them; reuse=True: one of each (the backward evaluation opens the next bridge).
+    max_bridges / max_particles: walk only a prefix of the chain / of the batch (bench.py's bounded timing samples; the
+    returned loss is then not the bound)."""
     clip = 1e2 if p.var_mode else 1e3
     iv = 1.0 / (p.std * p.std)
 
@@ -108,15 +110,17 @@ def run(p, reuse=False):
                 gq = gq.clamp(-clip, clip)
         return gp, gq, _net(p, z, i)
 
-    z = p.std * p.e0 + p.mean
-    w = -(-0.5 * p.e0 * p.e0 - torch.log(p.std) - 0.5 * LOG_2PI).sum(-1)
+    m = p.e0.shape[0] if max_particles is None else min(int(max_particles), p.e0.shape[0])
+    e0 = p.e0[:m]
+    z = p.std * e0 + p.mean
+    w = -(-0.5 * e0 * e0 - torch.log(p.std) - 0.5 * LOG_2PI).sum(-1)
     carried = None
-    for i in range(p.K):
+    for i in range(p.K if max_bridges is None else min(int(max_bridges), p.K)):
         beta, eps = p.betas[i], p.eps[i]
         gp, gq, s = carried if (reuse and carried is not None) else ev(z, i)
         fk = z + eps * (beta * gp + (1 - beta) * gq) - eps * s
         sig = torch.sqrt(2 * eps)
-        n = p.noise[:, i, :]
+        n = p.noise[:m, i, :]
         zn = fk + sig * n
         gp2, gq2, s2 = ev(zn, i + 1)
         bk = zn + eps * (beta * gp2 + (1 - beta) * gq2) + eps * s2
