@@ -257,16 +257,19 @@ def time_leg(leg, steps, warmup, use_dist, device, world, sharded=True, spinup=0
 
     # device spin-up (untimed, in front of the W warm-up steps without a synchronisation in between): ~0.1 s of launches
     # so that the GPU's clocks have settled even when the caller asks for a handful of steps (20 steps = 5 ms)
-    for k in range(spinup + warmup):
-        step(k)
-    if pending:
-        drain()
-    barrier()
-    _lib.profile_enable(True)
+    # the collector runs BEFORE the spin-up: between the opening barrier and the first timed launch nothing may idle the
+    # GPU (tools/probes/post_sync_ramp.py: a 10 ms gap drops the clocks for the next > 40 calls, 203 -> 218 us per call;
+    # r02's 20-step driver run read 0.2245 ms per step with a gc.collect() sitting in exactly that gap)
     import gc
     gc.collect()
     gc_was = gc.isenabled()
     gc.disable()          # a 20-step timed region is 4 ms: one collector pause on the launching thread would be 10 % of it
+    for k in range(spinup + warmup):
+        step(k)
+    if pending:
+        drain()
+    _lib.profile_enable(True)
+    barrier()
     t0 = time.perf_counter()
     for k in range(steps):
         losses, z, stats = step(k)

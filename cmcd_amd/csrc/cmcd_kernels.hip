@@ -1479,6 +1479,12 @@ int cmcd_debug_grad_item(int mode) {
 int cmcd_profile_enable(int on) {
   g_prof.on = on != 0;
   g_prof.used = 0;
+  // the first 512 event pairs are created here, outside any timed region (a 20-step measurement would otherwise pay two
+  // hipEventCreate calls inside every one of its steps)
+  for (; on && g_prof.created < 512; ++g_prof.created) {
+    CMCD_HIP_CHECK(hipEventCreate(&g_prof.ev[g_prof.created][0]));
+    CMCD_HIP_CHECK(hipEventCreate(&g_prof.ev[g_prof.created][1]));
+  }
   return CMCD_OK;
 }
 
