@@ -138,8 +138,10 @@ def cpu_baseline(built, seeds_np, losses_hip, max_particles, min_seconds=8.0):
         prep = torch_port.Prepared(seeds_np[:n], params_np, dim, K, mode, spec.arch, cfg["model"], oracle_target(cfg),
                                    cfg["eps_schedule"], cfg["grad_clipping"])
         ncpu, was = os.cpu_count() or 1, torch.get_num_threads()
-        for tag, nt, reuse in (("torch_cpu_all_cores", ncpu, False), ("torch_cpu_all_cores_reuse", ncpu, True),
-                               ("torch_cpu_1_thread", 1, False)):
+        # (r03 on the MI355X host: 128 torch threads on these 64-wide matrices run at 6 particle-steps/s — thread hand-over,
+        # not arithmetic — against 3.8e5 on ONE thread; a 16-thread line is reported beside the all-cores line BASELINE.md asks for)
+        for tag, nt, reuse in (("torch_cpu_all_cores", ncpu, False), ("torch_cpu_16_threads", min(16, ncpu), False),
+                               ("torch_cpu_16_threads_reuse", min(16, ncpu), True), ("torch_cpu_1_thread", 1, False)):
             torch.set_num_threads(nt)
             # bounded samples: a 4-bridge probe of 64 particles gives the rate, the timed sample is then the largest
             # (particles x bridges) prefix of the same batch that fits ~3 s at that rate (128 threads on small matrices can
