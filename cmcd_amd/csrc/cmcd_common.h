@@ -64,6 +64,7 @@ int net_in_dim(const cmcd_desc& d);                    // dim, or 2 dim when the
 bool uha_available(const cmcd_desc& d, int T);
 int64_t uha_traj_floats(const cmcd_desc& d, int64_t n);
 int uha_forward_launch(const cmcd_desc& d, const TrajArgs& ta, void* stream);
+const char* uha_last_kernel_name();                    // "uha_traj_kernel" | "uha_coop_kernel" (this host thread's last launch)
 // reparameterised gradient: reverse sweep over the kept trajectory
 bool uha_grad_available(const cmcd_desc& d, int T);
 int64_t uha_grad_workspace_floats(const cmcd_desc& d, int HP, int64_t n);

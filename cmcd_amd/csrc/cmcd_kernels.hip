@@ -1113,8 +1113,8 @@ static int forward_impl(const cmcd_desc* desc, const cmcd_layout* lay, const int
     TrajArgs tu{seeds, params, ws, reinterpret_cast<double*>(ws + w.partials), out_loss, out_z, *lay, w, n,
                 (int32_t)K, 0, 1, traj, 0};
     tu.dbg_bits = cap.bits; tu.dbg_keys = cap.keys; tu.dbg_noise = cap.noise;
-    snprintf(g_kernel_name, sizeof(g_kernel_name), "uha_traj_kernel");
     rc = uha_forward_launch(d, tu, stream);
+    snprintf(g_kernel_name, sizeof(g_kernel_name), "%s", uha_last_kernel_name());
     if (rc != CMCD_OK) return fail(rc, "MCD_CAIS_UHA_sn launch failed%s");
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, stream,
                        reinterpret_cast<const double*>(ws + w.partials), w.n_waves, out_stats);

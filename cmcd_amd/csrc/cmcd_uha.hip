@@ -378,6 +378,341 @@ __global__ __launch_bounds__(512, (T > 4 || D > 4) ? 2 : 4) void uha_traj_kernel
 }
 
 // ------------------------------------------------------------------------------------------
+// uha_coop_kernel — the CU-cooperative form for batches that cannot fill the chip with one wave per tile (the named
+// shape: 125 tiles on a 256-long chain).  One workgroup of T + 2 waves per 16-particle tile:
+//   waves 0..T-1  MLP: wave v owns hidden units 16 v .. 16 v + 15 — its W1 rows, its W2 A-fragments (resident in VGPRs for
+//                 the whole launch), its slice of the layer-3 dot product;
+//   wave T        STATE + TGT: (z, rho, w) of the 16 particles, the leap-frog, both kernels' log-densities, grad log p(z')
+//                 (evaluated while the MLP waves run the bridge's SECOND network evaluation);
+//   wave T + 1    RNG: jax's key chain one bridge ahead, bits -> deviates.
+// A bridge is two passes of the MLP waves — s([z; rho], i), then s([z; rho'], i) — each: layer 1 + activation -> LDS (MFMA B
+// layout) | barrier | layer 2 on the matrix cores from LDS, activation, layer-3 partials -> LDS | barrier | the state wave
+// combines the partials and publishes the next network input | barrier.  Every wave executes the same barrier sequence
+// (plain workgroup barriers, uniform control flow), so the kernel cannot dead-lock on a role mismatch.  Same arithmetic as
+// uha_traj_kernel up to the summation order of the layer-3 partials (per wave, then over waves).
+// ------------------------------------------------------------------------------------------
+template <int TARGET, int ARCH, int D, int T>
+__global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
+  constexpr int HP = 16 * T;
+  constexpr int DIN = 2 * D;
+  constexpr int Hh = (D + 1) / 2;
+  constexpr bool GEF = ARCH == CMCD_ARCH_GEFFNER;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* hbuf = lds;                          // [T][64 lanes][4]   layer-1 activations, MFMA B order
+  float* part = hbuf + T * 256;               // [T][16][D]         layer-3 partials per MLP wave
+  float* xin = part + T * 16 * D;             // [16][2 D]          network input [z; rho] / [z; rho']
+  float* nzb = xin + 16 * DIN;                // [2][16][D]         deviates of bridge i (parity i & 1)
+  uint32_t* keyb = reinterpret_cast<uint32_t*>(nzb + 2 * 16 * D);   // [16][2]  gen_0 handed from the state wave to the RNG wave
+  float* lds_tgt = nzb + 2 * 16 * D + 32;     // tgt_floats
+  for (int i = threadIdx.x; i < a.w.tgt_floats; i += blockDim.x) lds_tgt[i] = a.ws[a.w.tgt + i];
+
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  const bool is_mlp = wv < T, is_state = wv == T, is_rng = wv == T + 1;
+  const int64_t tile = blockIdx.x;
+  const int64_t p = tile * 16 + c;
+  const bool valid = p < a.n;
+  const int K = a.K;
+  const int gb = g & 1;
+
+  // ---- MLP waves: resident weights
+  float w1[DIN][4], w3[D][4];
+  f32x4 afrag[T], b2v = {0.f, 0.f, 0.f, 0.f};
+  const int nb = 16 * (is_mlp ? wv : 0) + 4 * g;      // first of this lane's four hidden units
+  if (is_mlp) {
+#pragma unroll
+    for (int j = 0; j < DIN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w1[j][r] = a.ws[a.w.w1z + j * HP + nb + r];
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w3[j][r] = a.ws[a.w.w3t + j * HP + nb + r];
+#pragma unroll
+    for (int ti = 0; ti < T; ++ti) afrag[ti] = *reinterpret_cast<const f32x4*>(a.ws + a.w.w2 + ((ti * T + wv) * 64 + lane) * 4);
+    b2v = *reinterpret_cast<const f32x4*>(a.ws + a.w.b2 + nb);
+  }
+  const float factor = a.ws[a.w.b3 + 15];
+
+  // ---- state wave: q, gamma, initial draws (the prologue of uha_traj_kernel)
+  float qmean[D], qstd[D], qiv[D], z[D], rho[D], gp[D], gq[D];
+  float w = 0.f, logp = 0.f, gamma = 0.f;
+  uint32_t k0 = 0u, k1 = 0u;
+  float* tz = a.traj;
+  float* trho = a.traj ? a.traj + (int64_t)(K + 1) * a.n * D : nullptr;
+  float* trhop = a.traj ? a.traj + (int64_t)(2 * K + 2) * a.n * D : nullptr;
+  const bool keep = a.traj && valid && g == 0;
+  constexpr float clipv = 1e2f;
+  __syncthreads();                                   // target constants staged
+  if (is_state) {
+    gamma = a.params[a.lay.gamma];
+    const int32_t seed = a.seeds[valid ? p : a.n - 1];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      qmean[j] = a.params[a.lay.vd_mean + j];
+      qstd[j] = expf(a.params[a.lay.vd_logdiag + j]);
+      qiv[j] = 1.0f / (qstd[j] * qstd[j]);
+    }
+    uint32_t x0 = gb, x1 = 2 + gb;
+    k1 = (uint32_t)seed;
+    threefry2x32(k0, k1, x0, x1);
+    uint32_t a0, a1, b0, b1;
+    rows01(x0, a0, a1);
+    rows01(x1, b0, b1);
+    float nz[2 * Hh];
+    draw_normal<D>(a0, a1, g, nz, a, 0, p, valid);
+#pragma unroll
+    for (int j = 0; j < D; ++j) z[j] = qstd[j] * nz[j] + qmean[j];
+    x0 = gb; x1 = 2 + gb;
+    threefry2x32(b0, b1, x0, x1);
+    uint32_t c0, c1;
+    rows01(x0, c0, c1);
+    x0 = gb; x1 = 2 + gb;
+    threefry2x32(c0, c1, x0, x1);
+    uint32_t r0, r1, p0, p1;
+    rows01(x0, r0, r1);
+    rows01(x1, p0, p1);
+    draw_normal<D>(r0, r1, g, nz, a, 1, p, valid);
+#pragma unroll
+    for (int j = 0; j < D; ++j) rho[j] = nz[j];
+    x0 = gb; x1 = 2 + gb;
+    threefry2x32(p0, p1, x0, x1);
+    rows01(x1, k0, k1);
+    if (g == 0) { keyb[2 * c] = k0; keyb[2 * c + 1] = k1; }
+    if (a.dbg_keys && valid && g == 0) {
+      a.dbg_keys[p * 2] = k0;
+      a.dbg_keys[p * 2 + 1] = k1;
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const float dz = z[j] - qmean[j];
+      w -= -(dz * dz) / (2.0f * qstd[j] * qstd[j]) - logf(qstd[j]) - kHalfLog2Pi;
+    }
+    float l0 = 0.f;
+#pragma unroll
+    for (int j = 0; j < D; ++j) l0 += -(rho[j] * rho[j]) * 0.5f - kHalfLog2Pi;
+    w -= l0;
+    if (keep) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        tz[p * D + j] = z[j];
+        trho[p * D + j] = rho[j];
+      }
+    }
+    Target<TARGET, D>::eval(z, g, lds_tgt, logp, gp);
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      gp[j] = fminf(fmaxf(gp[j], -clipv), clipv);
+      gq[j] = -(z[j] - qmean[j]) * qiv[j];
+    }
+    if (g == 0) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) { xin[c * DIN + j] = z[j]; xin[c * DIN + D + j] = rho[j]; }
+    }
+  }
+  __syncthreads();                                   // gen_0 and the first network input published
+  // one stage of the key chain on the RNG wave: deviates of bridge `ib` -> nzb[ib & 1], gen advanced
+  auto rng_stage = [&](int ib) {
+    uint32_t x0 = gb, x1 = 2 + gb;
+    threefry2x32(k0, k1, x0, x1);
+    uint32_t g0, g1, h0, h1;
+    rows01(x0, g0, g1);
+    rows01(x1, h0, h1);
+    x0 = gb; x1 = 2 + gb;
+    threefry2x32(h0, h1, x0, x1);
+    rows01(x1, k0, k1);
+    if (a.dbg_keys && valid && g == 0) {
+      a.dbg_keys[((int64_t)(ib + 1) * a.n + p) * 2] = k0;
+      a.dbg_keys[((int64_t)(ib + 1) * a.n + p) * 2 + 1] = k1;
+    }
+    float nz[2 * Hh];
+    draw_normal<D>(g0, g1, g, nz, a, ib + 2, p, valid);
+    if (g == 0) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) nzb[((ib & 1) * 16 + c) * D + j] = nz[j];
+    }
+  };
+  if (is_rng) {
+    k0 = keyb[2 * c]; k1 = keyb[2 * c + 1];
+    rng_stage(0);
+  }
+  __syncthreads();                                   // deviates of bridge 0 published
+
+  const float* bias1 = a.ws + a.w.bias1;
+  const float* utab = a.ws + a.w.utab;
+  f32x4 brow_n = {0.f, 0.f, 0.f, 0.f}, urow_n = {0.f, 0.f, 0.f, 0.f};
+  if (is_mlp) {
+    brow_n = *reinterpret_cast<const f32x4*>(bias1 + nb);
+    if (GEF) urow_n = *reinterpret_cast<const f32x4*>(utab + nb);
+  }
+
+  for (int i = 0; i < K; ++i) {
+    f32x4 brow = brow_n, urow = urow_n;
+    if (is_mlp && i + 1 < K) {                       // the next bridge's rows arrive while this bridge runs
+      brow_n = *reinterpret_cast<const f32x4*>(bias1 + (int64_t)(i + 1) * HP + nb);
+      if (GEF) urow_n = *reinterpret_cast<const f32x4*>(utab + (int64_t)(i + 1) * HP + nb);
+    }
+    float beta = 0.f, eps = 0.f, eta = 0.f, sig = 0.f, inv2s2 = 0.f, cst = 0.f, ome = 0.f;
+    if (is_state) {
+      beta = a.ws[a.w.beta + i]; eps = a.ws[a.w.eps + i];
+      eta = gamma * eps; sig = sqrtf(2.0f * eta);
+      inv2s2 = 1.0f / (2.0f * sig * sig); cst = logf(sig) + kHalfLog2Pi; ome = 1.0f - eta;
+    }
+    float rhop[D], rpp[D], fk_lp = 0.f;
+#pragma unroll
+    for (int j = 0; j < D; ++j) { rhop[j] = 0.f; rpp[j] = 0.f; }
+
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      // ---------------------------------------------------------------- interval 1
+      float h[4] = {0.f, 0.f, 0.f, 0.f};
+      if (is_mlp) {
+        float x[DIN];
+#pragma unroll
+        for (int j = 0; j < DIN; ++j) x[j] = xin[c * DIN + j];
+        float pre[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pre[r] = brow[r];
+#pragma unroll
+          for (int j = 0; j < DIN; ++j) pre[r] = fmaf(x[j], w1[j][r], pre[r]);
+        }
+        if (!GEF) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[r] = gelu_fast(pre[r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float u = urow[r];
+            if (nb + r < DIN) u = xin[c * DIN + nb + r];      // the first 2 D entries of u are [z; rho] themselves
+            h[r] = u + softplus(pre[r]);
+          }
+        }
+        *reinterpret_cast<f32x4*>(hbuf + (wv * 64 + lane) * 4) = f32x4{h[0], h[1], h[2], h[3]};
+      } else if (is_rng && pass == 0) {
+        if (i + 1 < K) rng_stage(i + 1);
+      } else if (is_state && pass == 1) {
+        // grad log p(z') while the MLP waves run the second evaluation; z already holds z'
+        Target<TARGET, D>::eval(z, g, lds_tgt, logp, gp);
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          gp[j] = fminf(fmaxf(gp[j], -clipv), clipv);
+          gq[j] = -(z[j] - qmean[j]) * qiv[j];
+        }
+      }
+      __syncthreads();
+      // ---------------------------------------------------------------- interval 2
+      if (is_mlp) {
+        f32x4 acc = b2v;
+#pragma unroll
+        for (int ti = 0; ti < T; ++ti) {
+          const f32x4 hb = *reinterpret_cast<const f32x4*>(hbuf + (ti * 64 + lane) * 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ti][r], hb[r], acc, 0, 0, 0);
+        }
+        float h2[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h2[r] = GEF ? h[r] + softplus(acc[r]) : gelu_fast(acc[r]);
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          float pj = h2[0] * w3[j][0] + h2[1] * w3[j][1] + h2[2] * w3[j][2] + h2[3] * w3[j][3];
+          pj = group_sum(pj);
+          if (g == 0) part[(wv * 16 + c) * D + j] = pj;
+        }
+      }
+      __syncthreads();
+      // ---------------------------------------------------------------- the state wave combines
+      if (is_state) {
+        float s[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          float o = a.ws[a.w.b3 + j];
+#pragma unroll
+          for (int v = 0; v < T; ++v) o += part[(v * 16 + c) * D + j];
+          s[j] = GEF ? o * factor : fminf(fmaxf(o, -1e4f), 1e4f);
+        }
+        if (pass == 0) {
+          fk_lp = 0.f;
+#pragma unroll
+          for (int j = 0; j < D; ++j) {
+            const float mf = rho[j] * ome - 2.0f * eta * s[j];
+            rhop[j] = mf + sig * nzb[((i & 1) * 16 + c) * D + j];
+            const float df = rhop[j] - mf;
+            fk_lp += -(df * df) * inv2s2 - cst;
+            const float uf = -1.0f * (beta * gp[j] + (1.0f - beta) * gq[j]);
+            rpp[j] = rhop[j] - eps * uf / 2.0f;
+          }
+          if (g == 0) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) xin[c * DIN + D + j] = rhop[j];      // [z; rho']: the z half stays
+          }
+        } else {
+          float bk_lp = 0.f;
+#pragma unroll
+          for (int j = 0; j < D; ++j) {
+            const float mb = rhop[j] * ome + 2.0f * eta * s[j];
+            const float db = rho[j] - mb;
+            bk_lp += -(db * db) * inv2s2 - cst;
+            const float ub = -1.0f * (beta * gp[j] + (1.0f - beta) * gq[j]);   // gp / gq are those of z' by now
+            rho[j] = rpp[j] - eps * ub / 2.0f;
+          }
+          w += bk_lp - fk_lp;
+          if (g == 0) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) { xin[c * DIN + j] = z[j]; xin[c * DIN + D + j] = rho[j]; }
+          }
+          if (keep) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+              tz[((int64_t)(i + 1) * a.n + p) * D + j] = z[j];
+              trho[((int64_t)(i + 1) * a.n + p) * D + j] = rho[j];
+              trhop[((int64_t)i * a.n + p) * D + j] = rhop[j];
+            }
+          }
+        }
+        if (pass == 0) {
+#pragma unroll
+          for (int j = 0; j < D; ++j) z[j] = z[j] + eps * rpp[j];      // z' (the network input keeps the old z until pass 1 ends)
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (!is_state) return;
+  {
+    float lK = 0.f;
+#pragma unroll
+    for (int j = 0; j < D; ++j) lK += -(rho[j] * rho[j]) * 0.5f - kHalfLog2Pi;
+    w += lK;
+  }
+  w += logp;
+  const float loss = -w;
+  if (valid && g == 0) {
+    a.out_loss[p] = loss;
+#pragma unroll
+    for (int j = 0; j < D; ++j) a.out_z[p * D + j] = z[j];
+  }
+  const bool use = valid && g == 0;
+  double cnt = (use && isfinite(loss)) ? 1.0 : 0.0;
+  double sm = use ? (double)loss : 0.0;
+  double sq = use ? (double)loss * (double)loss : 0.0;
+  double mx = use ? -(double)loss : -INFINITY;
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) {
+    cnt += __shfl_xor(cnt, o);
+    sm += __shfl_xor(sm, o);
+    sq += __shfl_xor(sq, o);
+    mx = fmax(mx, __shfl_xor(mx, o));
+  }
+  double ex = (use && mx > -INFINITY && mx < INFINITY) ? exp(-(double)loss - mx) : 0.0;
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) ex += __shfl_xor(ex, o);
+  if (lane == 0) {
+    double* o = a.partials + tile * CMCD_NSTATS;
+    o[0] = cnt; o[1] = sm; o[2] = sq; o[3] = mx; o[4] = ex;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 typedef void (*uha_fn)(TrajArgs);
@@ -407,7 +742,37 @@ static uha_fn uha_pick(const cmcd_desc& d, int T) {
   return nullptr;
 }
 
+template <int TARGET, int ARCH, int D>
+static uha_fn uha_coop_pick_T(int T) {
+  switch (T) {
+    case 2: return uha_coop_kernel<TARGET, ARCH, D, 2>;
+    case 4: return uha_coop_kernel<TARGET, ARCH, D, 4>;
+    case 5: return uha_coop_kernel<TARGET, ARCH, D, 5>;
+    case 9: return uha_coop_kernel<TARGET, ARCH, D, 9>;
+    default: return nullptr;
+  }
+}
+
+static uha_fn uha_coop_pick(const cmcd_desc& d, int T) {
+  if (d.arch == CMCD_ARCH_DDS) {
+    if (T != 4) return nullptr;
+    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2) return uha_coop_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_DDS, 2, 4>;
+    if (d.target == CMCD_TARGET_GMM && d.dim == 2) return uha_coop_kernel<CMCD_TARGET_GMM, CMCD_ARCH_DDS, 2, 4>;
+    if (d.target == CMCD_TARGET_FUNNEL && d.dim == 10) return uha_coop_kernel<CMCD_TARGET_FUNNEL, CMCD_ARCH_DDS, 10, 4>;
+    return nullptr;
+  }
+  if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2) return uha_coop_pick_T<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2>(T);
+  if (d.target == CMCD_TARGET_GMM && d.dim == 2) return uha_coop_pick_T<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER, 2>(T);
+  if (d.target == CMCD_TARGET_FUNNEL && d.dim == 10) return uha_coop_pick_T<CMCD_TARGET_FUNNEL, CMCD_ARCH_GEFFNER, 10>(T);
+  return nullptr;
+}
+
 bool uha_available(const cmcd_desc& d, int T) { return uha_pick(d, T) != nullptr; }
+
+// tiles up to which the cooperative form is preferred (MI355X, profiles/r03_uha_variant_crossover.txt)
+static int uha_coop_max_tiles(const cmcd_desc& d) { (void)d; return 1024; }
+static thread_local const char* g_uha_kernel_name = "uha_traj_kernel";
+const char* uha_last_kernel_name() { return g_uha_kernel_name; }
 
 int64_t uha_traj_floats(const cmcd_desc& d, int64_t n) { return (int64_t)(3 * d.nbridges + 2) * n * d.dim; }
 
@@ -417,6 +782,17 @@ int uha_forward_launch(const cmcd_desc& d, const TrajArgs& ta, void* stream_) {
   uha_fn fn = uha_pick(d, w.T);
   if (!fn) return CMCD_ERR_UNSUPPORTED;
   const int64_t tiles = w.n_waves;
+  // kernel variant (desc.reserved, as for the overdamped kernels): 0 auto, 1 wave per tile, 2 - 4 cooperative
+  uha_fn cfn = uha_coop_pick(d, w.T);
+  const bool forced = d.reserved >= 2 && d.reserved <= 4;
+  if (forced && !cfn) return CMCD_ERR_UNSUPPORTED;
+  if (cfn && (forced || (d.reserved != 1 && tiles <= uha_coop_max_tiles(d)))) {
+    const size_t cl = size_t(w.T * 256 + w.T * 16 * d.dim + 16 * 2 * d.dim + 2 * 16 * d.dim + 32 + w.tgt_floats) * 4;
+    g_uha_kernel_name = "uha_coop_kernel";
+    hipLaunchKernelGGL(cfn, dim3((unsigned)tiles), dim3(64 * (w.T + 2)), cl, stream, ta);
+    return hipGetLastError() == hipSuccess ? CMCD_OK : CMCD_ERR_HIP;
+  }
+  g_uha_kernel_name = "uha_traj_kernel";
   const size_t lds_bytes = size_t(w.HP * w.HP + 3 * d.dim * w.HP + w.HP + 16 + w.tgt_floats) * 4;
   if (lds_bytes > 160 * 1024) return CMCD_ERR_UNSUPPORTED;
   // waves per workgroup as in the overdamped wave-per-tile kernel: one wave per workgroup until every SIMD has one

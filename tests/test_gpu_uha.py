@@ -31,8 +31,15 @@ FWD_CASES = [
 ]
 
 
+# 1 = one wave per tile (uha_traj_kernel), 2 = CU-cooperative (uha_coop_kernel: T MLP waves + state / target wave + RNG wave)
+@pytest.fixture(params=[1, 2], ids=["wave_per_tile", "cooperative"])
+def variant(request, monkeypatch):
+    monkeypatch.setattr(mcdbm, "KERNEL_VARIANT", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("name,n,over", FWD_CASES)
-def test_bound_matches_oracle(hip_lib, param_set, name, n, over):
+def test_bound_matches_oracle(hip_lib, param_set, variant, name, n, over):
     b = synthetic.build(name, device="cuda", boundmode=MODE, **over)
     seeds = synthetic.parity_seeds(n)
     mean, (losses, z) = mcdbm.compute_bound(torch.from_numpy(seeds).cuda(), b["params_flat"], b["unflatten"],
@@ -42,6 +49,7 @@ def test_bound_matches_oracle(hip_lib, param_set, name, n, over):
     l_ref, z_ref = run_oracle(b, seeds, dtype=np.float64)
     rep = compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"UHA {name} n={n}")
     print(name, n, over, rep)
+    assert _lib.last_kernel_name() == ("uha_traj_kernel" if variant == 1 else "uha_coop_kernel")
     want = np.mean(losses.double().cpu().numpy())
     if np.isfinite(want):
         assert abs(float(mean) - want) <= 1e-5 * max(1.0, abs(want))
@@ -84,7 +92,7 @@ def oracle_chain_uha(seeds, dim, K):
 
 @pytest.mark.parametrize("name,n,K", [("many_gmm_n2000_k256_dds", 203, 40), ("funnel_n300_k64", 77, 9),
                                       ("gmm_n300_k8", 2000, 64)])
-def test_key_chain_and_deviates_are_bit_exact(hip_lib, name, n, K):
+def test_key_chain_and_deviates_are_bit_exact(hip_lib, variant, name, n, K):
     b = synthetic.build(name, device="cuda", boundmode=MODE, nbridges=K, init_eps=0.02, dense=True)
     dim = b["params_fixed"][0]
     seeds = np.random.default_rng(3).integers(1, 10 ** 6, n).astype(np.int32)
@@ -119,7 +127,7 @@ GRAD_CASES = [
 
 
 @pytest.mark.parametrize("name,n,over", GRAD_CASES)
-def test_reparameterised_gradient_matches_autograd(hip_lib, param_set, name, n, over):
+def test_reparameterised_gradient_matches_autograd(hip_lib, param_set, variant, name, n, over):
     """jax.grad(compute_bound, 1) (/root/reference/src/main.py:174-176) through mcd_under_lp_a_cais.py:42-88: every leaf of
     params_flat (network, eps, gamma, q, mgridref_y) against torch-autograd through the float64 restatement."""
     from test_gpu_grad import _compare, oracle_grad_flat
