@@ -432,6 +432,9 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
     b2v = *reinterpret_cast<const f32x4*>(a.ws + a.w.b2 + nb);
   }
   const float factor = a.ws[a.w.b3 + 15];
+  float b3r[D];                                       // output bias, resident (a load per pass would sit on the bridge's critical path)
+#pragma unroll
+  for (int j = 0; j < D; ++j) b3r[j] = a.ws[a.w.b3 + j];
 
   // ---- state wave: q, gamma, initial draws (the prologue of uha_traj_kernel)
   float qmean[D], qstd[D], qiv[D], z[D], rho[D], gp[D], gq[D];
@@ -510,22 +513,28 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
     }
   }
   __syncthreads();                                   // gen_0 and the first network input published
-  // one stage of the key chain on the RNG wave: deviates of bridge `ib` -> nzb[ib & 1], gen advanced
-  auto rng_stage = [&](int ib) {
+  // one stage of the key chain on the RNG wave, in two halves that each sit in the matrix interval of a pass (three Threefry
+  // passes of ~100 dependent integer instructions are longer than any single interval: in front of a barrier they would
+  // hold every wave of the workgroup):  A: (G, H) = split(gen);  B: gen = second(split(H)), deviates of bridge `ib` = normal(G).
+  // Measured and rejected (r03): a dedicated target wave (T + 3 waves) with both splits in half A: 0.567 -> 0.599 ms — a
+  // matrix instruction blocks the VALU of its SIMD, so a seventh wave and a longer half A only move the long pole.
+  uint32_t sg0 = 0, sg1 = 0, sh0 = 0, sh1 = 0;
+  auto rng_stage_a = [&]() {
     uint32_t x0 = gb, x1 = 2 + gb;
     threefry2x32(k0, k1, x0, x1);
-    uint32_t g0, g1, h0, h1;
-    rows01(x0, g0, g1);
-    rows01(x1, h0, h1);
-    x0 = gb; x1 = 2 + gb;
-    threefry2x32(h0, h1, x0, x1);
+    rows01(x0, sg0, sg1);
+    rows01(x1, sh0, sh1);
+  };
+  auto rng_stage_b = [&](int ib) {
+    uint32_t x0 = gb, x1 = 2 + gb;
+    threefry2x32(sh0, sh1, x0, x1);
     rows01(x1, k0, k1);
     if (a.dbg_keys && valid && g == 0) {
       a.dbg_keys[((int64_t)(ib + 1) * a.n + p) * 2] = k0;
       a.dbg_keys[((int64_t)(ib + 1) * a.n + p) * 2 + 1] = k1;
     }
     float nz[2 * Hh];
-    draw_normal<D>(g0, g1, g, nz, a, ib + 2, p, valid);
+    draw_normal<D>(sg0, sg1, g, nz, a, ib + 2, p, valid);
     if (g == 0) {
 #pragma unroll
       for (int j = 0; j < D; ++j) nzb[((ib & 1) * 16 + c) * D + j] = nz[j];
@@ -533,7 +542,8 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
   };
   if (is_rng) {
     k0 = keyb[2 * c]; k1 = keyb[2 * c + 1];
-    rng_stage(0);
+    rng_stage_a();
+    rng_stage_b(0);
   }
   __syncthreads();                                   // deviates of bridge 0 published
 
@@ -588,10 +598,13 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
           }
         }
         *reinterpret_cast<f32x4*>(hbuf + (wv * 64 + lane) * 4) = f32x4{h[0], h[1], h[2], h[3]};
-      } else if (is_rng && pass == 0) {
-        if (i + 1 < K) rng_stage(i + 1);
+      }
+      __syncthreads();
+      // ---------------------------------------------------------------- interval 2 (the long one: the auxiliary work sits here)
+      if (is_rng && i + 1 < K) {
+        if (pass == 0) rng_stage_a(); else rng_stage_b(i + 1);
       } else if (is_state && pass == 1) {
-        // grad log p(z') while the MLP waves run the second evaluation; z already holds z'
+        // grad log p(z') while the MLP waves run the second evaluation's matrix phase; z already holds z'
         Target<TARGET, D>::eval(z, g, lds_tgt, logp, gp);
 #pragma unroll
         for (int j = 0; j < D; ++j) {
@@ -599,16 +612,21 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
           gq[j] = -(z[j] - qmean[j]) * qiv[j];
         }
       }
-      __syncthreads();
-      // ---------------------------------------------------------------- interval 2
       if (is_mlp) {
-        f32x4 acc = b2v;
+        // two accumulator chains (even / odd input tiles): a 16x16x4 that reads its predecessor's result waits for it
+        f32x4 acc = b2v, acc1 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 hbv[T];
 #pragma unroll
-        for (int ti = 0; ti < T; ++ti) {
-          const f32x4 hb = *reinterpret_cast<const f32x4*>(hbuf + (ti * 64 + lane) * 4);
+        for (int ti = 0; ti < T; ++ti) hbv[ti] = *reinterpret_cast<const f32x4*>(hbuf + (ti * 64 + lane) * 4);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ti][r], hb[r], acc, 0, 0, 0);
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+          for (int ti = 0; ti < T; ++ti) {
+            if (ti & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ti][r], hbv[ti][r], acc1, 0, 0, 0);
+            else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ti][r], hbv[ti][r], acc, 0, 0, 0);
+          }
         }
+        acc += acc1;
         float h2[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) h2[r] = GEF ? h[r] + softplus(acc[r]) : gelu_fast(acc[r]);
@@ -625,7 +643,7 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
         float s[D];
 #pragma unroll
         for (int j = 0; j < D; ++j) {
-          float o = a.ws[a.w.b3 + j];
+          float o = b3r[j];
 #pragma unroll
           for (int v = 0; v < T; ++v) o += part[(v * 16 + c) * D + j];
           s[j] = GEF ? o * factor : fminf(fmaxf(o, -1e4f), 1e4f);
