@@ -49,13 +49,14 @@ def _run(model, k, seed):
                                      ("funnel", 256)])
 def test_trained_bound_reproduces_the_reference_notebook_table(hip_lib, model, k):
     ref = _row(model, k)
-    runs = np.array([_run(model, k, s) for s in SEEDS])          # [seed, (elbo, ln Z)]
+    seeds = SEEDS if k < 128 else SEEDS[:2]                      # the long chains: two training seeds (the suite's time budget)
+    runs = np.array([_run(model, k, s) for s in seeds])          # [seed, (elbo, ln Z)]
     mean, std = runs.mean(0), runs.std(0, ddof=1)
     print(f"{model} K={k}: ELBO {mean[0]:.4f} +- {std[0]:.4f} (reference {ref['elbo']:.4f} +- {ref['elbo_std']:.4f}, "
           f"ipynb:{ref['cite']}), ln Z {mean[1]:.4f} +- {std[1]:.4f} (reference {ref['ln_Z']:.4f} +- {ref['ln_Z_std']:.4f}); "
           f"per seed {runs.tolist()}")
     prior = TABLES[model].get("train_seed_spread", {})
-    n = len(SEEDS)
+    n = len(seeds)
     for q, key in ((0, "elbo"), (1, "ln_Z")):
         s_train = max(std[q], prior.get(key + "_std", 0.0))
         tol = 3.0 * np.sqrt(ref[key + "_std"] ** 2 + s_train ** 2 * (1.0 + 1.0 / n))
