@@ -377,26 +377,83 @@ __global__ __launch_bounds__(512, (T > 4 || D > 4) ? 2 : 4) void uha_traj_kernel
   }
 }
 
+// Diagnostic build only (-DCMCD_STAMPS, tools/probes/uha_stamp_probe.py): per-wave cycle totals of each phase of
+// workgroup 0 of uha_coop_kernel.  Never compiled into the product.
+#ifdef CMCD_STAMPS
+__device__ unsigned long long g_uha_stamps[16][16];
+#define USTAMP(slot)                                                                     \
+  do {                                                                                   \
+    unsigned long long t_;                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    st_acc[slot] += t_ - st_last;                                                        \
+    st_last = t_;                                                                        \
+  } while (0)
+#else
+#define USTAMP(slot)
+#endif
+
+// workgroup barrier that publishes LDS writes but does not drain outstanding global loads / stores (the next bridge's
+// bias row is in flight across the first barrier of every bridge; __syncthreads() would wait for it there)
+__device__ __forceinline__ void uha_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ------------------------------------------------------------------------------------------
 // uha_coop_kernel — the CU-cooperative form for batches that cannot fill the chip with one wave per tile (the named
 // shape: 125 tiles on a 256-long chain).  One workgroup of T + 2 waves per 16-particle tile:
 //   waves 0..T-1  MLP: wave v owns hidden units 16 v .. 16 v + 15 — its W1 rows, its W2 A-fragments (resident in VGPRs for
 //                 the whole launch), its slice of the layer-3 dot product;
 //   wave T        STATE + TGT: (z, rho, w) of the 16 particles, the leap-frog, both kernels' log-densities, grad log p(z')
-//                 (evaluated while the MLP waves run the bridge's SECOND network evaluation);
+//                 (distance pass / exponential pass in the two intervals of the bridge's SECOND network evaluation);
 //   wave T + 1    RNG: jax's key chain one bridge ahead, bits -> deviates.
 // A bridge is two passes of the MLP waves — s([z; rho], i), then s([z; rho'], i) — each: layer 1 + activation -> LDS (MFMA B
 // layout) | barrier | layer 2 on the matrix cores from LDS, activation, layer-3 partials -> LDS | barrier | the state wave
-// combines the partials and publishes the next network input | barrier.  Every wave executes the same barrier sequence
-// (plain workgroup barriers, uniform control flow), so the kernel cannot dead-lock on a role mismatch.  Same arithmetic as
-// uha_traj_kernel up to the summation order of the layer-3 partials (per wave, then over waves).
+// combines the partials and publishes the next network input | barrier.
+// Every role runs its OWN loop with the same barrier sequence (raw s_barrier counts arrivals, not program counters): as
+// branches of one shared loop body (r03 first form) every role's loop-carried registers were live in every wave — the
+// d = 10 instances spilled 270 - 990 bytes per lane and ran 21 000 cycles per bridge (tools/probes/uha_stamp_probe.py).
+// The key chain of bridge i + 1 is laid over the bridge's intervals so that no auxiliary interval is longer than the MLP
+// waves' own:  pass 0, matrix interval: (G, H) = split(gen) | pass 1, matrix interval: ONE Threefry pass whose rows 0, 1
+// encrypt split(H) (-> gen') and rows 2, 3 the first two blocks of normal(G) | next bridge's first interval: bits ->
+// deviates; for d > 4 the remaining blocks of normal(G) ride in the two intervals in between, split at a key injection.
+// Same arithmetic as uha_traj_kernel up to the summation order of the layer-3 partials (per wave, then over waves).
 // ------------------------------------------------------------------------------------------
+// Threefry-2x32 in two resumable parts (8 + 12 rounds): the same 20 rounds and key injections as threefry2x32
+// (cmcd_device.h), cut at the second key injection.
+struct TfState { uint32_t x0, x1, k0, k1, k2; };
+#define UHA_TF_ROUND(r) \
+  t.x0 += t.x1;         \
+  t.x1 = rotl32(t.x1, r); \
+  t.x1 ^= t.x0;
+__device__ __forceinline__ void tf_part1(TfState& t, uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1) {
+  t.k0 = k0; t.k1 = k1; t.k2 = k0 ^ k1 ^ 0x1BD11BDAu;
+  t.x0 = c0 + k0; t.x1 = c1 + k1;
+  UHA_TF_ROUND(13) UHA_TF_ROUND(15) UHA_TF_ROUND(26) UHA_TF_ROUND(6)
+  t.x0 += t.k1; t.x1 += t.k2 + 1u;
+  UHA_TF_ROUND(17) UHA_TF_ROUND(29) UHA_TF_ROUND(16) UHA_TF_ROUND(24)
+  t.x0 += t.k2; t.x1 += t.k0 + 2u;
+}
+__device__ __forceinline__ void tf_part2(TfState& t) {
+  UHA_TF_ROUND(13) UHA_TF_ROUND(15) UHA_TF_ROUND(26) UHA_TF_ROUND(6)
+  t.x0 += t.k0; t.x1 += t.k1 + 3u;
+  UHA_TF_ROUND(17) UHA_TF_ROUND(29) UHA_TF_ROUND(16) UHA_TF_ROUND(24)
+  t.x0 += t.k1; t.x1 += t.k2 + 4u;
+  UHA_TF_ROUND(13) UHA_TF_ROUND(15) UHA_TF_ROUND(26) UHA_TF_ROUND(6)
+  t.x0 += t.k2; t.x1 += t.k0 + 5u;
+}
+#undef UHA_TF_ROUND
+
 template <int TARGET, int ARCH, int D, int T>
 __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
   constexpr int HP = 16 * T;
   constexpr int DIN = 2 * D;
   constexpr int Hh = (D + 1) / 2;
   constexpr bool GEF = ARCH == CMCD_ARCH_GEFFNER;
+  constexpr bool RNG_C = Hh > 2;              // normal(G) needs more than the two blocks that ride beside split(H)
+  static_assert(Hh <= 6, "normal(G): at most 2 + 4 Threefry blocks per draw");
+  using Tg = Target<TARGET, D>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* hbuf = lds;                          // [T][64 lanes][4]   layer-1 activations, MFMA B order
   float* part = hbuf + T * 256;               // [T][16][D]         layer-3 partials per MLP wave
@@ -406,19 +463,31 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
   float* lds_tgt = nzb + 2 * 16 * D + 32;     // tgt_floats
   for (int i = threadIdx.x; i < a.w.tgt_floats; i += blockDim.x) lds_tgt[i] = a.ws[a.w.tgt + i];
 
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
-  const bool is_mlp = wv < T, is_state = wv == T, is_rng = wv == T + 1;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   const int64_t tile = blockIdx.x;
   const int64_t p = tile * 16 + c;
   const bool valid = p < a.n;
   const int K = a.K;
   const int gb = g & 1;
+  __syncthreads();                                   // target constants staged
 
-  // ---- MLP waves: resident weights
-  float w1[DIN][4], w3[D][4];
-  f32x4 afrag[T], b2v = {0.f, 0.f, 0.f, 0.f};
-  const int nb = 16 * (is_mlp ? wv : 0) + 4 * g;      // first of this lane's four hidden units
-  if (is_mlp) {
+#ifdef CMCD_STAMPS
+  unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
+#define USTAMP_START() asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory")
+#define USTAMP_END()                                                  \
+  if (blockIdx.x == 0 && lane == 0)                                   \
+    for (int k = 0; k < 16; ++k) g_uha_stamps[wv][k] = st_acc[k]
+#else
+#define USTAMP_START()
+#define USTAMP_END()
+#endif
+
+  // =========================================================================================== MLP waves
+  if (wv < T) {
+    float w1[DIN][4], w3[D][4];
+    f32x4 afrag[T];
+    const int nb = 16 * wv + 4 * g;                  // first of this lane's four hidden units
 #pragma unroll
     for (int j = 0; j < DIN; ++j)
 #pragma unroll
@@ -429,25 +498,200 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
       for (int r = 0; r < 4; ++r) w3[j][r] = a.ws[a.w.w3t + j * HP + nb + r];
 #pragma unroll
     for (int ti = 0; ti < T; ++ti) afrag[ti] = *reinterpret_cast<const f32x4*>(a.ws + a.w.w2 + ((ti * T + wv) * 64 + lane) * 4);
-    b2v = *reinterpret_cast<const f32x4*>(a.ws + a.w.b2 + nb);
-  }
-  const float factor = a.ws[a.w.b3 + 15];
-  float b3r[D];                                       // output bias, resident (a load per pass would sit on the bridge's critical path)
+    const f32x4 b2v = *reinterpret_cast<const f32x4*>(a.ws + a.w.b2 + nb);
+    const float* bias1 = a.ws + a.w.bias1;
+    const float* utab = a.ws + a.w.utab;
+    f32x4 brow_n = *reinterpret_cast<const f32x4*>(bias1 + nb), urow_n = {0.f, 0.f, 0.f, 0.f};
+    if (GEF) urow_n = *reinterpret_cast<const f32x4*>(utab + nb);
+    uha_lds_barrier();                               // gen_0 and the first network input published
+    uha_lds_barrier();                               // deviates of bridge 0 under way
+    USTAMP_START();
+    for (int i = 0; i < K; ++i) {
+      const f32x4 brow = brow_n, urow = urow_n;
+      if (i + 1 < K) {                               // the next bridge's rows arrive while this bridge runs
+        brow_n = *reinterpret_cast<const f32x4*>(bias1 + (int64_t)(i + 1) * HP + nb);
+        if (GEF) urow_n = *reinterpret_cast<const f32x4*>(utab + (int64_t)(i + 1) * HP + nb);
+      }
 #pragma unroll
-  for (int j = 0; j < D; ++j) b3r[j] = a.ws[a.w.b3 + j];
+      for (int pass = 0; pass < 2; ++pass) {
+        // ---------------------------------------------------------------- interval 1
+        float h[4];
+        {
+          float x[DIN];
+#pragma unroll
+          for (int j = 0; j < DIN; ++j) x[j] = xin[c * DIN + j];
+          float pre[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            pre[r] = brow[r];
+#pragma unroll
+            for (int j = 0; j < DIN; ++j) pre[r] = fmaf(x[j], w1[j][r], pre[r]);
+          }
+          if (!GEF) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = gelu_fast(pre[r]);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float u = urow[r];
+              if (nb + r < DIN) u = xin[c * DIN + nb + r];      // the first 2 D entries of u are [z; rho] themselves
+              h[r] = u + softplus(pre[r]);
+            }
+          }
+          *reinterpret_cast<f32x4*>(hbuf + (wv * 64 + lane) * 4) = f32x4{h[0], h[1], h[2], h[3]};
+        }
+        USTAMP(pass * 6 + 0);
+        uha_lds_barrier();
+        USTAMP(pass * 6 + 1);
+        // ---------------------------------------------------------------- interval 2
+        {
+          // two accumulator chains (even / odd input tiles): a 16x16x4 that reads its predecessor's result waits for it
+          f32x4 acc = b2v, acc1 = {0.f, 0.f, 0.f, 0.f};
+          f32x4 hbv[T];
+#pragma unroll
+          for (int ti = 0; ti < T; ++ti) hbv[ti] = *reinterpret_cast<const f32x4*>(hbuf + (ti * 64 + lane) * 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int ti = 0; ti < T; ++ti) {
+              if (ti & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ti][r], hbv[ti][r], acc1, 0, 0, 0);
+              else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ti][r], hbv[ti][r], acc, 0, 0, 0);
+            }
+          }
+          acc += acc1;
+          float h2[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h2[r] = GEF ? h[r] + softplus(acc[r]) : gelu_fast(acc[r]);
+#pragma unroll
+          for (int j = 0; j < D; ++j) {
+            float pj = h2[0] * w3[j][0] + h2[1] * w3[j][1] + h2[2] * w3[j][2] + h2[3] * w3[j][3];
+            pj = group_sum(pj);
+            if (g == 0) part[(wv * 16 + c) * D + j] = pj;
+          }
+        }
+        USTAMP(pass * 6 + 2);
+        uha_lds_barrier();
+        USTAMP(pass * 6 + 3);
+        if (pass == 0) {
+          uha_lds_barrier();                         // the state wave forms rho' from the partials
+          USTAMP(pass * 6 + 5);
+        }
+      }
+    }
+    USTAMP_END();
+    return;
+  }
 
-  // ---- state wave: q, gamma, initial draws (the prologue of uha_traj_kernel)
+  // =========================================================================================== RNG wave
+  if (wv == T + 1) {
+    uha_lds_barrier();                               // gen_0 published
+    uint32_t k0 = keyb[2 * c], k1 = keyb[2 * c + 1];
+    uint32_t sg0 = 0, sg1 = 0, sh0 = 0, sh1 = 0;     // (G, H) = split(gen)
+    uint32_t bb0 = 0, bb1 = 0, cb0 = 0, cb1 = 0;     // random words of this row's block of normal(G): pass B / pass C
+    TfState tb, tc;
+    // A: (G, H) = split(gen)
+    auto pass_a = [&]() {
+      uint32_t x0 = gb, x1 = 2 + gb;
+      threefry2x32(k0, k1, x0, x1);
+      rows01(x0, sg0, sg1);
+      rows01(x1, sh0, sh1);
+    };
+    // B (in two parts): rows 0, 1: gen' = second(split(H));  rows 2, 3: blocks 0, 1 of normal(G) — block j encrypts (j, Hh + j)
+    auto pass_b1 = [&]() {
+      const int j = g - 2;
+      tf_part1(tb, g < 2 ? sh0 : sg0, g < 2 ? sh1 : sg1, g < 2 ? (uint32_t)gb : (uint32_t)j,
+               g < 2 ? (uint32_t)(2 + gb) : (uint32_t)((Hh + j < D) ? Hh + j : 0));
+    };
+    auto pass_b2 = [&](int ib) {
+      tf_part2(tb);
+      bb0 = tb.x0; bb1 = tb.x1;
+      rows01(tb.x1, k0, k1);
+      if (a.dbg_keys && valid && g == 0) {
+        a.dbg_keys[((int64_t)(ib + 1) * a.n + p) * 2] = k0;
+        a.dbg_keys[((int64_t)(ib + 1) * a.n + p) * 2 + 1] = k1;
+      }
+    };
+    // one random word -> deviate `idx` of bridge ib
+    auto put = [&](int ib, int idx, uint32_t y) {
+      const float nv = bits_to_normal(y);
+      nzb[((ib & 1) * 16 + c) * D + idx] = nv;
+      if (a.dbg_bits && valid) {
+        const int64_t o = ((int64_t)(ib + 2) * a.n + p) * D + idx;
+        a.dbg_bits[o] = y;
+        a.dbg_noise[o] = nv;
+      }
+    };
+    // the words of pass B -> deviates, by the rows that encrypted them; d <= 2 (one block): its second word moves to the
+    // idle row 3, so each row converts one word
+    auto publish_b = [&](int ib) {
+      if (Hh == 1) {
+        uint32_t r0, r1;
+        swap16(bb0, bb1, r0, r1);                    // r0 = rows [bb0(0) bb1(0) bb0(2) bb1(2)]
+        if (g >= 2 && g - 2 < D) put(ib, g - 2, r0);
+      } else if (g >= 2) {
+        const int j = g - 2;
+        put(ib, j, bb0);
+        if (Hh + j < D) put(ib, Hh + j, bb1);
+      }
+    };
+    auto pass_c1 = [&]() {                           // C: blocks 2 .. 5 of normal(G) on rows 0 .. 3
+      const int j = 2 + g;
+      tf_part1(tc, sg0, sg1, (uint32_t)j, (uint32_t)((Hh + j < D) ? Hh + j : 0));
+    };
+    auto pass_c2 = [&]() { tf_part2(tc); cb0 = tc.x0; cb1 = tc.x1; };
+    auto publish_c = [&](int ib) {
+      const int j = 2 + g;
+      if (j < Hh) {
+        put(ib, j, cb0);
+        if (Hh + j < D) put(ib, Hh + j, cb1);
+      }
+    };
+    pass_a();
+    if (RNG_C) { pass_c1(); pass_c2(); }
+    pass_b1();
+    pass_b2(0);
+    publish_b(0);
+    if (RNG_C) publish_c(0);
+    uha_lds_barrier();                               // deviates of bridge 0 published
+    USTAMP_START();
+    for (int i = 0; i < K; ++i) {
+      const bool more = i + 1 < K;
+      if (i > 0) {                                   // words -> deviates of bridge i (read behind the next barrier)
+        publish_b(i);
+        if (RNG_C) publish_c(i);
+      }
+      USTAMP(0); uha_lds_barrier(); USTAMP(1);       // pass 0, barrier 1
+      if (more) pass_a();
+      USTAMP(2); uha_lds_barrier(); USTAMP(3);
+      if (RNG_C && more) pass_c1();
+      USTAMP(4); uha_lds_barrier(); USTAMP(5);
+      if (more) pass_b1();
+      USTAMP(6); uha_lds_barrier(); USTAMP(7);       // pass 1, barrier 1
+      if (more) pass_b2(i + 1);
+      if (RNG_C && more) pass_c2();
+      USTAMP(8); uha_lds_barrier(); USTAMP(9);
+    }
+    USTAMP_END();
+    return;
+  }
+
+  // =========================================================================================== state wave
+  // (equal issue priorities: one or two s_setprio levels for this wave and / or the RNG wave measured 0.444 - 0.466 ms
+  //  against 0.426 at the named shape, r03 — the MLP waves' chain is the one the bridge waits for in four of five intervals)
+  // q, gamma, initial draws (the prologue of uha_traj_kernel)
   float qmean[D], qstd[D], qiv[D], z[D], rho[D], gp[D], gq[D];
-  float w = 0.f, logp = 0.f, gamma = 0.f;
-  uint32_t k0 = 0u, k1 = 0u;
+  float w = 0.f, logp = 0.f;
   float* tz = a.traj;
   float* trho = a.traj ? a.traj + (int64_t)(K + 1) * a.n * D : nullptr;
   float* trhop = a.traj ? a.traj + (int64_t)(2 * K + 2) * a.n * D : nullptr;
   const bool keep = a.traj && valid && g == 0;
   constexpr float clipv = 1e2f;
-  __syncthreads();                                   // target constants staged
-  if (is_state) {
-    gamma = a.params[a.lay.gamma];
+  const float gamma = a.params[a.lay.gamma];
+  const float factor = a.ws[a.w.b3 + 15];
+  float b3r[D];                                       // output bias, resident (a load per pass would sit on the bridge's critical path)
+#pragma unroll
+  for (int j = 0; j < D; ++j) b3r[j] = a.ws[a.w.b3 + j];
+  {
     const int32_t seed = a.seeds[valid ? p : a.n - 1];
 #pragma unroll
     for (int j = 0; j < D; ++j) {
@@ -455,8 +699,8 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
       qstd[j] = expf(a.params[a.lay.vd_logdiag + j]);
       qiv[j] = 1.0f / (qstd[j] * qstd[j]);
     }
+    uint32_t k0 = 0u, k1 = (uint32_t)seed;
     uint32_t x0 = gb, x1 = 2 + gb;
-    k1 = (uint32_t)seed;
     threefry2x32(k0, k1, x0, x1);
     uint32_t a0, a1, b0, b1;
     rows01(x0, a0, a1);
@@ -501,7 +745,7 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
         trho[p * D + j] = rho[j];
       }
     }
-    Target<TARGET, D>::eval(z, g, lds_tgt, logp, gp);
+    Tg::eval(z, g, lds_tgt, logp, gp);
 #pragma unroll
     for (int j = 0; j < D; ++j) {
       gp[j] = fminf(fmaxf(gp[j], -clipv), clipv);
@@ -512,190 +756,124 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
       for (int j = 0; j < D; ++j) { xin[c * DIN + j] = z[j]; xin[c * DIN + D + j] = rho[j]; }
     }
   }
-  __syncthreads();                                   // gen_0 and the first network input published
-  // one stage of the key chain on the RNG wave, in two halves that each sit in the matrix interval of a pass (three Threefry
-  // passes of ~100 dependent integer instructions are longer than any single interval: in front of a barrier they would
-  // hold every wave of the workgroup):  A: (G, H) = split(gen);  B: gen = second(split(H)), deviates of bridge `ib` = normal(G).
-  // Measured and rejected (r03): a dedicated target wave (T + 3 waves) with both splits in half A: 0.567 -> 0.599 ms — a
-  // matrix instruction blocks the VALU of its SIMD, so a seventh wave and a longer half A only move the long pole.
-  uint32_t sg0 = 0, sg1 = 0, sh0 = 0, sh1 = 0;
-  auto rng_stage_a = [&]() {
-    uint32_t x0 = gb, x1 = 2 + gb;
-    threefry2x32(k0, k1, x0, x1);
-    rows01(x0, sg0, sg1);
-    rows01(x1, sh0, sh1);
+  typename Tg::Means means;
+  Tg::template load_means<4>(g, lds_tgt, means);
+  const bool tfast = Tg::kHasFast && Tg::is_fast(means);   // wave-uniform: the register-resident form of the target (many_gmm, 40 modes)
+  // the scalars of a bridge (mcd_under_lp_a_cais.py: eta_aux = gamma eps; the refresh's scale sqrt(2 eta))
+  struct Sc { float beta, eps, eta, sig, inv2s2, cst, ome; };
+  auto scalars = [&](float beta, float eps) {
+    Sc q;
+    q.beta = beta; q.eps = eps;
+    q.eta = gamma * eps; q.sig = sqrtf(2.0f * q.eta);
+    q.inv2s2 = 1.0f / (2.0f * q.sig * q.sig); q.cst = logf(q.sig) + kHalfLog2Pi; q.ome = 1.0f - q.eta;
+    return q;
   };
-  auto rng_stage_b = [&](int ib) {
-    uint32_t x0 = gb, x1 = 2 + gb;
-    threefry2x32(sh0, sh1, x0, x1);
-    rows01(x1, k0, k1);
-    if (a.dbg_keys && valid && g == 0) {
-      a.dbg_keys[((int64_t)(ib + 1) * a.n + p) * 2] = k0;
-      a.dbg_keys[((int64_t)(ib + 1) * a.n + p) * 2 + 1] = k1;
+  Sc sc_n = scalars(a.ws[a.w.beta], a.ws[a.w.eps]);
+  // what the backward kernel of a bridge still needs once the next bridge's input is out: closed one interval later,
+  // beside the MLP waves' first layer (its network evaluation feeds the log-weight only, not the state)
+  float cl_rome[D], cl_rho[D], cl_eta = 0.f, cl_inv2s2 = 0.f, cl_cst = 0.f, cl_fk = 0.f;
+  auto net_out = [&](float (&s)[D]) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      float o = b3r[j];
+#pragma unroll
+      for (int v = 0; v < T; ++v) o += part[(v * 16 + c) * D + j];
+      s[j] = GEF ? o * factor : fminf(fmaxf(o, -1e4f), 1e4f);
     }
-    float nz[2 * Hh];
-    draw_normal<D>(sg0, sg1, g, nz, a, ib + 2, p, valid);
+  };
+  auto close_bridge = [&]() {
+    float s[D];
+    net_out(s);
+    float bk_lp = 0.f;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const float mb = cl_rome[j] + 2.0f * cl_eta * s[j];
+      const float db = cl_rho[j] - mb;
+      bk_lp += -(db * db) * cl_inv2s2 - cl_cst;
+    }
+    w += bk_lp - cl_fk;
+  };
+  uha_lds_barrier();                                 // gen_0 and the first network input published
+  uha_lds_barrier();
+  USTAMP_START();
+  for (int i = 0; i < K; ++i) {
+    const Sc q = sc_n;
+    float beta_n = 0.f, eps_n = 0.f;
+    if (i + 1 < K) { beta_n = a.ws[a.w.beta + i + 1]; eps_n = a.ws[a.w.eps + i + 1]; }   // used one interval on
+    // ------------------------------------------------------------------ beside the first layer of pass 0
+    if (i > 0) close_bridge();
+    USTAMP(0); uha_lds_barrier(); USTAMP(1);
+    // ------------------------------------------------------------------ pass 0, matrix interval: everything of rho' but the network
+    float rome[D], snz[D], huf[D], mf[D], rhop[D], rpp[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const float nzv = nzb[((i & 1) * 16 + c) * D + j];
+      rome[j] = rho[j] * q.ome;
+      snz[j] = q.sig * nzv;
+      const float uf = -1.0f * (q.beta * gp[j] + (1.0f - q.beta) * gq[j]);
+      huf[j] = q.eps * uf / 2.0f;
+    }
+    if (i + 1 < K) sc_n = scalars(beta_n, eps_n);
+    USTAMP(2); uha_lds_barrier(); USTAMP(3);
+    // ------------------------------------------------------------------ pass 0: rho' -> the second evaluation's input
+    {
+      float s[D];
+      net_out(s);
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        mf[j] = rome[j] - 2.0f * q.eta * s[j];
+        rhop[j] = mf[j] + snz[j];
+      }
+      if (g == 0) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) xin[c * DIN + D + j] = rhop[j];      // [z; rho']: the z half stays
+      }
+    }
+    USTAMP(4); uha_lds_barrier(); USTAMP(5);
+    // ------------------------------------------------------------------ pass 1, first layer: forward log-density, half step, z',
+    //                                                                    distance pass of grad log p(z')
+    float fk_lp = 0.f;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const float df = rhop[j] - mf[j];
+      fk_lp += -(df * df) * q.inv2s2 - q.cst;
+      rpp[j] = rhop[j] - huf[j];
+      cl_rho[j] = rho[j];
+      cl_rome[j] = rhop[j] * q.ome;
+      z[j] = z[j] + q.eps * rpp[j];
+      gq[j] = -(z[j] - qmean[j]) * qiv[j];
+    }
+    cl_eta = q.eta; cl_inv2s2 = q.inv2s2; cl_cst = q.cst; cl_fk = fk_lp;
+    typename Tg::State tst;
+    if (tfast) Tg::template pass1f<4>(z, g, means, tst);
+    else Tg::template pass1r<4>(z, g, lds_tgt, means, tst);
+    USTAMP(6); uha_lds_barrier(); USTAMP(7);
+    // ------------------------------------------------------------------ pass 1, matrix interval: exponential pass, second half
+    //                                                                    step -> the NEXT bridge's input (it does not need s)
+    if (tfast) Tg::template pass2f<4>(z, g, means, tst, logp, gp);
+    else Tg::template pass2<4>(z, g, lds_tgt, tst, logp, gp);
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      gp[j] = fminf(fmaxf(gp[j], -clipv), clipv);
+      const float ub = -1.0f * (q.beta * gp[j] + (1.0f - q.beta) * gq[j]);
+      rho[j] = rpp[j] - q.eps * ub / 2.0f;
+    }
     if (g == 0) {
 #pragma unroll
-      for (int j = 0; j < D; ++j) nzb[((ib & 1) * 16 + c) * D + j] = nz[j];
+      for (int j = 0; j < D; ++j) { xin[c * DIN + j] = z[j]; xin[c * DIN + D + j] = rho[j]; }
     }
-  };
-  if (is_rng) {
-    k0 = keyb[2 * c]; k1 = keyb[2 * c + 1];
-    rng_stage_a();
-    rng_stage_b(0);
+    if (keep) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        tz[((int64_t)(i + 1) * a.n + p) * D + j] = z[j];
+        trho[((int64_t)(i + 1) * a.n + p) * D + j] = rho[j];
+        trhop[((int64_t)i * a.n + p) * D + j] = rhop[j];
+      }
+    }
+    USTAMP(8); uha_lds_barrier(); USTAMP(9);
   }
-  __syncthreads();                                   // deviates of bridge 0 published
-
-  const float* bias1 = a.ws + a.w.bias1;
-  const float* utab = a.ws + a.w.utab;
-  f32x4 brow_n = {0.f, 0.f, 0.f, 0.f}, urow_n = {0.f, 0.f, 0.f, 0.f};
-  if (is_mlp) {
-    brow_n = *reinterpret_cast<const f32x4*>(bias1 + nb);
-    if (GEF) urow_n = *reinterpret_cast<const f32x4*>(utab + nb);
-  }
-
-  for (int i = 0; i < K; ++i) {
-    f32x4 brow = brow_n, urow = urow_n;
-    if (is_mlp && i + 1 < K) {                       // the next bridge's rows arrive while this bridge runs
-      brow_n = *reinterpret_cast<const f32x4*>(bias1 + (int64_t)(i + 1) * HP + nb);
-      if (GEF) urow_n = *reinterpret_cast<const f32x4*>(utab + (int64_t)(i + 1) * HP + nb);
-    }
-    float beta = 0.f, eps = 0.f, eta = 0.f, sig = 0.f, inv2s2 = 0.f, cst = 0.f, ome = 0.f;
-    if (is_state) {
-      beta = a.ws[a.w.beta + i]; eps = a.ws[a.w.eps + i];
-      eta = gamma * eps; sig = sqrtf(2.0f * eta);
-      inv2s2 = 1.0f / (2.0f * sig * sig); cst = logf(sig) + kHalfLog2Pi; ome = 1.0f - eta;
-    }
-    float rhop[D], rpp[D], fk_lp = 0.f;
-#pragma unroll
-    for (int j = 0; j < D; ++j) { rhop[j] = 0.f; rpp[j] = 0.f; }
-
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      // ---------------------------------------------------------------- interval 1
-      float h[4] = {0.f, 0.f, 0.f, 0.f};
-      if (is_mlp) {
-        float x[DIN];
-#pragma unroll
-        for (int j = 0; j < DIN; ++j) x[j] = xin[c * DIN + j];
-        float pre[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          pre[r] = brow[r];
-#pragma unroll
-          for (int j = 0; j < DIN; ++j) pre[r] = fmaf(x[j], w1[j][r], pre[r]);
-        }
-        if (!GEF) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) h[r] = gelu_fast(pre[r]);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float u = urow[r];
-            if (nb + r < DIN) u = xin[c * DIN + nb + r];      // the first 2 D entries of u are [z; rho] themselves
-            h[r] = u + softplus(pre[r]);
-          }
-        }
-        *reinterpret_cast<f32x4*>(hbuf + (wv * 64 + lane) * 4) = f32x4{h[0], h[1], h[2], h[3]};
-      }
-      __syncthreads();
-      // ---------------------------------------------------------------- interval 2 (the long one: the auxiliary work sits here)
-      if (is_rng && i + 1 < K) {
-        if (pass == 0) rng_stage_a(); else rng_stage_b(i + 1);
-      } else if (is_state && pass == 1) {
-        // grad log p(z') while the MLP waves run the second evaluation's matrix phase; z already holds z'
-        Target<TARGET, D>::eval(z, g, lds_tgt, logp, gp);
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-          gp[j] = fminf(fmaxf(gp[j], -clipv), clipv);
-          gq[j] = -(z[j] - qmean[j]) * qiv[j];
-        }
-      }
-      if (is_mlp) {
-        // two accumulator chains (even / odd input tiles): a 16x16x4 that reads its predecessor's result waits for it
-        f32x4 acc = b2v, acc1 = {0.f, 0.f, 0.f, 0.f};
-        f32x4 hbv[T];
-#pragma unroll
-        for (int ti = 0; ti < T; ++ti) hbv[ti] = *reinterpret_cast<const f32x4*>(hbuf + (ti * 64 + lane) * 4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-          for (int ti = 0; ti < T; ++ti) {
-            if (ti & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ti][r], hbv[ti][r], acc1, 0, 0, 0);
-            else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ti][r], hbv[ti][r], acc, 0, 0, 0);
-          }
-        }
-        acc += acc1;
-        float h2[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) h2[r] = GEF ? h[r] + softplus(acc[r]) : gelu_fast(acc[r]);
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-          float pj = h2[0] * w3[j][0] + h2[1] * w3[j][1] + h2[2] * w3[j][2] + h2[3] * w3[j][3];
-          pj = group_sum(pj);
-          if (g == 0) part[(wv * 16 + c) * D + j] = pj;
-        }
-      }
-      __syncthreads();
-      // ---------------------------------------------------------------- the state wave combines
-      if (is_state) {
-        float s[D];
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-          float o = b3r[j];
-#pragma unroll
-          for (int v = 0; v < T; ++v) o += part[(v * 16 + c) * D + j];
-          s[j] = GEF ? o * factor : fminf(fmaxf(o, -1e4f), 1e4f);
-        }
-        if (pass == 0) {
-          fk_lp = 0.f;
-#pragma unroll
-          for (int j = 0; j < D; ++j) {
-            const float mf = rho[j] * ome - 2.0f * eta * s[j];
-            rhop[j] = mf + sig * nzb[((i & 1) * 16 + c) * D + j];
-            const float df = rhop[j] - mf;
-            fk_lp += -(df * df) * inv2s2 - cst;
-            const float uf = -1.0f * (beta * gp[j] + (1.0f - beta) * gq[j]);
-            rpp[j] = rhop[j] - eps * uf / 2.0f;
-          }
-          if (g == 0) {
-#pragma unroll
-            for (int j = 0; j < D; ++j) xin[c * DIN + D + j] = rhop[j];      // [z; rho']: the z half stays
-          }
-        } else {
-          float bk_lp = 0.f;
-#pragma unroll
-          for (int j = 0; j < D; ++j) {
-            const float mb = rhop[j] * ome + 2.0f * eta * s[j];
-            const float db = rho[j] - mb;
-            bk_lp += -(db * db) * inv2s2 - cst;
-            const float ub = -1.0f * (beta * gp[j] + (1.0f - beta) * gq[j]);   // gp / gq are those of z' by now
-            rho[j] = rpp[j] - eps * ub / 2.0f;
-          }
-          w += bk_lp - fk_lp;
-          if (g == 0) {
-#pragma unroll
-            for (int j = 0; j < D; ++j) { xin[c * DIN + j] = z[j]; xin[c * DIN + D + j] = rho[j]; }
-          }
-          if (keep) {
-#pragma unroll
-            for (int j = 0; j < D; ++j) {
-              tz[((int64_t)(i + 1) * a.n + p) * D + j] = z[j];
-              trho[((int64_t)(i + 1) * a.n + p) * D + j] = rho[j];
-              trhop[((int64_t)i * a.n + p) * D + j] = rhop[j];
-            }
-          }
-        }
-        if (pass == 0) {
-#pragma unroll
-          for (int j = 0; j < D; ++j) z[j] = z[j] + eps * rpp[j];      // z' (the network input keeps the old z until pass 1 ends)
-        }
-      }
-      __syncthreads();
-    }
-  }
-  if (!is_state) return;
+  if (K > 0) close_bridge();
+  USTAMP_END();
   {
     float lK = 0.f;
 #pragma unroll
@@ -729,6 +907,8 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
     o[0] = cnt; o[1] = sm; o[2] = sq; o[3] = mx; o[4] = ex;
   }
 }
+#undef USTAMP_START
+#undef USTAMP_END
 
 // ------------------------------------------------------------------------------------------
 // host side
@@ -788,6 +968,11 @@ static uha_fn uha_coop_pick(const cmcd_desc& d, int T) {
 bool uha_available(const cmcd_desc& d, int T) { return uha_pick(d, T) != nullptr; }
 
 // tiles up to which the cooperative form is preferred (MI355X, profiles/r03_uha_variant_crossover.txt)
+#ifdef CMCD_STAMPS
+extern "C" int cmcd_debug_read_uha_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_uha_stamps), sizeof(unsigned long long) * 16 * 16);
+}
+#endif
 static int uha_coop_max_tiles(const cmcd_desc& d) { (void)d; return 1024; }
 static thread_local const char* g_uha_kernel_name = "uha_traj_kernel";
 const char* uha_last_kernel_name() { return g_uha_kernel_name; }
