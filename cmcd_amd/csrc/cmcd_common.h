@@ -44,12 +44,27 @@ struct TrajArgs {
   float* traj;  // optional [K+1][n][D] trajectory z_0..z_K (the reparameterised gradient's reverse sweep reads it)
   int32_t ula;  // 0: CAIS; 1: MCD_ULA (no network); 2: MCD_ULA_sn (network in the backward kernel only, index i)
   int32_t prio = 0;  // cooperative kernel: s_setprio level per role, 2 bits each {MLP, TGT, RNG, ACC} from bit 0
+  int32_t tail = 0;  // cooperative kernel, 8-particle tiles of the 9-tile net: the ninth MLP wave runs the 4-neuron form (coop_tail4)
   // cmcd_debug_capture_noise (tests): the PRNG path of THIS launch, written next to the arithmetic that consumes it.
   // Stage 0 = the draw of z_0, stage i + 1 = bridge i.  All nullable.
   uint32_t* dbg_bits = nullptr;   // [K+1][n][D]  the random words that become the deviates (jax random_bits)
   uint32_t* dbg_keys = nullptr;   // [K+1][n][2]  gen_0 .. gen_K: the chain key entering bridge i (mcd_cais.py:66,87,94)
   float* dbg_noise = nullptr;     // [K+1][n][D]  the deviates (jax.random.normal)
 };
+
+// The 132-wide net (BASELINE configuration 4) is 8 neuron tiles + 4 neurons: on 8-particle tiles its ninth MLP wave
+// contracts those 4 neurons over EIGHT slices of the 144 inputs (20 matrix instructions) instead of carrying 12 zero
+// neurons through 72.  One rule for the prep launch (operand packing of that wave) and the launch (TrajArgs::tail).
+__host__ __device__ inline bool coop_tail4(int T, int real_width) {
+#ifdef CMCD_COOP_NO_TAIL   // A / B builds (tools/probes/t9_tail_ab.sh)
+  return false;
+#else
+  return T == 9 && real_width > 128 && real_width <= 132;
+#endif
+}
+// slice s of the tail wave's contraction: inputs [coop_tail_start(s), + coop_tail_len(s)), 16-byte aligned starts
+__host__ __device__ inline int coop_tail_start(int s) { return s < 4 ? 20 * s : 80 + 16 * (s - 4); }
+__host__ __device__ inline int coop_tail_len(int s) { return s < 4 ? 20 : 16; }
 
 // cmcd_coop.hip: the CU-cooperative variant (one workgroup per 16-particle tile).
 // Returns nullptr-equivalent (false) when no instance exists for this (target, arch, dim, T).
@@ -63,8 +78,8 @@ int coop_launch(const cmcd_desc& d, const TrajArgs& ta, bool half, void* stream)
 int net_in_dim(const cmcd_desc& d);                    // dim, or 2 dim when the network takes concat(z, rho)
 bool uha_available(const cmcd_desc& d, int T);
 int64_t uha_traj_floats(const cmcd_desc& d, int64_t n);
-int uha_forward_launch(const cmcd_desc& d, const TrajArgs& ta, void* stream);
-const char* uha_last_kernel_name();                    // "uha_traj_kernel" | "uha_coop_kernel" (this host thread's last launch)
+int uha_forward_launch(const cmcd_desc& d, const TrajArgs& ta, void* stream, int* n_records);   // n_records: statistics records written
+const char* uha_last_kernel_name();                    // "uha_traj_kernel" | "uha_coop_kernel<N-particle tiles>" (this host thread's last launch)
 // reparameterised gradient: reverse sweep over the kept trajectory
 bool uha_grad_available(const cmcd_desc& d, int T);
 int64_t uha_grad_workspace_floats(const cmcd_desc& d, int HP, int64_t n);

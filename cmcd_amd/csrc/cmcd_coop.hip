@@ -436,10 +436,11 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
   // branch instructions per bridge beside ~105 useful ones (ISA reading), and a lone wave issues one instruction per
   // ~5 cycles whatever it is.  Each role now runs its own copy of the loop with the same barrier sequence (raw
   // `s_barrier` counts arrivals, not program counters).
-  enum { kMLP = 0, kTGT = 1, kRNG = 2, kACC = 3, kRNGACC = 4, kTGTF = 5 };   // kTGTF: target waves, register-resident mixture (Target::is_fast)
+  // kTGTF: target waves, register-resident mixture (Target::is_fast); kMLPT: the ninth MLP wave of the 132-wide net (coop_tail4)
+  enum { kMLP = 0, kTGT = 1, kRNG = 2, kACC = 3, kRNGACC = 4, kTGTF = 5, kMLPT = 6 };
   auto role_loop = [&](auto role_tag) {
     constexpr int R = decltype(role_tag)::value;
-    constexpr bool r_mlp = R == kMLP, r_tgt = R == kTGT || R == kTGTF, r_tgtf = R == kTGTF;
+    constexpr bool r_mlp = R == kMLP || R == kMLPT, r_tail = R == kMLPT, r_tgt = R == kTGT || R == kTGTF, r_tgtf = R == kTGTF;
     constexpr bool r_rng = R == kRNG || R == kRNGACC, r_acc = R == kACC || R == kRNGACC;
     // The body is instantiated for both parities of the evaluation index: every double-buffered exchange row is then at
     // a compile-time offset from a loop-invariant address (immediate offset field of the LDS instruction) instead of
@@ -518,7 +519,37 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
         if (ARCH == CMCD_ARCH_GEFFNER) urow = load_row(a.ws + a.w.utab + (int64_t)nrow * HP + nb);
         // layer 2: rows = my 16 output neurons, cols = particles, k = all HP inputs from LDS
         float av[NR], h2[NR];
-        if (HALF) {
+        if constexpr (r_tail) {
+          // 132 = 8 x 16 + 4: this wave's tile holds 4 real neurons.  All 16 blocks of the instruction work on those
+          // four — block (pg, slice) contracts slice `slice` of the 144 inputs (8 slices of 20 / 16, 16-byte aligned
+          // starts) — 20 matrix instructions instead of 72 on the SIMD that carries three of the nine chains; every lane
+          // fetches its own slice of its particle's activations (no row broadcast), the slices are summed over lanes
+          // l ^ 8, l ^ 16, l ^ 32.  Steps 16 .. 19 of the short slices re-read valid activations against zero operands.
+          const int sl = (lane >> 3) & 7;
+          const float* rd_t = hbuf + c * HQP + coop_tail_start(sl);
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+          f32x4 hb[5];
+#pragma unroll
+          for (int q = 0; q < 5; ++q) hb[q] = *reinterpret_cast<const f32x4*>(rd_t + 4 * ((q == 4 && sl >= 4) ? 3 : q));
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int sq = 0; sq < 20; ++sq) {
+            f32x4& ac = (sq & 1) ? acc1 : acc;
+            ac = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[sq], hb[sq / 4][sq % 4], ac, 0, 0, 0);
+          }
+          acc += acc1;
+          STAMP(7);
+          float tot[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float t = acc[r];
+            t += xor8(t);
+            tot[r] = group_sum(t);
+          }
+          // lane (kh, ng) keeps neurons 4 ng + 2 kh + {0, 1} of the tile: real ones only in group 0
+          av[0] = (ng == 0 ? (kh ? tot[2] : tot[0]) : 0.f) + b2p[0];
+          av[1] = (ng == 0 ? (kh ? tot[3] : tot[1]) : 0.f) + b2p[1];
+        } else if (HALF) {
           // 16 blocks of 4 neurons x 4 particles per instruction: block (pg, kh, ng) accumulates half kh of the
           // contraction; no column of the product is wasted (the 16x16x4 shape would carry every particle twice).
           // Step s takes its activation from the row that fetched it (BLGP broadcast); all LDS reads are in flight
@@ -671,7 +702,14 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
       if (i + 1 <= K) body(i + 1, std::integral_constant<int, 1>{});
     }
   };
-  if (is_mlp) role_loop(std::integral_constant<int, kMLP>{});
+  if (is_mlp) {
+    if constexpr (HALF && T == 9) {
+      if (a.tail && wv == T - 1) role_loop(std::integral_constant<int, kMLPT>{});
+      else role_loop(std::integral_constant<int, kMLP>{});
+    } else {
+      role_loop(std::integral_constant<int, kMLP>{});
+    }
+  }
   else if (is_tgt) {
     if (Target<TARGET, D>::kHasFast && __builtin_amdgcn_readfirstlane((int)Target<TARGET, D>::is_fast(tmeans)))
       role_loop(std::integral_constant<int, kTGTF>{});
@@ -789,6 +827,7 @@ int coop_launch(const cmcd_desc& d, const TrajArgs& ta_in, bool half, void* stre
   coop_fn fn = inst.fn;
   if (!fn) return CMCD_ERR_UNSUPPORTED;
   ta.prio = g_coop_prio >= 0 ? g_coop_prio : default_prio(d, half, inst.waves);
+  ta.tail = half && d.arch == CMCD_ARCH_GEFFNER && coop_tail4(T, net_in_dim(d) + d.emb_dim);
   const size_t lds_bytes = size_t(16 * T * 16 + 2 * 16 * PT + 2 * 16 * GP + 2 * 16 * NZ + 2 * 16 * NZ + ta.w.tgt_floats +
                                  (D > 4 ? 16 * ((D + 3) & ~3) : 0)) * 4;   // + the published state (d > 4)
   const unsigned tiles = half ? unsigned((ta.n + 7) / 8) : (unsigned)ta.w.n_waves;

@@ -377,7 +377,13 @@ __device__ __forceinline__ void pack_weights_body(const PackArgs& a, int vblock,
   // activations can be broadcast from one row to all four by the instruction's B lane-group pattern)
   for (int64_t idx = tid; has_net && idx < 2 * (int64_t)HP * HP; idx += stride) {
     const int lane = idx & 63, rest = int(idx >> 6), sq = rest % (HP / 2), wvq = rest / (HP / 2);
-    const int kin = sq + (HP / 2) * ((lane >> 3) & 1), nout = 16 * wvq + 4 * (lane >> 4) + (lane & 3);
+    int kin = sq + (HP / 2) * ((lane >> 3) & 1), nout = 16 * wvq + 4 * (lane >> 4) + (lane & 3);
+    if (wvq == 8 && coop_tail4(T, a.IN)) {
+      // the ninth wave's 4-neuron form: lane = i + 4 pg + 8 slice, step sq of slice `slice` (cmcd_common.h: coop_tail4)
+      const int sl = (lane >> 3) & 7;
+      kin = sq < coop_tail_len(sl) ? coop_tail_start(sl) + sq : a.IN;   // a.IN: out of range -> 0
+      nout = 128 + (lane & 3);
+    }
     a.ws[a.w.w2q + idx] = (kin < a.IN && nout < a.IN) ? P[a.o_w2 + (int64_t)kin * a.IN + nout] : 0.f;
   }
   for (int64_t idx = tid; has_net && idx < (int64_t)a.D * HP; idx += stride) {
@@ -1113,11 +1119,12 @@ static int forward_impl(const cmcd_desc* desc, const cmcd_layout* lay, const int
     TrajArgs tu{seeds, params, ws, reinterpret_cast<double*>(ws + w.partials), out_loss, out_z, *lay, w, n,
                 (int32_t)K, 0, 1, traj, 0};
     tu.dbg_bits = cap.bits; tu.dbg_keys = cap.keys; tu.dbg_noise = cap.noise;
-    rc = uha_forward_launch(d, tu, stream);
+    int n_records = w.n_waves;
+    rc = uha_forward_launch(d, tu, stream, &n_records);
     snprintf(g_kernel_name, sizeof(g_kernel_name), "%s", uha_last_kernel_name());
     if (rc != CMCD_OK) return fail(rc, "MCD_CAIS_UHA_sn launch failed%s");
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, stream,
-                       reinterpret_cast<const double*>(ws + w.partials), w.n_waves, out_stats);
+                       reinterpret_cast<const double*>(ws + w.partials), (int32_t)n_records, out_stats);
     CMCD_HIP_CHECK(hipGetLastError());
     return CMCD_OK;
   }

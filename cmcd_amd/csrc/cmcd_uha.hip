@@ -445,11 +445,23 @@ __device__ __forceinline__ void tf_part2(TfState& t) {
 }
 #undef UHA_TF_ROUND
 
-template <int TARGET, int ARCH, int D, int T>
+// HALF: 8 particles per tile (batches of <= 2048 particles: twice the workgroups, on CUs that would otherwise idle).  The
+// state and RNG waves keep 16 columns — columns c and c + 8 carry the SAME particle (same seed: identical values in both)
+// — so a particle has 8 lanes for its target gradient; the MLP waves give every particle 8 lanes instead of 4 (lane (qi,
+// pg, kh, ng) = particle 4 pg + qi, neurons 4 ng + 2 kh + {0, 1} of the wave's 16) and run layer 2 on `4x4x1` (16 blocks of
+// 4 neurons x 4 particles, the activations broadcast from one 16-lane row by the instruction): half the matrix time and
+// half the element-wise work per lane — the overdamped kernel's form (cmcd_coop.hip), same operand table (w2q).
+template <int TARGET, int ARCH, int D, int T, bool HALF>
 __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
   constexpr int HP = 16 * T;
   constexpr int DIN = 2 * D;
   constexpr int Hh = (D + 1) / 2;
+  constexpr int PPT = HALF ? 8 : 16;          // particles per tile
+  constexpr int LP = HALF ? 8 : 4;            // lanes per particle on the state wave
+  constexpr int HQP = HP + 4;                 // HALF: pitch of the [particle][neuron] activation buffer (bank spread)
+  constexpr int NQ = HP / 2;                  // HALF: 4x4x1 steps per pass (two contraction halves side by side)
+  constexpr int RSA = ((HP / 2 + 15) / 16) * 4;   // HALF: activations one row of an MLP wave fetches
+  static_assert(!HALF || D % 2 == 0, "8-particle tiles pair the outputs");
   constexpr bool GEF = ARCH == CMCD_ARCH_GEFFNER;
   constexpr bool RNG_C = Hh > 2;              // normal(G) needs more than the two blocks that ride beside split(H)
   static_assert(Hh <= 6, "normal(G): at most 2 + 4 Threefry blocks per draw");
@@ -466,8 +478,11 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   const int64_t tile = blockIdx.x;
-  const int64_t p = tile * 16 + c;
+  const int cp = HALF ? (c & 7) : c;                 // particle column
+  const int64_t p = tile * PPT + cp;
   const bool valid = p < a.n;
+  const bool own = g == 0 && (!HALF || c < 8);       // the lane that writes its particle's exchange rows and outputs
+  const int sub = HALF ? (lane >> 3) : g;            // state wave: which share of the target's terms this lane owns
   const int K = a.K;
   const int gb = g & 1;
   __syncthreads();                                   // target constants staged
@@ -485,6 +500,111 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
 
   // =========================================================================================== MLP waves
   if (wv < T) {
+    if constexpr (HALF) {
+      const int ng = g, kh = (lane >> 3) & 1;
+      const int nb = 16 * wv + 4 * ng + 2 * kh;        // first of this lane's two hidden units
+      float w1[DIN][2], w3[D][2], aq[NQ], b2p[2];
+#pragma unroll
+      for (int j = 0; j < DIN; ++j)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) w1[j][r] = a.ws[a.w.w1z + j * HP + nb + r];
+#pragma unroll
+      for (int j = 0; j < D; ++j)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) w3[j][r] = a.ws[a.w.w3t + j * HP + nb + r];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) aq[q] = a.ws[a.w.w2q + (int64_t)(wv * NQ + q) * 64 + lane];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) b2p[r] = a.ws[a.w.b2 + nb + r];
+      const float* bias1 = a.ws + a.w.bias1;
+      const float* utab = a.ws + a.w.utab;
+      float2 brow_n = *reinterpret_cast<const float2*>(bias1 + nb), urow_n = {0.f, 0.f};
+      if (GEF) urow_n = *reinterpret_cast<const float2*>(utab + nb);
+      float* const my_h = hbuf + cp * HQP + nb;
+      const float* const rd_h = hbuf + cp * HQP + (HP / 2) * kh + RSA * ng;
+      uha_lds_barrier();                             // gen_0 and the first network input published
+      uha_lds_barrier();                             // deviates of bridge 0 published
+      USTAMP_START();
+      for (int i = 0; i < K; ++i) {
+        const float2 brow = brow_n, urow = urow_n;
+        if (i + 1 < K) {
+          brow_n = *reinterpret_cast<const float2*>(bias1 + (int64_t)(i + 1) * HP + nb);
+          if (GEF) urow_n = *reinterpret_cast<const float2*>(utab + (int64_t)(i + 1) * HP + nb);
+        }
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+          // -------------------------------------------------------------- interval 1
+          float h[2];
+          {
+            float x[DIN];
+#pragma unroll
+            for (int j = 0; j < DIN; ++j) x[j] = xin[cp * DIN + j];
+            float pre[2] = {brow.x, brow.y};
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+              for (int j = 0; j < DIN; ++j) pre[r] = fmaf(x[j], w1[j][r], pre[r]);
+            if (!GEF) {
+              h[0] = gelu_fast(pre[0]); h[1] = gelu_fast(pre[1]);
+            } else {
+              float u[2] = {urow.x, urow.y};
+#pragma unroll
+              for (int r = 0; r < 2; ++r) {
+                if (nb + r < DIN) u[r] = xin[cp * DIN + nb + r];   // the first 2 D entries of u are [z; rho] themselves
+                h[r] = u[r] + softplus(pre[r]);
+              }
+            }
+            *reinterpret_cast<float2*>(my_h) = float2{h[0], h[1]};
+          }
+          USTAMP(pass * 6 + 0);
+          uha_lds_barrier();
+          USTAMP(pass * 6 + 1);
+          // -------------------------------------------------------------- interval 2
+          {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            f32x4 hb[RSA / 4];
+#pragma unroll
+            for (int q = 0; q < RSA / 4; ++q) hb[q] = *reinterpret_cast<const f32x4*>(rd_h + 4 * q);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int sq = 0; sq < NQ; ++sq) {
+              const int row = sq / RSA, t = sq % RSA;
+              const float bv = hb[t / 4][t % 4];
+              f32x4& ac = (sq & 1) ? acc1 : acc;
+              if (row == 0) ac = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[sq], bv, ac, 0, 0, 4);
+              else if (row == 1) ac = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[sq], bv, ac, 0, 0, 5);
+              else if (row == 2) ac = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[sq], bv, ac, 0, 0, 6);
+              else ac = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[sq], bv, ac, 0, 0, 7);
+            }
+            acc += acc1;
+            // the two halves of the contraction sit in lanes l and l ^ 8; lane kh keeps neurons 2 kh + {0, 1} of its group
+            float av[2], h2[2];
+            av[0] = ((kh ? acc[2] : acc[0]) + xor8(kh ? acc[0] : acc[2])) + b2p[0];
+            av[1] = ((kh ? acc[3] : acc[1]) + xor8(kh ? acc[1] : acc[3])) + b2p[1];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) h2[r] = GEF ? h[r] + softplus(av[r]) : gelu_fast(av[r]);
+            // outputs in pairs (j, j + 1): lane kh = 0 collects both halves of output j, lane kh = 1 both of output j + 1
+#pragma unroll
+            for (int j = 0; j < D; j += 2) {
+              const float p0 = h2[0] * w3[j][0] + h2[1] * w3[j][1];
+              const float p1 = h2[0] * w3[j + 1][0] + h2[1] * w3[j + 1][1];
+              float pj = (kh ? p1 : p0) + xor8(kh ? p0 : p1);
+              pj = group_sum(pj);
+              if (ng == 0) part[(wv * 16 + cp) * D + j + kh] = pj;
+            }
+          }
+          USTAMP(pass * 6 + 2);
+          uha_lds_barrier();
+          USTAMP(pass * 6 + 3);
+          if (pass == 0) {
+            uha_lds_barrier();                       // the state wave forms rho' from the partials
+            USTAMP(pass * 6 + 5);
+          }
+        }
+      }
+      USTAMP_END();
+      return;
+    }
     float w1[DIN][4], w3[D][4];
     f32x4 afrag[T];
     const int nb = 16 * wv + 4 * g;                  // first of this lane's four hidden units
@@ -614,7 +734,7 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
     // one random word -> deviate `idx` of bridge ib
     auto put = [&](int ib, int idx, uint32_t y) {
       const float nv = bits_to_normal(y);
-      nzb[((ib & 1) * 16 + c) * D + idx] = nv;
+      nzb[((ib & 1) * 16 + cp) * D + idx] = nv;      // (HALF: the twin columns write the same value)
       if (a.dbg_bits && valid) {
         const int64_t o = ((int64_t)(ib + 2) * a.n + p) * D + idx;
         a.dbg_bits[o] = y;
@@ -684,7 +804,7 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
   float* tz = a.traj;
   float* trho = a.traj ? a.traj + (int64_t)(K + 1) * a.n * D : nullptr;
   float* trhop = a.traj ? a.traj + (int64_t)(2 * K + 2) * a.n * D : nullptr;
-  const bool keep = a.traj && valid && g == 0;
+  const bool keep = a.traj && valid && own;
   constexpr float clipv = 1e2f;
   const float gamma = a.params[a.lay.gamma];
   const float factor = a.ws[a.w.b3 + 15];
@@ -725,7 +845,7 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
     threefry2x32(p0, p1, x0, x1);
     rows01(x1, k0, k1);
     if (g == 0) { keyb[2 * c] = k0; keyb[2 * c + 1] = k1; }
-    if (a.dbg_keys && valid && g == 0) {
+    if (a.dbg_keys && valid && own) {
       a.dbg_keys[p * 2] = k0;
       a.dbg_keys[p * 2 + 1] = k1;
     }
@@ -745,19 +865,23 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
         trho[p * D + j] = rho[j];
       }
     }
-    Tg::eval(z, g, lds_tgt, logp, gp);
+    if (own) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) { xin[cp * DIN + j] = z[j]; xin[cp * DIN + D + j] = rho[j]; }
+    }
+  }
+  typename Tg::Means means;
+  Tg::template load_means<LP>(sub, lds_tgt, means);
+  {
+    typename Tg::State t0;
+    Tg::template pass1r<LP>(z, sub, lds_tgt, means, t0);
+    Tg::template pass2<LP>(z, sub, lds_tgt, t0, logp, gp);
 #pragma unroll
     for (int j = 0; j < D; ++j) {
       gp[j] = fminf(fmaxf(gp[j], -clipv), clipv);
       gq[j] = -(z[j] - qmean[j]) * qiv[j];
     }
-    if (g == 0) {
-#pragma unroll
-      for (int j = 0; j < D; ++j) { xin[c * DIN + j] = z[j]; xin[c * DIN + D + j] = rho[j]; }
-    }
   }
-  typename Tg::Means means;
-  Tg::template load_means<4>(g, lds_tgt, means);
   const bool tfast = Tg::kHasFast && Tg::is_fast(means);   // wave-uniform: the register-resident form of the target (many_gmm, 40 modes)
   // the scalars of a bridge (mcd_under_lp_a_cais.py: eta_aux = gamma eps; the refresh's scale sqrt(2 eta))
   struct Sc { float beta, eps, eta, sig, inv2s2, cst, ome; };
@@ -777,7 +901,7 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
     for (int j = 0; j < D; ++j) {
       float o = b3r[j];
 #pragma unroll
-      for (int v = 0; v < T; ++v) o += part[(v * 16 + c) * D + j];
+      for (int v = 0; v < T; ++v) o += part[(v * 16 + cp) * D + j];
       s[j] = GEF ? o * factor : fminf(fmaxf(o, -1e4f), 1e4f);
     }
   };
@@ -807,7 +931,7 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
     float rome[D], snz[D], huf[D], mf[D], rhop[D], rpp[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) {
-      const float nzv = nzb[((i & 1) * 16 + c) * D + j];
+      const float nzv = nzb[((i & 1) * 16 + cp) * D + j];
       rome[j] = rho[j] * q.ome;
       snz[j] = q.sig * nzv;
       const float uf = -1.0f * (q.beta * gp[j] + (1.0f - q.beta) * gq[j]);
@@ -824,9 +948,9 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
         mf[j] = rome[j] - 2.0f * q.eta * s[j];
         rhop[j] = mf[j] + snz[j];
       }
-      if (g == 0) {
+      if (own) {
 #pragma unroll
-        for (int j = 0; j < D; ++j) xin[c * DIN + D + j] = rhop[j];      // [z; rho']: the z half stays
+        for (int j = 0; j < D; ++j) xin[cp * DIN + D + j] = rhop[j];     // [z; rho']: the z half stays
       }
     }
     USTAMP(4); uha_lds_barrier(); USTAMP(5);
@@ -845,22 +969,22 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
     }
     cl_eta = q.eta; cl_inv2s2 = q.inv2s2; cl_cst = q.cst; cl_fk = fk_lp;
     typename Tg::State tst;
-    if (tfast) Tg::template pass1f<4>(z, g, means, tst);
-    else Tg::template pass1r<4>(z, g, lds_tgt, means, tst);
+    if (tfast) Tg::template pass1f<LP>(z, sub, means, tst);
+    else Tg::template pass1r<LP>(z, sub, lds_tgt, means, tst);
     USTAMP(6); uha_lds_barrier(); USTAMP(7);
     // ------------------------------------------------------------------ pass 1, matrix interval: exponential pass, second half
     //                                                                    step -> the NEXT bridge's input (it does not need s)
-    if (tfast) Tg::template pass2f<4>(z, g, means, tst, logp, gp);
-    else Tg::template pass2<4>(z, g, lds_tgt, tst, logp, gp);
+    if (tfast) Tg::template pass2f<LP>(z, sub, means, tst, logp, gp);
+    else Tg::template pass2<LP>(z, sub, lds_tgt, tst, logp, gp);
 #pragma unroll
     for (int j = 0; j < D; ++j) {
       gp[j] = fminf(fmaxf(gp[j], -clipv), clipv);
       const float ub = -1.0f * (q.beta * gp[j] + (1.0f - q.beta) * gq[j]);
       rho[j] = rpp[j] - q.eps * ub / 2.0f;
     }
-    if (g == 0) {
+    if (own) {
 #pragma unroll
-      for (int j = 0; j < D; ++j) { xin[c * DIN + j] = z[j]; xin[c * DIN + D + j] = rho[j]; }
+      for (int j = 0; j < D; ++j) { xin[cp * DIN + j] = z[j]; xin[cp * DIN + D + j] = rho[j]; }
     }
     if (keep) {
 #pragma unroll
@@ -882,12 +1006,12 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
   }
   w += logp;
   const float loss = -w;
-  if (valid && g == 0) {
+  if (valid && own) {
     a.out_loss[p] = loss;
 #pragma unroll
     for (int j = 0; j < D; ++j) a.out_z[p * D + j] = z[j];
   }
-  const bool use = valid && g == 0;
+  const bool use = valid && own;
   double cnt = (use && isfinite(loss)) ? 1.0 : 0.0;
   double sm = use ? (double)loss : 0.0;
   double sq = use ? (double)loss * (double)loss : 0.0;
@@ -940,29 +1064,35 @@ static uha_fn uha_pick(const cmcd_desc& d, int T) {
   return nullptr;
 }
 
-template <int TARGET, int ARCH, int D>
+template <int TARGET, int ARCH, int D, bool HALF>
 static uha_fn uha_coop_pick_T(int T) {
   switch (T) {
-    case 2: return uha_coop_kernel<TARGET, ARCH, D, 2>;
-    case 4: return uha_coop_kernel<TARGET, ARCH, D, 4>;
-    case 5: return uha_coop_kernel<TARGET, ARCH, D, 5>;
-    case 9: return uha_coop_kernel<TARGET, ARCH, D, 9>;
+    case 2: return uha_coop_kernel<TARGET, ARCH, D, 2, HALF>;
+    case 4: return uha_coop_kernel<TARGET, ARCH, D, 4, HALF>;
+    case 5: return uha_coop_kernel<TARGET, ARCH, D, 5, HALF>;
+    case 9:
+      if constexpr (HALF) return nullptr;   // (72 resident 4x4x1 operands + the d = 10 first layer: no 8-particle instance)
+      else return uha_coop_kernel<TARGET, ARCH, D, 9, false>;
     default: return nullptr;
   }
 }
 
-static uha_fn uha_coop_pick(const cmcd_desc& d, int T) {
+template <bool HALF>
+static uha_fn uha_coop_pick_h(const cmcd_desc& d, int T) {
   if (d.arch == CMCD_ARCH_DDS) {
     if (T != 4) return nullptr;
-    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2) return uha_coop_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_DDS, 2, 4>;
-    if (d.target == CMCD_TARGET_GMM && d.dim == 2) return uha_coop_kernel<CMCD_TARGET_GMM, CMCD_ARCH_DDS, 2, 4>;
-    if (d.target == CMCD_TARGET_FUNNEL && d.dim == 10) return uha_coop_kernel<CMCD_TARGET_FUNNEL, CMCD_ARCH_DDS, 10, 4>;
+    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2) return uha_coop_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_DDS, 2, 4, HALF>;
+    if (d.target == CMCD_TARGET_GMM && d.dim == 2) return uha_coop_kernel<CMCD_TARGET_GMM, CMCD_ARCH_DDS, 2, 4, HALF>;
+    if (d.target == CMCD_TARGET_FUNNEL && d.dim == 10) return uha_coop_kernel<CMCD_TARGET_FUNNEL, CMCD_ARCH_DDS, 10, 4, HALF>;
     return nullptr;
   }
-  if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2) return uha_coop_pick_T<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2>(T);
-  if (d.target == CMCD_TARGET_GMM && d.dim == 2) return uha_coop_pick_T<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER, 2>(T);
-  if (d.target == CMCD_TARGET_FUNNEL && d.dim == 10) return uha_coop_pick_T<CMCD_TARGET_FUNNEL, CMCD_ARCH_GEFFNER, 10>(T);
+  if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2) return uha_coop_pick_T<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, HALF>(T);
+  if (d.target == CMCD_TARGET_GMM && d.dim == 2) return uha_coop_pick_T<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER, 2, HALF>(T);
+  if (d.target == CMCD_TARGET_FUNNEL && d.dim == 10) return uha_coop_pick_T<CMCD_TARGET_FUNNEL, CMCD_ARCH_GEFFNER, 10, HALF>(T);
   return nullptr;
+}
+static uha_fn uha_coop_pick(const cmcd_desc& d, int T, bool half) {
+  return half ? uha_coop_pick_h<true>(d, T) : uha_coop_pick_h<false>(d, T);
 }
 
 bool uha_available(const cmcd_desc& d, int T) { return uha_pick(d, T) != nullptr; }
@@ -979,20 +1109,27 @@ const char* uha_last_kernel_name() { return g_uha_kernel_name; }
 
 int64_t uha_traj_floats(const cmcd_desc& d, int64_t n) { return (int64_t)(3 * d.nbridges + 2) * n * d.dim; }
 
-int uha_forward_launch(const cmcd_desc& d, const TrajArgs& ta, void* stream_) {
+int uha_forward_launch(const cmcd_desc& d, const TrajArgs& ta, void* stream_, int* n_records) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const WsLayout& w = ta.w;
   uha_fn fn = uha_pick(d, w.T);
   if (!fn) return CMCD_ERR_UNSUPPORTED;
   const int64_t tiles = w.n_waves;
-  // kernel variant (desc.reserved, as for the overdamped kernels): 0 auto, 1 wave per tile, 2 - 4 cooperative
-  uha_fn cfn = uha_coop_pick(d, w.T);
+  *n_records = w.n_waves;
+  // kernel variant (desc.reserved, as for the overdamped kernels): 0 auto, 1 wave per tile, 2 cooperative, 3 cooperative on
+  // 16-particle tiles, 4 cooperative on 8-particle tiles (auto: while those still get a CU each, n <= 8 x 256)
   const bool forced = d.reserved >= 2 && d.reserved <= 4;
+  const bool half_ok = uha_coop_pick(d, w.T, true) != nullptr;
+  if (d.reserved == 4 && !half_ok) return CMCD_ERR_UNSUPPORTED;
+  const bool half = d.reserved == 4 || (d.reserved != 3 && half_ok && ta.n <= 8 * 256);
+  uha_fn cfn = uha_coop_pick(d, w.T, half);
   if (forced && !cfn) return CMCD_ERR_UNSUPPORTED;
   if (cfn && (forced || (d.reserved != 1 && tiles <= uha_coop_max_tiles(d)))) {
     const size_t cl = size_t(w.T * 256 + w.T * 16 * d.dim + 16 * 2 * d.dim + 2 * 16 * d.dim + 32 + w.tgt_floats) * 4;
-    g_uha_kernel_name = "uha_coop_kernel";
-    hipLaunchKernelGGL(cfn, dim3((unsigned)tiles), dim3(64 * (w.T + 2)), cl, stream, ta);
+    const int64_t wgs = half ? (ta.n + 7) / 8 : tiles;
+    g_uha_kernel_name = half ? "uha_coop_kernel<8-particle tiles>" : "uha_coop_kernel<16-particle tiles>";
+    *n_records = (int)wgs;
+    hipLaunchKernelGGL(cfn, dim3((unsigned)wgs), dim3(64 * (w.T + 2)), cl, stream, ta);
     return hipGetLastError() == hipSuccess ? CMCD_OK : CMCD_ERR_HIP;
   }
   g_uha_kernel_name = "uha_traj_kernel";

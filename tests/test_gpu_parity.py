@@ -146,6 +146,23 @@ def test_network_widths_between_the_instances_run_zero_padded(hip_lib, param_set
     compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"{model} emb_dim={emb_dim}")
 
 
+@pytest.mark.parametrize("variant", [2, 3, 4])
+@pytest.mark.parametrize("emb_dim", [127, 128, 129, 130, 131, 136])
+def test_widths_around_the_132_wide_net_on_the_cooperative_kernels(hip_lib, param_set, monkeypatch, emb_dim, variant):
+    """129 ... 132 hidden units (emb_dim 127 ... 130, d = 2) run the ninth MLP wave of the 8-particle tiling in its
+    4-neuron form (eight contraction slices, cmcd_common.h coop_tail4), with 1 ... 4 real neurons; 133 and 138 units run it
+    in the general form; the 16-particle tiling has only the general form.  Same numbers as the oracle either way."""
+    monkeypatch.setattr(mcdbm, "KERNEL_VARIANT", variant)
+    b = synthetic.build("many_gmm_var_n16000_k256", device="cuda", emb_dim=emb_dim, nbridges=9, boundmode="MCD_CAIS_sn")
+    seeds = synthetic.parity_seeds(203)            # ragged last tile on both tilings
+    mean, (losses, z) = mcdbm.compute_bound(torch.from_numpy(seeds).cuda(), b["params_flat"], b["unflatten"],
+                                            b["params_fixed"], b["target"], eps_schedule=b["eps_schedule"],
+                                            grad_clipping=b["grad_clipping"])
+    torch.cuda.synchronize()
+    l_ref, z_ref = run_oracle(b, seeds, dtype=np.float64)
+    compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"many_gmm emb_dim={emb_dim} variant={variant}")
+
+
 @pytest.mark.parametrize("tag", ["gmm_k8", "funnel_k64", "many_gmm_dds_k256", "many_gmm_var_k32", "dense_gmm_k8",
                                  "dense_funnel_k64", "dense_many_gmm_dds_k256", "dense_many_gmm_var_k32"])
 def test_bound_matches_committed_golden_vectors(hip_lib, variant, tag):

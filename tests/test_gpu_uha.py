@@ -31,15 +31,29 @@ FWD_CASES = [
 ]
 
 
-# 1 = one wave per tile (uha_traj_kernel), 2 = CU-cooperative (uha_coop_kernel: T MLP waves + state / target wave + RNG wave)
-@pytest.fixture(params=[1, 2], ids=["wave_per_tile", "cooperative"])
+# 1 = one wave per tile (uha_traj_kernel); CU-cooperative (uha_coop_kernel: T MLP waves + state / target wave + RNG wave) on
+# 3 = 16-particle tiles, 4 = 8-particle tiles (4x4x1 matrix instructions, 8 lanes per particle on the state wave)
+KERNEL_NAMES = {1: "uha_traj_kernel", 3: "uha_coop_kernel<16-particle tiles>", 4: "uha_coop_kernel<8-particle tiles>"}
+
+
+@pytest.fixture(params=[1, 3, 4], ids=["wave_per_tile", "cooperative16", "cooperative8"])
 def variant(request, monkeypatch):
     monkeypatch.setattr(mcdbm, "KERNEL_VARIANT", request.param)
     return request.param
 
 
+def _skip_without_instance(variant, name, over):
+    if variant != 4 or over.get("nn_arch") == "dds" or name.endswith("_dds"):
+        return
+    dim = 10 if name.startswith("funnel") else 2
+    emb = over.get("emb_dim", {"gmm": 20, "fun": 48, "man": 130}[name[:3]])
+    if 2 * dim + emb > 80:
+        pytest.skip("the 9-tile nets (e.g. 2 x 2 + 130 = 134 wide) have no 8-particle-tile instance")
+
+
 @pytest.mark.parametrize("name,n,over", FWD_CASES)
 def test_bound_matches_oracle(hip_lib, param_set, variant, name, n, over):
+    _skip_without_instance(variant, name, over)
     b = synthetic.build(name, device="cuda", boundmode=MODE, **over)
     seeds = synthetic.parity_seeds(n)
     mean, (losses, z) = mcdbm.compute_bound(torch.from_numpy(seeds).cuda(), b["params_flat"], b["unflatten"],
@@ -49,7 +63,7 @@ def test_bound_matches_oracle(hip_lib, param_set, variant, name, n, over):
     l_ref, z_ref = run_oracle(b, seeds, dtype=np.float64)
     rep = compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"UHA {name} n={n}")
     print(name, n, over, rep)
-    assert _lib.last_kernel_name() == ("uha_traj_kernel" if variant == 1 else "uha_coop_kernel")
+    assert _lib.last_kernel_name() == KERNEL_NAMES[variant]
     want = np.mean(losses.double().cpu().numpy())
     if np.isfinite(want):
         assert abs(float(mean) - want) <= 1e-5 * max(1.0, abs(want))
@@ -128,8 +142,9 @@ GRAD_CASES = [
 
 @pytest.mark.parametrize("name,n,over", GRAD_CASES)
 def test_reparameterised_gradient_matches_autograd(hip_lib, param_set, variant, name, n, over):
-    if variant == 1 and GRAD_CASES.index((name, n, over)) not in (0, 2, 4, 7):
-        pytest.skip("the wave-per-tile forward keeps the trajectory for four representative cases (suite time)")
+    _skip_without_instance(variant, name, over)
+    if variant != 3 and GRAD_CASES.index((name, n, over)) not in (0, 2, 4, 7):
+        pytest.skip("the wave-per-tile and 8-particle forwards keep the trajectory for four representative cases (suite time)")
     """jax.grad(compute_bound, 1) (/root/reference/src/main.py:174-176) through mcd_under_lp_a_cais.py:42-88: every leaf of
     params_flat (network, eps, gamma, q, mgridref_y) against torch-autograd through the float64 restatement."""
     from test_gpu_grad import _compare, oracle_grad_flat

@@ -1,0 +1,29 @@
+"""Builds an A / B variant of the library next to the product one: python tools/probes/build_variant.py NAME -DFLAG [...]
+-> cmcd_amd/libcmcd_hip_NAME.so (git-ignored, travels with the gpurun snapshot; select it with CMCD_LIB_PATH)."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from cmcd_amd import build as B  # noqa: E402
+
+name, flags = sys.argv[1], sys.argv[2:]
+obj = os.path.join("/tmp", "cmcd_variant_" + name)
+os.makedirs(obj, exist_ok=True)
+common = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"),
+          "-I", B.CSRC, "-Wno-format-security"] + flags
+
+
+def one(src):
+    o = os.path.join(obj, src.replace(".hip", ".o"))
+    subprocess.run(common + B.EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(B.CSRC, src), "-o", o], check=True)
+    return o
+
+
+with ThreadPoolExecutor(max_workers=6) as ex:
+    objs = list(ex.map(one, B.SOURCES))
+lib = os.path.join(ROOT, "cmcd_amd", "libcmcd_hip_%s.so" % name)
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, check=True)
+print(lib)
