@@ -542,6 +542,28 @@ def main():
                                "achieved": ns * K * f_alg / ks / 1e12,
                                "frac": ns * K * f_alg / ks / 1e12 / PEAK_FP32_TFLOPS}
 
+    if rank == 0 and world == 1 and default_workload and not args.no_legs:
+        # The reference's 2nd-order mode (config.boundmode = "MCD_CAIS_UHA_sn") on the SAME batch shape:
+        # an extra measured line, not the headline (BASELINE.json's metric is quoted on MCD_CAIS_sn).  Two network
+        # evaluations per bridge on concat(z, rho); unit = the headline's (particles x bridge steps per second).
+        from cmcd_amd import mcdboundingmachine as _m
+        ub = synthetic.build(name, device=device, boundmode="MCD_CAIS_UHA_sn", init_eps=0.2,
+                             init_gamma=2.0, init_sigma=15.0)
+        useeds = torch.from_numpy(synthetic.throughput_seeds(n, stream=0)).to(device)
+        uargs = (useeds, ub["params_flat"], ub["unflatten"], ub["params_fixed"], ub["target"])
+        for _ in range(50):
+            _m.bound_forward(*uargs)
+        torch.cuda.synchronize()
+        ureps = 200
+        tu0 = time.perf_counter()
+        for _ in range(ureps):
+            ur = _m.bound_forward(*uargs)
+        torch.cuda.synchronize()
+        tu = (time.perf_counter() - tu0) / ureps
+        result["second_order"] = {"workload": f"{weak.cfg_name}:MCD_CAIS_UHA_sn", "particles": n, "nbridges": ub["params_fixed"][1],
+                                  "ms_per_step": tu * 1e3, "value": n * ub["params_fixed"][1] / tu, "steps": ureps,
+                                  "kernel": _lib.last_kernel_name(), "n_finite": int(torch.isfinite(ur[0]).sum())}
+
     if cfg["model"] == "lgcp":
         # weight-bandwidth bound: every evaluation streams K^-1 and the three weight matrices
         IN = dim + cfg["emb_dim"]
@@ -549,12 +571,14 @@ def main():
         # measured L2 <-> fabric bytes of the three GEMM launches of one evaluation (tools/probes/pmc_hbm_lgcp.sh: separate
         # rocprofv3 --pmc passes, FETCH_SIZE doubled per the gfx950 note), x (K + 1) evaluations x passes
         traffic = None
-        try:   # only a summary measured on this build of the kernels counts (kernel_sources_sha)
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc", "lgcp_summary.json")))
-            if pm.get("kernel_sources_sha") == kernel_sources_sha() and dim == 1600 and IN == 1620:
-                traffic = sum(v["hbm_bytes_per_launch"] for v in pm.values() if isinstance(v, dict)) * (K + 1) * -(-n // 32)
-        except Exception:
-            pass
+        for rnd in ("r03_pmc", "r02_pmc"):
+            try:   # only a summary measured on this build of the kernels counts (kernel_sources_sha)
+                pm = json.load(open(os.path.join(ROOT, "profiles", rnd, "lgcp_summary.json")))
+                if pm.get("kernel_sources_sha") == kernel_sources_sha() and dim == 1600 and IN == 1620:
+                    traffic = sum(v["hbm_bytes_per_launch"] for v in pm.values() if isinstance(v, dict)) * (K + 1) * -(-n // 32)
+                    break
+            except Exception:
+                pass
         result["roofline"].update({"bound": "hbm", "achieved": wbytes / kern_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                    "frac": wbytes / kern_s / 1e9 / PEAK_HBM_GBS, "traffic": traffic,
                                    "traffic_unit": "bytes/call (PMC)", "weight_bytes_per_call": wbytes})

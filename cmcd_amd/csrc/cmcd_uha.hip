@@ -797,7 +797,9 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
 
   // =========================================================================================== state wave
   // (equal issue priorities: one or two s_setprio levels for this wave and / or the RNG wave measured 0.444 - 0.466 ms
-  //  against 0.426 at the named shape, r03 — the MLP waves' chain is the one the bridge waits for in four of five intervals)
+  //  against 0.426 at the named shape on 16-particle tiles, 0.336 - 0.354 against 0.323 on 8-particle tiles; two extra TARGET
+  //  waves taking grad log p(z') off this wave on 8-particle tiles: 0.343 against 0.3225 ms — the exponential pass is a
+  //  dependent chain that runs no faster on 16 lanes per particle, profiles/r03_uha_target_wave_pair_rejected.txt)
   // q, gamma, initial draws (the prologue of uha_traj_kernel)
   float qmean[D], qstd[D], qiv[D], z[D], rho[D], gp[D], gq[D];
   float w = 0.f, logp = 0.f;

@@ -37,6 +37,10 @@ def test_bench_single_gpu_line(hip_lib):
     c4 = legs["strong_sharded_cfg4"]
     assert c4["workload"] == "many_gmm_var_n16000_k256" and c4["global_particles"] == 16000 and c4["value"] > 1e8
     assert c4["train_step_ms"] > c4["ms_per_step"]
+    # the reference's 2nd-order mode on the same batch shape rides along as an extra measured line
+    so = r["second_order"]
+    assert so["workload"] == "many_gmm_n2000_k256_dds:MCD_CAIS_UHA_sn" and so["value"] > 1e8 and so["particles"] == 2000
+    assert so["kernel"] == "uha_coop_kernel<8-particle tiles>" and so["n_finite"] > 1000
 
 
 def test_bench_two_ranks_share_the_gpu(hip_lib):
