@@ -131,6 +131,7 @@ int grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, c
                 bool bptt, bool item, const float* traj, float* item_ws, float* gws, float* grad, void* stream);
 bool bptt_available(const cmcd_desc& d, int T);
 bool grad_item_mode(const cmcd_desc& d, int T, int64_t n);
+int get_grad_item_override();
 void set_grad_item_override(int v);   // -1: measured rule; 0 / 1: whole chains / work items (process-wide; diagnostics)
 int64_t bptt_item_floats(const cmcd_desc& d, int64_t n);
 

@@ -1382,6 +1382,7 @@ bool bptt_available(const cmcd_desc& d, int T) { return pick_grad(d, T, true) !=
 // CMCD_GRAD_ITEM from the environment), -1 returns to the measured rule.  No getenv on the per-call path.
 static int grad_item_override = -1;   // process-wide (diagnostic)
 void set_grad_item_override(int v) { grad_item_override = v; }
+int get_grad_item_override() { return grad_item_override; }
 bool grad_item_mode(const cmcd_desc& d, int T, int64_t n) {
   if (pick_grad(d, T, false, true) == nullptr) return false;
   if (grad_item_override >= 0) return grad_item_override != 0;

@@ -29,11 +29,30 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "cmcd_common.h"
 #include "cmcd_device.h"
 #include "cmcd_hip.h"
 
 namespace cmcd {
+
+// The opt-in for dynamic LDS once per (function, device) and size, not on every call (the work-item gradient path launches
+// three kernels with opted-in LDS per gradient; the attribute call costs host microseconds each time).
+static bool ensure_dynamic_lds(const void* fn, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, size_t> raised;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  std::lock_guard<std::mutex> lock(mu);
+  auto& have = raised[std::make_pair(fn, dev)];
+  if (have >= bytes) return true;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
+  have = bytes;
+  return true;
+}
 
 // d standard normals from key (ka, kb): jax.random.normal(key, (D,)) — block j encrypts (j, Hh + j); the blocks are dealt
 // to the four rows of the wave.  `stage`: row of the capture buffers (tests), or -1.
@@ -1141,9 +1160,7 @@ int uha_forward_launch(const cmcd_desc& d, const TrajArgs& ta, void* stream_, in
   const int64_t per_cu = (160 * 1024) / (int64_t)lds_bytes;
   int nw = tiles <= 1024 ? 1 : (tiles <= 8192 ? 4 : 8);
   if (per_cu < 2 && tiles > 256) nw = tiles <= 1024 ? 4 : 8;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)lds_bytes) != hipSuccess)
-    return CMCD_ERR_HIP;
+  if (!ensure_dynamic_lds(reinterpret_cast<const void*>(fn), lds_bytes)) return CMCD_ERR_HIP;
   const unsigned blocks = unsigned((tiles + nw - 1) / nw);
   hipLaunchKernelGGL(fn, dim3(blocks), dim3(64 * nw), lds_bytes, stream, ta);
   return hipGetLastError() == hipSuccess ? CMCD_OK : CMCD_ERR_HIP;
@@ -1189,14 +1206,20 @@ struct UhaGradArgs {
   int32_t K, nquads;
   float omega;
   int64_t o_S, o_S2, o_gbeta, o_geps, slab_stride;
+  // small-batch path (work items over chain chunks; 0 / nullptr: one sweep over the whole chain)
+  int32_t nchunks = 1, chunk_len = 1 << 30;
+  const float* xbuf = nullptr;   // [K+1][3 D][n]  adjoint state (lz, lr, arpp) entering point e   (uha_scan_kernel)
+  float* jac = nullptr;          // [K][3 D^2 + 3 D][n]  Jacobian launch output
+  float* xdump = nullptr;        // tests: the sweep writes the state it carries in the xbuf layout
 };
 
 __device__ __forceinline__ int uha_sw(int f, int p) { return f * 16 + (p ^ (f & 15)); }
 
-template <int TARGET, int ARCH, int D, int T, int NW, bool WGLOBAL>
+template <int TARGET, int ARCH, int D, int T, int NW, bool WGLOBAL, bool JAC = false>
 __global__ __launch_bounds__(64 * NW) void uha_grad_kernel(UhaGradArgs a) {
   constexpr int HP = 16 * T;
   constexpr int DIN = 2 * D;
+  constexpr int S_JAC = 3 * D * D + 3 * D;     // floats per (point, particle) of the Jacobian launch, see uha_scan_kernel
   constexpr int XT = (DIN + 15) / 16;          // 16-row tiles of the staged network input
   constexpr bool GEF = ARCH == CMCD_ARCH_GEFFNER;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1288,7 +1311,15 @@ __global__ __launch_bounds__(64 * NW) void uha_grad_kernel(UhaGradArgs a) {
 #pragma unroll
   for (int j = 0; j < D; ++j) { gmu[j] = 0.f; glam[j] = 0.f; gb3[j] = 0.f; }
 
-  for (int64_t quad = blockIdx.x; quad < a.nquads; quad += gridDim.x) {
+  // Work items: MODE_SWEEP — a quad of tiles x a chunk of the chain (nchunks = 1: the whole chain, adjoints carried from e = K;
+  // else the adjoint state entering the chunk's first point comes from `xbuf`, written by uha_scan_kernel);  MODE_JAC — a quad
+  // x ONE point / bridge pair: no parameter contraction, the pieces of the affine adjoint map are written to `jac`.
+  const int64_t nwork = JAC ? (int64_t)a.nquads * K : (int64_t)a.nquads * a.nchunks;
+  for (int64_t work = blockIdx.x; work < nwork; work += gridDim.x) {
+    const int64_t quad = JAC ? work / K : work / a.nchunks;
+    const int ch = JAC ? 0 : (int)(work % a.nchunks);
+    const int e_hi = JAC ? K - (int)(work % K) : K - ch * a.chunk_len;
+    const int e_lo = JAC ? e_hi : (e_hi - a.chunk_len + 1 > 0 ? e_hi - a.chunk_len + 1 : 0);
     const int64_t tile = quad * NW + wv;
     const int64_t p = tile * 16 + c;
     const bool valid = p < a.n;
@@ -1304,9 +1335,27 @@ __global__ __launch_bounds__(64 * NW) void uha_grad_kernel(UhaGradArgs a) {
       arpp_c[j] = 0.f;
       znext[j] = 0.f;
     }
+    if (!JAC && e_hi < K) {          // the adjoint state entering point e_hi (uha_scan_kernel)
+      const float* xs = a.xbuf + (int64_t)e_hi * 3 * D * a.n + pc;
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        lz[j] = valid ? xs[(int64_t)j * a.n] : 0.f;
+        lr[j] = valid ? xs[(int64_t)(D + j) * a.n] : 0.f;
+        arpp_c[j] = valid ? xs[(int64_t)(2 * D + j) * a.n] : 0.f;
+      }
+    }
 
-    for (int e = K; e >= 0; --e) {
+    for (int e = e_hi; e >= e_lo; --e) {
       asm volatile("" ::: "memory");   // LDS contents are loop-invariant: keep the weights in LDS, not in hoisted registers
+      if (!JAC && a.xdump && valid && g == 0) {   // tests: the adjoint state entering point e, as the sweep carries it
+        float* xs = a.xdump + (int64_t)e * 3 * D * a.n + p;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          xs[(int64_t)j * a.n] = lz[j];
+          xs[(int64_t)(D + j) * a.n] = lr[j];
+          xs[(int64_t)(2 * D + j) * a.n] = arpp_c[j];
+        }
+      }
       // ---------------------------------------------------------------- point e
       float z[D], gp[D], gq[D], gpraw[D], logp;
       constexpr int HN = Target<TARGET, D>::HN;
@@ -1323,64 +1372,85 @@ __global__ __launch_bounds__(64 * NW) void uha_grad_kernel(UhaGradArgs a) {
         a_gp[j] = 0.f;
         a_gq[j] = 0.f;
       }
-      if (e >= 1) {   // ub of bridge e - 1:  rho_e = rho'' - eps ub / 2
-        const float be = a.ws[a.w.beta + e - 1], ee = a.ws[a.w.eps + e - 1];
-        float sb = 0.f, se = 0.f;
+      float* jrow = nullptr;           // JAC: this particle's item (e), entries strided by n
+      if constexpr (JAC) {
+        jrow = a.jac + (int64_t)(e - 1) * S_JAC * a.n + pc;
+        // P = H_p(z_e) diag(clip mask), column k;  c0 = the direct term of point e (e = K: - omega grad log p(z_K))
 #pragma unroll
-        for (int j = 0; j < D; ++j) {
-          const float adj = -0.5f * ee * lr[j];
-          const float ub = -1.0f * (be * gp[j] + (1.0f - be) * gq[j]);
-          a_gp[j] -= be * adj;
-          a_gq[j] -= (1.0f - be) * adj;
-          sb -= (gp[j] - gq[j]) * adj;
-          se -= 0.5f * ub * lr[j];
-        }
-        const float tb = row_sum16(sb), te = row_sum16(se);
-        if (lane == 0) {
-          atomicAdd(a.gtab + a.o_gbeta + (e - 1), tb);
-          atomicAdd(a.gtab + a.o_geps + (e - 1), te);
-        }
-      }
-      if (e <= K - 1) {   // uf of bridge e:  rho'' = rho' - eps uf / 2
-        const float be = a.ws[a.w.beta + e], ee = a.ws[a.w.eps + e];
-        float sb = 0.f, se = 0.f;
+        for (int k = 0; k < D; ++k) {
+          float v[D], hv[D];
 #pragma unroll
-        for (int j = 0; j < D; ++j) {
-          const float adj = -0.5f * ee * arpp_c[j];
-          const float uf = -1.0f * (be * gp[j] + (1.0f - be) * gq[j]);
-          a_gp[j] -= be * adj;
-          a_gq[j] -= (1.0f - be) * adj;
-          sb -= (gp[j] - gq[j]) * adj;
-          se -= 0.5f * uf * arpp_c[j];
-        }
-        const float tb = row_sum16(sb), te = row_sum16(se);
-        if (lane == 0) {
-          atomicAdd(a.gtab + a.o_gbeta + e, tb);
-          atomicAdd(a.gtab + a.o_geps + e, te);
-        }
-      }
-      {
-        float v[D], hv[D];
+          for (int j = 0; j < D; ++j) v[j] = (j == k && fabsf(gpraw[k]) < clipv) ? 1.f : 0.f;
+          Target<TARGET, D>::hvp(hs, z, v, hv);
+          if (valid && g == 0) {
 #pragma unroll
-        for (int j = 0; j < D; ++j) {
-          if (e == K) lz[j] -= om * gpraw[j];                    // + log p(z_K), unclipped   mcdboundingmachine.py:178
-          if (e == 0) lz[j] += om * gq[j];                       // - log q(z_0) in w  ->  + omega log q in L
-          v[j] = fabsf(gpraw[j]) < clipv ? a_gp[j] : 0.f;        // jnp.clip passes no gradient outside its bounds
-          gmu[j] += a_gq[j] * qiv[j];
-          glam[j] += a_gq[j] * (-2.0f * gq[j]);
+            for (int j = 0; j < D; ++j) jrow[(int64_t)(j * D + k) * a.n] = hv[j];
+          }
         }
-        Target<TARGET, D>::hvp(hs, z, v, hv);
+        if (valid && g == 0) {
 #pragma unroll
-        for (int j = 0; j < D; ++j) lz[j] += hv[j] - a_gq[j] * qiv[j];   // H_q = -diag(1 / std^2)
-      }
-      if (e == 0) {   // z_0 = mean + std e0 and the explicit parameters of log q(z_0)
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-          const float dz = z[j] - qmean[j];
-          gmu[j] += lz[j] - om * gq[j];
-          glam[j] += lz[j] * dz + om * (dz * dz * qiv[j] - 1.0f);
+          for (int j = 0; j < D; ++j) jrow[(int64_t)(3 * D * D + j) * a.n] = e == K ? -om * gpraw[j] : 0.f;
         }
-        break;
+      } else {
+        if (e >= 1) {   // ub of bridge e - 1:  rho_e = rho'' - eps ub / 2
+          const float be = a.ws[a.w.beta + e - 1], ee = a.ws[a.w.eps + e - 1];
+          float sb = 0.f, se = 0.f;
+#pragma unroll
+          for (int j = 0; j < D; ++j) {
+            const float adj = -0.5f * ee * lr[j];
+            const float ub = -1.0f * (be * gp[j] + (1.0f - be) * gq[j]);
+            a_gp[j] -= be * adj;
+            a_gq[j] -= (1.0f - be) * adj;
+            sb -= (gp[j] - gq[j]) * adj;
+            se -= 0.5f * ub * lr[j];
+          }
+          const float tb = row_sum16(sb), te = row_sum16(se);
+          if (lane == 0) {
+            atomicAdd(a.gtab + a.o_gbeta + (e - 1), tb);
+            atomicAdd(a.gtab + a.o_geps + (e - 1), te);
+          }
+        }
+        if (e <= K - 1) {   // uf of bridge e:  rho'' = rho' - eps uf / 2
+          const float be = a.ws[a.w.beta + e], ee = a.ws[a.w.eps + e];
+          float sb = 0.f, se = 0.f;
+#pragma unroll
+          for (int j = 0; j < D; ++j) {
+            const float adj = -0.5f * ee * arpp_c[j];
+            const float uf = -1.0f * (be * gp[j] + (1.0f - be) * gq[j]);
+            a_gp[j] -= be * adj;
+            a_gq[j] -= (1.0f - be) * adj;
+            sb -= (gp[j] - gq[j]) * adj;
+            se -= 0.5f * uf * arpp_c[j];
+          }
+          const float tb = row_sum16(sb), te = row_sum16(se);
+          if (lane == 0) {
+            atomicAdd(a.gtab + a.o_gbeta + e, tb);
+            atomicAdd(a.gtab + a.o_geps + e, te);
+          }
+        }
+        {
+          float v[D], hv[D];
+#pragma unroll
+          for (int j = 0; j < D; ++j) {
+            if (e == K) lz[j] -= om * gpraw[j];                    // + log p(z_K), unclipped   mcdboundingmachine.py:178
+            if (e == 0) lz[j] += om * gq[j];                       // - log q(z_0) in w  ->  + omega log q in L
+            v[j] = fabsf(gpraw[j]) < clipv ? a_gp[j] : 0.f;        // jnp.clip passes no gradient outside its bounds
+            gmu[j] += a_gq[j] * qiv[j];
+            glam[j] += a_gq[j] * (-2.0f * gq[j]);
+          }
+          Target<TARGET, D>::hvp(hs, z, v, hv);
+#pragma unroll
+          for (int j = 0; j < D; ++j) lz[j] += hv[j] - a_gq[j] * qiv[j];   // H_q = -diag(1 / std^2)
+        }
+        if (e == 0) {   // z_0 = mean + std e0 and the explicit parameters of log q(z_0)
+#pragma unroll
+          for (int j = 0; j < D; ++j) {
+            const float dz = z[j] - qmean[j];
+            gmu[j] += lz[j] - om * gq[j];
+            glam[j] += lz[j] * dz + om * (dz * dz * qiv[j] - 1.0f);
+          }
+          break;
+        }
       }
 #pragma unroll
       for (int j = 0; j < D; ++j) znext[j] = z[j];
@@ -1404,6 +1474,9 @@ __global__ __launch_bounds__(64 * NW) void uha_grad_kernel(UhaGradArgs a) {
       }
       const int64_t erow = i;
       const float* brow = bias1 + erow * HP;
+      float karp[D], dz2[D];           // JAC: the inhomogeneous part of dL/drho', and J_s2^T (2 eta g_b) on z
+#pragma unroll
+      for (int j = 0; j < D; ++j) { karp[j] = 0.f; dz2[j] = 0.f; }
 
       for (int pass = 0; pass < 2; ++pass) {   // pass 0: s2 = s([z; rho'], i) (backward kernel); pass 1: s1 = s([z; rho], i)
         asm volatile("" ::: "memory");
@@ -1450,8 +1523,10 @@ __global__ __launch_bounds__(64 * NW) void uha_grad_kernel(UhaGradArgs a) {
             }
           }
           if (KEEP_A1) a1[KEEP_A1 ? t : 0] = dact;
+          if constexpr (!JAC) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) u1T[wb[r] + 256 * t] = u1[t][r];
+            for (int r = 0; r < 4; ++r) u1T[wb[r] + 256 * t] = u1[t][r];
+          }
         }
 #pragma unroll
         for (int t = 0; t < T; ++t) a2[t] = *reinterpret_cast<const f32x4*>(lds_b2 + 16 * t + 4 * g);
@@ -1496,7 +1571,7 @@ __global__ __launch_bounds__(64 * NW) void uha_grad_kernel(UhaGradArgs a) {
               float dact2;
               u2t[r] = GEF ? u1[t][r] + softplus_both(a2[t][r], dact2) : gelu_fast_both(a2[t][r], dact2);
               a2[t][r] = dact2;
-              u2T[wb[r] + 256 * t] = u2t[r];
+              if constexpr (!JAC) u2T[wb[r] + 256 * t] = u2t[r];
             }
 #pragma unroll
             for (int j = 0; j < D; ++j) {
@@ -1510,211 +1585,275 @@ __global__ __launch_bounds__(64 * NW) void uha_grad_kernel(UhaGradArgs a) {
             sn[j] = GEF ? opre[j] * factor : fminf(fmaxf(opre[j], -1e4f), 1e4f);
           }
         }
-        // ------------------------------------------------------------ cotangent of this evaluation
-        float cot[D];
-        if (pass == 0) {
-          float r2 = 0.f;
+        // ------------------------------------------------------------ MLP backward: (dzo, dro) = J_s([z; rin])^T cot; ACC: with
+        // the parameter contractions of this evaluation (staged rows, bias sums, this wave's dW1 outer products)
+        auto backward = [&](const float (&cot)[D], auto acc_tag, float (&dzo)[D], float (&dro)[D]) {
+          constexpr bool ACC = decltype(acc_tag)::value;
+          asm volatile("" ::: "memory");
+          float dob[D];
 #pragma unroll
           for (int j = 0; j < D; ++j) {
-            const float mb = rhop[j] * ome + 2.0f * eta * sn[j];
-            const float r = rho[j] - mb;
-            gb[j] = -om * r * inv2eta;                            // dL/dm_b
-            arp[j] += ome * gb[j];
-            cot[j] = 2.0f * eta * gb[j];
-            geta += (2.0f * sn[j] - rhop[j]) * gb[j];
-            r2 += r * r;
-          }
-          geta -= om * r2 * inv2eta * inv2eta;
-        } else {
-#pragma unroll
-          for (int j = 0; j < D; ++j) {
-            const float mf = rho[j] * ome - 2.0f * eta * sn[j];
-            cot[j] = -2.0f * eta * arp[j];
-            geta += ((rhop[j] - mf) * inv2eta - rho[j] - 2.0f * sn[j]) * arp[j];   // sigma n / sigma^2 = (rho' - m_f) / (2 eta)
-            lrn[j] = ome * arp[j] - gb[j];
-          }
-        }
-        // ------------------------------------------------------------ MLP backward
-        asm volatile("" ::: "memory");
-        float dob[D];
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-          if (GEF) {
-            dob[j] = cot[j] * factor;
-            if (g == 0) gfac += cot[j] * opre[j];
-          } else {
-            dob[j] = fabsf(opre[j]) < 1e4f ? cot[j] : 0.f;
-          }
-          if (g == 0) gb3[j] += dob[j];
-        }
-        f32x4 d2[T];
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-          f32x4 du2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int j = 0; j < D; ++j) du2 += dob[j] * *reinterpret_cast<const f32x4*>(lds_w3t + j * HP + 16 * t + 4 * g);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            d2[t][r] = du2[r] * a2[t][r];
-            da2T[wb[r] + 256 * t] = d2[t][r];
-            const float s = row_sum16(d2[t][r]);                  // db2[n] += sum over the tile's particles
-            if (c == 0) accB2[16 * t + 4 * g + r] += s;
-          }
-          if (GEF) a2[t] = du2;  // keep d u2 (residual path)
-        }
-        f32x4 d1[T];
-#pragma unroll
-        for (int tk = 0; tk < T; ++tk) d1[tk] = GEF ? a2[tk] : f32x4{0.f, 0.f, 0.f, 0.f};
-        {
-          f32x4 atn[T];
-          {
-            int lofs = lane * 4;
-            asm volatile("" : "+v"(lofs));
-#pragma unroll
-            for (int tk = 0; tk < T; ++tk) atn[tk] = *reinterpret_cast<const f32x4*>(w2tf + (tk * T) * 256 + lofs);
-          }
-#pragma unroll
-          for (int tn = 0; tn < T; ++tn) {
-            asm volatile("" ::: "memory");
-            int lofs = lane * 4;
-            asm volatile("" : "+v"(lofs));
-            f32x4 atc[T];
-#pragma unroll
-            for (int tk = 0; tk < T; ++tk) atc[tk] = atn[tk];
-            if (tn + 1 < T) {
-#pragma unroll
-              for (int tk = 0; tk < T; ++tk) atn[tk] = *reinterpret_cast<const f32x4*>(w2tf + (tk * T + tn + 1) * 256 + lofs);
-            }
-            if (WGLOBAL) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int tk = 0; tk < T; ++tk) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) d1[tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(atc[tk][r], d2[tn][r], d1[tk], 0, 0, 0);
-            }
-          }
-        }
-        // the two small tiles: network input [z; rin] and d o
-#pragma unroll
-        for (int xt = 0; xt < XT; ++xt) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int f = 16 * xt + 4 * g + r;
-            float xv = 0.f;
-#pragma unroll
-            for (int j = 0; j < D; ++j) {
-              xv = (f == j) ? z[j] : xv;
-              xv = (f == D + j) ? rin[j] : xv;
-            }
-            xT[wb[r] + 256 * xt] = xv;
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int f = 4 * g + r;
-          float dv = 0.f;
-#pragma unroll
-          for (int j = 0; j < D; ++j) dv = (f == j) ? dob[j] : dv;
-          doT[wb[r]] = dv;
-        }
-        float xa_own[XT][4];
-#pragma unroll
-        for (int xt = 0; xt < XT; ++xt)
-#pragma unroll
-          for (int s = 0; s < 4; ++s) xa_own[xt][s] = xT[rb[s] + 256 * xt];
-        float jpart[DIN];   // J_s^T cot, this lane's share of the hidden units
-#pragma unroll
-        for (int j = 0; j < DIN; ++j) jpart[j] = 0.f;
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-          f32x4 pre1;
-          if (KEEP_A1) {
-            pre1 = a1[KEEP_A1 ? t : 0];
-          } else {
-            pre1 = *reinterpret_cast<const f32x4*>(brow + 16 * t + 4 * g);
-#pragma unroll
-            for (int j = 0; j < D; ++j) {
-              pre1 += z[j] * *reinterpret_cast<const f32x4*>(lds_w1z + j * HP + 16 * t + 4 * g);
-              pre1 += rin[j] * *reinterpret_cast<const f32x4*>(lds_w1z + (D + j) * HP + 16 * t + 4 * g);
-            }
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
             if (GEF) {
-              du1T[wb[r]] = d1[t][r];
-              const float s2v = row_sum16(d1[t][r]);              // residual row: sum_p d u1  (-> d emb)
-              if (c == 0) atomicAdd(gS2 + erow * HP + 16 * t + 4 * g + r, s2v);
-              if (16 * t < DIN) {                                 // residual path of the first block: d x_j += d u1_j
-#pragma unroll
-                for (int j = 0; j < DIN; ++j)
-                  if (j >= 16 * t && j < 16 * t + 16) jpart[j] += (16 * t + 4 * g + r == j) ? d1[t][r] : 0.f;
-              }
+              dob[j] = cot[j] * factor;
+              if (ACC && g == 0) gfac += cot[j] * opre[j];
+            } else {
+              dob[j] = fabsf(opre[j]) < 1e4f ? cot[j] : 0.f;
             }
-            d1[t][r] *= KEEP_A1 ? pre1[r] : (GEF ? sigmoid_fast(pre1[r]) : gelu_grad_fast(pre1[r]));
-            da1T[wb[r]] = d1[t][r];
-            const float s1v = row_sum16(d1[t][r]);                // d / d bias-table row i
-            if (c == 0) atomicAdd(gS + erow * HP + 16 * t + 4 * g + r, s1v);
+            if (ACC && g == 0) gb3[j] += dob[j];
           }
+          f32x4 d2[T], d1[T];
 #pragma unroll
-          for (int j = 0; j < DIN; ++j) {
-            const f32x4 wv4 = *reinterpret_cast<const f32x4*>(lds_w1z + j * HP + 16 * t + 4 * g);
-            jpart[j] += d1[t][0] * wv4[0] + d1[t][1] * wv4[1] + d1[t][2] * wv4[2] + d1[t][3] * wv4[3];
-          }
-          // this wave's own outer products for tile t (same wave: the LDS queue is in order, no barrier): dW1[:2d]
+          for (int t = 0; t < T; ++t) {
+            f32x4 du2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int xt = 0; xt < XT; ++xt) {
-            f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa_own[xt][s4], da1T[rb[s4]], sacc, 0, 0, 0);
+            for (int j = 0; j < D; ++j) du2 += dob[j] * *reinterpret_cast<const f32x4*>(lds_w3t + j * HP + 16 * t + 4 * g);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const int row = 16 * xt + 4 * g + r;
-              if (row < DIN) accZ1[row * HP + 16 * t + c] += sacc[r];
-            }
-          }
-          asm volatile("" ::: "memory");   // the next tile's stores stay behind these reads
-        }
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-          lz[j] += group_sum(jpart[j]);
-          const float dr = group_sum(jpart[D + j]);
-          if (pass == 0) arp[j] += dr; else lrn[j] += dr;
-        }
-        __syncthreads();
-        // ------------------------------------------------------------ outer products over particles (all tiles of the workgroup)
-#pragma unroll
-        for (int k = 0; k < OWN; ++k) {
-          const int ti = wv + NW * k;
-          if (ti < T) {
-#pragma unroll
-            for (int q = 0; q < NW; ++q) {
-              const float* base = stage + q * STG;
-              float xa[4], x2[4];
-#pragma unroll
-              for (int s = 0; s < 4; ++s) {
-                xa[s] = base[rb[s] + 256 * ti];                 // u1T
-                x2[s] = base[HP * 16 + rb[s] + 256 * ti];       // u2T
+              d2[t][r] = du2[r] * a2[t][r];
+              if constexpr (ACC) {
+                da2T[wb[r] + 256 * t] = d2[t][r];
+                const float s = row_sum16(d2[t][r]);                  // db2[n] += sum over the tile's particles
+                if (c == 0) accB2[16 * t + 4 * g + r] += s;
               }
+            }
+            d1[t] = GEF ? du2 : f32x4{0.f, 0.f, 0.f, 0.f};           // (geffner: d u2 rides on through the residual path)
+          }
+          {
+            f32x4 atn[T];
+            {
+              int lofs = lane * 4;
+              asm volatile("" : "+v"(lofs));
 #pragma unroll
-              for (int to = 0; to < T; ++to)
+              for (int tk = 0; tk < T; ++tk) atn[tk] = *reinterpret_cast<const f32x4*>(w2tf + (tk * T) * 256 + lofs);
+            }
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
-                  gW2[k][to] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], base[2 * HP * 16 + rb[s] + 256 * to], gW2[k][to], 0, 0, 0);
+            for (int tn = 0; tn < T; ++tn) {
+              asm volatile("" ::: "memory");
+              int lofs = lane * 4;
+              asm volatile("" : "+v"(lofs));
+              f32x4 atc[T];
 #pragma unroll
-              for (int s = 0; s < 4; ++s) gW3[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(x2[s], base[OFF_DOT + rb[s]], gW3[k], 0, 0, 0);
+              for (int tk = 0; tk < T; ++tk) atc[tk] = atn[tk];
+              if (tn + 1 < T) {
+#pragma unroll
+                for (int tk = 0; tk < T; ++tk) atn[tk] = *reinterpret_cast<const f32x4*>(w2tf + (tk * T + tn + 1) * 256 + lofs);
+              }
+              if (WGLOBAL) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int tk = 0; tk < T; ++tk) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d1[tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(atc[tk][r], d2[tn][r], d1[tk], 0, 0, 0);
+              }
             }
           }
-        }
-        __syncthreads();
-      }
+          float xa_own[XT][4];
+          if constexpr (ACC) {
+            // the two small tiles: network input [z; rin] and d o
 #pragma unroll
-      for (int j = 0; j < D; ++j) lr[j] = lrn[j];
-      {
+            for (int xt = 0; xt < XT; ++xt) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int f = 16 * xt + 4 * g + r;
+                float xv = 0.f;
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                  xv = (f == j) ? z[j] : xv;
+                  xv = (f == D + j) ? rin[j] : xv;
+                }
+                xT[wb[r] + 256 * xt] = xv;
+              }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int f = 4 * g + r;
+              float dv = 0.f;
+#pragma unroll
+              for (int j = 0; j < D; ++j) dv = (f == j) ? dob[j] : dv;
+              doT[wb[r]] = dv;
+            }
+#pragma unroll
+            for (int xt = 0; xt < XT; ++xt)
+#pragma unroll
+              for (int s = 0; s < 4; ++s) xa_own[xt][s] = xT[rb[s] + 256 * xt];
+          }
+          float jpart[DIN];   // J_s^T cot, this lane's share of the hidden units
+#pragma unroll
+          for (int j = 0; j < DIN; ++j) jpart[j] = 0.f;
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            f32x4 pre1;
+            if (KEEP_A1) {
+              pre1 = a1[KEEP_A1 ? t : 0];
+            } else {
+              pre1 = *reinterpret_cast<const f32x4*>(brow + 16 * t + 4 * g);
+#pragma unroll
+              for (int j = 0; j < D; ++j) {
+                pre1 += z[j] * *reinterpret_cast<const f32x4*>(lds_w1z + j * HP + 16 * t + 4 * g);
+                pre1 += rin[j] * *reinterpret_cast<const f32x4*>(lds_w1z + (D + j) * HP + 16 * t + 4 * g);
+              }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if (GEF) {
+                if constexpr (ACC) {
+                  du1T[wb[r]] = d1[t][r];
+                  const float s2v = row_sum16(d1[t][r]);              // residual row: sum_p d u1  (-> d emb)
+                  if (c == 0) atomicAdd(gS2 + erow * HP + 16 * t + 4 * g + r, s2v);
+                }
+                if (16 * t < DIN) {                                 // residual path of the first block: d x_j += d u1_j
+#pragma unroll
+                  for (int j = 0; j < DIN; ++j)
+                    if (j >= 16 * t && j < 16 * t + 16) jpart[j] += (16 * t + 4 * g + r == j) ? d1[t][r] : 0.f;
+                }
+              }
+              d1[t][r] *= KEEP_A1 ? pre1[r] : (GEF ? sigmoid_fast(pre1[r]) : gelu_grad_fast(pre1[r]));
+              if constexpr (ACC) {
+                da1T[wb[r]] = d1[t][r];
+                const float s1v = row_sum16(d1[t][r]);                // d / d bias-table row i
+                if (c == 0) atomicAdd(gS + erow * HP + 16 * t + 4 * g + r, s1v);
+              }
+            }
+#pragma unroll
+            for (int j = 0; j < DIN; ++j) {
+              const f32x4 wv4 = *reinterpret_cast<const f32x4*>(lds_w1z + j * HP + 16 * t + 4 * g);
+              jpart[j] += d1[t][0] * wv4[0] + d1[t][1] * wv4[1] + d1[t][2] * wv4[2] + d1[t][3] * wv4[3];
+            }
+            if constexpr (ACC) {
+              // this wave's own outer products for tile t (same wave: the LDS queue is in order, no barrier): dW1[:2d]
+#pragma unroll
+              for (int xt = 0; xt < XT; ++xt) {
+                f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa_own[xt][s4], da1T[rb[s4]], sacc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const int row = 16 * xt + 4 * g + r;
+                  if (row < DIN) accZ1[row * HP + 16 * t + c] += sacc[r];
+                }
+              }
+              asm volatile("" ::: "memory");   // the next tile's stores stay behind these reads
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < D; ++j) {
+            dzo[j] = group_sum(jpart[j]);
+            dro[j] = group_sum(jpart[D + j]);
+          }
+        };
+        if constexpr (JAC) {
+          if (pass == 0) {
+            // the second evaluation feeds the log-weight only: everything behind it is the INHOMOGENEOUS part of the map
+            float cot[D], dr2[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+              const float mb = rhop[j] * ome + 2.0f * eta * sn[j];
+              const float r = rho[j] - mb;
+              gb[j] = -om * r * inv2eta;
+              cot[j] = 2.0f * eta * gb[j];
+            }
+            backward(cot, std::false_type{}, dz2, dr2);
+#pragma unroll
+            for (int j = 0; j < D; ++j) karp[j] = ome * gb[j] + dr2[j];
+          } else {
+            // J_s1 row by row (cotangent e_k): JzT[j][k] = d s_k / d z_j, JrT[j][k] = d s_k / d rho_j;  then
+            // cz = dz2 - 2 eta JzT karp,  cr = (1 - eta) karp - 2 eta JrT karp - g_b
+            float cz[D], cr[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) { cz[j] = dz2[j]; cr[j] = ome * karp[j] - gb[j]; }
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+              float cot[D], dzk[D], drk[D];
+#pragma unroll
+              for (int j = 0; j < D; ++j) cot[j] = j == k ? 1.f : 0.f;
+              backward(cot, std::false_type{}, dzk, drk);
+#pragma unroll
+              for (int j = 0; j < D; ++j) {
+                cz[j] -= 2.0f * eta * dzk[j] * karp[k];
+                cr[j] -= 2.0f * eta * drk[j] * karp[k];
+                if (valid && g == 0) {
+                  jrow[(int64_t)(D * D + j * D + k) * a.n] = dzk[j];
+                  jrow[(int64_t)(2 * D * D + j * D + k) * a.n] = drk[j];
+                }
+              }
+            }
+            if (valid && g == 0) {
+#pragma unroll
+              for (int j = 0; j < D; ++j) {
+                jrow[(int64_t)(3 * D * D + D + j) * a.n] = cz[j];
+                jrow[(int64_t)(3 * D * D + 2 * D + j) * a.n] = cr[j];
+              }
+            }
+          }
+        } else {
+          // ------------------------------------------------------------ cotangent of this evaluation
+          float cot[D];
+          if (pass == 0) {
+            float r2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+              const float mb = rhop[j] * ome + 2.0f * eta * sn[j];
+              const float r = rho[j] - mb;
+              gb[j] = -om * r * inv2eta;                            // dL/dm_b
+              arp[j] += ome * gb[j];
+              cot[j] = 2.0f * eta * gb[j];
+              geta += (2.0f * sn[j] - rhop[j]) * gb[j];
+              r2 += r * r;
+            }
+            geta -= om * r2 * inv2eta * inv2eta;
+          } else {
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+              const float mf = rho[j] * ome - 2.0f * eta * sn[j];
+              cot[j] = -2.0f * eta * arp[j];
+              geta += ((rhop[j] - mf) * inv2eta - rho[j] - 2.0f * sn[j]) * arp[j];   // sigma n / sigma^2 = (rho' - m_f) / (2 eta)
+              lrn[j] = ome * arp[j] - gb[j];
+            }
+          }
+          float dzo[D], dro[D];
+          backward(cot, std::true_type{}, dzo, dro);
+#pragma unroll
+          for (int j = 0; j < D; ++j) {
+            lz[j] += dzo[j];
+            if (pass == 0) arp[j] += dro[j]; else lrn[j] += dro[j];
+          }
+          __syncthreads();
+          // ---------------------------------------------------------- outer products over particles (all tiles of the workgroup)
+#pragma unroll
+          for (int k = 0; k < OWN; ++k) {
+            const int ti = wv + NW * k;
+            if (ti < T) {
+#pragma unroll
+              for (int q = 0; q < NW; ++q) {
+                const float* base = stage + q * STG;
+                float xa[4], x2[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                  xa[s] = base[rb[s] + 256 * ti];                 // u1T
+                  x2[s] = base[HP * 16 + rb[s] + 256 * ti];       // u2T
+                }
+#pragma unroll
+                for (int to = 0; to < T; ++to)
+#pragma unroll
+                  for (int s = 0; s < 4; ++s)
+                    gW2[k][to] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], base[2 * HP * 16 + rb[s] + 256 * to], gW2[k][to], 0, 0, 0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) gW3[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(x2[s], base[OFF_DOT + rb[s]], gW3[k], 0, 0, 0);
+              }
+            }
+          }
+          __syncthreads();
+        }
+      }
+      if constexpr (!JAC) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) lr[j] = lrn[j];
         ggam += eps * geta;
         const float te = row_sum16(gepsd + gamma * geta);
         if (lane == 0) atomicAdd(a.gtab + a.o_geps + i, te);
       }
     }
   }
+  if constexpr (JAC) return;
 
   // ---------------------------------------------------------------- write the workgroup slab
   // layout: dW2 [HP][HP] | dW3 [HP][16] | per wave: dW1x [DIN][HP], db2 [HP], scalars [64]: gfac, ggam, gmu[D], glam[D], gb3[D]
@@ -1784,14 +1923,123 @@ __global__ __launch_bounds__(256) void uha_reduce_kernel(UhaReduceArgs a) {
     dst = a.lay.g_factor; off = (int64_t)(DIN + 1) * HP; perwave = true;
   }
   if (dst < 0) return;
+  // fixed slab order; eight loads in flight per thread (the work-item path writes up to 256 slabs: one dependent load per
+  // slab made this launch 0.26 ms)
   float v = 0.f;
-  if (!perwave) {
-    for (int sl = 0; sl < a.nslabs; ++sl) v += a.slabs[(int64_t)sl * a.slab_stride + off];
-  } else {
-    for (int sl = 0; sl < a.nslabs; ++sl)
-      for (int q = 0; q < a.nw; ++q) v += a.slabs[(int64_t)sl * a.slab_stride + base + q * per + off];
+  const int64_t nterms = perwave ? (int64_t)a.nslabs * a.nw : a.nslabs;
+  auto term = [&](int64_t t) -> int64_t {
+    return perwave ? (t / a.nw) * a.slab_stride + base + (t % a.nw) * per + off : t * a.slab_stride + off;
+  };
+  int64_t t = 0;
+  for (; t + 8 <= nterms; t += 8) {
+    float x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x[u] = a.slabs[term(t + u)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += x[u];
   }
+  for (; t < nterms; ++t) v += a.slabs[term(t)];
   a.grad[dst] = v;
+}
+
+// The small-batch path's second launch: the adjoint recursion of the reverse sweep is AFFINE in the state
+// X_e = (lz, lr, arpp) entering point e, and its coefficients depend on the kept trajectory only (uha_grad_kernel<.., JAC>
+// writes them per (point, particle): P = H_p(z_e) diag(clip mask) [d][d], JzT / JrT = the rows of J_s([z; rho], i)
+// [d][d] each, c0, cz, cr [d] — the second evaluation and everything behind it sit in cz / cr):
+//   u = beta_{e-1} eps_{e-1} lr / 2 + beta_e eps_e arpp / 2,   v = the same with 1 - beta
+//   lz+ = lz + P u - v / std_q^2 + c0;   a = lr + eps_{e-1} lz+
+//   lz' = lz+ - 2 eta JzT a + cz;   lr' = (1 - eta) a - 2 eta JrT a + cr;   arpp' = a          (eta = gamma eps_{e-1})
+// One thread per particle walks e = K .. 1 and stores X_e for the work items of the third launch.
+struct UhaScanArgs {
+  const float* params;
+  const float* ws;
+  const float* traj;
+  const float* jac;
+  float* xbuf;
+  cmcd_layout lay;
+  WsLayout w;
+  int64_t n;
+  int32_t K;
+  float omega;
+};
+
+template <int D>
+__global__ __launch_bounds__(64) void uha_scan_kernel(UhaScanArgs a) {
+  constexpr int S = 3 * D * D + 3 * D;
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= a.n) return;
+  const int K = a.K;
+  const float gamma = a.params[a.lay.gamma];
+  float qiv[D], lz[D], lr[D], ar[D];
+  const float* trho = a.traj + (int64_t)(K + 1) * a.n * D;
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    const float sd = expf(a.params[a.lay.vd_logdiag + j]);
+    qiv[j] = 1.0f / (sd * sd);
+    lz[j] = 0.f;
+    lr[j] = a.omega * trho[((int64_t)K * a.n + p) * D + j];
+    ar[j] = 0.f;
+  }
+  float it[S], nx[S];
+  {
+    const float* jr = a.jac + (int64_t)(K - 1) * S * a.n + p;
+#pragma unroll
+    for (int s = 0; s < S; ++s) nx[s] = jr[(int64_t)s * a.n];
+  }
+  for (int e = K; e >= 1; --e) {
+#pragma unroll
+    for (int s = 0; s < S; ++s) it[s] = nx[s];
+    if (e >= 2) {                                  // the next item's coefficients arrive during this step
+      const float* jr = a.jac + (int64_t)(e - 2) * S * a.n + p;
+#pragma unroll
+      for (int s = 0; s < S; ++s) nx[s] = jr[(int64_t)s * a.n];
+    }
+    float* xs = a.xbuf + (int64_t)e * 3 * D * a.n + p;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      xs[(int64_t)j * a.n] = lz[j];
+      xs[(int64_t)(D + j) * a.n] = lr[j];
+      xs[(int64_t)(2 * D + j) * a.n] = ar[j];
+    }
+    const float eps_i = a.ws[a.w.eps + e - 1], be_i = a.ws[a.w.beta + e - 1];
+    const float eps_e = e <= K - 1 ? a.ws[a.w.eps + e] : 0.f, be_e = e <= K - 1 ? a.ws[a.w.beta + e] : 0.f;
+    const float eta = gamma * eps_i, ome = 1.0f - eta;
+    float lzp[D], arh[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      float acc = lz[j] + it[3 * D * D + j];
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const float tub = 0.5f * eps_i * lr[k], tuf = 0.5f * eps_e * ar[k];
+        acc += it[j * D + k] * (be_i * tub + be_e * tuf);
+      }
+      const float tub = 0.5f * eps_i * lr[j], tuf = 0.5f * eps_e * ar[j];
+      acc -= qiv[j] * ((1.0f - be_i) * tub + (1.0f - be_e) * tuf);
+      lzp[j] = acc;
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) arh[j] = lr[j] + eps_i * lzp[j];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      float az = lzp[j] + it[3 * D * D + D + j], al = ome * arh[j] + it[3 * D * D + 2 * D + j];
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        az -= 2.0f * eta * it[D * D + j * D + k] * arh[k];
+        al -= 2.0f * eta * it[2 * D * D + j * D + k] * arh[k];
+      }
+      lz[j] = az;
+      lr[j] = al;
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) ar[j] = arh[j];
+  }
+  float* xs = a.xbuf + p;                          // X_0
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    xs[(int64_t)j * a.n] = lz[j];
+    xs[(int64_t)(D + j) * a.n] = lr[j];
+    xs[(int64_t)(2 * D + j) * a.n] = ar[j];
+  }
 }
 
 typedef void (*uha_grad_fn)(UhaGradArgs);
@@ -1822,6 +2070,47 @@ static uha_grad_fn uha_grad_pick(const cmcd_desc& d, int T) {
   return nullptr;
 }
 
+// the Jacobian launch of the small-batch path (2-d targets: the per-item map is 3 d^2 + 3 d = 18 floats)
+template <int TARGET, int ARCH>
+static uha_grad_fn uha_jac_pick_T(int T) {
+  switch (T) {
+    case 2: return uha_grad_kernel<TARGET, ARCH, 2, 2, kUhaNW, false, true>;
+    case 4: return uha_grad_kernel<TARGET, ARCH, 2, 4, kUhaNW, false, true>;
+    case 5: return uha_grad_kernel<TARGET, ARCH, 2, 5, kUhaNW, true, true>;
+    case 9: return uha_grad_kernel<TARGET, ARCH, 2, 9, kUhaNW, true, true>;
+    default: return nullptr;
+  }
+}
+static uha_grad_fn uha_jac_pick(const cmcd_desc& d, int T) {
+  if (d.dim != 2) return nullptr;
+  if (d.arch == CMCD_ARCH_DDS) {
+    if (T != 4) return nullptr;
+    if (d.target == CMCD_TARGET_MANY_GMM) return uha_grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_DDS, 2, 4, kUhaNW, false, true>;
+    if (d.target == CMCD_TARGET_GMM) return uha_grad_kernel<CMCD_TARGET_GMM, CMCD_ARCH_DDS, 2, 4, kUhaNW, false, true>;
+    return nullptr;
+  }
+  if (d.target == CMCD_TARGET_MANY_GMM) return uha_jac_pick_T<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER>(T);
+  if (d.target == CMCD_TARGET_GMM) return uha_jac_pick_T<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER>(T);
+  return nullptr;
+}
+// Small-batch path: while whole-chain waves cannot fill the chip (quads of tiles < CUs) and the chain is long enough to cut.
+// cmcd_debug_grad_item(0 / 1) pins it, as for the overdamped modes.
+constexpr int64_t kUhaItemMaxN = 16384;            // the item buffers are part of the workspace up to this batch size
+static bool uha_item_capable(const cmcd_desc& d, int T, int64_t n) {
+  return uha_jac_pick(d, T) != nullptr && n <= kUhaItemMaxN && d.nbridges >= 2;
+}
+static bool uha_item_mode(const cmcd_desc& d, int T, int64_t n) {
+  if (!uha_item_capable(d, T, n)) return false;
+  const int ov = get_grad_item_override();
+  if (ov >= 0) return ov != 0;
+  return n <= 8192 && d.nbridges >= 16;
+}
+static int64_t uha_item_floats(const cmcd_desc& d, int T, int64_t n) {
+  if (!uha_item_capable(d, T, n)) return 0;
+  const int64_t D = d.dim, K = d.nbridges;
+  return (K + 1) * 3 * D * n + K * (3 * D * D + 3 * D) * n;
+}
+
 bool uha_grad_available(const cmcd_desc& d, int T) { return uha_grad_pick(d, T) != nullptr; }
 
 static void uha_grad_offsets(const cmcd_desc& d, int HP, int64_t& o_S, int64_t& o_S2, int64_t& o_gbeta, int64_t& o_geps,
@@ -1842,8 +2131,11 @@ static int64_t uha_dds_tail_floats(const cmcd_desc& d) { return d.arch == CMCD_A
 int64_t uha_grad_workspace_floats(const cmcd_desc& d, int HP, int64_t n) {
   int64_t oS, oS2, ob, oe, tot;
   uha_grad_offsets(d, HP, oS, oS2, ob, oe, tot);
-  return tot + uha_dds_tail_floats(d) + uha_slab_floats(d, HP) * 256;
+  return tot + uha_dds_tail_floats(d) + uha_slab_floats(d, HP) * 256 + uha_item_floats(d, HP / 16, n);
 }
+
+static float* g_uha_xdump = nullptr;   // tests: cmcd_debug_uha_xdump — the next sweeps write the adjoint state they carry
+extern "C" void cmcd_debug_uha_xdump(float* buf) { g_uha_xdump = buf; }
 
 // ws_fwd / traj as left by the forward launch on the SAME desc / params; gws: uha_grad_workspace_floats; grad: [n_params],
 // fully overwritten (zeros for the leaves the loss does not reach).
@@ -1870,13 +2162,35 @@ int uha_grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& 
   const size_t stg = size_t(3 * HP * 16 + 3 * 256 + XT * 256 + (DIN + 1) * HP);
   const size_t lds_bytes = size_t((wglobal ? 0 : 2 * HP * HP) + DIN * HP + D * HP + HP + 16 + w.tgt_floats + nw * stg) * 4;
   if (lds_bytes > 160 * 1024) return CMCD_ERR_UNSUPPORTED;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)lds_bytes) != hipSuccess)
-    return CMCD_ERR_HIP;
-  hipLaunchKernelGGL(fn, dim3(nslabs), dim3(64 * nw), lds_bytes, stream, ga);
+  if (!ensure_dynamic_lds(reinterpret_cast<const void*>(fn), lds_bytes)) return CMCD_ERR_HIP;
+  int nslabs_used = nslabs;
+  if (uha_item_mode(d, w.T, n)) {
+    // small-batch path: Jacobian launch over (quad, point) -> per-particle scan -> the sweep over (quad, chunk) work items
+    uha_grad_fn jfn = uha_jac_pick(d, w.T);
+    float* xbuf = slabs + uha_slab_floats(d, HP) * 256;
+    float* jac = xbuf + (int64_t)(K + 1) * 3 * D * n;
+    if (!ensure_dynamic_lds(reinterpret_cast<const void*>(jfn), lds_bytes)) return CMCD_ERR_HIP;
+    UhaGradArgs ja = ga;
+    ja.jac = jac;
+    const int64_t jwork = nquads * K;
+    hipLaunchKernelGGL(jfn, dim3((unsigned)(jwork < 1024 ? jwork : 1024)), dim3(64 * nw), lds_bytes, stream, ja);
+    UhaScanArgs sa{params, ws_fwd, traj, jac, xbuf, lay, w, n, K, omega};
+    hipLaunchKernelGGL(uha_scan_kernel<2>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, sa);
+    // chunks: enough work items for every CU, each at least 4 points long
+    int nchunks = (int)((256 + nquads - 1) / nquads);
+    if (nchunks > (K + 1) / 4) nchunks = (K + 1) / 4;
+    if (nchunks < 1) nchunks = 1;
+    ga.chunk_len = (K + 1 + nchunks - 1) / nchunks;
+    ga.nchunks = (K + 1 + ga.chunk_len - 1) / ga.chunk_len;
+    ga.xbuf = xbuf;
+    const int64_t nwork = nquads * ga.nchunks;
+    nslabs_used = (int)(nwork < 256 ? nwork : 256);
+  }
+  ga.xdump = g_uha_xdump;
+  hipLaunchKernelGGL(fn, dim3(nslabs_used), dim3(64 * nw), lds_bytes, stream, ga);
 
   UhaReduceArgs ra{};
-  ra.slabs = slabs; ra.grad = grad; ra.lay = lay; ra.slab_stride = ga.slab_stride; ra.nslabs = nslabs; ra.nw = nw;
+  ra.slabs = slabs; ra.grad = grad; ra.lay = lay; ra.slab_stride = ga.slab_stride; ra.nslabs = nslabs_used; ra.nw = nw;
   ra.HP = HP; ra.D = D; ra.wid = d.arch == CMCD_ARCH_DDS ? 64 : DIN + d.emb_dim; ra.arch = d.arch;
   const int64_t outs = (int64_t)ra.wid * ra.wid + (int64_t)ra.wid * D + (int64_t)DIN * ra.wid + ra.wid + 3 * D + 2;
   hipLaunchKernelGGL(uha_reduce_kernel, dim3((unsigned)((outs + 255) / 256)), dim3(256), 0, stream, ra);
