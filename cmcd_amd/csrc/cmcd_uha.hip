@@ -1269,7 +1269,9 @@ __global__ __launch_bounds__(64 * NW) void uha_grad_kernel(UhaGradArgs a) {
   float* xT = my + OFF_X;
   float* accZ1 = my + OFF_ACC;             // [DIN][HP]
   float* accB2 = accZ1 + DIN * HP;         // [HP]
-  for (int i = lane; i < (DIN + 1) * HP; i += 64) accZ1[i] = 0.f;
+  if constexpr (!JAC) {                    // (the Jacobian launch stages nothing: it is launched without the staging area)
+    for (int i = lane; i < (DIN + 1) * HP; i += 64) accZ1[i] = 0.f;
+  }
   const int K = a.K;
   const float factor = lds_b3[15];
   int wb[4], rb[4];
@@ -1894,12 +1896,17 @@ struct UhaReduceArgs {
 };
 
 __global__ __launch_bounds__(256) void uha_reduce_kernel(UhaReduceArgs a) {
+  // block = 32 outputs x 8 groups of slabs: thread (o, gr) sums its eighth of the terms in slab order with eight loads in
+  // flight, the eight partial sums are added in group order — a fixed order whatever the launch (the work-item path writes up
+  // to 512 slabs: one thread per output with one dependent load per slab took 0.32 ms)
+  __shared__ float red[8][32];
   const int HP = a.HP, D = a.D, DIN = 2 * D, wid = a.wid;
   const bool dds = a.arch == CMCD_ARCH_DDS;
   const int64_t o_w1 = dds ? a.lay.d_sw1 : a.lay.g_w1, o_w2 = dds ? a.lay.d_sw2 : a.lay.g_w2;
   const int64_t o_b2 = dds ? a.lay.d_sb2 : a.lay.g_b2, o_w3 = dds ? a.lay.d_sw3 : a.lay.g_w3;
   const int64_t o_b3 = dds ? a.lay.d_sb3 : a.lay.g_b3;
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int ol = threadIdx.x & 31, gr = threadIdx.x >> 5;
+  int64_t i = (int64_t)blockIdx.x * 32 + ol;
   const int64_t per = (int64_t)(DIN + 1) * HP + 64, base = (int64_t)HP * HP + HP * 16;
   int64_t dst = -1, off = 0;
   bool perwave = false;
@@ -1922,24 +1929,32 @@ __global__ __launch_bounds__(256) void uha_reduce_kernel(UhaReduceArgs a) {
   } else if ((i -= 1) < 1 && !dds) {                              // d factor_sn
     dst = a.lay.g_factor; off = (int64_t)(DIN + 1) * HP; perwave = true;
   }
-  if (dst < 0) return;
-  // fixed slab order; eight loads in flight per thread (the work-item path writes up to 256 slabs: one dependent load per
-  // slab made this launch 0.26 ms)
   float v = 0.f;
-  const int64_t nterms = perwave ? (int64_t)a.nslabs * a.nw : a.nslabs;
-  auto term = [&](int64_t t) -> int64_t {
-    return perwave ? (t / a.nw) * a.slab_stride + base + (t % a.nw) * per + off : t * a.slab_stride + off;
-  };
-  int64_t t = 0;
-  for (; t + 8 <= nterms; t += 8) {
-    float x[8];
+  if (dst >= 0) {
+    const int64_t nterms = perwave ? (int64_t)a.nslabs * a.nw : a.nslabs;
+    auto term = [&](int64_t t) -> int64_t {
+      return perwave ? (t / a.nw) * a.slab_stride + base + (t % a.nw) * per + off : t * a.slab_stride + off;
+    };
+    const int64_t chunk = (nterms + 7) / 8;
+    int64_t t = gr * chunk;
+    const int64_t tend = t + chunk < nterms ? t + chunk : nterms;
+    for (; t + 8 <= tend; t += 8) {
+      float x[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) x[u] = a.slabs[term(t + u)];
+      for (int u = 0; u < 8; ++u) x[u] = a.slabs[term(t + u)];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v += x[u];
+      for (int u = 0; u < 8; ++u) v += x[u];
+    }
+    for (; t < tend; ++t) v += a.slabs[term(t)];
   }
-  for (; t < nterms; ++t) v += a.slabs[term(t)];
-  a.grad[dst] = v;
+  red[gr][ol] = v;
+  __syncthreads();
+  if (gr == 0 && dst >= 0) {
+    float tot = red[0][ol];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) tot += red[q][ol];
+    a.grad[dst] = tot;
+  }
 }
 
 // The small-batch path's second launch: the adjoint recursion of the reverse sweep is AFFINE in the state
@@ -1980,20 +1995,24 @@ __global__ __launch_bounds__(64) void uha_scan_kernel(UhaScanArgs a) {
     lr[j] = a.omega * trho[((int64_t)K * a.n + p) * D + j];
     ar[j] = 0.f;
   }
-  float it[S], nx[S];
-  {
-    const float* jr = a.jac + (int64_t)(K - 1) * S * a.n + p;
+  // the coefficients do not depend on the state: items e - 1 .. e - PF are requested before item e is consumed
+  constexpr int PF = 4;
+  float ring[PF][S], it[S];
+  auto fetch = [&](int e, float (&dst)[S]) {      // item of point e (clamped: a request below 1 re-reads item 1)
+    const float* jr = a.jac + (int64_t)((e >= 1 ? e : 1) - 1) * S * a.n + p;
 #pragma unroll
-    for (int s = 0; s < S; ++s) nx[s] = jr[(int64_t)s * a.n];
-  }
-  for (int e = K; e >= 1; --e) {
+    for (int s = 0; s < S; ++s) dst[s] = jr[(int64_t)s * a.n];
+  };
 #pragma unroll
-    for (int s = 0; s < S; ++s) it[s] = nx[s];
-    if (e >= 2) {                                  // the next item's coefficients arrive during this step
-      const float* jr = a.jac + (int64_t)(e - 2) * S * a.n + p;
+  for (int q = 0; q < PF; ++q) fetch(K - q, ring[q]);
+  for (int e0 = K; e0 >= 1; e0 -= PF) {
 #pragma unroll
-      for (int s = 0; s < S; ++s) nx[s] = jr[(int64_t)s * a.n];
-    }
+   for (int q = 0; q < PF; ++q) {
+    const int e = e0 - q;
+    if (e < 1) break;
+#pragma unroll
+    for (int s = 0; s < S; ++s) it[s] = ring[q][s];
+    fetch(e - PF, ring[q]);
     float* xs = a.xbuf + (int64_t)e * 3 * D * a.n + p;
 #pragma unroll
     for (int j = 0; j < D; ++j) {
@@ -2032,6 +2051,7 @@ __global__ __launch_bounds__(64) void uha_scan_kernel(UhaScanArgs a) {
     }
 #pragma unroll
     for (int j = 0; j < D; ++j) ar[j] = arh[j];
+   }
   }
   float* xs = a.xbuf + p;                          // X_0
 #pragma unroll
@@ -2093,6 +2113,32 @@ static uha_grad_fn uha_jac_pick(const cmcd_desc& d, int T) {
   if (d.target == CMCD_TARGET_GMM) return uha_jac_pick_T<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER>(T);
   return nullptr;
 }
+// The sweep over work items streams the W2 / W2^T fragments from L2 (WGLOBAL) also for the narrow nets: without the 32 KB of
+// LDS-resident weights a workgroup needs 73 KB, two share a CU, and the second wave per SIMD covers the first one's latencies.
+template <int TARGET, int ARCH>
+static uha_grad_fn uha_item_pick_T(int T) {
+  switch (T) {
+    case 2: return uha_grad_kernel<TARGET, ARCH, 2, 2, kUhaNW, true>;
+    case 4: return uha_grad_kernel<TARGET, ARCH, 2, 4, kUhaNW, true>;
+    case 5: return uha_grad_kernel<TARGET, ARCH, 2, 5, kUhaNW, true>;
+    case 9: return uha_grad_kernel<TARGET, ARCH, 2, 9, kUhaNW, true>;
+    default: return nullptr;
+  }
+}
+static uha_grad_fn uha_item_pick(const cmcd_desc& d, int T) {
+  if (d.dim != 2) return nullptr;
+  if (d.arch == CMCD_ARCH_DDS) {
+    if (T != 4) return nullptr;
+    if (d.target == CMCD_TARGET_MANY_GMM) return uha_grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_DDS, 2, 4, kUhaNW, true>;
+    if (d.target == CMCD_TARGET_GMM) return uha_grad_kernel<CMCD_TARGET_GMM, CMCD_ARCH_DDS, 2, 4, kUhaNW, true>;
+    return nullptr;
+  }
+  if (d.target == CMCD_TARGET_MANY_GMM) return uha_item_pick_T<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER>(T);
+  if (d.target == CMCD_TARGET_GMM) return uha_item_pick_T<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER>(T);
+  return nullptr;
+}
+constexpr int kUhaSlabs = 512;                     // workgroup slabs of the gradient workspace
+
 // Small-batch path: while whole-chain waves cannot fill the chip (quads of tiles < CUs) and the chain is long enough to cut.
 // cmcd_debug_grad_item(0 / 1) pins it, as for the overdamped modes.
 constexpr int64_t kUhaItemMaxN = 16384;            // the item buffers are part of the workspace up to this batch size
@@ -2103,7 +2149,9 @@ static bool uha_item_mode(const cmcd_desc& d, int T, int64_t n) {
   if (!uha_item_capable(d, T, n)) return false;
   const int ov = get_grad_item_override();
   if (ov >= 0) return ov != 0;
-  return n <= 8192 && d.nbridges >= 16;
+  // measured on MI355X (profiles/r03_uha_grad_work_items.txt): faster at every batch up to 8192 particles (5.03 vs 6.31 ms
+  // there; 16384: 12.0 vs 8.5) and down to K = 8 (N = 300: 0.117 vs 0.135 ms)
+  return n <= 8192 && d.nbridges >= 4;
 }
 static int64_t uha_item_floats(const cmcd_desc& d, int T, int64_t n) {
   if (!uha_item_capable(d, T, n)) return 0;
@@ -2131,7 +2179,7 @@ static int64_t uha_dds_tail_floats(const cmcd_desc& d) { return d.arch == CMCD_A
 int64_t uha_grad_workspace_floats(const cmcd_desc& d, int HP, int64_t n) {
   int64_t oS, oS2, ob, oe, tot;
   uha_grad_offsets(d, HP, oS, oS2, ob, oe, tot);
-  return tot + uha_dds_tail_floats(d) + uha_slab_floats(d, HP) * 256 + uha_item_floats(d, HP / 16, n);
+  return tot + uha_dds_tail_floats(d) + uha_slab_floats(d, HP) * kUhaSlabs + uha_item_floats(d, HP / 16, n);
 }
 
 static float* g_uha_xdump = nullptr;   // tests: cmcd_debug_uha_xdump — the next sweeps write the adjoint state they carry
@@ -2167,33 +2215,41 @@ int uha_grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& 
   if (uha_item_mode(d, w.T, n)) {
     // small-batch path: Jacobian launch over (quad, point) -> per-particle scan -> the sweep over (quad, chunk) work items
     uha_grad_fn jfn = uha_jac_pick(d, w.T);
-    float* xbuf = slabs + uha_slab_floats(d, HP) * 256;
+    float* xbuf = slabs + uha_slab_floats(d, HP) * kUhaSlabs;
     float* jac = xbuf + (int64_t)(K + 1) * 3 * D * n;
-    if (!ensure_dynamic_lds(reinterpret_cast<const void*>(jfn), lds_bytes)) return CMCD_ERR_HIP;
+    // (no staging area: weights + target constants only, so several workgroups share a CU)
+    const size_t jlds = size_t((wglobal ? 0 : 2 * HP * HP) + DIN * HP + D * HP + HP + 16 + w.tgt_floats) * 4;
+    if (!ensure_dynamic_lds(reinterpret_cast<const void*>(jfn), jlds)) return CMCD_ERR_HIP;
     UhaGradArgs ja = ga;
     ja.jac = jac;
     const int64_t jwork = nquads * K;
-    hipLaunchKernelGGL(jfn, dim3((unsigned)(jwork < 1024 ? jwork : 1024)), dim3(64 * nw), lds_bytes, stream, ja);
+    hipLaunchKernelGGL(jfn, dim3((unsigned)(jwork < 2048 ? jwork : 2048)), dim3(64 * nw), jlds, stream, ja);
     UhaScanArgs sa{params, ws_fwd, traj, jac, xbuf, lay, w, n, K, omega};
     hipLaunchKernelGGL(uha_scan_kernel<2>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, sa);
-    // chunks: enough work items for every CU, each at least 4 points long
-    int nchunks = (int)((256 + nquads - 1) / nquads);
+    // chunks: enough work items for two workgroups on every CU, each at least 4 points long
+    int nchunks = (int)((kUhaSlabs + nquads - 1) / nquads);
     if (nchunks > (K + 1) / 4) nchunks = (K + 1) / 4;
     if (nchunks < 1) nchunks = 1;
     ga.chunk_len = (K + 1 + nchunks - 1) / nchunks;
     ga.nchunks = (K + 1 + ga.chunk_len - 1) / ga.chunk_len;
     ga.xbuf = xbuf;
     const int64_t nwork = nquads * ga.nchunks;
-    nslabs_used = (int)(nwork < 256 ? nwork : 256);
+    nslabs_used = (int)(nwork < kUhaSlabs ? nwork : kUhaSlabs);
+    ga.xdump = g_uha_xdump;
+    uha_grad_fn ifn = uha_item_pick(d, w.T);
+    const size_t ilds = size_t(DIN * HP + D * HP + HP + 16 + w.tgt_floats + nw * stg) * 4;
+    if (!ensure_dynamic_lds(reinterpret_cast<const void*>(ifn), ilds)) return CMCD_ERR_HIP;
+    hipLaunchKernelGGL(ifn, dim3(nslabs_used), dim3(64 * nw), ilds, stream, ga);
+  } else {
+    ga.xdump = g_uha_xdump;
+    hipLaunchKernelGGL(fn, dim3(nslabs_used), dim3(64 * nw), lds_bytes, stream, ga);
   }
-  ga.xdump = g_uha_xdump;
-  hipLaunchKernelGGL(fn, dim3(nslabs_used), dim3(64 * nw), lds_bytes, stream, ga);
 
   UhaReduceArgs ra{};
   ra.slabs = slabs; ra.grad = grad; ra.lay = lay; ra.slab_stride = ga.slab_stride; ra.nslabs = nslabs_used; ra.nw = nw;
   ra.HP = HP; ra.D = D; ra.wid = d.arch == CMCD_ARCH_DDS ? 64 : DIN + d.emb_dim; ra.arch = d.arch;
   const int64_t outs = (int64_t)ra.wid * ra.wid + (int64_t)ra.wid * D + (int64_t)DIN * ra.wid + ra.wid + 3 * D + 2;
-  hipLaunchKernelGGL(uha_reduce_kernel, dim3((unsigned)((outs + 255) / 256)), dim3(256), 0, stream, ra);
+  hipLaunchKernelGGL(uha_reduce_kernel, dim3((unsigned)((outs + 31) / 32)), dim3(256), 0, stream, ra);
   // the particle-independent tails: schedules (cos^2 always), time coder / embedding table with the network's state
   // inputs = 2 dim wide
   const int rc = launch_net_tails(d, DIN, CMCD_EPS_COS_SQ, lay, w, params, gws, ga.o_S, ga.o_S2, ga.o_gbeta, ga.o_geps, HP,
