@@ -563,6 +563,15 @@ def main():
         result["second_order"] = {"workload": f"{weak.cfg_name}:MCD_CAIS_UHA_sn", "particles": n, "nbridges": ub["params_fixed"][1],
                                   "ms_per_step": tu * 1e3, "value": n * ub["params_fixed"][1] / tu, "steps": ureps,
                                   "kernel": _lib.last_kernel_name(), "n_finite": int(torch.isfinite(ur[0]).sum())}
+        if not args.forward_only:
+            for _ in range(3):
+                _m.compute_bound_grad(*uargs)
+            torch.cuda.synchronize()
+            tg0 = time.perf_counter()
+            for _ in range(20):
+                _m.compute_bound_grad(*uargs)
+            torch.cuda.synchronize()
+            result["second_order"]["value_and_grad_ms"] = (time.perf_counter() - tg0) / 20 * 1e3
 
     if cfg["model"] == "lgcp":
         # weight-bandwidth bound: every evaluation streams K^-1 and the three weight matrices

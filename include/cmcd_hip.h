@@ -173,6 +173,12 @@ int cmcd_debug_capture_noise(uint32_t* bits, uint32_t* gen_keys, float* noise);
  * CMCD_GRAD_ITEM environment variable through this call, the library itself reads no environment per call.) */
 int cmcd_debug_grad_item(int mode);
 
+/* Diagnostic (tools/probes/uha_item_check.py): while `buf` is non-NULL the MCD_CAIS_UHA_sn gradient's sweep writes the
+ * adjoint state it carries — (dL/dz_e, dL/drho_e, dL/drho''_e) entering point e — to buf, float [nbridges+1][3 dim][n]
+ * [device]: the whole-chain sweep and the work-item path (whose chunks load that state from the scan launch) can be compared
+ * point by point.  Process-wide; NULL disarms. */
+void cmcd_debug_uha_xdump(float* buf);
+
 /* ---- VarGrad gradient ("compute_log_var_grad"): d/d params_flat of compute_bound_var
  * (/root/reference/src/main.py:161-176 takes jax.grad of it; /root/reference/src/mcd_cais_var.py:59,79
  * detach z, which makes the gradient local per bridge).  Two calls after a cmcd_bound_forward on the

@@ -41,6 +41,7 @@ def test_bench_single_gpu_line(hip_lib):
     so = r["second_order"]
     assert so["workload"] == "many_gmm_n2000_k256_dds:MCD_CAIS_UHA_sn" and so["value"] > 1e8 and so["particles"] == 2000
     assert so["kernel"] == "uha_coop_kernel<8-particle tiles>" and so["n_finite"] > 1000
+    assert so["value_and_grad_ms"] > so["ms_per_step"]
 
 
 def test_bench_two_ranks_share_the_gpu(hip_lib):
