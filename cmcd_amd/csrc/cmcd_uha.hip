@@ -1378,11 +1378,11 @@ __global__ __launch_bounds__(64 * NW) void uha_grad_kernel(UhaGradArgs a) {
       if constexpr (JAC) {
         jrow = a.jac + (int64_t)(e - 1) * S_JAC * a.n + pc;
         // P = H_p(z_e) diag(clip mask), column k;  c0 = the direct term of point e (e = K: - omega grad log p(z_K))
-#pragma unroll
+#pragma unroll(D <= 4 ? D : 1)
         for (int k = 0; k < D; ++k) {
           float v[D], hv[D];
 #pragma unroll
-          for (int j = 0; j < D; ++j) v[j] = (j == k && fabsf(gpraw[k]) < clipv) ? 1.f : 0.f;
+          for (int j = 0; j < D; ++j) v[j] = (j == k && fabsf(gpraw[j]) < clipv) ? 1.f : 0.f;
           Target<TARGET, D>::hvp(hs, z, v, hv);
           if (valid && g == 0) {
 #pragma unroll
@@ -1762,16 +1762,19 @@ __global__ __launch_bounds__(64 * NW) void uha_grad_kernel(UhaGradArgs a) {
             float cz[D], cr[D];
 #pragma unroll
             for (int j = 0; j < D; ++j) { cz[j] = dz2[j]; cr[j] = ome * karp[j] - gb[j]; }
+#pragma unroll(D <= 4 ? D : 1)
+            for (int k = 0; k < D; ++k) {               // (d = 10: a rolled loop, one copy of the backward pass)
+              float cot[D], dzk[D], drk[D], kk = 0.f;
 #pragma unroll
-            for (int k = 0; k < D; ++k) {
-              float cot[D], dzk[D], drk[D];
-#pragma unroll
-              for (int j = 0; j < D; ++j) cot[j] = j == k ? 1.f : 0.f;
+              for (int j = 0; j < D; ++j) {
+                cot[j] = j == k ? 1.f : 0.f;
+                kk = j == k ? karp[j] : kk;
+              }
               backward(cot, std::false_type{}, dzk, drk);
 #pragma unroll
               for (int j = 0; j < D; ++j) {
-                cz[j] -= 2.0f * eta * dzk[j] * karp[k];
-                cr[j] -= 2.0f * eta * drk[j] * karp[k];
+                cz[j] -= 2.0f * eta * dzk[j] * kk;
+                cr[j] -= 2.0f * eta * drk[j] * kk;
                 if (valid && g == 0) {
                   jrow[(int64_t)(D * D + j * D + k) * a.n] = dzk[j];
                   jrow[(int64_t)(2 * D * D + j * D + k) * a.n] = drk[j];
@@ -1995,24 +1998,8 @@ __global__ __launch_bounds__(64) void uha_scan_kernel(UhaScanArgs a) {
     lr[j] = a.omega * trho[((int64_t)K * a.n + p) * D + j];
     ar[j] = 0.f;
   }
-  // the coefficients do not depend on the state: items e - 1 .. e - PF are requested before item e is consumed
-  constexpr int PF = 4;
-  float ring[PF][S], it[S];
-  auto fetch = [&](int e, float (&dst)[S]) {      // item of point e (clamped: a request below 1 re-reads item 1)
-    const float* jr = a.jac + (int64_t)((e >= 1 ? e : 1) - 1) * S * a.n + p;
-#pragma unroll
-    for (int s = 0; s < S; ++s) dst[s] = jr[(int64_t)s * a.n];
-  };
-#pragma unroll
-  for (int q = 0; q < PF; ++q) fetch(K - q, ring[q]);
-  for (int e0 = K; e0 >= 1; e0 -= PF) {
-#pragma unroll
-   for (int q = 0; q < PF; ++q) {
-    const int e = e0 - q;
-    if (e < 1) break;
-#pragma unroll
-    for (int s = 0; s < S; ++s) it[s] = ring[q][s];
-    fetch(e - PF, ring[q]);
+  // one step of the recursion with the item's coefficients read through `co(s)`
+  auto step = [&](int e, auto co) {
     float* xs = a.xbuf + (int64_t)e * 3 * D * a.n + p;
 #pragma unroll
     for (int j = 0; j < D; ++j) {
@@ -2023,15 +2010,14 @@ __global__ __launch_bounds__(64) void uha_scan_kernel(UhaScanArgs a) {
     const float eps_i = a.ws[a.w.eps + e - 1], be_i = a.ws[a.w.beta + e - 1];
     const float eps_e = e <= K - 1 ? a.ws[a.w.eps + e] : 0.f, be_e = e <= K - 1 ? a.ws[a.w.beta + e] : 0.f;
     const float eta = gamma * eps_i, ome = 1.0f - eta;
-    float lzp[D], arh[D];
+    float u[D], lzp[D], arh[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) u[k] = be_i * (0.5f * eps_i * lr[k]) + be_e * (0.5f * eps_e * ar[k]);
 #pragma unroll
     for (int j = 0; j < D; ++j) {
-      float acc = lz[j] + it[3 * D * D + j];
+      float acc = lz[j] + co(3 * D * D + j);
 #pragma unroll
-      for (int k = 0; k < D; ++k) {
-        const float tub = 0.5f * eps_i * lr[k], tuf = 0.5f * eps_e * ar[k];
-        acc += it[j * D + k] * (be_i * tub + be_e * tuf);
-      }
+      for (int k = 0; k < D; ++k) acc += co(j * D + k) * u[k];
       const float tub = 0.5f * eps_i * lr[j], tuf = 0.5f * eps_e * ar[j];
       acc -= qiv[j] * ((1.0f - be_i) * tub + (1.0f - be_e) * tuf);
       lzp[j] = acc;
@@ -2040,18 +2026,46 @@ __global__ __launch_bounds__(64) void uha_scan_kernel(UhaScanArgs a) {
     for (int j = 0; j < D; ++j) arh[j] = lr[j] + eps_i * lzp[j];
 #pragma unroll
     for (int j = 0; j < D; ++j) {
-      float az = lzp[j] + it[3 * D * D + D + j], al = ome * arh[j] + it[3 * D * D + 2 * D + j];
+      float az = lzp[j] + co(3 * D * D + D + j), al = ome * arh[j] + co(3 * D * D + 2 * D + j);
 #pragma unroll
       for (int k = 0; k < D; ++k) {
-        az -= 2.0f * eta * it[D * D + j * D + k] * arh[k];
-        al -= 2.0f * eta * it[2 * D * D + j * D + k] * arh[k];
+        az -= 2.0f * eta * co(D * D + j * D + k) * arh[k];
+        al -= 2.0f * eta * co(2 * D * D + j * D + k) * arh[k];
       }
       lz[j] = az;
       lr[j] = al;
     }
 #pragma unroll
     for (int j = 0; j < D; ++j) ar[j] = arh[j];
-   }
+  };
+  if constexpr (D <= 4) {
+    // the coefficients do not depend on the state: items e - 1 .. e - PF are requested before item e is consumed
+    constexpr int PF = 4;
+    float ring[PF][S], it[S];
+    auto fetch = [&](int e, float (&dst)[S]) {      // item of point e (clamped: a request below 1 re-reads item 1)
+      const float* jr = a.jac + (int64_t)((e >= 1 ? e : 1) - 1) * S * a.n + p;
+#pragma unroll
+      for (int s = 0; s < S; ++s) dst[s] = jr[(int64_t)s * a.n];
+    };
+#pragma unroll
+    for (int q = 0; q < PF; ++q) fetch(K - q, ring[q]);
+    for (int e0 = K; e0 >= 1; e0 -= PF) {
+#pragma unroll
+      for (int q = 0; q < PF; ++q) {
+        const int e = e0 - q;
+        if (e < 1) break;
+#pragma unroll
+        for (int s = 0; s < S; ++s) it[s] = ring[q][s];
+        fetch(e - PF, ring[q]);
+        step(e, [&](int s) { return it[s]; });
+      }
+    }
+  } else {
+    // d = 10: 330 coefficients per item — read where they are used (each once), not staged in registers
+    for (int e = K; e >= 1; --e) {
+      const float* jr = a.jac + (int64_t)(e - 1) * S * a.n + p;
+      step(e, [&](int s) { return jr[(int64_t)s * a.n]; });
+    }
   }
   float* xs = a.xbuf + p;                          // X_0
 #pragma unroll
@@ -2101,7 +2115,20 @@ static uha_grad_fn uha_jac_pick_T(int T) {
     default: return nullptr;
   }
 }
+template <int ARCH>
+static uha_grad_fn uha_jac_pick_funnel(int T) {
+  switch (T) {
+    case 2: return uha_grad_kernel<CMCD_TARGET_FUNNEL, ARCH, 10, 2, kUhaNW, false, true>;
+    case 4: return uha_grad_kernel<CMCD_TARGET_FUNNEL, ARCH, 10, 4, kUhaNW, false, true>;
+    case 5: return uha_grad_kernel<CMCD_TARGET_FUNNEL, ARCH, 10, 5, kUhaNW, true, true>;
+    default: return nullptr;          // (the 9-tile instance of d = 10 spills 3.6 KB per lane already: whole chains only)
+  }
+}
 static uha_grad_fn uha_jac_pick(const cmcd_desc& d, int T) {
+  if (d.target == CMCD_TARGET_FUNNEL && d.dim == 10) {
+    if (d.arch == CMCD_ARCH_DDS) return T == 4 ? uha_jac_pick_funnel<CMCD_ARCH_DDS>(4) : nullptr;
+    return uha_jac_pick_funnel<CMCD_ARCH_GEFFNER>(T);
+  }
   if (d.dim != 2) return nullptr;
   if (d.arch == CMCD_ARCH_DDS) {
     if (T != 4) return nullptr;
@@ -2225,7 +2252,8 @@ int uha_grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& 
     const int64_t jwork = nquads * K;
     hipLaunchKernelGGL(jfn, dim3((unsigned)(jwork < 2048 ? jwork : 2048)), dim3(64 * nw), jlds, stream, ja);
     UhaScanArgs sa{params, ws_fwd, traj, jac, xbuf, lay, w, n, K, omega};
-    hipLaunchKernelGGL(uha_scan_kernel<2>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, sa);
+    if (D == 2) hipLaunchKernelGGL(uha_scan_kernel<2>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, sa);
+    else hipLaunchKernelGGL(uha_scan_kernel<10>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, sa);
     // chunks: enough work items for two workgroups on every CU, each at least 4 points long
     int nchunks = (int)((kUhaSlabs + nquads - 1) / nquads);
     if (nchunks > (K + 1) / 4) nchunks = (K + 1) / 4;
@@ -2236,8 +2264,9 @@ int uha_grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& 
     const int64_t nwork = nquads * ga.nchunks;
     nslabs_used = (int)(nwork < kUhaSlabs ? nwork : kUhaSlabs);
     ga.xdump = g_uha_xdump;
-    uha_grad_fn ifn = uha_item_pick(d, w.T);
-    const size_t ilds = size_t(DIN * HP + D * HP + HP + 16 + w.tgt_floats + nw * stg) * 4;
+    // (d = 10: the whole-chain instance — its staging fills the CU either way)
+    uha_grad_fn ifn = D == 2 ? uha_item_pick(d, w.T) : fn;
+    const size_t ilds = D == 2 ? size_t(DIN * HP + D * HP + HP + 16 + w.tgt_floats + nw * stg) * 4 : lds_bytes;
     if (!ensure_dynamic_lds(reinterpret_cast<const void*>(ifn), ilds)) return CMCD_ERR_HIP;
     hipLaunchKernelGGL(ifn, dim3(nslabs_used), dim3(64 * nw), ilds, stream, ga);
   } else {

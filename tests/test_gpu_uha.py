@@ -137,7 +137,8 @@ GRAD_CASES = [
     ("gmm_n300_k8", 50, dict(emb_dim=40, nbridges=5)),                                      # width 44 -> 64
     ("gmm_n300_k8", 300, dict(nbridges=3)),                                                 # 19 tiles: five workgroups, ragged
     ("gmm_n300_k8", 20, dict(nbridges=1, nn_arch="dds")),                                   # a single bridge
-    ("gmm_n300_k8", 70, dict(nbridges=40, init_eps=0.05)),                                  # 41 points: five chunks of work items
+    ("gmm_n300_k8", 70, dict(nbridges=40, init_eps=0.05)),                                  # 41 points: ten chunks of work items
+    ("funnel_n300_k64", 50, dict(nbridges=19, init_eps=0.03, init_gamma=4.0)),              # d = 10 in chunks (330-float items)
 ]
 
 
@@ -147,9 +148,9 @@ def test_reparameterised_gradient_matches_autograd(hip_lib, param_set, variant, 
     _skip_without_instance(variant, name, over)
     if variant != 3 and GRAD_CASES.index((name, n, over)) not in (0, 2, 4, 7):
         pytest.skip("the wave-per-tile and 8-particle forwards keep the trajectory for four representative cases (suite time)")
-    if item and (name.startswith("funnel") or variant != 3):
-        pytest.skip("the work-item path (Jacobian launch, scan, chunked sweep) exists for the 2-d targets; it reads the same "
-                    "kept trajectory whatever forward wrote it")
+    if item and variant != 3:
+        pytest.skip("the work-item path (Jacobian launch, scan, chunked sweep) reads the same kept trajectory whatever forward "
+                    "wrote it")
     # whole_chain: one sweep over every chain; work_items: cmcd_uha.hip's small-batch path (both pinned, not auto-selected)
     monkeypatch.setenv("CMCD_GRAD_ITEM", str(item))
     """jax.grad(compute_bound, 1) (/root/reference/src/main.py:174-176) through mcd_under_lp_a_cais.py:42-88: every leaf of
