@@ -2168,9 +2168,14 @@ constexpr int kUhaSlabs = 512;                     // workgroup slabs of the gra
 
 // Small-batch path: while whole-chain waves cannot fill the chip (quads of tiles < CUs) and the chain is long enough to cut.
 // cmcd_debug_grad_item(0 / 1) pins it, as for the overdamped modes.
-constexpr int64_t kUhaItemMaxN = 16384;            // the item buffers are part of the workspace up to this batch size
+constexpr int64_t kUhaItemMaxN = 8192;             // the item buffers are part of the workspace up to this batch size ...
+constexpr int64_t kUhaItemMaxFloats = int64_t(1) << 28;   // ... and up to 1 GB (d = 10: 330 floats per point and particle)
+static int64_t uha_item_floats_raw(const cmcd_desc& d, int64_t n) {
+  const int64_t D = d.dim, K = d.nbridges;
+  return (K + 1) * 3 * D * n + K * (3 * D * D + 3 * D) * n;
+}
 static bool uha_item_capable(const cmcd_desc& d, int T, int64_t n) {
-  return uha_jac_pick(d, T) != nullptr && n <= kUhaItemMaxN && d.nbridges >= 2;
+  return uha_jac_pick(d, T) != nullptr && n <= kUhaItemMaxN && d.nbridges >= 2 && uha_item_floats_raw(d, n) <= kUhaItemMaxFloats;
 }
 static bool uha_item_mode(const cmcd_desc& d, int T, int64_t n) {
   if (!uha_item_capable(d, T, n)) return false;
@@ -2181,9 +2186,7 @@ static bool uha_item_mode(const cmcd_desc& d, int T, int64_t n) {
   return n <= 8192 && d.nbridges >= 4;
 }
 static int64_t uha_item_floats(const cmcd_desc& d, int T, int64_t n) {
-  if (!uha_item_capable(d, T, n)) return 0;
-  const int64_t D = d.dim, K = d.nbridges;
-  return (K + 1) * 3 * D * n + K * (3 * D * D + 3 * D) * n;
+  return uha_item_capable(d, T, n) ? uha_item_floats_raw(d, n) : 0;
 }
 
 bool uha_grad_available(const cmcd_desc& d, int T) { return uha_grad_pick(d, T) != nullptr; }
