@@ -1220,6 +1220,7 @@ __global__ __launch_bounds__(64 * NW) void uha_grad_kernel(UhaGradArgs a) {
   constexpr int HP = 16 * T;
   constexpr int DIN = 2 * D;
   constexpr int S_JAC = 3 * D * D + 3 * D;     // floats per (point, particle) of the Jacobian launch, see uha_scan_kernel
+  constexpr int UNR_D = D <= 4 ? D : 1;        // Jacobian launch: loops over output dimensions unrolled for the 2-d targets only
   constexpr int XT = (DIN + 15) / 16;          // 16-row tiles of the staged network input
   constexpr bool GEF = ARCH == CMCD_ARCH_GEFFNER;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1378,7 +1379,7 @@ __global__ __launch_bounds__(64 * NW) void uha_grad_kernel(UhaGradArgs a) {
       if constexpr (JAC) {
         jrow = a.jac + (int64_t)(e - 1) * S_JAC * a.n + pc;
         // P = H_p(z_e) diag(clip mask), column k;  c0 = the direct term of point e (e = K: - omega grad log p(z_K))
-#pragma unroll(D <= 4 ? D : 1)
+#pragma unroll UNR_D
         for (int k = 0; k < D; ++k) {
           float v[D], hv[D];
 #pragma unroll
@@ -1762,7 +1763,7 @@ __global__ __launch_bounds__(64 * NW) void uha_grad_kernel(UhaGradArgs a) {
             float cz[D], cr[D];
 #pragma unroll
             for (int j = 0; j < D; ++j) { cz[j] = dz2[j]; cr[j] = ome * karp[j] - gb[j]; }
-#pragma unroll(D <= 4 ? D : 1)
+#pragma unroll UNR_D
             for (int k = 0; k < D; ++k) {               // (d = 10: a rolled loop, one copy of the backward pass)
               float cot[D], dzk[D], drk[D], kk = 0.f;
 #pragma unroll
