@@ -2077,6 +2077,192 @@ __global__ __launch_bounds__(64) void uha_scan_kernel(UhaScanArgs a) {
   }
 }
 
+// d = 10: the scan with one LANE per state row — lane (particle, j) owns row j of the three d x d products and the j-th
+// components of (lz, lr, arpp); the vectors every row needs (lr, arpp, then a) pass through LDS inside the wave (one
+// single-wave workgroup holds 64 / d particles).  33 coefficient loads and ~35 FMAs per lane and step instead of 330 and
+// ~700 on one thread per particle: funnel, N = 300, K = 64: 0.42 -> see profiles/r03_uha_grad_work_items.txt.
+template <int D>
+__global__ __launch_bounds__(64) void uha_scan_rows_kernel(UhaScanArgs a) {
+  constexpr int S = 3 * D * D + 3 * D, PPB = 64 / D;
+  __shared__ float sh[3][64];
+  const int lane = threadIdx.x, pl = lane / D, j = lane % D;
+  const int64_t p0 = (int64_t)blockIdx.x * PPB + pl;
+  const bool act = pl < PPB && p0 < a.n;
+  const int64_t p = act ? p0 : a.n - 1;
+  const int K = a.K;
+  const float gamma = a.params[a.lay.gamma];
+  const float* trho = a.traj + (int64_t)(K + 1) * a.n * D;
+  const float sd = expf(a.params[a.lay.vd_logdiag + j]);
+  const float qiv = 1.0f / (sd * sd);
+  float lz = 0.f, lr = a.omega * trho[((int64_t)K * a.n + p) * D + j], ar = 0.f;
+  const int base = pl * D;                       // this particle's slots in the exchange rows
+  for (int e = K; e >= 1; --e) {
+    const float* jr = a.jac + (int64_t)(e - 1) * S * a.n + p;
+    float rp[D], rz[D], rr[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      rp[k] = jr[(int64_t)(j * D + k) * a.n];
+      rz[k] = jr[(int64_t)(D * D + j * D + k) * a.n];
+      rr[k] = jr[(int64_t)(2 * D * D + j * D + k) * a.n];
+    }
+    const float c0 = jr[(int64_t)(3 * D * D + j) * a.n], cz = jr[(int64_t)(3 * D * D + D + j) * a.n];
+    const float cr = jr[(int64_t)(3 * D * D + 2 * D + j) * a.n];
+    if (act) {
+      float* xs = a.xbuf + (int64_t)e * 3 * D * a.n + p;
+      xs[(int64_t)j * a.n] = lz;
+      xs[(int64_t)(D + j) * a.n] = lr;
+      xs[(int64_t)(2 * D + j) * a.n] = ar;
+    }
+    const float eps_i = a.ws[a.w.eps + e - 1], be_i = a.ws[a.w.beta + e - 1];
+    const float eps_e = e <= K - 1 ? a.ws[a.w.eps + e] : 0.f, be_e = e <= K - 1 ? a.ws[a.w.beta + e] : 0.f;
+    const float eta = gamma * eps_i, ome = 1.0f - eta;
+    const float tub = 0.5f * eps_i * lr, tuf = 0.5f * eps_e * ar;
+    sh[0][lane] = be_i * tub + be_e * tuf;         // u_j
+    __syncthreads();
+    float acc = lz + c0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) acc += rp[k] * sh[0][base + k];
+    acc -= qiv * ((1.0f - be_i) * tub + (1.0f - be_e) * tuf);
+    const float arh = lr + eps_i * acc;
+    sh[1][lane] = arh;
+    __syncthreads();
+    float az = acc + cz, al = ome * arh + cr;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      const float ak = sh[1][base + k];
+      az -= 2.0f * eta * rz[k] * ak;
+      al -= 2.0f * eta * rr[k] * ak;
+    }
+    lz = az; lr = al; ar = arh;
+  }
+  if (act) {
+    float* xs = a.xbuf + p;                        // X_0
+    xs[(int64_t)j * a.n] = lz;
+    xs[(int64_t)(D + j) * a.n] = lr;
+    xs[(int64_t)(2 * D + j) * a.n] = ar;
+  }
+}
+
+// The scan in two parallel launches (2-d targets): the work items of the third launch need X only where their chunks START,
+// and a chunk's composite map is affine too.  uha_compose_kernel: thread (particle, chunk, v) runs the recursion over the
+// chunk from the unit vector e_v with the inhomogeneous terms switched off (v < 3 d: column v of the chunk's matrix) or from
+// zero with them on (v = 3 d: its offset); uha_chain_kernel: one thread per particle applies the nchunks composite maps in
+// turn and stores X at the chunk starts.  256 dependent steps of 2000 threads (0.16 ms) become 17 steps of 224 000 threads
+// and 16 steps of 2000.
+struct UhaComposeArgs {
+  const float* params;
+  const float* ws;
+  const float* traj;
+  const float* jac;
+  float* cbuf;       // [nchunks][3 d + 1][3 d][n]
+  float* xbuf;
+  cmcd_layout lay;
+  WsLayout w;
+  int64_t n;
+  int32_t K, nchunks, chunk_len;
+  float omega;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void uha_compose_kernel(UhaComposeArgs a) {
+  constexpr int S = 3 * D * D + 3 * D, NV = 3 * D + 1;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t p = tid % a.n;
+  const int64_t rest = tid / a.n;
+  const int v = (int)(rest % NV), ch = (int)(rest / NV);
+  if (ch >= a.nchunks) return;
+  const int K = a.K;
+  const int e_hi = K - ch * a.chunk_len;
+  const int e_lo = e_hi - a.chunk_len + 1 > 0 ? e_hi - a.chunk_len + 1 : 0;
+  const float gamma = a.params[a.lay.gamma];
+  const bool inh = v == 3 * D;
+  float qiv[D], lz[D], lr[D], ar[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    const float sd = expf(a.params[a.lay.vd_logdiag + j]);
+    qiv[j] = 1.0f / (sd * sd);
+    lz[j] = v == j ? 1.f : 0.f;
+    lr[j] = v == D + j ? 1.f : 0.f;
+    ar[j] = v == 2 * D + j ? 1.f : 0.f;
+  }
+  // iteration e (point e, bridge e - 1) for e = e_hi .. max(e_lo, 1): the state entering the NEXT chunk's first point
+  for (int e = e_hi; e >= e_lo && e >= 1; --e) {
+    const float* jr = a.jac + (int64_t)(e - 1) * S * a.n + p;
+    float it[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) it[s] = jr[(int64_t)s * a.n];
+    const float eps_i = a.ws[a.w.eps + e - 1], be_i = a.ws[a.w.beta + e - 1];
+    const float eps_e = e <= K - 1 ? a.ws[a.w.eps + e] : 0.f, be_e = e <= K - 1 ? a.ws[a.w.beta + e] : 0.f;
+    const float eta = gamma * eps_i, ome = 1.0f - eta;
+    float u[D], lzp[D], arh[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) u[k] = be_i * (0.5f * eps_i * lr[k]) + be_e * (0.5f * eps_e * ar[k]);
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      float acc = lz[j] + (inh ? it[3 * D * D + j] : 0.f);
+#pragma unroll
+      for (int k = 0; k < D; ++k) acc += it[j * D + k] * u[k];
+      const float tub = 0.5f * eps_i * lr[j], tuf = 0.5f * eps_e * ar[j];
+      acc -= qiv[j] * ((1.0f - be_i) * tub + (1.0f - be_e) * tuf);
+      lzp[j] = acc;
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) arh[j] = lr[j] + eps_i * lzp[j];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      float az = lzp[j] + (inh ? it[3 * D * D + D + j] : 0.f), al = ome * arh[j] + (inh ? it[3 * D * D + 2 * D + j] : 0.f);
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        az -= 2.0f * eta * it[D * D + j * D + k] * arh[k];
+        al -= 2.0f * eta * it[2 * D * D + j * D + k] * arh[k];
+      }
+      lz[j] = az;
+      lr[j] = al;
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) ar[j] = arh[j];
+  }
+  float* cb = a.cbuf + ((int64_t)(ch * NV + v) * 3 * D) * a.n + p;
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    cb[(int64_t)j * a.n] = lz[j];
+    cb[(int64_t)(D + j) * a.n] = lr[j];
+    cb[(int64_t)(2 * D + j) * a.n] = ar[j];
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void uha_chain_kernel(UhaComposeArgs a) {
+  constexpr int NV = 3 * D + 1, N3 = 3 * D;
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= a.n) return;
+  const int K = a.K;
+  const float* trho = a.traj + (int64_t)(K + 1) * a.n * D;
+  float x[N3];
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    x[j] = 0.f;
+    x[D + j] = a.omega * trho[((int64_t)K * a.n + p) * D + j];
+    x[2 * D + j] = 0.f;
+  }
+  for (int ch = 0; ch < a.nchunks; ++ch) {
+    const int e_hi = K - ch * a.chunk_len;
+    float* xs = a.xbuf + (int64_t)e_hi * N3 * a.n + p;
+#pragma unroll
+    for (int j = 0; j < N3; ++j) xs[(int64_t)j * a.n] = x[j];
+    const float* cb = a.cbuf + ((int64_t)ch * NV * N3) * a.n + p;
+    float y[N3];
+#pragma unroll
+    for (int j = 0; j < N3; ++j) y[j] = cb[((int64_t)N3 * N3 + j) * a.n];          // the offset (v = 3 d)
+#pragma unroll
+    for (int v = 0; v < N3; ++v)
+#pragma unroll
+      for (int j = 0; j < N3; ++j) y[j] += cb[((int64_t)v * N3 + j) * a.n] * x[v];
+#pragma unroll
+    for (int j = 0; j < N3; ++j) x[j] = y[j];
+  }
+}
+
 typedef void (*uha_grad_fn)(UhaGradArgs);
 constexpr int kUhaNW = 4;
 
@@ -2173,7 +2359,8 @@ constexpr int64_t kUhaItemMaxN = 8192;             // the item buffers are part 
 constexpr int64_t kUhaItemMaxFloats = int64_t(1) << 28;   // ... and up to 1 GB (d = 10: 330 floats per point and particle)
 static int64_t uha_item_floats_raw(const cmcd_desc& d, int64_t n) {
   const int64_t D = d.dim, K = d.nbridges;
-  return (K + 1) * 3 * D * n + K * (3 * D * D + 3 * D) * n;
+  const int64_t compose = D == 2 ? ((K + 1) / 4 + 1) * (3 * D + 1) * 3 * D * n : 0;   // composite maps of the chunks
+  return (K + 1) * 3 * D * n + K * (3 * D * D + 3 * D) * n + compose;
 }
 static bool uha_item_capable(const cmcd_desc& d, int T, int64_t n) {
   return uha_jac_pick(d, T) != nullptr && n <= kUhaItemMaxN && d.nbridges >= 2 && uha_item_floats_raw(d, n) <= kUhaItemMaxFloats;
@@ -2255,9 +2442,6 @@ int uha_grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& 
     ja.jac = jac;
     const int64_t jwork = nquads * K;
     hipLaunchKernelGGL(jfn, dim3((unsigned)(jwork < 2048 ? jwork : 2048)), dim3(64 * nw), jlds, stream, ja);
-    UhaScanArgs sa{params, ws_fwd, traj, jac, xbuf, lay, w, n, K, omega};
-    if (D == 2) hipLaunchKernelGGL(uha_scan_kernel<2>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, sa);
-    else hipLaunchKernelGGL(uha_scan_kernel<10>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, sa);
     // chunks: enough work items for two workgroups on every CU, each at least 4 points long
     int nchunks = (int)((kUhaSlabs + nquads - 1) / nquads);
     if (nchunks > (K + 1) / 4) nchunks = (K + 1) / 4;
@@ -2265,6 +2449,18 @@ int uha_grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& 
     ga.chunk_len = (K + 1 + nchunks - 1) / nchunks;
     ga.nchunks = (K + 1 + ga.chunk_len - 1) / ga.chunk_len;
     ga.xbuf = xbuf;
+    if (D == 2 && ga.nchunks >= 4) {
+      // composite maps per chunk, then a short chain over the chunks: X at the chunk starts only (all the work items read)
+      float* cbuf = jac + (int64_t)K * (3 * D * D + 3 * D) * n;
+      UhaComposeArgs ca{params, ws_fwd, traj, jac, cbuf, xbuf, lay, w, n, K, ga.nchunks, ga.chunk_len, omega};
+      const int64_t threads = n * ga.nchunks * (3 * D + 1);
+      hipLaunchKernelGGL(uha_compose_kernel<2>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, ca);
+      hipLaunchKernelGGL(uha_chain_kernel<2>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, ca);
+    } else {
+      UhaScanArgs sa{params, ws_fwd, traj, jac, xbuf, lay, w, n, K, omega};
+      if (D == 2) hipLaunchKernelGGL(uha_scan_kernel<2>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, sa);
+      else hipLaunchKernelGGL(uha_scan_rows_kernel<10>, dim3((unsigned)((n + 5) / 6)), dim3(64), 0, stream, sa);
+    }
     const int64_t nwork = nquads * ga.nchunks;
     nslabs_used = (int)(nwork < kUhaSlabs ? nwork : kUhaSlabs);
     ga.xdump = g_uha_xdump;
