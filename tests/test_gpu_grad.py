@@ -363,7 +363,7 @@ def test_opt_run_stops_at_a_nan_loss_with_the_last_finite_parameters(hip_lib):
     assert not torch.equal(out, flat)
 
 
-@pytest.mark.parametrize("mode", ["MCD_CAIS_sn", "MCD_CAIS_var_sn"])
+@pytest.mark.parametrize("mode", ["MCD_CAIS_sn", "MCD_CAIS_var_sn", "MCD_CAIS_UHA_sn"])
 def test_graph_replayed_training_equals_eager_training(hip_lib, mode):
     """opt.run with the iteration captured in a HIP graph (static seed buffer, device-side Adam step count) ends
     where the eager loop ends, from the same seeds."""
