@@ -1092,8 +1092,9 @@ static uha_fn uha_coop_pick_T(int T) {
     case 4: return uha_coop_kernel<TARGET, ARCH, D, 4, HALF>;
     case 5: return uha_coop_kernel<TARGET, ARCH, D, 5, HALF>;
     case 9:
-      if constexpr (HALF) return nullptr;   // (72 resident 4x4x1 operands + the d = 10 first layer: no 8-particle instance)
-      else return uha_coop_kernel<TARGET, ARCH, D, 9, false>;
+      // (d = 10: 72 resident 4x4x1 operands beside a 20-wide first layer do not fit three waves per SIMD)
+      if constexpr (HALF && D > 4) return nullptr;
+      else return uha_coop_kernel<TARGET, ARCH, D, 9, HALF>;
     default: return nullptr;
   }
 }
