@@ -2085,7 +2085,7 @@ __global__ __launch_bounds__(64) void uha_scan_kernel(UhaScanArgs a) {
 template <int D>
 __global__ __launch_bounds__(64) void uha_scan_rows_kernel(UhaScanArgs a) {
   constexpr int S = 3 * D * D + 3 * D, PPB = 64 / D;
-  __shared__ float sh[3][64];
+  __shared__ float sh[2][64 + D];                 // (+ D: the idle lanes behind the last whole particle read their own slots)
   const int lane = threadIdx.x, pl = lane / D, j = lane % D;
   const int64_t p0 = (int64_t)blockIdx.x * PPB + pl;
   const bool act = pl < PPB && p0 < a.n;
