@@ -166,13 +166,15 @@ def test_full_length_gradient_against_autograd(hip_lib, mode):
     assert cos > 0.9999 and worst < 2e-2
 
 
-@pytest.mark.parametrize("mode", ["MCD_CAIS_sn", "MCD_CAIS_var_sn"])
+@pytest.mark.parametrize("mode", ["MCD_CAIS_sn", "MCD_CAIS_var_sn", "MCD_CAIS_UHA_sn"])
 def test_work_item_and_whole_chain_gradients_agree_on_a_large_batch(hip_lib, monkeypatch, mode):
     """N = 6000 (ragged last tile), K = 256: the two gradient paths are different kernels and launch sequences of the
-    same arithmetic; they must agree to float32 accumulation noise."""
-    b = synthetic.build("many_gmm_n2000_k256_dds", device="cuda", boundmode=mode, init_sigma=15.0)
+    same arithmetic; they must agree to float32 accumulation noise.  (2nd-order mode: the work-item path is the Jacobian
+    launch + composite-map scan + chain-chunk sweep of cmcd_uha.hip, 94 quads x 6 chunks here.)"""
+    over = dict(init_eps=0.2, init_gamma=2.0) if mode == "MCD_CAIS_UHA_sn" else {}
+    b = synthetic.build("many_gmm_n2000_k256_dds", device="cuda", boundmode=mode, init_sigma=15.0, **over)
     seeds = torch.from_numpy(synthetic.throughput_seeds(6000 - 7, stream=3)).cuda()
-    fn = mcdbm.compute_bound_grad if mode == "MCD_CAIS_sn" else mcdbm.compute_log_var_grad
+    fn = mcdbm.compute_log_var_grad if mode == "MCD_CAIS_var_sn" else mcdbm.compute_bound_grad
     out = {}
     for item in ("0", "1"):
         monkeypatch.setenv("CMCD_GRAD_ITEM", item)
