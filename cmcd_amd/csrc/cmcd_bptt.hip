@@ -36,6 +36,12 @@ struct JacArgs {
   int64_t n, nitems;
   int32_t K, grad_clipping, ula;
   float omega;
+  // the gradient's accumulation tables and output, zeroed by this launch (it precedes every launch that adds into them):
+  // two memset launches fewer per gradient — ~5 us each, 7 % of a small configuration's training iteration
+  float* zero_a = nullptr;
+  int64_t n_a = 0;
+  float* zero_b = nullptr;
+  int64_t n_b = 0;
 };
 
 template <int TARGET, int ARCH, int D, int T>
@@ -65,6 +71,11 @@ __global__ __launch_bounds__(256) void bptt_jac_kernel(JacArgs a) {
     for (int i = threadIdx.x; i < a.w.tgt_floats; i += blockDim.x) lds_tgt[i] = a.ws[a.w.tgt + i];
   }
   __syncthreads();
+  {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = tid; i < a.n_a; i += nth) a.zero_a[i] = 0.f;
+    for (int64_t i = tid; i < a.n_b; i += nth) a.zero_b[i] = 0.f;
+  }
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   const int K = a.K;
   const float factor = lds_b3[15];
@@ -351,12 +362,13 @@ static jac_fn pick_jac(const cmcd_desc& d, int T) {
 
 int bptt_jac_scan_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, int64_t n, int64_t nitems,
                          const float* params, const float* ws_fwd, const float* traj, float* jac, float* lam,
-                         float omega_scalar, void* stream_) {
+                         float omega_scalar, float* zero_a, int64_t n_a, float* zero_b, int64_t n_b, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const int D = d.dim, K = d.nbridges, HP = 16 * w.T;
   jac_fn jf = pick_jac(d, w.T);
   if (!jf) return CMCD_ERR_UNSUPPORTED;
   JacArgs ja{params, ws_fwd, traj, jac, lay, w, n, nitems, K, d.grad_clipping, d.mode == CMCD_MODE_ULA_SN ? 2 : 0, omega_scalar};
+  ja.zero_a = zero_a; ja.n_a = n_a; ja.zero_b = zero_b; ja.n_b = n_b;
   const size_t jl = size_t(HP * HP + 2 * D * HP + HP + 16 + w.tgt_floats) * 4;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(jf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)jl) != hipSuccess)
     return CMCD_ERR_HIP;

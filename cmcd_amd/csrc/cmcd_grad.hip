@@ -50,7 +50,7 @@ namespace cmcd {
 // cmcd_bptt.hip: Jacobian rows of every (tile, evaluation) + the per-particle lambda recursion
 int bptt_jac_scan_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, int64_t n, int64_t nitems,
                          const float* params, const float* ws_fwd, const float* traj, float* jac, float* lam,
-                         float omega_scalar, void* stream);
+                         float omega_scalar, float* zero_a, int64_t n_a, float* zero_b, int64_t n_b, void* stream);
 
 struct GradArgs {
   const int32_t* seeds;
@@ -1451,16 +1451,18 @@ int grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, c
   ga.ula = d.mode == CMCD_MODE_ULA_SN ? 2 : 0;
   ga.nitems = nitems;
   ga.slab_stride = (int64_t)HP * HP + HP * 16 + 4 * (2 * 16 * HP + 256 + 32);
-  if (hipMemsetAsync(gws, 0, sizeof(float) * tot, stream) != hipSuccess) return CMCD_ERR_HIP;
-  if (hipMemsetAsync(grad, 0, sizeof(float) * n_params, stream) != hipSuccess) return CMCD_ERR_HIP;
-
   if (bptt && item) {
+    // (the Jacobian launch zeroes the accumulation tables and the output on its way: no memset launches on this path)
     const int64_t S = (int64_t)D * D + 2 * D;
     float* jac = item_ws;
     float* lam = item_ws + (int64_t)(K + 1) * n * S;
-    const int rc = bptt_jac_scan_launch(d, lay, w, n, nitems, params, ws_fwd, traj, jac, lam, omega_scalar, stream);
+    const int rc = bptt_jac_scan_launch(d, lay, w, n, nitems, params, ws_fwd, traj, jac, lam, omega_scalar, gws, tot, grad,
+                                        n_params, stream);
     if (rc != CMCD_OK) return rc;
     ga.lam = lam;
+  } else {
+    if (hipMemsetAsync(gws, 0, sizeof(float) * tot, stream) != hipSuccess) return CMCD_ERR_HIP;
+    if (hipMemsetAsync(grad, 0, sizeof(float) * n_params, stream) != hipSuccess) return CMCD_ERR_HIP;
   }
 
   const size_t stg = w.T > 4 ? size_t(3 * HP * 16 + 2 * 256 + 512 + (D + 1) * HP) : size_t((5 * HP + 32) * 16 + (D + 1) * HP);

@@ -1212,6 +1212,11 @@ struct UhaGradArgs {
   const float* xbuf = nullptr;   // [K+1][3 D][n]  adjoint state (lz, lr, arpp) entering point e   (uha_scan_kernel)
   float* jac = nullptr;          // [K][3 D^2 + 3 D][n]  Jacobian launch output
   float* xdump = nullptr;        // tests: the sweep writes the state it carries in the xbuf layout
+  // Jacobian launch: the accumulation tables and the output vector, zeroed on its way (no memset launches on that path)
+  float* zero_a = nullptr;
+  int64_t n_a = 0;
+  float* zero_b = nullptr;
+  int64_t n_b = 0;
 };
 
 __device__ __forceinline__ int uha_sw(int f, int p) { return f * 16 + (p ^ (f & 15)); }
@@ -1273,6 +1278,10 @@ __global__ __launch_bounds__(64 * NW) void uha_grad_kernel(UhaGradArgs a) {
   float* accB2 = accZ1 + DIN * HP;         // [HP]
   if constexpr (!JAC) {                    // (the Jacobian launch stages nothing: it is launched without the staging area)
     for (int i = lane; i < (DIN + 1) * HP; i += 64) accZ1[i] = 0.f;
+  } else {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = tid; i < a.n_a; i += nth) a.zero_a[i] = 0.f;
+    for (int64_t i = tid; i < a.n_b; i += nth) a.zero_b[i] = 0.f;
   }
   const int K = a.K;
   const float factor = lds_b3[15];
@@ -2423,15 +2432,18 @@ int uha_grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& 
   float* slabs = tailbuf + uha_dds_tail_floats(d);
   ga.params = params; ga.ws = ws_fwd; ga.traj = traj; ga.gtab = gws; ga.slabs = slabs; ga.lay = lay; ga.w = w; ga.n = n;
   ga.K = K; ga.nquads = (int)nquads; ga.omega = omega; ga.slab_stride = uha_slab_floats(d, HP);
-  if (hipMemsetAsync(gws, 0, sizeof(float) * tot, stream) != hipSuccess) return CMCD_ERR_HIP;
-  if (hipMemsetAsync(grad, 0, sizeof(float) * n_params, stream) != hipSuccess) return CMCD_ERR_HIP;
+  const bool items = uha_item_mode(d, w.T, n);
+  if (!items) {   // (the work-item path's Jacobian launch zeroes both on its way)
+    if (hipMemsetAsync(gws, 0, sizeof(float) * tot, stream) != hipSuccess) return CMCD_ERR_HIP;
+    if (hipMemsetAsync(grad, 0, sizeof(float) * n_params, stream) != hipSuccess) return CMCD_ERR_HIP;
+  }
   const bool wglobal = w.T > 4;
   const size_t stg = size_t(3 * HP * 16 + 3 * 256 + XT * 256 + (DIN + 1) * HP);
   const size_t lds_bytes = size_t((wglobal ? 0 : 2 * HP * HP) + DIN * HP + D * HP + HP + 16 + w.tgt_floats + nw * stg) * 4;
   if (lds_bytes > 160 * 1024) return CMCD_ERR_UNSUPPORTED;
   if (!ensure_dynamic_lds(reinterpret_cast<const void*>(fn), lds_bytes)) return CMCD_ERR_HIP;
   int nslabs_used = nslabs;
-  if (uha_item_mode(d, w.T, n)) {
+  if (items) {
     // small-batch path: Jacobian launch over (quad, point) -> per-particle scan -> the sweep over (quad, chunk) work items
     uha_grad_fn jfn = uha_jac_pick(d, w.T);
     float* xbuf = slabs + uha_slab_floats(d, HP) * kUhaSlabs;
@@ -2441,6 +2453,7 @@ int uha_grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& 
     if (!ensure_dynamic_lds(reinterpret_cast<const void*>(jfn), jlds)) return CMCD_ERR_HIP;
     UhaGradArgs ja = ga;
     ja.jac = jac;
+    ja.zero_a = gws; ja.n_a = tot; ja.zero_b = grad; ja.n_b = n_params;
     const int64_t jwork = nquads * K;
     hipLaunchKernelGGL(jfn, dim3((unsigned)(jwork < 2048 ? jwork : 2048)), dim3(64 * nw), jlds, stream, ja);
     // chunks: enough work items for two workgroups on every CU, each at least 4 points long
