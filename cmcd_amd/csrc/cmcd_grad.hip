@@ -1090,17 +1090,26 @@ __device__ __forceinline__ void grad_reduce_body(const TailArgs& a, const unsign
   } else if ((i -= D) < 1 && !dds) {                              // d factor_sn
     dst = a.lay.g_factor; off = 2 * 16 * HP + 256; perwave = true;
   }
+  // lane `sub` of an output sums the terms sub, sub + 16, ... in that order — as before, but with eight loads in flight: the
+  // per-wave outputs of a 256-slab work-item gradient are 1024 terms = 64 DEPENDENT loads per lane otherwise (29 us of a
+  // 320 us funnel K = 64 training iteration, 42 us of the named shape's)
   float v = 0.f;
   if (dst >= 0) {
-    if (!perwave) {
-      for (int sl = sub; sl < a.nslabs; sl += 16) v += a.slabs[(int64_t)sl * a.slab_stride + off];
-    } else {
-      const int tot = a.nslabs * a.nw;
-      for (int t = sub; t < tot; t += 16) {
-        const int sl = t / a.nw, q = t - sl * a.nw;
-        v += a.slabs[(int64_t)sl * a.slab_stride + base + q * per + off];
-      }
+    const int tot = perwave ? a.nslabs * a.nw : a.nslabs;
+    auto term = [&](int t) -> int64_t {
+      if (!perwave) return (int64_t)t * a.slab_stride + off;
+      const int sl = t / a.nw, q = t - sl * a.nw;
+      return (int64_t)sl * a.slab_stride + base + q * per + off;
+    };
+    int t = sub;
+    for (; t + 16 * 7 < tot; t += 16 * 8) {
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = a.slabs[term(t + 16 * u)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += x[u];
     }
+    for (; t < tot; t += 16) v += a.slabs[term(t)];
   }
   v += __shfl_xor(v, 8);
   v += __shfl_xor(v, 4);
