@@ -1185,13 +1185,30 @@ __device__ __forceinline__ void grad_geffner_tail_body(const TailArgs& a, const 
   for (int64_t t = tid; t < n_out * 16; t += stride) {
     const int64_t o = t >> 4;
     const int part = int(t & 15);
+    // (same per-lane order, eight loads — or pairs of loads — in flight instead of one dependent round trip per evaluation)
     float v = 0.f;
     if (o < IN) {
-      for (int e = part; e <= K; e += 16) v += S[(int64_t)e * HP + o];
+      int e = part;
+      for (; e + 16 * 7 <= K; e += 16 * 8) {
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = S[(int64_t)(e + 16 * u) * HP + o];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += x[u];
+      }
+      for (; e <= K; e += 16) v += S[(int64_t)e * HP + o];
     } else {
       const int j = int((o - IN) / IN), n = int((o - IN) % IN);
-      for (int e = part; e <= K; e += 16)
-        v += P[a.lay.g_emb + (int64_t)(e < K ? e : K - 1) * E + j] * S[(int64_t)e * HP + n];
+      auto emb = [&](int e) { return P[a.lay.g_emb + (int64_t)(e < K ? e : K - 1) * E + j]; };
+      int e = part;
+      for (; e + 16 * 7 <= K; e += 16 * 8) {
+        float x[8], y[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { x[u] = emb(e + 16 * u); y[u] = S[(int64_t)(e + 16 * u) * HP + n]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += x[u] * y[u];
+      }
+      for (; e <= K; e += 16) v += emb(e) * S[(int64_t)e * HP + n];
     }
 #pragma unroll
     for (int sh = 8; sh > 0; sh >>= 1) v += __shfl_xor(v, sh);
@@ -1341,12 +1358,19 @@ __global__ __launch_bounds__(256) void grad_dds_tail_sum_kernel(TailArgs a) {
   else if ((o -= 8192) < 64) { dst = a.lay.d_phase + o; xb = 384 + o; }
   float v = 0.f;
   if (dst >= 0) {
-    for (int e = sub; e < E1; e += 16) {
-      const float* row = T0 + (int64_t)e * kTailRow;
-      const float fa = xa >= 0 ? row[xa] : 1.0f;
-      const float fb = xb >= 0 ? row[xb] : S[(int64_t)e * 64 + (-xb - 1)];
-      v = fmaf(fa, fb, v);
+    // lane `sub` sums the evaluations sub, sub + 16, ... in that order, eight pairs of loads in flight (K = 256: 17 terms per
+    // lane were 17 dependent round trips of two loads)
+    auto fac_a = [&](int e) { return xa >= 0 ? T0[(int64_t)e * kTailRow + xa] : 1.0f; };
+    auto fac_b = [&](int e) { return xb >= 0 ? T0[(int64_t)e * kTailRow + xb] : S[(int64_t)e * 64 + (-xb - 1)]; };
+    int e = sub;
+    for (; e + 16 * 7 < E1; e += 16 * 8) {
+      float fa[8], fb[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { fa[u] = fac_a(e + 16 * u); fb[u] = fac_b(e + 16 * u); }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v = fmaf(fa[u], fb[u], v);
     }
+    for (; e < E1; e += 16) v = fmaf(fac_a(e), fac_b(e), v);
   }
   v += __shfl_xor(v, 8);
   v += __shfl_xor(v, 4);
