@@ -563,6 +563,14 @@ def main():
         result["second_order"] = {"workload": f"{weak.cfg_name}:MCD_CAIS_UHA_sn", "particles": n, "nbridges": ub["params_fixed"][1],
                                   "ms_per_step": tu * 1e3, "value": n * ub["params_fixed"][1] / tu, "steps": ureps,
                                   "kernel": _lib.last_kernel_name(), "n_finite": int(torch.isfinite(ur[0]).sum())}
+        # algorithmic work of a 2nd-order particle-bridge-step: TWO network evaluations on concat(z, rho) (first layer 2 d
+        # wide, time path folded as for the headline), one target gradient, ~24 flops per state dimension of (z, rho)
+        umac = (2 * dim * 64 + 64 * 64 + 64 * dim) if cfg["nn_arch"] == "dds" else \
+               (2 * dim * (2 * dim + cfg["emb_dim"]) + (2 * dim + cfg["emb_dim"]) ** 2 + (2 * dim + cfg["emb_dim"]) * dim)
+        uf = 2 * 2 * umac + {"gmm": 200, "funnel": 60, "many_gmm": 800}.get(cfg["model"], 0) + 24 * 2 * dim
+        result["second_order"]["flop_per_particle_step"] = uf
+        result["second_order"]["achieved_tflops_per_call"] = result["second_order"]["value"] * uf / 1e12
+        result["second_order"]["frac_of_fp32_peak_per_call"] = result["second_order"]["value"] * uf / 1e12 / PEAK_FP32_TFLOPS
         if not args.forward_only:
             for _ in range(3):
                 _m.compute_bound_grad(*uargs)
