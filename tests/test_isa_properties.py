@@ -115,3 +115,55 @@ def test_wave_per_tile_kernel_is_built_without_slp(traj_asm):
     body, _ = _kernel(traj_asm, "_ZN4cmcd11traj_kernelILi2ELi1ELi2ELi4EEEvNS_8TrajArgsE")
     packed = sum(1 for l in body if re.match(r"\s*v_pk_(fma|mul|add)_f32", l))
     assert packed <= 40, f"{packed} packed fp32 instructions: is -fno-slp-vectorize still applied to cmcd_kernels.hip?"
+
+
+# ---------------------------------------------------------------------------------------------- 2nd-order mode (cmcd_uha.hip)
+@pytest.fixture(scope="module")
+def uha_asm(tmp_path_factory):
+    from cmcd_amd import build
+    return _asm(tmp_path_factory, "cmcd_uha.hip", build.EXTRA_FLAGS.get("cmcd_uha.hip", []))
+
+
+# many_gmm (2), dds (1), D = 2, T = 4 on 8-particle tiles: the kernel bench.py's `second_order` line runs
+UHA_HALF = "_ZN4cmcd15uha_coop_kernelILi2ELi1ELi2ELi4ELb1EEEvNS_8TrajArgsE"
+# funnel (1), geffner (0), D = 10, T = 5 on 16-particle tiles: the instance that spilled 344 bytes per lane (and ran 21 000
+# cycles per bridge) while the roles were branches of one loop body
+UHA_FUNNEL = "_ZN4cmcd15uha_coop_kernelILi1ELi0ELi10ELi5ELb0EEEvNS_8TrajArgsE"
+
+
+def _kernel_whole(lines, mangled_prefix):
+    """Like _kernel, for kernels whose roles return separately (several s_endpgm): up to the function-end label."""
+    start = next(i for i, l in enumerate(lines) if l.startswith(mangled_prefix + ":"))
+    end = next(i for i in range(start + 1, len(lines)) if lines[i].startswith(".Lfunc_end"))
+    tail = next(i for i in range(end, len(lines)) if "ScratchSize" in lines[i])
+    return lines[start:end + 1], lines[end:tail + 1]
+
+
+def test_second_order_kernel_runs_one_loop_per_role_with_five_barriers_per_bridge(uha_asm):
+    body, _ = _kernel_whole(uha_asm, UHA_HALF)
+    barriers = [i for i, l in enumerate(body) if l.strip() == "s_barrier"]
+    # one staging barrier, two prologue barriers and five per bridge IN EACH of the three roles' own code (as branches of one
+    # shared loop body the whole kernel held nine)
+    assert len(barriers) >= 1 + 3 * (2 + 5), len(barriers)
+    # the barriers of the bridge loops wait for LDS only (the next bridge's bias row and the schedule scalars are in flight
+    # across them): at most the staging barrier in front of the loops drains vmcnt
+    drains = [body[i - 1] for i in barriers if "vmcnt(0)" in body[i - 1]]
+    assert len(drains) <= 1, drains
+    # and every role has a loop of its own: at least three depth-1 loops are followed by barriers before the next one starts
+    heads = [i for i, l in enumerate(body) if "Loop Header: Depth=1" in l] + [len(body)]
+    with_barriers = sum(any(h < b < heads[k + 1] for b in barriers) for k, h in enumerate(heads[:-1]))
+    assert with_barriers >= 3, with_barriers
+
+
+def test_second_order_kernel_on_8_particle_tiles_broadcasts_the_layer2_operand(uha_asm):
+    body, _ = _kernel_whole(uha_asm, UHA_HALF)
+    mfma = [l for l in body if "v_mfma_f32_4x4x1_16b_f32" in l]
+    assert len(mfma) >= 64          # 32 per pass, two passes per bridge
+    assert all(re.search(r"blgp:[4-7]", l) for l in mfma), "a 4x4x1 matrix instruction without the row broadcast"
+
+
+@pytest.mark.parametrize("kern", [UHA_HALF, UHA_FUNNEL], ids=["named_shape_8_tiles", "funnel_16_tiles"])
+def test_second_order_kernels_do_not_spill(uha_asm, kern):
+    _, meta = _kernel_whole(uha_asm, kern)
+    scratch = next(l for l in meta if "ScratchSize" in l)
+    assert re.search(r"ScratchSize:\s*0\b", scratch), scratch
