@@ -45,6 +45,10 @@ struct TrajArgs {
   int32_t ula;  // 0: CAIS; 1: MCD_ULA (no network); 2: MCD_ULA_sn (network in the backward kernel only, index i)
   int32_t prio = 0;  // cooperative kernel: s_setprio level per role, 2 bits each {MLP, TGT, RNG, ACC} from bit 0
   int32_t tail = 0;  // cooperative kernel, 8-particle tiles of the 9-tile net: the ninth MLP wave runs the 4-neuron form (coop_tail4)
+  // cooperative kernels: statistics merged by the LAST workgroup to arrive (no finalize launch): out[5] and an int32 arrival
+  // counter the prep launch zeroes on every call (WsLayout::b3 slot 14).  Both null: the caller launches finalize_kernel.
+  double* fin_out = nullptr;
+  int32_t* fin_counter = nullptr;
   // cmcd_debug_capture_noise (tests): the PRNG path of THIS launch, written next to the arithmetic that consumes it.
   // Stage 0 = the draw of z_0, stage i + 1 = bridge i.  All nullable.
   uint32_t* dbg_bits = nullptr;   // [K+1][n][D]  the random words that become the deviates (jax random_bits)

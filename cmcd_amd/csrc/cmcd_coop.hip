@@ -747,10 +747,30 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
   double ex = (use && mx > -INFINITY && mx < INFINITY) ? exp(-(double)loss - mx) : 0.0;
 #pragma unroll
   for (int o = 1; o < 16; o <<= 1) ex += __shfl_xor(ex, o);
+  if (!a.fin_out) {
+    if (lane == 0) {
+      double* o = a.partials + tile * CMCD_NSTATS;
+      o[0] = cnt; o[1] = sm; o[2] = sq; o[3] = mx; o[4] = ex;
+    }
+    return;
+  }
+  // Fused merge: the record goes out with agent-scope (write-through) stores, the workgroup takes a ticket, and the LAST one
+  // to arrive merges all records in finalize_kernel's order — the finalize launch (4.4 us + a kernel boundary) is gone from
+  // every forward call; the protocol is the lgcp launch sequence's (cmcd_lgcp.hip): no L2 write-back fence.
+  int last = 0;
   if (lane == 0) {
     double* o = a.partials + tile * CMCD_NSTATS;
-    o[0] = cnt; o[1] = sm; o[2] = sq; o[3] = mx; o[4] = ex;
+    __hip_atomic_store(o + 0, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(o + 1, sm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(o + 2, sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(o + 3, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(o + 4, ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0);                   // the stores are complete at agent scope once vmcnt drains
+    last = __hip_atomic_fetch_add(a.fin_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
   }
+  last = __builtin_amdgcn_readfirstlane(last);
+  if (!last) return;
+  wave_merge_stats(a.partials, (int)gridDim.x, a.fin_out, lane);
 }
 
 typedef void (*coop_fn)(TrajArgs);

@@ -658,4 +658,56 @@ struct Target<CMCD_TARGET_FUNNEL, D> {
   }
 };
 
+// The merge of the per-workgroup statistics records {count, sum, sum of squares, max, sum exp(. - max)} by ONE wave, in the
+// order of finalize_kernel (cmcd_kernels.hip) — 256 virtual threads, each a contiguous chunk of records, then the halving
+// tree — so that the fused form returns the same five doubles bit for bit.  Lane l plays virtual threads l, l + 64, l + 128,
+// l + 192.  `partials` is read with agent-scope loads: the records come from other workgroups of the same launch.
+__device__ __forceinline__ void wave_merge_stats(const double* partials, int n_rec, double* out, int lane) {
+  auto ld = [&](int64_t i) { return __hip_atomic_load(partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  const int per = (n_rec + 255) / 256;
+  double mv[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int t = lane + 64 * q, lo = t * per, hi = min(n_rec, lo + per);
+    double m = -INFINITY;
+    for (int i = lo; i < hi; ++i) m = fmax(m, ld((int64_t)i * CMCD_NSTATS + 3));
+    mv[q] = m;
+  }
+  double m = fmax(fmax(mv[0], mv[2]), fmax(mv[1], mv[3]));     // max is order-free
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+  const double M = m;
+  double acc[4][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int t = lane + 64 * q, lo = t * per, hi = min(n_rec, lo + per);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[q][k] = 0.0;
+    for (int i = lo; i < hi; ++i) {
+      const int64_t b = (int64_t)i * CMCD_NSTATS;
+      const double p0 = ld(b), p1 = ld(b + 1), p2 = ld(b + 2), p3 = ld(b + 3), p4 = ld(b + 4);
+      acc[q][0] += p0;
+      acc[q][1] += p1;
+      acc[q][2] += p2;
+      acc[q][3] += (p3 > -INFINITY && M < INFINITY) ? p4 * exp(p3 - M) : (p3 == M ? p4 : 0.0);
+    }
+  }
+  double v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    // tree steps s = 128 (t += t + 128), s = 64 (t += t + 64): inside the lane; s = 32 .. 1: t += t + s across lanes
+    const double a0 = acc[0][k] + acc[2][k], a1 = acc[1][k] + acc[3][k];
+    double x = a0 + a1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double y = __shfl_down(x, o);
+      x = lane < o ? x + y : x;
+    }
+    v[k] = x;
+  }
+  if (lane == 0) {
+    out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; out[3] = M; out[4] = v[3];
+  }
+}
+
 }  // namespace cmcd
