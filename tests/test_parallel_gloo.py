@@ -201,3 +201,46 @@ def test_sharded_reparameterised_gradient_equals_single_process():
     for r in (0, 1):
         np.testing.assert_allclose(out[r][0], g["sn"]["W3"].reshape(-1), rtol=1e-9, atol=1e-12)
         assert abs(out[r][1] - val) < 1e-9
+
+
+def _uha_worker(rank, world, port, n, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import cmcd_oracle_torch as ot
+    from oracle.cmcd_oracle import stats5
+    b = synthetic.build("gmm_n300_k8", device="cpu", boundmode="MCD_CAIS_UHA_sn", nbridges=3, init_gamma=3.0)
+    dim, K, mode, spec = b["params_fixed"]
+    p = synthetic.oracle_params(b["unflatten"], b["params_flat"])
+
+    def value_and_grad(seeds, n_total):
+        pt = ot.to_torch(p)
+        l, z = ot.losses(seeds.numpy(), pt, dim, K, mode, spec.arch, "gmm", b["cfg"]["eps_schedule"], False)
+        g_w3, g_gam = torch.autograd.grad(l.sum() / n_total, [pt["sn"]["W3"], pt["gamma"]])
+        flat = torch.cat([g_w3.reshape(-1), g_gam.reshape(-1)]).clone()
+        return flat, (l.detach(), z.detach()), torch.from_numpy(stats5(l.detach().numpy()))
+
+    r = parallel.sharded_bound_grad(torch.from_numpy(synthetic.parity_seeds(n)), value_and_grad)
+    out[rank] = (r["grad"].numpy(), float(r["mean"]), r["lo"], r["hi"])
+    dist.destroy_process_group()
+
+
+def test_sharded_second_order_gradient_equals_single_process():
+    """MCD_CAIS_UHA_sn (2nd-order CMCD, state (z, rho), no stop_gradient): the sharded value-and-gradient — local gradients
+    weighted 1 / N_total, statistics all-gather, ONE all-reduce — equals the single-process gradient of the global mean, for a
+    network leaf and for the friction gamma, which only this mode trains."""
+    from oracle import cmcd_oracle_torch as ot
+    n = 23                                                    # ragged: 12 + 11
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_uha_worker, args=(2, _free_port(), n, out), nprocs=2, join=True)
+    b = synthetic.build("gmm_n300_k8", device="cpu", boundmode="MCD_CAIS_UHA_sn", nbridges=3, init_gamma=3.0)
+    dim, K, mode, spec = b["params_fixed"]
+    p = synthetic.oracle_params(b["unflatten"], b["params_flat"])
+    val, _, _, g = ot.bound_and_grad(synthetic.parity_seeds(n), p, dim, K, mode, spec.arch, "gmm",
+                                     b["cfg"]["eps_schedule"], False)
+    want = np.concatenate([np.asarray(g["sn"]["W3"]).reshape(-1), np.asarray(g["gamma"]).reshape(-1)])
+    assert (out[0][2], out[0][3], out[1][2], out[1][3]) == (0, 12, 12, 23)
+    assert abs(want[-1]) > 0                                  # the friction's gradient is not trivially zero
+    for r in (0, 1):
+        np.testing.assert_allclose(out[r][0], want, rtol=1e-9, atol=1e-12)
+        assert abs(out[r][1] - val) < 1e-9
