@@ -68,3 +68,17 @@ def test_bench_two_ranks_share_the_gpu(hip_lib):
     assert legs["strong_sharded_cfg4"]["global_particles"] == 16000 and legs["strong_sharded_cfg4"]["particles_per_gpu"] == 8000
     assert legs["strong_sharded_cfg4"]["train_step_ms"] > 0
     assert r["roofline"]["kernel"].startswith("coop_kernel<8-particle tiles")       # asked of the library, not re-derived
+
+
+def test_bench_single_rank_over_rccl(hip_lib):
+    """The `nccl` (= RCCL) branch of bench.py on a one-GPU box: a single-rank process group — RCCL initialisation, the
+    per-step all-gather of the statistics, the all-reduce of the timings and the barriers all go through the library the
+    8-GPU run uses (two ranks cannot share one device under RCCL, so the two-rank test above runs over gloo)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29657", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--saturated", "0", "--no-legs"]
+    env = {k: v for k, v in os.environ.items() if k != "CMCD_BENCH_SHARED_GPU"}
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    r = _line(out.stdout)
+    assert r["n_gpus"] == 1 and r["config"]["workload"] == "many_gmm_n2000_k256_dds" and r["value"] > 1e8
