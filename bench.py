@@ -5,13 +5,16 @@ A "step" is one `compute_bound` forward over one batch of synthetic particles.  
 `roofline`) is the same workload at every N: the hot path named by BASELINE.json (many_gmm, MCD_CAIS_sn, N=2000,
 nbridges=256, dds net) with 2000 particles PER GPU ("scaling": "weak"), so a driver-built 1 -> 8 curve divides like by
 like.  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), particles sharded, one all-gather of the
-5-number statistics vector per step merges the ELBO mean / ln Z across ranks; in the headline every step's all-gather
-and merge COMPLETE (in stream order) before the next step's forward — what a `compute_bound` call returning the merged
-scalar costs.  Further legs are timed in the same job and reported under "legs":
+5-number statistics vector per step merges the ELBO mean / ln Z across ranks.  At N > 1 the headline is the job's
+THROUGHPUT (`headline_leg` = weak_pipelined: the all-gather of step k runs on the process group's stream beside the forward
+of step k + 1 and is merged one step late; every collective and merge inside the timed region), with the per-call-latency
+form — every step's all-gather and merge COMPLETE, in stream order, before the next step's forward — beside it in
+legs.weak and the collective's own cost in `collective`.  Legs timed in the same job and reported under "legs":
 
-  weak                 the headline measurement
-  weak_pipelined       the same with the all-gather issued async and merged one step late (its latency hidden behind
-                       the next forward): the rate of an evaluation loop that does not consume each scalar at once
+  weak                 N = 1: the headline measurement.  N > 1: all-gather + merge completed inside every step — what ONE
+                       `compute_bound` call returning the merged scalar costs
+  weak_pipelined       N > 1 (the headline there): the all-gather issued async and merged one step late — the rate of a
+                       loop of independent calls that does not consume each scalar at once
   strong_named         the named batch split over the ranks (2000 / N each) — north_star's "strong scaling", latency-bound
   strong_sharded_cfg4  BASELINE.json configs[3]: many_gmm, MCD_CAIS_var_sn, 16000 particles x 132-wide net split over
                        the ranks (the configuration BASELINE names for 8 GPUs), with its sharded VarGrad training step
