@@ -5,16 +5,16 @@ A "step" is one `compute_bound` forward over one batch of synthetic particles.  
 `roofline`) is the same workload at every N: the hot path named by BASELINE.json (many_gmm, MCD_CAIS_sn, N=2000,
 nbridges=256, dds net) with 2000 particles PER GPU ("scaling": "weak"), so a driver-built 1 -> 8 curve divides like by
 like.  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), particles sharded, one all-gather of the
-5-number statistics vector per step merges the ELBO mean / ln Z across ranks.  At N > 1 the headline is the job's
-THROUGHPUT (`headline_leg` = weak_pipelined: the all-gather of step k runs on the process group's stream beside the forward
-of step k + 1 and is merged one step late; every collective and merge inside the timed region), with the per-call-latency
-form — every step's all-gather and merge COMPLETE, in stream order, before the next step's forward — beside it in
-legs.weak and the collective's own cost in `collective`.  Legs timed in the same job and reported under "legs":
+5-number statistics vector per step merges the ELBO mean / ln Z across ranks.  At every N the headline is the PER-CALL form
+(`headline_leg` = weak): every step's all-gather and merge COMPLETE, in stream order, before the next step's forward — what
+one `compute_bound` call that returns the merged scalar costs (SURVEY.md section 8d times "the launch sequence incl. the
+collective").  The throughput form (all-gather of step k beside the forward of step k + 1) is reported beside it in
+legs.weak_pipelined and the collective's own cost in `collective`; the north_star's STRONG-scaling figures of the same job are
+at top level in `strong_scaling`.  Legs timed in the same job and reported under "legs":
 
-  weak                 N = 1: the headline measurement.  N > 1: all-gather + merge completed inside every step — what ONE
-                       `compute_bound` call returning the merged scalar costs
-  weak_pipelined       N > 1 (the headline there): the all-gather issued async and merged one step late — the rate of a
-                       loop of independent calls that does not consume each scalar at once
+  weak                 the headline measurement at every N.  N > 1: all-gather + merge completed inside every step
+  weak_pipelined       N > 1: the all-gather issued async and merged one step late — the rate of a loop of independent
+                       calls that does not consume each scalar at once (NOT the headline)
   strong_named         the named batch split over the ranks (2000 / N each) — north_star's "strong scaling", latency-bound
   strong_sharded_cfg4  BASELINE.json configs[3]: many_gmm, MCD_CAIS_var_sn, 16000 particles x 132-wide net split over
                        the ranks (the configuration BASELINE names for 8 GPUs), with its sharded VarGrad training step
@@ -141,9 +141,10 @@ def cpu_baseline(built, seeds_np, losses_hip, max_particles, min_seconds=8.0):
         prep = torch_port.Prepared(seeds_np[:n], params_np, dim, K, mode, spec.arch, cfg["model"], oracle_target(cfg),
                                    cfg["eps_schedule"], cfg["grad_clipping"])
         ncpu, was = os.cpu_count() or 1, torch.get_num_threads()
-        # (r03 on the MI355X host: 128 torch threads on these 64-wide matrices run at 6 particle-steps/s — thread hand-over,
-        # not arithmetic — against 3.8e5 on ONE thread; a 16-thread line is reported beside the all-cores line BASELINE.md asks for)
-        for tag, nt, reuse in (("torch_cpu_all_cores", ncpu, False), ("torch_cpu_16_threads", min(16, ncpu), False),
+        # (r03 on the MI355X host: one torch thread per logical CPU — 256 — on these 64-wide matrices ran at 6 particle-steps/s:
+        # thread hand-over, not arithmetic, against 3.8e5 on ONE thread.  That line was an oversubscription artefact, not a
+        # baseline, and is no longer printed; the vectorised port is timed on 16 threads and on one)
+        for tag, nt, reuse in (("torch_cpu_16_threads", min(16, ncpu), False),
                                ("torch_cpu_16_threads_reuse", min(16, ncpu), True), ("torch_cpu_1_thread", 1, False)):
             torch.set_num_threads(nt)
             # bounded samples: a 4-bridge probe of 64 particles gives the rate, the timed sample is then the largest
@@ -227,12 +228,15 @@ class Leg:
 def time_leg(leg, steps, warmup, use_dist, device, world, sharded=True, spinup=0, pipelined=False):
     """W untimed + K timed forward steps of `leg` on this rank's shard: barrier + synchronize on both sides, MAX over ranks.
     Multi-GPU: one RCCL all-gather of the 40-byte statistics vector + one merge kernel per step.
-    pipelined=False (the headline): the all-gather and the merge of step k are enqueued behind its forward and complete, in
-    stream order, before the forward of step k + 1 — the cost of a call that returns the merged scalar.
-    pipelined=True: the collective is latency-only, so it is taken off the launch stream: torch's process group runs it
-    on its own stream (async_op=True) behind an event on the forward of step k, and the launch stream waits for it only
-    after the forward of step k+1 has been enqueued — the statistics of step k are merged one step late, every step's
-    all-gather and merge still run inside the timed region (the last one is drained before the closing barrier)."""
+    pipelined=False (the headline at every N): the all-gather and the merge of step k are enqueued behind its forward and
+    complete, in stream order, before the forward of step k + 1 — the cost of a call that returns the merged scalar.
+    pipelined=True (legs.weak_pipelined only): the collective is latency-only, so it is taken off the launch stream: torch's
+    process group runs it on its own stream (async_op=True) behind an event on the forward of step k, and the launch stream
+    waits for it only after the forward of step k+1 has been enqueued — the statistics of step k are merged one step late,
+    every step's all-gather and merge still run inside the timed region (the last one is drained before the closing barrier).
+    The timed region contains NO measurement code: the per-launch HIP-event hook (cmcd_profile_enable) is off; the kernel's
+    own duration (`kern_ms` / `launches`) comes from a SECOND, separate loop of the same forward calls behind the closing
+    barrier, with the hook on and no collective."""
     from cmcd_amd import _lib, parallel
     gathered = [torch.zeros(world * parallel.NSTATS, dtype=torch.float64, device=device) for _ in range(2)]
     pending = []
@@ -269,11 +273,11 @@ def time_leg(leg, steps, warmup, use_dist, device, world, sharded=True, spinup=0
     gc.collect()
     gc_was = gc.isenabled()
     gc.disable()          # a 20-step timed region is 4 ms: one collector pause on the launching thread would be 10 % of it
+    _lib.profile_enable(False)
     for k in range(spinup + warmup):
         step(k)
     if pending:
         drain()
-    _lib.profile_enable(True)
     barrier()
     t0 = time.perf_counter()
     for k in range(steps):
@@ -282,10 +286,16 @@ def time_leg(leg, steps, warmup, use_dist, device, world, sharded=True, spinup=0
         stats = drain()   # global statistics of the last step
     barrier()
     elapsed = time.perf_counter() - t0
-    if gc_was:
-        gc.enable()
+    # kernel duration: a separate loop of the same forward calls (no collective), HIP events around every trajectory-kernel
+    # launch on the launch stream — outside the region timed above
+    _lib.profile_enable(True)
+    for k in range(min(steps, 500)):      # the hook holds 512 event pairs
+        leg.forward()
+    torch.cuda.synchronize()
     kern_ms, launches = _lib.profile_collect()
     _lib.profile_enable(False)
+    if gc_was:
+        gc.enable()
     if use_dist and sharded:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -406,7 +416,6 @@ def main():
         # the same batch with the statistics all-gather taken off the critical path (merged one step late)
         tp = time_leg(weak, args.steps, args.warmup, use_dist, device, world, spinup=0, pipelined=True)
         legs["weak_pipelined"] = leg_report(weak, tp, args.steps)
-        head_t = tp
         # the collective alone: all-gather of the 5 doubles + merge kernel, back to back on the launch stream, HIP events
         buf = torch.zeros(world * parallel.NSTATS, dtype=torch.float64, device=device)
         st5 = tw["stats"].clone()
@@ -480,15 +489,30 @@ def main():
                 tg = float(tt.item())
             legs["strong_sharded_cfg4"]["train_step_ms"] = tg * 1e3
             legs["strong_sharded_cfg4"]["train_value"] = cfg4.n_global * cfg4.K / tg
+            if world > 1:
+                # the same job's single-GPU training step: rank 0 runs the un-split VarGrad value + gradient alone
+                if rank == 0:
+                    sargs = gargs + ()
+                    skw = dict(eps_schedule=cfg4.b["eps_schedule"], grad_clipping=cfg4.b["grad_clipping"])
+                    mcdbm.compute_log_var_grad(*sargs, **skw)
+                    torch.cuda.synchronize()
+                    ts0 = time.perf_counter()
+                    for _ in range(2):
+                        mcdbm.compute_log_var_grad(*sargs, **skw)
+                    torch.cuda.synchronize()
+                    single_train_ms = (time.perf_counter() - ts0) / 2 * 1e3
+                    legs["strong_sharded_cfg4"]["train_step_single_gpu_ms"] = single_train_ms
+                    legs["strong_sharded_cfg4"]["train_step_speedup_vs_single_gpu"] = single_train_ms / (tg * 1e3)
+                dist.barrier()
         except NotImplementedError as e:
             legs["strong_sharded_cfg4"]["train_step_error"] = str(e)
 
-    # ---- headline: the named batch per GPU at every N (weak scaling; the collective completes inside every step)
-    # N > 1: the job's THROUGHPUT is the pipelined form (consecutive compute_bound calls are independent: the 40-byte
-    # all-gather of step k rides on the process group's stream beside the forward of step k + 1; every step's collective and
-    # merge run inside the timed region).  `legs.weak` beside it is the same batch with the collective completed inside
-    # every step — the latency of ONE call that returns the merged scalar — and `collective.us_per_call` its measured cost.
-    hl = legs["weak_pipelined"] if world > 1 else legs["weak"]
+    # ---- headline: the named batch per GPU at every N (weak scaling), in the PER-CALL form: every step's statistics
+    # all-gather and merge complete in stream order inside the step (legs.weak) — the cost of one compute_bound call that
+    # returns the merged scalar, which is what SURVEY.md section 8d's metric times.  The throughput form (all-gather of step k
+    # beside the forward of step k + 1) stays beside it in legs.weak_pipelined, `collective.us_per_call` is the collective alone,
+    # and `strong_scaling` lifts the strong legs' same-job speed-ups to the top level.
+    hl = legs["weak"]
     hcfg = head_leg.b["cfg"]
     f_alg, f_survey = flops_per_particle_step(hcfg, head_leg.dim, head_leg.spec.width)
     value, n, K, dim = hl["value"], head_leg.n_local, head_leg.K, head_leg.dim
@@ -519,15 +543,25 @@ def main():
         "elbo": hl["elbo"], "ln_z": hl["ln_z"], "n_finite": hl["n_finite"],
         "legs": legs,
     }
+    result["headline_leg"] = "weak"
     if world > 1:
         result["collective"] = collective
-        result["headline_leg"] = "weak_pipelined"
-        result["scaling_note"] = ("headline = the named batch (2000 particles) per GPU, the statistics all-gather of step k "
-                                  "overlapped with the forward of step k + 1 (legs.weak_pipelined; every collective and merge inside "
-                                  "the timed region); legs.weak = the same batch with all-gather + merge completed inside every "
-                                  "step (per-call latency), collective.us_per_call = the collective alone; "
-                                  "legs.strong_named / legs.strong_sharded_cfg4 split ONE batch over the ranks and carry the same "
-                                  "job's single-GPU time (speedup_vs_single_gpu)")
+        result["value_per_call"] = legs["weak"]["value"]
+        result["value_pipelined"] = legs["weak_pipelined"]["value"]
+        # the north_star's strong-scaling figures, measured in this job (one batch split over the ranks against the same batch
+        # on rank 0's GPU alone): named = 2000 particles x 256 bridges (latency-bound by construction), cfg4 = BASELINE
+        # configs[3] forward, cfg4_train_step = its sharded VarGrad value + gradient + all-reduce
+        sl = legs.get("strong_sharded_cfg4", {})
+        result["strong_scaling"] = {"named": legs.get("strong_named", {}).get("speedup_vs_single_gpu"),
+                                    "cfg4": sl.get("speedup_vs_single_gpu"),
+                                    "cfg4_train_step": sl.get("train_step_speedup_vs_single_gpu"),
+                                    "n_gpus": world, "what": "single-GPU time / sharded time, same job"}
+        result["scaling_note"] = ("headline = the named batch (2000 particles) per GPU with the statistics all-gather + merge "
+                                  "completed inside every step (legs.weak: the per-call latency of a compute_bound that returns "
+                                  "the merged scalar); legs.weak_pipelined = the throughput form (all-gather of step k beside the "
+                                  "forward of step k + 1), collective.us_per_call = the collective alone; strong_scaling = "
+                                  "legs.strong_named / legs.strong_sharded_cfg4 (ONE batch split over the ranks) against the same "
+                                  "job's single-GPU time")
     # untrained net at init_sigma = 60: some particles leave float32 range exactly as in the reference (parity.inf_set_equal),
     # so the plain mean is -inf; the mean over this rank's finite particles is reported beside it
     lfin = losses[torch.isfinite(losses)]

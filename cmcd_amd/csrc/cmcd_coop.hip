@@ -765,11 +765,15 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
     __hip_atomic_store(o + 2, sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(o + 3, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(o + 4, ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_s_waitcnt(0);                   // the stores are complete at agent scope once vmcnt drains
-    last = __hip_atomic_fetch_add(a.fin_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    // the ticket is a release (this workgroup's record happens-before it) / acquire (the last arriver sees every earlier
+    // arriver's record) read-modify-write at agent scope: a well-defined protocol under the HIP memory model, not one that
+    // leans on the write-through stores draining in program order.  Only grids of <= 64 workgroups take this path, one lane
+    // each, once per launch: the L2 write-back the release implies has nothing to write (the records went out write-through)
+    last = __hip_atomic_fetch_add(a.fin_counter, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
   }
   last = __builtin_amdgcn_readfirstlane(last);
   if (!last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the other lanes of the merging wave read the records too
   wave_merge_stats(a.partials, (int)gridDim.x, a.fin_out, lane);
 }
 

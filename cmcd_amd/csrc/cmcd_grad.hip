@@ -37,6 +37,7 @@
 // Widths <= 64 keep W2 / W2^T fragments in LDS with 4 tiles per workgroup; the 132-wide net (T = 9) runs 3
 // tiles per workgroup (3 accumulator row tiles per wave) and streams both fragment copies from L2.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -1416,12 +1417,12 @@ bool bptt_available(const cmcd_desc& d, int T) { return pick_grad(d, T, true) !=
 // Work-item (small-batch) path: worthwhile while whole-chain waves cannot fill the chip.  cmcd_debug_grad_item(0 / 1)
 // pins it process-wide (tests and probes run every case through both paths; the Python binding forwards
 // CMCD_GRAD_ITEM from the environment), -1 returns to the measured rule.  No getenv on the per-call path.
-static int grad_item_override = -1;   // process-wide (diagnostic)
-void set_grad_item_override(int v) { grad_item_override = v; }
-int get_grad_item_override() { return grad_item_override; }
+static std::atomic<int> grad_item_override{-1};   // process-wide (diagnostic); host threads may call concurrently
+void set_grad_item_override(int v) { grad_item_override.store(v, std::memory_order_relaxed); }
+int get_grad_item_override() { return grad_item_override.load(std::memory_order_relaxed); }
 bool grad_item_mode(const cmcd_desc& d, int T, int64_t n) {
   if (pick_grad(d, T, false, true) == nullptr) return false;
-  if (grad_item_override >= 0) return grad_item_override != 0;
+  if (const int ov = get_grad_item_override(); ov >= 0) return ov != 0;
   // measured crossover on MI355X (tools/probes/grad_item_sweep.py, dds net, K = 256): ~11k particles for the
   // reparameterised gradient (it pays the Jacobian pass), ~17k for the local one
   // the 132-wide net (3-wave workgroups, fragments from L2) is faster item-wise at every size measured (N = 2000:

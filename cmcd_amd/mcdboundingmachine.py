@@ -161,7 +161,7 @@ def initialize(
 
 # --------------------------------------------------------------------------- the HIP call
 _workspaces = {}
-_WORKSPACE_CACHE = 16    # (device, stream, purpose) entries kept; beyond that the least recently used buffer is released
+_WORKSPACE_CACHE = 16    # (stream, purpose) entries kept PER DEVICE; beyond that the least recently used buffer is released
 
 # Kernel variant handed to the library in cmcd_desc.reserved: 0 = auto (library heuristic),
 # 1 = wave-per-tile kernel, 2 = CU-cooperative kernel (library picks the tile), 3 / 4 = cooperative on 16- / 8-particle
@@ -173,18 +173,28 @@ def _workspace(device, nbytes, tag=""):
     """Scratch buffer of one (device, HIP stream, purpose): calls enqueued on different streams of one device — from
     one host thread or several — never share a workspace, so they may overlap on the GPU (include/cmcd_hip.h: the
     library itself keeps nothing between calls).  Calls on the same stream are ordered and reuse the buffer."""
-    capturing = torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing()
+    dev = torch.device(device)
+    is_cuda = dev.type == "cuda"
+    if is_cuda:
+        # the capture status and the stream handle are both those of `device` — which need not be the current device
+        with torch.cuda.device(dev):
+            capturing = torch.cuda.is_current_stream_capturing()
+            stream = torch.cuda.current_stream().cuda_stream
+            dev_key = torch.cuda.current_device()       # "cuda" and "cuda:0" are one device
+    else:
+        capturing, stream, dev_key = False, 0, str(dev)
     if capturing:
         # inside torch.cuda.graph(): the buffer must come from (and stay with) the graph's private pool, so it is neither
         # taken from the cache nor put into it — an eager call that later runs on a recycled stream handle never sees it
         return torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0, tag)
-    ws = _workspaces.pop(key, None)          # re-inserted below: the dict is ordered by last use
+    per_dev = _workspaces.setdefault(dev_key, {})      # one LRU per device: a busy device never evicts another's buffers
+    key = (stream, tag)
+    ws = per_dev.pop(key, None)              # re-inserted below: the dict is ordered by last use
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-    _workspaces[key] = ws
-    while len(_workspaces) > _WORKSPACE_CACHE:     # least recently used first: streams that died, one-off streams
-        _workspaces.pop(next(iter(_workspaces)))
+    per_dev[key] = ws
+    while len(per_dev) > _WORKSPACE_CACHE:         # least recently used first: streams that died, one-off streams
+        per_dev.pop(next(iter(per_dev)))
     return ws
 
 

@@ -142,8 +142,9 @@ int cmcd_bound_forward(const cmcd_desc* desc, const cmcd_layout* layout,
 
 /* ---- Measurement and diagnostic hooks: NOT part of the product path.  Nothing a result depends on goes through them;
  * they exist for bench.py (kernel time, kernel name) and the PRNG parity test, are per host thread, and a deployment can
- * leave them unbound.  (The CMCD_COOP_PRIO / CMCD_GRAD_ITEM environment overrides are read once per process, for the
- * probes under tools/probes only.) */
+ * leave them unbound.  (The library reads ONE environment variable, CMCD_COOP_PRIO, once per process, for the probes under
+ * tools/probes.  CMCD_GRAD_ITEM is NOT read by the library: only the Python binding forwards it, through
+ * cmcd_debug_grad_item below — a C caller that sets the variable gets the measured batch-size rule.) */
 
 /* Name of the trajectory kernel (or launch sequence) the last cmcd_bound_forward of this host thread enqueued, e.g.
  * "coop_kernel<8-particle tiles>", "traj_kernel", "uha_traj_kernel", "lgcp launch sequence"; "" before the first call.

@@ -28,7 +28,8 @@ def test_bench_single_gpu_line(hip_lib):
     r = _line(out.stdout)
     for f in FIELDS:
         assert f in r, f
-    assert r["n_gpus"] == 1 and r["steps"] == 3 and r["scaling"] == "weak" and r["value"] > 1e8
+    assert r["n_gpus"] == 1 and r["steps"] == 3 and r["scaling"] == "weak" and r["value"] > 1e8 and r["headline_leg"] == "weak"
+    assert "torch_cpu_all_cores" not in json.dumps(r)
     assert r["roofline"]["frac"] > 0 and r["config"]["workload"] == "many_gmm_n2000_k256_dds"
     # the N = 1 points of the scaling legs ride in the same line
     legs = r["legs"]
@@ -52,15 +53,21 @@ def test_bench_two_ranks_share_the_gpu(hip_lib):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     r = _line(out.stdout)
-    # the headline is ONE workload at every N: the named batch per GPU (weak scaling); at N > 1 its throughput form (the
-    # collective of step k overlapped with the forward of step k + 1), the per-call-latency form beside it in legs.weak
+    # the headline is ONE workload at every N: the named batch per GPU (weak scaling) in the PER-CALL form (all-gather +
+    # merge completed inside every step, legs.weak); the throughput form rides beside it in legs.weak_pipelined
     assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["config"]["workload"] == "many_gmm_n2000_k256_dds"
     assert r["config"]["global_particles"] == 4000 and r["config"]["particles_per_gpu"] == 2000 and r["value"] > 1e6
     assert r["collective"]["us_per_call"] > 0 and r["collective"]["bytes_per_rank"] == 40
     legs = r["legs"]
     assert set(legs) == {"weak", "weak_pipelined", "strong_named", "strong_sharded_cfg4"}
-    assert legs["weak_pipelined"]["value"] == pytest.approx(r["value"]) and r["headline_leg"] == "weak_pipelined"
+    assert legs["weak"]["value"] == pytest.approx(r["value"]) and r["headline_leg"] == "weak"
+    assert r["ms_per_step"] == pytest.approx(legs["weak"]["ms_per_step"])
+    assert r["value_per_call"] == pytest.approx(r["value"]) and r["value_pipelined"] == pytest.approx(legs["weak_pipelined"]["value"])
     assert legs["weak_pipelined"]["global_particles"] == 4000
+    # the north_star's strong-scaling figures at the top level of the line
+    ss = r["strong_scaling"]
+    assert ss["n_gpus"] == 2 and ss["named"] == pytest.approx(legs["strong_named"]["speedup_vs_single_gpu"])
+    assert ss["cfg4"] == pytest.approx(legs["strong_sharded_cfg4"]["speedup_vs_single_gpu"]) and ss["cfg4_train_step"] > 0
     # whole-job units: both ranks' particles counted
     # (two processes time-slice one GPU and gather over gloo through the host here: the rates themselves mean nothing)
     assert legs["weak"]["global_particles"] == 4000 and legs["weak"]["particles_per_gpu"] == 2000

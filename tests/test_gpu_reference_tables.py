@@ -4,7 +4,7 @@ tools/make_notebook_tables.py with the .ipynb line of every value).
 
 The reference's replicate command lines (/root/reference/README.md:53,63,73) are run flag for flag through
 cmcd_amd.main — HIP forward, reparameterised HIP gradient, fused Adam, 30 x n_samples evaluation — with three training
-seeds each for the funnel rows (all six bridge counts), eight for the widely spread gmm row (envelope + lower-end check), one for the
+seeds each for the funnel rows (all six bridge counts), eight for the widely spread gmm row (unselected seed mean), one for the
 three lgcp modes.  The stored value is ONE trained model of the reference (sigma_notebook = the spread of its 30 evaluation
 groups), so the difference between it and the mean of n training seeds of this build has variance
 sigma_notebook^2 + sigma_train^2 (1 + 1 / n); the test holds it to 3 of those sigmas, with sigma_train = the sample sigma
@@ -64,27 +64,35 @@ def test_trained_bound_reproduces_the_reference_notebook_table(hip_lib, model, k
     assert mean[0] < mean[1] + 0.02 and abs(mean[1]) < 0.5
 
 
-def test_gmm_runs_stay_in_the_measured_envelope_and_its_lower_end_is_the_notebooks(hip_lib):
+def test_gmm_seed_mean_against_the_notebook_row(hip_lib):
     """gmm K = 8 (README.md:73 flags) spreads WIDELY over training seeds in this build: ten seeds of r02 ended between -0.69 and
-    -0.43 (profiles/r02_gmm_training_seed_spread.txt: five near -0.65, five near -0.48 — read as two modes then), eight
-    seeds of r03 filled the gap (-0.660, -0.610, -0.603, -0.597, -0.575, -0.533, -0.448, -0.425: a continuum; where a seed
-    lands flips with last-bit changes — the gradient tails sum with float atomics).  A +-3 sigma interval around the seed
-    mean pins nothing there, and a two-mode partition does not exist, so the check is: (i) every one of eight seeds ends
-    inside the measured envelope, (ii) the notebook's single stored run (-0.6937 +- 0.0525, ipynb:554; ln Z -0.1358 +-
-    0.0835) sits at its LOWER end and the three lowest seeds reproduce it (3 sigma of the notebook's evaluation spread and
-    theirs), (iii) every run respects ELBO <= ln Z ~ 0 of the normalised target."""
+    -0.43 (profiles/r02_gmm_training_seed_spread.txt), eight seeds of r03 between -0.660 and -0.425 (mean -0.556, sample sigma
+    0.083: a continuum; where a seed lands flips with last-bit changes — the gradient tails sum with float atomics).  The
+    notebook stores ONE trained model (-0.6937 +- 0.0525 over its 30 evaluation groups, ipynb:554; ln Z -0.1358 +- 0.0835).
+
+    The comparison is UNSELECTED (r04; the r03 form compared the three lowest of eight seeds with the notebook, which passes
+    by construction): the mean of ALL eight seeds against the stored run, whose difference has variance
+    sigma_notebook^2 + sigma_train^2 (1 + 1 / n) when the notebook's model is one more draw from the same training-seed
+    distribution — the same rule as the funnel rows above.  Measured: the seed mean sits ~0.14 ABOVE the notebook's run
+    (1.3 of those sigmas; 2.6 sigma_notebook alone).  The restatement-trained model (tests/golden/oracle_trained_rows.json:
+    -0.533) lands at the same place as the HIP-trained ones, so the offset is not the kernels'; it is recorded as a known
+    deviation in DESIGN.md section 5b, and this test fails if it grows beyond 3 sigma of the combined spread."""
     ref = _row("gmm", 8)
-    runs = np.array([_run("gmm", 8, s) for s in range(1, 9)])
-    order = np.argsort(runs[:, 0])
-    elbo, lnz = runs[order, 0], runs[order, 1]
-    print("gmm K=8 per seed (sorted by ELBO)", runs[order].tolist())
+    n = 8
+    runs = np.array([_run("gmm", 8, s) for s in range(1, n + 1)])
+    elbo, lnz = runs[:, 0], runs[:, 1]
+    mean, std = runs.mean(0), runs.std(0, ddof=1)
+    z = []
+    for q, key in ((0, "elbo"), (1, "ln_Z")):
+        sig = np.sqrt(ref[key + "_std"] ** 2 + std[q] ** 2 * (1.0 + 1.0 / n))
+        z.append((mean[q] - ref[key]) / sig)
+    print(f"gmm K=8 over {n} training seeds: ELBO {mean[0]:.4f} +- {std[0]:.4f} (reference {ref['elbo']:.4f} +- {ref['elbo_std']:.4f}: "
+          f"{z[0]:+.2f} combined sigma), ln Z {mean[1]:.4f} +- {std[1]:.4f} (reference {ref['ln_Z']:.4f} +- {ref['ln_Z_std']:.4f}: "
+          f"{z[1]:+.2f}); per seed {runs.tolist()}")
+    assert abs(z[0]) <= 3.0 and abs(z[1]) <= 3.0, z
+    # the seed spread itself must stay what was measured (a collapsed or exploded spread would make the rule above vacuous)
+    assert 0.02 < std[0] < 0.15, std
     assert np.all((elbo > -0.80) & (elbo < -0.35)), elbo
-    lo_e, lo_z = elbo[:3], lnz[:3]
-    tol_e = 3.0 * np.sqrt(ref["elbo_std"] ** 2 + lo_e.var(ddof=1) / 3)
-    tol_z = 3.0 * np.sqrt(ref["ln_Z_std"] ** 2 + lo_z.var(ddof=1) / 3)
-    assert abs(lo_e.mean() - ref["elbo"]) <= tol_e, (lo_e.mean(), ref["elbo"], tol_e)
-    assert abs(lo_z.mean() - ref["ln_Z"]) <= tol_z, (lo_z.mean(), ref["ln_Z"], tol_z)
-    assert ref["elbo"] < np.median(elbo), "the notebook's run is expected at the lower end of this build's seeds"
     assert np.all(elbo < lnz + 0.05) and np.all(np.abs(lnz) < 0.5)      # normalised target: ELBO <= ln Z = 0
 
 

@@ -213,10 +213,11 @@ def test_training_lowers_the_loss(hip_lib):
 
 
 # ---------------------------------------------------------------------------------------------- lgcp (d = 1600)
-@pytest.mark.parametrize("n,k", [(20, 8), (5, 3), (40, 2), (20, 32)])
+@pytest.mark.parametrize("n,k", [(20, 8), (5, 3), (40, 2), (20, 32), (20, 128)])
 def test_lgcp_matches_oracle(hip_lib, param_set, n, k):
     """d = 1600, geffner net on concat(z, rho): width 2 * 1600 + 20 = 3220 (the reference's lgcp runs of this mode,
-    /root/reference/src/notebooks/plotting_rebuttal.ipynb:3538-3548).  40 particles = two passes of the 32-row GEMM."""
+    /root/reference/src/notebooks/plotting_rebuttal.ipynb:3538-3548).  40 particles = two passes of the 32-row GEMM;
+    (20, 128) is the configuration's own size (BASELINE.json configs[4] on this mode; /root/reference/src/mcd_under_lp_a_cais.py:42-88)."""
     from helpers import lgcp_counts_fixture
     counts = lgcp_counts_fixture()
     b = synthetic.build("lgcp_n20_k128", device="cuda", lgcp_counts=counts, boundmode=MODE, nbridges=k, init_eps=0.02,
@@ -230,6 +231,37 @@ def test_lgcp_matches_oracle(hip_lib, param_set, n, k):
     rep = compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"UHA lgcp n={n} k={k}")
     print("UHA lgcp", n, k, rep, "mean loss", float(val), l_ref.mean())
     assert abs(float(val) - losses.double().mean().item()) <= 1e-5 * abs(l_ref.mean())
+
+
+@pytest.mark.parametrize("n,k,reps", [(20, 128, 100), (40, 8, 30)])
+def test_lgcp_repeat_calls_are_bitwise_identical(hip_lib, n, k, reps):
+    """The 2nd-order launch sequences on d = 1600 at the configuration's size, the same call `reps` times: forward (8 GEMM
+    launches per bridge) and the reverse sweep must return bit-identical results every time.  Every launch carries the
+    split-K ticket protocol of cmcd_lgcp.hip (K-slice workgroups of a column block count arrivals on a device counter, the
+    last one sums the slabs in fixed order and runs the fused consumer) — this sequence has more seams per bridge than the
+    overdamped one stressed in tests/test_gpu_fullsize.py: a missing release / acquire would show as a stale slab, i.e. a
+    run-to-run difference.  (40, 8) runs two concurrent passes on side streams."""
+    from helpers import lgcp_counts_fixture
+    b = synthetic.build("lgcp_n20_k128", device="cuda", lgcp_counts=lgcp_counts_fixture(), boundmode=MODE, nbridges=k, N=n,
+                        dense=True, init_eps=0.02, init_gamma=5.0)
+    seeds = torch.from_numpy(synthetic.throughput_seeds(n, stream=4)).cuda()
+    args = (b["params_flat"], b["unflatten"], b["params_fixed"], b["target"])
+    l0, z0, s0 = mcdbm.bound_forward(seeds, *args)
+    torch.cuda.synchronize()
+    assert torch.isfinite(l0).all()
+    for r in range(reps):
+        l, z, st = mcdbm.bound_forward(seeds, *args)
+        assert torch.equal(l, l0) and torch.equal(z, z0) and torch.equal(st, s0), f"forward repeat {r} differs"
+    g0, (lg0, _) = mcdbm.compute_bound_grad(seeds, *args)
+    torch.cuda.synchronize()
+    assert torch.equal(lg0, l0) and torch.isfinite(g0).all()
+    for r in range(max(reps // 5, 6)):
+        g, (lg, _) = mcdbm.compute_bound_grad(seeds, *args)
+        assert torch.equal(lg, l0) and torch.equal(g, g0), f"gradient repeat {r} differs"
+    # batch-composition invariance: a particle's loss does not depend on its row / pass
+    perm = torch.from_numpy(np.random.default_rng(1).permutation(n)).cuda()
+    lp, _, _ = mcdbm.bound_forward(seeds[perm], *args)
+    assert torch.equal(lp, l0[perm])
 
 
 @pytest.mark.parametrize("n,K", [(5, 3), (37, 2)])
