@@ -51,7 +51,7 @@ def kernel_sources_sha():
     """Identifies the kernel build a stored PMC figure belongs to: sha1 over the HIP sources of the trajectory kernels."""
     import hashlib
     h = hashlib.sha1()
-    for f in ("cmcd_coop.hip", "cmcd_kernels.hip", "cmcd_device.h", "cmcd_common.h", "cmcd_lgcp.hip"):
+    for f in ("cmcd_coop.hip", "cmcd_kernels.hip", "cmcd_device.h", "cmcd_common.h", "cmcd_lgcp.hip", "cmcd_lgcp_wide.hip"):
         with open(os.path.join(ROOT, "cmcd_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

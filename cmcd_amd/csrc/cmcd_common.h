@@ -100,6 +100,17 @@ int64_t lgcp_workspace_floats(const cmcd_desc& d, int64_t n, int64_t base);
 int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, const int32_t* seeds, int64_t n,
                  const float* params, const float* tc, float* ws, float* out_loss, float* out_z,
                  double** partials_out, float* traj, void* stream);
+// cmcd_lgcp_wide.hip: forward-only calls on wide batches (>= kLgcpWideMin particles): whole-batch launches of a real fp32
+// GEMM body (32 x 128 tiles over the whole contraction, no split-K seam) instead of 32-row weight-streaming passes
+constexpr int64_t kLgcpWideMin = 160;   // measured crossover (profiles/r04_b_lgcp_wide_first_timing.txt: 128 particles 13.3 vs 10.5 ms, 256: 13.3 vs 20.6)
+bool lgcp_wide_supported(const cmcd_desc& d);
+bool lgcp_use_wide(const cmcd_desc& d, int64_t n, bool keeps_trajectory);    // the one selection rule (workspace query + launch)
+int64_t lgcp_wide_workspace_floats(const cmcd_desc& d, int64_t n, int64_t base);
+int lgcp_wide_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, const int32_t* seeds, int64_t n,
+                      const float* params, const float* tc, float* ws, float* out_loss, float* out_z,
+                      double** partials_out, void* stream);
+// per-bridge first-layer bias table b1 + emb[min(i, K-1)] W1[d:, :] -> bias1[K+1][IN] (cmcd_lgcp.hip's prep launch)
+int lgcp_launch_prep(const cmcd_desc& d, const cmcd_layout& lay, const float* params, float* bias1, void* stream);
 // reverse sweep of the reparameterised gradient on the d = 1600 path (cmcd_lgcp.hip); traj as left by lgcp_forward
 int64_t lgcp_grad_workspace_floats(const cmcd_desc& d, int64_t n);
 int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, int64_t n, const float* params,

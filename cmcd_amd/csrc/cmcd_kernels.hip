@@ -1108,7 +1108,9 @@ static int forward_impl(const cmcd_desc* desc, const cmcd_layout* lay, const int
     SchedArgs sa{params, wsf, *lay, lw, (int32_t)K, d.ngrid, dl.eps_schedule, -1, -1};
     hipLaunchKernelGGL(prep_sched_kernel, dim3(1), dim3(256), 0, st, sa);
     double* partials = nullptr;
-    snprintf(g_kernel_name, sizeof(g_kernel_name), "lgcp launch sequence (skinny GEMMs + state kernels)");
+    snprintf(g_kernel_name, sizeof(g_kernel_name), "%s", lgcp_use_wide(dl, n, traj != nullptr)
+                 ? "lgcp wide-batch sequence (32x128-tile fp32 GEMM launches)"
+                 : "lgcp launch sequence (skinny GEMMs + state kernels)");
     rc = lgcp_forward(dl, *lay, lw, seeds, n, params, target_consts, wsf, out_loss, out_z, &partials, traj, stream_);
     if (rc != CMCD_OK) return fail(rc, "lgcp launch sequence failed%s");
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, partials, (int32_t)n, out_stats);

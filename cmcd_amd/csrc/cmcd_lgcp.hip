@@ -20,6 +20,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "cmcd_common.h"
 #include "cmcd_device.h"
 #include "cmcd_hip.h"
@@ -813,9 +815,24 @@ static int lgcp_uha_forward(const cmcd_desc& d, const cmcd_layout& lay, const Ws
                             const float* params, const float* tc, float* ws, float* out_loss, float* out_z,
                             double** partials_out, float* traj, hipStream_t stream);
 
+// desc.reserved (the kernel-variant hook of tests / probes): 1 pins the 32-row passes, 2 the wide-batch path
+bool lgcp_use_wide(const cmcd_desc& d, int64_t n, bool keeps_trajectory) {
+  if (keeps_trajectory || !lgcp_wide_supported(d) || d.reserved == 1) return false;
+  return d.reserved == 2 || n >= kLgcpWideMin;
+}
+
 int64_t lgcp_workspace_floats(const cmcd_desc& d, int64_t n, int64_t base) {
   if (d.mode == CMCD_MODE_CAIS_UHA_SN) return lgcp_uha_ws_total(d, n, base);
-  return lgcp_ws(d, n, base).total;
+  // a gradient call keeps the trajectory and stays on the 32-row passes: the query covers whichever form the call takes
+  const int64_t narrow = lgcp_ws(d, n, base).total;
+  return lgcp_use_wide(d, n, false) ? std::max(narrow, lgcp_wide_workspace_floats(d, n, base)) : narrow;
+}
+
+int lgcp_launch_prep(const cmcd_desc& d, const cmcd_layout& lay, const float* params, float* bias1, void* stream) {
+  const int D = d.dim, E = d.emb_dim, IN = D + E, K = d.nbridges;
+  LgcpPrepArgs pa{params, bias1, lay, D, E, K, IN};
+  hipLaunchKernelGGL(lgcp_prep_kernel, dim3((IN + 255) / 256, K + 1), dim3(256), 0, static_cast<hipStream_t>(stream), pa);
+  return hipGetLastError() == hipSuccess ? CMCD_OK : CMCD_ERR_HIP;
 }
 
 static int lgcp_gemm_attrs() {
@@ -836,6 +853,8 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (d.mode == CMCD_MODE_CAIS_UHA_SN)
     return lgcp_uha_forward(d, lay, sw, seeds, n, params, tc, ws, out_loss, out_z, partials_out, traj, stream);
+  if (lgcp_use_wide(d, n, traj != nullptr))
+    return lgcp_wide_forward(d, lay, sw, seeds, n, params, tc, ws, out_loss, out_z, partials_out, stream_);
   const int D = d.dim, E = d.emb_dim, IN = D + E, K = d.nbridges;
   const LgcpWs w = lgcp_ws(d, n, sw.total_floats);
   if (d.mode != CMCD_MODE_ULA) {   // MCD_ULA has no network leaves at all

@@ -1,0 +1,547 @@
+// lgcp (d = 1600, geffner net of width 1620) on WIDE batches — the reference's evaluation batches (`opt.sample`,
+// /root/reference/src/opt.py:167-197: n_input_dist_seeds x n_samples = 30 x 500 particles, README.md:63) and any other
+// forward-only call of >= kWideMin particles.
+//
+// cmcd_lgcp.hip serves <= 32 particles per pass: there one evaluation is three weight-STREAMING skinny GEMMs (41.5 MB of
+// weights per pass and evaluation) and a batch of 600 re-streams the weights nineteen times.  Above ~50 particles per weight
+// pass the evaluation is matrix-pipe bound (2 N FLOP per 4 weight bytes against a machine balance of
+// ~25 FLOP / B), so this file runs the same per-evaluation launch sequence
+//   A: x W1[:d]           -> u1 = [x; emb_i] + softplus(. + bias1_i)                                nn.py:45-50,68
+//   B: u1 W2              -> u2 = u1 + softplus(. + b2)          and   (x - mu0) K^-1 -> kr          model_handler.py:386-396
+//   C: u2 W3              -> the state update of evaluation i (closes step i-1, opens step i)       mcd_cais.py:46-89
+// on ALL particles at once with a real fp32 GEMM body:
+//
+//   * a workgroup (4 waves) owns a 32-row x 128-column output tile over the WHOLE contraction: no split-K across
+//     workgroups, hence no slab / ticket / last-arriver seam and no inter-workgroup communication at all;
+//   * the contraction is split over the four WAVES in interleaved 8-deep chunks; every operand goes global -> register ->
+//     v_mfma_f32_32x32x2_f32 (exact fp32) with no LDS staging and no barrier in the loop: per chunk a wave issues one
+//     16-byte load of its activation rows (lane = row, 4 consecutive k) and four 16-byte loads of weight rows (lane = 4
+//     consecutive columns of one k row: the tile's 128 columns are FOUR 32-column MFMA blocks interleaved by column mod 4,
+//     so one load feeds four matrix instructions) — 5 loads per 16 matrix instructions (1024 matrix-pipe cycles), three
+//     chunks in flight;
+//   * the four partial tiles are summed in fixed order through LDS (67.6 KB) and the consumer runs on the summed tile:
+//     4 consecutive columns of one row per thread, vector loads / stores, per-row partial log-weights by a fixed butterfly
+//     over the 32 lanes that share the row => bitwise deterministic and independent of a particle's row or tile;
+//   * weights are re-packed once per call into zero-padded [K rounded to 32][N rounded to 128] arrays (16-byte aligned rows:
+//     `params_flat` leaves sit at arbitrary offsets) and the activations live in [rows rounded to 32][width rounded to 32]
+//     buffers whose padding stays zero, so the loop has no edge predicate;
+//   * tile -> workgroup mapping is XCD-aware: consecutive tiles (row tiles of one column tile first) go to ONE XCD, so a
+//     column tile's 850 KB of weights is fetched into one L2 instead of eight.
+//
+// The chain keys G_0 .. G_{K-1} of every particle (mcd_cais.py:66-67,87,94) are produced once per call by the init launch.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "cmcd_common.h"
+#include "cmcd_device.h"
+#include "cmcd_hip.h"
+
+namespace cmcd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kWRows = 32;       // rows of a tile (one 32x32x2 MFMA block)
+constexpr int kWCols = 128;      // columns of a tile (four interleaved MFMA blocks)
+constexpr int kRedLd = 132;      // LDS row pitch of the cross-wave sum (floats; 528 B: 16-byte aligned, off the bank period)
+constexpr int kWideLds = 4 * kWRows * kRedLd * 4;
+
+static inline int64_t rup(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+enum { WEPI_ACT1 = 1, WEPI_ACT2 = 2, WEPI_KR = 3, WEPI_STEP = 4, WEPI_STEP_NONET = 5 };
+
+struct WideSeg {
+  const float* A;    // [Mp][lda]   activations; padding rows / columns hold zeros
+  const float* W;    // [Kp][ldw]   packed weights; padding rows / columns hold zeros
+  int lda, ldw, Kp;  // Kp: multiple of 32
+  int epi;
+  float a_shift;     // the operand is A - a_shift   (K^-1 (x - mu0) without a subtraction pass)
+};
+
+struct WideStep {            // evaluation i at z_i: closes step i-1, opens step i (i = K: collects log p(z_K))
+  const float* sched;        // [K][8]
+  const float* tc;           // {Kinv[d,d], counts[d], mu0, a, lognorm}
+  float* xp;                 // [Mp][ldx]  previous z
+  const float* kr;           // [Mp][ldx]  (z - mu0) K^-1 of this evaluation (launch B)
+  const float* b3;           // packed, [Np]
+  const float* mean;         // packed vd.mean
+  const float* sd;           // packed exp(vd.logdiag)
+  const float* counts;       // packed
+  const float* factor;       // factor_sn (device scalar)
+  const uint32_t* gktab;     // [K][n][2]
+  float* wslot;              // [CT][Mp]  running sum over closed steps of (bk - fk) on the tile's columns
+  float* fkslot;             // [CT][Mp]  forward-kernel log-density of the open step on the tile's columns
+  float* lpslot;             // [CT][Mp]  log p(z_K) on the tile's columns
+  float* out_z;              // [n][D]
+  int64_t n;
+  int Mp, K, i, var_mode, grad_clipping, ula;
+};
+
+struct WideArgs {
+  WideSeg seg[2];
+  int nct0, CT, RT, M;       // column tiles of segment 0 / of the launch, row tiles, real rows
+  const float* bias;         // ACT1: bias1_i [IN] (workspace);  ACT2: packed b2
+  const float* emb;          // ACT1: emb_i [E] (params)
+  float* x;                  // [Mp][ldx]  z (read by ACT1, updated in place by STEP on the tile's own columns)
+  const float* u_prev;       // ACT2: u1
+  float* u_out;              // ACT1: u1, ACT2: u2      [Mp][ldu]
+  float* kr_out;             // KR: [Mp][ldx]
+  int D, IN, ldx, ldu;
+  WideStep st;
+};
+
+__device__ __forceinline__ float half_sum32(float v) {   // sum over the 32 lanes of a half wave, fixed butterfly
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// The state update of evaluation i for 4 consecutive columns [col, col + 4) of particle row m (the arithmetic of
+// lgcp_step_tile in cmcd_lgcp.hip: /root/reference/src/mcd_cais.py:46-89, model_handler.py:386-396); `o` = (u2 W3)[cols]
+// (NONET: `o` = the K^-1 product itself).  The three per-row partial log-weights are returned for the caller's butterfly.
+template <bool NO_NET>
+__device__ __forceinline__ void wide_step4(const WideArgs& a, int m, int col, const float (&o)[4], float& bk_s, float& fk_s,
+                                           float& lp_s) {
+  const WideStep& s = a.st;
+  const int D = a.D, H = (D + 1) / 2, i = s.i;
+  const bool last = i == s.K;
+  const float fsn = s.ula ? 0.f : 1.f;
+  const float mu0 = s.tc[(int64_t)D * D + D], pa = s.tc[(int64_t)D * D + D + 1];
+  const float clipv = s.var_mode ? 1e2f : 1e3f;
+  const bool clip_p = s.grad_clipping != 0, clip_q = clip_p && s.var_mode;
+  const float* sp = s.sched + 8 * (i > 0 ? i - 1 : 0);
+  const float pbeta = sp[0], peps = sp[1], pcst = sp[3], pinv2s2 = sp[4];
+  const float* sc = s.sched + 8 * (last ? s.K - 1 : i);
+  const float beta = sc[0], eps = sc[1], sig = sc[2], cst = sc[3], inv2s2 = sc[4];
+  const float fac = NO_NET ? 0.f : s.factor[0];
+  // col is a multiple of 4 and D % 4 == 0 (checked on the host): the four columns are inside or outside together
+  if (col >= D) return;
+  const int64_t ro = (int64_t)m * a.ldx + col;
+  const f32x4 zv = *reinterpret_cast<const f32x4*>(a.x + ro);
+  const f32x4 xpv = *reinterpret_cast<const f32x4*>(s.xp + ro);
+  f32x4 krv;
+  if (NO_NET) { krv[0] = o[0]; krv[1] = o[1]; krv[2] = o[2]; krv[3] = o[3]; }
+  else krv = *reinterpret_cast<const f32x4*>(s.kr + ro);
+  const f32x4 b3v = *reinterpret_cast<const f32x4*>(s.b3 + col);
+  const f32x4 mnv = *reinterpret_cast<const f32x4*>(s.mean + col);
+  const f32x4 sdv = *reinterpret_cast<const f32x4*>(s.sd + col);
+  const f32x4 cnv = *reinterpret_cast<const f32x4*>(s.counts + col);
+  uint32_t g0 = 0, g1 = 0;
+  if (!last) {
+    const uint32_t* gk = s.gktab + ((int64_t)i * s.n + m) * 2;
+    g0 = gk[0]; g1 = gk[1];
+  }
+  f32x4 znv;
+  float bk_acc = 0.f, fk_acc = 0.f, lp_acc = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = col + j;
+    const float z = zv[j], kr = krv[j], cnt = cnv[j], sd = sdv[j];
+    const float sn = NO_NET ? 0.f : (o[j] + b3v[j]) * fac;       // factor_sn (u2 W3 + b3)        nn.py:70
+    const float ez = expf(z);
+    float gp = -kr + cnt - pa * ez;                               // grad log p                    model_handler.py:386-396
+    float gq = -(z - mnv[j]) / (sd * sd);
+    if (clip_p) gp = fminf(fmaxf(gp, -clipv), clipv);
+    if (clip_q) gq = fminf(fmaxf(gq, -clipv), clipv);
+    float zn = 0.f;
+    if (i > 0) {     // backward kernel of step i-1                                                mcd_cais.py:71-86
+      const float ub = -1.0f * (pbeta * gp + (1.0f - pbeta) * gq);
+      const float bk = z - peps * ub + peps * sn;
+      const float db = xpv[j] - bk;
+      bk_acc += -(db * db) * pinv2s2 - pcst;
+    }
+    if (last) {      // log p(z_K)
+      lp_acc += -0.5f * (z - mu0) * kr + z * cnt - pa * ez;
+    } else {         // forward kernel of step i                                                   mcd_cais.py:52-67
+      // eps_i = normal(G_i, (D,)): element e is word (e >= H) of the block with counters (jj, H + jj), jj = e mod H
+      const int jj = e < H ? e : e - H;
+      uint32_t y0 = jj, y1 = (H + jj < D) ? H + jj : 0;
+      threefry2x32(g0, g1, y0, y1);
+      const float uf = -1.0f * (beta * gp + (1.0f - beta) * gq);
+      const float fk = z - eps * uf - fsn * eps * sn;
+      zn = fk + sig * bits_to_normal(e < H ? y0 : y1);
+      const float df = zn - fk;
+      fk_acc += -(df * df) * inv2s2 - cst;
+    }
+    znv[j] = zn;
+  }
+  if (last) {
+    float* oz = s.out_z + (int64_t)m * D + col;
+    oz[0] = zv[0]; oz[1] = zv[1]; oz[2] = zv[2]; oz[3] = zv[3];
+  } else {
+    *reinterpret_cast<f32x4*>(s.xp + ro) = zv;
+    *reinterpret_cast<f32x4*>(a.x + ro) = znv;
+  }
+  bk_s = bk_acc; fk_s = fk_acc; lp_s = lp_acc;
+}
+
+__global__ __launch_bounds__(256, 2) void lgcp_wide_gemm_kernel(WideArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][32 rows][kRedLd]
+  // XCD-aware tile mapping: workgroup b runs on XCD b % 8; XCD x takes the contiguous tile range [x per, (x + 1) per) of
+  // the order "row tiles of column tile 0, row tiles of column tile 1, ...", so the workgroups that share a column tile's
+  // weights share an L2
+  const int nt = a.CT * a.RT, per = (nt + 7) >> 3;
+  const int slot = blockIdx.x >> 3, t = (blockIdx.x & 7) * per + slot;
+  if (slot >= per || t >= nt) return;
+  const int ct = t / a.RT, rt = t - ct * a.RT;
+  const int sI = ct >= a.nct0 ? 1 : 0;
+  const WideSeg sg = a.seg[sI];
+  const int ctl = ct - (sI ? a.nct0 : 0), n0 = ctl * kWCols;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+  const int nch = sg.Kp >> 3, T = nch >> 2;                      // 8-deep chunks; T per wave (Kp is a multiple of 32)
+  const float* Ap = sg.A + (int64_t)(rt * kWRows + c) * sg.lda + 4 * h;
+  const float* Wp = sg.W + (int64_t)(4 * h) * sg.ldw + n0 + 4 * c;
+  const int64_t ldw = sg.ldw;
+  const float shift = sg.a_shift;
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+
+  // chunk ch = 4 tt + wave (interleaved over the waves: the workgroup walks the contraction front to back together).
+  // MFMA step s of a chunk contracts the k pair (k0 + s, k0 + 4 + s): lane half h supplies k0 + 4 h + s for both operands,
+  // so its four A values are ONE 16-byte load and step s's four B values (the four column blocks) another.
+  f32x4 av[3], bv[3][4];
+  auto issue = [&](f32x4& a_, f32x4 (&b_)[4], int tt) {
+    const int ch = min(4 * tt + wv, nch - 1);                    // past the end: a valid, unused reload of the last chunk
+    a_ = *reinterpret_cast<const f32x4*>(Ap + 8 * ch);
+    const float* wp = Wp + (int64_t)(8 * ch) * ldw;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) b_[s] = *reinterpret_cast<const f32x4*>(wp + s * ldw);
+  };
+  auto contract = [&](const f32x4& a_, const f32x4 (&b_)[4]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float as = a_[s] - shift;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(as, b_[s][j], acc[j], 0, 0, 0);
+    }
+  };
+  issue(av[0], bv[0], 0);
+  issue(av[1], bv[1], 1);
+  // Three chunks in flight; the body is UNCONDITIONAL (a branch around an issue makes the compiler's wait-count merge
+  // pessimistic: it put s_waitcnt vmcnt(0) at the loop head, draining the two younger chunks on every trip).  The last
+  // T mod 3 chunks are already in flight when the loop ends.
+  int tt = 0;
+  for (; tt + 3 <= T; tt += 3) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      issue(av[(u + 2) % 3], bv[(u + 2) % 3], tt + u + 2);
+      __builtin_amdgcn_sched_barrier(0);     // the machine scheduler otherwise sinks these loads to just before their use
+      contract(av[u], bv[u]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (tt < T) contract(av[0], bv[0]);                             // wave-uniform
+  if (tt + 1 < T) contract(av[1], bv[1]);
+
+  // ---- sum of the four waves' partial tiles, fixed order.  D layout of the MFMA: column = lane & 31 (= c, i.e. tile
+  // column 4 c + block), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+    f32x4 v;
+    v[0] = acc[0][i]; v[1] = acc[1][i]; v[2] = acc[2][i]; v[3] = acc[3][i];
+    *reinterpret_cast<f32x4*>(red + (wv * kWRows + row) * kRedLd + 4 * c) = v;
+  }
+  __syncthreads();
+  const int epi = sg.epi;
+#pragma unroll 1
+  for (int q = 0; q < 4; ++q) {
+    const int e = q * 256 + threadIdx.x, row = e >> 5, c4 = e & 31;
+    f32x4 v = *reinterpret_cast<const f32x4*>(red + row * kRedLd + 4 * c4);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(red + (w * kWRows + row) * kRedLd + 4 * c4);
+    const int m = rt * kWRows + row, col = n0 + 4 * c4;
+    const bool live = m < a.M;                                   // uniform over the 32 lanes that share the row
+    if (epi == WEPI_ACT1 || epi == WEPI_ACT2) {
+      if (live && col < a.IN) {                                  // IN % 4 == 0 (host check): four columns in or out together
+        float u[4], bb[4];
+        if (epi == WEPI_ACT1) {                                  // u = [x; emb_i]      nn.py:68-69
+          const f32x4 bv4 = *reinterpret_cast<const f32x4*>(a.bias + col);
+          bb[0] = bv4[0]; bb[1] = bv4[1]; bb[2] = bv4[2]; bb[3] = bv4[3];
+          if (col < a.D) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(a.x + (int64_t)m * a.ldx + col);
+            u[0] = xv[0]; u[1] = xv[1]; u[2] = xv[2]; u[3] = xv[3];
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) u[j] = a.emb[col - a.D + j];
+          }
+        } else {
+          const f32x4 bv4 = *reinterpret_cast<const f32x4*>(a.bias + col);
+          const f32x4 uv = *reinterpret_cast<const f32x4*>(a.u_prev + (int64_t)m * a.ldu + col);
+          bb[0] = bv4[0]; bb[1] = bv4[1]; bb[2] = bv4[2]; bb[3] = bv4[3];
+          u[0] = uv[0]; u[1] = uv[1]; u[2] = uv[2]; u[3] = uv[3];
+        }
+        f32x4 out;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[j] = u[j] + softplus(v[j] + bb[j]);        // nn.py:45-50
+        *reinterpret_cast<f32x4*>(a.u_out + (int64_t)m * a.ldu + col) = out;
+      }
+    } else if (epi == WEPI_KR) {
+      if (live && col < a.D) *reinterpret_cast<f32x4*>(a.kr_out + (int64_t)m * a.ldx + col) = v;
+    } else {
+      float bk = 0.f, fk = 0.f, lp = 0.f;
+      if (live) {
+        const float o[4] = {v[0], v[1], v[2], v[3]};
+        if (epi == WEPI_STEP) wide_step4<false>(a, m, col, o, bk, fk, lp);
+        else wide_step4<true>(a, m, col, o, bk, fk, lp);
+      }
+      bk = half_sum32(bk); fk = half_sum32(fk); lp = half_sum32(lp);
+      if (live && c4 == 0) {
+        const WideStep& s = a.st;
+        const int64_t sl = (int64_t)ctl * s.Mp + m;
+        if (s.i > 0) s.wslot[sl] += bk - s.fkslot[sl];
+        if (s.i < s.K) s.fkslot[sl] = fk;
+        else s.lpslot[sl] = lp;
+      }
+    }
+  }
+}
+
+// dst[Kp][Np] = zero-padded copy of src[K][N] (row stride lds)
+__global__ void lgcp_wide_pack_kernel(const float* __restrict__ src, int K, int N, int lds, float* __restrict__ dst, int Kp,
+                                      int Np) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+  if (n >= Np) return;
+  dst[(int64_t)k * Np + n] = (k < K && n < N) ? src[(int64_t)k * lds + n] : 0.f;
+}
+
+struct WideVecArgs {
+  const float* params;
+  const float* tc;
+  float* b2; float* b3; float* mean; float* sd; float* counts;
+  cmcd_layout lay;
+  int D, IN, NpD, NpIN, has_net;
+};
+__global__ void lgcp_wide_vec_kernel(WideVecArgs a) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < a.NpIN) a.b2[n] = (a.has_net && n < a.IN) ? a.params[a.lay.g_b2 + n] : 0.f;
+  if (n < a.NpD) {
+    const bool in = n < a.D;
+    a.b3[n] = (a.has_net && in) ? a.params[a.lay.g_b3 + n] : 0.f;
+    a.mean[n] = in ? a.params[a.lay.vd_mean + n] : 0.f;
+    a.sd[n] = in ? expf(a.params[a.lay.vd_logdiag + n]) : 1.f;
+    a.counts[n] = in ? a.tc[(int64_t)a.D * a.D + n] : 0.f;
+  }
+}
+
+// z0 = mean + std * normal(A, (D,)); w = -log q(z0); gen = second(split(first(split(B)))); then the whole key chain
+// (G_i, H_i) = split(gen_i), gen_{i+1} = second(split(H_i))      mcdboundingmachine.py:151-162, mcd_cais.py:66-67,87,94
+struct WideInitArgs {
+  const int32_t* seeds;
+  const float* params;
+  float* x;           // [Mp][ldx]
+  float* w0;          // [Mp]
+  uint32_t* gktab;    // [K][n][2]
+  cmcd_layout lay;
+  int64_t n;
+  int D, ldx, K;
+};
+
+__global__ __launch_bounds__(256) void lgcp_wide_init_kernel(WideInitArgs a) {
+  __shared__ float sh[4];
+  const int64_t p = blockIdx.x;
+  const int D = a.D, H = (D + 1) / 2;
+  const uint32_t seed = (uint32_t)a.seeds[p];
+  uint32_t s0 = 0, s1 = 2, t0 = 1, t1 = 3;
+  threefry2x32(0u, seed, s0, s1);   // block (0,2) -> out0, out2
+  threefry2x32(0u, seed, t0, t1);   // block (1,3) -> out1, out3
+  const uint32_t a0 = s0, a1 = t0, b0 = s1, b1 = t1;   // A = (out0,out1), B = (out2,out3)
+  float acc = 0.f;
+  for (int j = threadIdx.x; j < H; j += blockDim.x) {
+    uint32_t y0 = j, y1 = (H + j < D) ? H + j : 0;
+    threefry2x32(a0, a1, y0, y1);
+    const int idx[2] = {j, H + j};
+    const uint32_t bits[2] = {y0, y1};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (idx[q] < D) {
+        const float mean = a.params[a.lay.vd_mean + idx[q]];
+        const float sd = expf(a.params[a.lay.vd_logdiag + idx[q]]);
+        const float z = sd * bits_to_normal(bits[q]) + mean;
+        a.x[p * a.ldx + idx[q]] = z;
+        const float dz = z - mean;
+        acc += -(dz * dz) / (2.0f * sd * sd) - logf(sd) - kHalfLog2Pi;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a.w0[p] = -(sh[0] + sh[1] + sh[2] + sh[3]);
+    uint32_t c0 = 0, c2 = 2, c1 = 1, c3 = 3;
+    threefry2x32(b0, b1, c0, c2);
+    threefry2x32(b0, b1, c1, c3);       // C = (c0, c1)
+    uint32_t g0 = 0, g2 = 2, g1 = 1, g3 = 3;
+    threefry2x32(c0, c1, g0, g2);
+    threefry2x32(c0, c1, g1, g3);       // gen = second(split(C)) = (g2, g3)
+    uint32_t k0 = g2, k1 = g3;
+    for (int i = 0; i < a.K; ++i) {
+      uint32_t G0 = 0, h0 = 2, G1 = 1, h1 = 3;
+      threefry2x32(k0, k1, G0, h0);
+      threefry2x32(k0, k1, G1, h1);     // G = (out0, out1), H = (out2, out3)
+      uint32_t n0 = 0, n2 = 2, n1 = 1, n3 = 3;
+      threefry2x32(h0, h1, n0, n2);
+      threefry2x32(h0, h1, n1, n3);     // gen' = second(split(H))
+      uint32_t* gt = a.gktab + ((int64_t)i * a.n + p) * 2;
+      gt[0] = G0; gt[1] = G1;
+      k0 = n2; k1 = n3;
+    }
+  }
+}
+
+// loss = -(w_0 + sum over column tiles of the closed steps' (bk - fk) + log p(z_K)); fixed summation order
+struct WideFinalArgs {
+  const float* w0; const float* wslot; const float* lpslot; const float* tc;
+  float* out_loss; double* partials;
+  int64_t n;
+  int Mp, D, CT;
+};
+__global__ void lgcp_wide_final_kernel(WideFinalArgs a) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= a.n) return;
+  float w = a.w0[p], lp = 0.f;
+  for (int ct = 0; ct < a.CT; ++ct) {
+    w += a.wslot[(int64_t)ct * a.Mp + p];
+    lp += a.lpslot[(int64_t)ct * a.Mp + p];
+  }
+  w += lp + a.tc[(int64_t)a.D * a.D + a.D + 2];     // + log p(z_K)   mcdboundingmachine.py:178
+  const float loss = -w;
+  a.out_loss[p] = loss;
+  double* o = a.partials + p * CMCD_NSTATS;
+  o[0] = isfinite(loss) ? 1.0 : 0.0;
+  o[1] = loss;
+  o[2] = (double)loss * (double)loss;
+  o[3] = -(double)loss;
+  o[4] = isfinite(loss) ? 1.0 : 0.0;
+}
+
+// ------------------------------------------------------------------------------------------ host side
+struct WideWs {
+  int64_t bias1, w1p, w2p, w3p, kip, b2, b3, mean, sd, counts, x, xp, kr, u1, u2, w0, gktab, slots, partials, total;
+  int Mp, ldx, ldu, NpD, NpIN, KpD, KpIN, ctD, ctIN;
+};
+
+static WideWs wide_ws(const cmcd_desc& d, int64_t n, int64_t base) {
+  const int64_t D = d.dim, IN = D + d.emb_dim, K = d.nbridges;
+  WideWs w;
+  w.Mp = (int)rup(n, kWRows);
+  w.ldx = (int)rup(D, 32); w.ldu = (int)rup(IN, 32);
+  w.KpD = w.ldx; w.KpIN = w.ldu;
+  w.NpD = (int)rup(D, kWCols); w.NpIN = (int)rup(IN, kWCols);
+  w.ctD = w.NpD / kWCols; w.ctIN = w.NpIN / kWCols;
+  int64_t o = base;
+  auto take = [&](int64_t cnt) { int64_t r = o; o += (cnt + 3) & ~int64_t(3); return r; };
+  w.bias1 = take((K + 1) * IN);
+  w.w1p = take((int64_t)w.KpD * w.NpIN);
+  w.w2p = take((int64_t)w.KpIN * w.NpIN);
+  w.w3p = take((int64_t)w.KpIN * w.NpD);
+  w.kip = take((int64_t)w.KpD * w.NpD);
+  w.b2 = take(w.NpIN); w.b3 = take(w.NpD); w.mean = take(w.NpD); w.sd = take(w.NpD); w.counts = take(w.NpD);
+  w.x = take((int64_t)w.Mp * w.ldx); w.xp = take((int64_t)w.Mp * w.ldx); w.kr = take((int64_t)w.Mp * w.ldx);
+  w.u1 = take((int64_t)w.Mp * w.ldu); w.u2 = take((int64_t)w.Mp * w.ldu);
+  w.w0 = take(w.Mp);
+  w.gktab = take(2 * K * n);
+  w.slots = take((int64_t)3 * w.ctD * w.Mp);
+  o = (o + 1) & ~int64_t(1);
+  w.partials = take(n * CMCD_NSTATS * 2);
+  w.total = o;
+  return w;
+}
+
+bool lgcp_wide_supported(const cmcd_desc& d) {
+  const int D = d.dim, IN = D + d.emb_dim;
+  return d.mode != CMCD_MODE_CAIS_UHA_SN && D % 4 == 0 && IN % 4 == 0 && D >= 32;
+}
+
+int64_t lgcp_wide_workspace_floats(const cmcd_desc& d, int64_t n, int64_t base) { return wide_ws(d, n, base).total; }
+
+int lgcp_wide_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, const int32_t* seeds, int64_t n,
+                      const float* params, const float* tc, float* ws, float* out_loss, float* out_z,
+                      double** partials_out, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int D = d.dim, E = d.emb_dim, IN = D + E, K = d.nbridges;
+  const WideWs w = wide_ws(d, n, sw.total_floats);
+  const int ula = d.mode == CMCD_MODE_ULA ? 1 : (d.mode == CMCD_MODE_ULA_SN ? 2 : 0);
+  const bool has_net = ula != 1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(lgcp_wide_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          kWideLds) != hipSuccess)
+    return CMCD_ERR_HIP;
+  double* partials = reinterpret_cast<double*>(ws + w.partials);
+  *partials_out = partials;
+
+  // once per call: first-layer bias table, zero-padded weight copies, padded vectors, zeroed activations / slots
+  if (has_net) {
+    int rc = lgcp_launch_prep(d, lay, params, ws + w.bias1, stream);
+    if (rc != CMCD_OK) return rc;
+    auto pack = [&](const float* src, int Kr, int Nr, int64_t dst, int Kp, int Np) {
+      hipLaunchKernelGGL(lgcp_wide_pack_kernel, dim3((Np + 255) / 256, Kp), dim3(256), 0, stream, src, Kr, Nr, Nr, ws + dst, Kp, Np);
+    };
+    pack(params + lay.g_w1, D, IN, w.w1p, w.KpD, w.NpIN);     // only the state rows W1[:d]: the embedding rows are in bias1
+    pack(params + lay.g_w2, IN, IN, w.w2p, w.KpIN, w.NpIN);
+    pack(params + lay.g_w3, IN, D, w.w3p, w.KpIN, w.NpD);
+  }
+  hipLaunchKernelGGL(lgcp_wide_pack_kernel, dim3((w.NpD + 255) / 256, w.KpD), dim3(256), 0, stream, tc, D, D, D, ws + w.kip,
+                     w.KpD, w.NpD);
+  WideVecArgs va{params, tc, ws + w.b2, ws + w.b3, ws + w.mean, ws + w.sd, ws + w.counts, lay, D, IN, w.NpD, w.NpIN, has_net ? 1 : 0};
+  hipLaunchKernelGGL(lgcp_wide_vec_kernel, dim3((w.NpIN + 255) / 256), dim3(256), 0, stream, va);
+  // x | xp | kr | u1 | u2 | w0 are contiguous up to alignment: padding rows and columns must read as zeros
+  if (hipMemsetAsync(ws + w.x, 0, sizeof(float) * (size_t)(w.w0 + w.Mp - w.x), stream) != hipSuccess) return CMCD_ERR_HIP;
+  if (hipMemsetAsync(ws + w.slots, 0, sizeof(float) * (size_t)3 * w.ctD * w.Mp, stream) != hipSuccess) return CMCD_ERR_HIP;
+  WideInitArgs ia{seeds, params, ws + w.x, ws + w.w0, reinterpret_cast<uint32_t*>(ws + w.gktab), lay, n, D, w.ldx, K};
+  hipLaunchKernelGGL(lgcp_wide_init_kernel, dim3((unsigned)n), dim3(256), 0, stream, ia);
+
+  const float mu0 = 3.8812819069514780f;      // log(126) - 0.5 * 1.91 (model_handler.py:346); the state update reads tc's copy
+  WideArgs g{};
+  g.M = (int)n; g.RT = w.Mp / kWRows;
+  g.x = ws + w.x; g.D = D; g.IN = IN; g.ldx = w.ldx; g.ldu = w.ldu;
+  WideStep& st = g.st;
+  st.sched = ws + sw.sched; st.tc = tc; st.xp = ws + w.xp; st.kr = ws + w.kr; st.b3 = ws + w.b3; st.mean = ws + w.mean;
+  st.sd = ws + w.sd; st.counts = ws + w.counts; st.factor = has_net ? params + lay.g_factor : nullptr;
+  st.gktab = reinterpret_cast<const uint32_t*>(ws + w.gktab);
+  st.wslot = ws + w.slots; st.fkslot = st.wslot + (int64_t)w.ctD * w.Mp; st.lpslot = st.fkslot + (int64_t)w.ctD * w.Mp;
+  st.out_z = out_z; st.n = n; st.Mp = w.Mp; st.K = K;
+  st.var_mode = d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0; st.grad_clipping = d.grad_clipping; st.ula = ula;
+  auto launch = [&](int ct_total) {
+    g.CT = ct_total;
+    const int nt = g.CT * g.RT, per = (nt + 7) / 8;
+    hipLaunchKernelGGL(lgcp_wide_gemm_kernel, dim3(8 * per), dim3(256), kWideLds, stream, g);
+  };
+  for (int i = 0; i <= K; ++i) {
+    st.i = i;
+    if (ula == 1) {    // MCD_ULA: one launch per evaluation, (x - mu0) K^-1 with the state update as its consumer
+      g.seg[0] = WideSeg{ws + w.x, ws + w.kip, w.ldx, w.NpD, w.KpD, WEPI_STEP_NONET, mu0};
+      g.nct0 = w.ctD;
+      launch(w.ctD);
+      continue;
+    }
+    // CAIS: s(z_i, i) serves both kernels; MCD_ULA_sn: s(z_i, i - 1) serves the backward kernel only
+    const int it = ula == 2 ? (i > 0 ? i - 1 : 0) : i;
+    const int ie = it < K ? it : K - 1;
+    // A
+    g.seg[0] = WideSeg{ws + w.x, ws + w.w1p, w.ldx, w.NpIN, w.KpD, WEPI_ACT1, 0.f};
+    g.nct0 = w.ctIN;
+    g.bias = ws + w.bias1 + (int64_t)it * IN; g.emb = params + lay.g_emb + (int64_t)ie * E; g.u_out = ws + w.u1;
+    launch(w.ctIN);
+    // B: the second layer and, beside it, the K^-1 product (needs only the state; consumed by C)
+    g.seg[0] = WideSeg{ws + w.u1, ws + w.w2p, w.ldu, w.NpIN, w.KpIN, WEPI_ACT2, 0.f};
+    g.seg[1] = WideSeg{ws + w.x, ws + w.kip, w.ldx, w.NpD, w.KpD, WEPI_KR, mu0};
+    g.nct0 = w.ctIN;
+    g.bias = ws + w.b2; g.u_prev = ws + w.u1; g.u_out = ws + w.u2; g.kr_out = ws + w.kr;
+    launch(w.ctIN + w.ctD);
+    // C
+    g.seg[0] = WideSeg{ws + w.u2, ws + w.w3p, w.ldu, w.NpD, w.KpIN, WEPI_STEP, 0.f};
+    g.nct0 = w.ctD;
+    launch(w.ctD);
+  }
+  WideFinalArgs fa{ws + w.w0, st.wslot, st.lpslot, tc, out_loss, partials, n, w.Mp, D, w.ctD};
+  hipLaunchKernelGGL(lgcp_wide_final_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, fa);
+  return hipGetLastError() == hipSuccess ? CMCD_OK : CMCD_ERR_HIP;
+}
+
+}  // namespace cmcd

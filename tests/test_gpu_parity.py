@@ -74,6 +74,58 @@ def test_lgcp_matches_oracle(hip_lib, param_set, n, k):
     assert abs(float(val) - losses.double().mean().item()) <= 1e-5 * abs(l_ref.mean())
 
 
+@pytest.mark.parametrize("mode,n,k,over", [
+    ("MCD_CAIS_sn", 130, 3, {}),                                   # 4 full row tiles + 2 rows
+    ("MCD_CAIS_sn", 33, 2, dict(grad_clipping=True)),              # one row past a tile; clip on grad log p
+    ("MCD_CAIS_var_sn", 70, 2, dict(grad_clipping=True)),          # clip at 1e2 on both gradients (mcd_cais_var.py:33-40)
+    ("MCD_ULA_sn", 40, 3, {}),                                     # network in the backward kernel only (mcd_over_orig.py)
+    ("MCD_ULA", 40, 3, {}),                                        # no network: one launch per evaluation
+    ("MCD_CAIS_sn", 257, 2, dict(emb_dim=12)),                     # width 1612: other padding of rows / columns
+    ("MCD_CAIS_sn", 96, 16, dict(eps_schedule="cos_sq", init_eps=1e-3)),
+])
+def test_lgcp_wide_batch_path_matches_oracle(hip_lib, param_set, monkeypatch, mode, n, k, over):
+    """The wide-batch form of the d = 1600 path (cmcd_lgcp_wide.hip: whole-batch launches of a 32 x 128-tile fp32 GEMM body,
+    taken by forward-only calls of >= 128 particles — the reference's evaluation batches, /root/reference/src/opt.py:167-197)
+    pinned here at small sizes through the kernel-variant hook, for every mode flag of its state update, against the
+    float64 oracle AND against the 32-row launch sequence on the same seeds."""
+    from cmcd_amd import _lib
+    from helpers import lgcp_counts_fixture, oracle_target
+    counts = lgcp_counts_fixture()
+    b = synthetic.build("lgcp_n20_k128", device="cuda", lgcp_counts=counts, nbridges=k, boundmode=mode, **over)
+    dim, K, _, spec = b["params_fixed"]
+    if mode == "MCD_ULA":    # the reference keeps no network for this mode: params_fixed[3] is None
+        flat, unflatten, fixed = mcdbm.initialize(dim=dim, nbridges=K, vdparams=None, eps=b["cfg"]["init_eps"],
+                                                  trainable=("eps",), mode="MCD_ULA", device="cuda")
+        b = dict(b, params_flat=flat, unflatten=unflatten, params_fixed=fixed)
+    seeds = synthetic.parity_seeds(n)
+    fn = mcdbm.compute_bound_var if "var" in mode else mcdbm.compute_bound
+    out = {}
+    for variant in (2, 1):
+        monkeypatch.setattr(mcdbm, "KERNEL_VARIANT", variant)
+        val, (losses, z) = fn(torch.from_numpy(seeds).cuda(), b["params_flat"], b["unflatten"], b["params_fixed"],
+                              b["target"], eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
+        torch.cuda.synchronize()
+        out[variant] = (float(val), losses.cpu().numpy(), z.cpu().numpy(), _lib.last_kernel_name())
+    assert out[2][3].startswith("lgcp wide-batch") and out[1][3].startswith("lgcp launch sequence"), (out[2][3], out[1][3])
+    if mode == "MCD_ULA":
+        train, notrain = b["unflatten"](b["params_flat"].cpu())
+        allp = {**train, **notrain}
+        f = lambda t: np.asarray(t.numpy(), np.float64)
+        p = {"vd": {kk: f(v) for kk, v in allp["vd"].items()}, "eps": f(allp["eps"]), "mgridref_y": f(allp["mgridref_y"]),
+             "gridref_x": f(allp["gridref_x"]), "target_x": f(allp["target_x"])}
+        l_ref, z_ref = orc.compute_log_elbo_batch(seeds, p, dim, K, mode, "dds", oracle_target(b["cfg"], counts), dtype=np.float64)
+    elif mode == "MCD_ULA_sn":
+        p = synthetic.oracle_params(b["unflatten"], b["params_flat"])
+        l_ref, z_ref = orc.compute_log_elbo_batch(seeds, p, dim, K, mode, spec.arch, oracle_target(b["cfg"], counts), dtype=np.float64)
+    else:
+        l_ref, z_ref = run_oracle(b, seeds, dtype=np.float64, lgcp_counts=counts)
+    rep = compare_losses(out[2][1], l_ref, out[2][2], z_ref, tag=f"lgcp wide {mode} n={n} k={k}")
+    print("lgcp wide", mode, n, k, over, rep)
+    # the two forms of the path sum the contractions in different orders: float32 rounding apart, nothing else
+    np.testing.assert_allclose(out[2][1], out[1][1], rtol=2e-5, atol=2e-3)
+    np.testing.assert_allclose(out[2][2], out[1][2], rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("name,mode,n,over", [
     ("gmm_n300_k8", "MCD_ULA", 300, {}),
     ("gmm_n300_k8", "MCD_ULA_sn", 300, {}),
