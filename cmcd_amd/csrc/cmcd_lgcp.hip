@@ -625,6 +625,218 @@ __global__ __launch_bounds__(64 * (kGemmWaves + ((EPI == EPI_STEP || EPI == EPI_
 }
 
 // ------------------------------------------------------------------------------------------
+// r04: the FORWARD launch sequence on a skinny GEMM WITHOUT split-K across workgroups ("nsk").
+//
+// The split-K kernel above pays, per dependent launch, a seam inside the launch: partial slabs published write-through, an
+// arrival ticket, the last arriver reading eight slabs back (10 - 13 us per launch, 3 x 129 launches per call).  Here a
+// workgroup owns a 16-row x 16-column output tile over the WHOLE contraction and the contraction is split over its 8 WAVES
+// only (interleaved 16-deep chunks, 13 per wave for K <= 1664): the cross-wave sum goes through 8 KB of LDS and one barrier,
+// no workgroup ever waits for another, no counter, no slab.  What made the earlier no-split-K attempts slow (section 4 of
+// 10.5 / 4.9 ms) — half-used 64-byte row segments, duplicated operand rows, the load latency paid several
+// times over — is removed by PACKING both operands once so that every wave-load is 1 KB contiguous and a wave holds its whole
+// share of the contraction in registers (26 x 16-byte loads per lane, all in flight before the first wait):
+//   weights    Wp[tile = n / 16][chunk = k / 16][lane = n % 16 + 16 ((k % 16) / 4)][k % 4]   (re-packed once per call)
+//   operands   Ap[half = r / 16][chunk = k / 16][lane = r % 16 + 16 ((k % 16) / 4)][k % 4]   (written by the consumers)
+// = the operand layout of v_mfma_f32_16x16x4_f32 (A: lane -> row lane % 16, k lane / 16; B: lane -> column lane % 16, k lane /
+// 16): MFMA step s of a chunk contracts k = 16 chunk + 4 (lane / 16) + s, i.e. component s of both 16-byte loads.  A
+// workgroup's 16 x 16 outputs are ONE contiguous 1 KB block of the next launch's packed operand.
+// Measured (tools/probes/nsk_probe.hip, the three-launch chain x 129 with a stand-in state update): 3.0 ms against the
+// split-K sequence's 4.55 ms; per launch 5.1 (204 workgroups) / 9.7 (404) / 5.2 us.
+// ------------------------------------------------------------------------------------------
+constexpr int kNskChunks = 104;                  // 16-deep chunks of a packed operand (K <= 1664), 13 per wave
+constexpr int kNskCpw = kNskChunks / kGemmWaves;
+constexpr int64_t kNskOperand = (int64_t)2 * kNskChunks * 256;   // floats of one packed [32 x 1664] operand
+
+__host__ __device__ __forceinline__ int64_t nsk_pack(int r, int k) {
+  return (((int64_t)(r >> 4) * kNskChunks + (k >> 4)) * 64 + (r & 15) + 16 * ((k & 15) >> 2)) * 4 + (k & 3);
+}
+
+enum { NSK_ACT1 = 1, NSK_ACT2 = 2, NSK_KR = 3, NSK_STEP = 4, NSK_STEP_NONET = 5 };
+
+struct NskSeg {
+  const float* A;      // packed operand
+  const float* W;      // packed weights [ceil(N / 16)][kNskChunks][64][4]
+  int N, epi;
+  float a_shift;       // the operand is A - a_shift
+};
+
+struct NskArgs {
+  NskSeg seg[2];
+  int nt0;             // column tiles of segment 0
+  int M;
+  // activations
+  const float* bias;   // ACT1: bias1_i [IN];  ACT2: b2 [IN] (params)
+  const float* emb;    // ACT1: emb_i [E]
+  float* xA;           // packed z (ACT1 reads it; STEP updates the tile's own elements in place)
+  const float* uA;     // ACT2: packed u1
+  float* outA;         // ACT1: packed u1; ACT2: packed u2; KR: packed K^-1 product
+  int D, IN;
+  // state update (the fields of StepEpi; x / xp / kr in the packed layout, one value per element instead of slabs)
+  StepEpi step;
+  float* xpA;
+  const float* krA;    // STEP: the K^-1 product of this evaluation (launch B)
+  float* krOut;        // KR
+};
+
+// one element (row m of the pass, column e) of evaluation i's state update: the arithmetic of lgcp_step_tile
+template <bool NO_NET>
+__device__ __forceinline__ void nsk_step_elem(const NskArgs& a, float o, int m, int e, int tile, int lane16_reduce_ok) {
+  const StepEpi& s = a.step;
+  const int D = s.D, H = (D + 1) / 2, i = s.i;
+  const float fsn = s.ula ? 0.f : 1.f;
+  const float* counts = s.tc + (int64_t)D * D;
+  const float mu0 = s.tc[(int64_t)D * D + D], pa = s.tc[(int64_t)D * D + D + 1];
+  const float clipv = s.var_mode ? 1e2f : 1e3f;
+  const bool clip_p = s.grad_clipping != 0, clip_q = clip_p && s.var_mode;
+  const bool last = i == s.K;
+  const float* sp = s.sched + 8 * (i > 0 ? i - 1 : 0);
+  const float pbeta = sp[0], peps = sp[1], pcst = sp[3], pinv2s2 = sp[4];
+  const float* sc = s.sched + 8 * (last ? s.K - 1 : i);
+  const float beta = sc[0], eps = sc[1], sig = sc[2], cst = sc[3], inv2s2 = sc[4];
+  const bool live = lane16_reduce_ok != 0;                  // real row and column (padding lanes only join the butterfly)
+  const int ec = min(e, D - 1), mc = min(m, a.M - 1);
+  const int64_t ix = nsk_pack(mc, ec);
+  // every load first, from clamped (always valid) addresses
+  const float z = a.xA[ix], xp = a.xpA[ix];
+  const float kr = NO_NET ? o : a.krA[ix];
+  const float cnt = counts[ec], b3 = NO_NET ? 0.f : s.b3[ec];
+  const float mean = s.params[s.lay.vd_mean + ec];
+  const float sd = expf(s.params[s.lay.vd_logdiag + ec]);
+  const uint32_t* gk = s.gkey + (i & 1) * 2 * kMP;
+  const uint32_t g0 = gk[2 * mc], g1 = gk[2 * mc + 1];
+  const float fac = NO_NET ? 0.f : s.factor[0];
+  __builtin_amdgcn_sched_barrier(0);
+  const float sn = NO_NET ? 0.f : (o + b3) * fac;             // factor_sn (u2 W3 + b3)           nn.py:70
+  float bk_acc = 0.f, fk_acc = 0.f, lp_acc = 0.f, zn = 0.f;
+  const float ez = expf(z);
+  float gp = -kr + cnt - pa * ez;                             // grad log p      model_handler.py:386-396
+  float gq = -(z - mean) / (sd * sd);
+  if (clip_p) gp = fminf(fmaxf(gp, -clipv), clipv);
+  if (clip_q) gq = fminf(fmaxf(gq, -clipv), clipv);
+  if (i > 0) {   // backward kernel of step i-1                             mcd_cais.py:71-86
+    const float ub = -1.0f * (pbeta * gp + (1.0f - pbeta) * gq);
+    const float bk = z - peps * ub + peps * sn;
+    const float db = xp - bk;
+    bk_acc = -(db * db) * pinv2s2 - pcst;
+  }
+  if (last) {    // log p(z_K)
+    lp_acc = -0.5f * (z - mu0) * kr + z * cnt - pa * ez;
+  } else {       // forward kernel of step i                                mcd_cais.py:52-67
+    // eps_i = normal(G_i, (D,)): element e is word (e >= H) of the block with counters (j, H + j), j = e mod H
+    const int j = ec < H ? ec : ec - H;
+    uint32_t y0 = j, y1 = (H + j < D) ? H + j : 0;
+    threefry2x32(g0, g1, y0, y1);
+    const float uf = -1.0f * (beta * gp + (1.0f - beta) * gq);
+    const float fk = z - eps * uf - fsn * eps * sn;
+    zn = fk + sig * bits_to_normal(ec < H ? y0 : y1);
+    const float df = zn - fk;
+    fk_acc = -(df * df) * inv2s2 - cst;
+  }
+  if (live) {
+    if (last) {
+      s.out_z[(int64_t)m * D + e] = z;
+    } else {
+      a.xpA[ix] = z;
+      a.xA[ix] = zn;
+      if (s.traj) s.traj[((int64_t)(i + 1) * s.n_total + s.base + m) * D + e] = zn;
+    }
+  }
+  // per-row partial log-weights over the tile's 16 columns: the 16 lanes that share the row, fixed butterfly
+  float bk_lp = live ? bk_acc : 0.f, fk_lp = live ? fk_acc : 0.f, lp = live ? lp_acc : 0.f;
+#pragma unroll
+  for (int ofs = 8; ofs > 0; ofs >>= 1) {
+    bk_lp += __shfl_xor(bk_lp, ofs);
+    fk_lp += __shfl_xor(fk_lp, ofs);
+    lp += __shfl_xor(lp, ofs);
+  }
+  if ((threadIdx.x & 15) == 0 && m < a.M) {
+    const int sl = tile * kMP + m;
+    if (i > 0) s.wslot[sl] += bk_lp - s.fkslot[sl];
+    if (!last) s.fkslot[sl] = fk_lp;
+    else s.lpslot[sl] = lp;
+  }
+}
+
+template <bool STEP>
+__global__ __launch_bounds__(64 * (kGemmWaves + (STEP ? 1 : 0))) void lgcp_nsk_kernel(NskArgs a) {
+  __shared__ float red[kGemmWaves][256];
+  const int sI = (int)blockIdx.x >= a.nt0 ? 1 : 0;
+  const NskSeg sg = a.seg[sI];
+  const int tile = blockIdx.x - (sI ? a.nt0 : 0), half = blockIdx.y;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (wv < kGemmWaves) {
+    const f32x4* Ap = reinterpret_cast<const f32x4*>(sg.A) + ((int64_t)half * kNskChunks + wv) * 64 + lane;
+    const f32x4* Wp = reinterpret_cast<const f32x4*>(sg.W) + ((int64_t)tile * kNskChunks + wv) * 64 + lane;
+    // chunk c = wave + 8 j: at every j the workgroup reads 8 KB contiguous of either operand.  All 26 loads in flight
+    // before the first wait, chunk by chunk, so the first matrix instruction waits for two of them.
+    f32x4 av[kNskCpw], bv[kNskCpw];
+#pragma unroll
+    for (int j = 0; j < kNskCpw; ++j) { bv[j] = Wp[j * 512]; av[j] = Ap[j * 512]; }
+    __builtin_amdgcn_sched_barrier(0);        // (the machine scheduler otherwise sinks the loads to their uses: 43 registers, 26 round trips)
+    f32x4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float shift = sg.a_shift;
+#pragma unroll
+    for (int j = 0; j < kNskCpw; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][q] - shift, bv[j][q], acc[q], 0, 0, 0);
+    const f32x4 t = (acc[0] + acc[1]) + (acc[2] + acc[3]);      // fixed order
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wv][r * 64 + lane] = t[r];
+  } else if (STEP && blockIdx.x == 0 && half == 0 && a.step.i + 1 < a.step.K && lane < a.M) {
+    // the chain's key for evaluation i + 1 (a dependent integer chain of ~450 instructions) on the ninth wave of one
+    // workgroup, beside its GEMM waves
+    const StepEpi& st = a.step;
+    uint32_t k0 = st.gen[2 * lane], k1 = st.gen[2 * lane + 1], G0, G1;
+    lgcp_key_advance(k0, k1, G0, G1);
+    st.gen[2 * lane] = k0; st.gen[2 * lane + 1] = k1;
+    uint32_t* gk = st.gkey + ((st.i + 1) & 1) * 2 * kMP;
+    gk[2 * lane] = G0; gk[2 * lane + 1] = G1;
+    uint32_t* gt = st.gktab + ((int64_t)(st.i + 1) * st.n_total + st.base + lane) * 2;
+    gt[0] = G0; gt[1] = G1;
+  }
+  __syncthreads();
+  if (threadIdx.x >= 256) return;
+  // D layout of 16x16x4: column = lane % 16, row = 4 (lane / 16) + register; thread (register = wave, lane)
+  const int reg = wv;
+  float v = 0.f;
+#pragma unroll
+  for (int w = 0; w < kGemmWaves; ++w) v += red[w][reg * 64 + lane];        // fixed order
+  const int cl = lane & 15, rl = 4 * (lane >> 4) + reg;
+  const int n = tile * 16 + cl, row = half * 16 + rl;
+  const bool live = n < sg.N && row < a.M;
+  if (STEP) {
+    if (sg.epi == NSK_STEP) nsk_step_elem<false>(a, v, row, n, tile, live ? 1 : 0);
+    else nsk_step_elem<true>(a, v, row, n, tile, live ? 1 : 0);
+    return;
+  }
+  if (!live) return;
+  const int64_t ix = nsk_pack(row, n);
+  if (sg.epi == NSK_ACT1) {                                   // u = [x; emb_i]      nn.py:68-69
+    const float u = n < a.D ? a.xA[ix] : a.emb[n - a.D];
+    a.outA[ix] = u + softplus(v + a.bias[n]);                 // nn.py:45-50
+  } else if (sg.epi == NSK_ACT2) {
+    a.outA[ix] = a.uA[ix] + softplus(v + a.bias[n]);
+  } else {                                                    // NSK_KR (second segment of launch B): its own output array
+    a.krOut[ix] = v;
+  }
+}
+
+// packed copy of a [K][N] weight matrix (row stride lds): one thread per 16-byte group {k, k+1, k+2, k+3} x column
+__global__ void lgcp_nsk_pack_kernel(const float* __restrict__ src, int K, int N, int lds_, float* __restrict__ dst, int ntile) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;          // (tile, chunk, lane)
+  if (g >= (int64_t)ntile * kNskChunks * 64) return;
+  const int lane = (int)(g & 63), chunk = (int)((g >> 6) % kNskChunks), tile = (int)((g >> 6) / kNskChunks);
+  const int n = tile * 16 + (lane & 15), k0 = chunk * 16 + 4 * (lane >> 4);
+  f32x4 v;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] = (n < N && k0 + q < K) ? src[(int64_t)(k0 + q) * lds_ + n] : 0.f;
+  reinterpret_cast<f32x4*>(dst)[g] = v;
+}
+
+// ------------------------------------------------------------------------------------------
 // per-bridge first-layer bias of the 1620-wide geffner net: b1 + emb[min(i, K-1)] W1[d:, :]
 // ------------------------------------------------------------------------------------------
 struct LgcpPrepArgs {
@@ -660,6 +872,7 @@ struct LgcpStateArgs {
   int64_t n_total, base;     // trajectory row of particle p of this pass: base + p
   cmcd_layout lay;
   int M, D;
+  int packed;                // x in the packed operand layout of the no-split-K GEMM (nsk_pack)
 };
 
 __device__ __forceinline__ float block_sum_256(float v, float* sh) {
@@ -693,7 +906,7 @@ __global__ __launch_bounds__(256) void lgcp_init_kernel(LgcpStateArgs a) {
         const float mean = a.params[a.lay.vd_mean + idx[q]];
         const float sd = expf(a.params[a.lay.vd_logdiag + idx[q]]);
         const float z = sd * bits_to_normal(bits[q]) + mean;
-        a.x[p * D + idx[q]] = z;
+        a.x[a.packed ? nsk_pack(p, idx[q]) : (int64_t)p * D + idx[q]] = z;
         if (a.traj) a.traj[(a.base + p) * D + idx[q]] = z;
         const float dz = z - mean;
         acc += -(dz * dz) / (2.0f * sd * sd) - logf(sd) - kHalfLog2Pi;
@@ -763,11 +976,20 @@ __global__ void lgcp_final_kernel(LgcpFinalArgs a) {
 constexpr int kLanes = 4;
 struct LgcpLane {
   int64_t x, xp, u1, u2, pre1, pre2, kr, slab1, slab2, sn, w, keys, gkey, slots, counters;
+  int64_t nsk;          // no-split-K form: packed x | xp | u1 | u2 | kr (kNskOperand floats each), then its slots [3][D / 16][kMP]
 };
 struct LgcpWs {
   int64_t bias1, gktab, partials, total;
+  int64_t w1p, w2p, w3p, kip;    // no-split-K form: packed weights (once per call, shared by the lanes)
   LgcpLane lane[kLanes];
 };
+
+// the no-split-K forward serves operands of up to 1664 inputs (kNskChunks) whose state part is whole 16-column tiles;
+// desc.reserved == 3 pins the split-K sequence (A / B measurements, tests)
+static bool lgcp_nsk_ok(const cmcd_desc& d) {
+  const int D = d.dim, IN = D + d.emb_dim;
+  return d.reserved != 3 && D % 16 == 0 && IN <= 16 * kNskChunks && d.mode != CMCD_MODE_CAIS_UHA_SN;
+}
 
 static int lgcp_lanes(int64_t n) {
   const int64_t passes = (n + kMP - 1) / kMP;
@@ -803,6 +1025,13 @@ static LgcpWs lgcp_ws(const cmcd_desc& d, int64_t n, int64_t base) {
     } else {
       w.lane[l] = w.lane[0];
     }
+  }
+  w.w1p = w.w2p = w.w3p = w.kip = 0;
+  if (lgcp_nsk_ok(d)) {
+    const int64_t tIN = (IN + 15) / 16, tD = D / 16, per_tile = (int64_t)kNskChunks * 256;
+    w.w1p = take(tIN * per_tile); w.w2p = take(tIN * per_tile); w.w3p = take(tD * per_tile); w.kip = take(tD * per_tile);
+    for (int l = 0; l < kLanes; ++l)
+      w.lane[l].nsk = (l < lgcp_lanes(n) || l == 0) ? take(5 * kNskOperand + 3 * tD * kMP) : w.lane[0].nsk;
   }
   w.total = o;
   return w;
@@ -863,6 +1092,22 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
   }
   const int gemm_lds = lgcp_gemm_attrs();
   if (gemm_lds < 0) return CMCD_ERR_HIP;
+  // r04: the forward runs on the no-split-K GEMM (header above lgcp_nsk_kernel); weights re-packed once per call
+  const bool nsk = lgcp_nsk_ok(d);
+  const int tIN = (IN + 15) / 16, tD = D / 16;
+  if (nsk) {
+    auto pack = [&](const float* src, int Kr, int Nr, int64_t dst, int nt) {
+      const int64_t groups = (int64_t)nt * kNskChunks * 64;
+      hipLaunchKernelGGL(lgcp_nsk_pack_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, stream, src, Kr, Nr, Nr,
+                         ws + dst, nt);
+    };
+    if (d.mode != CMCD_MODE_ULA) {
+      pack(params + lay.g_w1, D, IN, w.w1p, tIN);     // the state rows W1[:d] only: the embedding rows are in bias1
+      pack(params + lay.g_w2, IN, IN, w.w2p, tIN);
+      pack(params + lay.g_w3, IN, D, w.w3p, tD);
+    }
+    pack(tc, D, D, w.kip, tD);
+  }
   const float* kinv = tc;
   double* partials = reinterpret_cast<double*>(ws + w.partials);
   *partials_out = partials;
@@ -932,8 +1177,11 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
       const LgcpLane& wl = w.lane[l];
       M[l] = (int)((n - base) < kMP ? (n - base) : kMP);
       if (hipMemsetAsync(ws + wl.slots, 0, sizeof(float) * 3 * cbD * kMP, st_l) != hipSuccess) return bail();
+      // packed operands: the padding (rows >= M, inputs >= IN) must read as zeros; slots start at zero
+      if (nsk && hipMemsetAsync(ws + wl.nsk, 0, sizeof(float) * (5 * kNskOperand + 3 * (int64_t)tD * kMP), st_l) != hipSuccess)
+        return bail();
       LgcpStateArgs st{};
-      st.seeds = seeds + base; st.params = params; st.tc = tc; st.x = ws + wl.x;
+      st.seeds = seeds + base; st.params = params; st.tc = tc; st.x = nsk ? ws + wl.nsk : ws + wl.x; st.packed = nsk ? 1 : 0;
       st.w = ws + wl.w; st.keys = reinterpret_cast<uint32_t*>(ws + wl.keys);
       st.gkey = reinterpret_cast<uint32_t*>(ws + wl.gkey); st.gktab = reinterpret_cast<uint32_t*>(ws + w.gktab);
       st.lay = lay; st.M = M[l]; st.D = D;
@@ -949,6 +1197,9 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
       se.gen = reinterpret_cast<uint32_t*>(ws + wl.keys); se.gkey = reinterpret_cast<uint32_t*>(ws + wl.gkey);
       se.gktab = reinterpret_cast<uint32_t*>(ws + w.gktab);
       se.wslot = ws + wl.slots; se.fkslot = se.wslot + cbD * kMP; se.lpslot = se.fkslot + cbD * kMP;
+      if (nsk) {   // one slot row per 16-column tile
+        se.wslot = ws + wl.nsk + 5 * kNskOperand; se.fkslot = se.wslot + tD * kMP; se.lpslot = se.fkslot + tD * kMP;
+      }
       se.out_z = out_z + base * D; se.traj = traj; se.n_total = n; se.base = base; se.lay = lay;
       se.D = D; se.K = K; se.var_mode = d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0; se.grad_clipping = d.grad_clipping;
       se.ula = ula;
@@ -962,6 +1213,32 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
         const LgcpLane& wl = w.lane[l];
         GemmArgs& gl = g[l];
         gl.step.i = i;
+        if (nsk) {
+          float* xA = ws + wl.nsk;
+          float* xpA = xA + kNskOperand, *u1A = xpA + kNskOperand, *u2A = u1A + kNskOperand, *krA = u2A + kNskOperand;
+          NskArgs na{};
+          na.M = M[l]; na.D = D; na.IN = IN; na.xA = xA; na.xpA = xpA; na.krA = krA; na.krOut = krA; na.step = gl.step;
+          const dim3 grid_y(1, M[l] > 16 ? 2 : 1);
+          auto grid = [&](int tiles) { return dim3((unsigned)tiles, grid_y.y); };
+          if (ula == 1) {   // MCD_ULA: one launch per evaluation, (x - mu0) K^-1 with the state update as its consumer
+            na.seg[0] = NskSeg{xA, ws + w.kip, D, NSK_STEP_NONET, mu0}; na.nt0 = tD;
+            hipLaunchKernelGGL(lgcp_nsk_kernel<true>, grid(tD), gblock_step, 0, st_l, na);
+            continue;
+          }
+          // A: x W1[:D] -> u1 = [x; emb_i] + softplus(. + bias1_i)
+          na.seg[0] = NskSeg{xA, ws + w.w1p, IN, NSK_ACT1, 0.f}; na.nt0 = tIN;
+          na.bias = ws + w.bias1 + (int64_t)it * IN; na.emb = params + lay.g_emb + (int64_t)ie * E; na.outA = u1A;
+          hipLaunchKernelGGL(lgcp_nsk_kernel<false>, grid(tIN), gblock, 0, st_l, na);
+          // B: u1 W2 -> u2 = u1 + softplus(. + b2)   |   (x - mu0) K^-1 -> kr
+          na.seg[0] = NskSeg{u1A, ws + w.w2p, IN, NSK_ACT2, 0.f};
+          na.seg[1] = NskSeg{xA, ws + w.kip, D, NSK_KR, mu0};
+          na.bias = params + lay.g_b2; na.uA = u1A; na.outA = u2A;
+          hipLaunchKernelGGL(lgcp_nsk_kernel<false>, grid(tIN + tD), gblock, 0, st_l, na);
+          // C: u2 W3 -> the state update of evaluation i on the tile's elements
+          na.seg[0] = NskSeg{u2A, ws + w.w3p, D, NSK_STEP, 0.f}; na.nt0 = tD;
+          hipLaunchKernelGGL(lgcp_nsk_kernel<true>, grid(tD), gblock_step, 0, st_l, na);
+          continue;
+        }
         if (ula == 1) {   // MCD_ULA: one launch per evaluation, [x - mu0] Kinv with the state update as its consumer
           gl.Kdim = D; gl.Kdim1 = 0;
           gl.seg[0] = GemmSeg{ws + wl.x, kinv, ws + wl.kr, D, D, D, D, mu0};
@@ -998,7 +1275,8 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
       hipStream_t st_l = l == 0 ? stream : side[l];
       const int64_t base = gbase + (int64_t)l * kMP;
       const StepEpi& se = g[l].step;
-      LgcpFinalArgs fa{ws + w.lane[l].w, se.wslot, se.lpslot, tc, out_loss + base, partials + base * CMCD_NSTATS, M[l], D, cbD};
+      LgcpFinalArgs fa{ws + w.lane[l].w, se.wslot, se.lpslot, tc, out_loss + base, partials + base * CMCD_NSTATS, M[l], D,
+                       nsk ? tD : cbD};
       hipLaunchKernelGGL(lgcp_final_kernel, dim3(1), dim3(64), 0, st_l, fa);
     }
   }

@@ -215,10 +215,16 @@ def test_lgcp_repeat_calls_are_bitwise_identical(hip_lib, n, k, reps):
         assert torch.equal(l, l0) and torch.equal(z, z0) and torch.equal(st, s0), f"forward repeat {r} differs"
     g0, (lg0, _) = mcdbm.compute_bound_grad(seeds, *args)
     torch.cuda.synchronize()
-    assert torch.equal(lg0, l0) and torch.isfinite(g0).all()
+    assert torch.isfinite(g0).all()
+    if n < 224:
+        assert torch.equal(lg0, l0)
+    else:
+        # r04: a forward-only call of >= 224 particles takes the wide-batch GEMM launches (cmcd_lgcp_wide.hip) while a
+        # gradient call keeps the trajectory on 32-row passes: the same losses up to the float32 summation order
+        torch.testing.assert_close(lg0, l0, rtol=2e-5, atol=2e-3)
     for r in range(max(reps // 4, 10)):
         g, (lg, _) = mcdbm.compute_bound_grad(seeds, *args)
-        assert torch.equal(lg, l0) and torch.equal(g, g0), f"gradient repeat {r} differs"
+        assert torch.equal(lg, lg0) and torch.equal(g, g0), f"gradient repeat {r} differs"
     # the VarGrad sweep of the same sequence
     bv = synthetic.build("lgcp_n20_k128", device="cuda", lgcp_counts=lgcp_counts_fixture(), nbridges=k, N=n, dense=True,
                          boundmode="MCD_CAIS_var_sn")

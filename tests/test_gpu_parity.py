@@ -55,12 +55,17 @@ def test_bound_matches_oracle(hip_lib, param_set, variant, name, n, over):
         assert not np.isfinite(float(val))
 
 
-@pytest.mark.parametrize("n,k", [(20, 8), (5, 3), (40, 2), (20, 128), (600, 16)])
-def test_lgcp_matches_oracle(hip_lib, param_set, n, k):
-    """d = 1600 (config 5): per-bridge GEMM path.  40 particles = two passes of the 32-row GEMM; (20, 128) is the
+@pytest.mark.parametrize("n,k,form", [(20, 8, 0), (5, 3, 0), (40, 2, 0), (20, 128, 0), (600, 16, 0), (17, 3, 0), (16, 2, 0),
+                                      (20, 8, 3), (40, 2, 3), (20, 128, 3)])
+def test_lgcp_matches_oracle(hip_lib, param_set, monkeypatch, n, k, form):
+    """d = 1600 (config 5): per-bridge GEMM path.  40 particles = two passes of 32 rows; (20, 128) is the
     configuration's own size (BASELINE.json configs[4]), 600 particles the evaluation batch of the reference's lgcp
-    runs (n_samples 500-600 per seed group, /root/reference/README.md:63; 19 passes)."""
+    runs (n_samples 500-600 per seed group, /root/reference/README.md:63; the wide-batch form).  form 0 = the library's
+    choice (r04: the no-split-K GEMM on packed operands for <= 32-row passes; 16 / 17 particles = one row half / one row
+    into the second), form 3 = the split-K launch sequence (still the recompute of the reverse sweep and the fallback)."""
     import os
+    from cmcd_amd import _lib
+    monkeypatch.setattr(mcdbm, "KERNEL_VARIANT", form)
     counts = np.load(os.path.join(os.path.dirname(__file__), "golden", "lgcp_bin_counts.npy"))
     b = synthetic.build("lgcp_n20_k128", device="cuda", lgcp_counts=counts, nbridges=k)
     seeds = synthetic.parity_seeds(n)

@@ -1,0 +1,38 @@
+# per-launch durations of the <= 32-row lgcp forward (no-split-K GEMM launches A / B / C by position): bash tools/probes/lgcp_nsk_prof.sh [tag]
+T=${1:-lgcp_nsk_prof}
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/$T
+mkdir -p $O
+rm -rf $O/prof
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 tools/probes/lgcp_time20.py > $O/time_under_rocprof_n20.txt 2>&1
+cp $(find $O/prof -name "*kernel_stats.csv" | head -1) $O/kernel_stats_n20.csv
+python3 - $O <<'PY'
+import csv, glob, sys, collections
+O = sys.argv[1]
+out = open('%s/per_launch_n20.txt' % O, 'w')
+for f in glob.glob(O + '/prof/**/*kernel_trace.csv', recursive=True):
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
+    seq = [r for r in rows if 'lgcp_nsk_kernel' in r['Kernel_Name']]
+    acc = collections.defaultdict(list)
+    gaps = []
+    for i, r in enumerate(seq):
+        acc["ABC"[i % 3] + ' grid ' + r.get('Grid_Size_X', r.get('Grid_Size', '?'))].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+        if i:
+            gaps.append(int(r['Start_Timestamp']) - int(seq[i - 1]['End_Timestamp']))
+    for k, v in sorted(acc.items()):
+        v.sort()
+        print(k, 'launches', len(v), 'median %.2f us' % (v[len(v) // 2] / 1e3), 'p10 %.2f' % (v[len(v) // 10] / 1e3), 'p90 %.2f' % (v[9 * len(v) // 10] / 1e3), file=out)
+    gaps.sort()
+    print('gap end -> next start: median %.2f us p10 %.2f p90 %.2f' % (gaps[len(gaps) // 2] / 1e3, gaps[len(gaps) // 10] / 1e3, gaps[9 * len(gaps) // 10] / 1e3), file=out)
+    other = collections.defaultdict(list)
+    for r in rows:
+        if 'lgcp_nsk_kernel' not in r['Kernel_Name']:
+            other[r['Kernel_Name'][:60]].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+    for k, v in sorted(other.items(), key=lambda kv: -sum(kv[1]))[:8]:
+        print('%-60s launches %5d total %.3f ms avg %.2f us' % (k, len(v), sum(v) / 1e6, sum(v) / len(v) / 1e3), file=out)
+out.close()
+print(open('%s/per_launch_n20.txt' % O).read())
+PY
+rm -rf $O/prof
+tail -1 $O/time_under_rocprof_n20.txt
