@@ -678,57 +678,107 @@ struct NskArgs {
   float* krOut;        // KR
 };
 
-// one element (row m of the pass, column e) of evaluation i's state update: the arithmetic of lgcp_step_tile
+// One element (row m of the pass, column e) of evaluation i's state update — the arithmetic of lgcp_step_tile — in TWO
+// phases around the GEMM: everything that does not depend on this launch's product (the element's state, the target's
+// gradient from the previous launch's K^-1 product, grad log q, the Threefry block and its deviate: ~250 of the ~300
+// instructions and the one load round trip) is issued BEFORE the consumer wave waits for its GEMM operands, so that the
+// launch's tail after the last matrix instruction is the LDS sum, a dozen FMAs and the stores.
+struct NskStepPre {
+  float z, xp, kr, cnt, b3, gq, gp, ez, noise, fac;
+  float mean, ld;
+  uint32_t g0, g1;
+  int64_t ix;
+  // schedule scalars and the row's slot values (writer lanes): loaded up front too — after the last matrix instruction
+  // nothing waits for a load any more
+  float pbeta, peps, pcst, pinv2s2, beta, eps, sig, cst, inv2s2, mu0, pa, wsl, fksl;
+};
+
+// phase 0: the element's loads only (issued before the GEMM's own 26, so that they return first)
 template <bool NO_NET>
-__device__ __forceinline__ void nsk_step_elem(const NskArgs& a, float o, int m, int e, int tile, int lane16_reduce_ok) {
+__device__ __forceinline__ void nsk_step_loads(const NskArgs& a, int m, int e, NskStepPre& t) {
   const StepEpi& s = a.step;
-  const int D = s.D, H = (D + 1) / 2, i = s.i;
-  const float fsn = s.ula ? 0.f : 1.f;
+  const int D = s.D;
   const float* counts = s.tc + (int64_t)D * D;
-  const float mu0 = s.tc[(int64_t)D * D + D], pa = s.tc[(int64_t)D * D + D + 1];
-  const float clipv = s.var_mode ? 1e2f : 1e3f;
-  const bool clip_p = s.grad_clipping != 0, clip_q = clip_p && s.var_mode;
+  const int ec = min(e, D - 1), mc = min(m, a.M - 1);        // clamped (always valid) addresses: padding lanes only join the butterfly
+  t.ix = nsk_pack(mc, ec);
+  t.z = a.xA[t.ix]; t.xp = a.xpA[t.ix];
+  t.kr = NO_NET ? 0.f : a.krA[t.ix];
+  t.cnt = counts[ec]; t.b3 = NO_NET ? 0.f : s.b3[ec];
+  t.mean = s.params[s.lay.vd_mean + ec];
+  t.ld = s.params[s.lay.vd_logdiag + ec];
+  const uint32_t* gk = s.gkey + (s.i & 1) * 2 * kMP;
+  t.g0 = gk[2 * mc]; t.g1 = gk[2 * mc + 1];
+  t.fac = NO_NET ? 0.f : s.factor[0];
+  const int i = s.i;
   const bool last = i == s.K;
   const float* sp = s.sched + 8 * (i > 0 ? i - 1 : 0);
-  const float pbeta = sp[0], peps = sp[1], pcst = sp[3], pinv2s2 = sp[4];
+  t.pbeta = sp[0]; t.peps = sp[1]; t.pcst = sp[3]; t.pinv2s2 = sp[4];
   const float* sc = s.sched + 8 * (last ? s.K - 1 : i);
-  const float beta = sc[0], eps = sc[1], sig = sc[2], cst = sc[3], inv2s2 = sc[4];
-  const bool live = lane16_reduce_ok != 0;                  // real row and column (padding lanes only join the butterfly)
-  const int ec = min(e, D - 1), mc = min(m, a.M - 1);
-  const int64_t ix = nsk_pack(mc, ec);
-  // every load first, from clamped (always valid) addresses
-  const float z = a.xA[ix], xp = a.xpA[ix];
-  const float kr = NO_NET ? o : a.krA[ix];
-  const float cnt = counts[ec], b3 = NO_NET ? 0.f : s.b3[ec];
-  const float mean = s.params[s.lay.vd_mean + ec];
-  const float sd = expf(s.params[s.lay.vd_logdiag + ec]);
-  const uint32_t* gk = s.gkey + (i & 1) * 2 * kMP;
-  const uint32_t g0 = gk[2 * mc], g1 = gk[2 * mc + 1];
-  const float fac = NO_NET ? 0.f : s.factor[0];
-  __builtin_amdgcn_sched_barrier(0);
-  const float sn = NO_NET ? 0.f : (o + b3) * fac;             // factor_sn (u2 W3 + b3)           nn.py:70
-  float bk_acc = 0.f, fk_acc = 0.f, lp_acc = 0.f, zn = 0.f;
-  const float ez = expf(z);
-  float gp = -kr + cnt - pa * ez;                             // grad log p      model_handler.py:386-396
-  float gq = -(z - mean) / (sd * sd);
-  if (clip_p) gp = fminf(fmaxf(gp, -clipv), clipv);
-  if (clip_q) gq = fminf(fmaxf(gq, -clipv), clipv);
-  if (i > 0) {   // backward kernel of step i-1                             mcd_cais.py:71-86
-    const float ub = -1.0f * (pbeta * gp + (1.0f - pbeta) * gq);
-    const float bk = z - peps * ub + peps * sn;
-    const float db = xp - bk;
-    bk_acc = -(db * db) * pinv2s2 - pcst;
+  t.beta = sc[0]; t.eps = sc[1]; t.sig = sc[2]; t.cst = sc[3]; t.inv2s2 = sc[4];
+  t.mu0 = s.tc[(int64_t)D * D + D]; t.pa = s.tc[(int64_t)D * D + D + 1];
+  const int sl = (e >> 4) * kMP + mc;                        // the element's (tile, row) slot (e / 16 = the column tile)
+  t.wsl = s.wslot[sl]; t.fksl = s.fkslot[sl];
+}
+
+// phase 1: everything that does not depend on this launch's product, in the shadow of the GEMM operands' flight
+template <bool NO_NET>
+__device__ __forceinline__ void nsk_step_pre(const NskArgs& a, int e, NskStepPre& t) {
+  const StepEpi& s = a.step;
+  const int D = s.D, H = (D + 1) / 2, i = s.i;
+  const float pa = t.pa;
+  const float clipv = s.var_mode ? 1e2f : 1e3f;
+  const bool clip_p = s.grad_clipping != 0, clip_q = clip_p && s.var_mode;
+  const int ec = min(e, D - 1);
+  const float sd = expf(t.ld);
+  t.ez = expf(t.z);
+  t.gq = -(t.z - t.mean) / (sd * sd);
+  if (clip_q) t.gq = fminf(fmaxf(t.gq, -clipv), clipv);
+  t.gp = 0.f;
+  if (!NO_NET) {
+    t.gp = -t.kr + t.cnt - pa * t.ez;                          // grad log p      model_handler.py:386-396
+    if (clip_p) t.gp = fminf(fmaxf(t.gp, -clipv), clipv);
   }
-  if (last) {    // log p(z_K)
-    lp_acc = -0.5f * (z - mu0) * kr + z * cnt - pa * ez;
-  } else {       // forward kernel of step i                                mcd_cais.py:52-67
+  t.noise = 0.f;
+  if (i < s.K) {
     // eps_i = normal(G_i, (D,)): element e is word (e >= H) of the block with counters (j, H + j), j = e mod H
     const int j = ec < H ? ec : ec - H;
     uint32_t y0 = j, y1 = (H + j < D) ? H + j : 0;
-    threefry2x32(g0, g1, y0, y1);
+    threefry2x32(t.g0, t.g1, y0, y1);
+    t.noise = bits_to_normal(ec < H ? y0 : y1);
+  }
+}
+
+template <bool NO_NET>
+__device__ __forceinline__ void nsk_step_post(const NskArgs& a, const NskStepPre& t, float o, int m, int e, int tile, bool live) {
+  const StepEpi& s = a.step;
+  const int D = s.D, i = s.i;
+  const float fsn = s.ula ? 0.f : 1.f;
+  const float mu0 = t.mu0, pa = t.pa;
+  const float clipv = s.var_mode ? 1e2f : 1e3f;
+  const bool clip_p = s.grad_clipping != 0;
+  const bool last = i == s.K;
+  const float pbeta = t.pbeta, peps = t.peps, pcst = t.pcst, pinv2s2 = t.pinv2s2;
+  const float beta = t.beta, eps = t.eps, sig = t.sig, cst = t.cst, inv2s2 = t.inv2s2;
+  const float z = t.z, kr = NO_NET ? o : t.kr, gq = t.gq;
+  float gp = t.gp;
+  if (NO_NET) {                                               // MCD_ULA: the K^-1 product is this launch's own
+    gp = -kr + t.cnt - pa * t.ez;
+    if (clip_p) gp = fminf(fmaxf(gp, -clipv), clipv);
+  }
+  const float sn = NO_NET ? 0.f : (o + t.b3) * t.fac;         // factor_sn (u2 W3 + b3)           nn.py:70
+  float bk_acc = 0.f, fk_acc = 0.f, lp_acc = 0.f, zn = 0.f;
+  if (i > 0) {   // backward kernel of step i-1                             mcd_cais.py:71-86
+    const float ub = -1.0f * (pbeta * gp + (1.0f - pbeta) * gq);
+    const float bk = z - peps * ub + peps * sn;
+    const float db = t.xp - bk;
+    bk_acc = -(db * db) * pinv2s2 - pcst;
+  }
+  if (last) {    // log p(z_K)
+    lp_acc = -0.5f * (z - mu0) * kr + z * t.cnt - pa * t.ez;
+  } else {       // forward kernel of step i                                mcd_cais.py:52-67
     const float uf = -1.0f * (beta * gp + (1.0f - beta) * gq);
     const float fk = z - eps * uf - fsn * eps * sn;
-    zn = fk + sig * bits_to_normal(ec < H ? y0 : y1);
+    zn = fk + sig * t.noise;
     const float df = zn - fk;
     fk_acc = -(df * df) * inv2s2 - cst;
   }
@@ -736,8 +786,8 @@ __device__ __forceinline__ void nsk_step_elem(const NskArgs& a, float o, int m, 
     if (last) {
       s.out_z[(int64_t)m * D + e] = z;
     } else {
-      a.xpA[ix] = z;
-      a.xA[ix] = zn;
+      a.xpA[t.ix] = z;
+      a.xA[t.ix] = zn;
       if (s.traj) s.traj[((int64_t)(i + 1) * s.n_total + s.base + m) * D + e] = zn;
     }
   }
@@ -751,89 +801,146 @@ __device__ __forceinline__ void nsk_step_elem(const NskArgs& a, float o, int m, 
   }
   if ((threadIdx.x & 15) == 0 && m < a.M) {
     const int sl = tile * kMP + m;
-    if (i > 0) s.wslot[sl] += bk_lp - s.fkslot[sl];
+    if (i > 0) s.wslot[sl] = t.wsl + (bk_lp - t.fksl);
     if (!last) s.fkslot[sl] = fk_lp;
     else s.lpslot[sl] = lp;
   }
 }
 
-template <bool STEP>
-__global__ __launch_bounds__(64 * (kGemmWaves + (STEP ? 1 : 0))) void lgcp_nsk_kernel(NskArgs a) {
-  __shared__ float red[kGemmWaves][256];
+// MERGED (17 .. 20 particles, the named batch): ONE workgroup per column tile serves rows 0 .. 15 on 16x16x4 and rows
+// 16 .. 19 on v_mfma_f32_4x4x1 (16 blocks of 4 rows x 4 columns, block = (column group, k quarter)) against the SAME weight
+// registers — the weights are fetched once instead of once per 16-row half (launch B: 202 workgroups, one per CU, instead of
+// 404).  Lane l's 4x4x1 operands: A = packed operand of row 16 + l % 4 at the lane's k quarter, B = its 16x16x4 weight
+// register; D register r of lane l = row 16 + r, column l % 16, partial over the lane's k quarter (summed over the four
+// quarters in the LDS pass).  STEP launches carry one EXTRA workgroup (the last) that advances the chain's key.
+template <bool STEP, bool MERGED>
+__global__ __launch_bounds__(64 * kGemmWaves) void lgcp_nsk_kernel(NskArgs a) {
+  __shared__ float red[kGemmWaves][MERGED ? 512 : 256];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (STEP && blockIdx.x == gridDim.x - 1) {
+    // the chain's key for evaluation i + 1 (a dependent integer chain of ~450 instructions): its own workgroup
+    const StepEpi& st = a.step;
+    if (blockIdx.y == 0 && wv == 0 && st.i + 1 < st.K && lane < a.M) {
+      uint32_t k0 = st.gen[2 * lane], k1 = st.gen[2 * lane + 1], G0, G1;
+      lgcp_key_advance(k0, k1, G0, G1);
+      st.gen[2 * lane] = k0; st.gen[2 * lane + 1] = k1;
+      uint32_t* gk = st.gkey + ((st.i + 1) & 1) * 2 * kMP;
+      gk[2 * lane] = G0; gk[2 * lane + 1] = G1;
+      uint32_t* gt = st.gktab + ((int64_t)(st.i + 1) * st.n_total + st.base + lane) * 2;
+      gt[0] = G0; gt[1] = G1;
+    }
+    return;
+  }
   const int sI = (int)blockIdx.x >= a.nt0 ? 1 : 0;
   const NskSeg sg = a.seg[sI];
-  const int tile = blockIdx.x - (sI ? a.nt0 : 0), half = blockIdx.y;
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (wv < kGemmWaves) {
-    const f32x4* Ap = reinterpret_cast<const f32x4*>(sg.A) + ((int64_t)half * kNskChunks + wv) * 64 + lane;
-    const f32x4* Wp = reinterpret_cast<const f32x4*>(sg.W) + ((int64_t)tile * kNskChunks + wv) * 64 + lane;
-    // chunk c = wave + 8 j: at every j the workgroup reads 8 KB contiguous of either operand.  All 26 loads in flight
-    // before the first wait, chunk by chunk, so the first matrix instruction waits for two of them.
-    f32x4 av[kNskCpw], bv[kNskCpw];
+  const int tile = blockIdx.x - (sI ? a.nt0 : 0), half = MERGED ? 0 : blockIdx.y;
+  // the element this thread consumes: waves 0 .. 3 the 16 x 16 block (D layout of 16x16x4: column = lane % 16, row =
+  // 4 (lane / 16) + register, register = wave), wave 4 the 4 x 16 block of the merged form
+  const bool cons = wv < 4 || (MERGED && wv == 4);
+  const int n = tile * 16 + (lane & 15);
+  const int row = wv < 4 ? half * 16 + 4 * (lane >> 4) + wv : 16 + (lane >> 4);
+  const bool live = cons && n < sg.N && row < a.M;
+  // ---- consumer operands first (they come from earlier launches): in flight beside the GEMM's own loads
+  NskStepPre sp;
+  float cu = 0.f, cb = 0.f;
+  int64_t cix = 0;
+  if (cons) {
+    if (STEP) {
+      if (sg.epi == NSK_STEP) nsk_step_loads<false>(a, row, n, sp);
+      else nsk_step_loads<true>(a, row, n, sp);
+    } else if (sg.epi != NSK_KR) {
+      const int nc = min(n, sg.N - 1), rc = min(row, a.M - 1);
+      cix = nsk_pack(rc, nc);
+      cb = a.bias[nc];
+      cu = sg.epi == NSK_ACT2 ? a.uA[cix] : (nc < a.D ? a.xA[cix] : a.emb[max(nc - a.D, 0)]);     // u = [x; emb_i]  nn.py:68-69
+    }
+  }
+  const f32x4* Ap = reinterpret_cast<const f32x4*>(sg.A) + ((int64_t)half * kNskChunks + wv) * 64 + lane;
+  const f32x4* Wp = reinterpret_cast<const f32x4*>(sg.W) + ((int64_t)tile * kNskChunks + wv) * 64 + lane;
+  // chunk c = wave + 8 j: at every j the workgroup reads 8 KB contiguous of either operand.  All loads in flight before
+  // the first wait, chunk by chunk, so the first matrix instruction waits for two of them.
+  f32x4 av[kNskCpw], bv[kNskCpw], a2[MERGED ? kNskCpw : 1];
+  const f32x4* A2p = reinterpret_cast<const f32x4*>(sg.A) + ((int64_t)kNskChunks + wv) * 64 + (lane & 3) + 16 * (lane >> 4);
 #pragma unroll
-    for (int j = 0; j < kNskCpw; ++j) { bv[j] = Wp[j * 512]; av[j] = Ap[j * 512]; }
-    __builtin_amdgcn_sched_barrier(0);        // (the machine scheduler otherwise sinks the loads to their uses: 43 registers, 26 round trips)
-    f32x4 acc[4];
+  for (int j = 0; j < kNskCpw; ++j) {
+    bv[j] = Wp[j * 512]; av[j] = Ap[j * 512];
+    if (MERGED) a2[j] = A2p[j * 512];
+  }
+  __builtin_amdgcn_sched_barrier(0);        // (the machine scheduler otherwise sinks the loads to their uses: 43 registers, 26 round trips)
+  if (STEP && cons) {                        // waits for the consumer's own loads only (issued first): the GEMM's stay in flight
+    if (sg.epi == NSK_STEP) nsk_step_pre<false>(a, n, sp);
+    else nsk_step_pre<true>(a, n, sp);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 acc[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float shift = sg.a_shift;
+  for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float shift = sg.a_shift;
+#pragma unroll
+  for (int j = 0; j < kNskCpw; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][q] - shift, bv[j][q], acc[q], 0, 0, 0);
+  const f32x4 t = (acc[0] + acc[1]) + (acc[2] + acc[3]);      // fixed order
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[wv][r * 64 + lane] = t[r];
+  if (MERGED) {
+    f32x4 ac2[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ac2[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < kNskCpw; ++j)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][q] - shift, bv[j][q], acc[q], 0, 0, 0);
-    const f32x4 t = (acc[0] + acc[1]) + (acc[2] + acc[3]);      // fixed order
+        ac2[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(a2[j][q] - shift, bv[j][q], ac2[q], 0, 0, 0);
+    const f32x4 t2 = (ac2[0] + ac2[1]) + (ac2[2] + ac2[3]);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[wv][r * 64 + lane] = t[r];
-  } else if (STEP && blockIdx.x == 0 && half == 0 && a.step.i + 1 < a.step.K && lane < a.M) {
-    // the chain's key for evaluation i + 1 (a dependent integer chain of ~450 instructions) on the ninth wave of one
-    // workgroup, beside its GEMM waves
-    const StepEpi& st = a.step;
-    uint32_t k0 = st.gen[2 * lane], k1 = st.gen[2 * lane + 1], G0, G1;
-    lgcp_key_advance(k0, k1, G0, G1);
-    st.gen[2 * lane] = k0; st.gen[2 * lane + 1] = k1;
-    uint32_t* gk = st.gkey + ((st.i + 1) & 1) * 2 * kMP;
-    gk[2 * lane] = G0; gk[2 * lane + 1] = G1;
-    uint32_t* gt = st.gktab + ((int64_t)(st.i + 1) * st.n_total + st.base + lane) * 2;
-    gt[0] = G0; gt[1] = G1;
+    for (int r = 0; r < 4; ++r) red[wv][256 + r * 64 + lane] = t2[r];
   }
   __syncthreads();
-  if (threadIdx.x >= 256) return;
-  // D layout of 16x16x4: column = lane % 16, row = 4 (lane / 16) + register; thread (register = wave, lane)
-  const int reg = wv;
+  if (!cons) return;
   float v = 0.f;
+  if (wv < 4) {
 #pragma unroll
-  for (int w = 0; w < kGemmWaves; ++w) v += red[w][reg * 64 + lane];        // fixed order
-  const int cl = lane & 15, rl = 4 * (lane >> 4) + reg;
-  const int n = tile * 16 + cl, row = half * 16 + rl;
-  const bool live = n < sg.N && row < a.M;
+    for (int w = 0; w < kGemmWaves; ++w) v += red[w][wv * 64 + lane];        // fixed order
+  } else {
+    // row 16 + r, column c: the four k quarters (lanes c, c + 16, c + 32, c + 48) of every wave, fixed order
+    const int r = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int w = 0; w < kGemmWaves; ++w)
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq) v += red[w][256 + r * 64 + c + 16 * kq];
+  }
   if (STEP) {
-    if (sg.epi == NSK_STEP) nsk_step_elem<false>(a, v, row, n, tile, live ? 1 : 0);
-    else nsk_step_elem<true>(a, v, row, n, tile, live ? 1 : 0);
+    if (sg.epi == NSK_STEP) nsk_step_post<false>(a, sp, v, row, n, tile, live);
+    else nsk_step_post<true>(a, sp, v, row, n, tile, live);
     return;
   }
   if (!live) return;
-  const int64_t ix = nsk_pack(row, n);
-  if (sg.epi == NSK_ACT1) {                                   // u = [x; emb_i]      nn.py:68-69
-    const float u = n < a.D ? a.xA[ix] : a.emb[n - a.D];
-    a.outA[ix] = u + softplus(v + a.bias[n]);                 // nn.py:45-50
-  } else if (sg.epi == NSK_ACT2) {
-    a.outA[ix] = a.uA[ix] + softplus(v + a.bias[n]);
-  } else {                                                    // NSK_KR (second segment of launch B): its own output array
-    a.krOut[ix] = v;
-  }
+  if (sg.epi == NSK_KR) a.krOut[nsk_pack(row, n)] = v;         // second segment of launch B: its own output array
+  else a.outA[cix] = cu + softplus(v + cb);                    // nn.py:45-50
 }
 
-// packed copy of a [K][N] weight matrix (row stride lds): one thread per 16-byte group {k, k+1, k+2, k+3} x column
-__global__ void lgcp_nsk_pack_kernel(const float* __restrict__ src, int K, int N, int lds_, float* __restrict__ dst, int ntile) {
+// packed copies of up to four [K][N] weight matrices (row stride = N) in ONE launch (blockIdx.y = matrix): one thread per
+// 16-byte group {k, k+1, k+2, k+3} x column
+struct NskPackArgs {
+  const float* src[4];
+  float* dst[4];
+  int K[4], N[4], ntile[4];
+};
+__global__ void lgcp_nsk_pack_kernel(NskPackArgs a) {
+  const int q = blockIdx.y;
+  const float* __restrict__ src = a.src[q];
+  if (!src) return;
+  const int K = a.K[q], N = a.N[q];
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;          // (tile, chunk, lane)
-  if (g >= (int64_t)ntile * kNskChunks * 64) return;
+  if (g >= (int64_t)a.ntile[q] * kNskChunks * 64) return;
   const int lane = (int)(g & 63), chunk = (int)((g >> 6) % kNskChunks), tile = (int)((g >> 6) / kNskChunks);
   const int n = tile * 16 + (lane & 15), k0 = chunk * 16 + 4 * (lane >> 4);
   f32x4 v;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) v[q] = (n < N && k0 + q < K) ? src[(int64_t)(k0 + q) * lds_ + n] : 0.f;
-  reinterpret_cast<f32x4*>(dst)[g] = v;
+  for (int j = 0; j < 4; ++j) v[j] = (n < N && k0 + j < K) ? src[(int64_t)(k0 + j) * N + n] : 0.f;
+  reinterpret_cast<f32x4*>(a.dst[q])[g] = v;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -947,14 +1054,19 @@ struct LgcpFinalArgs {
   int M, D, ncb;
 };
 
-__global__ void lgcp_final_kernel(LgcpFinalArgs a) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= a.M) return;
-  float w = a.w0[p], lp = 0.f;
-  for (int cb = 0; cb < a.ncb; ++cb) {
+__global__ __launch_bounds__(64) void lgcp_final_kernel(LgcpFinalArgs a) {
+  // one wave per particle: lane c takes slot rows c, c + 64, ... (two dependent loads instead of a hundred), then a fixed
+  // butterfly — the same order on every call
+  const int p = blockIdx.x, lane = threadIdx.x;
+  float w = 0.f, lp = 0.f;
+  for (int cb = lane; cb < a.ncb; cb += 64) {
     w += a.wslot[cb * kMP + p];
     lp += a.lpslot[cb * kMP + p];
   }
+  w = wave_sum64(w);
+  lp = wave_sum64(lp);
+  if (lane != 0) return;
+  w += a.w0[p];
   w += lp + a.tc[(int64_t)a.D * a.D + a.D + 2];     // + log p(z_K)   mcdboundingmachine.py:178
   const float loss = -w;
   a.out_loss[p] = loss;
@@ -1096,17 +1208,19 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
   const bool nsk = lgcp_nsk_ok(d);
   const int tIN = (IN + 15) / 16, tD = D / 16;
   if (nsk) {
+    NskPackArgs pk{};
+    int np = 0;
     auto pack = [&](const float* src, int Kr, int Nr, int64_t dst, int nt) {
-      const int64_t groups = (int64_t)nt * kNskChunks * 64;
-      hipLaunchKernelGGL(lgcp_nsk_pack_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, stream, src, Kr, Nr, Nr,
-                         ws + dst, nt);
+      pk.src[np] = src; pk.dst[np] = ws + dst; pk.K[np] = Kr; pk.N[np] = Nr; pk.ntile[np] = nt; ++np;
     };
+    pack(tc, D, D, w.kip, tD);
     if (d.mode != CMCD_MODE_ULA) {
       pack(params + lay.g_w1, D, IN, w.w1p, tIN);     // the state rows W1[:d] only: the embedding rows are in bias1
       pack(params + lay.g_w2, IN, IN, w.w2p, tIN);
       pack(params + lay.g_w3, IN, D, w.w3p, tD);
     }
-    pack(tc, D, D, w.kip, tD);
+    const int64_t groups = (int64_t)tIN * kNskChunks * 64;
+    hipLaunchKernelGGL(lgcp_nsk_pack_kernel, dim3((unsigned)((groups + 255) / 256), np), dim3(256), 0, stream, pk);
   }
   const float* kinv = tc;
   double* partials = reinterpret_cast<double*>(ws + w.partials);
@@ -1218,25 +1332,41 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
           float* xpA = xA + kNskOperand, *u1A = xpA + kNskOperand, *u2A = u1A + kNskOperand, *krA = u2A + kNskOperand;
           NskArgs na{};
           na.M = M[l]; na.D = D; na.IN = IN; na.xA = xA; na.xpA = xpA; na.krA = krA; na.krOut = krA; na.step = gl.step;
-          const dim3 grid_y(1, M[l] > 16 ? 2 : 1);
-          auto grid = [&](int tiles) { return dim3((unsigned)tiles, grid_y.y); };
+          // 17 .. 20 particles (the named batch): one workgroup per column tile serves both row blocks (16x16x4 + 4x4x1);
+          // otherwise one workgroup per (tile, 16-row half).  State-update launches carry one extra workgroup (key chain).
+          // Measured at N = 20 (profiles/r04_f_lgcp_nsk_per_launch_n20.txt): merged helps the launch that is otherwise two
+          // workgroups per CU (B: 9.96 -> 7.44 us) and costs the two that are one per CU either way (A 6.48 -> 7.08, C 7.64 ->
+          // 8.40: half as many CUs pull the bytes), so only launch B takes it.
+          const bool can_merge = M[l] > 16 && M[l] <= 20;
+          auto launch = [&](bool step, int tiles, bool want_merged = false) {
+            const bool merged = can_merge && want_merged;
+            const unsigned gy = (!merged && M[l] > 16) ? 2 : 1;
+            const dim3 grid((unsigned)tiles + (step ? 1 : 0), gy);
+            if (step) {
+              if (merged) hipLaunchKernelGGL((lgcp_nsk_kernel<true, true>), grid, gblock, 0, st_l, na);
+              else hipLaunchKernelGGL((lgcp_nsk_kernel<true, false>), grid, gblock, 0, st_l, na);
+            } else {
+              if (merged) hipLaunchKernelGGL((lgcp_nsk_kernel<false, true>), grid, gblock, 0, st_l, na);
+              else hipLaunchKernelGGL((lgcp_nsk_kernel<false, false>), grid, gblock, 0, st_l, na);
+            }
+          };
           if (ula == 1) {   // MCD_ULA: one launch per evaluation, (x - mu0) K^-1 with the state update as its consumer
             na.seg[0] = NskSeg{xA, ws + w.kip, D, NSK_STEP_NONET, mu0}; na.nt0 = tD;
-            hipLaunchKernelGGL(lgcp_nsk_kernel<true>, grid(tD), gblock_step, 0, st_l, na);
+            launch(true, tD);
             continue;
           }
           // A: x W1[:D] -> u1 = [x; emb_i] + softplus(. + bias1_i)
           na.seg[0] = NskSeg{xA, ws + w.w1p, IN, NSK_ACT1, 0.f}; na.nt0 = tIN;
           na.bias = ws + w.bias1 + (int64_t)it * IN; na.emb = params + lay.g_emb + (int64_t)ie * E; na.outA = u1A;
-          hipLaunchKernelGGL(lgcp_nsk_kernel<false>, grid(tIN), gblock, 0, st_l, na);
+          launch(false, tIN);
           // B: u1 W2 -> u2 = u1 + softplus(. + b2)   |   (x - mu0) K^-1 -> kr
           na.seg[0] = NskSeg{u1A, ws + w.w2p, IN, NSK_ACT2, 0.f};
           na.seg[1] = NskSeg{xA, ws + w.kip, D, NSK_KR, mu0};
           na.bias = params + lay.g_b2; na.uA = u1A; na.outA = u2A;
-          hipLaunchKernelGGL(lgcp_nsk_kernel<false>, grid(tIN + tD), gblock, 0, st_l, na);
+          launch(false, tIN + tD, true);
           // C: u2 W3 -> the state update of evaluation i on the tile's elements
           na.seg[0] = NskSeg{u2A, ws + w.w3p, D, NSK_STEP, 0.f}; na.nt0 = tD;
-          hipLaunchKernelGGL(lgcp_nsk_kernel<true>, grid(tD), gblock_step, 0, st_l, na);
+          launch(true, tD);
           continue;
         }
         if (ula == 1) {   // MCD_ULA: one launch per evaluation, [x - mu0] Kinv with the state update as its consumer
@@ -1277,7 +1407,7 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
       const StepEpi& se = g[l].step;
       LgcpFinalArgs fa{ws + w.lane[l].w, se.wslot, se.lpslot, tc, out_loss + base, partials + base * CMCD_NSTATS, M[l], D,
                        nsk ? tD : cbD};
-      hipLaunchKernelGGL(lgcp_final_kernel, dim3(1), dim3(64), 0, st_l, fa);
+      hipLaunchKernelGGL(lgcp_final_kernel, dim3(M[l]), dim3(64), 0, st_l, fa);
     }
   }
   if (!join_all()) return CMCD_ERR_HIP;
