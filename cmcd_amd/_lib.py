@@ -60,6 +60,8 @@ def lib():
         L.cmcd_bound_forward.argtypes = [
             C.POINTER(Desc), C.POINTER(Layout), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
             C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cmcd_bound_forward_prepared.restype = C.c_int
+        L.cmcd_bound_forward_prepared.argtypes = L.cmcd_bound_forward.argtypes
         L.cmcd_stats_merge.restype = C.c_int
         L.cmcd_stats_merge.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32,
                                        C.POINTER(C.c_double), C.POINTER(C.c_double)]

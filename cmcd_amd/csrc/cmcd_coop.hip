@@ -775,6 +775,8 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
   if (!last) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the other lanes of the merging wave read the records too
   wave_merge_stats(a.partials, (int)gridDim.x, a.fin_out, lane);
+  // ready for the next launch on these tables (cmcd_bound_forward_prepared skips the prep launch that used to zero it)
+  if (lane == 0) __hip_atomic_store(a.fin_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 typedef void (*coop_fn)(TrajArgs);

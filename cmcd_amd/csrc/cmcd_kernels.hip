@@ -1055,7 +1055,7 @@ int64_t cmcd_workspace_bytes(const cmcd_desc* desc, int64_t n) {
 static int forward_impl(const cmcd_desc* desc, const cmcd_layout* lay, const int32_t* seeds, int64_t n,
                         const float* params, int64_t n_params, const float* target_consts, int64_t n_target,
                         void* workspace, int64_t workspace_bytes, float* out_loss, float* out_z,
-                        double* out_stats, float* traj, void* stream_) {
+                        double* out_stats, float* traj, void* stream_, bool tables_ready = false) {
   const NoiseCapture cap = g_capture;   // armed by cmcd_debug_capture_noise: this call consumes it, whatever happens
   g_capture = NoiseCapture{};
   int rc = check_desc(desc);
@@ -1126,7 +1126,9 @@ static int forward_impl(const cmcd_desc* desc, const cmcd_layout* lay, const int
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   float* ws = static_cast<float*>(workspace);
 
-  launch_prep(d, *lay, w, params, target_consts, n_mix, ws, stream);
+  // cmcd_bound_forward_prepared: the caller vouches that the workspace still holds the tables a previous call formed from the
+  // SAME (desc, layout, params, target constants, n): the prep launch (4.8 us + a kernel boundary per call) is skipped
+  if (!tables_ready) launch_prep(d, *lay, w, params, target_consts, n_mix, ws, stream);
 
   if (uha) {   // 2nd-order CMCD: its own trajectory kernel (cmcd_uha.hip), same prep tables and statistics merge
     TrajArgs tu{seeds, params, ws, reinterpret_cast<double*>(ws + w.partials), out_loss, out_z, *lay, w, n,
@@ -1241,6 +1243,16 @@ int cmcd_bound_forward(const cmcd_desc* desc, const cmcd_layout* lay, const int3
                        double* out_stats, void* stream_) {
   return forward_impl(desc, lay, seeds, n, params, n_params, target_consts, n_target, workspace, workspace_bytes,
                       out_loss, out_z, out_stats, nullptr, stream_);
+}
+
+int cmcd_bound_forward_prepared(const cmcd_desc* desc, const cmcd_layout* lay, const int32_t* seeds, int64_t n,
+                                const float* params, int64_t n_params, const float* target_consts, int64_t n_target,
+                                void* workspace, int64_t workspace_bytes, float* out_loss, float* out_z,
+                                double* out_stats, void* stream_) {
+  // the d = 1600 launch sequence re-packs its weights and zeroes its operands per call: it has no prepared form
+  const bool ready = desc && desc->target != CMCD_TARGET_LGCP;
+  return forward_impl(desc, lay, seeds, n, params, n_params, target_consts, n_target, workspace, workspace_bytes,
+                      out_loss, out_z, out_stats, nullptr, stream_, ready);
 }
 
 int64_t cmcd_bound_grad_workspace_bytes(const cmcd_desc* desc, int64_t n) {

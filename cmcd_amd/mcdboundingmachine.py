@@ -169,6 +169,18 @@ _WORKSPACE_CACHE = 16    # (stream, purpose) entries kept PER DEVICE; beyond tha
 KERNEL_VARIANT = int(__import__("os").environ.get("CMCD_KERNEL_VARIANT", "0"))
 
 
+# Prepared tables (include/cmcd_hip.h: cmcd_bound_forward_prepared): what the forward workspace of (device, buffer address)
+# holds, as the key of the call that formed it.  A forward call whose key matches skips the prep launch — evaluation loops on
+# fixed parameters (the reference's opt.sample: 30 calls of loss_fn on one params_flat).  The key carries the parameter
+# tensor's address AND its version counter: every in-place update through torch bumps it, and the two places of this package
+# that write parameters through a raw pointer (the fused optimiser step, eager and graph-replayed) bump it by hand
+# (torch.autograd.graph.increment_version).  Code that writes into params_flat through data_ptr() on its own must do the same,
+# or set CMCD_PREP_CACHE=0.  Never used while a graph is being captured (a captured "no prep" would outlive the parameters).
+_prepared = {}
+PREP_CACHE = __import__("os").environ.get("CMCD_PREP_CACHE", "1") != "0"
+PREP_CALLS = {"prepared": 0, "full": 0}      # forward calls that skipped / ran the prep launch (tests, bench)
+
+
 def _workspace(device, nbytes, tag=""):
     """Scratch buffer of one (device, HIP stream, purpose): calls enqueued on different streams of one device — from
     one host thread or several — never share a workspace, so they may overlap on the GPU (include/cmcd_hip.h: the
@@ -192,6 +204,7 @@ def _workspace(device, nbytes, tag=""):
     ws = per_dev.pop(key, None)              # re-inserted below: the dict is ordered by last use
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _prepared.pop((dev_key, ws.data_ptr()), None)      # a fresh buffer holds nobody's tables, whatever lived at its address
     per_dev[key] = ws
     while len(per_dev) > _WORKSPACE_CACHE:         # least recently used first: streams that died, one-off streams
         per_dev.pop(next(iter(per_dev)))
@@ -281,11 +294,24 @@ def bound_forward(seeds, params_flat, unflatten, params_fixed, log_prob, eps_sch
     stats = torch.empty(_lib.NSTATS, dtype=torch.float64, device=device)
     with torch.cuda.device(device):
         stream = torch.cuda.current_stream().cuda_stream
-        rc = L.cmcd_bound_forward(
+        # the tables this workspace holds: formed by the previous call from exactly these inputs?  (see _prepared)
+        slot = key = None
+        if PREP_CACHE and log_prob.target_id != _lib.TARGET["lgcp"] and not torch.cuda.is_current_stream_capturing():
+            slot = (torch.cuda.current_device(), ws.data_ptr())
+            key = (params_flat.data_ptr(), params_flat._version, params_flat.numel(), n, bytes(desc), id(unflatten), spec,
+                   None if consts is None else (consts.data_ptr(), consts._version, consts.numel()))
+        fn = L.cmcd_bound_forward_prepared if key is not None and _prepared.get(slot) == key else L.cmcd_bound_forward
+        _prepared.pop(slot, None)            # an error below leaves no claim on the buffer
+        PREP_CALLS["prepared" if fn is L.cmcd_bound_forward_prepared else "full"] += 1
+        rc = fn(
             C.byref(desc), C.byref(lay), seeds.data_ptr(), n, params_flat.data_ptr(), params_flat.numel(),
             consts.data_ptr() if consts is not None else None, consts.numel() if consts is not None else 0,
             ws.data_ptr(), ws.numel(), losses.data_ptr(), z.data_ptr(), stats.data_ptr(), stream)
     _lib.check(rc)
+    if key is not None:
+        _prepared[slot] = key
+        while len(_prepared) > 64:
+            _prepared.pop(next(iter(_prepared)))
     return losses, z, stats
 
 

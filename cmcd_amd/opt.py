@@ -91,6 +91,7 @@ class _FusedClipAdam(_ClipAdam):
                     ema.data_ptr() if ema is not None else None, params.numel(), self.lr, self.b1, self.b2, self.eps,
                     5.0, device_counter.data_ptr(), ema_step, arr, cnt, lptr, ln, dptr,
                     torch.cuda.current_stream().cuda_stream))
+            _bump(params, ema)
             return
         state["count"] += 1
         with torch.cuda.device(params.device):
@@ -98,6 +99,15 @@ class _FusedClipAdam(_ClipAdam):
                 params.data_ptr(), grad.data_ptr(), state["mu"].data_ptr(), state["nu"].data_ptr(),
                 ema.data_ptr() if ema is not None else None, params.numel(), self.lr, self.b1, self.b2, self.eps,
                 5.0, state["count"], ema_step, arr, cnt, lptr, ln, dptr, torch.cuda.current_stream().cuda_stream))
+        _bump(params, ema)
+
+
+def _bump(*tensors):
+    """The fused step writes its parameters through raw pointers: tell torch (the version counter is what the forward's
+    prepared-table cache keys on, cmcd_amd/mcdboundingmachine.py:_prepared)."""
+    for t in tensors:
+        if t is not None:
+            torch.autograd.graph.increment_version(t)
 
 
 def create_optimizer(step_size, b1=0.9, b2=0.999, eps=1e-8, trainable=None):
@@ -181,6 +191,7 @@ def run(info, lr, iters, params_flat, unflatten, params_fixed, log_prob_model, g
                 continue
             static_seeds.copy_(seeds)
             graph.replay()
+            _bump(params_flat, ema_params if use_ema else None)     # the replayed step wrote them through raw pointers
             opt_state["count"] += 1
             if i % every == 0:
                 mean_loss = float(g_loss.mean())

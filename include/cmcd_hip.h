@@ -140,6 +140,25 @@ int cmcd_bound_forward(const cmcd_desc* desc, const cmcd_layout* layout,
                        float* out_loss, float* out_z, double* out_stats,
                        void* stream);
 
+/* Evaluation loops on FIXED parameters (the reference's `opt.sample` calls its jitted loss_fn n_input_dist_seeds = 30 times
+ * with the same params_flat, /root/reference/src/opt.py:185-190; XLA keeps nothing between those calls either, but its
+ * executable has no per-call table-building stage): same arguments and results as cmcd_bound_forward, but the per-call PREP
+ * launch (the beta / eps schedule, the time path of the score network folded into per-bridge first-layer biases, the
+ * operand packing of the weights: everything that depends on params_flat and not on the particles) is skipped.
+ * CONTRACT: `workspace` was last used by a cmcd_bound_forward / cmcd_bound_forward_prepared call with the SAME desc, layout,
+ * n, params CONTENTS and target constants, and nothing wrote into it since.  The library cannot check this (it keeps no
+ * state and never reads params back to the host): the caller owns the invalidation — the Python mirror keys it on
+ * (workspace, params_flat.data_ptr(), params_flat._version, target constants, desc, n) and bumps the version counter
+ * wherever it updates parameters through a raw pointer (cmcd_adam_step).  The d = 1600 (lgcp) launch sequence has no prepared
+ * form: there the call is cmcd_bound_forward. */
+int cmcd_bound_forward_prepared(const cmcd_desc* desc, const cmcd_layout* lay,
+                                const int32_t* seeds, int64_t n,
+                                const float* params, int64_t n_params,
+                                const float* target_consts, int64_t n_target,
+                                void* workspace, int64_t workspace_bytes,
+                                float* out_loss, float* out_z, double* out_stats,
+                                void* stream);
+
 /* ---- Measurement and diagnostic hooks: NOT part of the product path.  Nothing a result depends on goes through them;
  * they exist for bench.py (kernel time, kernel name) and the PRNG parity test, are per host thread, and a deployment can
  * leave them unbound.  (The library reads ONE environment variable, CMCD_COOP_PRIO, once per process, for the probes under

@@ -238,3 +238,61 @@ def test_lgcp_repeat_calls_are_bitwise_identical(hip_lib, n, k, reps):
         perm = torch.from_numpy(np.random.default_rng(1).permutation(n)).cuda()
         lp, _, _ = mcdbm.bound_forward(seeds[perm], *args)
         assert torch.equal(lp, l0[perm])
+
+
+@pytest.mark.parametrize("name,n", [("many_gmm_n2000_k256_dds", 2000), ("gmm_n300_k8", 300), ("funnel_n300_k64", 300),
+                                    ("many_gmm_var_n16000_k256", 600)])
+def test_prepared_tables_are_reused_only_while_the_parameters_are_unchanged(hip_lib, name, n):
+    """Evaluation loops on fixed parameters (the reference's opt.sample: 30 loss_fn calls on one params_flat,
+    /root/reference/src/opt.py:185-190) skip the per-call prep launch (cmcd_bound_forward_prepared): the results must be
+    bit-identical to a full call, and ANY change of the inputs the tables are made of must bring the prep launch back —
+    in-place torch updates (version counter), the fused optimiser step (raw-pointer write + manual bump), another batch
+    size, another parameter tensor.  gmm / funnel at N = 300 also exercise the fused statistics merge, whose arrival
+    counter the prep launch used to zero."""
+    from cmcd_amd import opt
+    b = synthetic.build(name, device="cuda", nbridges=16) if n == 600 else synthetic.build(name, device="cuda")
+    seeds = torch.from_numpy(synthetic.throughput_seeds(n, stream=3)).cuda()
+    args = (b["unflatten"], b["params_fixed"], b["target"])
+    kw = dict(eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
+    p = b["params_flat"].clone()
+
+    def fresh(params):      # the same call with the cache off
+        was = mcdbm.PREP_CACHE
+        mcdbm.PREP_CACHE = False
+        try:
+            return mcdbm.bound_forward(seeds, params, *args, **kw)
+        finally:
+            mcdbm.PREP_CACHE = was
+
+    def calls():
+        return dict(mcdbm.PREP_CALLS)
+
+    l0, z0, s0 = fresh(p)
+    c0 = calls()
+    outs = [mcdbm.bound_forward(seeds, p, *args, **kw) for _ in range(6)]
+    c1 = calls()
+    assert c1["full"] - c0["full"] == 1 and c1["prepared"] - c0["prepared"] == 5
+    for l, z, st in outs:
+        assert torch.equal(l, l0) and torch.equal(z, z0) and torch.equal(st, s0)
+    # an in-place update through torch: version counter -> full call, new values
+    p.mul_(1.001)
+    c1 = calls()
+    l1, z1, s1 = mcdbm.bound_forward(seeds, p, *args, **kw)
+    assert calls()["full"] - c1["full"] == 1
+    lf, zf, sf = fresh(p)
+    assert torch.equal(l1, lf) and torch.equal(s1, sf) and not torch.equal(l1, l0)
+    # the fused optimiser step writes through raw pointers and bumps the counter by hand
+    optimizer = opt.create_optimizer(1e-3)
+    state = optimizer.init(p)
+    mcdbm.bound_forward(seeds, p, *args, **kw)                      # tables of the current values are in the workspace
+    optimizer.step(p, torch.full_like(p, 0.5), state, b["unflatten"], ("eps", "vd", "mgridref_y", "eta", "gamma"))
+    c1 = calls()
+    l2, _, s2 = mcdbm.bound_forward(seeds, p, *args, **kw)
+    assert calls()["full"] - c1["full"] == 1
+    lf, _, sf = fresh(p)
+    assert torch.equal(l2, lf) and torch.equal(s2, sf)
+    # another batch size, then another tensor with the same contents at another address
+    c1 = calls()
+    mcdbm.bound_forward(seeds[: n // 2], p, *args, **kw)
+    mcdbm.bound_forward(seeds, p.clone(), *args, **kw)
+    assert calls()["full"] - c1["full"] == 2

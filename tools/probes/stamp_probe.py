@@ -13,8 +13,8 @@ os.makedirs(os.path.dirname(lib), exist_ok=True)
 csrc = os.path.join(ROOT, "cmcd_amd", "csrc")
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                 "-DCMCD_STAMPS", "-I", os.path.join(ROOT, "include"), "-I", csrc, "-Wno-format-security",
-                "-o", lib, os.path.join(csrc, "cmcd_kernels.hip"), os.path.join(csrc, "cmcd_coop.hip"),
-                os.path.join(csrc, "cmcd_lgcp.hip"), os.path.join(csrc, "cmcd_grad.hip"), os.path.join(csrc, "cmcd_bptt.hip"),
+                "-o", lib, os.path.join(csrc, "cmcd_kernels.hip"), os.path.join(csrc, "cmcd_coop.hip"), os.path.join(csrc, "cmcd_uha.hip"),
+                os.path.join(csrc, "cmcd_lgcp.hip"), os.path.join(csrc, "cmcd_lgcp_wide.hip"), os.path.join(csrc, "cmcd_grad.hip"), os.path.join(csrc, "cmcd_bptt.hip"),
                 os.path.join(csrc, "cmcd_mfvi.hip"), os.path.join(csrc, "cmcd_opt.hip")], check=True)
 os.environ["CMCD_LIB_PATH"] = lib
 os.environ.setdefault("CMCD_KERNEL_VARIANT", "2")   # 3 / 4 pin the 16- / 8-particle tiling
