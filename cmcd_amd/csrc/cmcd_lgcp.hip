@@ -646,6 +646,7 @@ __global__ __launch_bounds__(64 * (kGemmWaves + ((EPI == EPI_STEP || EPI == EPI_
 constexpr int kNskChunks = 104;                  // 16-deep chunks of a packed operand (K <= 1664), 13 per wave
 constexpr int kNskCpw = kNskChunks / kGemmWaves;
 constexpr int64_t kNskOperand = (int64_t)2 * kNskChunks * 256;   // floats of one packed [32 x 1664] operand
+constexpr int kNskOps = 6;                      // per lane: z (three rotating buffers), u1, u2, K^-1 product
 
 __host__ __device__ __forceinline__ int64_t nsk_pack(int r, int k) {
   return (((int64_t)(r >> 4) * kNskChunks + (k >> 4)) * 64 + (r & 15) + 16 * ((k & 15) >> 2)) * 4 + (k & 3);
@@ -667,13 +668,15 @@ struct NskArgs {
   // activations
   const float* bias;   // ACT1: bias1_i [IN];  ACT2: b2 [IN] (params)
   const float* emb;    // ACT1: emb_i [E]
-  float* xA;           // packed z (ACT1 reads it; STEP updates the tile's own elements in place)
+  const float* xA;     // packed z of this evaluation (operand of A / of B's second product; ACT1 and STEP read it)
   const float* uA;     // ACT2: packed u1
   float* outA;         // ACT1: packed u1; ACT2: packed u2; KR: packed K^-1 product
   int D, IN;
   // state update (the fields of StepEpi; x / xp / kr in the packed layout, one value per element instead of slabs)
   StepEpi step;
-  float* xpA;
+  const float* xpA;    // packed z of the previous evaluation
+  float* xnA;          // packed z of the next one.  cur / prev / next ROTATE on the host: in MCD_ULA the state is the operand of
+                       // the very launch that updates it, so no launch writes a buffer another workgroup may still be loading
   const float* krA;    // STEP: the K^-1 product of this evaluation (launch B)
   float* krOut;        // KR
 };
@@ -786,8 +789,7 @@ __device__ __forceinline__ void nsk_step_post(const NskArgs& a, const NskStepPre
     if (last) {
       s.out_z[(int64_t)m * D + e] = z;
     } else {
-      a.xpA[t.ix] = z;
-      a.xA[t.ix] = zn;
+      a.xnA[t.ix] = zn;
       if (s.traj) s.traj[((int64_t)(i + 1) * s.n_total + s.base + m) * D + e] = zn;
     }
   }
@@ -1088,7 +1090,7 @@ __global__ __launch_bounds__(64) void lgcp_final_kernel(LgcpFinalArgs a) {
 constexpr int kLanes = 4;
 struct LgcpLane {
   int64_t x, xp, u1, u2, pre1, pre2, kr, slab1, slab2, sn, w, keys, gkey, slots, counters;
-  int64_t nsk;          // no-split-K form: packed x | xp | u1 | u2 | kr (kNskOperand floats each), then its slots [3][D / 16][kMP]
+  int64_t nsk;          // no-split-K form: packed x | xp | xn | u1 | u2 | kr (kNskOperand floats each), then its slots [3][D / 16][kMP]
 };
 struct LgcpWs {
   int64_t bias1, gktab, partials, total;
@@ -1143,7 +1145,7 @@ static LgcpWs lgcp_ws(const cmcd_desc& d, int64_t n, int64_t base) {
     const int64_t tIN = (IN + 15) / 16, tD = D / 16, per_tile = (int64_t)kNskChunks * 256;
     w.w1p = take(tIN * per_tile); w.w2p = take(tIN * per_tile); w.w3p = take(tD * per_tile); w.kip = take(tD * per_tile);
     for (int l = 0; l < kLanes; ++l)
-      w.lane[l].nsk = (l < lgcp_lanes(n) || l == 0) ? take(5 * kNskOperand + 3 * tD * kMP) : w.lane[0].nsk;
+      w.lane[l].nsk = (l < lgcp_lanes(n) || l == 0) ? take(kNskOps * kNskOperand + 3 * tD * kMP) : w.lane[0].nsk;
   }
   w.total = o;
   return w;
@@ -1292,7 +1294,7 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
       M[l] = (int)((n - base) < kMP ? (n - base) : kMP);
       if (hipMemsetAsync(ws + wl.slots, 0, sizeof(float) * 3 * cbD * kMP, st_l) != hipSuccess) return bail();
       // packed operands: the padding (rows >= M, inputs >= IN) must read as zeros; slots start at zero
-      if (nsk && hipMemsetAsync(ws + wl.nsk, 0, sizeof(float) * (5 * kNskOperand + 3 * (int64_t)tD * kMP), st_l) != hipSuccess)
+      if (nsk && hipMemsetAsync(ws + wl.nsk, 0, sizeof(float) * (kNskOps * kNskOperand + 3 * (int64_t)tD * kMP), st_l) != hipSuccess)
         return bail();
       LgcpStateArgs st{};
       st.seeds = seeds + base; st.params = params; st.tc = tc; st.x = nsk ? ws + wl.nsk : ws + wl.x; st.packed = nsk ? 1 : 0;
@@ -1312,7 +1314,7 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
       se.gktab = reinterpret_cast<uint32_t*>(ws + w.gktab);
       se.wslot = ws + wl.slots; se.fkslot = se.wslot + cbD * kMP; se.lpslot = se.fkslot + cbD * kMP;
       if (nsk) {   // one slot row per 16-column tile
-        se.wslot = ws + wl.nsk + 5 * kNskOperand; se.fkslot = se.wslot + tD * kMP; se.lpslot = se.fkslot + tD * kMP;
+        se.wslot = ws + wl.nsk + kNskOps * kNskOperand; se.fkslot = se.wslot + tD * kMP; se.lpslot = se.fkslot + tD * kMP;
       }
       se.out_z = out_z + base * D; se.traj = traj; se.n_total = n; se.base = base; se.lay = lay;
       se.D = D; se.K = K; se.var_mode = d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0; se.grad_clipping = d.grad_clipping;
@@ -1328,10 +1330,13 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
         GemmArgs& gl = g[l];
         gl.step.i = i;
         if (nsk) {
-          float* xA = ws + wl.nsk;
-          float* xpA = xA + kNskOperand, *u1A = xpA + kNskOperand, *u2A = u1A + kNskOperand, *krA = u2A + kNskOperand;
+          // evaluation i reads z_i from buffer i % 3, z_{i-1} from (i + 2) % 3 and writes z_{i+1} into (i + 1) % 3
+          float* const sb = ws + wl.nsk;
+          float* const xA = sb + (i % 3) * kNskOperand;
+          float* const u1A = sb + 3 * kNskOperand, *u2A = u1A + kNskOperand, *krA = u2A + kNskOperand;
           NskArgs na{};
-          na.M = M[l]; na.D = D; na.IN = IN; na.xA = xA; na.xpA = xpA; na.krA = krA; na.krOut = krA; na.step = gl.step;
+          na.M = M[l]; na.D = D; na.IN = IN; na.xA = xA; na.xpA = sb + ((i + 2) % 3) * kNskOperand;
+          na.xnA = sb + ((i + 1) % 3) * kNskOperand; na.krA = krA; na.krOut = krA; na.step = gl.step;
           // 17 .. 20 particles (the named batch): one workgroup per column tile serves both row blocks (16x16x4 + 4x4x1);
           // otherwise one workgroup per (tile, 16-row half).  State-update launches carry one extra workgroup (key chain).
           // Measured at N = 20 (profiles/r04_f_lgcp_nsk_per_launch_n20.txt): merged helps the launch that is otherwise two

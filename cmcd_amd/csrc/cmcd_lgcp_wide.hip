@@ -61,7 +61,11 @@ struct WideSeg {
 struct WideStep {            // evaluation i at z_i: closes step i-1, opens step i (i = K: collects log p(z_K))
   const float* sched;        // [K][8]
   const float* tc;           // {Kinv[d,d], counts[d], mu0, a, lognorm}
-  float* xp;                 // [Mp][ldx]  previous z
+  const float* xp;           // [Mp][ldx]  previous z
+  float* xn;                 // [Mp][ldx]  next z.  The state rotates through THREE buffers (cur -> prev, next -> cur on the host):
+                             // in MCD_ULA the state is the operand of the very launch that updates it, and a workgroup of
+                             // another column tile may still be streaming a row this one has finished (r04: an in-place
+                             // update there read as a 2.4-nat ELBO shift on 15 000-particle evaluations, and only there)
   const float* kr;           // [Mp][ldx]  (z - mu0) K^-1 of this evaluation (launch B)
   const float* b3;           // packed, [Np]
   const float* mean;         // packed vd.mean
@@ -82,7 +86,7 @@ struct WideArgs {
   int nct0, CT, RT, M;       // column tiles of segment 0 / of the launch, row tiles, real rows
   const float* bias;         // ACT1: bias1_i [IN] (workspace);  ACT2: packed b2
   const float* emb;          // ACT1: emb_i [E] (params)
-  float* x;                  // [Mp][ldx]  z (read by ACT1, updated in place by STEP on the tile's own columns)
+  const float* x;            // [Mp][ldx]  z of this evaluation (operand of A / B's second product, read by ACT1 and STEP)
   const float* u_prev;       // ACT2: u1
   float* u_out;              // ACT1: u1, ACT2: u2      [Mp][ldu]
   float* kr_out;             // KR: [Mp][ldx]
@@ -169,8 +173,7 @@ __device__ __forceinline__ void wide_step4(const WideArgs& a, int m, int col, co
     float* oz = s.out_z + (int64_t)m * D + col;
     oz[0] = zv[0]; oz[1] = zv[1]; oz[2] = zv[2]; oz[3] = zv[3];
   } else {
-    *reinterpret_cast<f32x4*>(s.xp + ro) = zv;
-    *reinterpret_cast<f32x4*>(a.x + ro) = znv;
+    *reinterpret_cast<f32x4*>(s.xn + ro) = znv;
   }
   bk_s = bk_acc; fk_s = fk_acc; lp_s = lp_acc;
 }
@@ -423,7 +426,7 @@ __global__ void lgcp_wide_final_kernel(WideFinalArgs a) {
 
 // ------------------------------------------------------------------------------------------ host side
 struct WideWs {
-  int64_t bias1, w1p, w2p, w3p, kip, b2, b3, mean, sd, counts, x, xp, kr, u1, u2, w0, gktab, slots, partials, total;
+  int64_t bias1, w1p, w2p, w3p, kip, b2, b3, mean, sd, counts, x, xp, xn, kr, u1, u2, w0, gktab, slots, partials, total;
   int Mp, ldx, ldu, NpD, NpIN, KpD, KpIN, ctD, ctIN;
 };
 
@@ -443,7 +446,8 @@ static WideWs wide_ws(const cmcd_desc& d, int64_t n, int64_t base) {
   w.w3p = take((int64_t)w.KpIN * w.NpD);
   w.kip = take((int64_t)w.KpD * w.NpD);
   w.b2 = take(w.NpIN); w.b3 = take(w.NpD); w.mean = take(w.NpD); w.sd = take(w.NpD); w.counts = take(w.NpD);
-  w.x = take((int64_t)w.Mp * w.ldx); w.xp = take((int64_t)w.Mp * w.ldx); w.kr = take((int64_t)w.Mp * w.ldx);
+  w.x = take((int64_t)w.Mp * w.ldx); w.xp = take((int64_t)w.Mp * w.ldx); w.xn = take((int64_t)w.Mp * w.ldx);
+  w.kr = take((int64_t)w.Mp * w.ldx);
   w.u1 = take((int64_t)w.Mp * w.ldu); w.u2 = take((int64_t)w.Mp * w.ldu);
   w.w0 = take(w.Mp);
   w.gktab = take(2 * K * n);
@@ -490,7 +494,7 @@ int lgcp_wide_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout
                      w.KpD, w.NpD);
   WideVecArgs va{params, tc, ws + w.b2, ws + w.b3, ws + w.mean, ws + w.sd, ws + w.counts, lay, D, IN, w.NpD, w.NpIN, has_net ? 1 : 0};
   hipLaunchKernelGGL(lgcp_wide_vec_kernel, dim3((w.NpIN + 255) / 256), dim3(256), 0, stream, va);
-  // x | xp | kr | u1 | u2 | w0 are contiguous up to alignment: padding rows and columns must read as zeros
+  // x | xp | xn | kr | u1 | u2 | w0 are contiguous up to alignment: padding rows and columns must read as zeros
   if (hipMemsetAsync(ws + w.x, 0, sizeof(float) * (size_t)(w.w0 + w.Mp - w.x), stream) != hipSuccess) return CMCD_ERR_HIP;
   if (hipMemsetAsync(ws + w.slots, 0, sizeof(float) * (size_t)3 * w.ctD * w.Mp, stream) != hipSuccess) return CMCD_ERR_HIP;
   WideInitArgs ia{seeds, params, ws + w.x, ws + w.w0, reinterpret_cast<uint32_t*>(ws + w.gktab), lay, n, D, w.ldx, K};
@@ -499,9 +503,9 @@ int lgcp_wide_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout
   const float mu0 = 3.8812819069514780f;      // log(126) - 0.5 * 1.91 (model_handler.py:346); the state update reads tc's copy
   WideArgs g{};
   g.M = (int)n; g.RT = w.Mp / kWRows;
-  g.x = ws + w.x; g.D = D; g.IN = IN; g.ldx = w.ldx; g.ldu = w.ldu;
+  g.D = D; g.IN = IN; g.ldx = w.ldx; g.ldu = w.ldu;
   WideStep& st = g.st;
-  st.sched = ws + sw.sched; st.tc = tc; st.xp = ws + w.xp; st.kr = ws + w.kr; st.b3 = ws + w.b3; st.mean = ws + w.mean;
+  st.sched = ws + sw.sched; st.tc = tc; st.kr = ws + w.kr; st.b3 = ws + w.b3; st.mean = ws + w.mean;
   st.sd = ws + w.sd; st.counts = ws + w.counts; st.factor = has_net ? params + lay.g_factor : nullptr;
   st.gktab = reinterpret_cast<const uint32_t*>(ws + w.gktab);
   st.wslot = ws + w.slots; st.fkslot = st.wslot + (int64_t)w.ctD * w.Mp; st.lpslot = st.fkslot + (int64_t)w.ctD * w.Mp;
@@ -512,10 +516,15 @@ int lgcp_wide_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout
     const int nt = g.CT * g.RT, per = (nt + 7) / 8;
     hipLaunchKernelGGL(lgcp_wide_gemm_kernel, dim3(8 * per), dim3(256), kWideLds, stream, g);
   };
+  float* xbuf[3] = {ws + w.x, ws + w.xp, ws + w.xn};      // cur, prev, next
   for (int i = 0; i <= K; ++i) {
     st.i = i;
+    float* const xc = xbuf[0];
+    g.x = xc; st.xp = xbuf[1]; st.xn = xbuf[2];
+    // after this evaluation: prev <- cur, cur <- next (the old prev is the buffer the next evaluation writes)
+    xbuf[0] = st.xn; xbuf[2] = xbuf[1]; xbuf[1] = xc;
     if (ula == 1) {    // MCD_ULA: one launch per evaluation, (x - mu0) K^-1 with the state update as its consumer
-      g.seg[0] = WideSeg{ws + w.x, ws + w.kip, w.ldx, w.NpD, w.KpD, WEPI_STEP_NONET, mu0};
+      g.seg[0] = WideSeg{xc, ws + w.kip, w.ldx, w.NpD, w.KpD, WEPI_STEP_NONET, mu0};
       g.nct0 = w.ctD;
       launch(w.ctD);
       continue;
@@ -524,13 +533,13 @@ int lgcp_wide_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout
     const int it = ula == 2 ? (i > 0 ? i - 1 : 0) : i;
     const int ie = it < K ? it : K - 1;
     // A
-    g.seg[0] = WideSeg{ws + w.x, ws + w.w1p, w.ldx, w.NpIN, w.KpD, WEPI_ACT1, 0.f};
+    g.seg[0] = WideSeg{xc, ws + w.w1p, w.ldx, w.NpIN, w.KpD, WEPI_ACT1, 0.f};
     g.nct0 = w.ctIN;
     g.bias = ws + w.bias1 + (int64_t)it * IN; g.emb = params + lay.g_emb + (int64_t)ie * E; g.u_out = ws + w.u1;
     launch(w.ctIN);
     // B: the second layer and, beside it, the K^-1 product (needs only the state; consumed by C)
     g.seg[0] = WideSeg{ws + w.u1, ws + w.w2p, w.ldu, w.NpIN, w.KpIN, WEPI_ACT2, 0.f};
-    g.seg[1] = WideSeg{ws + w.x, ws + w.kip, w.ldx, w.NpD, w.KpD, WEPI_KR, mu0};
+    g.seg[1] = WideSeg{xc, ws + w.kip, w.ldx, w.NpD, w.KpD, WEPI_KR, mu0};
     g.nct0 = w.ctIN;
     g.bias = ws + w.b2; g.u_prev = ws + w.u1; g.u_out = ws + w.u2; g.kr_out = ws + w.kr;
     launch(w.ctIN + w.ctD);

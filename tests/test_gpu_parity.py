@@ -87,6 +87,11 @@ def test_lgcp_matches_oracle(hip_lib, param_set, monkeypatch, n, k, form):
     ("MCD_ULA", 40, 3, {}),                                        # no network: one launch per evaluation
     ("MCD_CAIS_sn", 257, 2, dict(emb_dim=12)),                     # width 1612: other padding of rows / columns
     ("MCD_CAIS_sn", 96, 16, dict(eps_schedule="cos_sq", init_eps=1e-3)),
+    # grids of MORE workgroups than the chip holds at once (832 / 455 tiles): the row tiles of late column tiles start after
+    # early ones have finished.  r04: MCD_ULA updated the state in place while it was the launch's own operand — invisible on
+    # one-wave grids, a 2.4-nat ELBO shift on the reference's 15 000-particle evaluation (tests/test_gpu_reference_tables.py)
+    ("MCD_ULA", 2048, 3, dict(init_eps=2e-4)),
+    ("MCD_CAIS_sn", 1100, 2, {}),
 ])
 def test_lgcp_wide_batch_path_matches_oracle(hip_lib, param_set, monkeypatch, mode, n, k, over):
     """The wide-batch form of the d = 1600 path (cmcd_lgcp_wide.hip: whole-batch launches of a 32 x 128-tile fp32 GEMM body,
