@@ -67,8 +67,10 @@ struct StepEpi {         // evaluation i at z_i: closes step i-1, opens step i (
   const float* params;
   const float* tc;           // {Kinv[d,d], counts[d], mu0, a, lognorm}
   const float* sched;        // [K][8]
-  float* x;                  // [kMP][D]   current z (updated in place, own columns only)
+  float* x;                  // [kMP][D]   current z (updated in place, own columns only, unless xn is set)
   float* xp;                 // [kMP][D]   previous z
+  float* xn;                 // MCD_ULA (the state is this launch's own GEMM operand): z_{i+1} goes HERE and the host rotates
+                             // cur / prev / next; nullptr: in place (the operand of launch C is u2, never the state)
   const float* kr;           // [kSplit][kMP][D]   partial slabs of K^-1 (x - mu0)   (previous launch)
   const float* b3;           // [D]
   const float* factor;       // factor_sn (device scalar)
@@ -410,8 +412,12 @@ __device__ __forceinline__ void lgcp_step_tile(const StepEpi& a, const float* sn
       if (last) {
         a.out_z[(int64_t)m * D + e] = zv[r];
       } else {
-        a.xp[m * D + e] = zv[r];
-        a.x[m * D + e] = znv[r];
+        if (a.xn) {
+          a.xn[m * D + e] = znv[r];
+        } else {
+          a.xp[m * D + e] = zv[r];
+          a.x[m * D + e] = znv[r];
+        }
         if (a.traj) a.traj[((int64_t)(i + 1) * a.n_total + a.base + m) * D + e] = znv[r];
       }
     }
@@ -1375,8 +1381,12 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
           continue;
         }
         if (ula == 1) {   // MCD_ULA: one launch per evaluation, [x - mu0] Kinv with the state update as its consumer
+          // the state is this launch's operand: z_i / z_{i-1} / z_{i+1} rotate through x, xp and the (unused: no network)
+          // u1 buffer instead of an in-place update that a slower workgroup of another column block could still be loading
+          float* const sb3[3] = {ws + wl.x, ws + wl.xp, ws + wl.u1};
+          gl.step.x = sb3[i % 3]; gl.step.xp = sb3[(i + 2) % 3]; gl.step.xn = sb3[(i + 1) % 3];
           gl.Kdim = D; gl.Kdim1 = 0;
-          gl.seg[0] = GemmSeg{ws + wl.x, kinv, ws + wl.kr, D, D, D, D, mu0};
+          gl.seg[0] = GemmSeg{gl.step.x, kinv, ws + wl.kr, D, D, D, D, mu0};
           gl.nblk0 = cbD; gl.epi_seg = -1;
           hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_STEP_NONET>, dim3(cbD, kSplit), gblock_step, gemm_lds, st_l, gl);
           continue;

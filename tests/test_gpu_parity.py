@@ -110,7 +110,7 @@ def test_lgcp_wide_batch_path_matches_oracle(hip_lib, param_set, monkeypatch, mo
     seeds = synthetic.parity_seeds(n)
     fn = mcdbm.compute_bound_var if "var" in mode else mcdbm.compute_bound
     out = {}
-    for variant in (2, 1):
+    for variant in (2, 1, 3):       # wide batch | 32-row passes (no-split-K GEMM) | 32-row passes (split-K GEMM)
         monkeypatch.setattr(mcdbm, "KERNEL_VARIANT", variant)
         val, (losses, z) = fn(torch.from_numpy(seeds).cuda(), b["params_flat"], b["unflatten"], b["params_fixed"],
                               b["target"], eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
@@ -134,6 +134,8 @@ def test_lgcp_wide_batch_path_matches_oracle(hip_lib, param_set, monkeypatch, mo
     # the two forms of the path sum the contractions in different orders: float32 rounding apart, nothing else
     np.testing.assert_allclose(out[2][1], out[1][1], rtol=2e-5, atol=2e-3)
     np.testing.assert_allclose(out[2][2], out[1][2], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(out[3][1], out[1][1], rtol=2e-5, atol=2e-3)
+    np.testing.assert_allclose(out[3][2], out[1][2], rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize("name,mode,n,over", [

@@ -45,6 +45,25 @@ def test_funnel_k8_seed_mean_against_the_notebook_row():
     assert abs(lnz.mean() - rows[0]["reference_ln_Z"]) <= 0.15, lnz.mean()
 
 
+def test_gmm_k8_restatement_trained_seeds_sit_where_the_hip_trained_ones_do():
+    """The advisor's question (r03): why does this build train gmm K = 8 to a higher ELBO (-0.54 +- 0.09 over eight HIP
+    training seeds) than the notebook's single run (-0.694 +- 0.052)?  Five seeds trained by the RESTATEMENTS alone (no HIP
+    code): -0.555 +- 0.088, ln Z -0.04 — the same distribution.  So the offset belongs to the training recipe this repo runs
+    (optax-style Adam, torch initial weights) against whatever produced the notebook's row, not to the kernels; against the
+    notebook the seed mean is +1.3 combined sigma.  Asserted: the restatement-trained mean against the notebook (3 combined
+    sigma) and against the HIP path's recorded seed statistics."""
+    rows = _group("gmm", 8)
+    assert len(rows) >= 5
+    elbo = np.array([r["elbo"] for r in rows])
+    n, mean, sd = len(rows), elbo.mean(), elbo.std(ddof=1)
+    ref, ref_std = rows[0]["reference_elbo"], rows[0]["reference_elbo_std"]
+    z = (mean - ref) / np.sqrt(ref_std ** 2 + sd ** 2 * (1.0 + 1.0 / n))
+    print(f"gmm K=8, {n} restatement-trained seeds: ELBO {mean:.4f} +- {sd:.4f} (notebook {ref:.4f} +- {ref_std:.4f}: {z:+.2f} combined sigma)")
+    assert abs(z) <= 3.0, (mean, ref, z)
+    hip_mean, hip_sd, hip_n = -0.5383, 0.0870, 8      # tests/test_gpu_reference_tables.py, r04 run (profiles/r04_gpu_test_suite.log)
+    assert abs(mean - hip_mean) <= 3.0 * np.sqrt(sd ** 2 / n + hip_sd ** 2 / hip_n), (mean, hip_mean)
+
+
 @pytest.mark.parametrize("row", [r for r in FULL if not (r["model"] == "funnel" and r["nbridges"] == 8)],
                          ids=lambda r: f"{r['model']}_k{r['nbridges']}_seed{r['seed']}")
 def test_oracle_trained_model_reaches_the_reference_notebook_row(row):
