@@ -47,11 +47,19 @@ PEAK_HBM_GBS = 8000.0
 CFG4 = "many_gmm_var_n16000_k256"
 
 
-def kernel_sources_sha():
-    """Identifies the kernel build a stored PMC figure belongs to: sha1 over the HIP sources of the trajectory kernels."""
+SHA_FAMILIES = {
+    # which HIP sources a stored PMC figure depends on: the trajectory kernels of configs 1 - 4, and the d = 1600 launch
+    # sequences (r04: separate, so that work on one family does not void the other's counters)
+    "traj": ("cmcd_coop.hip", "cmcd_kernels.hip", "cmcd_device.h", "cmcd_common.h"),
+    "lgcp": ("cmcd_lgcp.hip", "cmcd_lgcp_wide.hip", "cmcd_device.h", "cmcd_common.h"),
+}
+
+
+def kernel_sources_sha(family="traj"):
+    """Identifies the kernel build a stored PMC figure belongs to: sha1 over the HIP sources of that kernel family."""
     import hashlib
     h = hashlib.sha1()
-    for f in ("cmcd_coop.hip", "cmcd_kernels.hip", "cmcd_device.h", "cmcd_common.h", "cmcd_lgcp.hip", "cmcd_lgcp_wide.hip"):
+    for f in SHA_FAMILIES[family]:
         with open(os.path.join(ROOT, "cmcd_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -664,7 +672,7 @@ def main():
             for rnd in ("r04_pmc", "r03_pmc", "r02_pmc"):
                 try:   # only a summary measured on this build of the kernels counts (kernel_sources_sha)
                     pm = json.load(open(os.path.join(ROOT, "profiles", rnd, "lgcp_summary.json")))
-                    if pm.get("kernel_sources_sha") == kernel_sources_sha() and dim == 1600 and IN == 1620:
+                    if pm.get("kernel_sources_sha") == kernel_sources_sha("lgcp") and dim == 1600 and IN == 1620:
                         traffic = sum(v["hbm_bytes_per_launch"] for v in pm.values() if isinstance(v, dict)) * (K + 1) * -(-n // 32)
                         break
                 except Exception:

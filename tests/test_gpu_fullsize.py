@@ -296,3 +296,35 @@ def test_prepared_tables_are_reused_only_while_the_parameters_are_unchanged(hip_
     mcdbm.bound_forward(seeds[: n // 2], p, *args, **kw)
     mcdbm.bound_forward(seeds, p.clone(), *args, **kw)
     assert calls()["full"] - c1["full"] == 2
+
+
+def test_a_captured_forward_keeps_its_prep_launch(hip_lib):
+    """A forward call captured into a HIP graph must carry its prep launch (the prepared-table shortcut is refused while a
+    stream is capturing): replays after an in-place parameter update have to see the new parameters."""
+    b = synthetic.build("gmm_n300_k8", device="cuda")
+    seeds = torch.from_numpy(synthetic.throughput_seeds(300, stream=5)).cuda()
+    args = (b["unflatten"], b["params_fixed"], b["target"])
+    kw = dict(eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
+    p = b["params_flat"].clone()
+    for _ in range(3):                                  # warm: the workspace now holds p's tables (prepared calls from here on)
+        mcdbm.bound_forward(seeds, p, *args, **kw)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        mcdbm.bound_forward(seeds, p, *args, **kw)      # allocator warm-up on the capture stream
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    c0 = dict(mcdbm.PREP_CALLS)
+    with torch.cuda.graph(graph):
+        l_g, z_g, s_g = mcdbm.bound_forward(seeds, p, *args, **kw)
+    assert mcdbm.PREP_CALLS["full"] - c0["full"] == 1 and mcdbm.PREP_CALLS["prepared"] == c0["prepared"]
+    graph.replay()
+    torch.cuda.synchronize()
+    l0 = l_g.clone()
+    p.mul_(1.01)                                        # new parameters, same tensor
+    graph.replay()
+    torch.cuda.synchronize()
+    l_new, _, _ = mcdbm.bound_forward(seeds, p, *args, **kw)
+    assert torch.equal(l_g, l_new) and not torch.equal(l_g, l0)

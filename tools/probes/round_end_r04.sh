@@ -81,7 +81,7 @@ for (k, g, c), v in sorted(acc.items()):
 for k, d in out.items():
     if 'FETCH_SIZE' in d and 'WRITE_SIZE' in d:
         d['hbm_bytes_per_launch'] = (2 * d['FETCH_SIZE'] + d['WRITE_SIZE']) * 1024
-out['kernel_sources_sha'] = bench.kernel_sources_sha()
+out['kernel_sources_sha'] = bench.kernel_sources_sha('lgcp')
 json.dump(out, open('gpurun_out/%s/lgcp_pmc_summary.json' % T, 'w'), indent=1)
 print(json.dumps(out)[:800])
 PY
