@@ -654,17 +654,21 @@ constexpr int kNskCpw = kNskChunks / kGemmWaves;
 constexpr int64_t kNskOperand = (int64_t)2 * kNskChunks * 256;   // floats of one packed [32 x 1664] operand
 constexpr int kNskOps = 6;                      // per lane: z (three rotating buffers), u1, u2, K^-1 product
 
-__host__ __device__ __forceinline__ int64_t nsk_pack(int r, int k) {
-  return (((int64_t)(r >> 4) * kNskChunks + (k >> 4)) * 64 + (r & 15) + 16 * ((k & 15) >> 2)) * 4 + (k & 3);
+// nch: 16-deep chunks of the packed array — kNskChunks (K <= 1664), or 2 kNskChunks for the 3220-wide layers of the 2nd-order
+// mode (two rounds of 13 chunks per wave)
+__host__ __device__ __forceinline__ int64_t nsk_pack(int r, int k, int nch = kNskChunks) {
+  return (((int64_t)(r >> 4) * nch + (k >> 4)) * 64 + (r & 15) + 16 * ((k & 15) >> 2)) * 4 + (k & 3);
 }
 
-enum { NSK_ACT1 = 1, NSK_ACT2 = 2, NSK_KR = 3, NSK_STEP = 4, NSK_STEP_NONET = 5 };
+// NSK_OUT: the plain product, stored row-major [kMP][N] (the element-wise kernels of the 2nd-order sequence read it)
+enum { NSK_ACT1 = 1, NSK_ACT2 = 2, NSK_KR = 3, NSK_STEP = 4, NSK_STEP_NONET = 5, NSK_OUT = 6, NSK_UHA_MID = 7 };
 
 struct NskSeg {
-  const float* A;      // packed operand
-  const float* W;      // packed weights [ceil(N / 16)][kNskChunks][64][4]
+  const float* A;      // packed operand [2][nch][64][4]
+  const float* W;      // packed weights [ceil(N / 16)][nch][64][4]
   int N, epi;
   float a_shift;       // the operand is A - a_shift
+  int nch = kNskChunks;   // chunks of THIS segment's contraction (a multiple of kNskChunks)
 };
 
 struct NskArgs {
@@ -678,13 +682,32 @@ struct NskArgs {
   const float* uA;     // ACT2: packed u1
   float* outA;         // ACT1: packed u1; ACT2: packed u2; KR: packed K^-1 product
   int D, IN;
+  int nch_out = kNskChunks;   // chunk count of the packed OUTPUT (outA)
+  float* outN = nullptr;      // NSK_OUT / NSK_KR with plain output: row-major [kMP][N]
   // state update (the fields of StepEpi; x / xp / kr in the packed layout, one value per element instead of slabs)
   StepEpi step;
   const float* xpA;    // packed z of the previous evaluation
   float* xnA;          // packed z of the next one.  cur / prev / next ROTATE on the host: in MCD_ULA the state is the operand of
                        // the very launch that updates it, so no launch writes a buffer another workgroup may still be loading
   const float* krA;    // STEP: the K^-1 product of this evaluation (launch B)
-  float* krOut;        // KR
+  float* krOut;        // KR (packed, the overdamped sequence)
+  float* krOutN = nullptr;   // KR, row-major [kMP][N] (the 2nd-order sequence's element-wise kernels read it)
+  // NSK_UHA_MID: F1 of the 2nd-order sequence (momentum refresh + half kick + drift, mcd_under_lp_a_cais.py:52-63) as the
+  // consumer of its launch L3 (u2 W3)
+  struct UhaMid {
+    const float* params; const float* tc; const float* sched;
+    const float* zr;           // packed [z | rho]
+    float* zrp;                // packed [z | rho']
+    float* zn;                 // packed z'
+    float* rpp;                // [kMP][D] rho''
+    const float* kr;           // [kMP][D] K^-1 (z - mu0)
+    const uint32_t* gkey;      // [kMP][2] G_i
+    float* fkslot;             // [D / 16][kMP] forward-kernel log-density of the bridge on the tile's columns
+    float* traj;
+    int64_t n_total, base;
+    cmcd_layout lay;
+    int D, K, i;
+  } um;
 };
 
 // One element (row m of the pass, column e) of evaluation i's state update — the arithmetic of lgcp_step_tile — in TWO
@@ -815,14 +838,78 @@ __device__ __forceinline__ void nsk_step_post(const NskArgs& a, const NskStepPre
   }
 }
 
+// F1 of the 2nd-order sequence as a consumer (the arithmetic of lgcp_uha_mid_kernel), loads and the deviate ahead of the GEMM
+struct NskMidPre {
+  float z, rho, kr, b3, mean, ld, cnt, noise, fac, beta, eps, gamma, pa;
+  uint32_t g0, g1;
+  int64_t iz, ir, in;
+};
+__device__ __forceinline__ void nsk_mid_loads(const NskArgs& a, int m, int e, NskMidPre& t) {
+  const NskArgs::UhaMid& u = a.um;
+  const int D = u.D, ec = min(e, D - 1), mc = min(m, a.M - 1);
+  t.iz = nsk_pack(mc, ec, 2 * kNskChunks); t.ir = nsk_pack(mc, D + ec, 2 * kNskChunks); t.in = t.iz;   // zn shares z's index
+  t.z = u.zr[t.iz]; t.rho = u.zr[t.ir];
+  t.kr = u.kr[(int64_t)mc * D + ec];
+  t.b3 = u.params[u.lay.g_b3 + ec];
+  t.mean = u.params[u.lay.vd_mean + ec];
+  t.ld = u.params[u.lay.vd_logdiag + ec];
+  t.cnt = u.tc[(int64_t)D * D + ec];
+  t.pa = u.tc[(int64_t)D * D + D + 1];
+  t.g0 = u.gkey[2 * mc]; t.g1 = u.gkey[2 * mc + 1];
+  t.fac = u.params[u.lay.g_factor];
+  t.beta = u.sched[8 * u.i]; t.eps = u.sched[8 * u.i + 1];
+  t.gamma = u.params[u.lay.gamma];
+}
+__device__ __forceinline__ void nsk_mid_pre(const NskArgs& a, int e, NskMidPre& t) {
+  const int D = a.um.D, H = (D + 1) / 2, ec = min(e, D - 1);
+  const int j = ec < H ? ec : ec - H;
+  uint32_t y0 = j, y1 = (H + j < D) ? H + j : 0;
+  threefry2x32(t.g0, t.g1, y0, y1);
+  t.noise = bits_to_normal(ec < H ? y0 : y1);
+}
+__device__ __forceinline__ void nsk_mid_post(const NskArgs& a, const NskMidPre& t, float o, int m, int e, int tile, bool live) {
+  const NskArgs::UhaMid& u = a.um;
+  const int D = u.D;
+  const float eps = t.eps, beta = t.beta;
+  const float eta = t.gamma * eps, ome = 1.0f - eta, sig = sqrtf(2.0f * eta);
+  const float inv2s2 = 1.0f / (2.0f * sig * sig), cst = logf(sig) + kHalfLog2Pi;
+  const float s1 = (o + t.b3) * t.fac;
+  const float sd = expf(t.ld);
+  float gp = -t.kr + t.cnt - t.pa * expf(t.z);
+  gp = fminf(fmaxf(gp, -1e2f), 1e2f);                          // gradU(z, beta, clip=1e2)          :23-30
+  const float gq = -(t.z - t.mean) / (sd * sd);
+  const float uf = -1.0f * (beta * gp + (1.0f - beta) * gq);
+  const float mf = t.rho * ome - 2.0f * eta * s1;               // :52-54
+  const float rhop = mf + sig * t.noise;                        // :58-59
+  const float df = rhop - mf;
+  float fk = -(df * df) * inv2s2 - cst;
+  const float rpp = rhop - eps * uf / 2.0f;                     // :62
+  if (live) {
+    u.zrp[t.iz] = t.z;
+    u.zrp[t.ir] = rhop;
+    u.zn[t.in] = t.z + eps * rpp;                               // :63
+    u.rpp[(int64_t)m * D + e] = rpp;
+    if (u.traj) u.traj[((int64_t)(2 * u.K + 2 + u.i) * u.n_total + u.base + m) * D + e] = rhop;
+  }
+  fk = live ? fk : 0.f;
+#pragma unroll
+  for (int ofs = 8; ofs > 0; ofs >>= 1) fk += __shfl_xor(fk, ofs);   // the 16 lanes that share the row, fixed butterfly
+  if ((threadIdx.x & 15) == 0 && m < a.M) u.fkslot[tile * kMP + m] = fk;
+}
+
 // MERGED (17 .. 20 particles, the named batch): ONE workgroup per column tile serves rows 0 .. 15 on 16x16x4 and rows
 // 16 .. 19 on v_mfma_f32_4x4x1 (16 blocks of 4 rows x 4 columns, block = (column group, k quarter)) against the SAME weight
 // registers — the weights are fetched once instead of once per 16-row half (launch B: 202 workgroups, one per CU, instead of
 // 404).  Lane l's 4x4x1 operands: A = packed operand of row 16 + l % 4 at the lane's k quarter, B = its 16x16x4 weight
 // register; D register r of lane l = row 16 + r, column l % 16, partial over the lane's k quarter (summed over the four
 // quarters in the LDS pass).  STEP launches carry one EXTRA workgroup (the last) that advances the chain's key.
-template <bool STEP, bool MERGED>
-__global__ __launch_bounds__(64 * kGemmWaves) void lgcp_nsk_kernel(NskArgs a) {
+// ROUNDS: rounds of 13 chunks per wave (compile time: the one-round instances of the overdamped sequence keep their registers —
+// 126, two workgroups per CU for the 404-workgroup launch B of a 21 .. 32-particle pass; a run-time round loop cost them 8
+// registers and 4 % of the call); 2 = the 3220-wide layers of the 2nd-order sequence (every segment of such a launch has its
+// own round count <= ROUNDS)
+template <int KIND, bool MERGED, int ROUNDS = 1>      // KIND 0: activations / plain products; 1: the state update; 2: the 2nd-order F1
+__global__ __launch_bounds__(64 * kGemmWaves, (KIND || MERGED) ? 2 : 4) void lgcp_nsk_kernel(NskArgs a) {
+  constexpr bool STEP = KIND == 1, MID = KIND == 2;
   __shared__ float red[kGemmWaves][MERGED ? 512 : 256];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (STEP && blockIdx.x == gridDim.x - 1) {
@@ -850,25 +937,36 @@ __global__ __launch_bounds__(64 * kGemmWaves) void lgcp_nsk_kernel(NskArgs a) {
   const bool live = cons && n < sg.N && row < a.M;
   // ---- consumer operands first (they come from earlier launches): in flight beside the GEMM's own loads
   NskStepPre sp;
+  NskMidPre mp;
   float cu = 0.f, cb = 0.f;
   int64_t cix = 0;
   if (cons) {
-    if (STEP) {
+    if (MID) {
+      nsk_mid_loads(a, row, n, mp);
+    } else if (STEP) {
       if (sg.epi == NSK_STEP) nsk_step_loads<false>(a, row, n, sp);
       else nsk_step_loads<true>(a, row, n, sp);
-    } else if (sg.epi != NSK_KR) {
+    } else if (sg.epi == NSK_ACT1 || sg.epi == NSK_ACT2) {
       const int nc = min(n, sg.N - 1), rc = min(row, a.M - 1);
-      cix = nsk_pack(rc, nc);
+      cix = nsk_pack(rc, nc, a.nch_out);
       cb = a.bias[nc];
-      cu = sg.epi == NSK_ACT2 ? a.uA[cix] : (nc < a.D ? a.xA[cix] : a.emb[max(nc - a.D, 0)]);     // u = [x; emb_i]  nn.py:68-69
+      // u = [x; emb_i] (nn.py:68-69); x is this launch's own operand (its chunk count), u1 the previous launch's output
+      cu = sg.epi == NSK_ACT2 ? a.uA[cix] : (nc < a.D ? a.xA[nsk_pack(rc, nc, sg.nch)] : a.emb[max(nc - a.D, 0)]);
     }
   }
-  const f32x4* Ap = reinterpret_cast<const f32x4*>(sg.A) + ((int64_t)half * kNskChunks + wv) * 64 + lane;
-  const f32x4* Wp = reinterpret_cast<const f32x4*>(sg.W) + ((int64_t)tile * kNskChunks + wv) * 64 + lane;
-  // chunk c = wave + 8 j: at every j the workgroup reads 8 KB contiguous of either operand.  All loads in flight before
-  // the first wait, chunk by chunk, so the first matrix instruction waits for two of them.
+  constexpr int nch = ROUNDS * kNskChunks;                      // every segment of a launch has ROUNDS rounds of 13 chunks per wave
+  const f32x4* Ap = reinterpret_cast<const f32x4*>(sg.A) + ((int64_t)half * nch + wv) * 64 + lane;
+  const f32x4* Wp = reinterpret_cast<const f32x4*>(sg.W) + ((int64_t)tile * nch + wv) * 64 + lane;
+  const f32x4* A2p = reinterpret_cast<const f32x4*>(sg.A) + ((int64_t)nch + wv) * 64 + (lane & 3) + 16 * (lane >> 4);
+  f32x4 acc[4], ac2[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { acc[q] = f32x4{0.f, 0.f, 0.f, 0.f}; ac2[q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const float shift = sg.a_shift;
+  // chunk c = wave + 8 j, j = 0 .. 13 ROUNDS - 1: at every j the workgroup reads 8 KB contiguous of either operand.  The first 13
+  // chunks' loads are all in flight before the first wait, chunk by chunk (the first matrix instruction waits for two of them);
+  // ROUNDS = 2: as soon as chunk j's matrix instructions have issued, its registers take chunk j + 13 — thirteen chunks stay in
+  // flight through the whole contraction instead of two serial rounds (13.2 -> see profiles/r04_s_*)
   f32x4 av[kNskCpw], bv[kNskCpw], a2[MERGED ? kNskCpw : 1];
-  const f32x4* A2p = reinterpret_cast<const f32x4*>(sg.A) + ((int64_t)kNskChunks + wv) * 64 + (lane & 3) + 16 * (lane >> 4);
 #pragma unroll
   for (int j = 0; j < kNskCpw; ++j) {
     bv[j] = Wp[j * 512]; av[j] = Ap[j * 512];
@@ -879,28 +977,30 @@ __global__ __launch_bounds__(64 * kGemmWaves) void lgcp_nsk_kernel(NskArgs a) {
     if (sg.epi == NSK_STEP) nsk_step_pre<false>(a, n, sp);
     else nsk_step_pre<true>(a, n, sp);
   }
+  if (MID && cons) nsk_mid_pre(a, n, mp);
   __builtin_amdgcn_sched_barrier(0);
-  f32x4 acc[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const float shift = sg.a_shift;
-#pragma unroll
-  for (int j = 0; j < kNskCpw; ++j)
+  for (int j = 0; j < kNskCpw * ROUNDS; ++j) {
+    const int sl = j % kNskCpw;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][q] - shift, bv[j][q], acc[q], 0, 0, 0);
+      acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[sl][q] - shift, bv[sl][q], acc[q], 0, 0, 0);
+    if (MERGED) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        ac2[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(a2[sl][q] - shift, bv[sl][q], ac2[q], 0, 0, 0);
+    }
+    if (ROUNDS > 1 && j + kNskCpw < kNskCpw * ROUNDS) {
+      __builtin_amdgcn_sched_barrier(0);
+      bv[sl] = Wp[(j + kNskCpw) * 512]; av[sl] = Ap[(j + kNskCpw) * 512];
+      if (MERGED) a2[sl] = A2p[(j + kNskCpw) * 512];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
   const f32x4 t = (acc[0] + acc[1]) + (acc[2] + acc[3]);      // fixed order
 #pragma unroll
   for (int r = 0; r < 4; ++r) red[wv][r * 64 + lane] = t[r];
   if (MERGED) {
-    f32x4 ac2[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) ac2[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < kNskCpw; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        ac2[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(a2[j][q] - shift, bv[j][q], ac2[q], 0, 0, 0);
     const f32x4 t2 = (ac2[0] + ac2[1]) + (ac2[2] + ac2[3]);
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wv][256 + r * 64 + lane] = t2[r];
@@ -924,9 +1024,18 @@ __global__ __launch_bounds__(64 * kGemmWaves) void lgcp_nsk_kernel(NskArgs a) {
     else nsk_step_post<true>(a, sp, v, row, n, tile, live);
     return;
   }
+  if (MID) {
+    nsk_mid_post(a, mp, v, row, n, tile, live);
+    return;
+  }
   if (!live) return;
-  if (sg.epi == NSK_KR) a.krOut[nsk_pack(row, n)] = v;         // second segment of launch B: its own output array
-  else a.outA[cix] = cu + softplus(v + cb);                    // nn.py:45-50
+  if (sg.epi == NSK_KR || sg.epi == NSK_OUT) {                 // plain products: the K^-1 product (second segment of launch B) / u2 W3
+    if (a.outN && sg.epi == NSK_OUT) a.outN[(int64_t)row * sg.N + n] = v;
+    else if (a.krOutN) a.krOutN[(int64_t)row * sg.N + n] = v;
+    else a.krOut[nsk_pack(row, n)] = v;
+  } else {
+    a.outA[cix] = cu + softplus(v + cb);                       // nn.py:45-50
+  }
 }
 
 // packed copies of up to four [K][N] weight matrices (row stride = N) in ONE launch (blockIdx.y = matrix): one thread per
@@ -935,15 +1044,16 @@ struct NskPackArgs {
   const float* src[4];
   float* dst[4];
   int K[4], N[4], ntile[4];
+  int nch[4];          // chunks per tile of the packed copy (0: kNskChunks)
 };
 __global__ void lgcp_nsk_pack_kernel(NskPackArgs a) {
   const int q = blockIdx.y;
   const float* __restrict__ src = a.src[q];
   if (!src) return;
-  const int K = a.K[q], N = a.N[q];
+  const int K = a.K[q], N = a.N[q], nch = a.nch[q] ? a.nch[q] : kNskChunks;
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;          // (tile, chunk, lane)
-  if (g >= (int64_t)a.ntile[q] * kNskChunks * 64) return;
-  const int lane = (int)(g & 63), chunk = (int)((g >> 6) % kNskChunks), tile = (int)((g >> 6) / kNskChunks);
+  if (g >= (int64_t)a.ntile[q] * nch * 64) return;
+  const int lane = (int)(g & 63), chunk = (int)((g >> 6) % nch), tile = (int)((g >> 6) / nch);
   const int n = tile * 16 + (lane & 15), k0 = chunk * 16 + 4 * (lane >> 4);
   f32x4 v;
 #pragma unroll
@@ -997,6 +1107,19 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh) {
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
   __syncthreads();
   return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+template <int NW>   // NW waves per block, fixed order
+__device__ __forceinline__ float block_sum_n(float v, float* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) t += sh[w];
+  return t;
 }
 
 // z0 = mean + std * normal(A, (D,)); w = -log q(z0); gen = second(split(first(split(B))))
@@ -1354,11 +1477,11 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
             const unsigned gy = (!merged && M[l] > 16) ? 2 : 1;
             const dim3 grid((unsigned)tiles + (step ? 1 : 0), gy);
             if (step) {
-              if (merged) hipLaunchKernelGGL((lgcp_nsk_kernel<true, true>), grid, gblock, 0, st_l, na);
-              else hipLaunchKernelGGL((lgcp_nsk_kernel<true, false>), grid, gblock, 0, st_l, na);
+              if (merged) hipLaunchKernelGGL((lgcp_nsk_kernel<1, true>), grid, gblock, 0, st_l, na);
+              else hipLaunchKernelGGL((lgcp_nsk_kernel<1, false>), grid, gblock, 0, st_l, na);
             } else {
-              if (merged) hipLaunchKernelGGL((lgcp_nsk_kernel<false, true>), grid, gblock, 0, st_l, na);
-              else hipLaunchKernelGGL((lgcp_nsk_kernel<false, false>), grid, gblock, 0, st_l, na);
+              if (merged) hipLaunchKernelGGL((lgcp_nsk_kernel<0, true>), grid, gblock, 0, st_l, na);
+              else hipLaunchKernelGGL((lgcp_nsk_kernel<0, false>), grid, gblock, 0, st_l, na);
             }
           };
           if (ula == 1) {   // MCD_ULA: one launch per evaluation, (x - mu0) K^-1 with the state update as its consumer
@@ -1967,7 +2090,16 @@ struct LgcpUhaWs {
   int64_t u1, u2, pre1, pre2;                      // [kMP][IN]
   int64_t slab1, slab2, sn, kr;                    // [kSplit][kMP][IN] x2, [kSplit][kMP][D] x2
   int64_t w, fk, keys, gkey, counters, partials, total;
+  // r04, no-split-K form: packed weights (W1[:2d] | W2 | W3 | K^-1 with 2 kNskChunks chunks per tile: K^-1 zero beyond d) and
+  // packed operands zr | zrp | u1 | u2 | zn (2 kNskOperand floats each)
+  int64_t w1p, w2p, w3p, kip, ops;
 };
+
+// the 2nd-order sequence on the no-split-K kernel: widths up to 2 * 1664 inputs; desc.reserved == 3 pins the split-K sequence
+static bool lgcp_uha_nsk_ok(const cmcd_desc& d) {
+  const int D = d.dim, IN = 2 * D + d.emb_dim;
+  return d.reserved != 3 && D % 16 == 0 && D <= 16 * kNskChunks && IN <= 32 * kNskChunks;
+}
 
 static LgcpUhaWs lgcp_uha_ws(const cmcd_desc& d, int64_t n, int64_t base) {
   const int64_t D = d.dim, IN = 2 * D + d.emb_dim, K = d.nbridges;
@@ -1983,6 +2115,12 @@ static LgcpUhaWs lgcp_uha_ws(const cmcd_desc& d, int64_t n, int64_t base) {
   w.counters = take(((D + 63) / 64) + ((IN + 63) / 64));
   o = (o + 1) & ~int64_t(1);
   w.partials = take(n * CMCD_NSTATS * 2);
+  w.w1p = w.w2p = w.w3p = w.kip = w.ops = 0;
+  if (lgcp_uha_nsk_ok(d)) {
+    const int64_t tIN = (IN + 15) / 16, tD = D / 16, big = (int64_t)2 * kNskChunks * 256;
+    w.w1p = take(tIN * big); w.w2p = take(tIN * big); w.w3p = take(tD * big); w.kip = take(tD * big);
+    w.ops = take(5 * 2 * kNskOperand);
+  }
   w.total = o;
   return w;
 }
@@ -2009,7 +2147,19 @@ struct LgcpUhaStepArgs {
   int64_t n_total, base;
   cmcd_layout lay;
   int M, D, K, i;
+  // r04 (the GEMMs on the no-split-K kernel): zr / zrp / zn are packed operands of 2 kNskChunks chunks (nsk_pack); kr / sn are
+  // ONE row-major [kMP][D] array each instead of kSplit slabs
+  int packed, nslab;
+  const float* fkslot;       // r04: F1 fused into its GEMM launch leaves the forward density per 16-column tile, [D / 16][kMP]
 };
+
+__device__ __forceinline__ int64_t uha_zr_ix(const LgcpUhaStepArgs& a, int p, int col) {     // element (p, col) of [z | rho]
+  return a.packed ? nsk_pack(p, col, 2 * kNskChunks) : (int64_t)p * 2 * a.D + col;
+}
+__device__ __forceinline__ int64_t uha_zn_ix(const LgcpUhaStepArgs& a, int p, int e) {
+  // (the K^-1 product's operand shares the two-round layout of its launch: its weights are zero-padded to 2 kNskChunks chunks)
+  return a.packed ? nsk_pack(p, e, 2 * kNskChunks) : (int64_t)p * a.D + e;
+}
 
 // z0 = mean + std normal(A); rho0 = normal(R); w = -log q(z0) - log N(rho0; 0, 1); gen_0, G_0
 // (mcdboundingmachine.py:151-162, mcd_under_lp_a_cais.py:92-100)
@@ -2055,8 +2205,9 @@ __global__ __launch_bounds__(256) void lgcp_uha_init_kernel(LgcpUhaStepArgs a) {
         const float sd = expf(a.params[a.lay.vd_logdiag + idx[q]]);
         const float z = sd * bits_to_normal(bz[q]) + mean;
         const float rho = bits_to_normal(br[q]);
-        a.zr[p * 2 * D + idx[q]] = z;
-        a.zr[p * 2 * D + D + idx[q]] = rho;
+        a.zr[uha_zr_ix(a, p, idx[q])] = z;
+        a.zr[uha_zr_ix(a, p, D + idx[q])] = rho;
+        if (a.packed) a.zn[uha_zn_ix(a, p, idx[q])] = z;       // operand of the K^-1 (z_0 - mu0) launch
         if (a.traj) {
           a.traj[(a.base + p) * D + idx[q]] = z;
           a.traj[((int64_t)(K + 1) * a.n_total + a.base + p) * D + idx[q]] = rho;
@@ -2071,9 +2222,11 @@ __global__ __launch_bounds__(256) void lgcp_uha_init_kernel(LgcpUhaStepArgs a) {
   if (threadIdx.x == 0) a.w[p] = -lq;
 }
 
-// F1 (see the header above)
-__global__ __launch_bounds__(256) void lgcp_uha_mid_kernel(LgcpUhaStepArgs a) {
-  __shared__ float sh[4];
+// F1 (see the header above).  NW waves per particle: 4 in the split-K sequence; 16 in the no-split-K one (r04: at 256 threads a
+// thread walks 6 - 7 elements one dependent load chain after the other, 9.6 us per launch; 1024 threads: one or two)
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void lgcp_uha_mid_kernel(LgcpUhaStepArgs a) {
+  __shared__ float sh[NW];
   const int p = blockIdx.x, D = a.D, H = (D + 1) / 2, K = a.K, i = a.i;
   const float* counts = a.tc + (int64_t)D * D;
   const float pa = a.tc[(int64_t)D * D + D + 1];
@@ -2085,10 +2238,9 @@ __global__ __launch_bounds__(256) void lgcp_uha_mid_kernel(LgcpUhaStepArgs a) {
   const uint32_t g0 = a.gkey[2 * p], g1 = a.gkey[2 * p + 1];
   float fk_acc = 0.f;
   for (int e = threadIdx.x; e < D; e += blockDim.x) {
-    const float z = a.zr[p * 2 * D + e], rho = a.zr[p * 2 * D + D + e];
+    const float z = a.zr[uha_zr_ix(a, p, e)], rho = a.zr[uha_zr_ix(a, p, D + e)];
     float kr = 0.f, o = a.params[a.lay.g_b3 + e];
-#pragma unroll
-    for (int ks = 0; ks < kSplit; ++ks) {
+    for (int ks = 0; ks < a.nslab; ++ks) {
       kr += a.kr[((int64_t)ks * kMP + p) * D + e];
       o += a.sn[((int64_t)ks * kMP + p) * D + e];
     }
@@ -2107,19 +2259,20 @@ __global__ __launch_bounds__(256) void lgcp_uha_mid_kernel(LgcpUhaStepArgs a) {
     const float df = rhop - mf;
     fk_acc += -(df * df) * inv2s2 - cst;
     const float rpp = rhop - eps * uf / 2.0f;                 // :62
-    a.zrp[p * 2 * D + e] = z;
-    a.zrp[p * 2 * D + D + e] = rhop;
-    a.zn[p * D + e] = z + eps * rpp;                          // :63
+    a.zrp[uha_zr_ix(a, p, e)] = z;
+    a.zrp[uha_zr_ix(a, p, D + e)] = rhop;
+    a.zn[uha_zn_ix(a, p, e)] = z + eps * rpp;                 // :63
     a.rpp[p * D + e] = rpp;
     if (a.traj) a.traj[((int64_t)(2 * K + 2 + i) * a.n_total + a.base + p) * D + e] = rhop;
   }
-  const float fk = block_sum_256(fk_acc, sh);
+  const float fk = block_sum_n<NW>(fk_acc, sh);
   if (threadIdx.x == 0) a.fk[p] = fk;
 }
 
 // F2 (see the header above)
-__global__ __launch_bounds__(256) void lgcp_uha_close_kernel(LgcpUhaStepArgs a) {
-  __shared__ float sh[4];
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void lgcp_uha_close_kernel(LgcpUhaStepArgs a) {
+  __shared__ float sh[NW];
   const int p = blockIdx.x, D = a.D, K = a.K, i = a.i;
   const bool last = i == K - 1;
   const float* counts = a.tc + (int64_t)D * D;
@@ -2129,7 +2282,9 @@ __global__ __launch_bounds__(256) void lgcp_uha_close_kernel(LgcpUhaStepArgs a) 
   const float eta = gamma * eps, ome = 1.0f - eta, sig = sqrtf(2.0f * eta);
   const float inv2s2 = 1.0f / (2.0f * sig * sig), cst = logf(sig) + kHalfLog2Pi;
   const float fac = a.params[a.lay.g_factor];
-  if (threadIdx.x == 0 && !last) {   // the key chain for bridge i + 1                  :55,84
+  // the key chain for bridge i + 1 (:55,84): ~450 dependent integer instructions, on the first lane of the LAST wave (the one
+  // with the fewest elements to walk)
+  if (threadIdx.x == 64 * (NW - 1) && !last) {
     uint32_t k0 = a.gen[2 * p], k1 = a.gen[2 * p + 1], G0, G1;
     lgcp_key_advance(k0, k1, G0, G1);
     a.gen[2 * p] = k0; a.gen[2 * p + 1] = k1;
@@ -2137,11 +2292,10 @@ __global__ __launch_bounds__(256) void lgcp_uha_close_kernel(LgcpUhaStepArgs a) 
   }
   float bk_acc = 0.f, lp_acc = 0.f, lr_acc = 0.f;
   for (int e = threadIdx.x; e < D; e += blockDim.x) {
-    const float rho = a.zr[p * 2 * D + D + e], rhop = a.zrp[p * 2 * D + D + e];
-    const float zn = a.zn[p * D + e], rpp = a.rpp[p * D + e];
+    const float rho = a.zr[uha_zr_ix(a, p, D + e)], rhop = a.zrp[uha_zr_ix(a, p, D + e)];
+    const float zn = a.zn[uha_zn_ix(a, p, e)], rpp = a.rpp[p * D + e];
     float kr = 0.f, o = a.params[a.lay.g_b3 + e];
-#pragma unroll
-    for (int ks = 0; ks < kSplit; ++ks) {
+    for (int ks = 0; ks < a.nslab; ++ks) {
       kr += a.kr[((int64_t)ks * kMP + p) * D + e];
       o += a.sn[((int64_t)ks * kMP + p) * D + e];
     }
@@ -2157,8 +2311,8 @@ __global__ __launch_bounds__(256) void lgcp_uha_close_kernel(LgcpUhaStepArgs a) 
     const float gq = -(zn - mean) / (sd * sd);
     const float ub = -1.0f * (beta * gp + (1.0f - beta) * gq);   // :65
     const float rnew = rpp - eps * ub / 2.0f;                 // :67
-    a.zr[p * 2 * D + e] = zn;
-    a.zr[p * 2 * D + D + e] = rnew;
+    a.zr[uha_zr_ix(a, p, e)] = zn;
+    a.zr[uha_zr_ix(a, p, D + e)] = rnew;
     if (a.traj) {
       a.traj[((int64_t)(i + 1) * a.n_total + a.base + p) * D + e] = zn;
       a.traj[((int64_t)(K + 2 + i) * a.n_total + a.base + p) * D + e] = rnew;
@@ -2169,11 +2323,17 @@ __global__ __launch_bounds__(256) void lgcp_uha_close_kernel(LgcpUhaStepArgs a) 
       a.out_z[(int64_t)p * D + e] = zn;
     }
   }
-  const float bk = block_sum_256(bk_acc, sh);
-  const float lp = block_sum_256(lp_acc, sh);
-  const float lr = block_sum_256(lr_acc, sh);
+  const float bk = block_sum_n<NW>(bk_acc, sh);
+  const float lp = block_sum_n<NW>(lp_acc, sh);
+  const float lr = block_sum_n<NW>(lr_acc, sh);
+  float fk_open = 0.f;
+  if (a.fkslot) {                                             // per-tile partials of the fused F1, fixed order
+    float t = 0.f;
+    for (int tl = threadIdx.x; tl < D / 16; tl += blockDim.x) t += a.fkslot[tl * kMP + p];
+    fk_open = block_sum_n<NW>(t, sh);
+  }
   if (threadIdx.x == 0) {
-    float w = a.w[p] + (bk - a.fk[p]);                        // :88
+    float w = a.w[p] + (bk - (a.fkslot ? fk_open : a.fk[p]));   // :88
     a.w[p] = w;
     if (last) {
       w += lr;                                                // + log N(rho_K; 0, 1)   :112
@@ -2221,6 +2381,91 @@ static void lgcp_uha_net(const cmcd_desc& d, const cmcd_layout& lay, const float
 
 static int64_t lgcp_uha_ws_total(const cmcd_desc& d, int64_t n, int64_t base) { return lgcp_uha_ws(d, n, base).total; }
 
+// The 2nd-order sequence on the no-split-K GEMM (r04; header above lgcp_nsk_kernel): the same eight launches per bridge, the six
+// GEMMs on 16 x 16 tiles over the whole contraction — 3200 / 3220 inputs are two rounds of 13 chunks per wave — with packed
+// operands; the K^-1 product of z' rides in L6 (100 + 100 tiles) instead of L4 (202 + 100 would not fit the chip at one
+// workgroup per CU in the 17 .. 20-particle form); F1 / F2 read ONE product array each instead of summing eight slabs.
+static int lgcp_uha_forward_nsk(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, const LgcpUhaWs& w,
+                                const int32_t* seeds, int64_t n, const float* params, const float* tc, float* ws, float* out_loss,
+                                float* out_z, double* partials, float* traj, hipStream_t stream) {
+  const int D = d.dim, E = d.emb_dim, IN = 2 * D + E, K = d.nbridges;
+  const int tIN = (IN + 15) / 16, tD = D / 16, big = 2 * kNskChunks;
+  const float mu0 = 3.8812819069514780f;
+  {
+    NskPackArgs pk{};
+    pk.src[0] = params + lay.g_w1; pk.dst[0] = ws + w.w1p; pk.K[0] = 2 * D; pk.N[0] = IN; pk.ntile[0] = tIN; pk.nch[0] = big;
+    pk.src[1] = params + lay.g_w2; pk.dst[1] = ws + w.w2p; pk.K[1] = IN; pk.N[1] = IN; pk.ntile[1] = tIN; pk.nch[1] = big;
+    pk.src[2] = params + lay.g_w3; pk.dst[2] = ws + w.w3p; pk.K[2] = IN; pk.N[2] = D; pk.ntile[2] = tD; pk.nch[2] = big;
+    pk.src[3] = tc; pk.dst[3] = ws + w.kip; pk.K[3] = D; pk.N[3] = D; pk.ntile[3] = tD; pk.nch[3] = big;   // zero rows beyond D
+    const int64_t groups = (int64_t)tIN * big * 64;
+    hipLaunchKernelGGL(lgcp_nsk_pack_kernel, dim3((unsigned)((groups + 255) / 256), 4), dim3(256), 0, stream, pk);
+  }
+  float* const zrA = ws + w.ops, *zrpA = zrA + 2 * kNskOperand, *u1A = zrpA + 2 * kNskOperand, *u2A = u1A + 2 * kNskOperand;
+  float* const znA = u2A + 2 * kNskOperand;
+  const dim3 gblock(64 * kGemmWaves);
+  for (int64_t base = 0; base < n; base += kMP) {
+    const int M = (int)((n - base) < kMP ? (n - base) : kMP);
+    // the padding of the packed operands (rows >= M, inputs >= IN) must read as zeros
+    if (hipMemsetAsync(zrA, 0, sizeof(float) * (5 * 2 * kNskOperand), stream) != hipSuccess) return CMCD_ERR_HIP;
+    LgcpUhaStepArgs sa{};
+    sa.seeds = seeds + base; sa.params = params; sa.tc = tc; sa.sched = ws + sw.sched;
+    sa.zr = zrA; sa.zrp = zrpA; sa.zn = znA; sa.rpp = ws + w.rpp; sa.kr = ws + w.kr; sa.sn = ws + w.sn;
+    sa.w = ws + w.w; sa.fk = ws + w.fk; sa.gen = reinterpret_cast<uint32_t*>(ws + w.keys);
+    sa.gkey = reinterpret_cast<uint32_t*>(ws + w.gkey);
+    sa.out_loss = out_loss + base; sa.out_z = out_z + base * D; sa.partials = partials + base * CMCD_NSTATS;
+    sa.traj = traj; sa.n_total = n; sa.base = base; sa.lay = lay; sa.M = M; sa.D = D; sa.K = K; sa.i = 0;
+    sa.packed = 1; sa.nslab = 1;
+    hipLaunchKernelGGL(lgcp_uha_init_kernel, dim3(M), dim3(256), 0, stream, sa);
+    const bool can_merge = M > 16 && M <= 20;
+    auto launch = [&](NskArgs& na, int tiles) {
+      // 17 .. 20 particles: one workgroup per column tile (16x16x4 + 4x4x1 on the same weight registers) — at these widths the
+      // weights are the bytes, so every launch takes the form that fetches them once
+      if (can_merge) hipLaunchKernelGGL((lgcp_nsk_kernel<0, true, 2>), dim3((unsigned)tiles, 1), gblock, 0, stream, na);
+      else hipLaunchKernelGGL((lgcp_nsk_kernel<0, false, 2>), dim3((unsigned)tiles, M > 16 ? 2 : 1), gblock, 0, stream, na);
+    };
+    auto kinv_seg = [&]() { NskSeg sg{znA, ws + w.kip, D, NSK_KR, mu0}; sg.nch = big; return sg; };
+    {   // K^-1 (z_0 - mu0)
+      NskArgs na{};
+      na.M = M; na.D = 2 * D; na.IN = IN; na.seg[0] = kinv_seg(); na.nt0 = tD; na.krOutN = ws + w.kr;
+      launch(na, tD);
+    }
+    float* const fkslot = ws + w.slab1;      // [D / 16][kMP] (the split-K form's slab region is free here)
+    sa.fkslot = fkslot;
+    // the network on `zin` at time index i: L1, L2, L3 of the header; with_kinv: (z' - mu0) K^-1 beside L3.  The first network of
+    // a bridge (!with_kinv) has F1 as the consumer of its L3
+    auto net = [&](int i, float* zin, bool with_kinv) {
+      NskArgs na{};
+      na.M = M; na.D = 2 * D; na.IN = IN; na.nch_out = big;
+      na.seg[0] = NskSeg{zin, ws + w.w1p, IN, NSK_ACT1, 0.f}; na.seg[0].nch = big; na.nt0 = tIN;
+      na.xA = zin; na.bias = ws + w.bias1 + (int64_t)i * IN; na.emb = params + lay.g_emb + (int64_t)i * E; na.outA = u1A;
+      launch(na, tIN);
+      na.seg[0] = NskSeg{u1A, ws + w.w2p, IN, NSK_ACT2, 0.f}; na.seg[0].nch = big;
+      na.bias = params + lay.g_b2; na.uA = u1A; na.outA = u2A;
+      launch(na, tIN);
+      na.seg[0] = NskSeg{u2A, ws + w.w3p, D, with_kinv ? NSK_OUT : NSK_UHA_MID, 0.f}; na.seg[0].nch = big; na.nt0 = tD;
+      na.outN = ws + w.sn;
+      if (with_kinv) {
+        na.seg[1] = kinv_seg(); na.krOutN = ws + w.kr;
+        launch(na, 2 * tD);
+        return;
+      }
+      NskArgs::UhaMid& um = na.um;
+      um.params = params; um.tc = tc; um.sched = ws + sw.sched; um.zr = zrA; um.zrp = zrpA; um.zn = znA; um.rpp = ws + w.rpp;
+      um.kr = ws + w.kr; um.gkey = reinterpret_cast<const uint32_t*>(ws + w.gkey); um.fkslot = fkslot; um.traj = traj;
+      um.n_total = n; um.base = base; um.lay = lay; um.D = D; um.K = K; um.i = i;
+      if (can_merge) hipLaunchKernelGGL((lgcp_nsk_kernel<2, true, 2>), dim3((unsigned)tD, 1), gblock, 0, stream, na);
+      else hipLaunchKernelGGL((lgcp_nsk_kernel<2, false, 2>), dim3((unsigned)tD, M > 16 ? 2 : 1), gblock, 0, stream, na);
+    };
+    for (int i = 0; i < K; ++i) {
+      sa.i = i;
+      net(i, zrA, false);       // L1, L2, L3 + F1
+      net(i, zrpA, true);       // L4, L5, L6 | K^-1 (z' - mu0)
+      hipLaunchKernelGGL(lgcp_uha_close_kernel<16>, dim3(M), dim3(1024), 0, stream, sa);
+    }
+  }
+  return hipGetLastError() == hipSuccess ? CMCD_OK : CMCD_ERR_HIP;
+}
+
 static int lgcp_uha_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, const int32_t* seeds, int64_t n,
                             const float* params, const float* tc, float* ws, float* out_loss, float* out_z,
                             double** partials_out, float* traj, hipStream_t stream) {
@@ -2228,6 +2473,11 @@ static int lgcp_uha_forward(const cmcd_desc& d, const cmcd_layout& lay, const Ws
   const LgcpUhaWs w = lgcp_uha_ws(d, n, sw.total_floats);
   LgcpPrepArgs pa{params, ws + w.bias1, lay, 2 * D, E, K, IN};   // bias1_i = b1 + emb_i W1[2d:, :]
   hipLaunchKernelGGL(lgcp_prep_kernel, dim3((IN + 255) / 256, K + 1), dim3(256), 0, stream, pa);
+  if (lgcp_uha_nsk_ok(d)) {
+    double* partials_n = reinterpret_cast<double*>(ws + w.partials);
+    *partials_out = partials_n;
+    return lgcp_uha_forward_nsk(d, lay, sw, w, seeds, n, params, tc, ws, out_loss, out_z, partials_n, traj, stream);
+  }
   const int gemm_lds = lgcp_gemm_attrs();
   if (gemm_lds < 0) return CMCD_ERR_HIP;
   double* partials = reinterpret_cast<double*>(ws + w.partials);
@@ -2245,6 +2495,7 @@ static int lgcp_uha_forward(const cmcd_desc& d, const cmcd_layout& lay, const Ws
     sa.gkey = reinterpret_cast<uint32_t*>(ws + w.gkey);
     sa.out_loss = out_loss + base; sa.out_z = out_z + base * D; sa.partials = partials + base * CMCD_NSTATS;
     sa.traj = traj; sa.n_total = n; sa.base = base; sa.lay = lay; sa.M = M; sa.D = D; sa.K = K; sa.i = 0;
+    sa.packed = 0; sa.nslab = kSplit;
     hipLaunchKernelGGL(lgcp_uha_init_kernel, dim3(M), dim3(256), 0, stream, sa);
     {   // K^-1 (z_0 - mu0)
       GemmArgs g{};
@@ -2257,10 +2508,10 @@ static int lgcp_uha_forward(const cmcd_desc& d, const cmcd_layout& lay, const Ws
       sa.i = i;
       lgcp_uha_net(d, lay, params, tc, M, i, ws + w.zr, ws + w.bias1, ws + w.slab1, ws + w.pre1, ws + w.u1, ws + w.slab2,
                    ws + w.pre2, ws + w.u2, ws + w.sn, nullptr, nullptr, counters, gemm_lds, stream);
-      hipLaunchKernelGGL(lgcp_uha_mid_kernel, dim3(M), dim3(256), 0, stream, sa);
+      hipLaunchKernelGGL(lgcp_uha_mid_kernel<4>, dim3(M), dim3(256), 0, stream, sa);
       lgcp_uha_net(d, lay, params, tc, M, i, ws + w.zrp, ws + w.bias1, ws + w.slab1, ws + w.pre1, ws + w.u1, ws + w.slab2,
                    ws + w.pre2, ws + w.u2, ws + w.sn, ws + w.zn, ws + w.kr, counters, gemm_lds, stream);
-      hipLaunchKernelGGL(lgcp_uha_close_kernel, dim3(M), dim3(256), 0, stream, sa);
+      hipLaunchKernelGGL(lgcp_uha_close_kernel<4>, dim3(M), dim3(256), 0, stream, sa);
     }
   }
   return hipGetLastError() == hipSuccess ? CMCD_OK : CMCD_ERR_HIP;

@@ -258,10 +258,16 @@ def test_lgcp_repeat_calls_are_bitwise_identical(hip_lib, n, k, reps):
     for r in range(max(reps // 5, 6)):
         g, (lg, _) = mcdbm.compute_bound_grad(seeds, *args)
         assert torch.equal(lg, l0) and torch.equal(g, g0), f"gradient repeat {r} differs"
-    # batch-composition invariance: a particle's loss does not depend on its row / pass
+    # batch-composition invariance: a particle's loss does not depend on its row / pass.  Bitwise, except for passes of 17 .. 20
+    # particles (r04): there rows 16 .. 19 share a workgroup with rows 0 .. 15 and run on v_mfma_f32_4x4x1 against the same weight
+    # registers — the same products, summed per k quarter first — so a particle that moves across row 16 changes in the last
+    # bits of every product (1e-7 relative, a few 1e-6 after 128 chaotic bridges); contamination from another row would be O(1)
     perm = torch.from_numpy(np.random.default_rng(1).permutation(n)).cuda()
     lp, _, _ = mcdbm.bound_forward(seeds[perm], *args)
-    assert torch.equal(lp, l0[perm])
+    if 16 < n % 32 <= 20:
+        torch.testing.assert_close(lp, l0[perm], rtol=5e-5, atol=1e-3)
+    else:
+        assert torch.equal(lp, l0[perm])
 
 
 @pytest.mark.parametrize("n,K", [(5, 3), (37, 2)])
