@@ -167,3 +167,58 @@ def test_second_order_kernels_do_not_spill(uha_asm, kern):
     _, meta = _kernel_whole(uha_asm, kern)
     scratch = next(l for l in meta if "ScratchSize" in l)
     assert re.search(r"ScratchSize:\s*0\b", scratch), scratch
+
+
+# ------------------------------------------------------------------------------------------ r04: the d = 1600 GEMM bodies
+@pytest.fixture(scope="module")
+def lgcp_asm(tmp_path_factory):
+    return _asm(tmp_path_factory, "cmcd_lgcp.hip")
+
+
+@pytest.fixture(scope="module")
+def wide_asm(tmp_path_factory):
+    return _asm(tmp_path_factory, "cmcd_lgcp_wide.hip")
+
+
+def _scratch(tail):
+    return int(next(l for l in tail if "ScratchSize" in l).split(":")[1].split()[0])
+
+
+def _vgprs(tail):
+    return int(next(l for l in tail if "NumVgprs:" in l or "; NumVgprs" in l).split(":")[1].split()[0])
+
+
+def test_wide_gemm_keeps_three_chunks_in_flight(wide_asm):
+    """cmcd_lgcp_wide.hip: the loop body is unconditional and fenced by sched_barriers — the machine scheduler had sunk every
+    load to its use, and a branch around an issue made the wait-count merge put `s_waitcnt vmcnt(0)` at the loop head."""
+    body, tail = _kernel(wide_asm, "_ZN4cmcd21lgcp_wide_gemm_kernelENS_8WideArgsE")
+    assert _scratch(tail) == 0
+    start = next(i for i, l in enumerate(body) if "Loop Header: Depth=1" in l)
+    end = next(i for i in range(start, len(body)) if "s_cbranch" in body[i])
+    loop = body[start:end]
+    mfma = [l for l in loop if "v_mfma_f32_32x32x2_f32" in l]
+    loads = [l for l in loop if "global_load_dwordx4" in l]
+    waits = [int(re.search(r"vmcnt\((\d+)\)", l).group(1)) for l in loop if "s_waitcnt vmcnt" in l]
+    assert len(mfma) == 48 and len(loads) == 15, (len(mfma), len(loads))     # 3 chunks x (16 matrix instructions, 5 loads)
+    assert waits and min(waits) >= 10, waits          # the oldest chunk only: two younger ones (10 loads) stay in flight
+
+
+def test_no_split_k_gemm_issues_all_its_loads_before_the_first_matrix_instruction(lgcp_asm):
+    """cmcd_lgcp.hip, lgcp_nsk_kernel: 26 sixteen-byte loads per lane in flight before the first wait (the scheduler left to
+    itself keeps 43 registers and pays 26 round trips); the activation instance fits two workgroups per CU without spilling."""
+    body, tail = _kernel(lgcp_asm, "_ZN4cmcd15lgcp_nsk_kernelILi0ELb0ELi1EEEvNS_7NskArgsE")
+    assert _scratch(tail) == 0
+    assert _vgprs(tail) <= 128
+    first = next(i for i, l in enumerate(body) if "v_mfma_f32_16x16x4_f32" in l)
+    assert sum("global_load_dwordx4" in l for l in body[:first]) >= 26
+    assert sum("v_mfma_f32_16x16x4_f32" in l for l in body) == 52
+    # the 17 .. 20-particle form runs its extra rows on 4x4x1 against the same weight registers
+    body_m, tail_m = _kernel(lgcp_asm, "_ZN4cmcd15lgcp_nsk_kernelILi0ELb1ELi1EEEvNS_7NskArgsE")
+    assert _scratch(tail_m) == 0
+    assert sum("v_mfma_f32_4x4x1_16b_f32" in l for l in body_m) == 52 and sum("v_mfma_f32_16x16x4_f32" in l for l in body_m) == 52
+    # the state-update instance waits for its OWN operands first: a vmcnt >= 26 in front of the first matrix instruction
+    body_s, tail_s = _kernel(lgcp_asm, "_ZN4cmcd15lgcp_nsk_kernelILi1ELb0ELi1EEEvNS_7NskArgsE")
+    assert _scratch(tail_s) == 0
+    first_s = next(i for i, l in enumerate(body_s) if "v_mfma_f32_16x16x4_f32" in l)
+    pre = [int(m.group(1)) for l in body_s[:first_s] for m in [re.search(r"vmcnt\((\d+)\)", l)] if m]
+    assert any(v >= 26 for v in pre), pre
