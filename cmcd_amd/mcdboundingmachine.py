@@ -298,7 +298,7 @@ def bound_forward(seeds, params_flat, unflatten, params_fixed, log_prob, eps_sch
         slot = key = None
         if PREP_CACHE and log_prob.target_id != _lib.TARGET["lgcp"] and not torch.cuda.is_current_stream_capturing():
             slot = (torch.cuda.current_device(), ws.data_ptr())
-            key = (params_flat.data_ptr(), params_flat._version, params_flat.numel(), n, bytes(desc), id(unflatten), spec,
+            key = (params_flat.data_ptr(), params_flat._version, params_flat.numel(), n, bytes(desc), bytes(lay), spec,
                    None if consts is None else (consts.data_ptr(), consts._version, consts.numel()))
         fn = L.cmcd_bound_forward_prepared if key is not None and _prepared.get(slot) == key else L.cmcd_bound_forward
         _prepared.pop(slot, None)            # an error below leaves no claim on the buffer
