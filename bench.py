@@ -419,7 +419,7 @@ def main():
     # /root/reference/src/opt.py:185-190), so all but the first skip the prep launch (cmcd_bound_forward_prepared; tables keyed
     # on params_flat's version counter).  The same loop with the prep launch in every call is timed beside it, not hidden.
     prep_note = None
-    if world == 1 and cfg["model"] != "lgcp":
+    if world == 1:
         was = mcdbm.PREP_CACHE
         mcdbm.PREP_CACHE = False
         try:

@@ -97,9 +97,11 @@ int launch_net_tails(const cmcd_desc& d, int din, int eps_schedule, const cmcd_l
 
 // cmcd_lgcp.hip: the d = 1600 path (per-bridge launch sequence)
 int64_t lgcp_workspace_floats(const cmcd_desc& d, int64_t n, int64_t base);
+// tables_ready (cmcd_bound_forward_prepared): the workspace still holds the first-layer bias table and the packed weight copies
+// of the same parameters — those launches are skipped (the per-call zeroing of the operands is not)
 int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, const int32_t* seeds, int64_t n,
                  const float* params, const float* tc, float* ws, float* out_loss, float* out_z,
-                 double** partials_out, float* traj, void* stream);
+                 double** partials_out, float* traj, void* stream, bool tables_ready = false);
 // cmcd_lgcp_wide.hip: forward-only calls on wide batches (>= kLgcpWideMin particles): whole-batch launches of a real fp32
 // GEMM body (32 x 128 tiles over the whole contraction, no split-K seam) instead of 32-row weight-streaming passes
 constexpr int64_t kLgcpWideMin = 224;   // measured crossover against the 32-row passes on four lanes (profiles/r04_e_lgcp_crossover.txt: 13.2 vs 13.4 ms at 224)
@@ -108,7 +110,7 @@ bool lgcp_use_wide(const cmcd_desc& d, int64_t n, bool keeps_trajectory);    // 
 int64_t lgcp_wide_workspace_floats(const cmcd_desc& d, int64_t n, int64_t base);
 int lgcp_wide_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, const int32_t* seeds, int64_t n,
                       const float* params, const float* tc, float* ws, float* out_loss, float* out_z,
-                      double** partials_out, void* stream);
+                      double** partials_out, void* stream, bool tables_ready = false);
 // per-bridge first-layer bias table b1 + emb[min(i, K-1)] W1[d:, :] -> bias1[K+1][IN] (cmcd_lgcp.hip's prep launch)
 int lgcp_launch_prep(const cmcd_desc& d, const cmcd_layout& lay, const float* params, float* bias1, void* stream);
 // reverse sweep of the reparameterised gradient on the d = 1600 path (cmcd_lgcp.hip); traj as left by lgcp_forward

@@ -1105,13 +1105,16 @@ static int forward_impl(const cmcd_desc* desc, const cmcd_layout* lay, const int
     cmcd_desc dl = d;
     if (d.mode == CMCD_MODE_ULA || d.mode == CMCD_MODE_ULA_SN) { dl.eps_schedule = CMCD_EPS_CONST; dl.grad_clipping = 0; }
     if (uha) { dl.eps_schedule = CMCD_EPS_COS_SQ; dl.grad_clipping = 1; }   // fixed by the function body (mcd_under_lp_a_cais.py:23-48)
+    // (cmcd_bound_forward_prepared: the schedule table, the first-layer bias table and the packed weights are still in the
+    // workspace; the 2nd-order sequence has no prepared form)
+    const bool lgcp_ready = tables_ready && !uha;
     SchedArgs sa{params, wsf, *lay, lw, (int32_t)K, d.ngrid, dl.eps_schedule, -1, -1};
-    hipLaunchKernelGGL(prep_sched_kernel, dim3(1), dim3(256), 0, st, sa);
+    if (!lgcp_ready) hipLaunchKernelGGL(prep_sched_kernel, dim3(1), dim3(256), 0, st, sa);
     double* partials = nullptr;
     snprintf(g_kernel_name, sizeof(g_kernel_name), "%s", lgcp_use_wide(dl, n, traj != nullptr)
                  ? "lgcp wide-batch sequence (32x128-tile fp32 GEMM launches)"
                  : "lgcp launch sequence (skinny GEMMs + state kernels)");
-    rc = lgcp_forward(dl, *lay, lw, seeds, n, params, target_consts, wsf, out_loss, out_z, &partials, traj, stream_);
+    rc = lgcp_forward(dl, *lay, lw, seeds, n, params, target_consts, wsf, out_loss, out_z, &partials, traj, stream_, lgcp_ready);
     if (rc != CMCD_OK) return fail(rc, "lgcp launch sequence failed%s");
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, partials, (int32_t)n, out_stats);
     CMCD_HIP_CHECK(hipGetLastError());
@@ -1249,8 +1252,7 @@ int cmcd_bound_forward_prepared(const cmcd_desc* desc, const cmcd_layout* lay, c
                                 const float* params, int64_t n_params, const float* target_consts, int64_t n_target,
                                 void* workspace, int64_t workspace_bytes, float* out_loss, float* out_z,
                                 double* out_stats, void* stream_) {
-  // the d = 1600 launch sequence re-packs its weights and zeroes its operands per call: it has no prepared form
-  const bool ready = desc && desc->target != CMCD_TARGET_LGCP;
+  const bool ready = desc != nullptr;
   return forward_impl(desc, lay, seeds, n, params, n_params, target_consts, n_target, workspace, workspace_bytes,
                       out_loss, out_z, out_stats, nullptr, stream_, ready);
 }

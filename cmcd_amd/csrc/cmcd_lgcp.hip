@@ -1321,15 +1321,15 @@ static int lgcp_gemm_attrs() {
 
 int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, const int32_t* seeds, int64_t n,
                  const float* params, const float* tc, float* ws, float* out_loss, float* out_z,
-                 double** partials_out, float* traj, void* stream_) {
+                 double** partials_out, float* traj, void* stream_, bool tables_ready) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (d.mode == CMCD_MODE_CAIS_UHA_SN)
     return lgcp_uha_forward(d, lay, sw, seeds, n, params, tc, ws, out_loss, out_z, partials_out, traj, stream);
   if (lgcp_use_wide(d, n, traj != nullptr))
-    return lgcp_wide_forward(d, lay, sw, seeds, n, params, tc, ws, out_loss, out_z, partials_out, stream_);
+    return lgcp_wide_forward(d, lay, sw, seeds, n, params, tc, ws, out_loss, out_z, partials_out, stream_, tables_ready);
   const int D = d.dim, E = d.emb_dim, IN = D + E, K = d.nbridges;
   const LgcpWs w = lgcp_ws(d, n, sw.total_floats);
-  if (d.mode != CMCD_MODE_ULA) {   // MCD_ULA has no network leaves at all
+  if (d.mode != CMCD_MODE_ULA && !tables_ready) {   // MCD_ULA has no network leaves at all
     LgcpPrepArgs pa{params, ws + w.bias1, lay, D, E, K, IN};
     hipLaunchKernelGGL(lgcp_prep_kernel, dim3((IN + 255) / 256, K + 1), dim3(256), 0, stream, pa);
   }
@@ -1338,7 +1338,7 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
   // r04: the forward runs on the no-split-K GEMM (header above lgcp_nsk_kernel); weights re-packed once per call
   const bool nsk = lgcp_nsk_ok(d);
   const int tIN = (IN + 15) / 16, tD = D / 16;
-  if (nsk) {
+  if (nsk && !tables_ready) {
     NskPackArgs pk{};
     int np = 0;
     auto pack = [&](const float* src, int Kr, int Nr, int64_t dst, int nt) {

@@ -467,7 +467,7 @@ int64_t lgcp_wide_workspace_floats(const cmcd_desc& d, int64_t n, int64_t base) 
 
 int lgcp_wide_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, const int32_t* seeds, int64_t n,
                       const float* params, const float* tc, float* ws, float* out_loss, float* out_z,
-                      double** partials_out, void* stream_) {
+                      double** partials_out, void* stream_, bool tables_ready) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const int D = d.dim, E = d.emb_dim, IN = D + E, K = d.nbridges;
   const WideWs w = wide_ws(d, n, sw.total_floats);
@@ -480,7 +480,7 @@ int lgcp_wide_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout
   *partials_out = partials;
 
   // once per call: first-layer bias table, zero-padded weight copies, padded vectors, zeroed activations / slots
-  if (has_net) {
+  if (has_net && !tables_ready) {
     int rc = lgcp_launch_prep(d, lay, params, ws + w.bias1, stream);
     if (rc != CMCD_OK) return rc;
     auto pack = [&](const float* src, int Kr, int Nr, int64_t dst, int Kp, int Np) {
@@ -490,10 +490,12 @@ int lgcp_wide_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout
     pack(params + lay.g_w2, IN, IN, w.w2p, w.KpIN, w.NpIN);
     pack(params + lay.g_w3, IN, D, w.w3p, w.KpIN, w.NpD);
   }
-  hipLaunchKernelGGL(lgcp_wide_pack_kernel, dim3((w.NpD + 255) / 256, w.KpD), dim3(256), 0, stream, tc, D, D, D, ws + w.kip,
-                     w.KpD, w.NpD);
-  WideVecArgs va{params, tc, ws + w.b2, ws + w.b3, ws + w.mean, ws + w.sd, ws + w.counts, lay, D, IN, w.NpD, w.NpIN, has_net ? 1 : 0};
-  hipLaunchKernelGGL(lgcp_wide_vec_kernel, dim3((w.NpIN + 255) / 256), dim3(256), 0, stream, va);
+  if (!tables_ready) {
+    hipLaunchKernelGGL(lgcp_wide_pack_kernel, dim3((w.NpD + 255) / 256, w.KpD), dim3(256), 0, stream, tc, D, D, D, ws + w.kip,
+                       w.KpD, w.NpD);
+    WideVecArgs va{params, tc, ws + w.b2, ws + w.b3, ws + w.mean, ws + w.sd, ws + w.counts, lay, D, IN, w.NpD, w.NpIN, has_net ? 1 : 0};
+    hipLaunchKernelGGL(lgcp_wide_vec_kernel, dim3((w.NpIN + 255) / 256), dim3(256), 0, stream, va);
+  }
   // x | xp | xn | kr | u1 | u2 | w0 are contiguous up to alignment: padding rows and columns must read as zeros
   if (hipMemsetAsync(ws + w.x, 0, sizeof(float) * (size_t)(w.w0 + w.Mp - w.x), stream) != hipSuccess) return CMCD_ERR_HIP;
   if (hipMemsetAsync(ws + w.slots, 0, sizeof(float) * (size_t)3 * w.ctD * w.Mp, stream) != hipSuccess) return CMCD_ERR_HIP;

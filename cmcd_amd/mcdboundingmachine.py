@@ -296,7 +296,7 @@ def bound_forward(seeds, params_flat, unflatten, params_fixed, log_prob, eps_sch
         stream = torch.cuda.current_stream().cuda_stream
         # the tables this workspace holds: formed by the previous call from exactly these inputs?  (see _prepared)
         slot = key = None
-        if PREP_CACHE and log_prob.target_id != _lib.TARGET["lgcp"] and not torch.cuda.is_current_stream_capturing():
+        if PREP_CACHE and not torch.cuda.is_current_stream_capturing():
             slot = (torch.cuda.current_device(), ws.data_ptr())
             key = (params_flat.data_ptr(), params_flat._version, params_flat.numel(), n, bytes(desc), bytes(lay), spec,
                    None if consts is None else (consts.data_ptr(), consts._version, consts.numel()))

@@ -149,8 +149,9 @@ int cmcd_bound_forward(const cmcd_desc* desc, const cmcd_layout* layout,
  * n, params CONTENTS and target constants, and nothing wrote into it since.  The library cannot check this (it keeps no
  * state and never reads params back to the host): the caller owns the invalidation — the Python mirror keys it on
  * (workspace, params_flat.data_ptr(), params_flat._version, target constants, desc, n) and bumps the version counter
- * wherever it updates parameters through a raw pointer (cmcd_adam_step).  The d = 1600 (lgcp) launch sequence has no prepared
- * form: there the call is cmcd_bound_forward. */
+ * wherever it updates parameters through a raw pointer (cmcd_adam_step).  On the d = 1600 (lgcp) launch sequences the prepared
+ * form skips the schedule / bias-table launches and the re-packing of the weights (the per-call zeroing of the operand
+ * buffers stays); the 2nd-order lgcp sequence ignores the hint and prepares every call. */
 int cmcd_bound_forward_prepared(const cmcd_desc* desc, const cmcd_layout* lay,
                                 const int32_t* seeds, int64_t n,
                                 const float* params, int64_t n_params,

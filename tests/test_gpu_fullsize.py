@@ -328,3 +328,36 @@ def test_a_captured_forward_keeps_its_prep_launch(hip_lib):
     torch.cuda.synchronize()
     l_new, _, _ = mcdbm.bound_forward(seeds, p, *args, **kw)
     assert torch.equal(l_g, l_new) and not torch.equal(l_g, l0)
+
+
+@pytest.mark.parametrize("n,k", [(20, 6), (40, 3), (230, 2)])
+def test_lgcp_prepared_tables(hip_lib, n, k):
+    """The d = 1600 sequences under cmcd_bound_forward_prepared (r04): the schedule / bias-table launches and the re-packing of
+    the weights are skipped on unchanged parameters, bit-identical results; a parameter update brings them back.  20 / 40
+    particles: the no-split-K passes (one, and two concurrent lanes); 230: the wide-batch form."""
+    from helpers import lgcp_counts_fixture
+    b = synthetic.build("lgcp_n20_k128", device="cuda", lgcp_counts=lgcp_counts_fixture(), nbridges=k, N=n, dense=True)
+    seeds = torch.from_numpy(synthetic.throughput_seeds(n, stream=6)).cuda()
+    args = (b["unflatten"], b["params_fixed"], b["target"])
+    p = b["params_flat"].clone()
+    was = mcdbm.PREP_CACHE
+    mcdbm.PREP_CACHE = False
+    try:
+        l0, z0, s0 = mcdbm.bound_forward(seeds, p, *args)
+    finally:
+        mcdbm.PREP_CACHE = was
+    c0 = dict(mcdbm.PREP_CALLS)
+    outs = [mcdbm.bound_forward(seeds, p, *args) for _ in range(4)]
+    assert mcdbm.PREP_CALLS["full"] - c0["full"] == 1 and mcdbm.PREP_CALLS["prepared"] - c0["prepared"] == 3
+    for l, z, st in outs:
+        assert torch.equal(l, l0) and torch.equal(z, z0) and torch.equal(st, s0)
+    p.mul_(1.0005)
+    c1 = dict(mcdbm.PREP_CALLS)
+    l1, _, s1 = mcdbm.bound_forward(seeds, p, *args)
+    assert mcdbm.PREP_CALLS["full"] - c1["full"] == 1
+    mcdbm.PREP_CACHE = False
+    try:
+        lf, _, sf = mcdbm.bound_forward(seeds, p, *args)
+    finally:
+        mcdbm.PREP_CACHE = was
+    assert torch.equal(l1, lf) and torch.equal(s1, sf) and not torch.equal(l1, l0)
