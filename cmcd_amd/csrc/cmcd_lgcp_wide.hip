@@ -206,7 +206,11 @@ __global__ __launch_bounds__(256, 2) void lgcp_wide_gemm_kernel(WideArgs a) {
   // chunk ch = 4 tt + wave (interleaved over the waves: the workgroup walks the contraction front to back together).
   // MFMA step s of a chunk contracts the k pair (k0 + s, k0 + 4 + s): lane half h supplies k0 + 4 h + s for both operands,
   // so its four A values are ONE 16-byte load and step s's four B values (the four column blocks) another.
-  f32x4 av[3], bv[3][4];
+#ifndef CMCD_WIDE_DEPTH
+#define CMCD_WIDE_DEPTH 3
+#endif
+  constexpr int P = CMCD_WIDE_DEPTH;     // chunks in flight per wave
+  f32x4 av[P], bv[P][4];
   auto issue = [&](f32x4& a_, f32x4 (&b_)[4], int tt) {
     const int ch = min(4 * tt + wv, nch - 1);                    // past the end: a valid, unused reload of the last chunk
     a_ = *reinterpret_cast<const f32x4*>(Ap + 8 * ch);
@@ -222,23 +226,24 @@ __global__ __launch_bounds__(256, 2) void lgcp_wide_gemm_kernel(WideArgs a) {
       for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(as, b_[s][j], acc[j], 0, 0, 0);
     }
   };
-  issue(av[0], bv[0], 0);
-  issue(av[1], bv[1], 1);
-  // Three chunks in flight; the body is UNCONDITIONAL (a branch around an issue makes the compiler's wait-count merge
-  // pessimistic: it put s_waitcnt vmcnt(0) at the loop head, draining the two younger chunks on every trip).  The last
-  // T mod 3 chunks are already in flight when the loop ends.
-  int tt = 0;
-  for (; tt + 3 <= T; tt += 3) {
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      issue(av[(u + 2) % 3], bv[(u + 2) % 3], tt + u + 2);
+  for (int u = 0; u < P - 1; ++u) issue(av[u], bv[u], u);
+  // P chunks in flight; the body is UNCONDITIONAL (a branch around an issue makes the compiler's wait-count merge
+  // pessimistic: it put s_waitcnt vmcnt(0) at the loop head, draining the younger chunks on every trip).  The last
+  // T mod P chunks are already in flight when the loop ends.
+  int tt = 0;
+  for (; tt + P <= T; tt += P) {
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+      issue(av[(u + P - 1) % P], bv[(u + P - 1) % P], tt + u + P - 1);
       __builtin_amdgcn_sched_barrier(0);     // the machine scheduler otherwise sinks these loads to just before their use
       contract(av[u], bv[u]);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  if (tt < T) contract(av[0], bv[0]);                             // wave-uniform
-  if (tt + 1 < T) contract(av[1], bv[1]);
+#pragma unroll
+  for (int u = 0; u < P - 1; ++u)
+    if (tt + u < T) contract(av[u], bv[u]);                       // wave-uniform
 
   // ---- sum of the four waves' partial tiles, fixed order.  D layout of the MFMA: column = lane & 31 (= c, i.e. tile
   // column 4 c + block), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
