@@ -8,6 +8,8 @@ there is no CPU fallback.
 """
 import ctypes as C
 
+import weakref
+
 import torch
 
 from . import _lib
@@ -300,7 +302,14 @@ def bound_forward(seeds, params_flat, unflatten, params_fixed, log_prob, eps_sch
             slot = (torch.cuda.current_device(), ws.data_ptr())
             key = (params_flat.data_ptr(), params_flat._version, params_flat.numel(), n, bytes(desc), bytes(lay), spec,
                    None if consts is None else (consts.data_ptr(), consts._version, consts.numel()))
-        fn = L.cmcd_bound_forward_prepared if key is not None and _prepared.get(slot) == key else L.cmcd_bound_forward
+        # (key, weak references to the very tensor OBJECTS the tables were formed from): an address and a version counter alone
+        # do not identify a tensor — the caching allocator hands a freed tensor's address to the next one of the same size, whose
+        # counter starts at the same value (r04: two parameter sets of one test module collided exactly so)
+        hit = False
+        ent = _prepared.get(slot) if key is not None else None
+        if ent is not None and ent[0] == key and ent[1]() is params_flat and (consts is None or ent[2]() is consts):
+            hit = True
+        fn = L.cmcd_bound_forward_prepared if hit else L.cmcd_bound_forward
         _prepared.pop(slot, None)            # an error below leaves no claim on the buffer
         PREP_CALLS["prepared" if fn is L.cmcd_bound_forward_prepared else "full"] += 1
         rc = fn(
@@ -309,7 +318,7 @@ def bound_forward(seeds, params_flat, unflatten, params_fixed, log_prob, eps_sch
             ws.data_ptr(), ws.numel(), losses.data_ptr(), z.data_ptr(), stats.data_ptr(), stream)
     _lib.check(rc)
     if key is not None:
-        _prepared[slot] = key
+        _prepared[slot] = (key, weakref.ref(params_flat), weakref.ref(consts) if consts is not None else None)
         while len(_prepared) > 64:
             _prepared.pop(next(iter(_prepared)))
     return losses, z, stats

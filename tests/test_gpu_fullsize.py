@@ -361,3 +361,33 @@ def test_lgcp_prepared_tables(hip_lib, n, k):
     finally:
         mcdbm.PREP_CACHE = was
     assert torch.equal(l1, lf) and torch.equal(s1, sf) and not torch.equal(l1, l0)
+
+
+def test_prepared_tables_survive_address_reuse(hip_lib):
+    """The caching allocator hands a freed tensor's address to the next tensor of the same size, and a fresh tensor's version
+    counter starts where the old one's did: (address, version) does not identify a parameter tensor.  The prepared-table cache
+    holds a weak reference to the tensor OBJECT; a new tensor at the old address must get a full call (r04: the sparse and the
+    dense parameter set of this module collided exactly so and the second ran on the first one's tables)."""
+    ba = synthetic.build("many_gmm_n2000_k256_dds", device="cuda", nbridges=8)
+    bb = synthetic.build("many_gmm_n2000_k256_dds", device="cuda", nbridges=8, dense=True)
+    seeds = torch.from_numpy(synthetic.throughput_seeds(512, stream=8)).cuda()
+    args = (ba["unflatten"], ba["params_fixed"], ba["target"])
+    kw = dict(eps_schedule=ba["eps_schedule"], grad_clipping=ba["grad_clipping"])
+    host_b = bb["params_flat"].cpu()
+    ref_b = mcdbm.bound_forward(seeds, bb["params_flat"], *args, **kw)[0].clone()
+    pa = ba["params_flat"].clone()
+    for _ in range(3):
+        mcdbm.bound_forward(seeds, pa, *args, **kw)          # the workspace now holds pa's tables
+    addr = pa.data_ptr()
+    del pa
+    reused = 0
+    for _ in range(8):                                       # the allocator usually returns the block just freed
+        pb = host_b.cuda()
+        reused += int(pb.data_ptr() == addr)
+        c0 = dict(mcdbm.PREP_CALLS)
+        l = mcdbm.bound_forward(seeds, pb, *args, **kw)[0]
+        assert mcdbm.PREP_CALLS["full"] - c0["full"] == 1, "a new tensor object was served another tensor's tables"
+        assert torch.equal(l, ref_b)
+        addr = pb.data_ptr()
+        del pb
+    print("address reused in", reused, "of 8 allocations")
