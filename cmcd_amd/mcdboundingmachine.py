@@ -173,13 +173,32 @@ KERNEL_VARIANT = int(__import__("os").environ.get("CMCD_KERNEL_VARIANT", "0"))
 
 # Prepared tables (include/cmcd_hip.h: cmcd_bound_forward_prepared): what the forward workspace of (device, buffer address)
 # holds, as the key of the call that formed it.  A forward call whose key matches skips the prep launch — evaluation loops on
-# fixed parameters (the reference's opt.sample: 30 calls of loss_fn on one params_flat).  The key carries the parameter
-# tensor's address AND its version counter: every in-place update through torch bumps it, and the two places of this package
-# that write parameters through a raw pointer (the fused optimiser step, eager and graph-replayed) bump it by hand
-# (torch.autograd.graph.increment_version).  Code that writes into params_flat through data_ptr() on its own must do the same,
-# or set CMCD_PREP_CACHE=0.  Never used while a graph is being captured (a captured "no prep" would outlive the parameters).
+# fixed parameters (the reference's opt.sample: 30 calls of loss_fn on one params_flat).
+# OPT-IN: `with fixed_parameters():` around the loop (or CMCD_PREP_CACHE=1 for the process).  Inside, the key carries the
+# parameter tensor's address AND its version counter, and the entry a weak reference to the tensor object: every in-place
+# update through torch bumps the counter, and the two places of this package that write parameters through a raw pointer (the
+# fused optimiser step, eager and graph-replayed) bump it by hand (torch.autograd.graph.increment_version).  What NO key can
+# see is a write that bypasses the counter — `params_flat.data.mul_(...)` (`.data` has a counter of its own), a raw-pointer
+# write from other code — which is why the shortcut is not the default: the caller states that the parameters are fixed.
+# Never used while a graph is being captured (a captured "no prep" would outlive the parameters).
 _prepared = {}
-PREP_CACHE = __import__("os").environ.get("CMCD_PREP_CACHE", "1") != "0"
+PREP_CACHE = __import__("os").environ.get("CMCD_PREP_CACHE", "0") == "1"
+_fixed = __import__("threading").local()
+
+
+class fixed_parameters:
+    """Context of an evaluation loop on unchanged parameters: forward calls inside may reuse the per-parameter tables the
+    previous call left in the workspace (cmcd_bound_forward_prepared).  Re-entrant, per host thread."""
+
+    def __enter__(self):
+        _fixed.depth = getattr(_fixed, "depth", 0) + 1
+        return self
+
+    def __exit__(self, *exc):
+        _fixed.depth -= 1
+        return False
+
+
 PREP_CALLS = {"prepared": 0, "full": 0}      # forward calls that skipped / ran the prep launch (tests, bench)
 
 
@@ -298,7 +317,7 @@ def bound_forward(seeds, params_flat, unflatten, params_fixed, log_prob, eps_sch
         stream = torch.cuda.current_stream().cuda_stream
         # the tables this workspace holds: formed by the previous call from exactly these inputs?  (see _prepared)
         slot = key = None
-        if PREP_CACHE and not torch.cuda.is_current_stream_capturing():
+        if (PREP_CACHE or getattr(_fixed, "depth", 0) > 0) and not torch.cuda.is_current_stream_capturing():
             slot = (torch.cuda.current_device(), ws.data_ptr())
             key = (params_flat.data_ptr(), params_flat._version, params_flat.numel(), n, bytes(desc), bytes(lay), spec,
                    None if consts is None else (consts.data_ptr(), consts._version, consts.numel()))

@@ -147,9 +147,10 @@ int cmcd_bound_forward(const cmcd_desc* desc, const cmcd_layout* layout,
  * operand packing of the weights: everything that depends on params_flat and not on the particles) is skipped.
  * CONTRACT: `workspace` was last used by a cmcd_bound_forward / cmcd_bound_forward_prepared call with the SAME desc, layout,
  * n, params CONTENTS and target constants, and nothing wrote into it since.  The library cannot check this (it keeps no
- * state and never reads params back to the host): the caller owns the invalidation — the Python mirror keys it on
- * (workspace, params_flat.data_ptr(), params_flat._version, target constants, desc, n) and bumps the version counter
- * wherever it updates parameters through a raw pointer (cmcd_adam_step).  On the d = 1600 (lgcp) launch sequences the prepared
+ * state and never reads params back to the host): the caller owns the invalidation — the Python mirror takes this entry point
+ * only inside an explicit `fixed_parameters()` context, where it keys the tables on (workspace, the parameter tensor OBJECT,
+ * its data_ptr() and version counter, target constants, desc, layout, n) and bumps the version counter wherever it updates
+ * parameters through a raw pointer (cmcd_adam_step).  On the d = 1600 (lgcp) launch sequences the prepared
  * form skips the schedule / bias-table launches and the re-packing of the weights (the per-call zeroing of the operand
  * buffers stays); the 2nd-order lgcp sequence ignores the hint and prepares every call. */
 int cmcd_bound_forward_prepared(const cmcd_desc* desc, const cmcd_layout* lay,

@@ -242,7 +242,7 @@ def test_lgcp_repeat_calls_are_bitwise_identical(hip_lib, n, k, reps):
 
 @pytest.mark.parametrize("name,n", [("many_gmm_n2000_k256_dds", 2000), ("gmm_n300_k8", 300), ("funnel_n300_k64", 300),
                                     ("many_gmm_var_n16000_k256", 600)])
-def test_prepared_tables_are_reused_only_while_the_parameters_are_unchanged(hip_lib, name, n):
+def test_prepared_tables_are_reused_only_while_the_parameters_are_unchanged(hip_lib, monkeypatch, name, n):
     """Evaluation loops on fixed parameters (the reference's opt.sample: 30 loss_fn calls on one params_flat,
     /root/reference/src/opt.py:185-190) skip the per-call prep launch (cmcd_bound_forward_prepared): the results must be
     bit-identical to a full call, and ANY change of the inputs the tables are made of must bring the prep launch back —
@@ -255,14 +255,14 @@ def test_prepared_tables_are_reused_only_while_the_parameters_are_unchanged(hip_
     args = (b["unflatten"], b["params_fixed"], b["target"])
     kw = dict(eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
     p = b["params_flat"].clone()
+    monkeypatch.setattr(mcdbm, "PREP_CACHE", True)         # what `with mcdbm.fixed_parameters():` does for a loop
 
     def fresh(params):      # the same call with the cache off
-        was = mcdbm.PREP_CACHE
         mcdbm.PREP_CACHE = False
         try:
             return mcdbm.bound_forward(seeds, params, *args, **kw)
         finally:
-            mcdbm.PREP_CACHE = was
+            mcdbm.PREP_CACHE = True
 
     def calls():
         return dict(mcdbm.PREP_CALLS)
@@ -298,9 +298,10 @@ def test_prepared_tables_are_reused_only_while_the_parameters_are_unchanged(hip_
     assert calls()["full"] - c1["full"] == 2
 
 
-def test_a_captured_forward_keeps_its_prep_launch(hip_lib):
+def test_a_captured_forward_keeps_its_prep_launch(hip_lib, monkeypatch):
     """A forward call captured into a HIP graph must carry its prep launch (the prepared-table shortcut is refused while a
     stream is capturing): replays after an in-place parameter update have to see the new parameters."""
+    monkeypatch.setattr(mcdbm, "PREP_CACHE", True)
     b = synthetic.build("gmm_n300_k8", device="cuda")
     seeds = torch.from_numpy(synthetic.throughput_seeds(300, stream=5)).cuda()
     args = (b["unflatten"], b["params_fixed"], b["target"])
@@ -331,7 +332,7 @@ def test_a_captured_forward_keeps_its_prep_launch(hip_lib):
 
 
 @pytest.mark.parametrize("n,k", [(20, 6), (40, 3), (230, 2)])
-def test_lgcp_prepared_tables(hip_lib, n, k):
+def test_lgcp_prepared_tables(hip_lib, monkeypatch, n, k):
     """The d = 1600 sequences under cmcd_bound_forward_prepared (r04): the schedule / bias-table launches and the re-packing of
     the weights are skipped on unchanged parameters, bit-identical results; a parameter update brings them back.  20 / 40
     particles: the no-split-K passes (one, and two concurrent lanes); 230: the wide-batch form."""
@@ -340,12 +341,9 @@ def test_lgcp_prepared_tables(hip_lib, n, k):
     seeds = torch.from_numpy(synthetic.throughput_seeds(n, stream=6)).cuda()
     args = (b["unflatten"], b["params_fixed"], b["target"])
     p = b["params_flat"].clone()
-    was = mcdbm.PREP_CACHE
-    mcdbm.PREP_CACHE = False
-    try:
-        l0, z0, s0 = mcdbm.bound_forward(seeds, p, *args)
-    finally:
-        mcdbm.PREP_CACHE = was
+    l0, z0, s0 = mcdbm.bound_forward(seeds, p, *args)       # outside any fixed_parameters() context: a full call
+    monkeypatch.setattr(mcdbm, "PREP_CACHE", True)
+    was = True
     c0 = dict(mcdbm.PREP_CALLS)
     outs = [mcdbm.bound_forward(seeds, p, *args) for _ in range(4)]
     assert mcdbm.PREP_CALLS["full"] - c0["full"] == 1 and mcdbm.PREP_CALLS["prepared"] - c0["prepared"] == 3
@@ -364,6 +362,29 @@ def test_lgcp_prepared_tables(hip_lib, n, k):
 
 
 def test_prepared_tables_survive_address_reuse(hip_lib):
+    with mcdbm.fixed_parameters():
+        _address_reuse_body()
+
+
+def test_the_shortcut_is_opt_in(hip_lib):
+    """Outside `fixed_parameters()` every forward call runs its prep launch: a write that bypasses the version counter
+    (`params_flat.data.mul_`) must be seen by the next call."""
+    b = synthetic.build("gmm_n300_k8", device="cuda")
+    seeds = torch.from_numpy(synthetic.throughput_seeds(300, stream=5)).cuda()
+    args = (b["unflatten"], b["params_fixed"], b["target"])
+    p = b["params_flat"].clone()
+    c0 = dict(mcdbm.PREP_CALLS)
+    l0 = mcdbm.bound_forward(seeds, p, *args)[0].clone()
+    mcdbm.bound_forward(seeds, p, *args)
+    assert mcdbm.PREP_CALLS["prepared"] == c0["prepared"] and mcdbm.PREP_CALLS["full"] - c0["full"] == 2
+    v = p._version
+    p.data.mul_(1.01)                                   # `.data` has its own counter: invisible to any key
+    assert p._version == v
+    l1 = mcdbm.bound_forward(seeds, p, *args)[0]
+    assert not torch.equal(l1, l0)
+
+
+def _address_reuse_body():
     """The caching allocator hands a freed tensor's address to the next tensor of the same size, and a fresh tensor's version
     counter starts where the old one's did: (address, version) does not identify a parameter tensor.  The prepared-table cache
     holds a weak reference to the tensor OBJECT; a new tensor at the old address must get a full call (r04: the sparse and the
