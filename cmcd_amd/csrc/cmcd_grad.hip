@@ -71,6 +71,13 @@ struct GradArgs {
   int32_t ula;               // 0: CAIS; 2: MCD_ULA_sn — no network in the forward kernel, s(z_{i+1}, i) in the backward one
   int64_t o_S, o_S2, o_gbeta, o_geps, o_gvd, o_gfac;   // offsets inside gtab
   int64_t slab_stride;                                   // floats per workgroup slab
+  // fixed-order accumulation (r04): when `det` is set, every (tile, evaluation) work unit STORES its contribution to
+  // the bias-table rows and to the schedule gradients in a slot of its own — each unit is visited by exactly one wave
+  // in every mode — and grad_det_reduce_kernel sums the slots over tiles in a fixed order.  With float atomics on the
+  // shared tables the order of the adds changed from run to run and a training seed did not reproduce.
+  // per tile: S [(K+1)][HP] | S2 [(K+1)][HP] (geffner) | [(K+1)][4] = {d beta_e, d eps_e, d beta_{e-1}, d eps_{e-1}}
+  float* det;                // nullptr: the atomics (batches whose slot table would pass kDetCapFloats)
+  int64_t det_tile_stride, det_tiles, det_obe;
 };
 
 // element (feature f, particle p) of a staged [features][16] array
@@ -202,6 +209,8 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
     }
     const int64_t p = tile * 16 + c;
     const bool valid = live && p < a.n;
+    // padding waves (a clamped work item, a tile past the batch) carry zeros: they must not overwrite a real slot
+    float* dslot = (a.det && live && tile < a.det_tiles) ? a.det + tile * a.det_tile_stride : nullptr;
     const int32_t seed = a.seeds[valid ? p : a.n - 1];
     const float om = valid ? (a.omega ? a.omega[p] : a.omega_scalar) : 0.f;
     const int64_t pc = valid ? p : a.n - 1;
@@ -489,16 +498,24 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
           }
           const float tb = row_sum16(pend_beta + ee * sb), te = row_sum16(pend_eps + se);
           if (lane == 0) {
-            atomicAdd(a.gtab + a.o_gbeta + e, tb);
-            atomicAdd(a.gtab + a.o_geps + e, te);
+            if (a.det) {
+              if (dslot) { dslot[a.det_obe + 4 * e + 0] = tb; dslot[a.det_obe + 4 * e + 1] = te; }
+            } else {
+              atomicAdd(a.gtab + a.o_gbeta + e, tb);
+              atomicAdd(a.gtab + a.o_geps + e, te);
+            }
           }
         }
         pend_beta = npb; pend_eps = npe;
         if (ITEM && e > 0) {  // no carry between work items: the backward-kernel part of step e-1 goes out now
           const float tb = row_sum16(npb), te = row_sum16(npe);
           if (lane == 0) {
-            atomicAdd(a.gtab + a.o_gbeta + (e - 1), tb);
-            atomicAdd(a.gtab + a.o_geps + (e - 1), te);
+            if (a.det) {
+              if (dslot) { dslot[a.det_obe + 4 * e + 2] = tb; dslot[a.det_obe + 4 * e + 3] = te; }
+            } else {
+              atomicAdd(a.gtab + a.o_gbeta + (e - 1), tb);
+              atomicAdd(a.gtab + a.o_geps + (e - 1), te);
+            }
           }
         }
         float v[D], hv[D];
@@ -537,8 +554,12 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
         // one value per particle; lanes g = 0 hold it: sum over the tile, one atomic per tile and step
         const float tb = row_sum16(gbe), te = row_sum16(gep);
         if (lane == 0) {
-          atomicAdd(a.gtab + a.o_gbeta + (e - 1), tb);
-          atomicAdd(a.gtab + a.o_geps + (e - 1), te);
+          if (a.det) {
+            if (dslot) { dslot[a.det_obe + 4 * e + 2] = tb; dslot[a.det_obe + 4 * e + 3] = te; }
+          } else {
+            atomicAdd(a.gtab + a.o_gbeta + (e - 1), tb);
+            atomicAdd(a.gtab + a.o_geps + (e - 1), te);
+          }
         }
       }
       float beta = 0.f, eps = 0.f, sig = 0.f;
@@ -597,8 +618,12 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
         if (ITEM) {  // no carry between work items: the forward-kernel part of step e goes out now
           const float tb = row_sum16(pend_beta), te = row_sum16(pend_eps);
           if (lane == 0) {
-            atomicAdd(a.gtab + a.o_gbeta + e, tb);
-            atomicAdd(a.gtab + a.o_geps + e, te);
+            if (a.det) {
+              if (dslot) { dslot[a.det_obe + 4 * e + 0] = tb; dslot[a.det_obe + 4 * e + 1] = te; }
+            } else {
+              atomicAdd(a.gtab + a.o_gbeta + e, tb);
+              atomicAdd(a.gtab + a.o_geps + e, te);
+            }
           }
         }
       }
@@ -764,8 +789,15 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
             const int row = 4 * g + r;
             if (row < D) atomicAdd(accZ1 + row * HP + 16 * t + c, sacc[r]);
             if (row == D) {
-              atomicAdd(gS + erow * HP + 16 * t + c, sacc[r]);
-              if (GEF) atomicAdd(gS2 + erow * HP + 16 * t + c, s2acc[r]);
+              if (a.det) {
+                if (dslot) {
+                  dslot[(int64_t)e * HP + 16 * t + c] = sacc[r];
+                  if (GEF) dslot[(int64_t)(K + 1 + e) * HP + 16 * t + c] = s2acc[r];
+                }
+              } else {
+                atomicAdd(gS + erow * HP + 16 * t + c, sacc[r]);
+                if (GEF) atomicAdd(gS2 + erow * HP + 16 * t + c, s2acc[r]);
+              }
             }
           }
         }
@@ -829,9 +861,16 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
             if (!TILE_LOCAL && row < D) atomicAdd(accZ1 + row * HP + 16 * t + c, sacc[r]);   // dW1[row][n] += z_row . d a1[n]
             if (row == D) {
               atomicAdd(accB2 + 16 * t + c, bacc[r]);                                  // db2[n] += sum_p d a2
-              if (!TILE_LOCAL) {
-                atomicAdd(gS + erow * HP + 16 * t + c, sacc[r]);                      // d / d bias-table row used
-                if (GEF) atomicAdd(gS2 + erow * HP + 16 * t + c, s2acc[r]);
+              if (!TILE_LOCAL) {                                                       // d / d bias-table row used
+                if (a.det) {
+                  if (dslot) {
+                    dslot[(int64_t)e * HP + 16 * t + c] = sacc[r];
+                    if (GEF) dslot[(int64_t)(K + 1 + e) * HP + 16 * t + c] = s2acc[r];
+                  }
+                } else {
+                  atomicAdd(gS + erow * HP + 16 * t + c, sacc[r]);
+                  if (GEF) atomicAdd(gS2 + erow * HP + 16 * t + c, s2acc[r]);
+                }
               }
             }
           }
@@ -908,6 +947,30 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
 
 // (the Jacobian and scan kernels of the work-item reparameterised gradient live in cmcd_bptt.hip)
 
+// fixed-order sum over tiles of per-tile rows of `len` floats: 16 lanes per output, lane l the tiles l, l + 16, ...
+// (entries with o % period >= used are padding nobody writes or reads)
+__global__ __launch_bounds__(256) void tile_rows_reduce_kernel(const float* rows, int64_t ntiles, int64_t len, int64_t period,
+                                                               int64_t used, float* out) {
+  const int sub = threadIdx.x & 15;
+  const int64_t o = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const bool on = o < len && o % period < used;
+  float v = 0.f;
+  if (on) {
+    int64_t t = sub;
+    for (; t + 16 * 7 < ntiles; t += 16 * 8) {
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = rows[(t + 16 * u) * len + o];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += x[u];
+    }
+    for (; t < ntiles; t += 16) v += rows[t * len + o];
+  }
+#pragma unroll
+  for (int sh = 8; sh > 0; sh >>= 1) v += __shfl_xor(v, sh);
+  if (on && sub == 0) out[o] = v;
+}
+
 // ------------------------------------------------------------------------------------------
 // MCD_ULA (no network; /root/reference/src/mcd_over_orig.py with use_sn = False): the reverse recursion
 // without the MLP — target Hessian product, q, schedules.  One wave per 16-particle tile, whole chain.
@@ -918,6 +981,7 @@ struct UlaGradArgs {
   const float* traj;     // [K+1][n][D]
   float* gtab;           // gbeta at o_gbeta, geps at o_geps
   float* gvd;            // [ntiles][2 D] per-tile q-gradient rows
+  float* det;            // [ntiles][2][K4] per-tile schedule-gradient rows (nullptr: float atomics on gtab)
   cmcd_layout lay;
   WsLayout w;
   int64_t n, o_gbeta, o_geps;
@@ -999,8 +1063,13 @@ __global__ __launch_bounds__(256) void ula_grad_kernel(UlaGradArgs a) {
       }
       const float tb = row_sum16(pend_beta + ee * sb), te = row_sum16(pend_eps + se);
       if (lane == 0) {
-        atomicAdd(a.gtab + a.o_gbeta + e, tb);
-        atomicAdd(a.gtab + a.o_geps + e, te);
+        if (a.det) {   // a.o_geps = K4 = the padded row length
+          a.det[tile * 2 * a.o_geps + e] = tb;
+          a.det[tile * 2 * a.o_geps + a.o_geps + e] = te;
+        } else {
+          atomicAdd(a.gtab + a.o_gbeta + e, tb);
+          atomicAdd(a.gtab + a.o_geps + e, te);
+        }
       }
     }
     pend_beta = npb; pend_eps = npe;
@@ -1122,33 +1191,49 @@ __device__ __forceinline__ void grad_reduce_body(const TailArgs& a, const unsign
 // d / d eps0 and d / d mgridref_y from the per-step tables (one 256-thread block, thread per bridge)
 __device__ __forceinline__ void grad_sched_tail_body(const TailArgs& a, const unsigned bidx, const unsigned gdim) {
   __shared__ float gyg[40], gyv[40], red[256], ms[40];
+  __shared__ float c_lo[1024], c_hi[1024];
+  __shared__ int c_j[1024];
   const int K = a.K, G = a.ngrid;
   const float* gbeta = a.gtab + a.o_gbeta;
   const float* geps = a.gtab + a.o_geps;
-  if (threadIdx.x < 40) gyg[threadIdx.x] = 0.f;
   // mgridref_y once, in parallel: thread 0's three serial passes below read it from LDS instead of issuing ~3 (G + 1)
   // dependent global loads (no measurable change of the tails launch: 0.1 us level)
   if ((int)threadIdx.x <= G) ms[threadIdx.x] = a.params[a.lay.mgridref_y + threadIdx.x];
-  __syncthreads();
-  float ge = 0.f;
-  for (int i = threadIdx.x; i < K; i += blockDim.x) {
-    float dedeps0 = 1.0f;                                                         // constant schedule
-    if (a.eps_schedule == CMCD_EPS_COS_SQ) {
-      const float cs = cosf(((float)i / (float)K + 0.008f) / 1.008f * 0.5f * 3.14159265358979323846f);
-      dedeps0 = cs * cs;
-    } else if (a.eps_schedule == CMCD_EPS_LINEAR) {
-      dedeps0 = 1.0f - (float)i / (float)(K - 1);
+  float ge = 0.f, gq = 0.f;   // gq: this thread's grid node q = threadIdx.x (q <= G + 1)
+  for (int base = 0; base < K; base += 1024) {
+    __syncthreads();
+    for (int i = base + threadIdx.x; i < K && i < base + 1024; i += blockDim.x) {
+      float dedeps0 = 1.0f;                                                         // constant schedule
+      if (a.eps_schedule == CMCD_EPS_COS_SQ) {
+        const float cs = cosf(((float)i / (float)K + 0.008f) / 1.008f * 0.5f * 3.14159265358979323846f);
+        dedeps0 = cs * cs;
+      } else if (a.eps_schedule == CMCD_EPS_LINEAR) {
+        dedeps0 = 1.0f - (float)i / (float)(K - 1);
+      }
+      ge += geps[i] * dedeps0;
+      // beta_i = gy[j-1] + frac_i (gy[j] - gy[j-1]),  gy = [0, cumsum(m)/sum(m)]
+      const float x = (float)(i + 1) / (float)(K + 1);
+      int j = 1;
+      while (j < G + 1 && (float)j / (float)(G + 1) <= x) ++j;
+      const float x0 = (float)(j - 1) / (float)(G + 1), x1 = (float)j / (float)(G + 1);
+      const float fr = (x - x0) / (x1 - x0);
+      c_j[i - base] = j;
+      c_lo[i - base] = gbeta[i] * (1.0f - fr);
+      c_hi[i - base] = gbeta[i] * fr;
     }
-    ge += geps[i] * dedeps0;
-    // beta_i = gy[j-1] + frac_i (gy[j] - gy[j-1]),  gy = [0, cumsum(m)/sum(m)]
-    const float x = (float)(i + 1) / (float)(K + 1);
-    int j = 1;
-    while (j < G + 1 && (float)j / (float)(G + 1) <= x) ++j;
-    const float x0 = (float)(j - 1) / (float)(G + 1), x1 = (float)j / (float)(G + 1);
-    const float fr = (x - x0) / (x1 - x0);
-    atomicAdd(&gyg[j - 1], gbeta[i] * (1.0f - fr));
-    atomicAdd(&gyg[j], gbeta[i] * fr);
+    __syncthreads();
+    // node q collects the steps of its two neighbouring cells in step order (LDS float atomics from 256 threads summed
+    // them in whatever order the waves arrived: the last source of run-to-run differences in a training step, r04)
+    if ((int)threadIdx.x <= G + 1) {
+      const int q = threadIdx.x, lim = K - base < 1024 ? K - base : 1024;
+      for (int i = 0; i < lim; ++i) {
+        const int j = c_j[i];
+        if (j - 1 == q) gq += c_lo[i];
+        if (j == q) gq += c_hi[i];
+      }
+    }
   }
+  if ((int)threadIdx.x <= G + 1) gyg[threadIdx.x] = gq;
   red[threadIdx.x] = ge;
   __syncthreads();
   for (int s2 = 128; s2 > 0; s2 >>= 1) {
@@ -1451,6 +1536,77 @@ static void grad_offsets(const cmcd_desc& d, int HP, int64_t& o_S, int64_t& o_S2
 // the dds tail's per-evaluation table sits after the zero-initialised tables
 static int64_t grad_tail_floats(const cmcd_desc& d) { return d.arch == CMCD_ARCH_DDS ? (int64_t)(d.nbridges + 1) * 448 : 0; }
 
+// ---- fixed-order sums of the per-(tile, evaluation) slots (GradArgs::det) into the shared tables the tails read
+struct DetArgs {
+  const float* det;
+  float* gtab;
+  int64_t o_S, o_S2, o_gbeta, o_geps, tile_stride, obe, ntiles;
+  int32_t K, HP, gef, ula, has_fwd, has_bwd;
+};
+// A block = 64 consecutive outputs x 4 tile classes: thread (q, l) sums the tiles q, q + 4, ... of output l in that order
+// (eight loads in flight), the four partial sums are added in the order q = 0..3.  Outputs: S[row][col] (and S2) for the
+// K + 1 bias-table rows, then d beta_i / d eps_i.  Consecutive outputs are consecutive floats of a slot: 256 B per wave load.
+__global__ __launch_bounds__(256) void grad_det_reduce_kernel(DetArgs a) {
+  __shared__ float part[4][64];
+  const int l = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int64_t nS = (int64_t)(a.K + 1) * a.HP, nSS = a.gef ? 2 * nS : nS;
+  const int64_t o = (int64_t)blockIdx.x * 64 + l;
+  // up to two source evaluations per output row: MCD_ULA_sn reads bias-table row e - 1 at evaluation e (and row 0 at e = 0)
+  int64_t src[2] = {-1, -1};
+  float* dst = nullptr;
+  if (o < nSS) {
+    const int64_t oo = o < nS ? o : o - nS, half = o < nS ? 0 : nS;
+    const int row = (int)(oo / a.HP), col = (int)(oo % a.HP);
+    if (!a.ula) {
+      src[0] = half + (int64_t)row * a.HP + col;
+    } else {
+      if (row == 0) src[0] = half + col;
+      if (row + 1 <= a.K) src[1] = half + (int64_t)(row + 1) * a.HP + col;
+    }
+    dst = a.gtab + (o < nS ? a.o_S : a.o_S2) + oo;
+  } else if (o < nSS + 2 * (int64_t)a.K) {
+    const int64_t oo = o - nSS;
+    const int i = (int)(oo >> 1), w = (int)(oo & 1);            // w = 0: d beta_i, 1: d eps_i
+    if (a.has_fwd) src[0] = a.obe + 4 * (int64_t)i + w;          // forward-kernel part, written at evaluation i
+    if (a.has_bwd) src[1] = a.obe + 4 * (int64_t)(i + 1) + 2 + w; // backward-kernel part, written at evaluation i + 1
+    dst = a.gtab + (w ? a.o_geps : a.o_gbeta) + i;
+  }
+  float v = 0.f;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if (src[k] < 0) continue;
+    const float* base = a.det + src[k];
+    int64_t t = q;
+    for (; t + 4 * 7 < a.ntiles; t += 4 * 8) {
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = base[(t + 4 * u) * a.tile_stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += x[u];
+    }
+    for (; t < a.ntiles; t += 4) v += base[t * a.tile_stride];
+  }
+  part[q][l] = v;
+  __syncthreads();
+  if (q == 0 && dst) *dst = ((part[0][l] + part[1][l]) + part[2][l]) + part[3][l];
+}
+// slot floats per tile, and the cap above which the accumulation falls back to float atomics (the table is written and
+// read once per gradient: 128 MB is ~30 us of HBM time; a 2000-particle shard of K = 256 needs 30 MB)
+constexpr int64_t kDetCapFloats = int64_t(1) << 25;
+static int64_t grad_det_tile_floats(const cmcd_desc& d, int HP) {
+  const int64_t K1 = d.nbridges + 1;
+  return K1 * HP * (d.arch == CMCD_ARCH_GEFFNER ? 2 : 1) + K1 * 4;
+}
+// CMCD_GRAD_ATOMICS=1: the float-atomic accumulation of rounds 1-3 (A/B measurements only; read once)
+static bool grad_atomics_forced() {
+  static const bool v = [] { const char* e = getenv("CMCD_GRAD_ATOMICS"); return e && e[0] == '1'; }();
+  return v;
+}
+static int64_t grad_det_floats(const cmcd_desc& d, int HP, int64_t n) {
+  const int64_t f = ((n + 15) / 16) * grad_det_tile_floats(d, HP);
+  return f <= kDetCapFloats ? f : 0;
+}
+
 static int grad_nslabs(int64_t n, int nw) {
   const int64_t nquads = (n + 16 * nw - 1) / (16 * nw);
   return (int)(nquads < 256 ? nquads : 256);
@@ -1460,7 +1616,8 @@ int64_t grad_workspace_floats(const cmcd_desc& d, int HP, int64_t n) {
   int64_t oS, oS2, ob, oe, ov, of, tot;
   grad_offsets(d, HP, oS, oS2, ob, oe, ov, of, tot);
   const int64_t slab = (int64_t)HP * HP + HP * 16 + 4 * (2 * 16 * HP + 256 + 32);
-  return tot + grad_tail_floats(d) + slab * 256;   // up to one slab per workgroup of a full-chip launch (either path)
+  // up to one slab per workgroup of a full-chip launch (either path), then the fixed-order slots
+  return tot + grad_tail_floats(d) + slab * 256 + grad_det_floats(d, HP, n);
 }
 
 // ws_fwd: the forward workspace as left by cmcd_bound_forward's prep on the SAME desc/params;
@@ -1488,6 +1645,13 @@ int grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, c
   ga.ula = d.mode == CMCD_MODE_ULA_SN ? 2 : 0;
   ga.nitems = nitems;
   ga.slab_stride = (int64_t)HP * HP + HP * 16 + 4 * (2 * 16 * HP + 256 + 32);
+  const bool det = grad_det_floats(d, HP, n) > 0 && !grad_atomics_forced();
+  if (det) {
+    ga.det = gws + tot + grad_tail_floats(d) + ga.slab_stride * 256;
+    ga.det_tile_stride = grad_det_tile_floats(d, HP);
+    ga.det_tiles = ntiles;
+    ga.det_obe = ga.det_tile_stride - (int64_t)(K + 1) * 4;
+  }
   if (bptt && item) {
     // (the Jacobian launch zeroes the accumulation tables and the output on its way: no memset launches on this path)
     const int64_t S = (int64_t)D * D + 2 * D;
@@ -1510,6 +1674,15 @@ int grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, c
                           (int)lds_bytes) != hipSuccess)
     return CMCD_ERR_HIP;
   hipLaunchKernelGGL(fn, dim3(nslabs), dim3(64 * nw), lds_bytes, stream, ga);
+  if (det) {
+    DetArgs da{};
+    da.det = ga.det; da.gtab = gws; da.o_S = ga.o_S; da.o_S2 = ga.o_S2; da.o_gbeta = ga.o_gbeta; da.o_geps = ga.o_geps;
+    da.tile_stride = ga.det_tile_stride; da.obe = ga.det_obe; da.ntiles = ntiles;
+    da.K = K; da.HP = HP; da.gef = d.arch == CMCD_ARCH_GEFFNER ? 1 : 0; da.ula = ga.ula ? 1 : 0;
+    da.has_fwd = (item || bptt) ? 1 : 0; da.has_bwd = (!bptt || item) ? 1 : 0;
+    const int64_t outs = (int64_t)(K + 1) * HP * (da.gef ? 2 : 1) + 2 * (int64_t)K;
+    hipLaunchKernelGGL(grad_det_reduce_kernel, dim3((unsigned)((outs + 63) / 64)), dim3(256), 0, stream, da);
+  }
 
   TailArgs ta{};
   ta.params = params; ta.ws = ws_fwd; ta.gtab = gws; ta.slabs = gws + tot + grad_tail_floats(d); ta.tail = gws + tot;
@@ -1543,8 +1716,13 @@ static ula_fn pick_ula(const cmcd_desc& d) {
   return nullptr;
 }
 bool ula_grad_available(const cmcd_desc& d) { return pick_ula(d) != nullptr; }
+static int64_t ula_det_floats(int64_t K4, int64_t ntiles) {
+  const int64_t f = ntiles * 2 * K4;
+  return f <= kDetCapFloats ? f : 0;
+}
 int64_t ula_grad_workspace_floats(const cmcd_desc& d, int64_t n) {
-  return (((int64_t)d.nbridges + 3) & ~int64_t(3)) * 2 + ((n + 15) / 16) * 2 * d.dim + 8;
+  const int64_t K4 = ((int64_t)d.nbridges + 3) & ~int64_t(3), ntiles = (n + 15) / 16;
+  return K4 * 2 + ntiles * 2 * d.dim + 8 + ula_det_floats(K4, ntiles);
 }
 
 // MCD_ULA: reverse sweep without a network.  gws: ula_grad_workspace_floats; ws_fwd / traj as left by the forward.
@@ -1557,8 +1735,13 @@ int ula_grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& 
   const int64_t K4 = ((int64_t)d.nbridges + 3) & ~int64_t(3), ntiles = (n + 15) / 16;
   if (hipMemsetAsync(grad, 0, sizeof(float) * n_params, stream) != hipSuccess) return CMCD_ERR_HIP;
   if (hipMemsetAsync(gws, 0, sizeof(float) * 2 * K4, stream) != hipSuccess) return CMCD_ERR_HIP;
-  UlaGradArgs a{params, ws_fwd, traj, gws, gws + 2 * K4, lay, w, n, 0, K4, d.nbridges, omega};
+  const bool det = ula_det_floats(K4, ntiles) > 0 && !grad_atomics_forced();
+  float* det_rows = det ? gws + 2 * K4 + ntiles * 2 * d.dim + 8 : nullptr;
+  UlaGradArgs a{params, ws_fwd, traj, gws, gws + 2 * K4, det_rows, lay, w, n, 0, K4, d.nbridges, omega};
   hipLaunchKernelGGL(fn, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), (size_t)(w.tgt_floats + 4) * 4, stream, a);
+  if (det)
+    hipLaunchKernelGGL(tile_rows_reduce_kernel, dim3((unsigned)((2 * K4 * 16 + 255) / 256)), dim3(256), 0, stream, det_rows,
+                       ntiles, 2 * K4, K4, (int64_t)d.nbridges, gws);
   hipLaunchKernelGGL(ula_vd_reduce_kernel, dim3(1), dim3(64), 0, stream, gws + 2 * K4, ntiles, d.dim, grad, lay.vd_mean,
                      lay.vd_logdiag);
   TailArgs ta{};

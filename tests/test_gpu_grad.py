@@ -608,3 +608,66 @@ def test_gradient_with_a_17_component_mixture(hip_lib, param_set, monkeypatch, i
     for leaf in ("mean", "logdiag"):
         off = b["unflatten"].offset("vd", leaf)
         assert np.abs(grad[off:off + 2].double().cpu().numpy() - g["vd"][leaf]).max() <= 2e-3 * np.abs(g["vd"][leaf]).max()
+
+
+REPEAT_CASES = [
+    # (synthetic config, particles, overrides, gradient function, CMCD_GRAD_ITEM)
+    ("gmm_n300_k8", 300, dict(), "compute_bound_grad", 0),
+    ("gmm_n300_k8", 300, dict(), "compute_bound_grad", 1),
+    ("gmm_n300_k8", 2000, dict(boundmode="MCD_CAIS_var_sn"), "compute_log_var_grad", 0),
+    ("gmm_n300_k8", 300, dict(boundmode="MCD_CAIS_var_sn"), "compute_log_var_grad", 1),
+    ("many_gmm_n2000_k256_dds", 500, dict(nbridges=12, init_sigma=15.0), "compute_bound_grad", 1),
+    ("many_gmm_n2000_k256_dds", 500, dict(nbridges=12, init_sigma=15.0, nn_arch="geffner", emb_dim=100), "compute_bound_grad", 0),
+    ("gmm_n300_k8", 333, dict(boundmode="MCD_ULA_sn"), "compute_bound_grad", 1),
+    ("gmm_n300_k8", 333, dict(boundmode="MCD_ULA"), "compute_bound_grad", 0),
+]
+
+
+@pytest.mark.parametrize("name,n,over,fn,item", REPEAT_CASES)
+def test_repeated_gradient_calls_are_bitwise_identical(hip_lib, monkeypatch, name, n, over, fn, item):
+    """The sums over particles behind d bias-table / d beta / d eps go through one slot per (tile, evaluation) and a
+    fixed-order reduction (cmcd_grad.hip: GradArgs::det, grad_det_reduce_kernel); rounds 1-3 used float atomics on the
+    shared tables and the same call returned gradients that differed in the last bits from run to run.  Twenty calls
+    with other launches in between (so the waves of the gradient kernel do not arrive in one fixed order)."""
+    monkeypatch.setenv("CMCD_GRAD_ITEM", str(item))
+    b = synthetic.build(name, device="cuda", **over)
+    seeds = torch.from_numpy(synthetic.parity_seeds(n)).cuda()
+    call = getattr(mcdbm, fn)
+    kw = dict(eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
+    first = None
+    noise = torch.randn(1 << 20, device="cuda")
+    for rep in range(20):
+        if rep % 3 == 1:
+            noise = noise * 1.0001   # an unrelated launch in between
+        grad, (losses, _) = call(seeds, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"], **kw)
+        g, l = grad.clone(), losses.clone()
+        if first is None:
+            first = (g, l)
+            assert torch.isfinite(g).all()
+        else:
+            assert torch.equal(g, first[0]), (rep, float((g - first[0]).abs().max()))
+            assert torch.equal(l, first[1])
+
+
+def test_a_training_seed_reproduces_bit_for_bit(hip_lib):
+    """Two opt.run trainings with one seed end at the same parameters, bit for bit (gmm K = 8 is chaotic enough that
+    last-bit differences in a gradient moved the trained ELBO by 0.05 nats between runs before: tools/probes/
+    train_determinism.py)."""
+    import types
+    from functools import partial
+    from cmcd_amd import opt
+    b = synthetic.build("gmm_n300_k8", device="cuda")
+    dim, K, mode, spec = b["params_fixed"]
+    kw = dict(eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
+    trainable = ("eps", "vd", "eta", "mgridref_y")
+    ends = []
+    for _ in range(2):
+        flat, unflatten, fixed = mcdbm.initialize(
+            dim=dim, nbridges=K, vdparams={"mean": torch.zeros(dim), "logdiag": torch.zeros(dim)}, eps=0.01,
+            trainable=trainable, mode=mode, emb_dim=20, nn_arch="geffner", device="cuda", seed=1)
+        losses, flat2, _ = opt.run(types.SimpleNamespace(N=300), 1e-3, 300, flat, unflatten, fixed, b["target"],
+                                   partial(mcdbm.compute_bound_grad, **kw), trainable, 7)
+        ends.append((flat2.clone(), torch.as_tensor(losses).clone()))
+    assert torch.isfinite(ends[0][0]).all()
+    assert torch.equal(ends[0][0], ends[1][0])
+    assert torch.equal(ends[0][1], ends[1][1])
