@@ -1192,7 +1192,7 @@ __device__ __forceinline__ void grad_reduce_body(const TailArgs& a, const unsign
 __device__ __forceinline__ void grad_sched_tail_body(const TailArgs& a, const unsigned bidx, const unsigned gdim) {
   __shared__ float gyg[40], gyv[40], red[256], ms[40];
   __shared__ float c_lo[1024], c_hi[1024];
-  __shared__ int c_j[1024];
+  __shared__ int c_j[1024], seg[41];
   const int K = a.K, G = a.ngrid;
   const float* gbeta = a.gtab + a.o_gbeta;
   const float* geps = a.gtab + a.o_geps;
@@ -1201,6 +1201,8 @@ __device__ __forceinline__ void grad_sched_tail_body(const TailArgs& a, const un
   if ((int)threadIdx.x <= G) ms[threadIdx.x] = a.params[a.lay.mgridref_y + threadIdx.x];
   float ge = 0.f, gq = 0.f;   // gq: this thread's grid node q = threadIdx.x (q <= G + 1)
   for (int base = 0; base < K; base += 1024) {
+    __syncthreads();
+    if (threadIdx.x < 41) seg[threadIdx.x] = -1;
     __syncthreads();
     for (int i = base + threadIdx.x; i < K && i < base + 1024; i += blockDim.x) {
       float dedeps0 = 1.0f;                                                         // constant schedule
@@ -1212,25 +1214,31 @@ __device__ __forceinline__ void grad_sched_tail_body(const TailArgs& a, const un
       }
       ge += geps[i] * dedeps0;
       // beta_i = gy[j-1] + frac_i (gy[j] - gy[j-1]),  gy = [0, cumsum(m)/sum(m)]
+      auto cell = [&](int ii) {
+        const float x = (float)(ii + 1) / (float)(K + 1);
+        int j = 1;
+        while (j < G + 1 && (float)j / (float)(G + 1) <= x) ++j;
+        return j;
+      };
       const float x = (float)(i + 1) / (float)(K + 1);
-      int j = 1;
-      while (j < G + 1 && (float)j / (float)(G + 1) <= x) ++j;
+      const int j = cell(i);
       const float x0 = (float)(j - 1) / (float)(G + 1), x1 = (float)j / (float)(G + 1);
       const float fr = (x - x0) / (x1 - x0);
       c_j[i - base] = j;
       c_lo[i - base] = gbeta[i] * (1.0f - fr);
       c_hi[i - base] = gbeta[i] * fr;
+      if (i == base || cell(i - 1) != j) seg[j] = i - base;   // the cell index grows with i: the steps of a cell are a run
     }
     __syncthreads();
-    // node q collects the steps of its two neighbouring cells in step order (LDS float atomics from 256 threads summed
-    // them in whatever order the waves arrived: the last source of run-to-run differences in a training step, r04)
+    // node q collects the run of cell q (upper ends) and then the run of cell q + 1 (lower ends), each in step order
+    // (LDS float atomics from 256 threads summed them in whatever order the waves arrived: the last source of
+    // run-to-run differences in a training step, r04)
     if ((int)threadIdx.x <= G + 1) {
       const int q = threadIdx.x, lim = K - base < 1024 ? K - base : 1024;
-      for (int i = 0; i < lim; ++i) {
-        const int j = c_j[i];
-        if (j - 1 == q) gq += c_lo[i];
-        if (j == q) gq += c_hi[i];
-      }
+      if (q >= 1)
+        for (int i = seg[q]; i >= 0 && i < lim && c_j[i] == q; ++i) gq += c_hi[i];
+      if (q <= G)
+        for (int i = seg[q + 1]; i >= 0 && i < lim && c_j[i] == q + 1; ++i) gq += c_lo[i];
     }
   }
   if ((int)threadIdx.x <= G + 1) gyg[threadIdx.x] = gq;

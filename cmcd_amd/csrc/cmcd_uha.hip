@@ -1217,12 +1217,22 @@ struct UhaGradArgs {
   int64_t n_a = 0;
   float* zero_b = nullptr;
   int64_t n_b = 0;
+  // fixed-order accumulation (r04, as GradArgs::det of cmcd_grad.hip): one slot per (tile, bridge, evaluation) for the bias-table
+  // rows and per (tile, point) for the schedule gradients — every one written by exactly one wave, with plain stores — summed
+  // over tiles by uha_det_reduce_kernel.  (r03: float atomics on the shared tables; a training seed did not reproduce, and
+  // the stores are cheaper: 592 -> 525 us for the named shape's sweep.)  The table holds a slot for every tile of every quad.
+  // per tile: S [2 evaluations][K][HP] | S2 [2][K][HP] (geffner) | [(K+1)][8] = {d beta_e, d eps_e, d beta_{e-1}, d eps_{e-1}, d eps_{e-1} (kernel side)}
+  float* det = nullptr;
 };
 
 __device__ __forceinline__ int uha_sw(int f, int p) { return f * 16 + (p ^ (f & 15)); }
 
 template <int TARGET, int ARCH, int D, int T, int NW, bool WGLOBAL, bool JAC = false>
-__global__ __launch_bounds__(64 * NW) void uha_grad_kernel(UhaGradArgs a) {
+// (r04) the d = 2 Jacobian launch at three waves per SIMD (168 registers, 12 spilled): 337 -> 314 us at the named shape.  The sweep
+// at two (241 registers, so that the second workgroup a CU's LDS has room for is really resident) measured 606 against 592 us
+// with one: on gfx950 an fp32 MFMA and the VALU work of the SIMD's other wave do not overlap (tools/probes/mfma_valu_probe.hip),
+// so a second wave only fills the stalls, and these are not what bounds the sweep ("the floor").
+__global__ __launch_bounds__(64 * NW, (D == 2 && JAC) ? 3 : 1) void uha_grad_kernel(UhaGradArgs a) {
   constexpr int HP = 16 * T;
   constexpr int DIN = 2 * D;
   constexpr int S_JAC = 3 * D * D + 3 * D;     // floats per (point, particle) of the Jacobian launch, see uha_scan_kernel
@@ -1305,8 +1315,6 @@ __global__ __launch_bounds__(64 * NW) void uha_grad_kernel(UhaGradArgs a) {
   constexpr float clipv = 1e2f;
   const float* bias1 = a.ws + a.w.bias1;
   const float* utab = a.ws + a.w.utab;
-  float* gS = a.gtab + a.o_S;
-  float* gS2 = a.gtab + a.o_S2;
   const float* tz = a.traj;
   const float* trho = a.traj + (int64_t)(K + 1) * a.n * D;
   const float* trhop = a.traj + (int64_t)(2 * K + 2) * a.n * D;
@@ -1323,6 +1331,9 @@ __global__ __launch_bounds__(64 * NW) void uha_grad_kernel(UhaGradArgs a) {
   float gfac = 0.f, ggam = 0.f, gmu[D], glam[D], gb3[D];
 #pragma unroll
   for (int j = 0; j < D; ++j) { gmu[j] = 0.f; glam[j] = 0.f; gb3[j] = 0.f; }
+  // the ones row of the staged network input: its product with d a1 is the sum of d a1 over the tile's particles
+  constexpr int XT0 = DIN / 16, G0 = (DIN % 16) / 4, R0 = DIN % 4;
+  static_assert(DIN % 16 != 0, "the staged network input needs a spare row for the ones");
 
   // Work items: MODE_SWEEP — a quad of tiles x a chunk of the chain (nchunks = 1: the whole chain, adjoints carried from e = K;
   // else the adjoint state entering the chunk's first point comes from `xbuf`, written by uha_scan_kernel);  MODE_JAC — a quad
@@ -1338,6 +1349,18 @@ __global__ __launch_bounds__(64 * NW) void uha_grad_kernel(UhaGradArgs a) {
     const bool valid = p < a.n;
     const int64_t pc = valid ? p : a.n - 1;
     const float om = valid ? a.omega : 0.f;
+    // this tile's slots (the table holds one per tile of every quad: a tile past the batch writes its zeros like any other).
+    // Per-lane (vector-register) pointers: the stores below then carry compile-time offsets only, and
+    // nothing of the slot addressing sits in scalar registers (the sweep is at its SGPR limit: 41 spilled with scalar bases)
+    const int64_t det_stride = (int64_t)K * HP * (GEF ? 4 : 2) + (int64_t)(K + 1) * 8;
+    float* dlane = a.det + tile * det_stride;
+    float* dbe = a.det + tile * det_stride + (det_stride - (int64_t)(K + 1) * 8);
+    asm volatile("" : "+v"(dlane), "+v"(dbe));
+    // schedule-gradient contribution `which` (0: bridge e, forward side; 2: bridge e - 1; 4: bridge e - 1, kernel side) of point e
+    auto emit_be = [&](int e, int which, float tb, float te) {
+      if (which < 4) { dbe[8 * e + which] = tb; dbe[8 * e + which + 1] = te; }
+      else dbe[8 * e + 4] = te;
+    };
 
     float lz[D], lr[D], arpp_c[D];   // dL/dz_e, dL/drho_e; dL/drho''_e of the bridge already walked (its uf side is pending)
     float znext[D];
@@ -1418,10 +1441,7 @@ __global__ __launch_bounds__(64 * NW) void uha_grad_kernel(UhaGradArgs a) {
             se -= 0.5f * ub * lr[j];
           }
           const float tb = row_sum16(sb), te = row_sum16(se);
-          if (lane == 0) {
-            atomicAdd(a.gtab + a.o_gbeta + (e - 1), tb);
-            atomicAdd(a.gtab + a.o_geps + (e - 1), te);
-          }
+          if (lane == 0) emit_be(e, 2, tb, te);
         }
         if (e <= K - 1) {   // uf of bridge e:  rho'' = rho' - eps uf / 2
           const float be = a.ws[a.w.beta + e], ee = a.ws[a.w.eps + e];
@@ -1436,10 +1456,7 @@ __global__ __launch_bounds__(64 * NW) void uha_grad_kernel(UhaGradArgs a) {
             se -= 0.5f * uf * arpp_c[j];
           }
           const float tb = row_sum16(sb), te = row_sum16(se);
-          if (lane == 0) {
-            atomicAdd(a.gtab + a.o_gbeta + e, tb);
-            atomicAdd(a.gtab + a.o_geps + e, te);
-          }
+          if (lane == 0) emit_be(e, 0, tb, te);
         }
         {
           float v[D], hv[D];
@@ -1496,6 +1513,7 @@ __global__ __launch_bounds__(64 * NW) void uha_grad_kernel(UhaGradArgs a) {
         float rin[D];
 #pragma unroll
         for (int j = 0; j < D; ++j) rin[j] = pass == 0 ? rhop[j] : rho[j];
+        float* srow = dlane + ((int64_t)pass * K + erow) * HP;   // this evaluation's row of the tile's slots
         // ------------------------------------------------------------ forward (keeps the activation derivatives)
         constexpr bool KEEP_A1 = T <= 4;
         f32x4 a1[KEEP_A1 ? T : 1], u1[T], a2[T];
@@ -1615,6 +1633,9 @@ __global__ __launch_bounds__(64 * NW) void uha_grad_kernel(UhaGradArgs a) {
             if (ACC && g == 0) gb3[j] += dob[j];
           }
           f32x4 d2[T], d1[T];
+          float b2sel[T];
+#pragma unroll
+          for (int t = 0; t < T; ++t) b2sel[t] = 0.f;
 #pragma unroll
           for (int t = 0; t < T; ++t) {
             f32x4 du2 = {0.f, 0.f, 0.f, 0.f};
@@ -1625,11 +1646,17 @@ __global__ __launch_bounds__(64 * NW) void uha_grad_kernel(UhaGradArgs a) {
               d2[t][r] = du2[r] * a2[t][r];
               if constexpr (ACC) {
                 da2T[wb[r] + 256 * t] = d2[t][r];
-                const float s = row_sum16(d2[t][r]);                  // db2[n] += sum over the tile's particles
-                if (c == 0) accB2[16 * t + 4 * g + r] += s;
+                const float s = row_sum16(d2[t][r]);                  // db2[n] += sum over the tile's particles: every lane has
+                b2sel[t] = (c & 3) == r ? s : b2sel[t];               // it, lane c < 4 keeps hidden unit 16 t + 4 g + c
               }
             }
             d1[t] = GEF ? du2 : f32x4{0.f, 0.f, 0.f, 0.f};           // (geffner: d u2 rides on through the residual path)
+          }
+          if constexpr (ACC) {   // db2: ONE exec region per evaluation (r03: a branch + a single-lane update per hidden-unit register)
+            if (c < 4) {
+#pragma unroll
+              for (int t = 0; t < T; ++t) accB2[16 * t + 4 * g + c] += b2sel[t];
+            }
           }
           {
             f32x4 atn[T];
@@ -1673,6 +1700,7 @@ __global__ __launch_bounds__(64 * NW) void uha_grad_kernel(UhaGradArgs a) {
                   xv = (f == j) ? z[j] : xv;
                   xv = (f == D + j) ? rin[j] : xv;
                 }
+                if (f == DIN) xv = 1.0f;
                 xT[wb[r] + 256 * xt] = xv;
               }
             }
@@ -1692,6 +1720,9 @@ __global__ __launch_bounds__(64 * NW) void uha_grad_kernel(UhaGradArgs a) {
           float jpart[DIN];   // J_s^T cot, this lane's share of the hidden units
 #pragma unroll
           for (int j = 0; j < DIN; ++j) jpart[j] = 0.f;
+          float s1row[T], s2sel[T];   // d / d bias-table row i (d a1 sums) and the residual row (d u1 sums), stored below
+#pragma unroll
+          for (int t = 0; t < T; ++t) { s1row[t] = 0.f; s2sel[t] = 0.f; }
 #pragma unroll
           for (int t = 0; t < T; ++t) {
             f32x4 pre1;
@@ -1710,8 +1741,8 @@ __global__ __launch_bounds__(64 * NW) void uha_grad_kernel(UhaGradArgs a) {
               if (GEF) {
                 if constexpr (ACC) {
                   du1T[wb[r]] = d1[t][r];
-                  const float s2v = row_sum16(d1[t][r]);              // residual row: sum_p d u1  (-> d emb)
-                  if (c == 0) atomicAdd(gS2 + erow * HP + 16 * t + 4 * g + r, s2v);
+                  const float s2v = row_sum16(d1[t][r]);              // residual row: sum_p d u1  (-> d emb): every lane has it
+                  s2sel[t] = (c & 3) == r ? s2v : s2sel[t];           // lane c < 4 keeps hidden unit 16 t + 4 g + c
                 }
                 if (16 * t < DIN) {                                 // residual path of the first block: d x_j += d u1_j
 #pragma unroll
@@ -1720,11 +1751,7 @@ __global__ __launch_bounds__(64 * NW) void uha_grad_kernel(UhaGradArgs a) {
                 }
               }
               d1[t][r] *= KEEP_A1 ? pre1[r] : (GEF ? sigmoid_fast(pre1[r]) : gelu_grad_fast(pre1[r]));
-              if constexpr (ACC) {
-                da1T[wb[r]] = d1[t][r];
-                const float s1v = row_sum16(d1[t][r]);                // d / d bias-table row i
-                if (c == 0) atomicAdd(gS + erow * HP + 16 * t + 4 * g + r, s1v);
-              }
+              if constexpr (ACC) da1T[wb[r]] = d1[t][r];
             }
 #pragma unroll
             for (int j = 0; j < DIN; ++j) {
@@ -1743,8 +1770,23 @@ __global__ __launch_bounds__(64 * NW) void uha_grad_kernel(UhaGradArgs a) {
                   const int row = 16 * xt + 4 * g + r;
                   if (row < DIN) accZ1[row * HP + 16 * t + c] += sacc[r];
                 }
+                if (xt == XT0) s1row[t] = sacc[R0];                   // lanes g == G0: sum_p d a1[16 t + c][p] (the ones row)
               }
               asm volatile("" ::: "memory");   // the next tile's stores stay behind these reads
+            }
+          }
+          if constexpr (ACC) {
+            // this evaluation's rows of the tile's slots: ONE exec region each (r04 first cut: a branch + a 4-lane store per
+            // hidden-unit register), 64-byte stores from the quarter wave that holds the ones row
+            if (g == G0) {
+              float* q = srow + c;
+#pragma unroll
+              for (int t = 0; t < T; ++t) q[16 * t] = s1row[t];
+            }
+            if (GEF && c < 4) {
+              float* q = srow + 2 * (int64_t)K * HP + 4 * g + c;
+#pragma unroll
+              for (int t = 0; t < T; ++t) q[16 * t] = s2sel[t];
             }
           }
 #pragma unroll
@@ -1865,7 +1907,7 @@ __global__ __launch_bounds__(64 * NW) void uha_grad_kernel(UhaGradArgs a) {
         for (int j = 0; j < D; ++j) lr[j] = lrn[j];
         ggam += eps * geta;
         const float te = row_sum16(gepsd + gamma * geta);
-        if (lane == 0) atomicAdd(a.gtab + a.o_geps + i, te);
+        if (lane == 0) emit_be(e, 4, 0.f, te);
       }
     }
   }
@@ -2404,10 +2446,68 @@ static int64_t uha_slab_floats(const cmcd_desc& d, int HP) {
 }
 static int64_t uha_dds_tail_floats(const cmcd_desc& d) { return d.arch == CMCD_ARCH_DDS ? (int64_t)(d.nbridges + 1) * 448 : 0; }
 
+// ---- fixed-order sums of the per-(tile, bridge / point) slots (UhaGradArgs::det) into the tables the tails read
+struct UhaDetArgs {
+  const float* det;
+  float* gtab;
+  int64_t o_S, o_S2, o_gbeta, o_geps, tile_stride, obe, ntiles;
+  int32_t K, HP, gef;
+};
+// A block = 64 consecutive outputs x 4 tile classes (thread (q, l): tiles q, q + 4, ... of output l in that order, eight loads
+// in flight; the four partial sums are added in the order q = 0 .. 3).  Outputs: S[i][col] (and S2) for the K bridges, then
+// d beta_i / d eps_i from the three contributions a bridge receives (point i's forward side, point i + 1's two).
+__global__ __launch_bounds__(256) void uha_det_reduce_kernel(UhaDetArgs a) {
+  __shared__ float part[4][64];
+  const int l = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int64_t nS = (int64_t)a.K * a.HP, nSS = a.gef ? 2 * nS : nS;
+  const int64_t o = (int64_t)blockIdx.x * 64 + l;
+  int64_t src[3] = {-1, -1, -1};
+  float* dst = nullptr;
+  if (o < nSS) {   // the bridge's two evaluations (s2 first, as the sweep walks them)
+    src[0] = o < nS ? o : 2 * nS + (o - nS);
+    src[1] = src[0] + nS;
+    dst = a.gtab + (o < nS ? a.o_S + o : a.o_S2 + (o - nS));
+  } else if (o < nSS + 2 * (int64_t)a.K) {
+    const int64_t oo = o - nSS;
+    const int i = (int)(oo >> 1), w = (int)(oo & 1);   // w = 0: d beta_i, 1: d eps_i
+    src[0] = a.obe + 8 * (int64_t)i + w;
+    src[1] = a.obe + 8 * (int64_t)(i + 1) + 2 + w;
+    if (w) src[2] = a.obe + 8 * (int64_t)(i + 1) + 4;
+    dst = a.gtab + (w ? a.o_geps : a.o_gbeta) + i;
+  }
+  float v = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (src[k] < 0) continue;
+    const float* base = a.det + src[k];
+    int64_t t = q;
+    for (; t + 4 * 7 < a.ntiles; t += 4 * 8) {
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = base[(t + 4 * u) * a.tile_stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += x[u];
+    }
+    for (; t < a.ntiles; t += 4) v += base[t * a.tile_stride];
+  }
+  part[q][l] = v;
+  __syncthreads();
+  if (q == 0 && dst) *dst = ((part[0][l] + part[1][l]) + part[2][l]) + part[3][l];
+}
+static int64_t uha_det_tile_floats(const cmcd_desc& d, int HP) {
+  const int64_t K = d.nbridges;
+  return K * HP * (d.arch == CMCD_ARCH_GEFFNER ? 4 : 2) + (K + 1) * 8;
+}
+static int64_t uha_det_floats(const cmcd_desc& d, int HP, int64_t n) {
+  // a slot per tile of every quad: the same order of memory as the kept trajectory ((3 K + 2) d floats per particle)
+  return ((n + 16 * kUhaNW - 1) / (16 * kUhaNW)) * kUhaNW * uha_det_tile_floats(d, HP);
+}
+
 int64_t uha_grad_workspace_floats(const cmcd_desc& d, int HP, int64_t n) {
   int64_t oS, oS2, ob, oe, tot;
   uha_grad_offsets(d, HP, oS, oS2, ob, oe, tot);
-  return tot + uha_dds_tail_floats(d) + uha_slab_floats(d, HP) * kUhaSlabs + uha_item_floats(d, HP / 16, n);
+  return tot + uha_dds_tail_floats(d) + uha_slab_floats(d, HP) * kUhaSlabs + uha_item_floats(d, HP / 16, n) +
+         uha_det_floats(d, HP, n);
 }
 
 static float* g_uha_xdump = nullptr;   // tests: cmcd_debug_uha_xdump — the next sweeps write the adjoint state they carry
@@ -2433,11 +2533,15 @@ int uha_grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& 
   ga.params = params; ga.ws = ws_fwd; ga.traj = traj; ga.gtab = gws; ga.slabs = slabs; ga.lay = lay; ga.w = w; ga.n = n;
   ga.K = K; ga.nquads = (int)nquads; ga.omega = omega; ga.slab_stride = uha_slab_floats(d, HP);
   const bool items = uha_item_mode(d, w.T, n);
+  // (behind the item buffers, whether this call uses them or not)
+  ga.det = slabs + uha_slab_floats(d, HP) * kUhaSlabs + uha_item_floats(d, w.T, n);
   if (!items) {   // (the work-item path's Jacobian launch zeroes both on its way)
     if (hipMemsetAsync(gws, 0, sizeof(float) * tot, stream) != hipSuccess) return CMCD_ERR_HIP;
     if (hipMemsetAsync(grad, 0, sizeof(float) * n_params, stream) != hipSuccess) return CMCD_ERR_HIP;
   }
   const bool wglobal = w.T > 4;
+  // (keep the small-batch sweep's workgroup under 80 KB: two then share a CU — measured 510 against 668 us for the named shape
+  // when a 13 KB table pushed it to 87 KB, profiles/r04_uha_sweep_variants.txt)
   const size_t stg = size_t(3 * HP * 16 + 3 * 256 + XT * 256 + (DIN + 1) * HP);
   const size_t lds_bytes = size_t((wglobal ? 0 : 2 * HP * HP) + DIN * HP + D * HP + HP + 16 + w.tgt_floats + nw * stg) * 4;
   if (lds_bytes > 160 * 1024) return CMCD_ERR_UNSUPPORTED;
@@ -2488,6 +2592,14 @@ int uha_grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& 
     hipLaunchKernelGGL(fn, dim3(nslabs_used), dim3(64 * nw), lds_bytes, stream, ga);
   }
 
+  {
+    UhaDetArgs da{};
+    da.det = ga.det; da.gtab = gws; da.o_S = ga.o_S; da.o_S2 = ga.o_S2; da.o_gbeta = ga.o_gbeta; da.o_geps = ga.o_geps;
+    da.tile_stride = uha_det_tile_floats(d, HP); da.obe = da.tile_stride - (int64_t)(K + 1) * 8; da.ntiles = (n + 15) / 16;
+    da.K = K; da.HP = HP; da.gef = d.arch == CMCD_ARCH_GEFFNER ? 1 : 0;
+    const int64_t douts = (int64_t)K * HP * (da.gef ? 2 : 1) + 2 * (int64_t)K;
+    hipLaunchKernelGGL(uha_det_reduce_kernel, dim3((unsigned)((douts + 63) / 64)), dim3(256), 0, stream, da);
+  }
   UhaReduceArgs ra{};
   ra.slabs = slabs; ra.grad = grad; ra.lay = lay; ra.slab_stride = ga.slab_stride; ra.nslabs = nslabs_used; ra.nw = nw;
   ra.HP = HP; ra.D = D; ra.wid = d.arch == CMCD_ARCH_DDS ? 64 : DIN + d.emb_dim; ra.arch = d.arch;

@@ -185,6 +185,32 @@ def test_reparameterised_gradient_matches_autograd(hip_lib, param_set, variant, 
     assert float(g_ref[b["unflatten"].offset("gamma")].abs()) > 0     # the friction is a trained leaf in this mode
 
 
+@pytest.mark.parametrize("item", [0, 1], ids=["whole_chain", "work_items"])
+@pytest.mark.parametrize("name,n,over", [("many_gmm_n2000_k256_dds", 500, dict(nbridges=16, init_sigma=15.0)),
+                                         ("gmm_n300_k8", 300, dict()),
+                                         ("funnel_n300_k64", 100, dict(nbridges=8))])
+def test_repeated_gradient_calls_are_bitwise_identical(hip_lib, monkeypatch, name, n, over, item):
+    """The sums over particles behind d bias-table / d beta / d eps go through one slot per (tile, bridge / point) and a
+    fixed-order reduction (cmcd_uha.hip: UhaGradArgs::det, uha_det_reduce_kernel); round 3 used float atomics on the shared
+    tables, so the same call returned gradients that differed in the last bits from run to run."""
+    monkeypatch.setenv("CMCD_GRAD_ITEM", str(item))
+    b = synthetic.build(name, device="cuda", boundmode=MODE, **over)
+    seeds = torch.from_numpy(synthetic.parity_seeds(n)).cuda()
+    first = None
+    noise = torch.randn(1 << 20, device="cuda")
+    for rep in range(20):
+        if rep % 3 == 1:
+            noise = noise * 1.0001   # an unrelated launch in between
+        grad, (losses, _) = mcdbm.compute_bound_grad(seeds, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"])
+        g, l = grad.clone(), losses.clone()
+        if first is None:
+            first = (g, l)
+            assert torch.isfinite(g).all()
+        else:
+            assert torch.equal(g, first[0]), (rep, float((g - first[0]).abs().max()))
+            assert torch.equal(l, first[1])
+
+
 def test_gradient_shards_add_up(hip_lib):
     """Multi-GPU contract: shards called with the global particle count sum to the single-call gradient."""
     b = synthetic.build("gmm_n300_k8", device="cuda", boundmode=MODE, dense=True)

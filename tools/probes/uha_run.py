@@ -8,9 +8,14 @@ from cmcd_amd import synthetic
 from cmcd_amd import mcdboundingmachine as mcdbm
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 out = {}
-for name, over in (("many_gmm_n2000_k256_dds", dict(init_eps=0.2, init_gamma=2.0, init_sigma=15.0)),
-                   ("funnel_n300_k64", dict(init_eps=0.05, init_gamma=4.0)),
-                   ("lgcp_n20_k128", dict(init_eps=0.02, init_gamma=5.0))):
+CASES = (("many_gmm_n2000_k256_dds", dict(init_eps=0.2, init_gamma=2.0, init_sigma=15.0)),
+         ("funnel_n300_k64", dict(init_eps=0.05, init_gamma=4.0)),
+         ("lgcp_n20_k128", dict(init_eps=0.02, init_gamma=5.0)))
+if "nolgcp" in sys.argv[2:]:
+    CASES = CASES[:2]
+if "manyonly" in sys.argv[2:]:
+    CASES = CASES[:1]
+for name, over in CASES:
     kw = {}
     if "lgcp" in name:
         import numpy as np
