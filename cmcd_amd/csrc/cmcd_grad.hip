@@ -88,7 +88,8 @@ __device__ __forceinline__ int sw(int f, int p) { return f * 16 + (p ^ (f & 15))
 // by construction; the reparameterised one once lambda_e is known from the scan), so a wave takes work
 // items instead of whole chains: small batches then fill the chip instead of 1/8 of it.
 template <int TARGET, int ARCH, int D, int T, int NW, bool WGLOBAL, bool BPTT, bool ITEM>
-__global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
+// (the work-item instances that stream W2 are launched two workgroups per CU: the register budget must allow it as the LDS does)
+__global__ __launch_bounds__(64 * NW, (WGLOBAL && T <= 4) ? 2 : 1) void grad_kernel(GradArgs a) {
   constexpr int HP = 16 * T;
   constexpr int Hh = (D + 1) / 2;
   constexpr bool GEF = ARCH == CMCD_ARCH_GEFFNER;
@@ -117,7 +118,9 @@ __global__ __launch_bounds__(64 * NW) void grad_kernel(GradArgs a) {
   // TILE_LOCAL (the 132-wide net, r02): da1 / du1 are consumed by this wave's own products right where they are formed,
   // 16 hidden units at a time through two 1 KB buffers, instead of being staged whole (2 x 9 KB per wave): 50 -> 33.5 KB
   // of staging per wave, so FOUR waves fit a CU's LDS instead of three (the fourth SIMD used to idle).
-  constexpr bool TILE_LOCAL = T > 4;
+  // (r04) the work-item instances of the narrow 2-d nets take the same staging AND stream W2 from L2: 69 KB per workgroup
+  // instead of 125, so that two share a CU (CMCD_GRAD_SMALL; the 2nd-order sweep gained 1.3x from exactly that)
+  constexpr bool TILE_LOCAL = T > 4 || WGLOBAL;
   constexpr int OWNBUF = TILE_LOCAL ? 256 : HP * 16;
   constexpr int OFF_DOT = 3 * HP * 16 + 2 * OWNBUF + 256;
   constexpr int STG = 3 * HP * 16 + 2 * OWNBUF + 512 + (D + 1) * HP;
@@ -1477,22 +1480,30 @@ __global__ __launch_bounds__(256) void grad_dds_tail_sum_kernel(TailArgs a) {
 }
 
 typedef void (*grad_fn)(GradArgs);
+#ifndef CMCD_GRAD_SMALL
+#define CMCD_GRAD_SMALL 1
+#endif
+constexpr bool kGradSmall = CMCD_GRAD_SMALL != 0;   // work items of the narrow 2-d nets: L2-streamed W2 + tile-local staging
+#ifndef CMCD_GRAD_SMALL_CHAIN
+#define CMCD_GRAD_SMALL_CHAIN 1
+#endif
+constexpr bool kGradSmallChain = CMCD_GRAD_SMALL_CHAIN != 0;   // ... and the whole-chain instances too
 
 static int grad_nw(int T) { (void)T; return 4; }   // (r02: the 132-wide net too — its staging shrank to 33.5 KB per wave)
 
 template <bool BPTT, bool ITEM>
 static grad_fn pick_grad_t(const cmcd_desc& d, int T) {
   if (d.arch == CMCD_ARCH_DDS && T == 4) {
-    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_DDS, 2, 4, 4, false, BPTT, ITEM>;
-    if (d.target == CMCD_TARGET_GMM && d.dim == 2) return grad_kernel<CMCD_TARGET_GMM, CMCD_ARCH_DDS, 2, 4, 4, false, BPTT, ITEM>;
+    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_DDS, 2, 4, 4, (ITEM ? kGradSmall : kGradSmallChain), BPTT, ITEM>;
+    if (d.target == CMCD_TARGET_GMM && d.dim == 2) return grad_kernel<CMCD_TARGET_GMM, CMCD_ARCH_DDS, 2, 4, 4, (ITEM ? kGradSmall : kGradSmallChain), BPTT, ITEM>;
     if (d.target == CMCD_TARGET_FUNNEL && d.dim == 10) return grad_kernel<CMCD_TARGET_FUNNEL, CMCD_ARCH_DDS, 10, 4, 4, false, BPTT, ITEM>;
     return nullptr;
   }
   if (d.arch == CMCD_ARCH_GEFFNER) {
-    if (d.target == CMCD_TARGET_GMM && d.dim == 2 && T == 2) return grad_kernel<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER, 2, 2, 4, false, BPTT, ITEM>;
-    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 2) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 2, 4, false, BPTT, ITEM>;
-    if (d.target == CMCD_TARGET_GMM && d.dim == 2 && T == 4) return grad_kernel<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER, 2, 4, 4, false, BPTT, ITEM>;
-    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 4) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 4, 4, false, BPTT, ITEM>;
+    if (d.target == CMCD_TARGET_GMM && d.dim == 2 && T == 2) return grad_kernel<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER, 2, 2, 4, (ITEM ? kGradSmall : kGradSmallChain), BPTT, ITEM>;
+    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 2) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 2, 4, (ITEM ? kGradSmall : kGradSmallChain), BPTT, ITEM>;
+    if (d.target == CMCD_TARGET_GMM && d.dim == 2 && T == 4) return grad_kernel<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER, 2, 4, 4, (ITEM ? kGradSmall : kGradSmallChain), BPTT, ITEM>;
+    if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 4) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 4, 4, (ITEM ? kGradSmall : kGradSmallChain), BPTT, ITEM>;
     if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2 && T == 9) return grad_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 9, 4, true, BPTT, ITEM>;
     if (d.target == CMCD_TARGET_GMM && d.dim == 2 && T == 9) return grad_kernel<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER, 2, 9, 4, true, BPTT, ITEM>;
     if (d.target == CMCD_TARGET_FUNNEL && d.dim == 10 && T == 4) return grad_kernel<CMCD_TARGET_FUNNEL, CMCD_ARCH_GEFFNER, 10, 4, 4, false, BPTT, ITEM>;
@@ -1615,9 +1626,9 @@ static int64_t grad_det_floats(const cmcd_desc& d, int HP, int64_t n) {
   return f <= kDetCapFloats ? f : 0;
 }
 
-static int grad_nslabs(int64_t n, int nw) {
+static int grad_nslabs(int64_t n, int nw, int max_slabs) {
   const int64_t nquads = (n + 16 * nw - 1) / (16 * nw);
-  return (int)(nquads < 256 ? nquads : 256);
+  return (int)(nquads < max_slabs ? nquads : max_slabs);
 }
 
 int64_t grad_workspace_floats(const cmcd_desc& d, int HP, int64_t n) {
@@ -1625,7 +1636,7 @@ int64_t grad_workspace_floats(const cmcd_desc& d, int HP, int64_t n) {
   grad_offsets(d, HP, oS, oS2, ob, oe, ov, of, tot);
   const int64_t slab = (int64_t)HP * HP + HP * 16 + 4 * (2 * 16 * HP + 256 + 32);
   // up to one slab per workgroup of a full-chip launch (either path), then the fixed-order slots
-  return tot + grad_tail_floats(d) + slab * 256 + grad_det_floats(d, HP, n);
+  return tot + grad_tail_floats(d) + slab * 512 + grad_det_floats(d, HP, n);
 }
 
 // ws_fwd: the forward workspace as left by cmcd_bound_forward's prep on the SAME desc/params;
@@ -1646,7 +1657,9 @@ int grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, c
   const int64_t ntiles = (n + 15) / 16;
   const int64_t nitems = ntiles * (K + 1);
   const int64_t n_outer = (nitems + nw - 1) / nw;
-  const int nslabs = item ? (int)(n_outer < 256 ? n_outer : 256) : grad_nslabs(n, nw);
+  const bool small = (item ? kGradSmall : kGradSmallChain) && D == 2 && w.T <= 4;   // two workgroups per CU: twice the slabs
+  const int max_slabs = small ? 512 : 256;
+  const int nslabs = item ? (int)(n_outer < max_slabs ? n_outer : max_slabs) : grad_nslabs(n, nw, max_slabs);
   ga.seeds = seeds; ga.params = params; ga.ws = ws_fwd; ga.omega = omega; ga.omega_scalar = omega_scalar; ga.traj = traj; ga.gtab = gws; ga.slabs = gws + tot + grad_tail_floats(d);
   ga.lay = lay; ga.w = w; ga.n = n; ga.K = K; ga.var_mode = d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0;
   ga.grad_clipping = d.grad_clipping; ga.nquads = (int)((n + 16 * nw - 1) / (16 * nw));
@@ -1655,7 +1668,7 @@ int grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, c
   ga.slab_stride = (int64_t)HP * HP + HP * 16 + 4 * (2 * 16 * HP + 256 + 32);
   const bool det = grad_det_floats(d, HP, n) > 0 && !grad_atomics_forced();
   if (det) {
-    ga.det = gws + tot + grad_tail_floats(d) + ga.slab_stride * 256;
+    ga.det = gws + tot + grad_tail_floats(d) + ga.slab_stride * 512;
     ga.det_tile_stride = grad_det_tile_floats(d, HP);
     ga.det_tiles = ntiles;
     ga.det_obe = ga.det_tile_stride - (int64_t)(K + 1) * 4;
@@ -1674,9 +1687,10 @@ int grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, c
     if (hipMemsetAsync(grad, 0, sizeof(float) * n_params, stream) != hipSuccess) return CMCD_ERR_HIP;
   }
 
-  const size_t stg = w.T > 4 ? size_t(3 * HP * 16 + 2 * 256 + 512 + (D + 1) * HP) : size_t((5 * HP + 32) * 16 + (D + 1) * HP);
+  const bool tile_local = w.T > 4 || small;
+  const size_t stg = tile_local ? size_t(3 * HP * 16 + 2 * 256 + 512 + (D + 1) * HP) : size_t((5 * HP + 32) * 16 + (D + 1) * HP);
   const size_t wsh = 0;   // (the shared fragment rows of the rejected WSHARE experiment would need 2 * T * 256 floats)
-  const size_t lds_bytes = size_t((w.T > 4 ? 0 : 2 * HP * HP) + 2 * D * HP + HP + 16 + w.tgt_floats + wsh + nw * stg) * 4;
+  const size_t lds_bytes = size_t((tile_local ? 0 : 2 * HP * HP) + 2 * D * HP + HP + 16 + w.tgt_floats + wsh + nw * stg) * 4;
   if (lds_bytes > 160 * 1024) return CMCD_ERR_UNSUPPORTED;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)lds_bytes) != hipSuccess)

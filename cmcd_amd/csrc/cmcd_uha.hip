@@ -1232,7 +1232,10 @@ template <int TARGET, int ARCH, int D, int T, int NW, bool WGLOBAL, bool JAC = f
 // at two (241 registers, so that the second workgroup a CU's LDS has room for is really resident) measured 606 against 592 us
 // with one: on gfx950 an fp32 MFMA and the VALU work of the SIMD's other wave do not overlap (tools/probes/mfma_valu_probe.hip),
 // so a second wave only fills the stalls, and these are not what bounds the sweep ("the floor").
-__global__ __launch_bounds__(64 * NW, (D == 2 && JAC) ? 3 : 1) void uha_grad_kernel(UhaGradArgs a) {
+#ifndef UHA_SWEEP_WAVES
+#define UHA_SWEEP_WAVES 1
+#endif
+__global__ __launch_bounds__(64 * NW, (D == 2 && JAC) ? 3 : ((D == 2 && WGLOBAL && T <= 4) ? UHA_SWEEP_WAVES : 1)) void uha_grad_kernel(UhaGradArgs a) {
   constexpr int HP = 16 * T;
   constexpr int DIN = 2 * D;
   constexpr int S_JAC = 3 * D * D + 3 * D;     // floats per (point, particle) of the Jacobian launch, see uha_scan_kernel
@@ -2589,7 +2592,20 @@ int uha_grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& 
     hipLaunchKernelGGL(ifn, dim3(nslabs_used), dim3(64 * nw), ilds, stream, ga);
   } else {
     ga.xdump = g_uha_xdump;
-    hipLaunchKernelGGL(fn, dim3(nslabs_used), dim3(64 * nw), lds_bytes, stream, ga);
+    // (r04) whole chains of the 2-d targets run on the work-item path's instance too — W2 streamed from L2, 73 KB of LDS, two
+    // workgroups per CU on up to 512 slabs (the narrow nets' LDS-resident W2 made it 105 KB and one)
+#ifndef UHA_SMALL_CHAIN
+#define UHA_SMALL_CHAIN 1
+#endif
+    uha_grad_fn cfn = (UHA_SMALL_CHAIN && D == 2) ? uha_item_pick(d, w.T) : nullptr;
+    if (cfn) {
+      const size_t clds = size_t(DIN * HP + D * HP + HP + 16 + w.tgt_floats + nw * stg) * 4;
+      if (!ensure_dynamic_lds(reinterpret_cast<const void*>(cfn), clds)) return CMCD_ERR_HIP;
+      nslabs_used = (int)(nquads < kUhaSlabs ? nquads : kUhaSlabs);
+      hipLaunchKernelGGL(cfn, dim3(nslabs_used), dim3(64 * nw), clds, stream, ga);
+    } else {
+      hipLaunchKernelGGL(fn, dim3(nslabs_used), dim3(64 * nw), lds_bytes, stream, ga);
+    }
   }
 
   {

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 for v in "$@"; do
   if [ "$v" = product ]; then unset CMCD_LIB_PATH; else export CMCD_LIB_PATH=$PWD/cmcd_amd/libcmcd_hip_$v.so; fi
   rm -rf $O/prof_$v
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$v -- python3 tools/probes/uha_run.py 2000 manyonly > $O/times_$v.json 2>/dev/null || { echo "$v failed"; continue; }
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$v -- python3 tools/probes/uha_run.py ${N:-2000} manyonly > $O/times_$v.json 2>/dev/null || { echo "$v failed"; continue; }
   f=$(find $O/prof_$v -name "*kernel_stats.csv" | head -1)
   python3 -c "
 import csv, sys
