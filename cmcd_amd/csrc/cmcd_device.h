@@ -356,7 +356,11 @@ struct Target<CMCD_TARGET_MANY_GMM, 2> {
   // The cooperative kernel's target waves when n_mixes == 40 (decided once per launch): no per-bridge read of the
   // header, no mixture-size branches; the same arithmetic as pass1r / pass2 (min over non-negative distances taken on
   // the bit patterns: identical value).
-  template <int LP>
+  // EARLY (r04, the 2nd-order forward: 314 -> 306 us; the overdamped cooperative kernel measured 182.6 -> 183.8 with it and
+  // keeps the r03 split): the exponents' scale and the reduction of the extremum move to the distance pass, so that the
+  // exponential pass opens with the exponentials.  d2 then holds c2 d^2 <= 0 (sign bit set: the unsigned minimum of the bit
+  // patterns is the value of smallest magnitude, i.e. the maximum).
+  template <int LP, bool EARLY = false>
   __device__ static __forceinline__ void pass1f(const float (&z)[2], int sub, const Means& m, State& st) {
     constexpr int kQ = (kFastMix + LP - 1) / LP;
     constexpr bool kRagged = kFastMix % LP != 0;
@@ -367,20 +371,26 @@ struct Target<CMCD_TARGET_MANY_GMM, 2> {
       st.dy[q] = z[1] - m.my[q];
       const float d2 = fmaf(st.dx[q], st.dx[q], st.dy[q] * st.dy[q]);
       st.d2[q] = (!kRagged || sub + LP * q < kFastMix) ? d2 : INFINITY;
-      dmin = q == 0 ? st.d2[q] : fminf(dmin, st.d2[q]);
+      if constexpr (EARLY) {
+        st.d2[q] *= m.c2;
+        dmin = q == 0 ? st.d2[q] : __uint_as_float(min(__float_as_uint(dmin), __float_as_uint(st.d2[q])));
+      } else {
+        dmin = q == 0 ? st.d2[q] : fminf(dmin, st.d2[q]);
+      }
     }
-    st.dmin = dmin;
+    if constexpr (EARLY) st.dmin = part_min_nonneg<LP>(dmin);
+    else st.dmin = dmin;
   }
-  template <int LP>
+  template <int LP, bool EARLY = false>
   __device__ static __forceinline__ void pass2f(const float (&z)[2], int sub, const Means& m, const State& st,
                                                 float& logp, float (&grad)[2]) {
     constexpr int kQ = (kFastMix + LP - 1) / LP;
     const float inv_s = m.inv_s, c2 = m.c2, c0 = m.c0;
-    const float dmin = part_min_nonneg<LP>(st.dmin);
+    const float dmin = EARLY ? st.dmin : part_min_nonneg<LP>(st.dmin);
     float s = 0.f, sx = 0.f, sy = 0.f;
 #pragma unroll
     for (int q = 0; q < kQ; ++q) {
-      const float e = __builtin_amdgcn_exp2f(c2 * (st.d2[q] - dmin));
+      const float e = __builtin_amdgcn_exp2f(EARLY ? st.d2[q] - dmin : c2 * (st.d2[q] - dmin));
       s += e;
       sx = fmaf(e, st.dx[q], sx);
       sy = fmaf(e, st.dy[q], sy);
@@ -388,7 +398,7 @@ struct Target<CMCD_TARGET_MANY_GMM, 2> {
     s = part_sum<LP>(s);
     sx = part_sum<LP>(sx);
     sy = part_sum<LP>(sy);
-    const float lp = 0.69314718055994530942f * (fmaf(c2, dmin, c0) + __builtin_amdgcn_logf(s));
+    const float lp = 0.69314718055994530942f * ((EARLY ? dmin + c0 : fmaf(c2, dmin, c0)) + __builtin_amdgcn_logf(s));
     const bool valid = lp > -1e4f;  // model_handler.py:279-280
     const float sc = -(inv_s * inv_s) * __builtin_amdgcn_rcpf(s);
     logp = valid ? lp : -INFINITY;
@@ -525,9 +535,9 @@ struct Target<CMCD_TARGET_GMM, 2> {
   __device__ static __forceinline__ void load_means(int, const float*, Means&) {}
   static constexpr bool kHasFast = false;
   __device__ static __forceinline__ bool is_fast(const Means&) { return false; }
-  template <int LP>
+  template <int LP, bool EARLY = false>
   __device__ static __forceinline__ void pass1f(const float (&)[2], int, const Means&, State&) {}
-  template <int LP>
+  template <int LP, bool EARLY = false>
   __device__ static __forceinline__ void pass2f(const float (&)[2], int, const Means&, const State&, float&, float (&)[2]) {}
   template <int LP>
   __device__ static __forceinline__ void pass1r(const float (&)[2], int, const float*, const Means&, State&) {}
@@ -609,9 +619,9 @@ struct Target<CMCD_TARGET_FUNNEL, D> {
   __device__ static __forceinline__ void load_means(int, const float*, Means&) {}
   static constexpr bool kHasFast = false;
   __device__ static __forceinline__ bool is_fast(const Means&) { return false; }
-  template <int LP>
+  template <int LP, bool EARLY = false>
   __device__ static __forceinline__ void pass1f(const float (&)[D], int, const Means&, State&) {}
-  template <int LP>
+  template <int LP, bool EARLY = false>
   __device__ static __forceinline__ void pass2f(const float (&)[D], int, const Means&, const State&, float&, float (&)[D]) {}
   template <int LP>
   __device__ static __forceinline__ void pass1r(const float (&)[D], int, const float*, const Means&, State&) {}

@@ -990,12 +990,12 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
     }
     cl_eta = q.eta; cl_inv2s2 = q.inv2s2; cl_cst = q.cst; cl_fk = fk_lp;
     typename Tg::State tst;
-    if (tfast) Tg::template pass1f<LP>(z, sub, means, tst);
+    if (tfast) Tg::template pass1f<LP, true>(z, sub, means, tst);
     else Tg::template pass1r<LP>(z, sub, lds_tgt, means, tst);
     USTAMP(6); uha_lds_barrier(); USTAMP(7);
     // ------------------------------------------------------------------ pass 1, matrix interval: exponential pass, second half
     //                                                                    step -> the NEXT bridge's input (it does not need s)
-    if (tfast) Tg::template pass2f<LP>(z, sub, means, tst, logp, gp);
+    if (tfast) Tg::template pass2f<LP, true>(z, sub, means, tst, logp, gp);
     else Tg::template pass2<LP>(z, sub, lds_tgt, tst, logp, gp);
 #pragma unroll
     for (int j = 0; j < D; ++j) {

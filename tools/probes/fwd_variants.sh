@@ -1,0 +1,20 @@
+#!/bin/bash
+# the headline forward kernel's time (rocprofv3 --kernel-trace --stats over bench.py's forward legs) for library variants
+# usage: bash tools/probes/fwd_variants.sh <tag> <variant> [...]   ("product" = cmcd_amd/libcmcd_hip.so)
+O=gpurun_out/$1; shift
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+for v in "$@"; do
+  if [ "$v" = product ]; then unset CMCD_LIB_PATH; else export CMCD_LIB_PATH=$PWD/cmcd_amd/libcmcd_hip_$v.so; fi
+  rm -rf $O/prof_$v
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$v -- python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline --saturated 0 --forward-only > $O/bench_$v.json 2>/dev/null || { echo "$v failed"; continue; }
+  f=$(find $O/prof_$v -name "*kernel_stats.csv" | head -1)
+  python3 -c "
+import csv, sys
+out = []
+for r in csv.reader(open(sys.argv[1])):
+    if 'coop_kernel' in r[0] or 'prep_fused' in r[0] or 'finalize' in r[0]:
+        out.append('%s %.2f us x%s' % (r[0].split('(')[0][-36:], float(r[3]) / 1000, r[1]))
+print(sys.argv[2] + ': ' + ' | '.join(out))" $f $v
+  rm -rf $O/prof_$v
+done
