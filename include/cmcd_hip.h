@@ -163,8 +163,9 @@ int cmcd_bound_forward_prepared(const cmcd_desc* desc, const cmcd_layout* lay,
 
 /* ---- Measurement and diagnostic hooks: NOT part of the product path.  Nothing a result depends on goes through them;
  * they exist for bench.py (kernel time, kernel name) and the PRNG parity test, are per host thread, and a deployment can
- * leave them unbound.  (The library reads ONE environment variable, CMCD_COOP_PRIO, once per process, for the probes under
- * tools/probes.  CMCD_GRAD_ITEM is NOT read by the library: only the Python binding forwards it, through
+ * leave them unbound.  (The library reads TWO environment variables, once per process, for the probes under tools/probes:
+ * CMCD_COOP_PRIO, and CMCD_GRAD_ATOMICS=1, which puts the overdamped gradients' sums over tiles back on the float atomics of
+ * rounds 1 - 3 — run-to-run differences in the last bits — for A / B timing.  CMCD_GRAD_ITEM is NOT read by the library: only the Python binding forwards it, through
  * cmcd_debug_grad_item below — a C caller that sets the variable gets the measured batch-size rule.) */
 
 /* Name of the trajectory kernel (or launch sequence) the last cmcd_bound_forward of this host thread enqueued, e.g.
@@ -241,7 +242,12 @@ int cmcd_bound_var_grad_kept(const cmcd_desc* desc, const cmcd_layout* layout, c
  * omega = d value / d loss_n = 1 / N_total (across ranks: all-reduce(sum) of grad).
  * Also MCD_ULA_sn and MCD_ULA (/root/reference/src/mcd_over_orig.py), on every target.
  * Targets gmm / funnel / many_gmm with the BASELINE nets (dds 64; geffner widths up to 144 on the 2-d targets,
- * 64 on funnel), and lgcp (geffner, any width: launch-sequence reverse sweep); CMCD_ERR_UNSUPPORTED otherwise. */
+ * 64 on funnel), and lgcp (geffner, any width: launch-sequence reverse sweep); CMCD_ERR_UNSUPPORTED otherwise.
+ * Repeated calls with the same arguments return the same bits (r04): every sum over particles is taken in a fixed order
+ * — per-tile slots + a reduction launch; the workspace holds the slots — for gmm / funnel / many_gmm in every mode, up to a
+ * slot table of 128 MB (about 30 000 particles at K = 256 with the 64-wide dds net, 870 000 at K = 8); above it the overdamped modes'
+ * bias-row and schedule sums fall back to float atomics and the last bits may differ from call to call.  (The
+ * reference's own gradients are XLA reductions: deterministic on one device.) */
 int64_t cmcd_bound_grad_workspace_bytes(const cmcd_desc* desc, int64_t n);
 int cmcd_bound_grad(const cmcd_desc* desc, const cmcd_layout* layout, const int32_t* seeds, int64_t n,
                     const float* params, int64_t n_params, const float* target_consts, int64_t n_target,
