@@ -222,3 +222,50 @@ def test_no_split_k_gemm_issues_all_its_loads_before_the_first_matrix_instructio
     first_s = next(i for i, l in enumerate(body_s) if "v_mfma_f32_16x16x4_f32" in l)
     pre = [int(m.group(1)) for l in body_s[:first_s] for m in [re.search(r"vmcnt\((\d+)\)", l)] if m]
     assert any(v >= 26 for v in pre), pre
+
+
+# ------------------------------------------------------------------------------------------ r04: the gradient kernels
+@pytest.fixture(scope="module")
+def grad_asm(tmp_path_factory):
+    from cmcd_amd import build
+    return _asm(tmp_path_factory, "cmcd_grad.hip", build.EXTRA_FLAGS.get("cmcd_grad.hip", []))
+
+
+def _total_vgprs(tail):
+    return int(next(l for l in tail if "TotalNumVgprs:" in l).split(":")[1].split()[0])
+
+
+# many_gmm (2), dds (1), D = 2, T = 4, 4 waves, W2 streamed, reparameterised / VarGrad, work items and whole chains
+NARROW_GRAD = ["_ZN4cmcd11grad_kernelILi2ELi1ELi2ELi4ELi4ELb1ELb%dELb%dEEEvNS_8GradArgsE" % (b, i) for b in (0, 1) for i in (0, 1)]
+
+
+@pytest.mark.parametrize("kern", NARROW_GRAD, ids=["vargrad_chains", "vargrad_items", "reparam_chains", "reparam_items"])
+def test_narrow_gradient_instances_fit_two_workgroups_per_cu(grad_asm, kern):
+    """r04: the narrow 2-d instances stream W2 from L2 and stage tile-locally so that two workgroups share a CU (69 KB of LDS
+    each, requested at launch) — which only happens if a wave also stays within half the register file, without scratch
+    (244.7 against 318.7 us for the named shape's reparameterised sweep, profiles/r04_grad_two_workgroups_per_cu.txt)."""
+    body, tail = _kernel(grad_asm, kern)
+    assert _scratch(tail) == 0
+    assert _total_vgprs(tail) <= 256, "VGPRs + AGPRs past half the register file: one wave per SIMD"
+    # the staged weight tiles of the LDS-resident form are gone: no ds_read of W2 fragments ahead of the layer-2 products means
+    # the fragments come through global loads
+    assert sum("global_load_dwordx4" in l for l in body) >= 8
+
+
+def test_gradient_table_sums_have_a_store_path(grad_asm):
+    """r04: the bias-row / schedule sums over tiles are per-tile slot stores + a fixed-order reduction launch; the float
+    atomics of rounds 1 - 3 survive as the fallback for slot tables past 128 MB only (both paths are in the instance)."""
+    body, _ = _kernel(grad_asm, NARROW_GRAD[3])
+    assert any("global_store_dword" in l for l in body)
+    assert any(l.startswith("_ZN4cmcd22grad_det_reduce_kernelENS_7DetArgsE") for l in grad_asm)
+    red, tail = _kernel(grad_asm, "_ZN4cmcd22grad_det_reduce_kernelENS_7DetArgsE")
+    assert not any("atomic" in l for l in red)
+    assert _scratch(tail) == 0
+
+
+def test_second_order_sweep_has_no_float_atomics(uha_asm):
+    """r04: the 2nd-order sweep's shared-table sums are slot stores only (cmcd_uha.hip: UhaGradArgs::det)."""
+    body, tail = _kernel_whole(uha_asm, "_ZN4cmcd15uha_grad_kernelILi2ELi1ELi2ELi4ELi4ELb1ELb0EEEvNS_11UhaGradArgsE")
+    assert not any("global_atomic_add_f32" in l for l in body)
+    scratch = next(l for l in tail if "ScratchSize" in l)
+    assert re.search(r"ScratchSize:\s*0\b", scratch), scratch
