@@ -79,6 +79,31 @@ def stored_traffic(key):
     return None, None
 
 
+def stored_issue_occupancy(key):
+    """Issue-slot occupancy of the kernel's SIMDs from the same stored PMC passes (sha-matched like stored_traffic):
+    on gfx950 an fp32 matrix instruction and fp32 VALU work of a SIMD do not overlap (profiles/r04_mfma_valu_overlap_probe.txt),
+    so (matrix busy cycles + VALU active cycles) / (SIMDs x launch duration) is the fraction of the launch in which a SIMD issued
+    arithmetic at all — the bound a latency chain like this one is held against, beside the matrix-peak fraction."""
+    for rnd in ("r04_pmc",):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", rnd, "summary.json")))
+        except Exception:
+            continue
+        d = pmc.get(key)
+        if pmc.get("kernel_sources_sha") != kernel_sources_sha() or not d:
+            continue
+        try:
+            simd_cycles = d["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0          # the counter sums the 8 XCDs; 256 CUs x 4 SIMDs
+            mfma = d["SQ_VALU_MFMA_BUSY_CYCLES"]
+            valu = 4.0 * (d["SQ_ACTIVE_INST_VALU"] - d["SQ_INSTS_MFMA"])   # quad-cycles -> cycles; matrix issues counted once
+            return {"mfma_busy_frac": mfma / simd_cycles, "valu_active_frac": valu / simd_cycles,
+                    "frac": (mfma + valu) / simd_cycles, "wait_any_frac": d["SQ_WAIT_ANY"] / d["SQ_WAVE_CYCLES"],
+                    "source": f"profiles/{rnd}/summary.json (kernel sources {kernel_sources_sha()})"}
+        except Exception:
+            return None
+    return None
+
+
 def flops_per_particle_step(cfg, dim, width):
     """Algorithmic work of one particle-bridge-step AFTER the two value-preserving restructurings of
     DESIGN.md (one net + one target-gradient evaluation per step; time path folded into a per-step
@@ -566,7 +591,8 @@ def main():
                      "kernel": hl["kernel"], "kernel_ms": kern_s * 1e3, "launches": launches,
                      "flop_per_particle_step": f_alg, "flop_per_particle_step_survey": f_survey,
                      "achieved_survey_flops": n * K * f_survey / kern_s / 1e12,
-                     "state_bytes_gbs": n * K * (8 * dim + 8) / kern_s / 1e9},
+                     "state_bytes_gbs": n * K * (8 * dim + 8) / kern_s / 1e9,
+                     "issue_occupancy": stored_issue_occupancy("coop_kernel") if traffic is not None else None},
         "elbo": hl["elbo"], "ln_z": hl["ln_z"], "n_finite": hl["n_finite"],
         "legs": legs,
     }

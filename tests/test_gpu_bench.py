@@ -31,6 +31,11 @@ def test_bench_single_gpu_line(hip_lib):
     assert r["n_gpus"] == 1 and r["steps"] == 3 and r["scaling"] == "weak" and r["value"] > 1e8 and r["headline_leg"] == "weak"
     assert "torch_cpu_all_cores" not in json.dumps(r)
     assert r["roofline"]["frac"] > 0 and r["config"]["workload"] == "many_gmm_n2000_k256_dds"
+    # PMC-derived figures are reported for the build they were measured on only (sha of the kernel sources), never as current
+    occ = r["roofline"]["issue_occupancy"]
+    assert (occ is None) == (r["roofline"]["traffic"] is None)
+    if occ is not None:
+        assert 0.0 < occ["mfma_busy_frac"] < occ["frac"] < 1.0
     # the N = 1 points of the scaling legs ride in the same line
     legs = r["legs"]
     assert set(legs) == {"weak", "strong_named", "strong_sharded_cfg4"}
