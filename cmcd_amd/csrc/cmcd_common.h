@@ -101,7 +101,7 @@ int64_t lgcp_workspace_floats(const cmcd_desc& d, int64_t n, int64_t base);
 // of the same parameters — those launches are skipped (the per-call zeroing of the operands is not)
 int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, const int32_t* seeds, int64_t n,
                  const float* params, const float* tc, float* ws, float* out_loss, float* out_z,
-                 double** partials_out, float* traj, void* stream, bool tables_ready = false);
+                 double** partials_out, float* traj, void* stream, bool tables_ready = false, float* keep_gws = nullptr);
 // cmcd_lgcp_wide.hip: forward-only calls on wide batches (>= kLgcpWideMin particles): whole-batch launches of a real fp32
 // GEMM body (32 x 128 tiles over the whole contraction, no split-K seam) instead of 32-row weight-streaming passes
 constexpr int64_t kLgcpWideMin = 224;   // measured crossover against the 32-row passes on four lanes (profiles/r04_e_lgcp_crossover.txt: 13.2 vs 13.4 ms at 224)

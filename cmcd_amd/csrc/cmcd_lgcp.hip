@@ -132,6 +132,7 @@ struct LgcpAdjArgs {
   const uint32_t* gktab;     // [K][n][2] noise keys of the forward pass (VarGrad: z_{e+1} - mean = sigma eps_e, exactly)
   int ula;                   // 0: CAIS; 1: MCD_ULA (no network); 2: MCD_ULA_sn (network in the backward kernel only)
   int bptt;                  // 1: gradient through the trajectory (lambda recursion); 0: z detached (mcd_cais_var.py:59,79)
+  int nslab = kSplit;        // slabs of kr / sn to sum: kSplit (recomputed by the split-K GEMM) or 1 (kept by the forward)
   int var_mode;              // MCD_CAIS_var_sn: clip at 1e2 and clip grad log q too (mcd_cais_var.py:29-36)
 };
 
@@ -197,6 +198,7 @@ __device__ __forceinline__ void lgcp_adj_elem(const LgcpAdjArgs& a, int p, int j
     float kr = 0.f, o = no_net ? 0.f : a.b3[j];
 #pragma unroll
     for (int ks = 0; ks < kSplit; ++ks) {
+      if (ks >= a.nslab) break;            // (1: the forward's kept sums; kSplit: the recompute's slabs)
       kr += a.kr[((int64_t)ks * kMP + p) * D + j];
       o += no_net ? 0.f : a.sn[((int64_t)ks * kMP + p) * D + j];
     }
@@ -594,7 +596,7 @@ __global__ __launch_bounds__(64 * (kGemmWaves + ((EPI == EPI_STEP || EPI == EPI_
         ab.du_out[m * ab.IN + k] = du[r];
         ab.da_out[m * ab.IN + k] = da;
         ab.da_big[(ab.row0 + m) * ab.IN + k] = da;
-        ab.u_big[(ab.row0 + m) * ab.IN + k] = us[r];
+        if (ab.u_big) ab.u_big[(ab.row0 + m) * ab.IN + k] = us[r];   // (nullptr: the forward kept u in that very table)
         sda += da; sdu += du[r];
       }
     }
@@ -692,6 +694,13 @@ struct NskArgs {
   const float* krA;    // STEP: the K^-1 product of this evaluation (launch B)
   float* krOut;        // KR (packed, the overdamped sequence)
   float* krOutN = nullptr;   // KR, row-major [kMP][N] (the 2nd-order sequence's element-wise kernels read it)
+  // r04: what the reverse sweep of the gradient used to RECOMPUTE per evaluation, kept by the forward's consumers instead —
+  // row-major [M][N] blocks of this evaluation and pass inside [(K+1) n][N] tables of the gradient workspace (nullptr: no keep):
+  // keepPre / keepU the ACT segment's pre-activation and output, keepKr the K^-1 product, keepSn the raw u2 W3 product
+  float* keepPre = nullptr;
+  float* keepU = nullptr;
+  float* keepKr = nullptr;
+  float* keepSn = nullptr;
   // NSK_UHA_MID: F1 of the 2nd-order sequence (momentum refresh + half kick + drift, mcd_under_lp_a_cais.py:52-63) as the
   // consumer of its launch L3 (u2 W3)
   struct UhaMid {
@@ -821,6 +830,8 @@ __device__ __forceinline__ void nsk_step_post(const NskArgs& a, const NskStepPre
       a.xnA[t.ix] = zn;
       if (s.traj) s.traj[((int64_t)(i + 1) * s.n_total + s.base + m) * D + e] = zn;
     }
+    if (NO_NET) { if (a.keepKr) a.keepKr[(int64_t)m * D + e] = o; }
+    else if (a.keepSn) a.keepSn[(int64_t)m * D + e] = o;        // the raw product: the sweep adds b3 and the factor itself
   }
   // per-row partial log-weights over the tile's 16 columns: the 16 lanes that share the row, fixed butterfly
   float bk_lp = live ? bk_acc : 0.f, fk_lp = live ? fk_acc : 0.f, lp = live ? lp_acc : 0.f;
@@ -1033,8 +1044,14 @@ __global__ __launch_bounds__(64 * kGemmWaves, (KIND || MERGED) ? 2 : 4) void lgc
     if (a.outN && sg.epi == NSK_OUT) a.outN[(int64_t)row * sg.N + n] = v;
     else if (a.krOutN) a.krOutN[(int64_t)row * sg.N + n] = v;
     else a.krOut[nsk_pack(row, n)] = v;
+    if (sg.epi == NSK_KR && a.keepKr) a.keepKr[(int64_t)row * sg.N + n] = v;
   } else {
-    a.outA[cix] = cu + softplus(v + cb);                       // nn.py:45-50
+    const float pre = v + cb, u = cu + softplus(pre);          // nn.py:45-50
+    a.outA[cix] = u;
+    if (a.keepPre) {
+      a.keepPre[(int64_t)row * sg.N + n] = pre;
+      a.keepU[(int64_t)row * sg.N + n] = u;
+    }
   }
 }
 
@@ -1319,9 +1336,15 @@ static int lgcp_gemm_attrs() {
   return gemm_lds;
 }
 
+// r04: tables of the gradient workspace that the forward's consumers fill when it runs for a gradient call (lgcp_keep below
+// lgcp_grad_ws): [(K+1) n][IN] pre1, u1, pre2, u2 and [(K+1) n][D] kr, sn.  `on` is false when the forward does not run on the
+// no-split-K GEMM or the tables would pass 1 GB: the reverse sweep then recomputes every evaluation as it did in r01 - r03.
+struct LgcpKeep { float *pre1, *u1, *pre2, *u2, *kr, *sn; bool on; };
+static LgcpKeep lgcp_keep(const cmcd_desc& d, int64_t n, float* gws);
+
 int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, const int32_t* seeds, int64_t n,
                  const float* params, const float* tc, float* ws, float* out_loss, float* out_z,
-                 double** partials_out, float* traj, void* stream_, bool tables_ready) {
+                 double** partials_out, float* traj, void* stream_, bool tables_ready, float* keep_gws) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (d.mode == CMCD_MODE_CAIS_UHA_SN)
     return lgcp_uha_forward(d, lay, sw, seeds, n, params, tc, ws, out_loss, out_z, partials_out, traj, stream);
@@ -1409,6 +1432,7 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
     if (hipMemsetAsync(counters[l], 0, sizeof(int) * (cbD + cbIN), st_l) != hipSuccess) return bail();
   }
   const int ula = d.mode == CMCD_MODE_ULA ? 1 : (d.mode == CMCD_MODE_ULA_SN ? 2 : 0);
+  const LgcpKeep keep = keep_gws ? lgcp_keep(d, n, keep_gws) : LgcpKeep{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, false};
   // groups of `lanes` passes; inside a group the launches are enqueued evaluation by evaluation, round-robin over the
   // lanes, so that the chains advance together (the same weights are in flight for all of them)
   for (int64_t gbase = 0; gbase < n; gbase += (int64_t)lanes * kMP) {
@@ -1484,22 +1508,29 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
               else hipLaunchKernelGGL((lgcp_nsk_kernel<0, false>), grid, gblock, 0, st_l, na);
             }
           };
+          // (gradient calls: this evaluation's rows of the kept tables)
+          const int64_t krow = (int64_t)i * n + gbase + (int64_t)l * kMP;
           if (ula == 1) {   // MCD_ULA: one launch per evaluation, (x - mu0) K^-1 with the state update as its consumer
             na.seg[0] = NskSeg{xA, ws + w.kip, D, NSK_STEP_NONET, mu0}; na.nt0 = tD;
+            if (keep.on) na.keepKr = keep.kr + krow * D;
             launch(true, tD);
             continue;
           }
           // A: x W1[:D] -> u1 = [x; emb_i] + softplus(. + bias1_i)
           na.seg[0] = NskSeg{xA, ws + w.w1p, IN, NSK_ACT1, 0.f}; na.nt0 = tIN;
           na.bias = ws + w.bias1 + (int64_t)it * IN; na.emb = params + lay.g_emb + (int64_t)ie * E; na.outA = u1A;
+          if (keep.on) { na.keepPre = keep.pre1 + krow * IN; na.keepU = keep.u1 + krow * IN; }
           launch(false, tIN);
           // B: u1 W2 -> u2 = u1 + softplus(. + b2)   |   (x - mu0) K^-1 -> kr
           na.seg[0] = NskSeg{u1A, ws + w.w2p, IN, NSK_ACT2, 0.f};
           na.seg[1] = NskSeg{xA, ws + w.kip, D, NSK_KR, mu0};
           na.bias = params + lay.g_b2; na.uA = u1A; na.outA = u2A;
+          if (keep.on) { na.keepPre = keep.pre2 + krow * IN; na.keepU = keep.u2 + krow * IN; na.keepKr = keep.kr + krow * D; }
           launch(false, tIN + tD, true);
           // C: u2 W3 -> the state update of evaluation i on the tile's elements
           na.seg[0] = NskSeg{u2A, ws + w.w3p, D, NSK_STEP, 0.f}; na.nt0 = tD;
+          na.keepPre = nullptr; na.keepU = nullptr; na.keepKr = nullptr;
+          if (keep.on) na.keepSn = keep.sn + krow * D;
           launch(true, tD);
           continue;
         }
@@ -1817,6 +1848,8 @@ struct LgcpGradWs {
   int64_t du2, du1, da2, da1;                  // [kMP][IN]
   int64_t gmu_acc, glam_acc;                   // [kMP][D]
   int64_t U1, U2, DA1, DA2;                    // [(K+1) n][IN]
+  int64_t kpre1, kpre2, kkr, ksn;              // [(K+1) n][IN] x 2, [(K+1) n][D] x 2: kept by the forward (lgcp_keep); 0 floats when off
+  bool keep;
   int64_t DO;                                  // [(K+1) n][D]
   int64_t S, S2, gbeta, geps, gfac, gb2;       // tables (gfac: [K+1] per-evaluation terms)
   int64_t adjpart, gb_lo, ge_lo, gb_hi, ge_hi; // adjoint step partial sums and their per-evaluation reductions
@@ -1852,8 +1885,18 @@ static LgcpGradWs lgcp_grad_ws(const cmcd_desc& d, int64_t n) {
   w.zero_hi = o;
   w.adjpart = take((K + 1) * n * ((D + 63) / 64) * 8);
   w.gb_lo = take(K + 1); w.ge_lo = take(K + 1); w.gb_hi = take(K + 1); w.ge_hi = take(K + 1);
+  // the forward's kept activations (behind everything else: the layout above does not move when they are off)
+  w.keep = lgcp_nsk_ok(d) && d.mode != CMCD_MODE_CAIS_UHA_SN && R * (2 * IN + 2 * D) <= (int64_t(1) << 28);
+  w.kpre1 = take(w.keep ? R * IN : 0); w.kpre2 = take(w.keep ? R * IN : 0);
+  w.kkr = take(w.keep ? R * D : 0); w.ksn = take(w.keep ? R * D : 0);
   w.total = o;
   return w;
+}
+
+static LgcpKeep lgcp_keep(const cmcd_desc& d, int64_t n, float* gws) {
+  const LgcpGradWs g = lgcp_grad_ws(d, n);
+  if (!g.keep) return LgcpKeep{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, false};
+  return LgcpKeep{gws + g.kpre1, gws + g.U1, gws + g.kpre2, gws + g.U2, gws + g.kkr, gws + g.ksn, true};
 }
 
 static int64_t lgcp_uha_grad_ws_total(const cmcd_desc& d, int64_t n);
@@ -1917,6 +1960,9 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
     }
     if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return CMCD_ERR_HIP;
   }
+  // r04: the forward kept pre1 / u1 / pre2 / u2 / kr / sn of every evaluation (lgcp_keep): nothing to recompute, one stream
+  const LgcpKeep keep = lgcp_keep(d, n, gws);
+  const bool kept = keep.on;
   // bias1 rows are still in the forward workspace (lgcp_forward's prep)
   for (int64_t base = 0; base < n; base += kMP) {
     const int M = (int)((n - base) < kMP ? (n - base) : kMP);
@@ -1924,7 +1970,7 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
       if (hipMemsetAsync(gws + g.lamn, 0, sizeof(float) * 2 * ((kMP * (int64_t)D + 3) & ~3), stream) != hipSuccess) return CMCD_ERR_HIP;
       if (hipMemsetAsync(gws + g.gmu_acc, 0, sizeof(float) * 2 * ((kMP * (int64_t)D + 3) & ~3), stream) != hipSuccess) return CMCD_ERR_HIP;
     }
-    if (hipEventRecord(ev_fork, stream) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess) return CMCD_ERR_HIP;
+    if (!kept && (hipEventRecord(ev_fork, stream) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess)) return CMCD_ERR_HIP;
 
     // forward recompute at z_e into buffer set e & 1, on stream st: the forward path's three launches (activations
     // fused into the GEMMs; the third has no consumer here: the adjoint step sums its slabs)
@@ -1961,22 +2007,34 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
       hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_NONE>, dim3(cbD, kSplit), gblock, gemm_lds, st, gm);
     };
 
-    forward_at(K, side);
-    if (hipEventRecord(ev_fwd[K & 1], side) != hipSuccess) return CMCD_ERR_HIP;
+    if (!kept) {
+      forward_at(K, side);
+      if (hipEventRecord(ev_fwd[K & 1], side) != hipSuccess) return CMCD_ERR_HIP;
+    }
     for (int e = K; e >= 0; --e) {
-      if (e > 0) {  // next evaluation's recompute: its buffer set was last read by the backward pass of e+1
-        if (e + 1 <= K && hipStreamWaitEvent(side, ev_bwd[(e - 1) & 1], 0) != hipSuccess) return CMCD_ERR_HIP;
-        forward_at(e - 1, side);
-        if (hipEventRecord(ev_fwd[(e - 1) & 1], side) != hipSuccess) return CMCD_ERR_HIP;
+      if (!kept) {
+        if (e > 0) {  // next evaluation's recompute: its buffer set was last read by the backward pass of e+1
+          if (e + 1 <= K && hipStreamWaitEvent(side, ev_bwd[(e - 1) & 1], 0) != hipSuccess) return CMCD_ERR_HIP;
+          forward_at(e - 1, side);
+          if (hipEventRecord(ev_fwd[(e - 1) & 1], side) != hipSuccess) return CMCD_ERR_HIP;
+        }
+        if (hipStreamWaitEvent(stream, ev_fwd[e & 1], 0) != hipSuccess) return CMCD_ERR_HIP;
       }
-      if (hipStreamWaitEvent(stream, ev_fwd[e & 1], 0) != hipSuccess) return CMCD_ERR_HIP;
       const LgcpFwdSet& f = g.fs[e & 1];
       const int64_t row0 = (int64_t)e * n + base;
+      // this evaluation's activations: the recompute's buffer set, or its rows of the tables the forward kept
+      const float* e_kr = kept ? keep.kr + row0 * D : gws + f.kr;
+      const float* e_sn = kept ? keep.sn + row0 * D : gws + f.sn;
+      const float* e_pre1 = kept ? keep.pre1 + row0 * IN : gws + f.pre1;
+      const float* e_pre2 = kept ? keep.pre2 + row0 * IN : gws + f.pre2;
+      const float* e_u1 = kept ? keep.u1 + row0 * IN : gws + f.u1;
+      const float* e_u2 = kept ? keep.u2 + row0 * IN : gws + f.u2;
       GemmArgs gm{};
       gm.M = M;
       // ---- adjoint step
       LgcpAdjArgs aa{};
-      aa.params = params; aa.tc = tc; aa.sched = ws + sw.sched; aa.traj = traj; aa.kr = gws + f.kr; aa.sn = gws + f.sn;
+      aa.params = params; aa.tc = tc; aa.sched = ws + sw.sched; aa.traj = traj; aa.kr = e_kr; aa.sn = e_sn;
+      aa.nslab = kept ? 1 : kSplit;
       aa.b3 = params + lay.g_b3; aa.factor = params + lay.g_factor; aa.lamn = gws + g.lamn; aa.gE = gws + g.gE;
       aa.gprev = gws + g.gprev; aa.dO = gws + g.dO; aa.v = gws + g.v; aa.lam_part = gws + g.lam_part;
       aa.gmu_acc = gws + g.gmu_acc; aa.glam_acc = gws + g.glam_acc; aa.part = gws + g.adjpart;
@@ -1995,7 +2053,7 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
         la.gE = gws + g.gE; la.gmu_acc = gws + g.gmu_acc; la.glam_acc = gws + g.glam_acc; la.lay = lay; la.n = n;
         la.base = base; la.M = M; la.D = D; la.IN = IN; la.e = e; la.omega = omega; la.no_net = 1;
         hipLaunchKernelGGL(lgcp_lam_finish_kernel, dim3((M * D + 255) / 256), dim3(256), 0, stream, la);
-        if (hipEventRecord(ev_bwd[e & 1], stream) != hipSuccess) return CMCD_ERR_HIP;
+        if (!kept && hipEventRecord(ev_bwd[e & 1], stream) != hipSuccess) return CMCD_ERR_HIP;
         continue;
       }
       // ---- net backward: d u2 = d o W3^T, then d a2 = d u2 sigmoid(pre2) as the GEMM's consumer
@@ -2004,23 +2062,23 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
       gm.seg[0] = GemmSeg{gws + g.dO, gws + g.wt3, gws + g.du2s, IN, D, IN, IN};
       gm.nblk0 = cbIN;
       LgcpActbArgs& ab = gm.actb;
-      ab.pre = gws + f.pre2; ab.du_prev = nullptr; ab.u_src = gws + f.u2;
-      ab.du_out = gws + g.du2; ab.da_out = gws + g.da2; ab.da_big = gws + g.DA2; ab.u_big = gws + g.U2;
+      ab.pre = e_pre2; ab.du_prev = nullptr; ab.u_src = e_u2;
+      ab.du_out = gws + g.du2; ab.da_out = gws + g.da2; ab.da_big = gws + g.DA2; ab.u_big = kept ? nullptr : gws + g.U2;
       ab.gb = gws + g.gb2; ab.row0 = row0; ab.IN = IN; ab.mode = 2;
       hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_ACTB>, dim3(cbIN, kSplit), gblock, gemm_lds, stream, gm);
       // d u1 = d u2 + d a2 W2^T, d a1 = d u1 sigmoid(pre1)
       gm.Kdim = IN;
       gm.seg[0] = GemmSeg{gws + g.da2, gws + g.wt2, gws + g.ts, IN, IN, IN, IN};
       gm.nblk0 = cbIN;
-      ab.pre = gws + f.pre1; ab.du_prev = gws + g.du2; ab.u_src = gws + f.u1;
-      ab.du_out = gws + g.du1; ab.da_out = gws + g.da1; ab.da_big = gws + g.DA1; ab.u_big = gws + g.U1;
+      ab.pre = e_pre1; ab.du_prev = gws + g.du2; ab.u_src = e_u1;
+      ab.du_out = gws + g.du1; ab.da_out = gws + g.da1; ab.da_big = gws + g.DA1; ab.u_big = kept ? nullptr : gws + g.U1;
       {
         const int er = ula == 2 ? (e > 0 ? e - 1 : 0) : e;     // the time index the network saw at this evaluation
         ab.S = gws + g.S + (int64_t)er * IN; ab.S2 = gws + g.S2 + (int64_t)er * IN; ab.mode = 1;
       }
       hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_ACTB>, dim3(cbIN, kSplit), gblock, gemm_lds, stream, gm);
       if (!bptt) {   // z detached: no lambda, no Hessian product; this evaluation's buffers are free after actb
-        if (hipEventRecord(ev_bwd[e & 1], stream) != hipSuccess) return CMCD_ERR_HIP;
+        if (!kept && hipEventRecord(ev_bwd[e & 1], stream) != hipSuccess) return CMCD_ERR_HIP;
         continue;
       }
       gm.Kdim = IN; gm.Kdim1 = D;                       // two independent products, one launch
@@ -2035,7 +2093,7 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
       la.gE = gws + g.gE; la.gmu_acc = gws + g.gmu_acc; la.glam_acc = gws + g.glam_acc; la.lay = lay; la.n = n;
       la.base = base; la.M = M; la.D = D; la.IN = IN; la.e = e; la.omega = omega;
       hipLaunchKernelGGL(lgcp_lam_finish_kernel, dim3((M * D + 255) / 256), dim3(256), 0, stream, la);
-      if (hipEventRecord(ev_bwd[e & 1], stream) != hipSuccess) return CMCD_ERR_HIP;
+      if (!kept && hipEventRecord(ev_bwd[e & 1], stream) != hipSuccess) return CMCD_ERR_HIP;
     }
     // q gradients of this pass: sum over its particles, accumulated into grad
     hipLaunchKernelGGL(lgcp_colsum_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, gws + g.gmu_acc, (int64_t)M, D, D,
