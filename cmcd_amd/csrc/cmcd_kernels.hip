@@ -1116,7 +1116,7 @@ static int forward_impl(const cmcd_desc* desc, const cmcd_layout* lay, const int
                  : "lgcp launch sequence (skinny GEMMs + state kernels)");
     // gradient calls (traj set) place the gradient workspace right in front of the kept trajectory: the forward's consumers
     // keep their activations in its tables, so that the reverse sweep does not recompute them (cmcd_lgcp.hip: lgcp_keep)
-    float* keep_gws = (traj && !uha) ? traj - align4(lgcp_grad_workspace_floats(dl, n)) : nullptr;
+    float* keep_gws = traj ? traj - align4(lgcp_grad_workspace_floats(dl, n)) : nullptr;
     rc = lgcp_forward(dl, *lay, lw, seeds, n, params, target_consts, wsf, out_loss, out_z, &partials, traj, stream_, lgcp_ready,
                       keep_gws);
     if (rc != CMCD_OK) return fail(rc, "lgcp launch sequence failed%s");

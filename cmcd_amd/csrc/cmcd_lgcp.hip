@@ -901,6 +901,7 @@ __device__ __forceinline__ void nsk_mid_post(const NskArgs& a, const NskMidPre& 
     u.zn[t.in] = t.z + eps * rpp;                               // :63
     u.rpp[(int64_t)m * D + e] = rpp;
     if (u.traj) u.traj[((int64_t)(2 * u.K + 2 + u.i) * u.n_total + u.base + m) * D + e] = rhop;
+    if (a.keepSn) a.keepSn[(int64_t)m * D + e] = o;              // the raw u2 W3 product of the bridge's first evaluation
   }
   fk = live ? fk : 0.f;
 #pragma unroll
@@ -1045,6 +1046,7 @@ __global__ __launch_bounds__(64 * kGemmWaves, (KIND || MERGED) ? 2 : 4) void lgc
     else if (a.krOutN) a.krOutN[(int64_t)row * sg.N + n] = v;
     else a.krOut[nsk_pack(row, n)] = v;
     if (sg.epi == NSK_KR && a.keepKr) a.keepKr[(int64_t)row * sg.N + n] = v;
+    if (sg.epi == NSK_OUT && a.keepSn) a.keepSn[(int64_t)row * sg.N + n] = v;
   } else {
     const float pre = v + cb, u = cu + softplus(pre);          // nn.py:45-50
     a.outA[cix] = u;
@@ -1300,9 +1302,18 @@ static LgcpWs lgcp_ws(const cmcd_desc& d, int64_t n, int64_t base) {
 struct LgcpUhaWs;
 static LgcpUhaWs lgcp_uha_ws(const cmcd_desc& d, int64_t n, int64_t base);
 static int64_t lgcp_uha_ws_total(const cmcd_desc& d, int64_t n, int64_t base);
+// r04: tables of the gradient workspace that the forward's consumers fill when it runs for a gradient call (lgcp_keep below
+// lgcp_grad_ws): [(K+1) n][IN] pre1, u1, pre2, u2 and [(K+1) n][D] kr, sn.  `on` is false when the forward does not run on the
+// no-split-K GEMM or the tables would pass 1 GB: the reverse sweep then recomputes every evaluation as it did in r01 - r03.
+struct LgcpKeep { float *pre1, *u1, *pre2, *u2, *kr, *sn; bool on; };
+static LgcpKeep lgcp_keep(const cmcd_desc& d, int64_t n, float* gws);
+
 static int lgcp_uha_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, const int32_t* seeds, int64_t n,
                             const float* params, const float* tc, float* ws, float* out_loss, float* out_z,
-                            double** partials_out, float* traj, hipStream_t stream);
+                            double** partials_out, float* traj, hipStream_t stream, float* keep_gws);
+// the 2nd-order sequence's kept tables: [2 K n][IN] pre1, u1, pre2, u2 and [2 K n][D] sn (rows 2 i: s([z_i; rho_i], i), 2 i + 1:
+// s([z_i; rho'_i], i)), [(K+1) n][D] kr (K^-1 (z_e - mu0))
+static LgcpKeep lgcp_uha_keep(const cmcd_desc& d, int64_t n, float* gws);
 
 // desc.reserved (the kernel-variant hook of tests / probes): 1 pins the 32-row passes, 2 the wide-batch path
 bool lgcp_use_wide(const cmcd_desc& d, int64_t n, bool keeps_trajectory) {
@@ -1336,18 +1347,12 @@ static int lgcp_gemm_attrs() {
   return gemm_lds;
 }
 
-// r04: tables of the gradient workspace that the forward's consumers fill when it runs for a gradient call (lgcp_keep below
-// lgcp_grad_ws): [(K+1) n][IN] pre1, u1, pre2, u2 and [(K+1) n][D] kr, sn.  `on` is false when the forward does not run on the
-// no-split-K GEMM or the tables would pass 1 GB: the reverse sweep then recomputes every evaluation as it did in r01 - r03.
-struct LgcpKeep { float *pre1, *u1, *pre2, *u2, *kr, *sn; bool on; };
-static LgcpKeep lgcp_keep(const cmcd_desc& d, int64_t n, float* gws);
-
 int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, const int32_t* seeds, int64_t n,
                  const float* params, const float* tc, float* ws, float* out_loss, float* out_z,
                  double** partials_out, float* traj, void* stream_, bool tables_ready, float* keep_gws) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (d.mode == CMCD_MODE_CAIS_UHA_SN)
-    return lgcp_uha_forward(d, lay, sw, seeds, n, params, tc, ws, out_loss, out_z, partials_out, traj, stream);
+    return lgcp_uha_forward(d, lay, sw, seeds, n, params, tc, ws, out_loss, out_z, partials_out, traj, stream, keep_gws);
   if (lgcp_use_wide(d, n, traj != nullptr))
     return lgcp_wide_forward(d, lay, sw, seeds, n, params, tc, ws, out_loss, out_z, partials_out, stream_, tables_ready);
   const int D = d.dim, E = d.emb_dim, IN = D + E, K = d.nbridges;
@@ -2445,9 +2450,10 @@ static int64_t lgcp_uha_ws_total(const cmcd_desc& d, int64_t n, int64_t base) { 
 // workgroup per CU in the 17 .. 20-particle form); F1 / F2 read ONE product array each instead of summing eight slabs.
 static int lgcp_uha_forward_nsk(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, const LgcpUhaWs& w,
                                 const int32_t* seeds, int64_t n, const float* params, const float* tc, float* ws, float* out_loss,
-                                float* out_z, double* partials, float* traj, hipStream_t stream) {
+                                float* out_z, double* partials, float* traj, hipStream_t stream, float* keep_gws) {
   const int D = d.dim, E = d.emb_dim, IN = 2 * D + E, K = d.nbridges;
   const int tIN = (IN + 15) / 16, tD = D / 16, big = 2 * kNskChunks;
+  const LgcpKeep keep = keep_gws ? lgcp_uha_keep(d, n, keep_gws) : LgcpKeep{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, false};
   const float mu0 = 3.8812819069514780f;
   {
     NskPackArgs pk{};
@@ -2485,6 +2491,7 @@ static int lgcp_uha_forward_nsk(const cmcd_desc& d, const cmcd_layout& lay, cons
     {   // K^-1 (z_0 - mu0)
       NskArgs na{};
       na.M = M; na.D = 2 * D; na.IN = IN; na.seg[0] = kinv_seg(); na.nt0 = tD; na.krOutN = ws + w.kr;
+      if (keep.on) na.keepKr = keep.kr + base * D;
       launch(na, tD);
     }
     float* const fkslot = ws + w.slab1;      // [D / 16][kMP] (the split-K form's slab region is free here)
@@ -2496,14 +2503,21 @@ static int lgcp_uha_forward_nsk(const cmcd_desc& d, const cmcd_layout& lay, cons
       na.M = M; na.D = 2 * D; na.IN = IN; na.nch_out = big;
       na.seg[0] = NskSeg{zin, ws + w.w1p, IN, NSK_ACT1, 0.f}; na.seg[0].nch = big; na.nt0 = tIN;
       na.xA = zin; na.bias = ws + w.bias1 + (int64_t)i * IN; na.emb = params + lay.g_emb + (int64_t)i * E; na.outA = u1A;
+      // (gradient calls: this evaluation's rows of the kept tables — 2 i for [z; rho], 2 i + 1 for [z; rho'])
+      const int64_t krow = (int64_t)(2 * i + (with_kinv ? 1 : 0)) * n + base;
+      if (keep.on) { na.keepPre = keep.pre1 + krow * IN; na.keepU = keep.u1 + krow * IN; }
       launch(na, tIN);
       na.seg[0] = NskSeg{u1A, ws + w.w2p, IN, NSK_ACT2, 0.f}; na.seg[0].nch = big;
       na.bias = params + lay.g_b2; na.uA = u1A; na.outA = u2A;
+      if (keep.on) { na.keepPre = keep.pre2 + krow * IN; na.keepU = keep.u2 + krow * IN; }
       launch(na, tIN);
       na.seg[0] = NskSeg{u2A, ws + w.w3p, D, with_kinv ? NSK_OUT : NSK_UHA_MID, 0.f}; na.seg[0].nch = big; na.nt0 = tD;
       na.outN = ws + w.sn;
+      na.keepPre = nullptr; na.keepU = nullptr;
+      if (keep.on) na.keepSn = keep.sn + krow * D;
       if (with_kinv) {
         na.seg[1] = kinv_seg(); na.krOutN = ws + w.kr;
+        if (keep.on) na.keepKr = keep.kr + ((int64_t)(i + 1) * n + base) * D;   // K^-1 (z_{i+1} - mu0)
         launch(na, 2 * tD);
         return;
       }
@@ -2526,7 +2540,7 @@ static int lgcp_uha_forward_nsk(const cmcd_desc& d, const cmcd_layout& lay, cons
 
 static int lgcp_uha_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, const int32_t* seeds, int64_t n,
                             const float* params, const float* tc, float* ws, float* out_loss, float* out_z,
-                            double** partials_out, float* traj, hipStream_t stream) {
+                            double** partials_out, float* traj, hipStream_t stream, float* keep_gws) {
   const int D = d.dim, E = d.emb_dim, IN = 2 * D + E, K = d.nbridges;
   const LgcpUhaWs w = lgcp_uha_ws(d, n, sw.total_floats);
   LgcpPrepArgs pa{params, ws + w.bias1, lay, 2 * D, E, K, IN};   // bias1_i = b1 + emb_i W1[2d:, :]
@@ -2534,7 +2548,7 @@ static int lgcp_uha_forward(const cmcd_desc& d, const cmcd_layout& lay, const Ws
   if (lgcp_uha_nsk_ok(d)) {
     double* partials_n = reinterpret_cast<double*>(ws + w.partials);
     *partials_out = partials_n;
-    return lgcp_uha_forward_nsk(d, lay, sw, w, seeds, n, params, tc, ws, out_loss, out_z, partials_n, traj, stream);
+    return lgcp_uha_forward_nsk(d, lay, sw, w, seeds, n, params, tc, ws, out_loss, out_z, partials_n, traj, stream, keep_gws);
   }
   const int gemm_lds = lgcp_gemm_attrs();
   if (gemm_lds < 0) return CMCD_ERR_HIP;
@@ -2599,6 +2613,8 @@ struct LgcpUhaGradWs {
   int64_t geta, gepsd;                          // [kMP]
   int64_t S, S2, gb2, gbeta, geps, counters;
   int64_t sc;                                   // [(K+1)][n][8]
+  int64_t kpre1, kpre2, ksn, kkr;               // kept by the forward (lgcp_uha_keep): [2 K n][IN] x 2, [2 K n][D], [(K+1) n][D]
+  bool keep;
   int64_t total;
 };
 
@@ -2627,8 +2643,18 @@ static LgcpUhaGradWs lgcp_uha_grad_ws(const cmcd_desc& d, int64_t n) {
   w.counters = take(((D + 63) / 64) + ((IN + 63) / 64));
   w.sc = take((K + 1) * n * 8);
   w.zero_hi = o;
+  // the forward's kept activations (behind everything else, outside the cleared range)
+  w.keep = lgcp_uha_nsk_ok(d) && R * (2 * IN + D) + (K + 1) * n * D <= (int64_t(1) << 28);
+  w.kpre1 = take(w.keep ? R * IN : 0); w.kpre2 = take(w.keep ? R * IN : 0);
+  w.ksn = take(w.keep ? R * D : 0); w.kkr = take(w.keep ? (K + 1) * n * D : 0);
   w.total = o;
   return w;
+}
+
+static LgcpKeep lgcp_uha_keep(const cmcd_desc& d, int64_t n, float* gws) {
+  const LgcpUhaGradWs g = lgcp_uha_grad_ws(d, n);
+  if (!g.keep) return LgcpKeep{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, false};
+  return LgcpKeep{gws + g.kpre1, gws + g.U1, gws + g.kpre2, gws + g.U2, gws + g.kkr, gws + g.ksn, true};
 }
 
 struct LgcpUhaAdjArgs {
@@ -2640,6 +2666,7 @@ struct LgcpUhaAdjArgs {
   const float* hv;           // [kSplit][kMP][D]  v K^-1
   const float* snA;          // [kSplit][kMP][D]  u2 W3 slabs of evaluation A / B
   const float* snB;
+  int nslab = kSplit;        // slabs of kr / snA / snB to sum: kSplit (recomputed) or 1 (kept by the forward)
   const float* du1;          // [kMP][IN]  d u1 of the evaluation just back-propagated (residual path)
   const float* dxf;          // [kSplit][kMP][2D]  d a1 W1[:2D]^T
   float* zinA;               // [kMP][2D]
@@ -2697,7 +2724,7 @@ __global__ __launch_bounds__(256) void lgcp_uha_adj_point_kernel(LgcpUhaAdjArgs 
     const float z = a.traj[((int64_t)e * a.n + pr) * D + j];
     float kr = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < kSplit; ++ks) kr += a.kr[((int64_t)ks * kMP + p) * D + j];
+    for (int ks = 0; ks < kSplit; ++ks) kr += ks < a.nslab ? a.kr[((int64_t)ks * kMP + p) * D + j] : 0.f;
     const float graw = -kr + counts[j] - pa * expf(z);
     const float gp = fminf(fmaxf(graw, -1e2f), 1e2f);
     const float msk = fabsf(graw) < 1e2f ? 1.0f : 0.f;
@@ -2760,7 +2787,7 @@ __global__ __launch_bounds__(256) void lgcp_uha_adj_b_kernel(LgcpUhaAdjArgs a) {
 #pragma unroll
     for (int ks = 0; ks < kSplit; ++ks) {
       hv += a.hv[((int64_t)ks * kMP + p) * D + j];
-      o += a.snB[((int64_t)ks * kMP + p) * D + j];
+      o += ks < a.nslab ? a.snB[((int64_t)ks * kMP + p) * D + j] : 0.f;
     }
     const float lz = a.lz[p * D + j] - hv - pa * expf(ze) * a.v[p * D + j];     // H_p v = -K^-1 v - a e^z v
     a.lz[p * D + j] = lz;
@@ -2804,7 +2831,7 @@ __global__ __launch_bounds__(256) void lgcp_uha_adj_a_kernel(LgcpUhaAdjArgs a) {
     for (int ks = 0; ks < kSplit; ++ks) {
       dz += a.dxf[((int64_t)ks * kMP + p) * 2 * D + j];
       dr += a.dxf[((int64_t)ks * kMP + p) * 2 * D + D + j];
-      o += a.snA[((int64_t)ks * kMP + p) * D + j];
+      o += ks < a.nslab ? a.snA[((int64_t)ks * kMP + p) * D + j] : 0.f;
     }
     a.lz[p * D + j] += dz;
     const float arp = a.arp[p * D + j] + dr;
@@ -2919,6 +2946,8 @@ static int lgcp_uha_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLay
   const int cbD = (D + 63) / 64, cbIN = (IN + 63) / 64, cb2D = (2 * D + 63) / 64;
   int* counters = reinterpret_cast<int*>(gws + g.counters);
   const float* bias1 = ws + w.bias1;    // still in the forward workspace (lgcp_uha_forward's prep)
+  const LgcpKeep keep = lgcp_uha_keep(d, n, gws);
+  const bool kept = keep.on;
 
   for (int64_t base = 0; base < n; base += kMP) {
     const int M = (int)((n - base) < kMP ? (n - base) : kMP);
@@ -2950,14 +2979,14 @@ static int lgcp_uha_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLay
       gm.seg[0] = GemmSeg{gws + g.dO, gws + g.wt3, gws + g.du2s, IN, D, IN, IN};
       gm.nblk0 = cbIN;
       LgcpActbArgs& ab = gm.actb;
-      ab.pre = gws + f.pre2; ab.du_prev = nullptr; ab.u_src = gws + f.u2;
-      ab.du_out = gws + g.du2; ab.da_out = gws + g.da2; ab.da_big = gws + g.DA2; ab.u_big = gws + g.U2;
+      ab.pre = kept ? keep.pre2 + row * IN : gws + f.pre2; ab.du_prev = nullptr; ab.u_src = kept ? keep.u2 + row * IN : gws + f.u2;
+      ab.du_out = gws + g.du2; ab.da_out = gws + g.da2; ab.da_big = gws + g.DA2; ab.u_big = kept ? nullptr : gws + g.U2;
       ab.gb = gws + g.gb2; ab.row0 = row; ab.IN = IN; ab.mode = 2;
       hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_ACTB>, dim3(cbIN, kSplit), gblock, gemm_lds, stream, gm);
       gm.Kdim = IN;
       gm.seg[0] = GemmSeg{gws + g.da2, gws + g.wt2, gws + g.ts, IN, IN, IN, IN};
-      ab.pre = gws + f.pre1; ab.du_prev = gws + g.du2; ab.u_src = gws + f.u1;
-      ab.du_out = gws + g.du1; ab.da_out = gws + g.da1; ab.da_big = gws + g.DA1; ab.u_big = gws + g.U1;
+      ab.pre = kept ? keep.pre1 + row * IN : gws + f.pre1; ab.du_prev = gws + g.du2; ab.u_src = kept ? keep.u1 + row * IN : gws + f.u1;
+      ab.du_out = gws + g.du1; ab.da_out = gws + g.da1; ab.da_big = gws + g.DA1; ab.u_big = kept ? nullptr : gws + g.U1;
       ab.S = gws + g.S + (int64_t)i * IN; ab.S2 = gws + g.S2 + (int64_t)i * IN; ab.mode = 1;
       hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_ACTB>, dim3(cbIN, kSplit), gblock, gemm_lds, stream, gm);
       gm.seg[0] = GemmSeg{gws + g.da1, gws + g.wt1, gws + g.dxf, 2 * D, IN, 2 * D, 2 * D};
@@ -2972,27 +3001,36 @@ static int lgcp_uha_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLay
       hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_NONE>, dim3(cbD, kSplit), gblock, gemm_lds, stream, gm);
     };
 
-    kr_at(K);
+    if (kept) aa.nslab = 1;
+    else kr_at(K);
     for (int e = K; e >= 1; --e) {
       const int i = e - 1;
       aa.e = e;
+      const int64_t rowA = (int64_t)(2 * i) * n + base, rowB = rowA + n;
+      if (kept) {   // the forward's sums of this bridge: nothing to recompute (r04)
+        aa.kr = keep.kr + ((int64_t)e * n + base) * D;
+        aa.snA = keep.sn + rowA * D; aa.snB = keep.sn + rowB * D;
+      }
       hipLaunchKernelGGL(lgcp_uha_adj_point_kernel, dim3(M), dim3(256), 0, stream, aa);
       hv_product();
       hipLaunchKernelGGL(lgcp_uha_gather_kernel, dim3((M * D + 255) / 256), dim3(256), 0, stream, aa);
       const LgcpUhaFwdSet& fa = g.fs[0];
       const LgcpUhaFwdSet& fb = g.fs[1];
-      lgcp_uha_net(d, lay, params, kinv, M, i, gws + fa.zin, bias1, gws + fa.slab1, gws + fa.pre1, gws + fa.u1, gws + fa.slab2,
-                   gws + fa.pre2, gws + fa.u2, gws + fa.sn, nullptr, nullptr, counters, gemm_lds, stream);
-      lgcp_uha_net(d, lay, params, kinv, M, i, gws + fb.zin, bias1, gws + fb.slab1, gws + fb.pre1, gws + fb.u1, gws + fb.slab2,
-                   gws + fb.pre2, gws + fb.u2, gws + fb.sn, nullptr, nullptr, counters, gemm_lds, stream);
+      if (!kept) {
+        lgcp_uha_net(d, lay, params, kinv, M, i, gws + fa.zin, bias1, gws + fa.slab1, gws + fa.pre1, gws + fa.u1, gws + fa.slab2,
+                     gws + fa.pre2, gws + fa.u2, gws + fa.sn, nullptr, nullptr, counters, gemm_lds, stream);
+        lgcp_uha_net(d, lay, params, kinv, M, i, gws + fb.zin, bias1, gws + fb.slab1, gws + fb.pre1, gws + fb.u1, gws + fb.slab2,
+                     gws + fb.pre2, gws + fb.u2, gws + fb.sn, nullptr, nullptr, counters, gemm_lds, stream);
+      }
       hipLaunchKernelGGL(lgcp_uha_adj_b_kernel, dim3(M), dim3(256), 0, stream, aa);
-      net_backward(fb, (int64_t)(2 * i + 1) * n + base, i);
+      net_backward(fb, rowB, i);
       hipLaunchKernelGGL(lgcp_uha_adj_a_kernel, dim3(M), dim3(256), 0, stream, aa);
-      net_backward(fa, (int64_t)(2 * i) * n + base, i);
+      net_backward(fa, rowA, i);
       hipLaunchKernelGGL(lgcp_uha_adj_fin_kernel, dim3(M), dim3(256), 0, stream, aa);
-      kr_at(i);
+      if (!kept) kr_at(i);
     }
     aa.e = 0;
+    if (kept) aa.kr = keep.kr + base * D;
     hipLaunchKernelGGL(lgcp_uha_adj_point_kernel, dim3(M), dim3(256), 0, stream, aa);
     hv_product();
     hipLaunchKernelGGL(lgcp_uha_adj_z0_kernel, dim3(M), dim3(256), 0, stream, aa);
