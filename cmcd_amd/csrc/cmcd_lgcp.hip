@@ -2709,6 +2709,19 @@ __global__ void lgcp_uha_gather_kernel(LgcpUhaAdjArgs a) {
   xb[j] = z; xb[D + j] = rhop;
 }
 
+// r04 (activations kept by the forward: no recompute operands needed): all rows of XIN in ONE launch, blockIdx.y = bridge
+__global__ void lgcp_uha_xin_kernel(LgcpUhaAdjArgs a) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x, D = a.D, K = a.K, i = blockIdx.y;
+  if (idx >= a.M * D) return;
+  const int m = idx / D, j = idx - m * D;
+  const int64_t pr = a.base + m;
+  const float z = a.traj[((int64_t)i * a.n + pr) * D + j];
+  float* xa = a.XIN + ((int64_t)(2 * i) * a.n + pr) * 2 * D;
+  float* xb = a.XIN + ((int64_t)(2 * i + 1) * a.n + pr) * 2 * D;
+  xa[j] = z; xa[D + j] = a.traj[((int64_t)(K + 1 + i) * a.n + pr) * D + j];
+  xb[j] = z; xb[D + j] = a.traj[((int64_t)(2 * K + 2 + i) * a.n + pr) * D + j];
+}
+
 // point e: cotangents of ub (bridge e - 1) and uf (bridge e) at z_e, v = clipmask . a_gp for the Hessian product, q gradients
 __global__ __launch_bounds__(256) void lgcp_uha_adj_point_kernel(LgcpUhaAdjArgs a) {
   __shared__ float sh[4];
@@ -3001,8 +3014,12 @@ static int lgcp_uha_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLay
       hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_NONE>, dim3(cbD, kSplit), gblock, gemm_lds, stream, gm);
     };
 
-    if (kept) aa.nslab = 1;
-    else kr_at(K);
+    if (kept) {
+      aa.nslab = 1;
+      hipLaunchKernelGGL(lgcp_uha_xin_kernel, dim3((M * D + 255) / 256, K), dim3(256), 0, stream, aa);
+    } else {
+      kr_at(K);
+    }
     for (int e = K; e >= 1; --e) {
       const int i = e - 1;
       aa.e = e;
@@ -3013,7 +3030,7 @@ static int lgcp_uha_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLay
       }
       hipLaunchKernelGGL(lgcp_uha_adj_point_kernel, dim3(M), dim3(256), 0, stream, aa);
       hv_product();
-      hipLaunchKernelGGL(lgcp_uha_gather_kernel, dim3((M * D + 255) / 256), dim3(256), 0, stream, aa);
+      if (!kept) hipLaunchKernelGGL(lgcp_uha_gather_kernel, dim3((M * D + 255) / 256), dim3(256), 0, stream, aa);
       const LgcpUhaFwdSet& fa = g.fs[0];
       const LgcpUhaFwdSet& fb = g.fs[1];
       if (!kept) {
