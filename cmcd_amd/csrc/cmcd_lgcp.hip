@@ -312,6 +312,31 @@ __global__ void lgcp_lam_finish_kernel(LgcpLamArgs a) {
   lgcp_lam_elem(a, m, j, dx, hv, lam, ge);
 }
 
+// r04 (activations kept by the forward: evaluation e - 1 has nothing to wait for): lambda_e from the products of evaluation e,
+// then the adjoint step of evaluation e - 1 on the same element — one launch instead of two per evaluation of the sweep
+__global__ __launch_bounds__(64) void lgcp_lam_adj_kernel(LgcpLamArgs la, LgcpAdjArgs a) {
+  const int p = blockIdx.y, D = a.D, lane = threadIdx.x, j = blockIdx.x * 64 + lane;
+  float t[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (j < D) {
+    float dx = la.no_net ? 0.f : la.du1[p * la.IN + j], hv = 0.f;     // residual path: d x_j += d u1_j
+#pragma unroll
+    for (int ks = 0; ks < kSplit; ++ks) {
+      dx += la.no_net ? 0.f : la.dxf[((int64_t)ks * kMP + p) * D + j];
+      hv += la.hv[((int64_t)ks * kMP + p) * D + j];
+    }
+    float lam, ge;
+    lgcp_lam_elem(la, p, j, dx, hv, lam, ge);
+    lgcp_adj_elem(a, p, j, lam, ge, t);
+  }
+#pragma unroll
+  for (int q = 0; q < 6; ++q) t[q] = wave_sum64(t[q]);
+  if (lane == 0) {
+    float* o = a.part + (((int64_t)a.e * a.n + a.base + p) * gridDim.x + blockIdx.x) * 8;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) o[q] = t[q];
+  }
+}
+
 // (G, H) = split(gen); gen' = second(split(H))     mcd_cais.py:66-67,87
 __device__ __forceinline__ void lgcp_key_advance(uint32_t& k0, uint32_t& k1, uint32_t& G0, uint32_t& G1) {
   uint32_t g0 = 0, h0 = 2, g1 = 1, h1 = 3;
@@ -2036,17 +2061,24 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
       const float* e_u2 = kept ? keep.u2 + row0 * IN : gws + f.u2;
       GemmArgs gm{};
       gm.M = M;
-      // ---- adjoint step
-      LgcpAdjArgs aa{};
-      aa.params = params; aa.tc = tc; aa.sched = ws + sw.sched; aa.traj = traj; aa.kr = e_kr; aa.sn = e_sn;
-      aa.nslab = kept ? 1 : kSplit;
-      aa.b3 = params + lay.g_b3; aa.factor = params + lay.g_factor; aa.lamn = gws + g.lamn; aa.gE = gws + g.gE;
-      aa.gprev = gws + g.gprev; aa.dO = gws + g.dO; aa.v = gws + g.v; aa.lam_part = gws + g.lam_part;
-      aa.gmu_acc = gws + g.gmu_acc; aa.glam_acc = gws + g.glam_acc; aa.part = gws + g.adjpart;
-      aa.DObig = gws + g.DO; aa.lay = lay; aa.n = n; aa.base = base;
-      aa.M = M; aa.D = D; aa.K = K; aa.e = e; aa.grad_clipping = d.grad_clipping; aa.omega = omega;
-      aa.ula = ula; aa.omega_vec = omega_vec; aa.gktab = reinterpret_cast<const uint32_t*>(ws + w.gktab); aa.bptt = bptt ? 1 : 0; aa.var_mode = d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0;
-      hipLaunchKernelGGL(lgcp_adj_step_kernel, dim3(cbD, M), dim3(64), 0, stream, aa);
+      // ---- adjoint step (of evaluation ev: its kr / sn are the recompute's buffers, or rows of the kept tables)
+      auto adj_args = [&](int ev) {
+        const int64_t rv = (int64_t)ev * n + base;
+        LgcpAdjArgs aa{};
+        aa.params = params; aa.tc = tc; aa.sched = ws + sw.sched; aa.traj = traj;
+        aa.kr = kept ? keep.kr + rv * D : e_kr; aa.sn = kept ? keep.sn + rv * D : e_sn;
+        aa.nslab = kept ? 1 : kSplit;
+        aa.b3 = params + lay.g_b3; aa.factor = params + lay.g_factor; aa.lamn = gws + g.lamn; aa.gE = gws + g.gE;
+        aa.gprev = gws + g.gprev; aa.dO = gws + g.dO; aa.v = gws + g.v; aa.lam_part = gws + g.lam_part;
+        aa.gmu_acc = gws + g.gmu_acc; aa.glam_acc = gws + g.glam_acc; aa.part = gws + g.adjpart;
+        aa.DObig = gws + g.DO; aa.lay = lay; aa.n = n; aa.base = base;
+        aa.M = M; aa.D = D; aa.K = K; aa.e = ev; aa.grad_clipping = d.grad_clipping; aa.omega = omega;
+        aa.ula = ula; aa.omega_vec = omega_vec; aa.gktab = reinterpret_cast<const uint32_t*>(ws + w.gktab); aa.bptt = bptt ? 1 : 0; aa.var_mode = d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0;
+        return aa;
+      };
+      // kept + reparameterised: the step of evaluation e was fused behind lambda_{e+1} by the previous iteration
+      const bool fuse = kept && bptt;
+      if (!(fuse && e < K)) hipLaunchKernelGGL(lgcp_adj_step_kernel, dim3(cbD, M), dim3(64), 0, stream, adj_args(e));
       if (!net) {   // MCD_ULA: lambda_e = lam_part - H_p v, one GEMM
         gm.Kdim = D; gm.Kdim1 = 0;
         gm.seg[0] = GemmSeg{gws + g.v, kinv, gws + g.hv, D, D, D, D};
@@ -2057,7 +2089,8 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
         la.v = gws + g.v; la.lam_part = gws + g.lam_part; la.gprev = gws + g.gprev; la.lamn = gws + g.lamn;
         la.gE = gws + g.gE; la.gmu_acc = gws + g.gmu_acc; la.glam_acc = gws + g.glam_acc; la.lay = lay; la.n = n;
         la.base = base; la.M = M; la.D = D; la.IN = IN; la.e = e; la.omega = omega; la.no_net = 1;
-        hipLaunchKernelGGL(lgcp_lam_finish_kernel, dim3((M * D + 255) / 256), dim3(256), 0, stream, la);
+        if (fuse && e > 0) hipLaunchKernelGGL(lgcp_lam_adj_kernel, dim3(cbD, M), dim3(64), 0, stream, la, adj_args(e - 1));
+        else hipLaunchKernelGGL(lgcp_lam_finish_kernel, dim3((M * D + 255) / 256), dim3(256), 0, stream, la);
         if (!kept && hipEventRecord(ev_bwd[e & 1], stream) != hipSuccess) return CMCD_ERR_HIP;
         continue;
       }
@@ -2097,7 +2130,8 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
       la.v = gws + g.v; la.lam_part = gws + g.lam_part; la.gprev = gws + g.gprev; la.lamn = gws + g.lamn;
       la.gE = gws + g.gE; la.gmu_acc = gws + g.gmu_acc; la.glam_acc = gws + g.glam_acc; la.lay = lay; la.n = n;
       la.base = base; la.M = M; la.D = D; la.IN = IN; la.e = e; la.omega = omega;
-      hipLaunchKernelGGL(lgcp_lam_finish_kernel, dim3((M * D + 255) / 256), dim3(256), 0, stream, la);
+      if (fuse && e > 0) hipLaunchKernelGGL(lgcp_lam_adj_kernel, dim3(cbD, M), dim3(64), 0, stream, la, adj_args(e - 1));
+      else hipLaunchKernelGGL(lgcp_lam_finish_kernel, dim3((M * D + 255) / 256), dim3(256), 0, stream, la);
       if (!kept && hipEventRecord(ev_bwd[e & 1], stream) != hipSuccess) return CMCD_ERR_HIP;
     }
     // q gradients of this pass: sum over its particles, accumulated into grad
