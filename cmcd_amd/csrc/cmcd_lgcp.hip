@@ -90,6 +90,18 @@ struct StepEpi {         // evaluation i at z_i: closes step i-1, opens step i (
 };
 
 // backward activations (consumer of the two IN-wide backward GEMMs): d u = [d u_next +] sum(slabs), d a = d u sigmoid(pre)
+// (constants and the packed-operand index of the no-split-K GEMM, section "r04" below: the adjoint step writes packed operands too)
+constexpr int kNskChunks = 104;                  // 16-deep chunks of a packed operand (K <= 1664), 13 per wave
+constexpr int kNskCpw = kNskChunks / kGemmWaves;
+constexpr int64_t kNskOperand = (int64_t)2 * kNskChunks * 256;   // floats of one packed [32 x 1664] operand
+constexpr int kNskOps = 6;                      // per lane: z (three rotating buffers), u1, u2, K^-1 product
+
+// nch: 16-deep chunks of the packed array — kNskChunks (K <= 1664), or 2 kNskChunks for the 3220-wide layers of the 2nd-order
+// mode (two rounds of 13 chunks per wave)
+__host__ __device__ __forceinline__ int64_t nsk_pack(int r, int k, int nch = kNskChunks) {
+  return (((int64_t)(r >> 4) * nch + (k >> 4)) * 64 + (r & 15) + 16 * ((k & 15) >> 2)) * 4 + (k & 3);
+}
+
 struct LgcpActbArgs {
   const float* pre;        // [kMP][IN] pre-activation of this layer
   const float* du_prev;    // [kMP][IN] (mode 1: d u2)
@@ -133,6 +145,8 @@ struct LgcpAdjArgs {
   int ula;                   // 0: CAIS; 1: MCD_ULA (no network); 2: MCD_ULA_sn (network in the backward kernel only)
   int bptt;                  // 1: gradient through the trajectory (lambda recursion); 0: z detached (mcd_cais_var.py:59,79)
   int nslab = kSplit;        // slabs of kr / sn to sum: kSplit (recomputed by the split-K GEMM) or 1 (kept by the forward)
+  float* dOp = nullptr;      // packed copies of dO / v: operands of the reverse sweep's no-split-K launches (nullptr: none)
+  float* vp = nullptr;
   int var_mode;              // MCD_CAIS_var_sn: clip at 1e2 and clip grad log q too (mcd_cais_var.py:29-36)
 };
 
@@ -155,6 +169,7 @@ struct LgcpLamArgs {
   int M, D, IN, e;
   float omega;
   int no_net;              // MCD_ULA: d x = 0 (no network to go back through)
+  int nslab = kSplit;      // slabs of dxf / hv to sum: kSplit, or 1 (row-major outputs of the no-split-K launch)
 };
 
 struct GemmArgs {
@@ -250,11 +265,13 @@ __device__ __forceinline__ void lgcp_adj_elem(const LgcpAdjArgs& a, int p, int j
     t[5] += a_s * o;
     if (!no_net) {
       a.dO[p * D + j] = a_s * fac;
+      if (a.dOp) a.dOp[nsk_pack(p, j)] = a_s * fac;
       a.DObig[((int64_t)e * a.n + a.base + p) * D + j] = a_s * fac;
     }
     if (bptt) {
       a.gprev[p * D + j] = gpv;
       a.v[p * D + j] = m * a_gp;
+      if (a.vp) a.vp[nsk_pack(p, j)] = m * a_gp;
       a.lam_part[p * D + j] = lam;
     }
   }
@@ -305,6 +322,7 @@ __global__ void lgcp_lam_finish_kernel(LgcpLamArgs a) {
   float dx = a.no_net ? 0.f : a.du1[m * a.IN + j], hv = 0.f;     // residual path: d x_j += d u1_j
 #pragma unroll
   for (int ks = 0; ks < kSplit; ++ks) {
+    if (ks >= a.nslab) break;
     dx += a.no_net ? 0.f : a.dxf[((int64_t)ks * kMP + m) * D + j];
     hv += a.hv[((int64_t)ks * kMP + m) * D + j];
   }
@@ -321,6 +339,7 @@ __global__ __launch_bounds__(64) void lgcp_lam_adj_kernel(LgcpLamArgs la, LgcpAd
     float dx = la.no_net ? 0.f : la.du1[p * la.IN + j], hv = 0.f;     // residual path: d x_j += d u1_j
 #pragma unroll
     for (int ks = 0; ks < kSplit; ++ks) {
+      if (ks >= la.nslab) break;
       dx += la.no_net ? 0.f : la.dxf[((int64_t)ks * kMP + p) * D + j];
       hv += la.hv[((int64_t)ks * kMP + p) * D + j];
     }
@@ -676,17 +695,6 @@ __global__ __launch_bounds__(64 * (kGemmWaves + ((EPI == EPI_STEP || EPI == EPI_
 // Measured (tools/probes/nsk_probe.hip, the three-launch chain x 129 with a stand-in state update): 3.0 ms against the
 // split-K sequence's 4.55 ms; per launch 5.1 (204 workgroups) / 9.7 (404) / 5.2 us.
 // ------------------------------------------------------------------------------------------
-constexpr int kNskChunks = 104;                  // 16-deep chunks of a packed operand (K <= 1664), 13 per wave
-constexpr int kNskCpw = kNskChunks / kGemmWaves;
-constexpr int64_t kNskOperand = (int64_t)2 * kNskChunks * 256;   // floats of one packed [32 x 1664] operand
-constexpr int kNskOps = 6;                      // per lane: z (three rotating buffers), u1, u2, K^-1 product
-
-// nch: 16-deep chunks of the packed array — kNskChunks (K <= 1664), or 2 kNskChunks for the 3220-wide layers of the 2nd-order
-// mode (two rounds of 13 chunks per wave)
-__host__ __device__ __forceinline__ int64_t nsk_pack(int r, int k, int nch = kNskChunks) {
-  return (((int64_t)(r >> 4) * nch + (k >> 4)) * 64 + (r & 15) + 16 * ((k & 15) >> 2)) * 4 + (k & 3);
-}
-
 // NSK_OUT: the plain product, stored row-major [kMP][N] (the element-wise kernels of the 2nd-order sequence read it)
 enum { NSK_ACT1 = 1, NSK_ACT2 = 2, NSK_KR = 3, NSK_STEP = 4, NSK_STEP_NONET = 5, NSK_OUT = 6, NSK_UHA_MID = 7 };
 
@@ -726,6 +734,15 @@ struct NskArgs {
   float* keepU = nullptr;
   float* keepKr = nullptr;
   float* keepSn = nullptr;
+  // KIND 3 (r04): the backward activation consumer of the reverse sweep (the arithmetic of EPI_ACTB): d u = product (+ d u of
+  // the layer above), d a = d u sigmoid(pre); d u row-major, d a packed (the next launch's operand) and into the big matrix of
+  // the deferred contraction, column sums over the pass's particles (one workgroup per column tile: a single writer)
+  const float* bPre = nullptr;      // [kMP][IN] pre-activation of this layer (the forward's kept table)
+  const float* bDuPrev = nullptr;   // [kMP][IN] d u of the layer above (nullptr: none)
+  float* bDu = nullptr;             // [kMP][IN]
+  float* bDaBig = nullptr;          // [(K+1) n][IN] rows of this evaluation and pass
+  float* bSumA = nullptr;           // [IN] += sum_m d a
+  float* bSumU = nullptr;           // [IN] += sum_m d u (nullptr: not needed)
   // NSK_UHA_MID: F1 of the 2nd-order sequence (momentum refresh + half kick + drift, mcd_under_lp_a_cais.py:52-63) as the
   // consumer of its launch L3 (u2 W3)
   struct UhaMid {
@@ -977,8 +994,13 @@ __global__ __launch_bounds__(64 * kGemmWaves, (KIND || MERGED) ? 2 : 4) void lgc
   NskMidPre mp;
   float cu = 0.f, cb = 0.f;
   int64_t cix = 0;
+  float bpre = 0.f, bdup = 0.f;
   if (cons) {
-    if (MID) {
+    if (KIND == 3) {   // the backward consumer's own operands (earlier launches): issued ahead of the GEMM's loads
+      const int64_t ixc = (int64_t)min(row, a.M - 1) * sg.N + min(n, sg.N - 1);
+      bpre = a.bPre[ixc];
+      bdup = a.bDuPrev ? a.bDuPrev[ixc] : 0.f;
+    } else if (MID) {
       nsk_mid_loads(a, row, n, mp);
     } else if (STEP) {
       if (sg.epi == NSK_STEP) nsk_step_loads<false>(a, row, n, sp);
@@ -1043,6 +1065,45 @@ __global__ __launch_bounds__(64 * kGemmWaves, (KIND || MERGED) ? 2 : 4) void lgc
     for (int r = 0; r < 4; ++r) red[wv][256 + r * 64 + lane] = t2[r];
   }
   __syncthreads();
+  if (KIND == 3) {
+    // every wave stays to the second barrier (the column sums cross the waves); only consumer waves hold an element
+    __shared__ float csum[5][2][16];
+    float v = 0.f;
+    if (wv < 4) {
+#pragma unroll
+      for (int w = 0; w < kGemmWaves; ++w) v += red[w][wv * 64 + lane];        // fixed order
+    } else if (MERGED && wv == 4) {
+      const int r = lane >> 4, c = lane & 15;
+#pragma unroll
+      for (int w = 0; w < kGemmWaves; ++w)
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) v += red[w][256 + r * 64 + c + 16 * kq];
+    }
+    float da = 0.f, du = 0.f;
+    if (live) {
+      const int64_t ix = (int64_t)row * sg.N + n;
+      du = v + bdup;
+      da = du * sigmoid_fast(bpre);
+      a.bDu[ix] = du;
+      a.outA[nsk_pack(row, n, a.nch_out)] = da;
+      a.bDaBig[ix] = da;
+    }
+    if (cons) {
+      float sa = da, su = du;     // rows of this wave: the four lane groups that share a column
+      sa += __shfl_xor(sa, 16); sa += __shfl_xor(sa, 32);
+      su += __shfl_xor(su, 16); su += __shfl_xor(su, 32);
+      if (lane < 16) { csum[wv][0][lane] = sa; csum[wv][1][lane] = su; }
+    }
+    __syncthreads();
+    if (wv == 0 && lane < 16 && n < sg.N) {
+      float ta = 0.f, tu = 0.f;
+      const int nw = MERGED ? 5 : 4;
+      for (int w = 0; w < nw; ++w) { ta += csum[w][0][lane]; tu += csum[w][1][lane]; }   // fixed order
+      a.bSumA[n] += ta;
+      if (a.bSumU) a.bSumU[n] += tu;
+    }
+    return;
+  }
   if (!cons) return;
   float v = 0.f;
   if (wv < 4) {
@@ -1089,19 +1150,20 @@ struct NskPackArgs {
   float* dst[4];
   int K[4], N[4], ntile[4];
   int nch[4];          // chunks per tile of the packed copy (0: kNskChunks)
+  int ld[4];           // row stride of the source (0: N)
 };
 __global__ void lgcp_nsk_pack_kernel(NskPackArgs a) {
   const int q = blockIdx.y;
   const float* __restrict__ src = a.src[q];
   if (!src) return;
-  const int K = a.K[q], N = a.N[q], nch = a.nch[q] ? a.nch[q] : kNskChunks;
+  const int K = a.K[q], N = a.N[q], nch = a.nch[q] ? a.nch[q] : kNskChunks, ld = a.ld[q] ? a.ld[q] : N;
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;          // (tile, chunk, lane)
   if (g >= (int64_t)a.ntile[q] * nch * 64) return;
   const int lane = (int)(g & 63), chunk = (int)((g >> 6) % nch), tile = (int)((g >> 6) / nch);
   const int n = tile * 16 + (lane & 15), k0 = chunk * 16 + 4 * (lane >> 4);
   f32x4 v;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) v[j] = (n < N && k0 + j < K) ? src[(int64_t)(k0 + j) * N + n] : 0.f;
+  for (int j = 0; j < 4; ++j) v[j] = (n < N && k0 + j < K) ? src[(int64_t)(k0 + j) * ld + n] : 0.f;
   reinterpret_cast<f32x4*>(a.dst[q])[g] = v;
 }
 
@@ -1880,6 +1942,7 @@ struct LgcpGradWs {
   int64_t U1, U2, DA1, DA2;                    // [(K+1) n][IN]
   int64_t kpre1, kpre2, kkr, ksn;              // [(K+1) n][IN] x 2, [(K+1) n][D] x 2: kept by the forward (lgcp_keep); 0 floats when off
   bool keep;
+  int64_t bops, wt3p, wt2p, wt1p;              // keep: packed dO | v | da2 | da1 operands and packed W3^T, W2^T, W1[:D]^T
   int64_t DO;                                  // [(K+1) n][D]
   int64_t S, S2, gbeta, geps, gfac, gb2;       // tables (gfac: [K+1] per-evaluation terms)
   int64_t adjpart, gb_lo, ge_lo, gb_hi, ge_hi; // adjoint step partial sums and their per-evaluation reductions
@@ -1919,6 +1982,12 @@ static LgcpGradWs lgcp_grad_ws(const cmcd_desc& d, int64_t n) {
   w.keep = lgcp_nsk_ok(d) && d.mode != CMCD_MODE_CAIS_UHA_SN && R * (2 * IN + 2 * D) <= (int64_t(1) << 28);
   w.kpre1 = take(w.keep ? R * IN : 0); w.kpre2 = take(w.keep ? R * IN : 0);
   w.kkr = take(w.keep ? R * D : 0); w.ksn = take(w.keep ? R * D : 0);
+  {
+    const int64_t tIN = (IN + 15) / 16, tD = D / 16;
+    w.bops = take(w.keep ? 4 * kNskOperand : 0);
+    w.wt3p = take(w.keep ? tIN * kNskChunks * 256 : 0); w.wt2p = take(w.keep ? tIN * kNskChunks * 256 : 0);
+    w.wt1p = take(w.keep ? tD * kNskChunks * 256 : 0);
+  }
   w.total = o;
   return w;
 }
@@ -1970,6 +2039,19 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
   const float mu0 = 3.8812819069514780f;
   const dim3 gblock(64 * kGemmWaves);
   const int cbD = (D + 63) / 64, cbIN = (IN + 63) / 64;
+  // r04: with the activations kept, passes of <= 20 particles run the three backward products on the no-split-K GEMM too
+  // (lgcp_nsk_kernel<3, ..>: the backward activation as the consumer, column sums by the tile's one workgroup); the packed
+  // W3^T / W2^T / W1[:D]^T copies are made once per call, K^-1 is the forward's packed copy
+  const int tIN = (IN + 15) / 16, tD = D / 16;
+  const bool nskb_ok = g.keep && net;
+  if (nskb_ok) {
+    NskPackArgs pk{};
+    pk.src[0] = gws + g.wt3; pk.dst[0] = gws + g.wt3p; pk.K[0] = D; pk.N[0] = IN; pk.ntile[0] = tIN;
+    pk.src[1] = gws + g.wt2; pk.dst[1] = gws + g.wt2p; pk.K[1] = IN; pk.N[1] = IN; pk.ntile[1] = tIN;
+    pk.src[2] = gws + g.wt1; pk.dst[2] = gws + g.wt1p; pk.K[2] = IN; pk.N[2] = D; pk.ntile[2] = tD; pk.ld[2] = IN;   // first D columns of W1^T
+    const int64_t groups = (int64_t)tIN * kNskChunks * 64;
+    hipLaunchKernelGGL(lgcp_nsk_pack_kernel, dim3((unsigned)((groups + 255) / 256), 3), dim3(256), 0, stream, pk);
+  }
   // Two streams: the forward recompute of evaluation e-1 (side stream, its own buffer set) overlaps the adjoint /
   // backward launches of evaluation e (caller's stream).  Every kernel here is launch-latency-bound, so the two
   // chains run side by side; events order the hand-overs (fork / join, capturable in a graph).
@@ -2001,6 +2083,10 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
       if (hipMemsetAsync(gws + g.gmu_acc, 0, sizeof(float) * 2 * ((kMP * (int64_t)D + 3) & ~3), stream) != hipSuccess) return CMCD_ERR_HIP;
     }
     if (!kept && (hipEventRecord(ev_fork, stream) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess)) return CMCD_ERR_HIP;
+    const bool nskb = nskb_ok && kept && M <= 20;      // (21 .. 32 particles: two workgroups per column tile — the split-K form)
+    float* const dOp = gws + g.bops, *vp = dOp + kNskOperand, *da2p = vp + kNskOperand, *da1p = da2p + kNskOperand;
+    // the padding of the packed operands (rows >= M, inputs past the contraction) must read as zeros
+    if (nskb && hipMemsetAsync(dOp, 0, sizeof(float) * 4 * kNskOperand, stream) != hipSuccess) return CMCD_ERR_HIP;
 
     // forward recompute at z_e into buffer set e & 1, on stream st: the forward path's three launches (activations
     // fused into the GEMMs; the third has no consumer here: the adjoint step sums its slabs)
@@ -2074,6 +2160,7 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
         aa.DObig = gws + g.DO; aa.lay = lay; aa.n = n; aa.base = base;
         aa.M = M; aa.D = D; aa.K = K; aa.e = ev; aa.grad_clipping = d.grad_clipping; aa.omega = omega;
         aa.ula = ula; aa.omega_vec = omega_vec; aa.gktab = reinterpret_cast<const uint32_t*>(ws + w.gktab); aa.bptt = bptt ? 1 : 0; aa.var_mode = d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0;
+        if (nskb) { aa.dOp = dOp; aa.vp = vp; }
         return aa;
       };
       // kept + reparameterised: the step of evaluation e was fused behind lambda_{e+1} by the previous iteration
@@ -2092,6 +2179,42 @@ int lgcp_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw, in
         if (fuse && e > 0) hipLaunchKernelGGL(lgcp_lam_adj_kernel, dim3(cbD, M), dim3(64), 0, stream, la, adj_args(e - 1));
         else hipLaunchKernelGGL(lgcp_lam_finish_kernel, dim3((M * D + 255) / 256), dim3(256), 0, stream, la);
         if (!kept && hipEventRecord(ev_bwd[e & 1], stream) != hipSuccess) return CMCD_ERR_HIP;
+        continue;
+      }
+      const int er_b = ula == 2 ? (e > 0 ? e - 1 : 0) : e;       // the time index the network saw at this evaluation
+      if (nskb) {
+        const bool merged = M > 16;
+        auto launch3 = [&](NskArgs& na, int tiles) {
+          if (merged) hipLaunchKernelGGL((lgcp_nsk_kernel<3, true>), dim3((unsigned)tiles, 1), gblock, 0, stream, na);
+          else hipLaunchKernelGGL((lgcp_nsk_kernel<3, false>), dim3((unsigned)tiles, 1), gblock, 0, stream, na);
+        };
+        NskArgs na{};
+        na.M = M; na.D = D; na.IN = IN;
+        // d u2 = d o W3^T, d a2 = d u2 sigmoid(pre2)
+        na.seg[0] = NskSeg{dOp, gws + g.wt3p, IN, 0, 0.f}; na.nt0 = tIN;
+        na.bPre = e_pre2; na.bDuPrev = nullptr; na.bDu = gws + g.du2; na.outA = da2p; na.bDaBig = gws + g.DA2 + row0 * IN;
+        na.bSumA = gws + g.gb2; na.bSumU = nullptr;
+        launch3(na, tIN);
+        // d u1 = d u2 + d a2 W2^T, d a1 = d u1 sigmoid(pre1)
+        na.seg[0] = NskSeg{da2p, gws + g.wt2p, IN, 0, 0.f};
+        na.bPre = e_pre1; na.bDuPrev = gws + g.du2; na.bDu = gws + g.du1; na.outA = da1p; na.bDaBig = gws + g.DA1 + row0 * IN;
+        na.bSumA = gws + g.S + (int64_t)er_b * IN; na.bSumU = gws + g.S2 + (int64_t)er_b * IN;
+        launch3(na, tIN);
+        if (!bptt) continue;
+        // d a1 W1[:D]^T | v K^-1: plain products, row-major
+        NskArgs nb{};
+        nb.M = M; nb.D = D; nb.IN = IN;
+        nb.seg[0] = NskSeg{da1p, gws + g.wt1p, D, NSK_OUT, 0.f}; nb.nt0 = tD; nb.outN = gws + g.dxf;
+        nb.seg[1] = NskSeg{vp, ws + w.kip, D, NSK_KR, 0.f}; nb.krOutN = gws + g.hv;
+        if (merged) hipLaunchKernelGGL((lgcp_nsk_kernel<0, true>), dim3((unsigned)(2 * tD), 1), gblock, 0, stream, nb);
+        else hipLaunchKernelGGL((lgcp_nsk_kernel<0, false>), dim3((unsigned)(2 * tD), 1), gblock, 0, stream, nb);
+        LgcpLamArgs la{};
+        la.params = params; la.tc = tc; la.traj = traj; la.dxf = gws + g.dxf; la.hv = gws + g.hv; la.du1 = gws + g.du1;
+        la.v = gws + g.v; la.lam_part = gws + g.lam_part; la.gprev = gws + g.gprev; la.lamn = gws + g.lamn;
+        la.gE = gws + g.gE; la.gmu_acc = gws + g.gmu_acc; la.glam_acc = gws + g.glam_acc; la.lay = lay; la.n = n;
+        la.base = base; la.M = M; la.D = D; la.IN = IN; la.e = e; la.omega = omega; la.nslab = 1;
+        if (fuse && e > 0) hipLaunchKernelGGL(lgcp_lam_adj_kernel, dim3(cbD, M), dim3(64), 0, stream, la, adj_args(e - 1));
+        else hipLaunchKernelGGL(lgcp_lam_finish_kernel, dim3((M * D + 255) / 256), dim3(256), 0, stream, la);
         continue;
       }
       // ---- net backward: d u2 = d o W3^T, then d a2 = d u2 sigmoid(pre2) as the GEMM's consumer
