@@ -2772,6 +2772,7 @@ struct LgcpUhaGradWs {
   int64_t sc;                                   // [(K+1)][n][8]
   int64_t kpre1, kpre2, ksn, kkr;               // kept by the forward (lgcp_uha_keep): [2 K n][IN] x 2, [2 K n][D], [(K+1) n][D]
   bool keep;
+  int64_t bops, wt3p, wt2p, wt1p, kip1;         // keep: packed dO | v (one round) | da2 | da1 (two rounds), packed W3^T, W2^T, W1[:2D]^T, K^-1
   int64_t total;
 };
 
@@ -2804,6 +2805,12 @@ static LgcpUhaGradWs lgcp_uha_grad_ws(const cmcd_desc& d, int64_t n) {
   w.keep = lgcp_uha_nsk_ok(d) && R * (2 * IN + D) + (K + 1) * n * D <= (int64_t(1) << 28);
   w.kpre1 = take(w.keep ? R * IN : 0); w.kpre2 = take(w.keep ? R * IN : 0);
   w.ksn = take(w.keep ? R * D : 0); w.kkr = take(w.keep ? (K + 1) * n * D : 0);
+  {
+    const int64_t tIN = (IN + 15) / 16, tD = D / 16, t2D = 2 * D / 16, c1 = kNskChunks * 256, c2 = 2 * c1;
+    w.bops = take(w.keep ? 6 * kNskOperand : 0);        // dO, v: kNskOperand each; da2, da1: 2 kNskOperand each
+    w.wt3p = take(w.keep ? tIN * c1 : 0); w.wt2p = take(w.keep ? tIN * c2 : 0); w.wt1p = take(w.keep ? t2D * c2 : 0);
+    w.kip1 = take(w.keep ? tD * c1 : 0);
+  }
   w.total = o;
   return w;
 }
@@ -2824,6 +2831,9 @@ struct LgcpUhaAdjArgs {
   const float* snA;          // [kSplit][kMP][D]  u2 W3 slabs of evaluation A / B
   const float* snB;
   int nslab = kSplit;        // slabs of kr / snA / snB to sum: kSplit (recomputed) or 1 (kept by the forward)
+  int bslab = kSplit;        // slabs of hv / dxf to sum: kSplit, or 1 (row-major outputs of the no-split-K launches)
+  float* dOp = nullptr;      // packed copies of dO / v for the no-split-K launches (nullptr: none)
+  float* vp = nullptr;
   const float* du1;          // [kMP][IN]  d u1 of the evaluation just back-propagated (residual path)
   const float* dxf;          // [kSplit][kMP][2D]  d a1 W1[:2D]^T
   float* zinA;               // [kMP][2D]
@@ -2927,6 +2937,7 @@ __global__ __launch_bounds__(256) void lgcp_uha_adj_point_kernel(LgcpUhaAdjArgs 
     a.gmu_acc[p * D + j] += a_gq * qiv;
     a.glam_acc[p * D + j] += a_gq * (-2.0f * gq);
     a.v[p * D + j] = msk * a_gp;
+    if (a.vp) a.vp[nsk_pack(p, j)] = msk * a_gp;
     a.lz[p * D + j] = lz;
   }
   sbl = block_sum_256(sbl, sh); sel = block_sum_256(sel, sh); sbh = block_sum_256(sbh, sh); seh = block_sum_256(seh, sh);
@@ -2956,7 +2967,7 @@ __global__ __launch_bounds__(256) void lgcp_uha_adj_b_kernel(LgcpUhaAdjArgs a) {
     float hv = 0.f, o = a.params[a.lay.g_b3 + j];
 #pragma unroll
     for (int ks = 0; ks < kSplit; ++ks) {
-      hv += a.hv[((int64_t)ks * kMP + p) * D + j];
+      hv += ks < a.bslab ? a.hv[((int64_t)ks * kMP + p) * D + j] : 0.f;
       o += ks < a.nslab ? a.snB[((int64_t)ks * kMP + p) * D + j] : 0.f;
     }
     const float lz = a.lz[p * D + j] - hv - pa * expf(ze) * a.v[p * D + j];     // H_p v = -K^-1 v - a e^z v
@@ -2974,6 +2985,7 @@ __global__ __launch_bounds__(256) void lgcp_uha_adj_b_kernel(LgcpUhaAdjArgs a) {
     geta += (2.0f * s2 - rhop) * gb - om * r * r * inv2eta * inv2eta;
     gfac += cot * o;
     a.dO[p * D + j] = cot * fac;
+    if (a.dOp) a.dOp[nsk_pack(p, j)] = cot * fac;
     a.DObig[((int64_t)(2 * i + 1) * a.n + pr) * D + j] = cot * fac;
   }
   geta = block_sum_256(geta, sh); gepsd = block_sum_256(gepsd, sh); gfac = block_sum_256(gfac, sh);
@@ -2999,8 +3011,8 @@ __global__ __launch_bounds__(256) void lgcp_uha_adj_a_kernel(LgcpUhaAdjArgs a) {
     float dz = a.du1[p * IN + j], dr = a.du1[p * IN + D + j], o = a.params[a.lay.g_b3 + j];   // residual path: d x += d u1[:2D]
 #pragma unroll
     for (int ks = 0; ks < kSplit; ++ks) {
-      dz += a.dxf[((int64_t)ks * kMP + p) * 2 * D + j];
-      dr += a.dxf[((int64_t)ks * kMP + p) * 2 * D + D + j];
+      dz += ks < a.bslab ? a.dxf[((int64_t)ks * kMP + p) * 2 * D + j] : 0.f;
+      dr += ks < a.bslab ? a.dxf[((int64_t)ks * kMP + p) * 2 * D + D + j] : 0.f;
       o += ks < a.nslab ? a.snA[((int64_t)ks * kMP + p) * D + j] : 0.f;
     }
     a.lz[p * D + j] += dz;
@@ -3012,6 +3024,7 @@ __global__ __launch_bounds__(256) void lgcp_uha_adj_a_kernel(LgcpUhaAdjArgs a) {
     a.lrn[p * D + j] = ome * arp - a.gb[p * D + j];
     gfac += cot * o;
     a.dO[p * D + j] = cot * fac;
+    if (a.dOp) a.dOp[nsk_pack(p, j)] = cot * fac;
     a.DObig[((int64_t)(2 * i) * a.n + pr) * D + j] = cot * fac;
   }
   geta = block_sum_256(geta, sh); gfac = block_sum_256(gfac, sh);
@@ -3029,8 +3042,8 @@ __global__ __launch_bounds__(256) void lgcp_uha_adj_fin_kernel(LgcpUhaAdjArgs a)
     float dz = a.du1[p * IN + j], dr = a.du1[p * IN + D + j];
 #pragma unroll
     for (int ks = 0; ks < kSplit; ++ks) {
-      dz += a.dxf[((int64_t)ks * kMP + p) * 2 * D + j];
-      dr += a.dxf[((int64_t)ks * kMP + p) * 2 * D + D + j];
+      dz += ks < a.bslab ? a.dxf[((int64_t)ks * kMP + p) * 2 * D + j] : 0.f;
+      dr += ks < a.bslab ? a.dxf[((int64_t)ks * kMP + p) * 2 * D + D + j] : 0.f;
     }
     a.lz[p * D + j] += dz;
     a.lr[p * D + j] = a.lrn[p * D + j] + dr;
@@ -3052,7 +3065,7 @@ __global__ __launch_bounds__(256) void lgcp_uha_adj_z0_kernel(LgcpUhaAdjArgs a) 
     const float z = a.traj[pr * D + j];
     float hv = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < kSplit; ++ks) hv += a.hv[((int64_t)ks * kMP + p) * D + j];
+    for (int ks = 0; ks < kSplit; ++ks) hv += ks < a.bslab ? a.hv[((int64_t)ks * kMP + p) * D + j] : 0.f;
     const float lz = a.lz[p * D + j] - hv - pa * expf(z) * a.v[p * D + j];
     const float mean = a.params[a.lay.vd_mean + j];
     const float sd = expf(a.params[a.lay.vd_logdiag + j]);
@@ -3118,6 +3131,17 @@ static int lgcp_uha_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLay
   const float* bias1 = ws + w.bias1;    // still in the forward workspace (lgcp_uha_forward's prep)
   const LgcpKeep keep = lgcp_uha_keep(d, n, gws);
   const bool kept = keep.on;
+  // r04: with the activations kept, passes of <= 20 particles run the seven products of a bridge on the no-split-K GEMM too
+  const int tIN = (IN + 15) / 16, tD = D / 16, t2D = 2 * D / 16, big = 2 * kNskChunks;
+  if (kept) {
+    NskPackArgs pk{};
+    pk.src[0] = gws + g.wt3; pk.dst[0] = gws + g.wt3p; pk.K[0] = D; pk.N[0] = IN; pk.ntile[0] = tIN;
+    pk.src[1] = gws + g.wt2; pk.dst[1] = gws + g.wt2p; pk.K[1] = IN; pk.N[1] = IN; pk.ntile[1] = tIN; pk.nch[1] = big;
+    pk.src[2] = gws + g.wt1; pk.dst[2] = gws + g.wt1p; pk.K[2] = IN; pk.N[2] = 2 * D; pk.ntile[2] = t2D; pk.nch[2] = big;
+    pk.src[3] = tc; pk.dst[3] = gws + g.kip1; pk.K[3] = D; pk.N[3] = D; pk.ntile[3] = tD;
+    const int64_t groups = (int64_t)tIN * big * 64;
+    hipLaunchKernelGGL(lgcp_nsk_pack_kernel, dim3((unsigned)((groups + 255) / 256), 4), dim3(256), 0, stream, pk);
+  }
 
   for (int64_t base = 0; base < n; base += kMP) {
     const int M = (int)((n - base) < kMP ? (n - base) : kMP);
@@ -3133,6 +3157,13 @@ static int lgcp_uha_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLay
     aa.glam_acc = gws + g.glam_acc; aa.geta = gws + g.geta; aa.gepsd = gws + g.gepsd; aa.sc = gws + g.sc;
     aa.lay = lay; aa.n = n; aa.base = base; aa.M = M; aa.D = D; aa.IN = IN; aa.K = K; aa.omega = omega;
 
+    const bool nskb = kept && M <= 20;
+    const bool merged = M > 16;
+    float* const dOp = gws + g.bops, *vp = dOp + kNskOperand, *da2p = vp + kNskOperand, *da1p = da2p + 2 * kNskOperand;
+    if (nskb) {
+      if (hipMemsetAsync(dOp, 0, sizeof(float) * 6 * kNskOperand, stream) != hipSuccess) return CMCD_ERR_HIP;
+      aa.dOp = dOp; aa.vp = vp; aa.bslab = 1;
+    }
     auto kr_at = [&](int e) {   // K^-1 (z_e - mu0)
       GemmArgs gm{};
       gm.M = M; gm.Kdim = D; gm.counters = counters;
@@ -3143,6 +3174,29 @@ static int lgcp_uha_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLay
     // back-propagation of one network evaluation (buffer set f, table row `row`, time index i) from the cotangent in dO:
     // leaves d u1 (residual path) and the d a1 W1[:2D]^T slabs
     auto net_backward = [&](const LgcpUhaFwdSet& f, int64_t row, int i) {
+      if (nskb) {
+        NskArgs na{};
+        na.M = M; na.D = 2 * D; na.IN = IN; na.nch_out = big;
+        // d u2 = d o W3^T (one round of the contraction), d a2 = d u2 sigmoid(pre2)
+        na.seg[0] = NskSeg{dOp, gws + g.wt3p, IN, 0, 0.f}; na.nt0 = tIN;
+        na.bPre = keep.pre2 + row * IN; na.bDuPrev = nullptr; na.bDu = gws + g.du2; na.outA = da2p;
+        na.bDaBig = gws + g.DA2 + row * IN; na.bSumA = gws + g.gb2; na.bSumU = nullptr;
+        if (merged) hipLaunchKernelGGL((lgcp_nsk_kernel<3, true>), dim3((unsigned)tIN, 1), gblock, 0, stream, na);
+        else hipLaunchKernelGGL((lgcp_nsk_kernel<3, false>), dim3((unsigned)tIN, 1), gblock, 0, stream, na);
+        // d u1 = d u2 + d a2 W2^T (two rounds), d a1 = d u1 sigmoid(pre1)
+        na.seg[0] = NskSeg{da2p, gws + g.wt2p, IN, 0, 0.f}; na.seg[0].nch = big;
+        na.bPre = keep.pre1 + row * IN; na.bDuPrev = gws + g.du2; na.bDu = gws + g.du1; na.outA = da1p;
+        na.bDaBig = gws + g.DA1 + row * IN; na.bSumA = gws + g.S + (int64_t)i * IN; na.bSumU = gws + g.S2 + (int64_t)i * IN;
+        if (merged) hipLaunchKernelGGL((lgcp_nsk_kernel<3, true, 2>), dim3((unsigned)tIN, 1), gblock, 0, stream, na);
+        else hipLaunchKernelGGL((lgcp_nsk_kernel<3, false, 2>), dim3((unsigned)tIN, 1), gblock, 0, stream, na);
+        // d a1 W1[:2D]^T: plain, row-major
+        NskArgs nb{};
+        nb.M = M; nb.D = 2 * D; nb.IN = IN;
+        nb.seg[0] = NskSeg{da1p, gws + g.wt1p, 2 * D, NSK_OUT, 0.f}; nb.seg[0].nch = big; nb.nt0 = t2D; nb.outN = gws + g.dxf;
+        if (merged) hipLaunchKernelGGL((lgcp_nsk_kernel<0, true, 2>), dim3((unsigned)t2D, 1), gblock, 0, stream, nb);
+        else hipLaunchKernelGGL((lgcp_nsk_kernel<0, false, 2>), dim3((unsigned)t2D, 1), gblock, 0, stream, nb);
+        return;
+      }
       GemmArgs gm{};
       gm.M = M; gm.counters = counters; gm.epi_seg = -1;
       gm.Kdim = D;
@@ -3164,6 +3218,14 @@ static int lgcp_uha_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLay
       hipLaunchKernelGGL(lgcp_gemm_kernel<EPI_NONE>, dim3(cb2D, kSplit), gblock, gemm_lds, stream, gm);
     };
     auto hv_product = [&]() {
+      if (nskb) {
+        NskArgs nb{};
+        nb.M = M; nb.D = 2 * D; nb.IN = IN;
+        nb.seg[0] = NskSeg{vp, gws + g.kip1, D, NSK_KR, 0.f}; nb.nt0 = tD; nb.krOutN = gws + g.hv;
+        if (merged) hipLaunchKernelGGL((lgcp_nsk_kernel<0, true>), dim3((unsigned)tD, 1), gblock, 0, stream, nb);
+        else hipLaunchKernelGGL((lgcp_nsk_kernel<0, false>), dim3((unsigned)tD, 1), gblock, 0, stream, nb);
+        return;
+      }
       GemmArgs gm{};
       gm.M = M; gm.Kdim = D; gm.counters = counters;
       gm.seg[0] = GemmSeg{gws + g.v, kinv, gws + g.hv, D, D, D, D};
