@@ -385,11 +385,18 @@ def test_graph_replayed_training_equals_eager_training(hip_lib, mode):
     assert float((out[True][1] - flat.double().cpu()).abs().max()) > 1e-3      # and it did train
 
 
-@pytest.mark.parametrize("n,K,clip", [(5, 3, False), (37, 2, True)])
-def test_lgcp_reparameterised_gradient_matches_autograd(hip_lib, param_set, n, K, clip):
+@pytest.mark.parametrize("form", [0, 3], ids=["kept_activations", "split_k_recompute"])
+@pytest.mark.parametrize("n,K,clip", [(5, 3, False), (37, 2, True), (20, 2, True)])
+def test_lgcp_reparameterised_gradient_matches_autograd(hip_lib, param_set, monkeypatch, n, K, clip, form):
     """d = 1600 (config 5): launch-sequence reverse sweep + deferred A^T B parameter contractions vs autograd
-    through the float64 restatement.  n = 37 spans two passes of 32 particles."""
+    through the float64 restatement.  n = 37 spans two passes of 32 and 5 particles, n = 20 is the named batch's pass (16 + 4
+    rows per workgroup).  form 0 (r04): the forward's consumers keep every evaluation's activations and the sweep runs on the
+    no-split-K GEMM where a pass has <= 20 particles (the 32-particle pass: kept activations, split-K products); form 3 pins
+    the split-K kernels, whose sweep recomputes each evaluation on a side stream (rounds 1 - 3)."""
     from helpers import lgcp_counts_fixture
+    if form == 3 and n == 20:
+        pytest.skip("the recompute form is covered by the two other shapes (suite time)")
+    monkeypatch.setattr(mcdbm, "KERNEL_VARIANT", form)
     counts = lgcp_counts_fixture()
     b = synthetic.build("lgcp_n20_k128", device="cuda", lgcp_counts=counts, nbridges=K, N=n, grad_clipping=clip,
                         init_eps=2e-3)

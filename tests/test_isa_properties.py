@@ -269,3 +269,14 @@ def test_second_order_sweep_has_no_float_atomics(uha_asm):
     assert not any("global_atomic_add_f32" in l for l in body)
     scratch = next(l for l in tail if "ScratchSize" in l)
     assert re.search(r"ScratchSize:\s*0\b", scratch), scratch
+
+
+@pytest.mark.parametrize("kern", ["_ZN4cmcd15lgcp_nsk_kernelILi3ELb1ELi1EEEvNS_7NskArgsE", "_ZN4cmcd15lgcp_nsk_kernelILi3ELb0ELi2EEEvNS_7NskArgsE"],
+                         ids=["merged_one_round", "two_rounds"])
+def test_reverse_sweep_gemm_consumer_sums_without_atomics(lgcp_asm, kern):
+    """r04: the backward activation consumer of the d = 1600 reverse sweep (lgcp_nsk_kernel<3, ..>) — its column sums over the
+    pass's particles have ONE writer per column (the tile's workgroup, fixed order through LDS): no atomics, no scratch."""
+    body, tail = _kernel(lgcp_asm, kern)
+    assert _scratch(tail) == 0
+    assert not any("atomic" in l for l in body)
+    assert sum("s_barrier" in l for l in body) >= 2      # cross-wave product sum, then the cross-wave column sums
