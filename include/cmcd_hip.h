@@ -222,7 +222,8 @@ int cmcd_bound_var_grad(const cmcd_desc* desc, const cmcd_layout* layout, const 
                         const float* omega, void* workspace, int64_t workspace_bytes, float* grad, void* stream);
 /* The same two steps without running the chain twice: cmcd_bound_var_forward is cmcd_bound_forward on the
  * GRADIENT workspace (cmcd_grad_workspace_bytes) and leaves the per-call tables — and, for batches small
- * enough for the work-item gradient path, the trajectory z_0..z_K — there; cmcd_bound_var_grad_kept then
+ * enough for the work-item gradient path, the trajectory z_0..z_K (lgcp: also every evaluation's activations, which the
+ * reverse launch sequence then reads instead of recomputing them) — there; cmcd_bound_var_grad_kept then
  * needs the same desc / seeds / params / workspace, untouched in between (weights from
  * cmcd_vargrad_weights as before). */
 int cmcd_bound_var_forward(const cmcd_desc* desc, const cmcd_layout* layout, const int32_t* seeds, int64_t n,
