@@ -371,6 +371,8 @@ def main():
     ap.add_argument("--config", default=None, help="name in cmcd_amd.synthetic.CONFIGS")
     ap.add_argument("--particles", type=int, default=None, help="override N per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-step", action="store_true",
+                    help="with --config: also time value-and-gradient of that configuration's own training loss (training_step)")
     ap.add_argument("--forward-only", action="store_true",
                     help="skip the vargrad / training_step legs (their trajectory-keeping forward launches would be averaged "
                          "into the same kernel name by rocprofv3 --stats)")
@@ -742,6 +744,26 @@ def main():
             torch.cuda.synchronize()
             tg = (time.perf_counter() - tg0) / 40
             result["training_step"] = {"ms_per_value_and_grad": tg * 1e3, "value": n * K / tg,
+                                       "unit": "bridge-steps*particles/s (forward + reverse sweep)"}
+        except NotImplementedError as e:
+            result["training_step"] = {"error": str(e)}
+
+    if rank == 0 and world == 1 and args.train_step and name != synthetic.NORTH_STAR:
+        # --train-step: value-and-gradient of THIS configuration's own training loss on the same batch (the VarGrad loss for
+        # MCD_CAIS_var_sn, the reparameterised gradient otherwise) — the per-configuration lines of profiles/*_all_configs.jsonl
+        try:
+            fn = mcdbm.compute_log_var_grad if b["params_fixed"][2] == "MCD_CAIS_var_sn" else mcdbm.compute_bound_grad
+            gargs = (seeds, b["params_flat"], b["unflatten"], b["params_fixed"], b["target"])
+            gkw = dict(eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
+            for _ in range(5):
+                fn(*gargs, **gkw)
+            torch.cuda.synchronize()
+            tg0 = time.perf_counter()
+            for _ in range(20):
+                fn(*gargs, **gkw)
+            torch.cuda.synchronize()
+            tg = (time.perf_counter() - tg0) / 20
+            result["training_step"] = {"ms_per_value_and_grad": tg * 1e3, "value": n * K / tg, "loss": fn.__name__,
                                        "unit": "bridge-steps*particles/s (forward + reverse sweep)"}
         except NotImplementedError as e:
             result["training_step"] = {"error": str(e)}

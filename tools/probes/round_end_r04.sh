@@ -90,6 +90,6 @@ python3 tools/probes/lgcp_time.py 20 32 64 128 600 2048 15000 > $O/lgcp_sizes.tx
 bash tools/probes/lgcp_nsk_prof.sh $T > /dev/null 2>&1
 bash tools/probes/lgcp_wide_prof.sh 600 $T > /dev/null 2>&1
 for c in gmm_n300_k8 funnel_n300_k64 many_gmm_n2000_k256_dds many_gmm_var_n16000_k256 lgcp_n20_k128; do
-  python3 bench.py --config $c --no-cpu-baseline --saturated 0 --no-legs 2>/dev/null | tail -1
+  python3 bench.py --config $c --no-cpu-baseline --saturated 0 --no-legs --train-step 2>/dev/null | tail -1
 done > $O/all_configs.jsonl
 head -c 600 $O/bench.json; echo; head -6 $O/kernel_stats.csv | cut -c1-160; head -5 $O/kernel_stats_cfg4_shard.csv | cut -c1-160
