@@ -1610,8 +1610,9 @@ __global__ __launch_bounds__(256) void grad_det_reduce_kernel(DetArgs a) {
   if (q == 0 && dst) *dst = ((part[0][l] + part[1][l]) + part[2][l]) + part[3][l];
 }
 // slot floats per tile, and the cap above which the accumulation falls back to float atomics (the table is written and
-// read once per gradient: 128 MB is ~30 us of HBM time; a 2000-particle shard of K = 256 needs 30 MB)
-constexpr int64_t kDetCapFloats = int64_t(1) << 25;
+// read once per gradient: 1 GB is ~0.3 ms of HBM time against the ~30 ms such a batch's sweep takes; a 2000-particle shard of
+// K = 256 needs 30 MB, 65 536 particles 290 MB)
+constexpr int64_t kDetCapFloats = int64_t(1) << 28;
 static int64_t grad_det_tile_floats(const cmcd_desc& d, int HP) {
   const int64_t K1 = d.nbridges + 1;
   return K1 * HP * (d.arch == CMCD_ARCH_GEFFNER ? 2 : 1) + K1 * 4;

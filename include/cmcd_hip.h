@@ -246,7 +246,7 @@ int cmcd_bound_var_grad_kept(const cmcd_desc* desc, const cmcd_layout* layout, c
  * 64 on funnel), and lgcp (geffner, any width: launch-sequence reverse sweep); CMCD_ERR_UNSUPPORTED otherwise.
  * Repeated calls with the same arguments return the same bits (r04): every sum over particles is taken in a fixed order
  * — per-tile slots + a reduction launch; the workspace holds the slots — for gmm / funnel / many_gmm in every mode, up to a
- * slot table of 128 MB (about 30 000 particles at K = 256 with the 64-wide dds net, 870 000 at K = 8); above it the overdamped modes'
+ * slot table of 1 GB (about 245 000 particles at K = 256 with the 64-wide dds net); above it the overdamped modes'
  * bias-row and schedule sums fall back to float atomics and the last bits may differ from call to call.  (The
  * reference's own gradients are XLA reductions: deterministic on one device.) */
 int64_t cmcd_bound_grad_workspace_bytes(const cmcd_desc* desc, int64_t n);

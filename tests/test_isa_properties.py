@@ -254,7 +254,7 @@ def test_narrow_gradient_instances_fit_two_workgroups_per_cu(grad_asm, kern):
 
 def test_gradient_table_sums_have_a_store_path(grad_asm):
     """r04: the bias-row / schedule sums over tiles are per-tile slot stores + a fixed-order reduction launch; the float
-    atomics of rounds 1 - 3 survive as the fallback for slot tables past 128 MB only (both paths are in the instance)."""
+    atomics of rounds 1 - 3 survive as the fallback for slot tables past 1 GB only (both paths are in the instance)."""
     body, _ = _kernel(grad_asm, NARROW_GRAD[3])
     assert any("global_store_dword" in l for l in body)
     assert any(l.startswith("_ZN4cmcd22grad_det_reduce_kernelENS_7DetArgsE") for l in grad_asm)
