@@ -2889,9 +2889,12 @@ __global__ void lgcp_uha_xin_kernel(LgcpUhaAdjArgs a) {
   xb[j] = z; xb[D + j] = a.traj[((int64_t)(2 * K + 2 + i) * a.n + pr) * D + j];
 }
 
+// r04: the per-bridge adjoint kernels run kUhaAdjW waves per particle (20 blocks of one 256-thread workgroup were latency
+// chains: what they needed was width, as the forward's closing step got); block sums in wave order (fixed)
+constexpr int kUhaAdjW = 16;
 // point e: cotangents of ub (bridge e - 1) and uf (bridge e) at z_e, v = clipmask . a_gp for the Hessian product, q gradients
-__global__ __launch_bounds__(256) void lgcp_uha_adj_point_kernel(LgcpUhaAdjArgs a) {
-  __shared__ float sh[4];
+__global__ __launch_bounds__(64 * kUhaAdjW) void lgcp_uha_adj_point_kernel(LgcpUhaAdjArgs a) {
+  __shared__ float sh[kUhaAdjW];
   const int p = blockIdx.x, D = a.D, K = a.K, e = a.e;
   const int64_t pr = a.base + p;
   const float* counts = a.tc + (int64_t)D * D;
@@ -2940,7 +2943,7 @@ __global__ __launch_bounds__(256) void lgcp_uha_adj_point_kernel(LgcpUhaAdjArgs 
     if (a.vp) a.vp[nsk_pack(p, j)] = msk * a_gp;
     a.lz[p * D + j] = lz;
   }
-  sbl = block_sum_256(sbl, sh); sel = block_sum_256(sel, sh); sbh = block_sum_256(sbh, sh); seh = block_sum_256(seh, sh);
+  sbl = block_sum_n<kUhaAdjW>(sbl, sh); sel = block_sum_n<kUhaAdjW>(sel, sh); sbh = block_sum_n<kUhaAdjW>(sbh, sh); seh = block_sum_n<kUhaAdjW>(seh, sh);
   if (threadIdx.x == 0) {
     float* o = a.sc + ((int64_t)e * a.n + pr) * 8;
     o[0] = sbl; o[1] = sel; o[2] = sbh; o[3] = seh;
@@ -2948,8 +2951,8 @@ __global__ __launch_bounds__(256) void lgcp_uha_adj_point_kernel(LgcpUhaAdjArgs 
 }
 
 // bridge i = e - 1, first half: finish lz_e with the Hessian product, leap-frog adjoints, g_b and the cotangent of s2
-__global__ __launch_bounds__(256) void lgcp_uha_adj_b_kernel(LgcpUhaAdjArgs a) {
-  __shared__ float sh[4];
+__global__ __launch_bounds__(64 * kUhaAdjW) void lgcp_uha_adj_b_kernel(LgcpUhaAdjArgs a) {
+  __shared__ float sh[kUhaAdjW];
   const int p = blockIdx.x, D = a.D, K = a.K, e = a.e, i = e - 1;
   const int64_t pr = a.base + p;
   const float pa = a.tc[(int64_t)D * D + D + 1];
@@ -2988,7 +2991,7 @@ __global__ __launch_bounds__(256) void lgcp_uha_adj_b_kernel(LgcpUhaAdjArgs a) {
     if (a.dOp) a.dOp[nsk_pack(p, j)] = cot * fac;
     a.DObig[((int64_t)(2 * i + 1) * a.n + pr) * D + j] = cot * fac;
   }
-  geta = block_sum_256(geta, sh); gepsd = block_sum_256(gepsd, sh); gfac = block_sum_256(gfac, sh);
+  geta = block_sum_n<kUhaAdjW>(geta, sh); gepsd = block_sum_n<kUhaAdjW>(gepsd, sh); gfac = block_sum_n<kUhaAdjW>(gfac, sh);
   if (threadIdx.x == 0) {
     a.geta[p] = geta; a.gepsd[p] = gepsd;
     a.sc[((int64_t)i * a.n + pr) * 8 + 6] = gfac;
@@ -2996,8 +2999,8 @@ __global__ __launch_bounds__(256) void lgcp_uha_adj_b_kernel(LgcpUhaAdjArgs a) {
 }
 
 // bridge i, second half: d [z; rho'] of s2 arrives; cotangent of s1
-__global__ __launch_bounds__(256) void lgcp_uha_adj_a_kernel(LgcpUhaAdjArgs a) {
-  __shared__ float sh[4];
+__global__ __launch_bounds__(64 * kUhaAdjW) void lgcp_uha_adj_a_kernel(LgcpUhaAdjArgs a) {
+  __shared__ float sh[kUhaAdjW];
   const int p = blockIdx.x, D = a.D, K = a.K, i = a.e - 1, IN = a.IN;
   const int64_t pr = a.base + p;
   const float eps = a.sched[8 * i + 1];
@@ -3027,7 +3030,7 @@ __global__ __launch_bounds__(256) void lgcp_uha_adj_a_kernel(LgcpUhaAdjArgs a) {
     if (a.dOp) a.dOp[nsk_pack(p, j)] = cot * fac;
     a.DObig[((int64_t)(2 * i) * a.n + pr) * D + j] = cot * fac;
   }
-  geta = block_sum_256(geta, sh); gfac = block_sum_256(gfac, sh);
+  geta = block_sum_n<kUhaAdjW>(geta, sh); gfac = block_sum_n<kUhaAdjW>(gfac, sh);
   if (threadIdx.x == 0) {
     a.geta[p] += geta;
     a.sc[((int64_t)i * a.n + pr) * 8 + 7] = gfac;
@@ -3035,7 +3038,7 @@ __global__ __launch_bounds__(256) void lgcp_uha_adj_a_kernel(LgcpUhaAdjArgs a) {
 }
 
 // bridge i, end: d [z; rho] of s1 arrives -> (lz, lr) of point i (its Hessian part follows in the point kernel)
-__global__ __launch_bounds__(256) void lgcp_uha_adj_fin_kernel(LgcpUhaAdjArgs a) {
+__global__ __launch_bounds__(64 * kUhaAdjW) void lgcp_uha_adj_fin_kernel(LgcpUhaAdjArgs a) {
   const int p = blockIdx.x, D = a.D, i = a.e - 1, IN = a.IN;
   const int64_t pr = a.base + p;
   for (int j = threadIdx.x; j < D; j += blockDim.x) {
@@ -3247,7 +3250,7 @@ static int lgcp_uha_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLay
         aa.kr = keep.kr + ((int64_t)e * n + base) * D;
         aa.snA = keep.sn + rowA * D; aa.snB = keep.sn + rowB * D;
       }
-      hipLaunchKernelGGL(lgcp_uha_adj_point_kernel, dim3(M), dim3(256), 0, stream, aa);
+      hipLaunchKernelGGL(lgcp_uha_adj_point_kernel, dim3(M), dim3(64 * kUhaAdjW), 0, stream, aa);
       hv_product();
       if (!kept) hipLaunchKernelGGL(lgcp_uha_gather_kernel, dim3((M * D + 255) / 256), dim3(256), 0, stream, aa);
       const LgcpUhaFwdSet& fa = g.fs[0];
@@ -3258,16 +3261,16 @@ static int lgcp_uha_grad(const cmcd_desc& d, const cmcd_layout& lay, const WsLay
         lgcp_uha_net(d, lay, params, kinv, M, i, gws + fb.zin, bias1, gws + fb.slab1, gws + fb.pre1, gws + fb.u1, gws + fb.slab2,
                      gws + fb.pre2, gws + fb.u2, gws + fb.sn, nullptr, nullptr, counters, gemm_lds, stream);
       }
-      hipLaunchKernelGGL(lgcp_uha_adj_b_kernel, dim3(M), dim3(256), 0, stream, aa);
+      hipLaunchKernelGGL(lgcp_uha_adj_b_kernel, dim3(M), dim3(64 * kUhaAdjW), 0, stream, aa);
       net_backward(fb, rowB, i);
-      hipLaunchKernelGGL(lgcp_uha_adj_a_kernel, dim3(M), dim3(256), 0, stream, aa);
+      hipLaunchKernelGGL(lgcp_uha_adj_a_kernel, dim3(M), dim3(64 * kUhaAdjW), 0, stream, aa);
       net_backward(fa, rowA, i);
-      hipLaunchKernelGGL(lgcp_uha_adj_fin_kernel, dim3(M), dim3(256), 0, stream, aa);
+      hipLaunchKernelGGL(lgcp_uha_adj_fin_kernel, dim3(M), dim3(64 * kUhaAdjW), 0, stream, aa);
       if (!kept) kr_at(i);
     }
     aa.e = 0;
     if (kept) aa.kr = keep.kr + base * D;
-    hipLaunchKernelGGL(lgcp_uha_adj_point_kernel, dim3(M), dim3(256), 0, stream, aa);
+    hipLaunchKernelGGL(lgcp_uha_adj_point_kernel, dim3(M), dim3(64 * kUhaAdjW), 0, stream, aa);
     hv_product();
     hipLaunchKernelGGL(lgcp_uha_adj_z0_kernel, dim3(M), dim3(256), 0, stream, aa);
     hipLaunchKernelGGL(lgcp_colsum_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, gws + g.gmu_acc, (int64_t)M, D, D,
