@@ -1954,11 +1954,16 @@ struct UhaReduceArgs {
   int32_t nslabs, nw, HP, D, wid, arch;
 };
 
-__global__ __launch_bounds__(256) void uha_reduce_kernel(UhaReduceArgs a) {
-  // block = 32 outputs x 8 groups of slabs: thread (o, gr) sums its eighth of the terms in slab order with eight loads in
-  // flight, the eight partial sums are added in group order — a fixed order whatever the launch (the work-item path writes up
-  // to 512 slabs: one thread per output with one dependent load per slab took 0.32 ms)
-  __shared__ float red[8][32];
+#ifndef UHA_RED_GROUPS
+#define UHA_RED_GROUPS 32
+#endif
+constexpr int kRedG = UHA_RED_GROUPS;
+__global__ __launch_bounds__(32 * kRedG) void uha_reduce_kernel(UhaReduceArgs a) {
+  // block = 32 outputs x kRedG groups of slabs: thread (o, gr) sums its share of the terms in slab order with eight loads in
+  // flight, the partial sums are added in group order — a fixed order whatever the launch (the work-item path writes up
+  // to 512 slabs: one thread per output with one dependent load per slab took 0.32 ms; r04: 32 groups instead of 8 — the
+  // per-wave outputs have 2048 terms, 32 dependent rounds of eight loads per thread were the launch's 30 us)
+  __shared__ float red[kRedG][32];
   const int HP = a.HP, D = a.D, DIN = 2 * D, wid = a.wid;
   const bool dds = a.arch == CMCD_ARCH_DDS;
   const int64_t o_w1 = dds ? a.lay.d_sw1 : a.lay.g_w1, o_w2 = dds ? a.lay.d_sw2 : a.lay.g_w2;
@@ -1994,7 +1999,7 @@ __global__ __launch_bounds__(256) void uha_reduce_kernel(UhaReduceArgs a) {
     auto term = [&](int64_t t) -> int64_t {
       return perwave ? (t / a.nw) * a.slab_stride + base + (t % a.nw) * per + off : t * a.slab_stride + off;
     };
-    const int64_t chunk = (nterms + 7) / 8;
+    const int64_t chunk = (nterms + kRedG - 1) / kRedG;
     int64_t t = gr * chunk;
     const int64_t tend = t + chunk < nterms ? t + chunk : nterms;
     for (; t + 8 <= tend; t += 8) {
@@ -2011,7 +2016,7 @@ __global__ __launch_bounds__(256) void uha_reduce_kernel(UhaReduceArgs a) {
   if (gr == 0 && dst >= 0) {
     float tot = red[0][ol];
 #pragma unroll
-    for (int q = 1; q < 8; ++q) tot += red[q][ol];
+    for (int q = 1; q < kRedG; ++q) tot += red[q][ol];
     a.grad[dst] = tot;
   }
 }
@@ -2620,7 +2625,7 @@ int uha_grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& 
   ra.slabs = slabs; ra.grad = grad; ra.lay = lay; ra.slab_stride = ga.slab_stride; ra.nslabs = nslabs_used; ra.nw = nw;
   ra.HP = HP; ra.D = D; ra.wid = d.arch == CMCD_ARCH_DDS ? 64 : DIN + d.emb_dim; ra.arch = d.arch;
   const int64_t outs = (int64_t)ra.wid * ra.wid + (int64_t)ra.wid * D + (int64_t)DIN * ra.wid + ra.wid + 3 * D + 2;
-  hipLaunchKernelGGL(uha_reduce_kernel, dim3((unsigned)((outs + 31) / 32)), dim3(256), 0, stream, ra);
+  hipLaunchKernelGGL(uha_reduce_kernel, dim3((unsigned)((outs + 31) / 32)), dim3(32 * kRedG), 0, stream, ra);
   // the particle-independent tails: schedules (cos^2 always), time coder / embedding table with the network's state
   // inputs = 2 dim wide
   const int rc = launch_net_tails(d, DIN, CMCD_EPS_COS_SQ, lay, w, params, gws, ga.o_S, ga.o_S2, ga.o_gbeta, ga.o_geps, HP,

@@ -13,8 +13,8 @@ for v in "$@"; do
 import csv, sys
 out = []
 for r in csv.reader(open(sys.argv[1])):
-    if 'uha_grad_kernel' in r[0] or 'uha_coop' in r[0]:
-        out.append('%s %.1f us' % (r[0].split('<')[0].split('::')[-1] + '<' + r[0].split('<')[1].split('>')[0][-12:] + '>', float(r[3]) / 1000))
+    if 'uha_grad_kernel' in r[0] or 'uha_coop' in r[0] or 'uha_reduce' in r[0] or 'compose' in r[0]:
+        out.append('%s %.1f us' % (r[0].split('(')[0][-34:], float(r[3]) / 1000))
 print(sys.argv[2] + ': ' + ' | '.join(out))" $f $v
   rm -rf $O/prof_$v
 done
