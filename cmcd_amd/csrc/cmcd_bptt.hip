@@ -301,16 +301,18 @@ struct ScanArgs {
 };
 
 template <int D, int EB>
-__global__ void bptt_scan_kernel(ScanArgs a) {
+__global__ __launch_bounds__(64) void bptt_scan_kernel(ScanArgs a) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= a.n) return;
   constexpr int S = D * D + 2 * D;
   float lam[D];
 #pragma unroll
   for (int j = 0; j < D; ++j) lam[j] = 0.f;
-  // rows do not depend on lambda: fetch EB of them ahead of the EB dependent matrix-vector products
-  for (int e1 = a.K; e1 >= 0; e1 -= EB) {
-    float rows[EB][S];
+  // rows do not depend on lambda: fetch EB of them ahead of the EB dependent matrix-vector products — and (r04) the NEXT EB
+  // while these are consumed: one thread per particle is 32 waves on the whole chip, so the launch was 17 exposed load round
+  // trips (35 us at K = 256); double-buffered, the recursion runs behind one
+  float cur[EB][S], nxt[EB][S];
+  auto fetch = [&](float (&rows)[EB][S], int e1) {
 #pragma unroll
     for (int q = 0; q < EB; ++q) {
       const int e = e1 - q;
@@ -318,6 +320,11 @@ __global__ void bptt_scan_kernel(ScanArgs a) {
 #pragma unroll
       for (int i = 0; i < S; ++i) rows[q][i] = row[i];
     }
+  };
+  fetch(cur, a.K);
+  for (int e1 = a.K; e1 >= 0; e1 -= EB) {
+    if (e1 - EB >= 0) fetch(nxt, e1 - EB);
+    __builtin_amdgcn_sched_barrier(0);      // (keep the next batch's loads in front of this batch's dependent chain)
 #pragma unroll
     for (int q = 0; q < EB; ++q) {
       const int e = e1 - q;
@@ -325,9 +332,9 @@ __global__ void bptt_scan_kernel(ScanArgs a) {
       float nl[D];
 #pragma unroll
       for (int j = 0; j < D; ++j) {
-        float acc = rows[q][D * D + j] - (e < a.K ? rows[q][D * D + D + j] : 0.f);
+        float acc = cur[q][D * D + j] - (e < a.K ? cur[q][D * D + D + j] : 0.f);
 #pragma unroll
-        for (int k = 0; k < D; ++k) acc = fmaf(rows[q][j * D + k], lam[k], acc);
+        for (int k = 0; k < D; ++k) acc = fmaf(cur[q][j * D + k], lam[k], acc);
         nl[j] = acc;
       }
 #pragma unroll
@@ -336,6 +343,10 @@ __global__ void bptt_scan_kernel(ScanArgs a) {
         a.lam[((int64_t)e * a.n + p) * D + j] = nl[j];
       }
     }
+#pragma unroll
+    for (int q = 0; q < EB; ++q)
+#pragma unroll
+      for (int i = 0; i < S; ++i) cur[q][i] = nxt[q][i];
   }
 }
 
