@@ -13,7 +13,7 @@ for v in "$@"; do
 import csv, sys
 out = []
 for r in csv.reader(open(sys.argv[1])):
-    if 'grad_kernel' in r[0] or 'bptt' in r[0] or 'coop_kernel' in r[0] or 'tails_fused' in r[0]:
+    if 'grad_kernel' in r[0] or 'bptt' in r[0] or 'coop_kernel' in r[0] or 'tails_fused' in r[0] or 'scan' in r[0]:
         out.append('%s %.1f us x%s' % (r[0].split('(')[0][-40:], float(r[3]) / 1000, r[1]))
 print(sys.argv[2] + ': ' + ' | '.join(out))" $f $v
   grep GRAD_TIMES $O/times_$v.json
