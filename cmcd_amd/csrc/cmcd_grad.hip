@@ -1565,11 +1565,10 @@ struct DetArgs {
 // A block = 64 consecutive outputs x 4 tile classes: thread (q, l) sums the tiles q, q + 4, ... of output l in that order
 // (eight loads in flight), the four partial sums are added in the order q = 0..3.  Outputs: S[row][col] (and S2) for the
 // K + 1 bias-table rows, then d beta_i / d eps_i.  Consecutive outputs are consecutive floats of a slot: 256 B per wave load.
-__global__ __launch_bounds__(256) void grad_det_reduce_kernel(DetArgs a) {
-  __shared__ float part[4][64];
+__device__ __forceinline__ void grad_det_reduce_body(const DetArgs& a, const unsigned bidx, float (*part)[64]) {
   const int l = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int64_t nS = (int64_t)(a.K + 1) * a.HP, nSS = a.gef ? 2 * nS : nS;
-  const int64_t o = (int64_t)blockIdx.x * 64 + l;
+  const int64_t o = (int64_t)bidx * 64 + l;
   // up to two source evaluations per output row: MCD_ULA_sn reads bias-table row e - 1 at evaluation e (and row 0 at e = 0)
   int64_t src[2] = {-1, -1};
   float* dst = nullptr;
@@ -1609,6 +1608,24 @@ __global__ __launch_bounds__(256) void grad_det_reduce_kernel(DetArgs a) {
   __syncthreads();
   if (q == 0 && dst) *dst = ((part[0][l] + part[1][l]) + part[2][l]) + part[3][l];
 }
+__global__ __launch_bounds__(256) void grad_det_reduce_kernel(DetArgs a) {
+  __shared__ float part[4][64];
+  grad_det_reduce_body(a, blockIdx.x, part);
+}
+// geffner nets (r04): the two reductions that depend on the gradient kernel only — slabs -> grad_flat, slots -> tables — as ONE
+// launch, then the two consumers of the tables (schedule tail, embedding tail) as ONE launch: 2 launches behind the gradient
+// kernel instead of 3 (the fixed-order slot reduction had added one: 49 -> 54 us per gmm training iteration, 9 %)
+__global__ __launch_bounds__(256) void grad_reduce_det_kernel(TailArgs a, DetArgs da, unsigned n_reduce) {
+  __shared__ float part[4][64];
+  if (blockIdx.x < n_reduce) grad_reduce_body(a, blockIdx.x, n_reduce);
+  else grad_det_reduce_body(da, blockIdx.x - n_reduce, part);
+}
+__global__ __launch_bounds__(256) void grad_sched_geffner_kernel(TailArgs a) {
+  if (blockIdx.x == 0) grad_sched_tail_body(a, 0, 1);
+  else grad_geffner_tail_body(a, blockIdx.x - 1, gridDim.x - 1);
+}
+
+
 // slot floats per tile, and the cap above which the accumulation falls back to float atomics (the table is written and
 // read once per gradient: 1 GB is ~0.3 ms of HBM time against the ~30 ms such a batch's sweep takes; a 2000-particle shard of
 // K = 256 needs 30 MB, 65 536 particles 290 MB)
@@ -1697,14 +1714,17 @@ int grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, c
                           (int)lds_bytes) != hipSuccess)
     return CMCD_ERR_HIP;
   hipLaunchKernelGGL(fn, dim3(nslabs), dim3(64 * nw), lds_bytes, stream, ga);
+  DetArgs da{};
+  unsigned n_det = 0;
+  const bool pair_launches = det && d.arch == CMCD_ARCH_GEFFNER;   // (see grad_reduce_det_kernel)
   if (det) {
-    DetArgs da{};
     da.det = ga.det; da.gtab = gws; da.o_S = ga.o_S; da.o_S2 = ga.o_S2; da.o_gbeta = ga.o_gbeta; da.o_geps = ga.o_geps;
     da.tile_stride = ga.det_tile_stride; da.obe = ga.det_obe; da.ntiles = ntiles;
     da.K = K; da.HP = HP; da.gef = d.arch == CMCD_ARCH_GEFFNER ? 1 : 0; da.ula = ga.ula ? 1 : 0;
     da.has_fwd = (item || bptt) ? 1 : 0; da.has_bwd = (!bptt || item) ? 1 : 0;
     const int64_t outs = (int64_t)(K + 1) * HP * (da.gef ? 2 : 1) + 2 * (int64_t)K;
-    hipLaunchKernelGGL(grad_det_reduce_kernel, dim3((unsigned)((outs + 63) / 64)), dim3(256), 0, stream, da);
+    n_det = (unsigned)((outs + 63) / 64);
+    if (!pair_launches) hipLaunchKernelGGL(grad_det_reduce_kernel, dim3(n_det), dim3(256), 0, stream, da);
   }
 
   TailArgs ta{};
@@ -1722,6 +1742,11 @@ int grad_launch(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& w, c
     // geffner: reduction + schedule tail; its embedding tail stays a launch of its own (4096 light blocks behind the
     // reduction's heavy ones in one grid measured 50 us against 24.5 + 17.9 apart)
     const unsigned n_third = d.arch == CMCD_ARCH_DDS ? (unsigned)(K + 1) : 0u;
+    if (pair_launches) {
+      hipLaunchKernelGGL(grad_reduce_det_kernel, dim3(n_reduce + n_det), dim3(256), 0, stream, ta, da, n_reduce);
+      hipLaunchKernelGGL(grad_sched_geffner_kernel, dim3(1 + geffner_tail_blocks(ta)), dim3(256), 0, stream, ta);
+      return hipGetLastError() == hipSuccess ? CMCD_OK : CMCD_ERR_HIP;
+    }
     hipLaunchKernelGGL(grad_tails_fused_kernel, dim3(n_reduce + 1 + n_third), dim3(256), 0, stream, ta, n_reduce, n_third);
   }
   if (d.arch == CMCD_ARCH_DDS)
