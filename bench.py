@@ -593,6 +593,7 @@ def main():
     result = {
         "metric": "bridge-steps*particles/sec", "value": value, "unit": "bridge-steps*particles/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup": args.spinup,
+        "rehearsal_steps": args.steps if os.environ.get("CMCD_BENCH_REHEARSE", "1") == "1" else 0,   # untimed, see time_leg
         "ms_per_step": hl["ms_per_step"], "higher_is_better": True, "scaling": hl["scaling"],
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": head_leg.cfg_name, "model": hcfg["model"], "boundmode": hcfg["boundmode"],
