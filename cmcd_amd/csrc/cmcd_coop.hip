@@ -271,6 +271,13 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
 #pragma unroll
     for (int j = 0; j < D; ++j) a.traj[p * D + j] = z[j];
   }
+#ifndef CMCD_TRAJ_PTR
+#define CMCD_TRAJ_PTR 1
+#endif
+  // (r04) gradient calls keep z_1 .. z_K: a per-lane row pointer that advances by n D floats per bridge, one 8-byte store for
+  // d = 2 — the row index was rebuilt from (e, n, p) in 64-bit arithmetic on the accounting wave every bridge
+  float* tnext = (CMCD_TRAJ_PTR && is_acc && a.traj && valid && own && g == 0) ? a.traj + ((int64_t)a.n + p) * D : nullptr;
+  const int64_t tstride = (int64_t)a.n * D;
 
   const float clipv = a.var_mode ? 1e2f : 1e3f;
   const bool clip_p = a.grad_clipping != 0;
@@ -410,7 +417,17 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
       }
       z[j] = znv[j];
     }
-    if (track_w && a.traj && valid && own && g == 0) {
+    if (CMCD_TRAJ_PTR) {
+      if (track_w && tnext) {
+        if (D == 2) {
+          *reinterpret_cast<float2*>(tnext) = float2{z[0], z[1]};
+        } else {
+#pragma unroll
+          for (int j = 0; j < D; ++j) tnext[j] = z[j];
+        }
+        tnext += tstride;
+      }
+    } else if (track_w && a.traj && valid && own && g == 0) {
 #pragma unroll
       for (int j = 0; j < D; ++j) a.traj[((int64_t)(e + 1) * a.n + p) * D + j] = z[j];
     }
