@@ -239,6 +239,11 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
   }
   lds_barrier();
   // bits -> deviates, words dealt to the 4 rows of the wave
+#ifndef CMCD_DBG_FLAG
+#define CMCD_DBG_FLAG 1
+#endif
+  // (r04) the diagnostic capture's three-term condition, once per launch instead of once per bridge on the accounting wave
+  const bool dbg_on = a.dbg_bits && valid && own;
   auto convert = [&](int buf, int stage) {
 #pragma unroll
     for (int q0 = 0; q0 < D; q0 += 4) {
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
         const uint32_t bits = raw[(buf * 16 + c) * NZ + q];
         const float dev = bits_to_normal(bits);
         nzb[(buf * 16 + c) * NZ + q] = dev;
-        if (a.dbg_bits && valid && own) {
+        if (CMCD_DBG_FLAG ? dbg_on : (a.dbg_bits && valid && own)) {
           a.dbg_bits[((int64_t)stage * a.n + p) * D + q] = bits;
           a.dbg_noise[((int64_t)stage * a.n + p) * D + q] = dev;
         }
