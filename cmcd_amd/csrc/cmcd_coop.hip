@@ -242,7 +242,10 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
 #ifndef CMCD_DBG_FLAG
 #define CMCD_DBG_FLAG 1
 #endif
-  // (r04) the diagnostic capture's three-term condition, once per launch instead of once per bridge on the accounting wave
+  // (r04) the diagnostic capture's three-term condition, once per launch instead of once per bridge on the accounting wave —
+  // for the 2-d instances only: the d = 10 instance (funnel) pays for every extra live value (95.6 -> 106.9 us with this flag
+  // and the trajectory row pointer below, profiles/r04_grad_two_workgroups_per_cu.txt)
+  constexpr bool kLeanAcc = D <= 4;
   const bool dbg_on = a.dbg_bits && valid && own;
   auto convert = [&](int buf, int stage) {
 #pragma unroll
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
         const uint32_t bits = raw[(buf * 16 + c) * NZ + q];
         const float dev = bits_to_normal(bits);
         nzb[(buf * 16 + c) * NZ + q] = dev;
-        if (CMCD_DBG_FLAG ? dbg_on : (a.dbg_bits && valid && own)) {
+        if ((CMCD_DBG_FLAG && kLeanAcc) ? dbg_on : (a.dbg_bits && valid && own)) {
           a.dbg_bits[((int64_t)stage * a.n + p) * D + q] = bits;
           a.dbg_noise[((int64_t)stage * a.n + p) * D + q] = dev;
         }
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
 #endif
   // (r04) gradient calls keep z_1 .. z_K: a per-lane row pointer that advances by n D floats per bridge, one 8-byte store for
   // d = 2 — the row index was rebuilt from (e, n, p) in 64-bit arithmetic on the accounting wave every bridge
-  float* tnext = (CMCD_TRAJ_PTR && is_acc && a.traj && valid && own && g == 0) ? a.traj + ((int64_t)a.n + p) * D : nullptr;
+  float* tnext = (CMCD_TRAJ_PTR && kLeanAcc && is_acc && a.traj && valid && own && g == 0) ? a.traj + ((int64_t)a.n + p) * D : nullptr;
   const int64_t tstride = (int64_t)a.n * D;
 
   const float clipv = a.var_mode ? 1e2f : 1e3f;
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
       }
       z[j] = znv[j];
     }
-    if (CMCD_TRAJ_PTR) {
+    if (CMCD_TRAJ_PTR && kLeanAcc) {
       if (track_w && tnext) {
         if (D == 2) {
           *reinterpret_cast<float2*>(tnext) = float2{z[0], z[1]};
