@@ -13,6 +13,7 @@ legs.weak_pipelined and the collective's own cost in `collective`; the north_sta
 at top level in `strong_scaling`.  Legs timed in the same job and reported under "legs":
 
   weak                 the headline measurement at every N.  N > 1: all-gather + merge completed inside every step
+  weak_prepared        the same loop inside fixed_parameters(): cmcd_bound_forward_prepared, no prep launch (NOT the headline)
   weak_pipelined       N > 1: the all-gather issued async and merged one step late — the rate of a loop of independent
                        calls that does not consume each scalar at once (NOT the headline)
   strong_named         the named batch split over the ranks (2000 / N each) — north_star's "strong scaling", latency-bound
@@ -24,8 +25,13 @@ Each strong leg also times the un-split batch on rank 0's GPU alone inside the s
 the statistics all-gather + merge.  Rank 0 prints ONE JSON line.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 8 --steps 20 --warmup 3          # starts the launcher below itself, as a child process
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 3
+
+`value` is the DEFAULT product path at every N (one plain compute_bound per step, prep launch included); the loop inside
+`fixed_parameters()` (prep launch skipped on unchanged parameters) is the side leg legs.weak_prepared.  `roofline`,
+`cpu_baseline` and `parity` are in the line at every N (rank 0 times the CPU baseline, the other ranks wait).
 """
 import argparse
 import json
@@ -152,7 +158,7 @@ def cpu_baseline(built, seeds_np, losses_hip, max_particles, min_seconds=8.0):
     dt_np = time.perf_counter() - t1
     out["numpy_port_value"] = n * K / dt_np
     # BASELINE.md section 3's other lines, each on a bounded sample: the same C port on ONE thread, and the vectorised
-    # torch-CPU float32 port (oracle/torch_port.py) on all cores and on one, reference-faithful (2 + 2 evaluations per
+    # torch-CPU float32 port (oracle/torch_port.py) on one thread, reference-faithful (2 + 2 evaluations per
     # bridge) and with the backward evaluation reused (1 + 1)
     lines = {}
     try:
@@ -176,9 +182,9 @@ def cpu_baseline(built, seeds_np, losses_hip, max_particles, min_seconds=8.0):
         ncpu, was = os.cpu_count() or 1, torch.get_num_threads()
         # (r03 on the MI355X host: one torch thread per logical CPU — 256 — on these 64-wide matrices ran at 6 particle-steps/s:
         # thread hand-over, not arithmetic, against 3.8e5 on ONE thread.  That line was an oversubscription artefact, not a
-        # baseline, and is no longer printed; the vectorised port is timed on 16 threads and on one)
-        for tag, nt, reuse in (("torch_cpu_16_threads", min(16, ncpu), False),
-                               ("torch_cpu_16_threads_reuse", min(16, ncpu), True), ("torch_cpu_1_thread", 1, False)):
+        # baseline, and is no longer printed; r04: 16 threads 2.6e5 against 3.7e5 on ONE — the vectorised port is timed at the
+        # thread count where it is fastest, one)
+        for tag, nt, reuse in (("torch_cpu_1_thread", 1, False), ("torch_cpu_1_thread_reuse", 1, True)):
             torch.set_num_threads(nt)
             # bounded samples: a 4-bridge probe of 64 particles gives the rate, the timed sample is then the largest
             # (particles x bridges) prefix of the same batch that fits ~3 s at that rate (128 threads on small matrices can
@@ -211,6 +217,29 @@ def cpu_baseline(built, seeds_np, losses_hip, max_particles, min_seconds=8.0):
         "n": int(n), "against": "plain-C float32 oracle (reference-faithful)",
     }
     return out, parity
+
+
+def self_launch(n_gpus):
+    """`python3 bench.py --gpus N` with N > 1 and no launcher in the environment: run
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <argv>`
+    as a child process and return its exit code.  Called before this process has initialised the GPU
+    (torch.cuda.device_count() does not); the child's stdout (rank 0's one JSON line) and stderr are inherited."""
+    import socket
+    import subprocess
+    shared = os.environ.get("CMCD_BENCH_SHARED_GPU") == "1"      # test hook: every rank on device 0 (see main)
+    have = torch.cuda.device_count()
+    if have < (1 if shared else n_gpus):
+        print(f"bench.py: --gpus {n_gpus} but {have} GPU(s) visible on this node", file=sys.stderr)
+        return 2
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.stdout.flush()
+    return subprocess.run(cmd, env=env).returncode
 
 
 def _strict(o):
@@ -398,6 +427,11 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["CMCD_BENCH_TRACE_AFTER"]), exit=True)
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # typed as `python3 bench.py --gpus N` (no launcher): start the one-process-per-GPU job as a CHILD, before anything in
+        # this process has touched the GPU, relay its output and leave with its return code
+        raise SystemExit(self_launch(args.gpus))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -409,13 +443,17 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ   # launched by torch.distributed.run
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if use_dist:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # rank 0 times the CPU baseline (tens of seconds of host work) while the other ranks wait at a barrier
+        patience = datetime.timedelta(minutes=30)
         if shared_gpu:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=patience)
         else:
-            dist.init_process_group("nccl", device_id=device)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+            dist.init_process_group("nccl", device_id=device, timeout=patience)
 
     from cmcd_amd import _lib, build, synthetic
     from cmcd_amd import mcdboundingmachine as mcdbm
@@ -453,27 +491,25 @@ def main():
             cnt = torch.tensor([args.spinup], dtype=torch.int64, device=device)
             dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
             args.spinup = int(cnt.item())
-    # every timed loop of this file is an evaluation loop on FIXED parameters: state it (cmcd_amd.mcdboundingmachine.fixed_parameters)
-    mcdbm.PREP_CACHE = True
+    # HEADLINE = the default product path: every step is one plain compute_bound call (cmcd_bound_forward: prep launch +
+    # trajectory kernel + statistics), what a training step or any caller without further statements pays.
+    mcdbm.PREP_CACHE = False
     tw = time_leg(weak, args.steps, args.warmup, use_dist, device, world, spinup=args.spinup)
     legs["weak"] = leg_report(weak, tw, args.steps)
-    # The steps of this loop call compute_bound on UNCHANGED parameters (like the 30 calls of the reference's opt.sample,
-    # /root/reference/src/opt.py:185-190) and say so (mcdbm.PREP_CACHE above = `with mcdbm.fixed_parameters():`), so all but the
-    # first skip the prep launch (cmcd_bound_forward_prepared).  The same loop with the prep launch in every call — what a
-    # caller gets without that statement — is timed beside it, not hidden.
-    prep_note = None
-    if world == 1:
+    # Side leg, at every N: the same loop inside `with mcdbm.fixed_parameters():` — an evaluation loop that STATES its
+    # parameters are unchanged (the shape of the reference's 30 loss_fn calls on one params_flat,
+    # /root/reference/src/opt.py:185-190), so all but the first call skip the prep launch (cmcd_bound_forward_prepared).
+    # Never the headline (r04 reported it as `value`; no default caller of this package takes that path).
+    calls0 = dict(mcdbm.PREP_CALLS)
+    mcdbm.PREP_CACHE = True
+    try:
+        tprep = time_leg(weak, args.steps, args.warmup, use_dist, device, world, spinup=min(args.spinup, 300))
+    finally:
         mcdbm.PREP_CACHE = False
-        try:
-            tfull = time_leg(weak, args.steps, args.warmup, use_dist, device, world, spinup=min(args.spinup, 300))
-        finally:
-            mcdbm.PREP_CACHE = True
-        prep_note = {"what": "headline steps reuse the per-parameter tables of the first call (cmcd_bound_forward_prepared: "
-                             "evaluation loop on fixed parameters); with_prep_every_call = the same loop with the prep launch "
-                             "in every call",
-                     "prepared_calls": mcdbm.PREP_CALLS["prepared"], "full_calls": mcdbm.PREP_CALLS["full"],
-                     "with_prep_every_call": {"ms_per_step": tfull["elapsed"] / args.steps * 1e3,
-                                              "value": weak.n_global * weak.K * args.steps / tfull["elapsed"]}}
+    legs["weak_prepared"] = leg_report(weak, tprep, args.steps)
+    legs["weak_prepared"]["what"] = ("the headline loop inside fixed_parameters(): per-parameter tables of the first call reused, "
+                                     "prep launch skipped; results bit-identical (tests/test_gpu_fullsize.py)")
+    legs["weak_prepared"]["prepared_calls"] = mcdbm.PREP_CALLS["prepared"] - calls0["prepared"]
     elapsed, kern_ms, launches, losses, stats = tw["elapsed"], tw["kern_ms"], tw["launches"], tw["losses"], tw["stats"]
     default_workload = name == synthetic.NORTH_STAR and not args.particles
 
@@ -612,8 +648,6 @@ def main():
         "elbo": hl["elbo"], "ln_z": hl["ln_z"], "n_finite": hl["n_finite"],
         "legs": legs,
     }
-    if prep_note is not None:
-        result["prep_tables"] = prep_note
     result["headline_leg"] = "weak"
     if world > 1:
         result["collective"] = collective
@@ -782,11 +816,16 @@ def main():
         except NotImplementedError as e:
             result["training_step"] = {"error": str(e)}
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        base, parity = cpu_baseline(b, seeds_np, losses.cpu().numpy(), args.cpu_particles)
-        result["cpu_baseline"] = base
-        result["parity"] = parity
-        result["speedup_vs_cpu"] = value / base["fastest_cpu_value"]     # against the FASTEST of the CPU lines
+    if not args.no_cpu_baseline:
+        # at EVERY N: rank 0 times the CPU baseline on its own shard's seeds (bounded sample, host cores of this box) and checks
+        # its GPU losses against it; the other ranks wait at the barrier (process-group timeout raised in main's init)
+        if rank == 0:
+            base, parity = cpu_baseline(b, seeds_np, losses.cpu().numpy(), args.cpu_particles)
+            result["cpu_baseline"] = base
+            result["parity"] = parity
+            result["speedup_vs_cpu"] = value / base["fastest_cpu_value"]     # against the FASTEST of the CPU lines
+        if use_dist:
+            dist.barrier()
 
     if rank == 0:
         print(json.dumps(_strict(result)))

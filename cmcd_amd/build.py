@@ -12,7 +12,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libcmcd_hip.so")
-SOURCES = ["cmcd_kernels.hip", "cmcd_uha.hip", "cmcd_coop.hip", "cmcd_lgcp.hip", "cmcd_lgcp_wide.hip", "cmcd_grad.hip", "cmcd_bptt.hip", "cmcd_mfvi.hip", "cmcd_opt.hip"]
+SOURCES = ["cmcd_kernels.hip", "cmcd_uha.hip", "cmcd_coop.hip", "cmcd_coop_wide.hip", "cmcd_lgcp.hip", "cmcd_lgcp_wide.hip", "cmcd_grad.hip", "cmcd_bptt.hip", "cmcd_mfvi.hip", "cmcd_opt.hip"]
 HEADERS = ["cmcd_device.h", os.path.join(ROOT, "include", "cmcd_hip.h")]
 # Per-file flags.  cmcd_kernels.hip holds the wave-per-tile trajectory kernel, which is VALU-issue bound at 4 waves per
 # SIMD: there a packed fp32 instruction holds the pipe ~1.8x as long as a plain one and the SLP vectoriser pays v_mov

@@ -49,6 +49,9 @@ struct TrajArgs {
   // counter the prep launch zeroes on every call (WsLayout::b3 slot 14).  Both null: the caller launches finalize_kernel.
   double* fin_out = nullptr;
   int32_t* fin_counter = nullptr;
+  // cmcd_bound_forward_prepared with the fused merge: where the forming call left its stamp, and this call's (finalize_kernel)
+  const uint32_t* stamp_slot = nullptr;
+  uint32_t stamp_expect = 0;
   // cmcd_debug_capture_noise (tests): the PRNG path of THIS launch, written next to the arithmetic that consumes it.
   // Stage 0 = the draw of z_0, stage i + 1 = bridge i.  All nullable.
   uint32_t* dbg_bits = nullptr;   // [K+1][n][D]  the random words that become the deviates (jax random_bits)
@@ -74,7 +77,12 @@ __host__ __device__ inline int coop_tail_len(int s) { return s < 4 ? 20 : 16; }
 // Returns nullptr-equivalent (false) when no instance exists for this (target, arch, dim, T).
 bool coop_available(const cmcd_desc& d, int T);
 bool coop_half_available(const cmcd_desc& d, int T);   // the 8-particle-tile instances (batches of <= 2048 particles)
-int coop_launch(const cmcd_desc& d, const TrajArgs& ta, bool half, void* stream);
+// narrow: keep a wide state (d > 8) on coop_kernel's 8-particle instance instead of coop_wide8_kernel (kernel variant 5: A / B, tests)
+int coop_launch(const cmcd_desc& d, const TrajArgs& ta, bool half, void* stream, bool narrow = false);
+// cmcd_coop_wide.hip: 8-particle tiles for wide states (the funnel, d = 10): every per-coordinate job dealt to the lanes of
+// its particle.  lds_claim_min: dynamic LDS to claim at least (the CU-exclusive claim of coop_launch), 0 = none.
+bool coop_wide8_available(const cmcd_desc& d, int T);
+int coop_wide8_launch(const cmcd_desc& d, const TrajArgs& ta, size_t lds_claim_min, void* stream);
 
 
 // cmcd_uha.hip: MCD_CAIS_UHA_sn (2nd-order CMCD) on the wave-per-tile mapping.  The kept trajectory is

@@ -402,7 +402,9 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
           *reinterpret_cast<f32x4*>(zpub + c * DP + q) = v;
         }
       }
+      STAMP(6);        // (ACC) new state formed and published
       lds_barrier();   // barrier 3 (every wave, every evaluation)
+      STAMP(5);
     }
     if (track_w && e > 0) {  // backward kernel of step e-1: bk = z - eps ub + eps s, ub = -(beta gp + (1-beta) gq)
       float bk_lp = 0.f;
@@ -706,6 +708,7 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
         phase_c(i, true, sc, sd, buf_tag);            // i = K: closes step K-1 and picks up log p(z_K); PUBZ: barrier 3 inside
       } else if constexpr (PUBZ) {
         lds_barrier();                                // barrier 3: z_{i+1} published by the ACC wave
+        STAMP(5);
         if constexpr (r_mlp || r_tgt) {
           if (i < K) {
 #pragma unroll
@@ -800,6 +803,7 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
   if (!last) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the other lanes of the merging wave read the records too
   wave_merge_stats(a.partials, (int)gridDim.x, a.fin_out, lane);
+  if (a.stamp_slot && lane < CMCD_NSTATS && *a.stamp_slot != a.stamp_expect) a.fin_out[lane] = __builtin_nan("");
   // ready for the next launch on these tables (cmcd_bound_forward_prepared skips the prep launch that used to zero it)
   if (lane == 0) __hip_atomic_store(a.fin_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -870,7 +874,7 @@ static int default_prio(const cmcd_desc&, bool half, int waves) {
   return 1 << 2 | 1 << 6;
 }
 
-int coop_launch(const cmcd_desc& d, const TrajArgs& ta_in, bool half, void* stream) {
+int coop_launch(const cmcd_desc& d, const TrajArgs& ta_in, bool half, void* stream, bool narrow) {
   TrajArgs ta = ta_in;
   const int T = ta.w.T, D = d.dim, Hh = (D + 1) / 2, NZ = 2 * Hh;
   const int GP = (2 * D + 1 + 3) & ~3, PT = (T * D + 3) & ~3;
@@ -893,8 +897,10 @@ int coop_launch(const cmcd_desc& d, const TrajArgs& ta_in, bool half, void* stre
     if (n_cu == 0 && hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
       cu_count[dev].store(n_cu, std::memory_order_relaxed);
   }
+  constexpr size_t kExclusive = 84 * 1024;
+  if (half && !narrow && coop_wide8_available(d, T))   // wide states (d = 10): their own kernel, same claim rule
+    return coop_wide8_launch(d, ta, (n_cu > 0 && (int)tiles <= n_cu) ? kExclusive : 0, stream);
   if (n_cu > 0 && (int)tiles <= n_cu) {
-    constexpr size_t kExclusive = 84 * 1024;
     static std::mutex mu;
     static std::set<std::pair<const void*, int>> raised;
     std::lock_guard<std::mutex> lock(mu);

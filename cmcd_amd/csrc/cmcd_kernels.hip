@@ -169,6 +169,7 @@ struct SchedArgs {
   WsLayout w;
   int32_t K, ngrid, eps_schedule;
   int64_t gridref_x, target_x;  // offsets in params, or -1: use linspace
+  uint32_t stamp = 0;           // tables_stamp() of the call that forms the tables: kept in sched[0][7] (see finalize_kernel)
 };
 
 __device__ __forceinline__ void prep_sched_body(const SchedArgs& a) {
@@ -237,7 +238,7 @@ __device__ __forceinline__ void prep_sched_body(const SchedArgs& a) {
     sc[4] = 1.0f / (2.0f * s * s);
     sc[5] = e * sc[0];            // eps * beta
     sc[6] = e * (1.0f - sc[0]);   // eps * (1 - beta)
-    sc[7] = 0.f;
+    sc[7] = i == 0 ? __uint_as_float(a.stamp) : 0.f;   // never read as a number
   }
 }
 
@@ -365,6 +366,7 @@ struct PackArgs {
   int32_t D, IN;                                   // state inputs of the net (z, or [z; rho]); true hidden width
   int32_t DO;                                      // outputs of the net (= dim)
   int32_t target, n_mix;
+  uint32_t stamp;                                  // tables_stamp() of this call -> b3[13]
 };
 
 __device__ __forceinline__ void pack_weights_body(const PackArgs& a, int vblock, int nblocks) {
@@ -410,6 +412,7 @@ __device__ __forceinline__ void pack_weights_body(const PackArgs& a, int vblock,
     float v = 0.f;
     if (has_net && idx < a.DO) v = P[a.o_b3 + idx];
     if (idx == 15) v = a.o_factor >= 0 ? P[a.o_factor] : 1.0f;
+    if (idx == 13) v = __uint_as_float(a.stamp);   // DO <= 10: slots 12 - 14 hold no bias (14 = the fused merge's counter)
     a.ws[a.w.b3 + idx] = v;
   }
   if (a.target == CMCD_TARGET_MANY_GMM) {
@@ -860,7 +863,11 @@ __device__ __forceinline__ void stats_merge(double* a, const double* b) {
 // Two passes over the records (L2-resident): the global maximum first, then every record scaled to it ONCE — one
 // double-precision exp per record instead of two per level of a pairwise merge tree (5.2 -> ~3 us for 250 records).
 // Same edge semantics as stats_merge (records of all-inf tiles, +inf maxima); fixed summation order.
-__global__ __launch_bounds__(256) void finalize_kernel(const double* partials, int32_t n_waves, double* out) {
+// cmcd_bound_forward_prepared: `stamp_slot` (non-null) points at the stamp the prep launch of the call that FORMED the tables
+// left in the workspace; when it is not the stamp of this call's (desc, layout, n, n_params, n_target) the caller broke the
+// entry point's contract and the five statistics go out as NaN ("diverged": loud, and no host synchronisation needed).
+__global__ __launch_bounds__(256) void finalize_kernel(const double* partials, int32_t n_waves, double* out,
+                                                       const uint32_t* stamp_slot = nullptr, uint32_t stamp_expect = 0) {
   __shared__ double shm[256];
   __shared__ double sh[256][4];
   // contiguous chunks keep the merge order independent of blockDim-strided races
@@ -896,6 +903,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(const double* partials, i
     out[2] = sh[0][2];
     out[3] = M;
     out[4] = sh[0][3];
+    if (stamp_slot && *stamp_slot != stamp_expect)
+      for (int k = 0; k < CMCD_NSTATS; ++k) out[k] = __builtin_nan("");
   }
 }
 
@@ -944,8 +953,22 @@ static traj_fn pick_kernel(const cmcd_desc& d, int T) {
   return nullptr;
 }
 
+// What a set of prepared tables was formed from, as far as the library can know it without reading device memory: FNV-1a
+// over the descriptor (minus the kernel-variant field, which selects a kernel and not a table), the layout and the sizes.
+static uint32_t tables_stamp(const cmcd_desc& d, const cmcd_layout& lay, int64_t n, int64_t n_params, int64_t n_target) {
+  uint32_t h = 2166136261u;
+  auto eat = [&](const void* p, size_t len) {
+    const unsigned char* b = static_cast<const unsigned char*>(p);
+    for (size_t i = 0; i < len; ++i) { h ^= b[i]; h *= 16777619u; }
+  };
+  cmcd_desc dd = d;
+  dd.reserved = 0;
+  eat(&dd, sizeof dd); eat(&lay, sizeof lay); eat(&n, sizeof n); eat(&n_params, sizeof n_params); eat(&n_target, sizeof n_target);
+  return h ? h : 1u;
+}
+
 static void launch_prep(const cmcd_desc& d, const cmcd_layout& layr, const WsLayout& w, const float* params,
-                        const float* target_consts, int n_mix, float* ws, hipStream_t stream) {
+                        const float* target_consts, int n_mix, float* ws, hipStream_t stream, uint32_t stamp) {
   const cmcd_layout* lay = &layr;
   // D here = the state inputs of the network: z, or concat(z, rho) for the momentum mode
   const int64_t K = d.nbridges, D = net_in_dim(d), E = d.emb_dim, IN = D + E;
@@ -955,6 +978,8 @@ static void launch_prep(const cmcd_desc& d, const cmcd_layout& layr, const WsLay
   const int sched = ula_mode ? CMCD_EPS_CONST : (d.mode == CMCD_MODE_CAIS_UHA_SN ? CMCD_EPS_COS_SQ : d.eps_schedule);
   pa.sched = SchedArgs{params, ws, *lay, w, (int32_t)K, d.ngrid, sched, -1, -1};
   PackArgs& pk = pa.pack;
+  pk.stamp = stamp;
+  pa.sched.stamp = stamp;
   pk.params = params; pk.tgt = target_consts; pk.ws = ws; pk.w = w;
   pk.D = (int32_t)D; pk.DO = d.dim; pk.target = d.target; pk.n_mix = n_mix;
   if (d.mode == CMCD_MODE_ULA) {
@@ -979,7 +1004,8 @@ static void launch_prep(const cmcd_desc& d, const cmcd_layout& layr, const WsLay
 int fail_msg(int code, const char* msg) { return fail(code, "%s", msg); }
 
 int launch_finalize(const double* partials, int32_t count, double* out5, void* stream) {
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), partials, count, out5);
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), partials, count, out5,
+                     (const uint32_t*)nullptr, 0u);
   return hipGetLastError() == hipSuccess ? CMCD_OK : fail(CMCD_ERR_HIP, "finalize launch failed%s");
 }
 
@@ -1109,6 +1135,8 @@ static int forward_impl(const cmcd_desc* desc, const cmcd_layout* lay, const int
     // workspace; the 2nd-order sequence has no prepared form)
     const bool lgcp_ready = tables_ready && !uha;
     SchedArgs sa{params, wsf, *lay, lw, (int32_t)K, d.ngrid, dl.eps_schedule, -1, -1};
+    const uint32_t lstamp = tables_stamp(d, *lay, n, n_params, n_target);
+    sa.stamp = lstamp;
     if (!lgcp_ready) hipLaunchKernelGGL(prep_sched_kernel, dim3(1), dim3(256), 0, st, sa);
     double* partials = nullptr;
     snprintf(g_kernel_name, sizeof(g_kernel_name), "%s", lgcp_use_wide(dl, n, traj != nullptr)
@@ -1120,7 +1148,9 @@ static int forward_impl(const cmcd_desc* desc, const cmcd_layout* lay, const int
     rc = lgcp_forward(dl, *lay, lw, seeds, n, params, target_consts, wsf, out_loss, out_z, &partials, traj, stream_, lgcp_ready,
                       keep_gws);
     if (rc != CMCD_OK) return fail(rc, "lgcp launch sequence failed%s");
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, partials, (int32_t)n, out_stats);
+    // (prepared form: the stamp the forming call's schedule launch left in sched[0][7] must be this call's)
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, partials, (int32_t)n, out_stats,
+                       lgcp_ready ? reinterpret_cast<const uint32_t*>(wsf + lw.sched + 7) : nullptr, lstamp);
     CMCD_HIP_CHECK(hipGetLastError());
     return CMCD_OK;
   }
@@ -1135,7 +1165,10 @@ static int forward_impl(const cmcd_desc* desc, const cmcd_layout* lay, const int
 
   // cmcd_bound_forward_prepared: the caller vouches that the workspace still holds the tables a previous call formed from the
   // SAME (desc, layout, params, target constants, n): the prep launch (4.8 us + a kernel boundary per call) is skipped
-  if (!tables_ready) launch_prep(d, *lay, w, params, target_consts, n_mix, ws, stream);
+  const uint32_t stamp = tables_stamp(d, *lay, n, n_params, n_target);
+  if (!tables_ready) launch_prep(d, *lay, w, params, target_consts, n_mix, ws, stream, stamp);
+  // prepared form: whoever writes the statistics compares the stamp left in b3[13] with this call's (finalize_kernel)
+  const uint32_t* stamp_slot = tables_ready ? reinterpret_cast<const uint32_t*>(ws + w.b3 + 13) : nullptr;
 
   if (uha) {   // 2nd-order CMCD: its own trajectory kernel (cmcd_uha.hip), same prep tables and statistics merge
     TrajArgs tu{seeds, params, ws, reinterpret_cast<double*>(ws + w.partials), out_loss, out_z, *lay, w, n,
@@ -1146,7 +1179,7 @@ static int forward_impl(const cmcd_desc* desc, const cmcd_layout* lay, const int
     snprintf(g_kernel_name, sizeof(g_kernel_name), "%s", uha_last_kernel_name());
     if (rc != CMCD_OK) return fail(rc, "MCD_CAIS_UHA_sn launch failed%s");
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, stream,
-                       reinterpret_cast<const double*>(ws + w.partials), (int32_t)n_records, out_stats);
+                       reinterpret_cast<const double*>(ws + w.partials), (int32_t)n_records, out_stats, stamp_slot, stamp);
     CMCD_HIP_CHECK(hipGetLastError());
     return CMCD_OK;
   }
@@ -1160,12 +1193,13 @@ static int forward_impl(const cmcd_desc* desc, const cmcd_layout* lay, const int
   // 4 cooperative on 8-particle tiles).  Auto: the cooperative kernel while the batch cannot fill the chip with one
   // wave per tile, on 8-particle tiles while those still get a CU each (n <= 8 x 256).
   const bool coop_ok = coop_available(d, w.T) && d.mode != CMCD_MODE_ULA;
-  const bool forced = d.reserved >= 2 && d.reserved <= 4;
+  const bool forced = d.reserved >= 2 && d.reserved <= 5;
   bool use_coop = forced ? coop_ok : (d.reserved == 1 ? false : (coop_ok && w.n_waves <= coop_max_tiles(d, w.T)));
   if (forced && !coop_ok) return fail(CMCD_ERR_UNSUPPORTED, "no cooperative kernel instance%s");
   const bool half_ok = coop_half_available(d, w.T);
-  if (d.reserved == 4 && !half_ok) return fail(CMCD_ERR_UNSUPPORTED, "no 8-particle-tile cooperative instance%s");
-  const bool half = d.reserved == 4 || (d.reserved != 3 && half_ok && n <= 8 * 256);
+  if ((d.reserved == 4 || d.reserved == 5) && !half_ok) return fail(CMCD_ERR_UNSUPPORTED, "no 8-particle-tile cooperative instance%s");
+  const bool half = d.reserved == 4 || d.reserved == 5 || (d.reserved != 3 && half_ok && n <= 8 * 256);
+  const bool wide8 = half && d.reserved != 5 && coop_wide8_available(d, w.T);   // d = 10: the dealt-coordinates kernel (5 = the narrow form, A / B)
   if (use_coop) {
     const bool prof = g_prof.on && g_prof.used < ProfileState::kMax;
     if (prof) {
@@ -1176,8 +1210,8 @@ static int forward_impl(const cmcd_desc* desc, const cmcd_layout* lay, const int
       }
       CMCD_HIP_CHECK(hipEventRecord(g_prof.ev[g_prof.used][0], stream));
     }
-    snprintf(g_kernel_name, sizeof(g_kernel_name), "coop_kernel<%d-particle tiles%s>", half ? 8 : 16,
-             w.T == 9 ? ", 132-wide net" : "");
+    snprintf(g_kernel_name, sizeof(g_kernel_name), "%s<%d-particle tiles%s>", wide8 ? "coop_wide8_kernel" : "coop_kernel",
+             half ? 8 : 16, w.T == 9 ? ", 132-wide net" : "");
     // Small grids (<= 64 workgroups: the launch-bound configurations — gmm / funnel at N = 300 are 38 workgroups): the
     // statistics are merged by the last workgroup to arrive (its counter: the free slot 14 of the b3 row, zeroed by the prep
     // launch of this call) and the finalize launch is dropped: gmm N = 300, K = 8 0.0266 -> 0.0245 ms per call.  Larger
@@ -1188,8 +1222,10 @@ static int forward_impl(const cmcd_desc* desc, const cmcd_layout* lay, const int
     if (fused_merge) {
       ta.fin_out = out_stats;
       ta.fin_counter = reinterpret_cast<int32_t*>(ws + w.b3 + 14);
+      ta.stamp_slot = stamp_slot;
+      ta.stamp_expect = stamp;
     }
-    rc = coop_launch(d, ta, half, stream);
+    rc = coop_launch(d, ta, half, stream, !wide8);
     if (rc != CMCD_OK) return fail(rc, "cooperative launch failed%s");
     if (prof) {
       CMCD_HIP_CHECK(hipEventRecord(g_prof.ev[g_prof.used][1], stream));
@@ -1197,7 +1233,7 @@ static int forward_impl(const cmcd_desc* desc, const cmcd_layout* lay, const int
     }
     if (!fused_merge)
       hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, stream,
-                         reinterpret_cast<const double*>(ws + w.partials), (int32_t)coop_wgs, out_stats);
+                         reinterpret_cast<const double*>(ws + w.partials), (int32_t)coop_wgs, out_stats, stamp_slot, stamp);
     CMCD_HIP_CHECK(hipGetLastError());
     return CMCD_OK;
   }
@@ -1233,7 +1269,7 @@ static int forward_impl(const cmcd_desc* desc, const cmcd_layout* lay, const int
     ++g_prof.used;
   }
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, stream,
-                     reinterpret_cast<const double*>(ws + w.partials), w.n_waves, out_stats);
+                     reinterpret_cast<const double*>(ws + w.partials), w.n_waves, out_stats, stamp_slot, stamp);
   CMCD_HIP_CHECK(hipGetLastError());
   return CMCD_OK;
 }
@@ -1462,7 +1498,7 @@ static int var_grad_impl(const cmcd_desc* desc, const cmcd_layout* lay, const in
                       traj, stream_);
     if (rc != CMCD_OK) return rc;
   } else if (!kept) {
-    launch_prep(d, *lay, w, params, target_consts, n_mix, ws, stream);
+    launch_prep(d, *lay, w, params, target_consts, n_mix, ws, stream, tables_stamp(d, *lay, n, n_params, n_target));
   }
   rc = grad_launch(d, *lay, w, seeds, n, params, n_params, ws, omega, 0.f, false, item, traj, nullptr, ws + fwd, grad,
                    stream_);
@@ -1515,7 +1551,8 @@ int cmcd_bound_var_grad_kept(const cmcd_desc* desc, const cmcd_layout* lay, cons
 
 int cmcd_stats_merge_device(const double* rows, int32_t count, double* out5, void* stream_) {
   if (!rows || !out5 || count < 1) return fail(CMCD_ERR_BAD_ARG, "null pointer argument%s");
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream_), rows, count, out5);
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream_), rows, count, out5,
+                     (const uint32_t*)nullptr, 0u);
   CMCD_HIP_CHECK(hipGetLastError());
   return CMCD_OK;
 }

@@ -316,9 +316,12 @@ def bound_forward(seeds, params_flat, unflatten, params_fixed, log_prob, eps_sch
     with torch.cuda.device(device):
         stream = torch.cuda.current_stream().cuda_stream
         # the tables this workspace holds: formed by the previous call from exactly these inputs?  (see _prepared)
-        slot = key = None
+        # `slot` names the buffer on EVERY call — in or out of fixed_parameters(), capturing or not — because every call
+        # overwrites the buffer's tables and must therefore retire whatever claim an earlier call left on it (r04 advisor:
+        # with the slot computed inside the context only, `with fixed: f(P)`; `f(Q)`; `with fixed: f(P)` ran P on Q's tables)
+        slot = (torch.cuda.current_device(), ws.data_ptr())
+        key = None
         if (PREP_CACHE or getattr(_fixed, "depth", 0) > 0) and not torch.cuda.is_current_stream_capturing():
-            slot = (torch.cuda.current_device(), ws.data_ptr())
             key = (params_flat.data_ptr(), params_flat._version, params_flat.numel(), n, bytes(desc), bytes(lay), spec,
                    None if consts is None else (consts.data_ptr(), consts._version, consts.numel()))
         # (key, weak references to the very tensor OBJECTS the tables were formed from): an address and a version counter alone
@@ -329,7 +332,7 @@ def bound_forward(seeds, params_flat, unflatten, params_fixed, log_prob, eps_sch
         if ent is not None and ent[0] == key and ent[1]() is params_flat and (consts is None or ent[2]() is consts):
             hit = True
         fn = L.cmcd_bound_forward_prepared if hit else L.cmcd_bound_forward
-        _prepared.pop(slot, None)            # an error below leaves no claim on the buffer
+        _prepared.pop(slot, None)            # unconditionally: this launch rewrites (or, on an error, may have rewritten) the tables
         PREP_CALLS["prepared" if fn is L.cmcd_bound_forward_prepared else "full"] += 1
         rc = fn(
             C.byref(desc), C.byref(lay), seeds.data_ptr(), n, params_flat.data_ptr(), params_flat.numel(),

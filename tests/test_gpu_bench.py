@@ -38,8 +38,10 @@ def test_bench_single_gpu_line(hip_lib):
         assert 0.0 < occ["mfma_busy_frac"] < occ["frac"] < 1.0
     # the N = 1 points of the scaling legs ride in the same line
     legs = r["legs"]
-    assert set(legs) == {"weak", "strong_named", "strong_sharded_cfg4"}
+    assert set(legs) == {"weak", "weak_prepared", "strong_named", "strong_sharded_cfg4"}
     assert legs["weak"]["value"] == pytest.approx(r["value"]) and legs["strong_named"]["global_particles"] == 2000
+    # the headline is the default path (prep launch in every call); the fixed_parameters() loop is a side leg and skipped it
+    assert legs["weak_prepared"]["prepared_calls"] >= 3 and legs["weak_prepared"]["value"] > 1e8
     c4 = legs["strong_sharded_cfg4"]
     assert c4["workload"] == "many_gmm_var_n16000_k256" and c4["global_particles"] == 16000 and c4["value"] > 1e8
     assert c4["train_step_ms"] > c4["ms_per_step"]
@@ -64,7 +66,7 @@ def test_bench_two_ranks_share_the_gpu(hip_lib):
     assert r["config"]["global_particles"] == 4000 and r["config"]["particles_per_gpu"] == 2000 and r["value"] > 1e6
     assert r["collective"]["us_per_call"] > 0 and r["collective"]["bytes_per_rank"] == 40
     legs = r["legs"]
-    assert set(legs) == {"weak", "weak_pipelined", "strong_named", "strong_sharded_cfg4"}
+    assert set(legs) == {"weak", "weak_prepared", "weak_pipelined", "strong_named", "strong_sharded_cfg4"}
     assert legs["weak"]["value"] == pytest.approx(r["value"]) and r["headline_leg"] == "weak"
     assert r["ms_per_step"] == pytest.approx(legs["weak"]["ms_per_step"])
     assert r["value_per_call"] == pytest.approx(r["value"]) and r["value_pipelined"] == pytest.approx(legs["weak_pipelined"]["value"])
@@ -82,6 +84,41 @@ def test_bench_two_ranks_share_the_gpu(hip_lib):
     assert legs["strong_sharded_cfg4"]["global_particles"] == 16000 and legs["strong_sharded_cfg4"]["particles_per_gpu"] == 8000
     assert legs["strong_sharded_cfg4"]["train_step_ms"] > 0
     assert r["roofline"]["kernel"].startswith("coop_kernel<8-particle tiles")       # asked of the library, not re-derived
+
+
+def test_bench_plain_command_starts_its_own_ranks(hip_lib):
+    """`python3 bench.py --gpus 2 ...` as typed — no launcher on the command line, the form of the driver's N = 1 command: bench.py
+    starts torch.distributed.run itself as a child process (before touching the GPU) and the one JSON line is complete at N > 1:
+    roofline AND cpu_baseline / parity (rank 0, the other rank waits), the collective and the strong-scaling figures."""
+    env = dict(os.environ, CMCD_BENCH_SHARED_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    r = _line(out.stdout)
+    for f in FIELDS:
+        assert f in r, f
+    assert r["n_gpus"] == 2 and r["steps"] == 5 and r["warmup"] == 2 and r["config"]["global_particles"] == 4000
+    assert r["roofline"]["frac"] > 0 and r["roofline"]["kernel"].startswith("coop_kernel<8-particle tiles")
+    cb = r["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port" and "sample" in cb
+    assert r["parity"]["inf_set_equal"] and r["parity"]["elbo_abs_err"] <= 1e-3 and r["parity"]["lnz_abs_err"] <= 1e-3
+    assert r["collective"]["us_per_call"] > 0
+    ss = r["strong_scaling"]
+    assert ss["n_gpus"] == 2 and ss["named"] > 0 and ss["cfg4"] > 0 and ss["cfg4_train_step"] > 0
+    assert "weak_prepared" in r["legs"] and r["headline_leg"] == "weak"
+
+
+def test_bench_refuses_more_ranks_than_gpus(hip_lib):
+    """Without the shared-GPU test hook a one-GPU box cannot run --gpus 2: a clear refusal, not a crash of a rank."""
+    env = {k: v for k, v in os.environ.items() if k not in ("CMCD_BENCH_SHARED_GPU", "RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a one-GPU box")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode == 2 and "GPU(s) visible" in out.stderr
 
 
 def test_bench_single_rank_over_rccl(hip_lib):

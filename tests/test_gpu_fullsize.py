@@ -31,7 +31,7 @@ def test_north_star_full_batch_against_oracle(hip_lib, param_set):
     seeds = synthetic.throughput_seeds(2000)
     losses, z, stats = _fwd(b, seeds)
     l_ref, z_ref = run_oracle(b, seeds, dtype=np.float32, reuse=False)
-    rep = compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag="config 3 full")
+    rep = compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag="config 3 full", K=b["params_fixed"][1])
     assert rep["n_inf"] > 0                                     # init_sigma = 60 leaves particles beyond the floor
     lh = losses.double().cpu().numpy()
     assert abs(orc.ln_z(lh) - orc.ln_z(l_ref)) < 0.05           # BASELINE.json's ln Z bar
@@ -83,7 +83,13 @@ def test_vargrad_config_full_batch_statistics(hip_lib, param_set):
     want = min(1e7, float(lh.var(unbiased=False)))
     assert abs(float(val) - want) <= 1e-6 * want
     l_ref, z_ref = run_oracle(b, seeds[:64], dtype=np.float64)
-    compare_losses(losses[:64].cpu().numpy(), l_ref, z[:64].cpu().numpy(), z_ref, tag="config 4 slice")
+    compare_losses(losses[:64].cpu().numpy(), l_ref, z[:64].cpu().numpy(), z_ref, tag="config 4 slice", K=b["params_fixed"][1])
+    # ... and the WHOLE batch against the reference-faithful float32 C restatement (oracle/cmcd_oracle.c, OpenMP over particles:
+    # 16 000 x 256 bridges x two 132-wide evaluations, ~15 s on the GPU box's host cores): every particle's loss and z_K
+    from helpers import run_c_oracle
+    lc, zc = run_c_oracle(b, seeds)
+    rep = compare_losses(losses.cpu().numpy(), lc, z.cpu().numpy(), zc, tag="config 4 full batch vs C oracle", K=b["params_fixed"][1])
+    print("config 4 full batch:", rep)
 
 
 def test_sharded_statistics_equal_single_launch(hip_lib):
@@ -296,6 +302,87 @@ def test_prepared_tables_are_reused_only_while_the_parameters_are_unchanged(hip_
     mcdbm.bound_forward(seeds[: n // 2], p, *args, **kw)
     mcdbm.bound_forward(seeds, p.clone(), *args, **kw)
     assert calls()["full"] - c1["full"] == 2
+
+
+@pytest.mark.parametrize("name,n", [("gmm_n300_k8", 300), ("many_gmm_n2000_k256_dds", 2000)])
+def test_a_call_outside_the_context_retires_the_prepared_tables(hip_lib, name, n):
+    """r04 advisor: `with fixed_parameters(): f(P)`; then OUTSIDE the context f(Q) (or f(P) at another batch size) on the same
+    stream — its prep launch overwrites the workspace's tables; then `with fixed_parameters(): f(P)` again.  The third call
+    must run its prep launch ('full') and return f(P), not P's chain on Q's tables."""
+    b = synthetic.build(name, device="cuda", nbridges=16)
+    seeds = torch.from_numpy(synthetic.throughput_seeds(n, stream=5)).cuda()
+    args = (b["unflatten"], b["params_fixed"], b["target"])
+    kw = dict(eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
+    P = b["params_flat"].clone()
+    Q = (b["params_flat"] * 1.01).contiguous()
+    ref_p = [t.clone() for t in mcdbm.bound_forward(seeds, P, *args, **kw)]
+    ref_q = [t.clone() for t in mcdbm.bound_forward(seeds, Q, *args, **kw)]
+    assert not torch.equal(ref_p[0], ref_q[0])
+    for other in ("other parameters", "other batch size", "other eps schedule"):
+        with mcdbm.fixed_parameters():
+            mcdbm.bound_forward(seeds, P, *args, **kw)
+            c = dict(mcdbm.PREP_CALLS)
+            got = mcdbm.bound_forward(seeds, P, *args, **kw)
+            assert mcdbm.PREP_CALLS["prepared"] - c["prepared"] == 1          # the shortcut is live inside the context
+            assert torch.equal(got[0], ref_p[0])
+        if other == "other parameters":
+            lq = mcdbm.bound_forward(seeds, Q, *args, **kw)[0]
+            assert torch.equal(lq, ref_q[0])
+        elif other == "other batch size":
+            mcdbm.bound_forward(seeds[: n // 2], P, *args, **kw)
+        else:
+            mcdbm.bound_forward(seeds, P, *args, eps_schedule="linear", grad_clipping=kw["grad_clipping"])
+        with mcdbm.fixed_parameters():
+            c = dict(mcdbm.PREP_CALLS)
+            got = mcdbm.bound_forward(seeds, P, *args, **kw)
+            assert mcdbm.PREP_CALLS["full"] - c["full"] == 1, other          # the claim on the buffer was retired
+            for g, r in zip(got, ref_p):
+                assert torch.equal(g, r), other
+
+
+@pytest.mark.parametrize("name,n", [("gmm_n300_k8", 300), ("many_gmm_n2000_k256_dds", 2000), ("many_gmm_n2000_k256_dds", 5000)])
+def test_the_prepared_entry_point_refuses_tables_of_another_call(hip_lib, name, n):
+    """cmcd_bound_forward_prepared's contract, checked on the device (include/cmcd_hip.h): the forming call leaves a stamp of
+    its (desc, layout, n, n_params, n_target) in the workspace; a prepared call with another n or descriptor gets NaN statistics
+    ("diverged") instead of silent garbage.  Covers the fused merge (38 workgroups), the finalize launch behind the cooperative
+    kernel (250) and behind the wave-per-tile kernel (n = 5000)."""
+    import ctypes as C
+    from cmcd_amd import _lib
+    L = _lib.lib()
+    b = synthetic.build(name, device="cuda", nbridges=8)
+    dim, K, mode, spec = b["params_fixed"]
+    un = b["unflatten"]
+    seeds = torch.from_numpy(synthetic.throughput_seeds(n, stream=9).astype(np.int32)).cuda()
+    consts = b["target"].consts_on(torch.device("cuda"))
+    cp, cn = (consts.data_ptr(), consts.numel()) if consts is not None else (None, 0)
+
+    def desc(eps_schedule):
+        return _lib.Desc(dim=dim, nbridges=K, mode=_lib.MODE[mode], arch=_lib.ARCH[spec.arch], emb_dim=spec.emb_dim,
+                         target=b["target"].target_id, eps_schedule=eps_schedule, grad_clipping=int(bool(b["grad_clipping"])),
+                         ngrid=un.shape("mgridref_y")[0] - 1, reserved=0)
+    d0 = desc(_lib.EPS_SCHEDULE[b["eps_schedule"]])
+    lay = mcdbm._layout(un, spec)
+    ws = torch.empty(L.cmcd_workspace_bytes(C.byref(d0), n) + 4096, dtype=torch.uint8, device="cuda")
+    p = b["params_flat"]
+
+    def call(fn, d, m):
+        loss = torch.empty(m, dtype=torch.float32, device="cuda")
+        z = torch.empty(m, dim, dtype=torch.float32, device="cuda")
+        st = torch.empty(5, dtype=torch.float64, device="cuda")
+        _lib.check(fn(C.byref(d), C.byref(lay), seeds.data_ptr(), m, p.data_ptr(), p.numel(), cp, cn, ws.data_ptr(), ws.numel(),
+                      loss.data_ptr(), z.data_ptr(), st.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        return loss, st
+    l0, s0 = call(L.cmcd_bound_forward, d0, n)
+    l1, s1 = call(L.cmcd_bound_forward_prepared, d0, n)              # the contract kept: same bits
+    assert torch.equal(l0, l1) and torch.equal(s0, s1) and not torch.isnan(s1).any()
+    _, s2 = call(L.cmcd_bound_forward_prepared, d0, n - 8)           # another batch size on these tables
+    assert torch.isnan(s2).all()
+    other = desc((d0.eps_schedule + 1) % 3)
+    _, s3 = call(L.cmcd_bound_forward_prepared, other, n)            # another descriptor
+    assert torch.isnan(s3).all()
+    _, s4 = call(L.cmcd_bound_forward_prepared, d0, n)               # and the right one still passes afterwards
+    assert torch.equal(s4, s0)
 
 
 def test_a_captured_forward_keeps_its_prep_launch(hip_lib, monkeypatch):

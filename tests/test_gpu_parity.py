@@ -41,7 +41,7 @@ def test_bound_matches_oracle(hip_lib, param_set, variant, name, n, over):
                           b["target"], eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
     torch.cuda.synchronize()
     l_ref, z_ref = run_oracle(b, seeds, dtype=np.float64)
-    rep = compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"{name} n={n}")
+    rep = compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"{name} n={n}", K=b["params_fixed"][1])
     print(name, n, over, rep)
     # the scalar the reference returns
     lh = losses.double().cpu().numpy()
@@ -53,6 +53,47 @@ def test_bound_matches_oracle(hip_lib, param_set, variant, name, n, over):
         assert abs(float(val) - want) <= 1e-5 * max(1.0, abs(want))
     else:
         assert not np.isfinite(float(val))
+
+
+@pytest.mark.parametrize("form", [4, 5], ids=["dealt_coordinates", "narrow_form"])
+@pytest.mark.parametrize("n,over", [
+    (300, {}),                                                    # BASELINE configs[1] itself
+    (13, dict(nbridges=9)),                                       # ragged: one full tile + 5; odd bridge count
+    (1, dict(nbridges=2)),
+    (64, dict(emb_dim=20, nbridges=12)),                          # 30-wide net: the two-MLP-wave instance
+    (64, dict(nn_arch="dds", nbridges=12)),                       # PISGRADNet on the funnel
+    (96, dict(boundmode="MCD_CAIS_var_sn", nbridges=12, grad_clipping=True, init_sigma=3.0)),   # both clips (1e2) active
+    (96, dict(boundmode="MCD_ULA_sn", nbridges=12)),
+    (2048, dict(nbridges=3)),                                     # the top of the 8-particle range: 256 workgroups
+])
+def test_funnel_on_8_particle_tiles(hip_lib, param_set, monkeypatch, n, over, form):
+    """d = 10 on 8-particle tiles: kernel variant 4 = coop_wide8_kernel (cmcd_coop_wide.hip: every per-coordinate job dealt to
+    the lanes of its particle; what a funnel batch of <= 2048 particles runs on), 5 = the same batch on coop_kernel's 8-particle
+    instance (the r04 form, kept for A / B)."""
+    from cmcd_amd import _lib
+    monkeypatch.setattr(mcdbm, "KERNEL_VARIANT", form)
+    b = synthetic.build("funnel_n300_k64", device="cuda", **over)
+    seeds = synthetic.parity_seeds(n)
+    fn = mcdbm.compute_bound_var if "var" in b["cfg"]["boundmode"] else mcdbm.compute_bound
+    val, (losses, z) = fn(torch.from_numpy(seeds).cuda(), b["params_flat"], b["unflatten"], b["params_fixed"], b["target"],
+                          eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
+    torch.cuda.synchronize()
+    assert _lib.last_kernel_name() == ("coop_wide8_kernel<8-particle tiles>" if form == 4 else "coop_kernel<8-particle tiles>")
+    l_ref, z_ref = run_oracle(b, seeds, dtype=np.float64)
+    rep = compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"funnel n={n} {over} form={form}",
+                         K=b["params_fixed"][1])
+    print(n, over, form, rep)
+    # determinism and batch-composition invariance of the new kernel: same bits on a repeat, and for a particle launched in
+    # another tile / column
+    if form == 4 and n >= 13:
+        l2 = fn(torch.from_numpy(seeds).cuda(), b["params_flat"], b["unflatten"], b["params_fixed"], b["target"],
+                eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])[1][0]
+        assert torch.equal(l2, losses)
+        if "var" not in b["cfg"]["boundmode"]:
+            perm = np.random.default_rng(0).permutation(n)
+            lp, zp = fn(torch.from_numpy(seeds[perm]).cuda(), b["params_flat"], b["unflatten"], b["params_fixed"], b["target"],
+                        eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])[1]
+            assert torch.equal(lp.cpu(), losses.cpu()[perm]) and torch.equal(zp.cpu(), z.cpu()[perm])
 
 
 @pytest.mark.parametrize("n,k,form", [(20, 8, 0), (5, 3, 0), (40, 2, 0), (20, 128, 0), (600, 16, 0), (17, 3, 0), (16, 2, 0),
@@ -74,7 +115,7 @@ def test_lgcp_matches_oracle(hip_lib, param_set, monkeypatch, n, k, form):
                                            grad_clipping=b["grad_clipping"])
     torch.cuda.synchronize()
     l_ref, z_ref = run_oracle(b, seeds, dtype=np.float64, lgcp_counts=counts)
-    rep = compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"lgcp n={n} k={k}")
+    rep = compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"lgcp n={n} k={k}", K=k)
     print("lgcp", n, k, rep, "mean loss", float(val), l_ref.mean())
     assert abs(float(val) - losses.double().mean().item()) <= 1e-5 * abs(l_ref.mean())
 
@@ -129,7 +170,7 @@ def test_lgcp_wide_batch_path_matches_oracle(hip_lib, param_set, monkeypatch, mo
         l_ref, z_ref = orc.compute_log_elbo_batch(seeds, p, dim, K, mode, spec.arch, oracle_target(b["cfg"], counts), dtype=np.float64)
     else:
         l_ref, z_ref = run_oracle(b, seeds, dtype=np.float64, lgcp_counts=counts)
-    rep = compare_losses(out[2][1], l_ref, out[2][2], z_ref, tag=f"lgcp wide {mode} n={n} k={k}")
+    rep = compare_losses(out[2][1], l_ref, out[2][2], z_ref, tag=f"lgcp wide {mode} n={n} k={k}", K=k)
     print("lgcp wide", mode, n, k, over, rep)
     # the two forms of the path sum the contractions in different orders: float32 rounding apart, nothing else
     np.testing.assert_allclose(out[2][1], out[1][1], rtol=2e-5, atol=2e-3)
@@ -173,7 +214,7 @@ def test_sibling_overdamped_modes_match_oracle(hip_lib, param_set, variant, name
         arch = spec.arch
     from helpers import oracle_target
     l_ref, z_ref = orc.compute_log_elbo_batch(seeds, p, dim, K, mode, arch, oracle_target(b["cfg"]), dtype=np.float64)
-    rep = compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"{name} {mode}")
+    rep = compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"{name} {mode}", K=K)
     print(name, mode, rep)
 
 
@@ -190,7 +231,7 @@ def test_many_gmm_with_other_mixture_sizes(hip_lib, monkeypatch, n_mixes, varian
                                             grad_clipping=b["grad_clipping"])
     torch.cuda.synchronize()
     l_ref, z_ref = run_oracle(b, seeds, dtype=np.float64)
-    compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"n_mixes={n_mixes}")
+    compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"n_mixes={n_mixes}", K=24)
 
 
 @pytest.mark.parametrize("variant", [1, 2, 3])
@@ -207,7 +248,7 @@ def test_network_widths_between_the_instances_run_zero_padded(hip_lib, param_set
                                             grad_clipping=b["grad_clipping"])
     torch.cuda.synchronize()
     l_ref, z_ref = run_oracle(b, seeds, dtype=np.float64)
-    compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"{model} emb_dim={emb_dim}")
+    compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"{model} emb_dim={emb_dim}", K=12)
 
 
 @pytest.mark.parametrize("variant", [2, 3, 4])
@@ -224,7 +265,7 @@ def test_widths_around_the_132_wide_net_on_the_cooperative_kernels(hip_lib, para
                                             grad_clipping=b["grad_clipping"])
     torch.cuda.synchronize()
     l_ref, z_ref = run_oracle(b, seeds, dtype=np.float64)
-    compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"many_gmm emb_dim={emb_dim} variant={variant}")
+    compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"many_gmm emb_dim={emb_dim} variant={variant}", K=9)
 
 
 @pytest.mark.parametrize("tag", ["gmm_k8", "funnel_k64", "many_gmm_dds_k256", "many_gmm_var_k32", "dense_gmm_k8",
@@ -238,4 +279,4 @@ def test_bound_matches_committed_golden_vectors(hip_lib, variant, tag):
     _, (losses, z) = fn(torch.from_numpy(g["seeds"]).cuda(), b["params_flat"], b["unflatten"], b["params_fixed"],
                         b["target"], eps_schedule=b["eps_schedule"], grad_clipping=b["grad_clipping"])
     torch.cuda.synchronize()
-    compare_losses(losses.cpu().numpy(), g["loss"], z.cpu().numpy(), g["z"], tag=f"golden {tag}")
+    compare_losses(losses.cpu().numpy(), g["loss"], z.cpu().numpy(), g["z"], tag=f"golden {tag}", K=b["params_fixed"][1])

@@ -74,7 +74,7 @@ def test_bound_matches_oracle(hip_lib, param_set, variant, name, n, over):
     if key not in _ORACLE_FWD:
         _ORACLE_FWD[key] = run_oracle(b, seeds, dtype=np.float64)
     l_ref, z_ref = _ORACLE_FWD[key]
-    rep = compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"UHA {name} n={n}")
+    rep = compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"UHA {name} n={n}", K=b["params_fixed"][1])
     print(name, n, over, rep)
     assert _lib.last_kernel_name() == KERNEL_NAMES[variant]
     want = np.mean(losses.double().cpu().numpy())
@@ -254,7 +254,7 @@ def test_lgcp_matches_oracle(hip_lib, param_set, n, k):
                                            b["params_fixed"], b["target"])
     torch.cuda.synchronize()
     l_ref, z_ref = run_oracle(b, seeds, dtype=np.float64, lgcp_counts=counts)
-    rep = compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"UHA lgcp n={n} k={k}")
+    rep = compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"UHA lgcp n={n} k={k}", K=k)
     print("UHA lgcp", n, k, rep, "mean loss", float(val), l_ref.mean())
     assert abs(float(val) - losses.double().mean().item()) <= 1e-5 * abs(l_ref.mean())
 

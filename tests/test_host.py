@@ -198,3 +198,45 @@ def test_unflatten_with_a_zero_size_leaf_in_the_middle():
     assert notrain["target_x"].shape == (0,)
     assert sum(int(np.prod(s)) if s else 1 for _, s in unflatten.layout.values()) == flat.numel()
     assert float(train["eps"]) == pytest.approx(0.01) and notrain["vd"]["mean"].shape == (2,)
+
+
+def test_bench_self_launch_builds_the_launcher_command(monkeypatch):
+    """`python3 bench.py --gpus N` (N > 1, no launcher in the environment) starts torch.distributed.run as a CHILD process
+    with the same argv, on 127.0.0.1 and a free port, and refuses clearly when the node shows fewer than N devices —
+    all before anything of the parent touches the GPU (no GPU here: the child is intercepted)."""
+    import importlib.util
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    class Done:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return Done()
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "5", "--warmup", "2"])
+    monkeypatch.delenv("CMCD_BENCH_SHARED_GPU", raising=False)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    assert bench.self_launch(4) == 2 and "cmd" not in seen                   # 1 device visible: refused, nothing started
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    assert bench.self_launch(4) == 7                                         # the child's return code comes back
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    assert cmd[-7:] == [os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "5", "--warmup", "2"]
+    assert seen["env"]["MASTER_ADDR"] == "127.0.0.1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # the plain command on this GPU-less box: exit code 2 and the reason, not an assertion error from a rank
+    monkeypatch.undo()
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=300,
+                         env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "CMCD_BENCH_SHARED_GPU")})
+    if torch.cuda.device_count() < 2:
+        assert out.returncode == 2 and "GPU(s) visible" in out.stderr

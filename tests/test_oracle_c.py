@@ -24,7 +24,7 @@ def test_c_oracle_matches_numpy_oracle(param_set, name, n, over):
     seeds = synthetic.parity_seeds(n)
     lc, zc = run_c_oracle(b, seeds)
     l64, z64 = run_oracle(b, seeds, dtype=np.float64)
-    rep = compare_losses(lc, l64, zc, z64, tag=f"C oracle {name}")
+    rep = compare_losses(lc, l64, zc, z64, tag=f"C oracle {name}", K=b["params_fixed"][1])
     assert rep["rel_p99"] < 1e-3
     l32, _ = run_oracle(b, seeds, dtype=np.float32, reuse=False)       # same arithmetic type
     f = np.isfinite(l32)

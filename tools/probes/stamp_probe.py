@@ -13,7 +13,7 @@ os.makedirs(os.path.dirname(lib), exist_ok=True)
 csrc = os.path.join(ROOT, "cmcd_amd", "csrc")
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                 "-DCMCD_STAMPS", "-I", os.path.join(ROOT, "include"), "-I", csrc, "-Wno-format-security",
-                "-o", lib, os.path.join(csrc, "cmcd_kernels.hip"), os.path.join(csrc, "cmcd_coop.hip"), os.path.join(csrc, "cmcd_uha.hip"),
+                "-o", lib, os.path.join(csrc, "cmcd_kernels.hip"), os.path.join(csrc, "cmcd_coop.hip"), os.path.join(csrc, "cmcd_coop_wide.hip"), os.path.join(csrc, "cmcd_uha.hip"),
                 os.path.join(csrc, "cmcd_lgcp.hip"), os.path.join(csrc, "cmcd_lgcp_wide.hip"), os.path.join(csrc, "cmcd_grad.hip"), os.path.join(csrc, "cmcd_bptt.hip"),
                 os.path.join(csrc, "cmcd_mfvi.hip"), os.path.join(csrc, "cmcd_opt.hip")], check=True)
 os.environ["CMCD_LIB_PATH"] = lib
@@ -32,8 +32,24 @@ for _ in range(3):
 torch.cuda.synchronize()
 L = _lib.lib()
 buf = (C.c_ulonglong * 256)()
-L.cmcd_debug_read_stamps(buf)
 K = b["params_fixed"][1]
+print("kernel:", _lib.last_kernel_name())
+if _lib.last_kernel_name().startswith("coop_wide8"):
+    # cmcd_coop_wide.hip: slots 0 = interval 1 work, 1 = wait at barrier 1, 2 = interval 2 work (MLP: 7 = layer 2, 2 = layer 3),
+    # 3 = wait at barrier 2, 4 = interval 3 work (ACC: z_{i+1}; RNG: chain segment), 5 = wait at barrier 3, 6 = after barrier 3
+    # (MLP / TGT: read the state; ACC: log-weight terms)
+    L.cmcd_debug_read_stamps_wide(buf)
+    Tw = (b["params_fixed"][3].width + 15) // 16 if b["params_fixed"][3].arch == "geffner" else 4
+    Tw = 2 if Tw <= 2 else 4
+    cols = [("int1 work", 0), ("wait bar1", 1), ("layer 2", 7), ("int2 work", 2), ("wait bar2", 3), ("int3 work", 4), ("wait bar3", 5),
+            ("after bar3", 6)]
+    print("cycles per bridge step, workgroup 0 (coop_wide8_kernel):")
+    for wv in range(Tw + 4):
+        role = "MLP%d" % wv if wv < Tw else ["TGT0", "TGT1", "RNG", "ACC"][wv - Tw]
+        vals = [buf[wv * 16 + k] / (K + 1) for _, k in cols]
+        print("%5s " % role + "  ".join("%s=%6.0f" % (nm, v) for (nm, _), v in zip(cols, vals)) + "  total=%7.0f" % sum(vals))
+    sys.exit(0)
+L.cmcd_debug_read_stamps(buf)
 names = ["int1 work", "wait bar1", "int2 tail", "wait bar2", "phaseC tail"]
 T = (b["params_fixed"][3].width + 15) // 16 if b["params_fixed"][3].arch == "geffner" else 4
 print("cycles per bridge step, workgroup 0:")
@@ -44,4 +60,4 @@ for wv in range(nw):
     row = [buf[wv * 16 + k] / (K + 1) for k in range(5)]
     fine = [buf[wv * 16 + k] / (K + 1) for k in range(5, 10)]
     role = "MLP%d" % wv if wv < T else (["TGT0", "TGT1", "RNG", "ACC"] if nw == T + 4 else ["TGT0", "TGT1", "RNG+ACC"])[wv - T]
-    print("%5s " % role + "  ".join("%s=%7.0f" % (nm, v) for nm, v in zip(names, row)) + "  total=%7.0f" % (sum(row) + sum(fine)) + "  | [-, -, int2 reads+MFMA, int2 fold+act, phaseC rows]=" + " ".join("%5.0f" % v for v in fine))
+    print("%5s " % role + "  ".join("%s=%7.0f" % (nm, v) for nm, v in zip(names, row)) + "  total=%7.0f" % (sum(row) + sum(fine)) + "  | [wait bar3 (d>4), ACC z publish (d>4), int2 reads+MFMA, int2 fold+act, phaseC rows]=" + " ".join("%5.0f" % v for v in fine))
