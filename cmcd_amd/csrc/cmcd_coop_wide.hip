@@ -124,15 +124,15 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_wide8_kernel(TrajArgs a) {
   constexpr int HP = 16 * T, NR = 2, Hh = D / 2, DP = (D + 3) & ~3;
   constexpr int HQP = HP + 4, NQ = HP / 2, RSA = ((HP / 2 + 15) / 16) * 4;
   constexpr int PTW = (D * T + 3) & ~3;           // layer-3 partials of one particle: [j][wave]
-  constexpr int GPW = (2 * D + 1 + 3) & ~3;       // base [D], grad log p [D], log p
-  constexpr int kCut1 = CMCD_WIDE_CUT1, kCut2 = CMCD_WIDE_CUT2;
+    constexpr int kCut1 = CMCD_WIDE_CUT1, kCut2 = CMCD_WIDE_CUT2;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const hbuf = lds;                        // [8][HQP]   layer-1 activations
-  float* const part = hbuf + 8 * HQP;             // [8][PTW]
-  float* const gpb = part + 8 * PTW;              // [8][GPW]
-  float* const nzb = gpb + 8 * GPW;               // [8][DP]    deviates of the current bridge
-  float* const zpub = nzb + 8 * DP;               // [8][DP]    the published state
-  uint32_t* const raw = reinterpret_cast<uint32_t*>(zpub + 8 * DP);   // [2][8][DP] random words, one bridge ahead
+  float* const part = hbuf + 8 * HQP;             // [8][PTW]   layer-3 partials [j][wave]
+  float* const baseb = part + 8 * PTW;            // [8][DP]    base_j of the forward mean (TGT -> ACC)
+  float* const spub = baseb + 8 * DP;             // [8][DP]    s(z_i, i)_j (ACC -> TGT)
+  float* const zpub = spub + 8 * DP;              // [8][DP]    the published state z_{i+1} (ACC -> MLP, TGT)
+  float* const lossb = zpub + 8 * DP;             // [8]        per-particle loss at the end (TGT -> ACC)
+  uint32_t* const raw = reinterpret_cast<uint32_t*>(lossb + 8);   // [2][8][DP] random words, one bridge ahead
 
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -195,7 +195,6 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_wide8_kernel(TrajArgs a) {
     const int own_slot = ((ng & 1) << 1) | (ng >> 1);
     float z[D], uz[2] = {0.f, 0.f};
     wbar();   // P1: random words of z_0
-    wbar();   // P2: deviates of z_0
     wbar();   // P3: z_0 published
     auto read_state = [&]() {
 #pragma unroll
@@ -281,6 +280,7 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_wide8_kernel(TrajArgs a) {
       if (i < K) read_state();
       WSTAMP(6);
     }
+    wbar();   // F1: per-particle losses handed to the ACC wave
   }
   // =============================================================================================== TGT
   else if (is_tgt) {
@@ -293,57 +293,68 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_wide8_kernel(TrajArgs a) {
     const float qmean = a.params[a.lay.vd_mean + j];
     const float qstd = expf(a.params[a.lay.vd_logdiag + j]);
     const float qiv = 1.0f / (qstd * qstd);
-    auto convert = [&](int buf, int stage) {
-      const uint32_t bits = raw[(buf * 8 + pc) * DP + j];
-      const float dev = bits_to_normal(bits);
-      if (act) {
-        nzb[pc * DP + j] = dev;
-        if (a.dbg_bits && valid) {
-          a.dbg_bits[((int64_t)stage * a.n + p) * D + j] = bits;
-          a.dbg_noise[((int64_t)stage * a.n + p) * D + j] = dev;
-        }
-      }
-    };
     wbar();   // P1
-    convert(1, 0);
-    wbar();   // P2
     wbar();   // P3
     float zj = zpub[pc * DP + j], v = zpub[pc * DP];
+    // this lane's share of the log-weight: coordinate j of w = -log q(z_0) + sum_i [log N(z_i; bk_i, sigma_i) - log N(z_{i+1}; fk_i, sigma_i)]
+    float wl = 0.f, zp = 0.f, lp = 0.f;
+    {
+      const float dz = zj - qmean;                        // -log q(z_0)      diag_gauss.py:49-62, mcdboundingmachine.py:157
+      wl = (dz * dz) / (2.0f * qstd * qstd) + logf(qstd) + kHalfLog2Pi;
+    }
+    float peps = 0.f, pinv2s2 = 0.f, pcst = 0.f, pA = 0.f, pB = 0.f;
 #ifdef CMCD_STAMPS
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
 #endif
     for (int i = 0; i <= K; ++i) {
       CMCD_WIDE_SCHED_LOAD(i);
-      if (i < K) convert(i & 1, i + 1);
-      WSTAMP(0);
-      CMCD_WIDE_BAR1_SCHED();
-      WSTAMP(1);
       // funnel (/root/reference/src/model_handler.py:124-143; the scale of v is the hard-coded 3.0):
       //   log p = logN(v; 0, 3) + sum_{j >= 1} logN(z_j; 0, e^{v / 2})
       //   d / dv = -v / 9 - (d - 1) / 2 + e^{-v} ss / 2,   d / dz_j = -z_j e^{-v},   ss = sum_{j >= 1} z_j^2
+      // Everything that does not need the schedule row runs in interval 1 (the MLP partners of these waves are short there and
+      // long in interval 2); e^{-v} through v_exp_f32, the constants as reciprocals (no IEEE division on these waves).
       const float ss = part_sum<16>((act && j >= 1) ? zj * zj : 0.f);
-      const float emv = expf(-v);
+      const float emv = __builtin_amdgcn_exp2f(-1.44269504088896340736f * v);
       constexpr float c0 = -0.5f * kLog2Pi - 1.0986122886681098f, c1 = -0.5f * (D - 1) * kLog2Pi;
-      const float g0 = -v / 9.0f - 0.5f * (D - 1) + 0.5f * emv * ss;
+      const float hes = 0.5f * emv * ss;
+      const float g0 = fmaf(v, -1.0f / 9.0f, hes - 0.5f * (D - 1));
       const float gp = j == 0 ? g0 : -zj * emv;
       const float gpc = __builtin_amdgcn_fmed3f(gp, -cp, cp);
       const float gqc = __builtin_amdgcn_fmed3f((qmean - zj) * qiv, -cq, cq);
-      if (act) {
-        gpb[pc * GPW + j] = fmaf(sd[1], gpc, fmaf(sd[2], gqc, zj));   // base_j = z_j + eps beta clip(gp_j) + eps (1 - beta) clip(gq_j)
-        gpb[pc * GPW + D + j] = gp;
-        if (j == 0) gpb[pc * GPW + 2 * D] = c0 - v * v / 18.0f + c1 - 0.5f * (D - 1) * v - 0.5f * emv * ss;
-      }
+      lp = fmaf(v * v, -1.0f / 18.0f, c0 + c1) - 0.5f * (D - 1) * v - hes;
+      WSTAMP(0);
+      CMCD_WIDE_BAR1_SCHED();
+      WSTAMP(1);
+      const float eps = sc[1], cst = sc[3], inv2s2 = sd[0], cA = sd[1], cB = sd[2];
+      const float base = fmaf(cA, gpc, fmaf(cB, gqc, zj));   // base_j = z_j + eps beta clip(gp_j) + eps (1 - beta) clip(gq_j)
+      if (act) baseb[pc * DP + j] = base;
       WSTAMP(2);
       wbar();   // barrier 2
       WSTAMP(3);
       wbar();   // barrier 3
       WSTAMP(5);
-      if (i < K) {
-        zj = zpub[pc * DP + j];
-        v = zpub[pc * DP];
+      // ---- the log-weight terms of coordinate j (mcd_cais.py:71-86), off the critical path: s(z_i, i)_j and z_{i+1, j} from the ACC wave
+      const float sn = spub[pc * DP + j], zn = zpub[pc * DP + j], vn = zpub[pc * DP];
+      if (i > 0) {   // backward kernel of step i - 1: bk = z - eps ub + eps s(z_i, i), ub = -(beta gp + (1 - beta) gq) at z_i
+        const float bk = fmaf(pA, gpc, fmaf(pB, gqc, fmaf(peps, sn, zj)));
+        const float db = zp - bk;
+        wl += -(db * db) * pinv2s2 - pcst;
+      }
+      if (i < K) {   // forward kernel of step i: fk = base - eps s, z_{i+1} = fk + sigma noise
+        const float fk = fmaf(a.ula ? 0.f : -eps, sn, base);
+        const float df = zn - fk;
+        wl -= -(df * df) * inv2s2 - cst;
+        zp = zj;
+        zj = zn;
+        v = vn;
+        peps = eps; pinv2s2 = inv2s2; pcst = cst; pA = cA; pB = cB;
       }
       WSTAMP(6);
     }
+    // w = sum over coordinates + log p(z_K); loss = -w                              mcdboundingmachine.py:178-179
+    const float wtot = part_sum<16>(act ? wl : 0.f) + lp;
+    if (sub == 0) lossb[pc] = -wtot;
+    wbar();   // F1
   }
   // =============================================================================================== RNG
   else if (is_rng) {
@@ -425,7 +436,6 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_wide8_kernel(TrajArgs a) {
     using I10 = std::integral_constant<int, 10>;
     chain(I0{}, I10{}, 0, 1);   // bridge 0
     wbar();   // P1
-    wbar();   // P2
     wbar();   // P3
 #ifdef CMCD_STAMPS
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
@@ -446,6 +456,7 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_wide8_kernel(TrajArgs a) {
       wbar();   // barrier 3
       WSTAMP(5);
     }
+    wbar();   // F1
   }
   // =============================================================================================== ACC
   else {
@@ -455,45 +466,55 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_wide8_kernel(TrajArgs a) {
     // coordinates of this lane: jA = s8 (always), jB = s8 + 8 (lanes s8 < D - 8)
     const int jc[2] = {s8, s8 + 8 < D ? s8 + 8 : s8};
     const bool on[2] = {true, s8 + 8 < D};
-    float qmean[2], qstd[2], qiv[2], b3[2];
+    float qmean[2], qstd[2], b3[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       qmean[q] = a.params[a.lay.vd_mean + jc[q]];
       qstd[q] = expf(a.params[a.lay.vd_logdiag + jc[q]]);
-      qiv[q] = 1.0f / (qstd[q] * qstd[q]);
       b3[q] = a.ws[a.w.b3 + jc[q]];
     }
     const float factor = a.ws[a.w.b3 + 15];
+    // random word -> deviate of coordinate jc[q] (jax.random.normal: Giles' erfinv); `stage` = debug-capture index
+    float nzv[2] = {0.f, 0.f};
+    auto convert = [&](int q, int buf, int stage) {
+      const uint32_t bits = raw[(buf * 8 + pc) * DP + jc[q]];
+      nzv[q] = bits_to_normal(bits);
+      if (a.dbg_bits && valid && on[q]) {
+        a.dbg_bits[((int64_t)stage * a.n + p) * D + jc[q]] = bits;
+        a.dbg_noise[((int64_t)stage * a.n + p) * D + jc[q]] = nzv[q];
+      }
+    };
     wbar();   // P1
-    wbar();   // P2
-    // z_0 = mean + std * normal(A, (D,)); w = -log q(z_0)            diag_gauss.py:49-62, mcdboundingmachine.py:157
-    float z[2], zp[2] = {0.f, 0.f}, w = 0.f;
+    convert(0, 1, 0);
+    convert(1, 1, 0);
+    // z_0 = mean + std * normal(A, (D,))                               diag_gauss.py:49-62, mcdboundingmachine.py:157
+    float z[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      z[q] = qstd[q] * nzb[pc * DP + jc[q]] + qmean[q];
-      const float dz = z[q] - qmean[q];
+      z[q] = qstd[q] * nzv[q] + qmean[q];
       if (on[q]) {
-        w -= -(dz * dz) / (2.0f * qstd[q] * qstd[q]) - logf(qstd[q]) - kHalfLog2Pi;
         zpub[pc * DP + jc[q]] = z[q];
         if (a.traj && valid) a.traj[p * D + jc[q]] = z[q];
       }
     }
     wbar();   // P3
-    float peps = 0.f, pinv2s2 = 0.f, pcst = 0.f, pA = 0.f, pB = 0.f, logp = 0.f;
 #ifdef CMCD_STAMPS
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
 #endif
     for (int i = 0; i <= K; ++i) {
       CMCD_WIDE_SCHED_LOAD(i);
+      // the deviates of bridge i for this lane's two coordinates: one conversion in interval 1, the other in interval 2
+      if (i < K) convert(0, i & 1, i + 1);
       WSTAMP(0);
       CMCD_WIDE_BAR1_SCHED();
       WSTAMP(1);
+      if (i < K) convert(1, i & 1, i + 1);
       WSTAMP(2);
       wbar();   // barrier 2
       WSTAMP(3);
       // ---- interval 3: s(z_i, i) of this lane's coordinates from the layer-3 partials, the forward mean, z_{i+1}
-      const float eps = sc[1], sig = sc[2], cst = sc[3], inv2s2 = sd[0], cA = sd[1], cB = sd[2];
-      float ptv[2][T], basev[2], gpv[2], nzv[2];
+      const float eps = sc[1], sig = sc[2];
+      float ptv[2][T], basev[2];
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         if (T == 4) {
@@ -505,57 +526,38 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_wide8_kernel(TrajArgs a) {
 #pragma unroll
           for (int r = 0; r < T; ++r) ptv[q][r] = t2[r & 1];
         }
-        basev[q] = gpb[pc * GPW + jc[q]];
-        gpv[q] = gpb[pc * GPW + D + jc[q]];
-        nzv[q] = nzb[pc * DP + jc[q]];
+        basev[q] = baseb[pc * DP + jc[q]];
       }
-      if (i == K) logp = gpb[pc * GPW + 2 * D];
-      float sn[2], fk[2], zn[2];
+      float zn[2];
       const float seps = a.ula ? 0.f : -eps;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         float o = b3[q];
         if (T == 4) o += (ptv[q][0] + ptv[q][1]) + (ptv[q][2] + ptv[q][3]);
         else o += ptv[q][0] + ptv[q][1];
-        sn[q] = (ARCH == CMCD_ARCH_DDS) ? __builtin_amdgcn_fmed3f(o, -1e4f, 1e4f) : o * factor;
-        fk[q] = fmaf(seps, sn[q], basev[q]);          // fk = z - eps uf - eps s                              mcd_cais.py:61
-        zn[q] = fmaf(sig, nzv[q], fk[q]);             // z' = fk + sqrt(2 eps) noise                           mcd_cais.py:63-67
-        if (i < K && on[q]) zpub[pc * DP + jc[q]] = zn[q];
+        const float sn = (ARCH == CMCD_ARCH_DDS) ? __builtin_amdgcn_fmed3f(o, -1e4f, 1e4f) : o * factor;
+        const float fk = fmaf(seps, sn, basev[q]);    // fk = z - eps uf - eps s                              mcd_cais.py:61
+        zn[q] = fmaf(sig, nzv[q], fk);                // z' = fk + sqrt(2 eps) noise                           mcd_cais.py:63-67
+        if (on[q]) {
+          spub[pc * DP + jc[q]] = sn;
+          if (i < K) zpub[pc * DP + jc[q]] = zn[q];
+        }
       }
       WSTAMP(4);
       wbar();   // barrier 3
       WSTAMP(5);
-      // ---- off the critical path: the log-weight terms of this lane's coordinates                           mcd_cais.py:71-86
-      if (i > 0) {   // backward kernel of step i - 1: bk = z - eps ub + eps s(z_i, i), ub = -(beta gp + (1 - beta) gq) at z_i
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const float gpc = __builtin_amdgcn_fmed3f(gpv[q], -cp, cp);
-          const float gqc = __builtin_amdgcn_fmed3f((qmean[q] - z[q]) * qiv[q], -cq, cq);
-          const float bk = fmaf(pA, gpc, fmaf(pB, gqc, fmaf(peps, sn[q], z[q])));
-          const float db = zp[q] - bk;
-          if (on[q]) w += -(db * db) * pinv2s2 - pcst;
-        }
-      }
       if (i < K) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-          const float df = zn[q] - fk[q];
-          if (on[q]) {
-            w -= -(df * df) * inv2s2 - cst;          // - log N(z'; fk, sigma)
-            if (a.traj && valid) a.traj[((int64_t)(i + 1) * a.n + p) * D + jc[q]] = zn[q];
-          }
-          zp[q] = z[q];
           z[q] = zn[q];
+          if (on[q] && a.traj && valid) a.traj[((int64_t)(i + 1) * a.n + p) * D + jc[q]] = zn[q];
         }
-        peps = eps; pinv2s2 = inv2s2; pcst = cst; pA = cA; pB = cB;
       }
       WSTAMP(6);
     }
-    // ---- outputs: the log-weight summed over the particle's 8 lanes, + log p(z_K)                  mcdboundingmachine.py:178-179
-    w += xor8(w);
-    w = group_sum(w);
-    w += logp;
-    const float loss = -w;
+    wbar();   // F1
+    // ---- outputs: the loss the TGT waves summed over the coordinates, z_K, the tile's statistics record
+    const float loss = lossb[pc];
     if (valid) {
 #pragma unroll
       for (int q = 0; q < 2; ++q)
@@ -633,8 +635,8 @@ int coop_wide8_launch(const cmcd_desc& d, const TrajArgs& ta, size_t lds_claim_m
   const int T = ta.w.T, D = d.dim, DP = (D + 3) & ~3;
   wide_fn fn = pick_wide(d, T);
   if (!fn) return CMCD_ERR_UNSUPPORTED;
-  const int HP = 16 * T, PTW = (D * T + 3) & ~3, GPW = (2 * D + 1 + 3) & ~3;
-  size_t lds_bytes = size_t(8 * (HP + 4) + 8 * PTW + 8 * GPW + 8 * DP + 8 * DP + 2 * 8 * DP) * 4;
+  const int HP = 16 * T, PTW = (D * T + 3) & ~3;
+  size_t lds_bytes = size_t(8 * (HP + 4) + 8 * PTW + 3 * 8 * DP + 8 + 2 * 8 * DP) * 4;
   if (lds_claim_min > lds_bytes) {
     // the caller's CU-exclusive claim (cmcd_coop.hip: coop_launch): the opt-in is per function and device, raised once
     static std::atomic<int> raised[64][2][8];
