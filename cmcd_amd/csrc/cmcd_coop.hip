@@ -898,8 +898,12 @@ int coop_launch(const cmcd_desc& d, const TrajArgs& ta_in, bool half, void* stre
       cu_count[dev].store(n_cu, std::memory_order_relaxed);
   }
   constexpr size_t kExclusive = 84 * 1024;
-  if (half && !narrow && coop_wide8_available(d, T))   // wide states (d = 10): their own kernel, same claim rule
+  if (half && !narrow && coop_wide8_available(d, T)) {   // wide states (d = 10): their own kernel, same claim rule
+    // no role raised there: the MLP waves are the critical path on every SIMD (profiles/r05_c_prio_sweep_funnel_wide8.txt:
+    // target + ACC one level up, this file's table for 8-particle tiles, +2.5 %; MLP up: +-0.3 %)
+    if (g_coop_prio < 0) ta.prio = 0;
     return coop_wide8_launch(d, ta, (n_cu > 0 && (int)tiles <= n_cu) ? kExclusive : 0, stream);
+  }
   if (n_cu > 0 && (int)tiles <= n_cu) {
     static std::mutex mu;
     static std::set<std::pair<const void*, int>> raised;

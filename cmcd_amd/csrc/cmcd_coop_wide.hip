@@ -1,34 +1,41 @@
-// coop_wide8_kernel — the CU-cooperative trajectory kernel for WIDE states (8 < d <= 12: the funnel, d = 10) on 8-particle
+// coop_wide8_kernel — the CU-cooperative trajectory kernel for WIDE states (d = 10: the funnel; d = 12 fits) on 8-particle
 // tiles: one workgroup per tile, T + 4 waves with the roles of coop_kernel (cmcd_coop.hip) — but laid out for a state that
 // is too wide to be carried redundantly.  r04's funnel instance was coop_kernel<.., D = 10, .., HALF> with its 2-d habits:
 // every lane of the accounting wave formed all ten coordinates of z_{i+1} (eight-fold redundant, ~250 instructions behind
-// barrier 2), the key chain ran three Threefry passes per bridge on a wave whose twin columns repeated each other, and the
-// ten deviates were three dependent erfinv evaluations on the same wave (profiles/r05_stamps_funnel_8tile_before.txt:
-// 1.45 us per bridge against the 2-d headline's 0.70).  Here every per-coordinate job is DEALT to the lanes of its particle:
+// barrier 2) and published them behind a THIRD barrier, the key chain ran three Threefry passes per bridge on a wave whose
+// twin columns repeated each other, and the ten deviates were three dependent erfinv evaluations on the same wave
+// (profiles/r05_stamps_funnel_8tile_before.txt: 3 513 stamped cycles per bridge, 97.0 us per call of N = 300, K = 64).
+// Here every per-coordinate job is DEALT to the lanes of its particle, and the state never leaves the waves that use it
+// (profiles/r05_stamps_funnel_8tile_after.txt: 2 040 cycles, 56.5 us):
 //
 //   waves 0..T-1  MLP   lane (qi, pg, kh, ng) = particle 4 pg + qi, neurons 16 wv + 4 ng + 2 kh + {0, 1} (v_mfma_f32_4x4x1
-//                       order, as coop_kernel on 8-particle tiles).  Layer 3 ends in a reduce-SCATTER over the particle's 8
-//                       lanes (1 DPP add + 2 row-swap adds per four outputs) instead of an all-reduce per output pair, and
-//                       each lane writes the one or two outputs it ends up owning.
-//   waves T, T+1  TGT   16 lanes per particle: lane `sub` owns coordinate `sub` — its share of grad log p (the funnel's
-//                       sum of squares is one 16-lane reduction), the clipped scores and base_j of the forward mean; in
-//                       interval 1 it converts random word `sub` of the bridge into its Gaussian deviate (one erfinv per lane).
+//                       order, as coop_kernel on 8-particle tiles).  Behind barrier 2 each lane takes the step of ITS
+//                       coordinates {s8, s8 + 8} (s8 = ng + 4 kh: sums the layer-3 partials of the T waves, fk = base - eps s,
+//                       z' = fk + sigma noise) and the particle's 8 lanes exchange their coordinates inside the wave (one DPP
+//                       rotate + row swaps): every MLP wave holds all of z_{i+1} with no LDS hand-over and no third barrier.
+//                       Layers 1 and 3 run on packed fp32 pairs (the lane's two neurons / two outputs per instruction);
+//                       layer 3 ends in a reduce-SCATTER over the particle's 8 lanes (1 DPP add + 2 row-swap adds per four
+//                       outputs) instead of an all-reduce per output pair, each lane writing the output it ends up owning.
+//   waves T, T+1  TGT   16 lanes per particle, lane `sub` owns coordinate `sub`: takes the same step for its coordinate (same
+//                       function, same bits), accumulates the log-weight terms of that coordinate (the backward kernel of the
+//                       step before, the forward kernel of this one) in a per-lane sum that is added over the particle's lanes
+//                       once, at the end of the launch; then its share of grad log p(z_{i+1}) (the funnel's sum of squares is
+//                       one 16-lane reduction), the clipped scores and base_j of the next forward mean.
 //   wave  T+2     RNG   the jax Threefry key chain one bridge ahead, 8 lanes per particle: pass A = split(gen) (2 blocks),
-//                       pass B = split(H) (2 blocks) + the Hh = d / 2 blocks of normal(G, (d,)) in ONE pass (7 of the 8 lanes
+//                       pass B = split(H) (2 blocks) + the d / 2 blocks of normal(G, (d,)) in ONE pass (7 of the 8 lanes
 //                       busy) — two dependent passes per bridge, the minimum the chain allows.  The ten groups of four rounds
-//                       of the two passes are cut into three segments that sit in the three intervals of the bridge
-//                       (kCut1 / kCut2), so the wave is never the last to arrive at a barrier.
-//   wave  T+3     ACC   8 lanes per particle, lane s8 owns coordinates {s8, s8 + 8}: between barrier 2 and barrier 3 it sums
-//                       the layer-3 partials of ITS coordinates, forms z_{i+1} and publishes it (3 LDS reads, ~10 instructions
-//                       per coordinate); the log-weight terms of its coordinates are accumulated per lane AFTER barrier 3 (off
-//                       the critical path) and summed over the particle's lanes once, at the end of the launch.
+//                       of the two passes are cut at kCut between the two intervals of the bridge, so that the wave is not
+//                       the last to arrive at either barrier.
+//   wave  T+3     ACC   random words -> Gaussian deviates (Giles' erfinv), 8 lanes per particle, lane s8 converts words
+//                       {s8, s8 + 8}: one conversion per interval; at the end of the launch, the tile's statistics record.
 //
-// Per evaluation i, three raw s_barriers:  interval 1 (layer 1 | deviates | chain segment) — barrier 1 — interval 2 (layer 2,
-// 3 | grad log p, base | chain segment) — barrier 2 — interval 3 (ACC: z_{i+1} | chain segment) — barrier 3 — every wave that
-// keeps a copy of z reads the published state.  Every exchange row is single-buffered except the raw words (written one
-// bridge ahead).  Same arithmetic as coop_kernel / traj_kernel up to the association of the sums over coordinates and
-// neurons; the PRNG path is bit-exact (tests/test_gpu_prng.py).  Reference lines: /root/reference/src/mcd_cais.py:46-89,
-// src/mcdboundingmachine.py:151-179, src/model_handler.py:124-143, src/nn.py:42-72; cited per statement in cmcd_kernels.hip.
+// Per evaluation i, TWO raw s_barriers:  [step -> z_i] interval 1 (layer 1 | grad log p | chain segment | conversion) —
+// barrier 1 — interval 2 (layers 2, 3 | base | chain segment | conversion) — barrier 2.  Every exchange row is single-buffered
+// except the raw words (written one bridge ahead): a row is written in the interval AFTER the barrier behind which its last
+// reader finished.  Same arithmetic as coop_kernel / traj_kernel up to the association of the sums over coordinates and
+// neurons, e^{-v} through v_exp_f32 and the funnel's constants as reciprocals; the PRNG path is bit-exact
+// (tests/test_gpu_prng.py).  Reference lines: /root/reference/src/mcd_cais.py:46-89, src/mcdboundingmachine.py:151-179,
+// src/model_handler.py:124-143, src/nn.py:42-72; cited per statement in cmcd_kernels.hip.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -109,30 +116,49 @@ __device__ __forceinline__ float rs16(float p, float q) {
 
 }  // namespace
 
-// segments of the RNG wave's ten round groups (pass A: 0 - 4, pass B: 5 - 9): [0, kCut1) in interval 1, [kCut1, kCut2) in
-// interval 2, the rest in interval 3 (profiles/r05_stamps_funnel_8tile_after.txt: no wave waits for the RNG wave)
-#ifndef CMCD_WIDE_CUT1
-#define CMCD_WIDE_CUT1 3
+// the RNG wave's ten round groups per bridge (pass A: 0 - 4, pass B: 5 - 9): [0, kCut) in interval 1, the rest in interval 2
+#ifndef CMCD_WIDE_CUT
+#define CMCD_WIDE_CUT 6
 #endif
-#ifndef CMCD_WIDE_CUT2
-#define CMCD_WIDE_CUT2 8
+#ifndef CMCD_WIDE_PK
+#define CMCD_WIDE_PK 1
 #endif
+
+// s(z_e, e)_j from the layer-3 partials of the T MLP waves and z_{e+1, j} = fk + sigma noise, fk = base - eps s: ONE function
+// for every wave that keeps a copy of the state (MLP lanes: two coordinates each, TGT lanes: one), so that all copies are
+// the same bits.   /root/reference/src/mcd_cais.py:61-67, src/nn.py:70, src/nn_dds.py:162
+template <int ARCH, int T>
+__device__ __forceinline__ void wide_step(const float* prow, float b3, float factor, float base, float noise, float seps,
+                                          float sig, float& sn, float& zn) {
+#pragma clang fp contract(off)
+  float o;
+  if (T == 4) {
+    const f32x4 t4 = *reinterpret_cast<const f32x4*>(prow);
+    o = b3 + ((t4[0] + t4[1]) + (t4[2] + t4[3]));
+  } else {
+    const f32x2 t2 = *reinterpret_cast<const f32x2*>(prow);
+    o = b3 + (t2[0] + t2[1]);
+  }
+  sn = (ARCH == CMCD_ARCH_DDS) ? __builtin_amdgcn_fmed3f(o, -1e4f, 1e4f) : o * factor;
+  zn = __builtin_fmaf(sig, noise, __builtin_fmaf(seps, sn, base));
+}
 
 template <int ARCH, int D, int T>
 __global__ __launch_bounds__(64 * (T + 4)) void coop_wide8_kernel(TrajArgs a) {
-  static_assert(D > 8 && D <= 12 && D % 2 == 0, "7 Threefry blocks per particle on 8 lanes, coordinates {s8, s8 + 8} per ACC lane");
+  static_assert(D == 10 || D == 12, "7 or 8 Threefry blocks per particle on 8 lanes; coordinates {s8, s8 + 8} per 8-lane group");
+  static_assert(T == 2 || T == 4, "partials of one coordinate are one 8- or 16-byte LDS read");
   constexpr int HP = 16 * T, NR = 2, Hh = D / 2, DP = (D + 3) & ~3;
   constexpr int HQP = HP + 4, NQ = HP / 2, RSA = ((HP / 2 + 15) / 16) * 4;
   constexpr int PTW = (D * T + 3) & ~3;           // layer-3 partials of one particle: [j][wave]
-    constexpr int kCut1 = CMCD_WIDE_CUT1, kCut2 = CMCD_WIDE_CUT2;
+  constexpr int kCut = CMCD_WIDE_CUT;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* const hbuf = lds;                        // [8][HQP]   layer-1 activations
-  float* const part = hbuf + 8 * HQP;             // [8][PTW]   layer-3 partials [j][wave]
-  float* const baseb = part + 8 * PTW;            // [8][DP]    base_j of the forward mean (TGT -> ACC)
-  float* const spub = baseb + 8 * DP;             // [8][DP]    s(z_i, i)_j (ACC -> TGT)
-  float* const zpub = spub + 8 * DP;              // [8][DP]    the published state z_{i+1} (ACC -> MLP, TGT)
-  float* const lossb = zpub + 8 * DP;             // [8]        per-particle loss at the end (TGT -> ACC)
-  uint32_t* const raw = reinterpret_cast<uint32_t*>(lossb + 8);   // [2][8][DP] random words, one bridge ahead
+  float* const hbuf = lds;                        // [8][HQP]   layer-1 activations                          (MLP -> MLP)
+  float* const part = hbuf + 8 * HQP;             // [8][PTW]   layer-3 partials [j][wave]                   (MLP -> MLP, TGT)
+  float* const baseb = part + 8 * PTW;            // [8][DP]    base_j of the forward mean                   (TGT -> MLP)
+  float* const nzb = baseb + 8 * DP;              // [8][DP]    deviates of the bridge                       (ACC -> MLP, TGT)
+  float* const zpub = nzb + 8 * DP;               // [8][DP]    z_0 (prologue only)                          (ACC -> MLP, TGT)
+  float* const lossb = zpub + 8 * DP;             // [8]        per-particle loss at the end                 (TGT -> ACC)
+  uint32_t* const raw = reinterpret_cast<uint32_t*>(lossb + 8);   // [2][8][DP] random words, one bridge ahead (RNG -> ACC)
 
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -153,10 +179,11 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_wide8_kernel(TrajArgs a) {
   const float cp = clip_p ? clipv : INFINITY, cq = clip_q ? clipv : INFINITY;
   const float* const sched_p = a.ws + a.w.sched;
   // the schedule row of evaluation i: {beta, eps, sigma, log sigma + log sqrt(2 pi) | 1 / (2 sigma^2), eps beta, eps (1 - beta), 0},
-  // requested as a scalar load at the top of the iteration and complete behind barrier 1's own wait (cmcd_coop.hip)
+  // requested as a scalar load and complete behind barrier 1's own wait, through which the values pass (cmcd_coop.hip)
 #define CMCD_WIDE_SCHED_LOAD(i_)                                                                              \
   f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sd = {0.f, 0.f, 0.f, 0.f};                                                 \
   {                                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);   /* not above the LDS reads of the step: their wait would include this load */ \
     const float* rowp = sched_p + __builtin_amdgcn_readfirstlane(8 * ((i_) < K ? (i_) : K - 1));              \
     asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x10" : "=&s"(sc), "=&s"(sd) : "s"(rowp)); \
     __builtin_amdgcn_sched_barrier(0);                                                                        \
@@ -187,49 +214,103 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_wide8_kernel(TrajArgs a) {
     if (ARCH == CMCD_ARCH_GEFFNER) urow = load_row(a.ws + a.w.utab + nb);
     float* const my_h = hbuf + pc * HQP + nb;
     const float* const rd_h = hbuf + pc * HQP + (HP / 2) * kh + RSA * ng;
-    const float* const rd_z = zpub + pc * DP;
+    // the coordinates whose step this lane takes (8 lanes per particle): jA = s8 always, jB = s8 + 8 on lanes s8 < D - 8
+    const int s8 = ng + 4 * kh;
+    const int jA = s8, jB = s8 + 8 < D ? s8 + 8 : s8;
+    const float b3A = a.ws[a.w.b3 + jA], b3B = a.ws[a.w.b3 + jB], factor = a.ws[a.w.b3 + 15];
+    const float* const rd_pA = part + pc * PTW + jA * T;
+    const float* const rd_pB = part + pc * PTW + jB * T;
     // the first D neurons of the geffner residual stream are z itself: wave 0, neurons nb, nb + 1 < D
     const bool z_in_u = ARCH == CMCD_ARCH_GEFFNER && wv == 0 && nb < D;
-    const float* const rd_u = zpub + pc * DP + (z_in_u ? nb : 0);
     // which output this lane owns after the reduce-scatter of a quad of pair-slots: row g -> slot {0, 2, 1, 3}[g]
     const int own_slot = ((ng & 1) << 1) | (ng >> 1);
     float z[D], uz[2] = {0.f, 0.f};
-    wbar();   // P1: random words of z_0
-    wbar();   // P3: z_0 published
-    auto read_state = [&]() {
-#pragma unroll
-      for (int q = 0; q < DP; q += 4) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(rd_z + q);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (q + r < D) z[q + r] = v[r];
-      }
-      if (ARCH == CMCD_ARCH_GEFFNER) {
-        const f32x2 u2 = *reinterpret_cast<const f32x2*>(rd_u);
-        uz[0] = z_in_u ? u2[0] : 0.f;
-        uz[1] = z_in_u ? u2[1] : 0.f;
+    auto residual_z = [&]() {   // uz = (z[nb], z[nb + 1]) on the lanes of wave 0 whose neurons are coordinates (nb = 4 ng + 2 kh)
+      if (ARCH == CMCD_ARCH_GEFFNER && wv == 0) {
+        const float e0 = kh ? z[2] : z[0], e1 = kh ? z[3] : z[1];
+        const float f0 = kh ? z[6] : z[4], f1 = kh ? z[7] : z[5];
+        const float g0 = (D > 10 && kh) ? z[D > 10 ? 10 : 0] : z[8], g1 = (D > 10 && kh) ? z[D > 10 ? 11 : 0] : z[9];
+        const float u0 = ng == 0 ? e0 : (ng == 1 ? f0 : g0), u1 = ng == 0 ? e1 : (ng == 1 ? f1 : g1);
+        uz[0] = z_in_u ? u0 : 0.f;
+        uz[1] = z_in_u ? u1 : 0.f;
       }
     };
-    read_state();
+    wbar();   // P1: random words of z_0
+    wbar();   // P3: z_0 published
+#pragma unroll
+    for (int q = 0; q < DP; q += 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(zpub + pc * DP + q);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (q + r < D) z[q + r] = v[r];
+    }
+    residual_z();
+    float sepsP = 0.f, sigP = 0.f;   // -eps and sigma of the previous evaluation's row
 #ifdef CMCD_STAMPS
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
 #endif
     for (int i = 0; i <= K; ++i) {
+      if (i > 0) {
+        // ---- z_i from evaluation i - 1 (everything it needs was published before barrier 2): this lane takes the step of its
+        // own coordinates, then the particle's 8 lanes exchange theirs inside the wave (DPP + row swaps: no LDS, no barrier)
+        const float baseA = baseb[pc * DP + jA], baseB = baseb[pc * DP + jB];
+        const float nzA = nzb[pc * DP + jA], nzB = nzb[pc * DP + jB];
+        float snA, snB, znA, znB;
+        wide_step<ARCH, T>(rd_pA, b3A, factor, baseA, nzA, sepsP, sigP, snA, znA);
+        wide_step<ARCH, T>(rd_pB, b3B, factor, baseB, nzB, sepsP, sigP, snB, znB);
+        const float ax = xor8(znA);                 // coordinate ng + 4 (1 - kh)
+        const float lo = kh ? ax : znA;             // coordinate ng
+        const float hi = kh ? znA : ax;             // coordinate ng + 4
+        uint32_t r4[4];
+        rows0123(__float_as_uint(lo), r4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z[r] = __uint_as_float(r4[r]);
+        rows0123(__float_as_uint(hi), r4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z[4 + r] = __uint_as_float(r4[r]);
+        const float bx = xor8(znB);
+        const float bb = kh ? bx : znB;             // coordinate 8 + ng, from the kh = 0 lane of the pair
+        if (D > 10) {
+          rows0123(__float_as_uint(bb), r4);
+#pragma unroll
+          for (int r = 0; r < D - 8; ++r) z[8 + r] = __uint_as_float(r4[r]);
+        } else {
+          uint32_t r0, r1;
+          rows01(__float_as_uint(bb), r0, r1);
+          z[8] = __uint_as_float(r0);
+          z[9] = __uint_as_float(r1);
+        }
+        residual_z();
+      }
+      WSTAMP(6);
+      CMCD_WIDE_SCHED_LOAD(i);
       // ---- interval 1: layer 1
       float pre[NR], h[NR];
+#if CMCD_WIDE_PK
+      {   // the lane's two neurons as one packed pair: v_pk_fma_f32, one issue slot per coordinate instead of two
+        f32x2 pv = brow;
+#pragma unroll
+        for (int j = 0; j < D; ++j) pv = __builtin_elementwise_fma(f32x2{z[j], z[j]}, f32x2{w1[j][0], w1[j][1]}, pv);
+        pre[0] = pv[0];
+        pre[1] = pv[1];
+      }
+#else
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         pre[r] = brow[r];
 #pragma unroll
         for (int j = 0; j < D; ++j) pre[r] = fmaf(z[j], w1[j][r], pre[r]);
       }
+#endif
 #pragma unroll
       for (int r = 0; r < NR; ++r)
         h[r] = (ARCH == CMCD_ARCH_DDS) ? gelu_fast(pre[r]) : (urow[r] + uz[r]) + softplus(pre[r]);
       *reinterpret_cast<float2*>(my_h) = float2{h[0], h[1]};
       WSTAMP(0);
-      wbar();   // barrier 1
+      CMCD_WIDE_BAR1_SCHED();   // barrier 1
       WSTAMP(1);
+      sepsP = a.ula ? 0.f : -sc[1];
+      sigP = sc[2];
       // ---- interval 2: layers 2 and 3
       const int nrow = (i < K ? i + 1 : K) - (a.ula == 2 ? 1 : 0);   // CAIS: s(z_{i+1}, i + 1); MCD_ULA_sn: s(z_{i+1}, i)
       brow = load_row(a.ws + a.w.bias1 + (int64_t)nrow * HP + nb);
@@ -259,8 +340,18 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_wide8_kernel(TrajArgs a) {
       // layer 3: this lane's two neurons against all D outputs, then the sum over the particle's 8 lanes as a
       // reduce-scatter: stage 1 over kh (DPP), stages 2 and 3 over the four rows (row-swap instructions)
       float ps[D];
+#if CMCD_WIDE_PK
+#pragma unroll
+      for (int m = 0; m < Hh; ++m) {   // outputs in packed pairs
+        const f32x2 pv = __builtin_elementwise_fma(f32x2{h2[1], h2[1]}, f32x2{w3s[2 * m][1], w3s[2 * m + 1][1]},
+                                                   f32x2{h2[0], h2[0]} * f32x2{w3s[2 * m][0], w3s[2 * m + 1][0]});
+        ps[2 * m] = pv[0];
+        ps[2 * m + 1] = pv[1];
+      }
+#else
 #pragma unroll
       for (int j = 0; j < D; ++j) ps[j] = fmaf(h2[1], w3s[j][1], h2[0] * w3s[j][0]);
+#endif
       constexpr int DQ = (Hh + 3) / 4;   // quads of pair-slots
       float vq[4 * DQ];
 #pragma unroll
@@ -275,10 +366,6 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_wide8_kernel(TrajArgs a) {
       WSTAMP(2);
       wbar();   // barrier 2
       WSTAMP(3);
-      wbar();   // barrier 3: z_{i+1} published
-      WSTAMP(5);
-      if (i < K) read_state();
-      WSTAMP(6);
     }
     wbar();   // F1: per-particle losses handed to the ACC wave
   }
@@ -293,6 +380,8 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_wide8_kernel(TrajArgs a) {
     const float qmean = a.params[a.lay.vd_mean + j];
     const float qstd = expf(a.params[a.lay.vd_logdiag + j]);
     const float qiv = 1.0f / (qstd * qstd);
+    const float b3j = a.ws[a.w.b3 + j], factor = a.ws[a.w.b3 + 15];
+    const float* const rd_p = part + pc * PTW + j * T;
     wbar();   // P1
     wbar();   // P3
     float zj = zpub[pc * DP + j], v = zpub[pc * DP];
@@ -302,58 +391,67 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_wide8_kernel(TrajArgs a) {
       const float dz = zj - qmean;                        // -log q(z_0)      diag_gauss.py:49-62, mcdboundingmachine.py:157
       wl = (dz * dz) / (2.0f * qstd * qstd) + logf(qstd) + kHalfLog2Pi;
     }
-    float peps = 0.f, pinv2s2 = 0.f, pcst = 0.f, pA = 0.f, pB = 0.f;
+    float gpc = 0.f, gqc = 0.f, base = 0.f;
+    float seps = 0.f, sig = 0.f, cst = 0.f, inv2s2 = 0.f, cA = 0.f, cB = 0.f, epsv = 0.f;   // row of the current evaluation
+    float peps = 0.f, pinv2s2 = 0.f, pcst = 0.f, pA = 0.f, pB = 0.f;                         // row of the previous step
+    // closes evaluation e (its partials, base and noise are published): s(z_e, e)_j, the backward kernel of step e - 1
+    // [bk = z - eps ub + eps s(z_e, e), ub = -(beta gp + (1 - beta) gq) at z_e] and, for e < K, the forward kernel of step e
+    // [fk = base - eps s, z_{e+1} = fk + sigma noise]: the log-weight terms of coordinate j      mcd_cais.py:52-86
+    auto finish = [&](int e) {
+      float sn, zn;
+      wide_step<ARCH, T>(rd_p, b3j, factor, base, nzb[pc * DP + j], seps, sig, sn, zn);
+      if (e > 0) {
+        const float bk = fmaf(pA, gpc, fmaf(pB, gqc, fmaf(peps, sn, zj)));
+        const float db = zp - bk;
+        wl += -(db * db) * pinv2s2 - pcst;
+      }
+      if (e < K) {
+        const float fk = fmaf(seps, sn, base);
+        const float df = zn - fk;
+        wl -= -(df * df) * inv2s2 - cst;
+        zp = zj;
+        zj = zn;
+        v = part_sum<16>(sub == 0 ? zn : 0.f);            // coordinate 0 to all 16 lanes of the particle
+        if (a.traj && valid && act) a.traj[((int64_t)(e + 1) * a.n + p) * D + j] = zn;
+        peps = epsv; pinv2s2 = inv2s2; pcst = cst; pA = cA; pB = cB;
+      }
+    };
 #ifdef CMCD_STAMPS
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
 #endif
     for (int i = 0; i <= K; ++i) {
+      if (i > 0) finish(i - 1);
+      WSTAMP(6);
       CMCD_WIDE_SCHED_LOAD(i);
       // funnel (/root/reference/src/model_handler.py:124-143; the scale of v is the hard-coded 3.0):
       //   log p = logN(v; 0, 3) + sum_{j >= 1} logN(z_j; 0, e^{v / 2})
       //   d / dv = -v / 9 - (d - 1) / 2 + e^{-v} ss / 2,   d / dz_j = -z_j e^{-v},   ss = sum_{j >= 1} z_j^2
-      // Everything that does not need the schedule row runs in interval 1 (the MLP partners of these waves are short there and
-      // long in interval 2); e^{-v} through v_exp_f32, the constants as reciprocals (no IEEE division on these waves).
+      // e^{-v} through v_exp_f32, the constants as reciprocals (no IEEE division on these waves).
       const float ss = part_sum<16>((act && j >= 1) ? zj * zj : 0.f);
       const float emv = __builtin_amdgcn_exp2f(-1.44269504088896340736f * v);
       constexpr float c0 = -0.5f * kLog2Pi - 1.0986122886681098f, c1 = -0.5f * (D - 1) * kLog2Pi;
       const float hes = 0.5f * emv * ss;
       const float g0 = fmaf(v, -1.0f / 9.0f, hes - 0.5f * (D - 1));
       const float gp = j == 0 ? g0 : -zj * emv;
-      const float gpc = __builtin_amdgcn_fmed3f(gp, -cp, cp);
-      const float gqc = __builtin_amdgcn_fmed3f((qmean - zj) * qiv, -cq, cq);
+      gpc = __builtin_amdgcn_fmed3f(gp, -cp, cp);
+      gqc = __builtin_amdgcn_fmed3f((qmean - zj) * qiv, -cq, cq);
       lp = fmaf(v * v, -1.0f / 18.0f, c0 + c1) - 0.5f * (D - 1) * v - hes;
       WSTAMP(0);
-      CMCD_WIDE_BAR1_SCHED();
+      CMCD_WIDE_BAR1_SCHED();   // barrier 1: every copy of z_i has been formed, base_{i-1} may be overwritten
       WSTAMP(1);
-      const float eps = sc[1], cst = sc[3], inv2s2 = sd[0], cA = sd[1], cB = sd[2];
-      const float base = fmaf(cA, gpc, fmaf(cB, gqc, zj));   // base_j = z_j + eps beta clip(gp_j) + eps (1 - beta) clip(gq_j)
+      epsv = sc[1]; sig = sc[2]; cst = sc[3]; inv2s2 = sd[0]; cA = sd[1]; cB = sd[2];
+      seps = a.ula ? 0.f : -epsv;
+      base = fmaf(cA, gpc, fmaf(cB, gqc, zj));   // base_j = z_j + eps beta clip(gp_j) + eps (1 - beta) clip(gq_j)
       if (act) baseb[pc * DP + j] = base;
       WSTAMP(2);
       wbar();   // barrier 2
       WSTAMP(3);
-      wbar();   // barrier 3
-      WSTAMP(5);
-      // ---- the log-weight terms of coordinate j (mcd_cais.py:71-86), off the critical path: s(z_i, i)_j and z_{i+1, j} from the ACC wave
-      const float sn = spub[pc * DP + j], zn = zpub[pc * DP + j], vn = zpub[pc * DP];
-      if (i > 0) {   // backward kernel of step i - 1: bk = z - eps ub + eps s(z_i, i), ub = -(beta gp + (1 - beta) gq) at z_i
-        const float bk = fmaf(pA, gpc, fmaf(pB, gqc, fmaf(peps, sn, zj)));
-        const float db = zp - bk;
-        wl += -(db * db) * pinv2s2 - pcst;
-      }
-      if (i < K) {   // forward kernel of step i: fk = base - eps s, z_{i+1} = fk + sigma noise
-        const float fk = fmaf(a.ula ? 0.f : -eps, sn, base);
-        const float df = zn - fk;
-        wl -= -(df * df) * inv2s2 - cst;
-        zp = zj;
-        zj = zn;
-        v = vn;
-        peps = eps; pinv2s2 = inv2s2; pcst = cst; pA = cA; pB = cB;
-      }
-      WSTAMP(6);
     }
+    finish(K);
     // w = sum over coordinates + log p(z_K); loss = -w                              mcdboundingmachine.py:178-179
     const float wtot = part_sum<16>(act ? wl : 0.f) + lp;
     if (sub == 0) lossb[pc] = -wtot;
+    if (valid && act) a.out_z[p * D + j] = zj;
     wbar();   // F1
   }
   // =============================================================================================== RNG
@@ -431,8 +529,7 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_wide8_kernel(TrajArgs a) {
       }
     };
     using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, kCut1>;
-    using I2 = std::integral_constant<int, kCut2>;
+    using I1 = std::integral_constant<int, kCut>;
     using I10 = std::integral_constant<int, 10>;
     chain(I0{}, I10{}, 0, 1);   // bridge 0
     wbar();   // P1
@@ -447,14 +544,10 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_wide8_kernel(TrajArgs a) {
       WSTAMP(0);
       wbar();   // barrier 1
       WSTAMP(1);
-      if (more) chain(I1{}, I2{}, buf, i + 2);
+      if (more) chain(I1{}, I10{}, buf, i + 2);
       WSTAMP(2);
       wbar();   // barrier 2
       WSTAMP(3);
-      if (more) chain(I2{}, I10{}, buf, i + 2);
-      WSTAMP(4);
-      wbar();   // barrier 3
-      WSTAMP(5);
     }
     wbar();   // F1
   }
@@ -463,17 +556,9 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_wide8_kernel(TrajArgs a) {
     const int c = lane & 15, g = lane >> 4, pc = c & 7, tw = c >> 3, s8 = g + 4 * tw;
     const int64_t p = tile * 8 + pc;
     const bool valid = p < a.n;
-    // coordinates of this lane: jA = s8 (always), jB = s8 + 8 (lanes s8 < D - 8)
+    // the random words this lane turns into deviates: coordinates jA = s8 (always), jB = s8 + 8 (lanes s8 < D - 8)
     const int jc[2] = {s8, s8 + 8 < D ? s8 + 8 : s8};
     const bool on[2] = {true, s8 + 8 < D};
-    float qmean[2], qstd[2], b3[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      qmean[q] = a.params[a.lay.vd_mean + jc[q]];
-      qstd[q] = expf(a.params[a.lay.vd_logdiag + jc[q]]);
-      b3[q] = a.ws[a.w.b3 + jc[q]];
-    }
-    const float factor = a.ws[a.w.b3 + 15];
     // random word -> deviate of coordinate jc[q] (jax.random.normal: Giles' erfinv); `stage` = debug-capture index
     float nzv[2] = {0.f, 0.f};
     auto convert = [&](int q, int buf, int stage) {
@@ -488,13 +573,12 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_wide8_kernel(TrajArgs a) {
     convert(0, 1, 0);
     convert(1, 1, 0);
     // z_0 = mean + std * normal(A, (D,))                               diag_gauss.py:49-62, mcdboundingmachine.py:157
-    float z[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      z[q] = qstd[q] * nzv[q] + qmean[q];
+      const float z0 = expf(a.params[a.lay.vd_logdiag + jc[q]]) * nzv[q] + a.params[a.lay.vd_mean + jc[q]];
       if (on[q]) {
-        zpub[pc * DP + jc[q]] = z[q];
-        if (a.traj && valid) a.traj[p * D + jc[q]] = z[q];
+        zpub[pc * DP + jc[q]] = z0;
+        if (a.traj && valid) a.traj[p * D + jc[q]] = z0;
       }
     }
     wbar();   // P3
@@ -502,67 +586,24 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_wide8_kernel(TrajArgs a) {
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
 #endif
     for (int i = 0; i <= K; ++i) {
-      CMCD_WIDE_SCHED_LOAD(i);
-      // the deviates of bridge i for this lane's two coordinates: one conversion in interval 1, the other in interval 2
+      // the deviates of bridge i (words written during iteration i - 1): one conversion per interval; published after
+      // barrier 1, when the last reader of bridge i - 1's deviates is done, and read behind barrier 2
       if (i < K) convert(0, i & 1, i + 1);
       WSTAMP(0);
-      CMCD_WIDE_BAR1_SCHED();
+      wbar();   // barrier 1
       WSTAMP(1);
-      if (i < K) convert(1, i & 1, i + 1);
+      if (i < K) {
+        nzb[pc * DP + jc[0]] = nzv[0];
+        convert(1, i & 1, i + 1);
+        if (on[1]) nzb[pc * DP + jc[1]] = nzv[1];
+      }
       WSTAMP(2);
       wbar();   // barrier 2
       WSTAMP(3);
-      // ---- interval 3: s(z_i, i) of this lane's coordinates from the layer-3 partials, the forward mean, z_{i+1}
-      const float eps = sc[1], sig = sc[2];
-      float ptv[2][T], basev[2];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        if (T == 4) {
-          const f32x4 t4 = *reinterpret_cast<const f32x4*>(part + pc * PTW + jc[q] * T);
-#pragma unroll
-          for (int r = 0; r < T; ++r) ptv[q][r] = t4[r & 3];
-        } else {
-          const f32x2 t2 = *reinterpret_cast<const f32x2*>(part + pc * PTW + jc[q] * T);
-#pragma unroll
-          for (int r = 0; r < T; ++r) ptv[q][r] = t2[r & 1];
-        }
-        basev[q] = baseb[pc * DP + jc[q]];
-      }
-      float zn[2];
-      const float seps = a.ula ? 0.f : -eps;
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        float o = b3[q];
-        if (T == 4) o += (ptv[q][0] + ptv[q][1]) + (ptv[q][2] + ptv[q][3]);
-        else o += ptv[q][0] + ptv[q][1];
-        const float sn = (ARCH == CMCD_ARCH_DDS) ? __builtin_amdgcn_fmed3f(o, -1e4f, 1e4f) : o * factor;
-        const float fk = fmaf(seps, sn, basev[q]);    // fk = z - eps uf - eps s                              mcd_cais.py:61
-        zn[q] = fmaf(sig, nzv[q], fk);                // z' = fk + sqrt(2 eps) noise                           mcd_cais.py:63-67
-        if (on[q]) {
-          spub[pc * DP + jc[q]] = sn;
-          if (i < K) zpub[pc * DP + jc[q]] = zn[q];
-        }
-      }
-      WSTAMP(4);
-      wbar();   // barrier 3
-      WSTAMP(5);
-      if (i < K) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          z[q] = zn[q];
-          if (on[q] && a.traj && valid) a.traj[((int64_t)(i + 1) * a.n + p) * D + jc[q]] = zn[q];
-        }
-      }
-      WSTAMP(6);
     }
     wbar();   // F1
-    // ---- outputs: the loss the TGT waves summed over the coordinates, z_K, the tile's statistics record
+    // ---- outputs: the loss the TGT waves summed over the coordinates, the tile's statistics record
     const float loss = lossb[pc];
-    if (valid) {
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-        if (on[q]) a.out_z[p * D + jc[q]] = z[q];
-    }
     const bool use = valid && s8 == 0;
     if (use) a.out_loss[p] = loss;
     double cnt = (use && isfinite(loss)) ? 1.0 : 0.0;
@@ -636,7 +677,7 @@ int coop_wide8_launch(const cmcd_desc& d, const TrajArgs& ta, size_t lds_claim_m
   wide_fn fn = pick_wide(d, T);
   if (!fn) return CMCD_ERR_UNSUPPORTED;
   const int HP = 16 * T, PTW = (D * T + 3) & ~3;
-  size_t lds_bytes = size_t(8 * (HP + 4) + 8 * PTW + 3 * 8 * DP + 8 + 2 * 8 * DP) * 4;
+  size_t lds_bytes = size_t(8 * (HP + 4) + 8 * PTW + 3 * 8 * DP + 8 + 2 * 8 * DP) * 4;   // hbuf, part, baseb / nzb / zpub, lossb, raw
   if (lds_claim_min > lds_bytes) {
     // the caller's CU-exclusive claim (cmcd_coop.hip: coop_launch): the opt-in is per function and device, raised once
     static std::atomic<int> raised[64][2][8];

@@ -34,7 +34,8 @@ for variant in ((int(sys.argv[3]),) if len(sys.argv) > 3 else (4,)):
     mcdbm.KERNEL_VARIANT = variant
     t(0, 50)   # clocks settle
     cands = [(0, 0, 0, 0), (0, 1, 0, 1), (1, 1, 0, 1), (1, 0, 0, 0), (1, 0, 0, 1), (2, 1, 0, 1), (0, 1, 0, 0), (0, 0, 0, 1), (0, 2, 0, 1),
-             (0, 1, 0, 2), (0, 2, 0, 2), (0, 0, 1, 0), (0, 1, 1, 0), (0, 1, 2, 0), (0, 0, 2, 0), (0, 1, 3, 0), (0, 2, 3, 0), (1, 2, 3, 0)]
+             (0, 1, 0, 2), (0, 2, 0, 2), (0, 0, 1, 0), (0, 1, 1, 0), (0, 1, 2, 0), (0, 0, 2, 0), (0, 1, 3, 0), (0, 2, 3, 0), (1, 2, 3, 0),
+             (2, 0, 0, 0), (3, 0, 0, 0), (2, 1, 0, 0), (2, 0, 0, 1), (2, 0, 1, 0), (1, 0, 1, 0), (3, 1, 1, 1), (3, 2, 1, 2), (2, 1, 1, 1)]
     res = {c: [] for c in cands}
     for rnd in range(4):   # interleaved rounds: drift hits every candidate alike
         for c in cands:

@@ -35,14 +35,13 @@ buf = (C.c_ulonglong * 256)()
 K = b["params_fixed"][1]
 print("kernel:", _lib.last_kernel_name())
 if _lib.last_kernel_name().startswith("coop_wide8"):
-    # cmcd_coop_wide.hip: slots 0 = interval 1 work, 1 = wait at barrier 1, 2 = interval 2 work (MLP: 7 = layer 2, 2 = layer 3),
-    # 3 = wait at barrier 2, 4 = interval 3 work (ACC: z_{i+1}; RNG: chain segment), 5 = wait at barrier 3, 6 = after barrier 3
-    # (MLP / TGT: read the state; ACC: log-weight terms)
+    # cmcd_coop_wide.hip: slot 6 = the step (MLP: z_i formed in the wave; TGT: log-weight terms + z_i), 0 = interval 1 work (MLP: layer 1;
+    # TGT: grad log p; RNG: chain segment; ACC: first conversion), 1 = wait at barrier 1, 7 = MLP layer 2, 2 = rest of interval 2
+    # (MLP: layer 3; TGT: base; RNG: chain segment; ACC: second conversion), 3 = wait at barrier 2
     L.cmcd_debug_read_stamps_wide(buf)
     Tw = (b["params_fixed"][3].width + 15) // 16 if b["params_fixed"][3].arch == "geffner" else 4
     Tw = 2 if Tw <= 2 else 4
-    cols = [("int1 work", 0), ("wait bar1", 1), ("layer 2", 7), ("int2 work", 2), ("wait bar2", 3), ("int3 work", 4), ("wait bar3", 5),
-            ("after bar3", 6)]
+    cols = [("step", 6), ("int1 work", 0), ("wait bar1", 1), ("layer 2", 7), ("int2 work", 2), ("wait bar2", 3)]
     print("cycles per bridge step, workgroup 0 (coop_wide8_kernel):")
     for wv in range(Tw + 4):
         role = "MLP%d" % wv if wv < Tw else ["TGT0", "TGT1", "RNG", "ACC"][wv - Tw]
