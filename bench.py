@@ -362,13 +362,21 @@ def time_leg(leg, steps, warmup, use_dist, device, world, sharded=True, spinup=0
     barrier()
     elapsed = time.perf_counter() - t0
     # kernel duration: a separate loop of the same forward calls (no collective), HIP events around every trajectory-kernel
-    # launch on the launch stream — outside the region timed above
-    _lib.profile_enable(True)
-    for k in range(min(steps, 500)):      # the hook holds 512 event pairs
+    # launch on the launch stream — outside the region timed above.  The loop runs inside fixed_parameters(): with the prep
+    # launch in front of it, the first event of a pair fires when the PREP kernel retires, and the pair then holds the
+    # dispatch gap between two dependent kernels on top of the trajectory kernel's own time (r05, under rocprofv3: 194.8 us
+    # by events with the prep launch in every call, 185.4 us without, 186.4 us = the profiler's own average of that kernel
+    # over both loops, profiles/r05_c_kernel_stats_bench_forward_only.csv).  The kernel's duration does not depend on who
+    # formed its tables; `value` / `ms_per_step` above stay the default path with the prep launch in every call.
+    from cmcd_amd import mcdboundingmachine as _mcdbm
+    with _mcdbm.fixed_parameters():
         leg.forward()
-    torch.cuda.synchronize()
-    kern_ms, launches = _lib.profile_collect()
-    _lib.profile_enable(False)
+        _lib.profile_enable(True)
+        for k in range(min(steps, 500)):      # the hook holds 512 event pairs
+            leg.forward()
+        torch.cuda.synchronize()
+        kern_ms, launches = _lib.profile_collect()
+        _lib.profile_enable(False)
     if gc_was:
         gc.enable()
     if use_dist and sharded:

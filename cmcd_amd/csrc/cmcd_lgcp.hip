@@ -710,6 +710,13 @@ struct NskArgs {
   NskSeg seg[2];
   int nt0;             // column tiles of segment 0
   int M;
+  // r05: launches with two 16-row halves per column tile (17 .. 32 particles, not merged) are 1-D grids of 16 ceil(gx / 8)
+  // workgroups in XCD-PAIRED order: workgroup L runs on XCD L % 8 (round-robin dispatch), slot s = L / 8 there; it takes tile
+  // (L % 8) + 8 (s / 2), half s % 2 — both halves of a tile, which read the SAME weight tile, share an XCD and its L2 (a
+  // (tile, half) = (blockIdx.x, blockIdx.y) grid of gx = 102 columns put them on XCDs t % 8 and (t + 6) % 8: every weight
+  // byte crossed the fabric twice, profiles/r04_pmc/lgcp_summary.json: 23.7 / 24.0 MB per launch for 10.5 MB of weights).
+  // gx = the logical grid width (column tiles + the key-chain workgroup of STEP launches); 0 = plain (blockIdx.x, blockIdx.y).
+  int pair_gx = 0;
   // activations
   const float* bias;   // ACT1: bias1_i [IN];  ACT2: b2 [IN] (params)
   const float* emb;    // ACT1: emb_i [E]
@@ -961,15 +968,32 @@ __device__ __forceinline__ void nsk_mid_post(const NskArgs& a, const NskMidPre& 
 // 126, two workgroups per CU for the 404-workgroup launch B of a 21 .. 32-particle pass; a run-time round loop cost them 8
 // registers and 4 % of the call); 2 = the 3220-wide layers of the 2nd-order sequence (every segment of such a launch has its
 // own round count <= ROUNDS)
+// The XCD-paired grid order of the two-half launches (NskArgs::pair_gx).  Measured at N = 20, K = 128 in one lease
+// (profiles/r05_d_lgcp_xcd_pairs_ab.txt): launch A 6.52 -> 5.96 us, C 7.76 -> 7.24 us, the call 2.999 -> 2.823 ms; launch B stays
+// merged (one workgroup per tile: 8.00 us; two paired halves: 9.12 us).  -DCMCD_LGCP_NO_XCD_PAIRS builds the (tile, half) grid.
+static constexpr bool lgcp_xcd_pairs() {
+#ifdef CMCD_LGCP_NO_XCD_PAIRS
+  return false;
+#else
+  return true;
+#endif
+}
+
 template <int KIND, bool MERGED, int ROUNDS = 1>      // KIND 0: activations / plain products; 1: the state update; 2: the 2nd-order F1
 __global__ __launch_bounds__(64 * kGemmWaves, (KIND || MERGED) ? 2 : 4) void lgcp_nsk_kernel(NskArgs a) {
   constexpr bool STEP = KIND == 1, MID = KIND == 2;
   __shared__ float red[kGemmWaves][MERGED ? 512 : 256];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (STEP && blockIdx.x == gridDim.x - 1) {
+  int bx = blockIdx.x, by = blockIdx.y, gx = gridDim.x;
+  if (!MERGED && a.pair_gx) {
+    const int L = blockIdx.x, s = L >> 3;
+    bx = (L & 7) + 8 * (s >> 1); by = s & 1; gx = a.pair_gx;
+    if (bx >= gx) return;          // the tail of the last group of eight tiles (uniform per workgroup)
+  }
+  if (STEP && bx == gx - 1) {
     // the chain's key for evaluation i + 1 (a dependent integer chain of ~450 instructions): its own workgroup
     const StepEpi& st = a.step;
-    if (blockIdx.y == 0 && wv == 0 && st.i + 1 < st.K && lane < a.M) {
+    if (by == 0 && wv == 0 && st.i + 1 < st.K && lane < a.M) {
       uint32_t k0 = st.gen[2 * lane], k1 = st.gen[2 * lane + 1], G0, G1;
       lgcp_key_advance(k0, k1, G0, G1);
       st.gen[2 * lane] = k0; st.gen[2 * lane + 1] = k1;
@@ -980,9 +1004,9 @@ __global__ __launch_bounds__(64 * kGemmWaves, (KIND || MERGED) ? 2 : 4) void lgc
     }
     return;
   }
-  const int sI = (int)blockIdx.x >= a.nt0 ? 1 : 0;
+  const int sI = bx >= a.nt0 ? 1 : 0;
   const NskSeg sg = a.seg[sI];
-  const int tile = blockIdx.x - (sI ? a.nt0 : 0), half = MERGED ? 0 : blockIdx.y;
+  const int tile = bx - (sI ? a.nt0 : 0), half = MERGED ? 0 : by;
   // the element this thread consumes: waves 0 .. 3 the 16 x 16 block (D layout of 16x16x4: column = lane % 16, row =
   // 4 (lane / 16) + register, register = wave), wave 4 the 4 x 16 block of the merged form
   const bool cons = wv < 4 || (MERGED && wv == 4);
@@ -1591,7 +1615,12 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
           auto launch = [&](bool step, int tiles, bool want_merged = false) {
             const bool merged = can_merge && want_merged;
             const unsigned gy = (!merged && M[l] > 16) ? 2 : 1;
-            const dim3 grid((unsigned)tiles + (step ? 1 : 0), gy);
+            dim3 grid((unsigned)tiles + (step ? 1 : 0), gy);
+            na.pair_gx = 0;
+            if (gy == 2 && lgcp_xcd_pairs()) {   // both row halves of a column tile on one XCD (NskArgs::pair_gx)
+              na.pair_gx = (int)grid.x;
+              grid = dim3(16u * ((grid.x + 7) / 8), 1);
+            }
             if (step) {
               if (merged) hipLaunchKernelGGL((lgcp_nsk_kernel<1, true>), grid, gblock, 0, st_l, na);
               else hipLaunchKernelGGL((lgcp_nsk_kernel<1, false>), grid, gblock, 0, st_l, na);
