@@ -103,9 +103,76 @@ __device__ __forceinline__ float half_sum32(float v) {   // sum over the 32 lane
 // The state update of evaluation i for 4 consecutive columns [col, col + 4) of particle row m (the arithmetic of
 // lgcp_step_tile in cmcd_lgcp.hip: /root/reference/src/mcd_cais.py:46-89, model_handler.py:386-396); `o` = (u2 W3)[cols]
 // (NONET: `o` = the K^-1 product itself).  The three per-row partial log-weights are returned for the caller's butterfly.
-template <bool NO_NET>
-__device__ __forceinline__ void wide_step4(const WideArgs& a, int m, int col, const float (&o)[4], float& bk_s, float& fk_s,
-                                           float& lp_s) {
+// PAIR (launch C with a network, r05): the tile's packed columns are PAIRED — packed column 128 ct + 4 c4 + {0, 1, 2, 3} is
+// element {e, e + 1, e + H, e + H + 1}, e = 64 ct + 2 c4, H = D / 2 (wide_nat_col) — because elements e and e + H are the two
+// words of ONE Threefry block of normal(G_i, (D,)) (counters (e, H + e)): the thread runs two blocks for its four deviates
+// instead of four (the block was ~80 of the ~150 instructions per element of this consumer; launch C at N = 600 40.2 ->
+// see profiles/r05_e_lgcp_per_launch_n600.txt).  W3's columns, b3, vd and the counts are packed in that order once per call; the
+// state rows x / xp / xn / kr and out_z keep the natural order (two 8-byte accesses per thread instead of one 16-byte).
+__host__ __device__ __forceinline__ int wide_nat_col(int q, int H) {       // packed column of a PAIRED tile -> element
+  const int ct = q >> 7, r = q & 127, c4 = r >> 2, j = r & 3;
+  const int e = 64 * ct + 2 * c4 + (j & 1);
+  if (e >= H) return 2 * H + e;                                  // pairs past H (the last tile's tail): outside [0, D) on both sides
+  return (j & 2) ? e + H : e;
+}
+
+// The consumer's own operands of one (row, 4 columns) element, requested ahead of the arithmetic that uses them: the state
+// rows (z, z of the previous evaluation, the K^-1 product of launch B) BEFORE the contraction loop — they come from earlier
+// launches — and the per-column vectors and the chain key behind it.  r04 loaded them inside the element loop, after the
+// cross-wave sum: four dependent trips to L2 / HBM per thread behind every tile (launch C at N = 600: 40.2 us for 22.2 us of
+// matrix time).
+struct WideStepRegs {
+  f32x4 zv, xpv, krv, b3v, mnv, sdv, cnv;
+  uint32_t g0, g1;
+  int e0;
+  bool in;
+};
+
+template <bool NO_NET, bool PAIR>
+__device__ __forceinline__ void wide_step_load_state(const WideArgs& a, int m, int col, bool live, WideStepRegs& r) {
+  const WideStep& s = a.st;
+  const int D = a.D, H = (D + 1) / 2;
+  // natural order: col is a multiple of 4 and D % 4 == 0 (checked on the host): the four columns are inside or outside
+  // together.  Paired order: element e0 = 64 ct + 2 c4 (even, H even): the pair (e0, e0 + 1) and its partners are in or out together
+  r.e0 = PAIR ? wide_nat_col(col, H) : col;
+  r.in = live && (PAIR ? r.e0 < H : col < D);
+  r.zv = r.xpv = r.krv = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (!r.in) return;
+  if (PAIR) {
+    const int64_t r0 = (int64_t)m * a.ldx + r.e0, r1 = r0 + H;
+    const f32x2 za = *reinterpret_cast<const f32x2*>(a.x + r0), zb = *reinterpret_cast<const f32x2*>(a.x + r1);
+    const f32x2 pa2 = *reinterpret_cast<const f32x2*>(s.xp + r0), pb2 = *reinterpret_cast<const f32x2*>(s.xp + r1);
+    const f32x2 ka = *reinterpret_cast<const f32x2*>(s.kr + r0), kb = *reinterpret_cast<const f32x2*>(s.kr + r1);
+    r.zv = f32x4{za[0], za[1], zb[0], zb[1]};
+    r.xpv = f32x4{pa2[0], pa2[1], pb2[0], pb2[1]};
+    r.krv = f32x4{ka[0], ka[1], kb[0], kb[1]};
+  } else {
+    const int64_t ro = (int64_t)m * a.ldx + col;
+    r.zv = *reinterpret_cast<const f32x4*>(a.x + ro);
+    r.xpv = *reinterpret_cast<const f32x4*>(s.xp + ro);
+    if (!NO_NET) r.krv = *reinterpret_cast<const f32x4*>(s.kr + ro);
+  }
+}
+
+__device__ __forceinline__ void wide_step_load_cols(const WideArgs& a, int m, int col, WideStepRegs& r) {
+  const WideStep& s = a.st;
+  r.g0 = r.g1 = 0u;
+  r.b3v = r.mnv = r.sdv = r.cnv = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (!r.in) return;
+  // (the per-column vectors are packed in the tile's own column order)
+  r.b3v = *reinterpret_cast<const f32x4*>(s.b3 + col);
+  r.mnv = *reinterpret_cast<const f32x4*>(s.mean + col);
+  r.sdv = *reinterpret_cast<const f32x4*>(s.sd + col);
+  r.cnv = *reinterpret_cast<const f32x4*>(s.counts + col);
+  if (s.i < s.K) {
+    const uint32_t* gk = s.gktab + ((int64_t)s.i * s.n + m) * 2;
+    r.g0 = gk[0]; r.g1 = gk[1];
+  }
+}
+
+template <bool NO_NET, bool PAIR>
+__device__ __forceinline__ void wide_step4(const WideArgs& a, int m, int col, const float (&o)[4], const WideStepRegs& r,
+                                           float& bk_s, float& fk_s, float& lp_s) {
   const WideStep& s = a.st;
   const int D = a.D, H = (D + 1) / 2, i = s.i;
   const bool last = i == s.K;
@@ -118,28 +185,40 @@ __device__ __forceinline__ void wide_step4(const WideArgs& a, int m, int col, co
   const float* sc = s.sched + 8 * (last ? s.K - 1 : i);
   const float beta = sc[0], eps = sc[1], sig = sc[2], cst = sc[3], inv2s2 = sc[4];
   const float fac = NO_NET ? 0.f : s.factor[0];
-  // col is a multiple of 4 and D % 4 == 0 (checked on the host): the four columns are inside or outside together
-  if (col >= D) return;
-  const int64_t ro = (int64_t)m * a.ldx + col;
-  const f32x4 zv = *reinterpret_cast<const f32x4*>(a.x + ro);
-  const f32x4 xpv = *reinterpret_cast<const f32x4*>(s.xp + ro);
-  f32x4 krv;
+  if (!r.in) return;
+  const int e0 = r.e0;
+  int el[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) el[j] = PAIR ? e0 + (j & 1) + ((j & 2) ? H : 0) : col + j;
+  const f32x4 zv = r.zv, xpv = r.xpv;
+  f32x4 krv = r.krv;
   if (NO_NET) { krv[0] = o[0]; krv[1] = o[1]; krv[2] = o[2]; krv[3] = o[3]; }
-  else krv = *reinterpret_cast<const f32x4*>(s.kr + ro);
-  const f32x4 b3v = *reinterpret_cast<const f32x4*>(s.b3 + col);
-  const f32x4 mnv = *reinterpret_cast<const f32x4*>(s.mean + col);
-  const f32x4 sdv = *reinterpret_cast<const f32x4*>(s.sd + col);
-  const f32x4 cnv = *reinterpret_cast<const f32x4*>(s.counts + col);
-  uint32_t g0 = 0, g1 = 0;
+  const f32x4 b3v = r.b3v, mnv = r.mnv, sdv = r.sdv, cnv = r.cnv;
+  const uint32_t g0 = r.g0, g1 = r.g1;
+  // eps_i = normal(G_i, (D,)): element e is word (e >= H) of the block with counters (jj, H + jj), jj = e mod H
+  uint32_t bits[4] = {0u, 0u, 0u, 0u};
   if (!last) {
-    const uint32_t* gk = s.gktab + ((int64_t)i * s.n + m) * 2;
-    g0 = gk[0]; g1 = gk[1];
+    if (PAIR) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        uint32_t y0 = (uint32_t)(e0 + q), y1 = (uint32_t)(H + e0 + q);
+        threefry2x32(g0, g1, y0, y1);
+        bits[q] = y0; bits[2 + q] = y1;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = col + j, jj = e < H ? e : e - H;
+        uint32_t y0 = jj, y1 = (H + jj < D) ? H + jj : 0;
+        threefry2x32(g0, g1, y0, y1);
+        bits[j] = e < H ? y0 : y1;
+      }
+    }
   }
   f32x4 znv;
   float bk_acc = 0.f, fk_acc = 0.f, lp_acc = 0.f;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int e = col + j;
     const float z = zv[j], kr = krv[j], cnt = cnv[j], sd = sdv[j];
     const float sn = NO_NET ? 0.f : (o[j] + b3v[j]) * fac;       // factor_sn (u2 W3 + b3)        nn.py:70
     const float ez = expf(z);
@@ -157,23 +236,23 @@ __device__ __forceinline__ void wide_step4(const WideArgs& a, int m, int col, co
     if (last) {      // log p(z_K)
       lp_acc += -0.5f * (z - mu0) * kr + z * cnt - pa * ez;
     } else {         // forward kernel of step i                                                   mcd_cais.py:52-67
-      // eps_i = normal(G_i, (D,)): element e is word (e >= H) of the block with counters (jj, H + jj), jj = e mod H
-      const int jj = e < H ? e : e - H;
-      uint32_t y0 = jj, y1 = (H + jj < D) ? H + jj : 0;
-      threefry2x32(g0, g1, y0, y1);
       const float uf = -1.0f * (beta * gp + (1.0f - beta) * gq);
       const float fk = z - eps * uf - fsn * eps * sn;
-      zn = fk + sig * bits_to_normal(e < H ? y0 : y1);
+      zn = fk + sig * bits_to_normal(bits[j]);
       const float df = zn - fk;
       fk_acc += -(df * df) * inv2s2 - cst;
     }
     znv[j] = zn;
   }
   if (last) {
-    float* oz = s.out_z + (int64_t)m * D + col;
-    oz[0] = zv[0]; oz[1] = zv[1]; oz[2] = zv[2]; oz[3] = zv[3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s.out_z[(int64_t)m * D + el[j]] = zv[j];
+  } else if (PAIR) {
+    const int64_t r0 = (int64_t)m * a.ldx + e0;
+    *reinterpret_cast<f32x2*>(s.xn + r0) = f32x2{znv[0], znv[1]};
+    *reinterpret_cast<f32x2*>(s.xn + r0 + H) = f32x2{znv[2], znv[3]};
   } else {
-    *reinterpret_cast<f32x4*>(s.xn + ro) = znv;
+    *reinterpret_cast<f32x4*>(s.xn + (int64_t)m * a.ldx + col) = znv;
   }
   bk_s = bk_acc; fk_s = fk_acc; lp_s = lp_acc;
 }
@@ -202,6 +281,33 @@ __global__ __launch_bounds__(256, 2) void lgcp_wide_gemm_kernel(WideArgs a) {
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+
+  // ---- the consumer's own operands (outputs of EARLIER launches), requested before the contraction so that their trip to
+  // L2 / HBM rides under it: element q of this thread = (row (q 256 + tid) / 32, columns 4 ((q 256 + tid) % 32) ..+3)
+  const int epi = sg.epi;
+  WideStepRegs sr[4];
+  f32x4 eb[4], eu[4];      // ACT: bias and residual input
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = q * 256 + threadIdx.x, row = e >> 5, c4 = e & 31;
+    const int m = rt * kWRows + row, col = n0 + 4 * c4;
+    const bool live = m < a.M;
+    eb[q] = eu[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    sr[q].in = false;
+    if (epi == WEPI_ACT1 || epi == WEPI_ACT2) {
+      if (live && col < a.IN) {                                  // IN % 4 == 0 (host check): four columns in or out together
+        eb[q] = *reinterpret_cast<const f32x4*>(a.bias + col);
+        if (epi == WEPI_ACT2) eu[q] = *reinterpret_cast<const f32x4*>(a.u_prev + (int64_t)m * a.ldu + col);
+        else if (col < a.D) eu[q] = *reinterpret_cast<const f32x4*>(a.x + (int64_t)m * a.ldx + col);   // u = [x; emb_i]   nn.py:68-69
+        else eu[q] = f32x4{a.emb[col - a.D], a.emb[col - a.D + 1], a.emb[col - a.D + 2], a.emb[col - a.D + 3]};
+      }
+    } else if (epi == WEPI_STEP) {
+      wide_step_load_state<false, true>(a, m, col, live, sr[q]);
+    } else if (epi == WEPI_STEP_NONET) {
+      wide_step_load_state<true, false>(a, m, col, live, sr[q]);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
 
   // chunk ch = 4 tt + wave (interleaved over the waves: the workgroup walks the contraction front to back together).
   // MFMA step s of a chunk contracts the k pair (k0 + s, k0 + 4 + s): lane half h supplies k0 + 4 h + s for both operands,
@@ -254,9 +360,15 @@ __global__ __launch_bounds__(256, 2) void lgcp_wide_gemm_kernel(WideArgs a) {
     v[0] = acc[0][i]; v[1] = acc[1][i]; v[2] = acc[2][i]; v[3] = acc[3][i];
     *reinterpret_cast<f32x4*>(red + (wv * kWRows + row) * kRedLd + 4 * c) = v;
   }
+  if (epi == WEPI_STEP || epi == WEPI_STEP_NONET) {   // the per-column vectors and the chain keys: in flight across the barrier
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = q * 256 + threadIdx.x, row = e >> 5, c4 = e & 31;
+      wide_step_load_cols(a, rt * kWRows + row, n0 + 4 * c4, sr[q]);
+    }
+  }
   __syncthreads();
-  const int epi = sg.epi;
-#pragma unroll 1
+#pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int e = q * 256 + threadIdx.x, row = e >> 5, c4 = e & 31;
     f32x4 v = *reinterpret_cast<const f32x4*>(red + row * kRedLd + 4 * c4);
@@ -265,27 +377,10 @@ __global__ __launch_bounds__(256, 2) void lgcp_wide_gemm_kernel(WideArgs a) {
     const int m = rt * kWRows + row, col = n0 + 4 * c4;
     const bool live = m < a.M;                                   // uniform over the 32 lanes that share the row
     if (epi == WEPI_ACT1 || epi == WEPI_ACT2) {
-      if (live && col < a.IN) {                                  // IN % 4 == 0 (host check): four columns in or out together
-        float u[4], bb[4];
-        if (epi == WEPI_ACT1) {                                  // u = [x; emb_i]      nn.py:68-69
-          const f32x4 bv4 = *reinterpret_cast<const f32x4*>(a.bias + col);
-          bb[0] = bv4[0]; bb[1] = bv4[1]; bb[2] = bv4[2]; bb[3] = bv4[3];
-          if (col < a.D) {
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(a.x + (int64_t)m * a.ldx + col);
-            u[0] = xv[0]; u[1] = xv[1]; u[2] = xv[2]; u[3] = xv[3];
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) u[j] = a.emb[col - a.D + j];
-          }
-        } else {
-          const f32x4 bv4 = *reinterpret_cast<const f32x4*>(a.bias + col);
-          const f32x4 uv = *reinterpret_cast<const f32x4*>(a.u_prev + (int64_t)m * a.ldu + col);
-          bb[0] = bv4[0]; bb[1] = bv4[1]; bb[2] = bv4[2]; bb[3] = bv4[3];
-          u[0] = uv[0]; u[1] = uv[1]; u[2] = uv[2]; u[3] = uv[3];
-        }
+      if (live && col < a.IN) {
         f32x4 out;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) out[j] = u[j] + softplus(v[j] + bb[j]);        // nn.py:45-50
+        for (int j = 0; j < 4; ++j) out[j] = eu[q][j] + softplus(v[j] + eb[q][j]);        // nn.py:45-50
         *reinterpret_cast<f32x4*>(a.u_out + (int64_t)m * a.ldu + col) = out;
       }
     } else if (epi == WEPI_KR) {
@@ -294,8 +389,8 @@ __global__ __launch_bounds__(256, 2) void lgcp_wide_gemm_kernel(WideArgs a) {
       float bk = 0.f, fk = 0.f, lp = 0.f;
       if (live) {
         const float o[4] = {v[0], v[1], v[2], v[3]};
-        if (epi == WEPI_STEP) wide_step4<false>(a, m, col, o, bk, fk, lp);
-        else wide_step4<true>(a, m, col, o, bk, fk, lp);
+        if (epi == WEPI_STEP) wide_step4<false, true>(a, m, col, o, sr[q], bk, fk, lp);
+        else wide_step4<true, false>(a, m, col, o, sr[q], bk, fk, lp);
       }
       bk = half_sum32(bk); fk = half_sum32(fk); lp = half_sum32(lp);
       if (live && c4 == 0) {
@@ -309,12 +404,13 @@ __global__ __launch_bounds__(256, 2) void lgcp_wide_gemm_kernel(WideArgs a) {
   }
 }
 
-// dst[Kp][Np] = zero-padded copy of src[K][N] (row stride lds)
+// dst[Kp][Np] = zero-padded copy of src[K][N] (row stride lds); pair_h > 0: columns in the PAIRED order of wide_nat_col (H = pair_h)
 __global__ void lgcp_wide_pack_kernel(const float* __restrict__ src, int K, int N, int lds, float* __restrict__ dst, int Kp,
-                                      int Np) {
+                                      int Np, int pair_h) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
   if (n >= Np) return;
-  dst[(int64_t)k * Np + n] = (k < K && n < N) ? src[(int64_t)k * lds + n] : 0.f;
+  const int nn = pair_h ? wide_nat_col(n, pair_h) : n;
+  dst[(int64_t)k * Np + n] = (k < K && nn < N) ? src[(int64_t)k * lds + nn] : 0.f;
 }
 
 struct WideVecArgs {
@@ -324,15 +420,18 @@ struct WideVecArgs {
   cmcd_layout lay;
   int D, IN, NpD, NpIN, has_net;
 };
+// the per-column vectors of the state update, in the column order of its launch: paired with a network (launch C), natural
+// without (MCD_ULA: the K^-1 product is its own launch's operand)
 __global__ void lgcp_wide_vec_kernel(WideVecArgs a) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n < a.NpIN) a.b2[n] = (a.has_net && n < a.IN) ? a.params[a.lay.g_b2 + n] : 0.f;
   if (n < a.NpD) {
-    const bool in = n < a.D;
-    a.b3[n] = (a.has_net && in) ? a.params[a.lay.g_b3 + n] : 0.f;
-    a.mean[n] = in ? a.params[a.lay.vd_mean + n] : 0.f;
-    a.sd[n] = in ? expf(a.params[a.lay.vd_logdiag + n]) : 1.f;
-    a.counts[n] = in ? a.tc[(int64_t)a.D * a.D + n] : 0.f;
+    const int e = a.has_net ? wide_nat_col(n, a.D / 2) : n;
+    const bool in = e < a.D;
+    a.b3[n] = (a.has_net && in) ? a.params[a.lay.g_b3 + e] : 0.f;
+    a.mean[n] = in ? a.params[a.lay.vd_mean + e] : 0.f;
+    a.sd[n] = in ? expf(a.params[a.lay.vd_logdiag + e]) : 1.f;
+    a.counts[n] = in ? a.tc[(int64_t)a.D * a.D + e] : 0.f;
   }
 }
 
@@ -488,16 +587,17 @@ int lgcp_wide_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout
   if (has_net && !tables_ready) {
     int rc = lgcp_launch_prep(d, lay, params, ws + w.bias1, stream);
     if (rc != CMCD_OK) return rc;
-    auto pack = [&](const float* src, int Kr, int Nr, int64_t dst, int Kp, int Np) {
-      hipLaunchKernelGGL(lgcp_wide_pack_kernel, dim3((Np + 255) / 256, Kp), dim3(256), 0, stream, src, Kr, Nr, Nr, ws + dst, Kp, Np);
+    auto pack = [&](const float* src, int Kr, int Nr, int64_t dst, int Kp, int Np, int pair_h) {
+      hipLaunchKernelGGL(lgcp_wide_pack_kernel, dim3((Np + 255) / 256, Kp), dim3(256), 0, stream, src, Kr, Nr, Nr, ws + dst, Kp, Np,
+                         pair_h);
     };
-    pack(params + lay.g_w1, D, IN, w.w1p, w.KpD, w.NpIN);     // only the state rows W1[:d]: the embedding rows are in bias1
-    pack(params + lay.g_w2, IN, IN, w.w2p, w.KpIN, w.NpIN);
-    pack(params + lay.g_w3, IN, D, w.w3p, w.KpIN, w.NpD);
+    pack(params + lay.g_w1, D, IN, w.w1p, w.KpD, w.NpIN, 0);     // only the state rows W1[:d]: the embedding rows are in bias1
+    pack(params + lay.g_w2, IN, IN, w.w2p, w.KpIN, w.NpIN, 0);
+    pack(params + lay.g_w3, IN, D, w.w3p, w.KpIN, w.NpD, D / 2);  // launch C's columns in paired order (wide_step4<.., PAIR>)
   }
   if (!tables_ready) {
     hipLaunchKernelGGL(lgcp_wide_pack_kernel, dim3((w.NpD + 255) / 256, w.KpD), dim3(256), 0, stream, tc, D, D, D, ws + w.kip,
-                       w.KpD, w.NpD);
+                       w.KpD, w.NpD, 0);
     WideVecArgs va{params, tc, ws + w.b2, ws + w.b3, ws + w.mean, ws + w.sd, ws + w.counts, lay, D, IN, w.NpD, w.NpIN, has_net ? 1 : 0};
     hipLaunchKernelGGL(lgcp_wide_vec_kernel, dim3((w.NpIN + 255) / 256), dim3(256), 0, stream, va);
   }
