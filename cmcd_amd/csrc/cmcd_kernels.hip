@@ -474,7 +474,16 @@ __device__ __forceinline__ float act(float pre) {
 #ifndef CMCD_TRAJ_ABL
 #define CMCD_TRAJ_ABL 0
 #endif
-template <int ARCH, int D, int T>
+// PF (r05): the A fragments of input tile ti + 1 are requested while tile ti's 4 T matrix instructions run (a second set of T
+// register quads), the two groups held apart by sched_barriers.  Without them the machine scheduler sinks every fragment read
+// to just in front of the four matrix instructions that use it — read, full lgkmcnt(0) wait, 128 cycles of matrix work, T^2 times
+// per evaluation; config 4 on one GPU (16 000 particles = 1000 waves on 1024 SIMDs, nothing else to issue) spent 27 % of its
+// wave cycles in s_waitcnt (profiles/r05_f_pmc_traj_kernel.json): 2.315 -> 2.003 ms per launch, 65 536 particles 7.63 -> 6.96.
+// -DCMCD_TRAJ_PF=0 builds the r04 form (A / B).
+#ifndef CMCD_TRAJ_PF
+#define CMCD_TRAJ_PF 1
+#endif
+template <int ARCH, int D, int T, bool PF = (CMCD_TRAJ_PF != 0)>
 __device__ __forceinline__ void eval_net(const float (&z)[D], const float* __restrict__ brow,
                                          const float* __restrict__ urow, const float* lds_w2,
                                          const float* lds_w1z, const float* lds_b2, const float* lds_w3t,
@@ -514,6 +523,31 @@ __device__ __forceinline__ void eval_net(const float (&z)[D], const float* __res
   f32x4 acc[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) acc[t] = *reinterpret_cast<const f32x4*>(lds_b2 + 16 * t + 4 * g);
+  if (PF) {
+    f32x4 a[2][T];
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int to = 0; to < T; ++to) a[0][to] = *reinterpret_cast<const f32x4*>(lds_w2 + (to * 64 + lane) * 4);
+#pragma unroll
+    for (int ti = 0; ti < T; ++ti) {
+      asm volatile("" ::: "memory");     // (as below: no hoisting of the fragments out of the bridge loop)
+      if (ti + 1 < T) {
+#pragma unroll
+        for (int to = 0; to < T; ++to)
+          a[(ti + 1) & 1][to] = *reinterpret_cast<const f32x4*>(lds_w2 + (((ti + 1) * T + to) * 64 + lane) * 4);
+      }
+      // (the machine scheduler otherwise sinks every fragment read to just in front of the four matrix instructions that
+      // use it — a read, a full lgkmcnt(0) wait, 128 cycles of matrix work, 81 times per evaluation: ISA reading r05)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int to = 0; to < T; ++to)
+          acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ti & 1][to][r], h[ti][r], acc[to], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
 #pragma unroll
   for (int ti = 0; ti < T; ++ti) {
     // wide nets: keep the A fragments streaming from LDS (a compiler-level fence stops LICM from
@@ -535,6 +569,7 @@ __device__ __forceinline__ void eval_net(const float (&z)[D], const float* __res
         for (int q = 0; q < 24; ++q) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(dummy) : "v"(z[0]));
       }
     }
+  }
   }
   if (CMCD_TRAJ_ABL & 32) {       // probe: the same 384 instructions after the MFMA loop
 #pragma unroll
@@ -565,7 +600,14 @@ __device__ __forceinline__ void eval_net(const float (&z)[D], const float* __res
   if (CMCD_TRAJ_ABL & 48) s[0] += dummy * 1e-30f;
 }
 
-template <int TARGET, int ARCH, int D, int T>
+// which instances keep the next input tile's fragments in flight (eval_net<.., PF>), measured on saturating batches against the
+// r04 form (profiles/r05_f_traj_fragment_prefetch_ab.txt): the 9-tile net -11 % (config 4: 2.360 -> 2.107 ms), dds on the 2-d
+// targets -1.6 %, the 2-tile net -1.4 %; the 4-tile geffner net (+1.9 %: 12 bytes of scratch at 128 registers) and the funnel
+// (+2.6 %) keep the plain loop
+constexpr bool traj_pf(int ARCH, int D, int T) {
+  return CMCD_TRAJ_PF != 0 && (T == 9 || (D == 2 && (T == 2 || ARCH == CMCD_ARCH_DDS)));
+}
+template <int TARGET, int ARCH, int D, int T, bool PF = traj_pf(ARCH, D, T)>
 __global__ __launch_bounds__(512, (T > 4 || D > 4) ? 2 : 4) void traj_kernel(TrajArgs a) {
   constexpr int HP = 16 * T;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -706,7 +748,7 @@ __global__ __launch_bounds__(512, (T > 4 || D > 4) ? 2 : 4) void traj_kernel(Tra
     } else {
       // CAIS: s(z_i, i) serves both kernels; MCD_ULA_sn: s(z_i, i - 1) serves the backward kernel only
       const int64_t row = (a.ula == 2) ? (i > 0 ? i - 1 : 0) : i;
-      eval_net<ARCH, D, T>(z, bias1 + row * HP, utab + row * HP, lds_w2, lds_w1z, lds_b2, lds_w3t, lds_b3, lane, sn);
+      eval_net<ARCH, D, T, PF>(z, bias1 + row * HP, utab + row * HP, lds_w2, lds_w1z, lds_b2, lds_w3t, lds_b3, lane, sn);
     }
     const float fsn = a.ula ? 0.f : 1.f;  // the ULA forward kernel has no network term
     float gq[D];
