@@ -39,6 +39,7 @@ class ProjectRange(C.Structure):
 
 
 _lib = None
+HAS_DIAG = False     # set by lib(): whether the loaded library carries the hooks of include/cmcd_hip_diag.h
 
 
 def lib():
@@ -100,15 +101,19 @@ def lib():
                                          C.c_void_p]
         L.cmcd_stats_merge_device.restype = C.c_int
         L.cmcd_stats_merge_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
-        L.cmcd_debug_capture_noise.restype = C.c_int
-        L.cmcd_debug_capture_noise.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-        L.cmcd_debug_grad_item.restype = C.c_int
-        L.cmcd_debug_grad_item.argtypes = [C.c_int]
-        L.cmcd_last_kernel_name.restype = C.c_char_p
-        L.cmcd_profile_enable.restype = C.c_int
-        L.cmcd_profile_enable.argtypes = [C.c_int]
-        L.cmcd_profile_collect.restype = C.c_int
-        L.cmcd_profile_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        # measurement / diagnostic hooks (include/cmcd_hip_diag.h): absent from a boundary-only build (-DCMCD_NO_DIAG_HOOKS)
+        global HAS_DIAG
+        HAS_DIAG = hasattr(L, "cmcd_profile_enable")
+        if HAS_DIAG:
+            L.cmcd_debug_capture_noise.restype = C.c_int
+            L.cmcd_debug_capture_noise.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+            L.cmcd_debug_grad_item.restype = C.c_int
+            L.cmcd_debug_grad_item.argtypes = [C.c_int]
+            L.cmcd_last_kernel_name.restype = C.c_char_p
+            L.cmcd_profile_enable.restype = C.c_int
+            L.cmcd_profile_enable.argtypes = [C.c_int]
+            L.cmcd_profile_collect.restype = C.c_int
+            L.cmcd_profile_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         _lib = L
     return _lib
 
@@ -148,21 +153,31 @@ def sync_grad_item_override():
     global _grad_item_sent
     want = os.environ.get("CMCD_GRAD_ITEM")
     if want != _grad_item_sent:
-        check(lib().cmcd_debug_grad_item(-1 if want is None else int(want != "0")))
+        L = lib()
+        if HAS_DIAG:
+            check(L.cmcd_debug_grad_item(-1 if want is None else int(want != "0")))
+        elif want is not None:
+            raise RuntimeError("CMCD_GRAD_ITEM needs a library built with the diagnostic hooks (include/cmcd_hip_diag.h)")
         _grad_item_sent = want
 
 
 def last_kernel_name():
-    """The trajectory kernel (or launch sequence) the last forward call of this thread enqueued."""
-    return lib().cmcd_last_kernel_name().decode()
+    """The trajectory kernel (or launch sequence) the last forward call of this thread enqueued ("" without the hooks)."""
+    L = lib()
+    return L.cmcd_last_kernel_name().decode() if HAS_DIAG else ""
 
 
 def profile_enable(on=True):
-    check(lib().cmcd_profile_enable(int(bool(on))))
+    L = lib()
+    if HAS_DIAG:
+        check(L.cmcd_profile_enable(int(bool(on))))
 
 
 def profile_collect():
     """-> (total trajectory-kernel milliseconds, launches) since the last enable/collect."""
     ms, cnt = C.c_double(), C.c_int64()
-    check(lib().cmcd_profile_collect(C.byref(ms), C.byref(cnt)))
+    L = lib()
+    if not HAS_DIAG:
+        return 0.0, 0        # callers fall back to the wall time per step (bench.py: leg_report)
+    check(L.cmcd_profile_collect(C.byref(ms), C.byref(cnt)))
     return ms.value, cnt.value

@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libcmcd_hip.so")
 SOURCES = ["cmcd_kernels.hip", "cmcd_uha.hip", "cmcd_coop.hip", "cmcd_coop_wide.hip", "cmcd_lgcp.hip", "cmcd_lgcp_wide.hip", "cmcd_grad.hip", "cmcd_bptt.hip", "cmcd_mfvi.hip", "cmcd_opt.hip"]
-HEADERS = ["cmcd_device.h", os.path.join(ROOT, "include", "cmcd_hip.h")]
+HEADERS = ["cmcd_device.h", os.path.join(ROOT, "include", "cmcd_hip.h"), os.path.join(ROOT, "include", "cmcd_hip_diag.h")]
 # Per-file flags.  cmcd_kernels.hip holds the wave-per-tile trajectory kernel, which is VALU-issue bound at 4 waves per
 # SIMD: there a packed fp32 instruction holds the pipe ~1.8x as long as a plain one and the SLP vectoriser pays v_mov
 # shuffles to form its operands (ISA reading r02: 126 v_pk_* + 4 v_mov per pair of mixture components), so it is off
@@ -58,6 +58,8 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
               "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-Wno-format-security"]
+    if os.environ.get("CMCD_DIAG_HOOKS", "1") == "0":     # the boundary only: no measurement / diagnostic exports (cmcd_hip_diag.h)
+        common.append("-DCMCD_NO_DIAG_HOOKS")
     todo = [s for s in SOURCES if force or _stale_obj(s)]
 
     def compile_one(src):

@@ -864,7 +864,9 @@ bool coop_half_available(const cmcd_desc& d, int T) { return pick(d, T, true).fn
 // that SIMD).  On 16-particle tiles no raise helps.  (Before the 4x4x1 chain the target waves were the long pole and
 // their raise alone gave -2.1 %: the table follows the balance, re-run the sweep after changing a role.)
 static int g_coop_prio = -1;   // -1: the table below
+#ifndef CMCD_NO_DIAG_HOOKS   // include/cmcd_hip_diag.h
 extern "C" void cmcd_debug_set_coop_prio(int prio) { g_coop_prio = prio; }   // tools/probes/prio_sweep.py
+#endif
 // 12-wave instance (132-wide net, RNG + ACC merged): the merged wave's stream is the longest of the workgroup (three
 // Threefry passes, two deviates and the log-weight per bridge against two partners with 72 matrix instructions each);
 // target waves and the merged wave one level up: 0.4957 -> 0.4602 ms at N = 2000 (profiles/r02_t_prio_t9.txt)

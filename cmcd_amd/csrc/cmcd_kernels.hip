@@ -26,6 +26,7 @@
 #include "cmcd_common.h"
 #include "cmcd_device.h"
 #include "cmcd_hip.h"
+#include "cmcd_hip_diag.h"
 
 namespace cmcd {
 
@@ -1088,7 +1089,9 @@ extern "C" {
 
 int cmcd_version(void) { return CMCD_ABI_VERSION; }
 const char* cmcd_last_error(void) { return g_err; }
+#ifndef CMCD_NO_DIAG_HOOKS   // include/cmcd_hip_diag.h: compiled out of a boundary-only build
 const char* cmcd_last_kernel_name(void) { return g_kernel_name; }
+#endif
 
 int64_t cmcd_target_floats(const cmcd_desc* desc, int32_t n_mixes) {
   if (!desc) return -1;
@@ -1316,11 +1319,13 @@ static int forward_impl(const cmcd_desc* desc, const cmcd_layout* lay, const int
   return CMCD_OK;
 }
 
+#ifndef CMCD_NO_DIAG_HOOKS
 int cmcd_debug_capture_noise(uint32_t* bits, uint32_t* gen_keys, float* noise) {
   if ((bits == nullptr) != (noise == nullptr)) return fail(CMCD_ERR_BAD_ARG, "bits and noise go together%s");
   g_capture.bits = bits; g_capture.keys = gen_keys; g_capture.noise = noise;
   return CMCD_OK;
 }
+#endif
 
 int cmcd_bound_forward(const cmcd_desc* desc, const cmcd_layout* lay, const int32_t* seeds, int64_t n,
                        const float* params, int64_t n_params, const float* target_consts, int64_t n_target,
@@ -1599,6 +1604,7 @@ int cmcd_stats_merge_device(const double* rows, int32_t count, double* out5, voi
   return CMCD_OK;
 }
 
+#ifndef CMCD_NO_DIAG_HOOKS
 int cmcd_debug_grad_item(int mode) {
   if (mode < -1 || mode > 1) return fail(CMCD_ERR_BAD_ARG, "mode must be -1, 0 or 1%s");
   set_grad_item_override(mode);
@@ -1631,6 +1637,7 @@ int cmcd_profile_collect(double* total_ms, int64_t* launches) {
   g_prof.used = 0;
   return CMCD_OK;
 }
+#endif   // CMCD_NO_DIAG_HOOKS
 
 int cmcd_stats_merge(const double* stats, const int64_t* n_per, int32_t count, double* merged5, double* out3) {
   if (!stats || !n_per || count < 1 || !merged5 || !out3) return fail(CMCD_ERR_BAD_ARG, "null pointer argument%s");

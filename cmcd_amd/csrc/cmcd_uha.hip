@@ -2519,7 +2519,9 @@ int64_t uha_grad_workspace_floats(const cmcd_desc& d, int HP, int64_t n) {
 }
 
 static float* g_uha_xdump = nullptr;   // tests: cmcd_debug_uha_xdump — the next sweeps write the adjoint state they carry
+#ifndef CMCD_NO_DIAG_HOOKS   // include/cmcd_hip_diag.h
 extern "C" void cmcd_debug_uha_xdump(float* buf) { g_uha_xdump = buf; }
+#endif
 
 // ws_fwd / traj as left by the forward launch on the SAME desc / params; gws: uha_grad_workspace_floats; grad: [n_params],
 // fully overwritten (zeros for the leaves the loss does not reach).

@@ -162,46 +162,9 @@ int cmcd_bound_forward_prepared(const cmcd_desc* desc, const cmcd_layout* lay,
                                 float* out_loss, float* out_z, double* out_stats,
                                 void* stream);
 
-/* ---- Measurement and diagnostic hooks: NOT part of the product path.  Nothing a result depends on goes through them;
- * they exist for bench.py (kernel time, kernel name) and the PRNG parity test, are per host thread, and a deployment can
- * leave them unbound.  (The library reads TWO environment variables, once per process, for the probes under tools/probes:
- * CMCD_COOP_PRIO, and CMCD_GRAD_ATOMICS=1, which puts the overdamped gradients' sums over tiles back on the float atomics of
- * rounds 1 - 3 — run-to-run differences in the last bits — for A / B timing.  CMCD_GRAD_ITEM is NOT read by the library: only the Python binding forwards it, through
- * cmcd_debug_grad_item below — a C caller that sets the variable gets the measured batch-size rule.) */
-
-/* Name of the trajectory kernel (or launch sequence) the last cmcd_bound_forward of this host thread enqueued, e.g.
- * "coop_kernel<8-particle tiles>", "traj_kernel", "uha_traj_kernel", "lgcp launch sequence"; "" before the first call.
- * bench.py reports it instead of re-deriving the library's selection rule. */
-const char* cmcd_last_kernel_name(void);
-
-/* Measurement hook (bench.py): while enabled (per host thread), every cmcd_bound_forward records a
- * hipEvent pair around its trajectory-kernel launch on the caller's stream.
- * cmcd_profile_collect synchronises those events, returns the summed kernel time and the number of
- * launches since the last enable/collect, and resets the counter.  Not for use under graph capture. */
-int cmcd_profile_enable(int on);
-int cmcd_profile_collect(double* total_ms, int64_t* launches);
-
-/* Diagnostic (tests/test_gpu_prng.py): arm a capture of the PRNG path of the NEXT cmcd_bound_forward issued by this host
- * thread (gmm / funnel / many_gmm; either trajectory kernel writes the words next to the arithmetic that consumes
- * them; consumed and disarmed by that call).  [device] buffers, stage 0 = the draw of z_0, stage i + 1 = bridge i:
- *   bits     uint32 [nbridges+1][n][dim]  the random words that become deviates (jax random_bits of normal(key, (dim,)))
- *   gen_keys uint32 [nbridges+1][n][2]    the chain key entering bridge i, gen_0 .. gen_K (mcd_cais.py:66,87,94); nullable
- *   noise    float  [nbridges+1][n][dim]  the deviates (jax.random.normal)
- * MCD_CAIS_UHA_sn has one more draw in front of the loop (the initial momentum, mcd_under_lp_a_cais.py:92-93): bits / noise
- * are [nbridges+2][n][dim] with stage 1 = rho_0 and stage i + 2 = bridge i; gen_keys stays [nbridges+1][n][2].
- * Pass three NULLs to disarm. */
-int cmcd_debug_capture_noise(uint32_t* bits, uint32_t* gen_keys, float* noise);
-
-/* Diagnostic: pin the gradient calls of this process to whole chains (0) or to the work-item path (1); -1 returns to
- * the measured batch-size rule.  (Tests and tools/probes run every case through both; the Python binding forwards the
- * CMCD_GRAD_ITEM environment variable through this call, the library itself reads no environment per call.) */
-int cmcd_debug_grad_item(int mode);
-
-/* Diagnostic (tools/probes/uha_item_check.py): while `buf` is non-NULL the MCD_CAIS_UHA_sn gradient's sweep writes the
- * adjoint state it carries — (dL/dz_e, dL/drho_e, dL/drho''_e) entering point e — to buf, float [nbridges+1][3 dim][n]
- * [device]: the whole-chain sweep and the work-item path (whose chunks load that state from the scan launch) can be compared
- * point by point.  Process-wide; NULL disarms. */
-void cmcd_debug_uha_xdump(float* buf);
+/* (Measurement and diagnostic hooks — kernel-time events, the PRNG capture of the parity tests, the probes' switches — are NOT
+ * part of this boundary: they are declared in include/cmcd_hip_diag.h and compiled out of the library by
+ * -DCMCD_NO_DIAG_HOOKS; a deployment binds nothing of them.) */
 
 /* ---- VarGrad gradient ("compute_log_var_grad"): d/d params_flat of compute_bound_var
  * (/root/reference/src/main.py:161-176 takes jax.grad of it; /root/reference/src/mcd_cais_var.py:59,79
@@ -250,6 +213,11 @@ int cmcd_bound_var_grad_kept(const cmcd_desc* desc, const cmcd_layout* layout, c
  * slot table of 1 GB (about 245 000 particles at K = 256 with the 64-wide dds net); above it the overdamped modes'
  * bias-row and schedule sums fall back to float atomics and the last bits may differ from call to call.  (The
  * reference's own gradients are XLA reductions: deterministic on one device.) */
+/* Workspace growth to plan for: beside the kept trajectory ((K + 1) n dim floats; 3 K + 2 rows of n dim for MCD_CAIS_UHA_sn) the
+ * fixed-order sums keep one slot row per (16-particle tile, evaluation): K HP (2 | 4) / 16 floats per particle.  The overdamped
+ * modes cap that table at 1 GB and fall back to atomics above it (see above); MCD_CAIS_UHA_sn has NO cap and no fallback — with the
+ * 144-wide geffner net and K = 256 it is ~37 KB per particle: 0.6 GB at n = 16 000, 2.4 GB at n = 65 536 on top of the trajectory.
+ * Query this function and split larger 2nd-order batches on the caller's side (gradients of particle batches add). */
 int64_t cmcd_bound_grad_workspace_bytes(const cmcd_desc* desc, int64_t n);
 int cmcd_bound_grad(const cmcd_desc* desc, const cmcd_layout* layout, const int32_t* seeds, int64_t n,
                     const float* params, int64_t n_params, const float* target_consts, int64_t n_target,

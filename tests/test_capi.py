@@ -13,19 +13,47 @@ from cmcd_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_functions():
-    src = open(os.path.join(ROOT, "include", "cmcd_hip.h")).read()
+def declared_functions(header="cmcd_hip.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(cmcd_[a-z_0-9]+)\s*\(", src)))
 
 
 def test_exports_every_declared_symbol(hip_lib):
     names = declared_functions()
-    assert {"cmcd_version", "cmcd_last_error", "cmcd_workspace_bytes", "cmcd_bound_forward",
-            "cmcd_stats_merge", "cmcd_target_floats", "cmcd_profile_enable", "cmcd_profile_collect"} <= set(names)
+    assert {"cmcd_version", "cmcd_last_error", "cmcd_workspace_bytes", "cmcd_bound_forward", "cmcd_bound_forward_prepared",
+            "cmcd_stats_merge", "cmcd_target_floats", "cmcd_bound_grad", "cmcd_adam_step"} <= set(names)
+    # the boundary header declares the boundary only: measurement / diagnostic hooks live in cmcd_hip_diag.h
+    assert not [n for n in names if n.startswith(("cmcd_debug_", "cmcd_profile_")) or n == "cmcd_last_kernel_name"]
     for n in names:
         assert hasattr(hip_lib, n), f"{n} declared in cmcd_hip.h but not exported"
+    diag = declared_functions("cmcd_hip_diag.h")
+    assert {"cmcd_profile_enable", "cmcd_profile_collect", "cmcd_last_kernel_name", "cmcd_debug_capture_noise",
+            "cmcd_debug_grad_item", "cmcd_debug_uha_xdump", "cmcd_debug_set_coop_prio"} == set(diag)
+    for n in diag:      # the in-tree build (tests, bench) carries them
+        assert hasattr(hip_lib, n), f"{n} declared in cmcd_hip_diag.h but not exported"
     assert hip_lib.cmcd_version() == 3
+
+
+def test_boundary_only_build_exports_no_hooks(tmp_path):
+    """-DCMCD_NO_DIAG_HOOKS (CMCD_DIAG_HOOKS=0 python -m cmcd_amd.build): every symbol of the hooks' header is gone from the three
+    translation units that define them, every boundary symbol they define is still there (checked on the objects: no link, no GPU)."""
+    import subprocess
+    from cmcd_amd import build
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not installed")
+    diag = set(declared_functions("cmcd_hip_diag.h"))
+    seen = set()
+    for src in ("cmcd_kernels.hip", "cmcd_coop.hip"):       # (cmcd_uha.hip holds one more hook behind the same guard)
+        obj = tmp_path / (src + ".o")
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O1", "-std=c++17", "-fPIC", "-DCMCD_NO_DIAG_HOOKS", "-I",
+                        os.path.join(ROOT, "include"), "-I", build.CSRC, "-Wno-format-security"] + build.EXTRA_FLAGS.get(src, []) +
+                       ["-c", os.path.join(build.CSRC, src), "-o", str(obj)], check=True)
+        out = subprocess.run(["nm", "--defined-only", str(obj)], capture_output=True, text=True, check=True).stdout
+        seen |= {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert not (seen & diag), seen & diag
+    assert {"cmcd_bound_forward", "cmcd_bound_forward_prepared", "cmcd_version", "cmcd_stats_merge"} <= seen
 
 
 def _desc(**kw):
