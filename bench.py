@@ -75,7 +75,7 @@ def stored_traffic(key):
     """HBM bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of
     this same command, tools/probes/pmc_hbm.sh) — bench.py cannot collect counters on itself.  The summary records the
     sha of the kernel sources it was measured on; a figure from another build is reported as null, not as current."""
-    for rnd in ("r04_pmc", "r03_pmc", "r02_pmc", "r01_pmc"):
+    for rnd in ("r05_pmc", "r04_pmc", "r03_pmc", "r02_pmc", "r01_pmc"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", rnd, "summary.json")))
         except Exception:
@@ -90,7 +90,7 @@ def stored_issue_occupancy(key):
     on gfx950 an fp32 matrix instruction and fp32 VALU work of a SIMD do not overlap (profiles/r04_mfma_valu_overlap_probe.txt),
     so (matrix busy cycles + VALU active cycles) / (SIMDs x launch duration) is the fraction of the launch in which a SIMD issued
     arithmetic at all — the bound a latency chain like this one is held against, beside the matrix-peak fraction."""
-    for rnd in ("r04_pmc",):
+    for rnd in ("r05_pmc", "r04_pmc"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", rnd, "summary.json")))
         except Exception:
@@ -755,7 +755,7 @@ def main():
             # measured L2 <-> fabric bytes of the three GEMM launches of one evaluation (tools/probes/round_end_r04.sh: separate
             # rocprofv3 --pmc passes, FETCH_SIZE doubled per the gfx950 note), x (K + 1) evaluations x passes
             traffic = None
-            for rnd in ("r04_pmc", "r03_pmc", "r02_pmc"):
+            for rnd in ("r05_pmc", "r04_pmc", "r03_pmc", "r02_pmc"):
                 try:   # only a summary measured on this build of the kernels counts (kernel_sources_sha)
                     pm = json.load(open(os.path.join(ROOT, "profiles", rnd, "lgcp_summary.json")))
                     if pm.get("kernel_sources_sha") == kernel_sources_sha("lgcp") and dim == 1600 and IN == 1620:

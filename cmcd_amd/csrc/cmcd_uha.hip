@@ -1231,7 +1231,7 @@ template <int TARGET, int ARCH, int D, int T, int NW, bool WGLOBAL, bool JAC = f
 // (r04) the d = 2 Jacobian launch at three waves per SIMD (168 registers, 12 spilled): 337 -> 314 us at the named shape.  The sweep
 // at two (241 registers, so that the second workgroup a CU's LDS has room for is really resident) measured 606 against 592 us
 // with one: on gfx950 an fp32 MFMA and the VALU work of the SIMD's other wave do not overlap (tools/probes/mfma_valu_probe.hip),
-// so a second wave only fills the stalls, and these are not what bounds the sweep ("the floor").
+// so a second wave only fills the stalls, and these are not what bounds the sweep (CHANGELOG.md (DESIGN r04 section 7d), "the floor").
 #ifndef UHA_SWEEP_WAVES
 #define UHA_SWEEP_WAVES 1
 #endif

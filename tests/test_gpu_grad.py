@@ -659,7 +659,7 @@ def test_repeated_gradient_calls_are_bitwise_identical(hip_lib, monkeypatch, nam
 def test_a_training_seed_reproduces_bit_for_bit(hip_lib):
     """Two opt.run trainings with one seed end at the same parameters, bit for bit (gmm K = 8 is chaotic enough that
     last-bit differences in a gradient moved the trained ELBO by 0.05 nats between runs before: tools/probes/
-    train_determinism.py)."""
+    train_determinism.py, CHANGELOG.md (DESIGN r04 section 6))."""
     import types
     from functools import partial
     from cmcd_amd import opt

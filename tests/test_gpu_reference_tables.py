@@ -76,7 +76,7 @@ def test_gmm_seed_mean_against_the_notebook_row(hip_lib):
     distribution — the same rule as the funnel rows above.  Measured: the seed mean sits ~0.14 ABOVE the notebook's run
     (1.3 of those sigmas; 2.6 sigma_notebook alone).  The restatement-trained model (tests/golden/oracle_trained_rows.json:
     -0.533) lands at the same place as the HIP-trained ones, so the offset is not the kernels'; it is recorded as a known
-    deviation in DESIGN.md section 5b, and this test fails if it grows beyond 3 sigma of the combined spread."""
+    deviation in CHANGELOG.md (DESIGN r04 section 5b), and this test fails if it grows beyond 3 sigma of the combined spread."""
     ref = _row("gmm", 8)
     n = 8
     runs = np.array([_run("gmm", 8, s) for s in range(1, n + 1)])

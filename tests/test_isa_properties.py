@@ -1,4 +1,4 @@
-"""Code-generation properties of the hot kernels that the measured speed depends on ("second pass
+"""Code-generation properties of the hot kernels that the measured speed depends on (CHANGELOG.md (DESIGN r04 section 4), "second pass
 of round 2"), checked on the gfx950 ISA that hipcc emits — no GPU needed.  Each assertion names a regression that was
 worth several percent when it was found by reading the ISA:
 

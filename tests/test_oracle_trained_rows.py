@@ -11,7 +11,7 @@ What the pin says, plainly (r04: six training seeds of funnel K = 8 instead of o
     2.1 notebook sigmas, 2.0 sigmas of the combined spread sqrt(sigma_nb^2 + sigma_seed^2 (1 + 1 / n));
   * ln Z agrees (-0.30 +- 0.05 against -0.304 +- 0.151), and so does the ELBO from K = 32 up (-0.687 against -0.681 +- 0.020);
   * K = 8 and K = 16 ELBOs are 0.03 - 0.06 HIGH, cause unknown — the HIP-trained models land on the same value as the
-    restatement-trained ones (-1.010 +- 0.006), so it is not the kernels', but which optimiser /
+    restatement-trained ones (-1.010 +- 0.006, CHANGELOG.md (DESIGN r04 section 5b)), so it is not the kernels', but which optimiser /
     initialisation produced the notebook's rows is not recorded anywhere in the reference, and no claim is made about it."""
 import json
 import os
@@ -40,7 +40,7 @@ def test_funnel_k8_seed_mean_against_the_notebook_row():
           f"combined sigma), ln Z {lnz.mean():.4f} +- {lnz.std(ddof=1):.4f} (notebook {rows[0]['reference_ln_Z']:.4f})")
     # the seed mean, not a single run: within 3 sigma of the combined spread — and the measured offset is recorded, not hidden
     assert abs(z) <= 3.0, (mean, ref, z)
-    assert 0.02 < mean - ref < 0.09, "the K = 8 ELBO offset against the notebook moved: re-read DESIGN.md section 5b"
+    assert 0.02 < mean - ref < 0.09, "the K = 8 ELBO offset against the notebook moved: re-read CHANGELOG.md (DESIGN r04 section 5b)"
     assert sd < 0.02, sd                       # training seeds agree with each other to ~0.008
     assert abs(lnz.mean() - rows[0]["reference_ln_Z"]) <= 0.15, lnz.mean()
 
@@ -70,7 +70,7 @@ def test_oracle_trained_model_reaches_the_reference_notebook_row(row):
     # ln Z: the reference's own spread over its 30 evaluation groups is the only sigma it holds (0.15 for funnel K = 8)
     assert abs(row["ln_Z"] - row["reference_ln_Z"]) <= 0.15, (row["ln_Z"], row["reference_ln_Z"])
     if row["model"] == "gmm":
-        # gmm K = 8 spreads between -0.69 and -0.42 over training seeds of the HIP path (the notebook's
+        # gmm K = 8 spreads between -0.69 and -0.42 over training seeds of the HIP path (CHANGELOG.md (DESIGN r04 section 5b); the notebook's
         # single run, -0.694, sits at the lower end): the restatement-trained models land INSIDE that spread — the width
         # belongs to the training dynamics, not to the kernels.  An envelope, not a pin (tests/test_gpu_reference_tables.py
         # holds the unselected seed mean of the HIP path against the notebook).

@@ -6,7 +6,7 @@ the same driver flow, optimiser, initial parameters and per-iteration particle s
 Purpose (test infrastructure, like tools/make_golden.py): (i) the first pin of the ORACLE itself to a number the
 reference holds — the stored notebook tables (tests/golden/reference_notebook_tables.json) — and (ii) to tell an
 optimiser / initialisation offset from a forward / gradient discrepancy: the HIP run of the same flags sits +0.05 above the
-reference's funnel K = 8 ELBO with a seed spread of 0.006; if the oracle-trained model lands on the
+reference's funnel K = 8 ELBO with a seed spread of 0.006 (CHANGELOG.md (DESIGN r04 section 5b)); if the oracle-trained model lands on the
 same value the HIP kernels are not the cause.  The result is appended to tests/golden/oracle_trained_rows.json (read by
 tests/test_oracle_trained_rows.py).  Only the funnel / gmm rows are small enough for the CPU."""
 import argparse
