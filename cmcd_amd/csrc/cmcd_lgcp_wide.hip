@@ -33,6 +33,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "cmcd_common.h"
 #include "cmcd_device.h"
 #include "cmcd_hip.h"
@@ -275,6 +277,20 @@ __global__ __launch_bounds__(256, 2) void lgcp_wide_gemm_kernel(WideArgs a) {
   const float* Wp = sg.W + (int64_t)(4 * h) * sg.ldw + n0 + 4 * c;
   const int64_t ldw = sg.ldw;
   const float shift = sg.a_shift;
+#ifndef CMCD_WIDE_BUF
+#define CMCD_WIDE_BUF 1
+#endif
+  // r05: the operands come through buffer descriptors — per-lane byte offset in a register that never changes, the chunk's
+  // position in a SCALAR offset (`buffer_load ... s_off offen`): no vector address arithmetic in the loop (the flat form
+  // spent ~10 of its ~14 VALU instructions per chunk on 64-bit addresses; on gfx950 VALU and fp32 matrix time add).
+  const int wvu = __builtin_amdgcn_readfirstlane(wv);
+  const uint32_t voffA = (uint32_t)(((rt * kWRows + c) * sg.lda + 4 * h) * 4);
+  const uint32_t voffW = (uint32_t)((4 * h * sg.ldw + n0 + 4 * c) * 4);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(sg.A), 0, __builtin_amdgcn_readfirstlane(a.RT * kWRows * sg.lda * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(sg.W), 0, __builtin_amdgcn_readfirstlane(sg.Kp * sg.ldw * 4), 0x00020000);
+  const int ldwB = __builtin_amdgcn_readfirstlane(sg.ldw * 4);
 
   f32x16 acc[4];
 #pragma unroll
@@ -282,9 +298,70 @@ __global__ __launch_bounds__(256, 2) void lgcp_wide_gemm_kernel(WideArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
 
-  // ---- the consumer's own operands (outputs of EARLIER launches), requested before the contraction so that their trip to
-  // L2 / HBM rides under it: element q of this thread = (row (q 256 + tid) / 32, columns 4 ((q 256 + tid) % 32) ..+3)
   const int epi = sg.epi;
+
+  // chunk ch = 4 tt + wave (interleaved over the waves: the workgroup walks the contraction front to back together).
+  // MFMA step s of a chunk contracts the k pair (k0 + s, k0 + 4 + s): lane half h supplies k0 + 4 h + s for both operands,
+  // so its four A values are ONE 16-byte load and step s's four B values (the four column blocks) another.
+#ifndef CMCD_WIDE_DEPTH
+#define CMCD_WIDE_DEPTH 3
+#endif
+  constexpr int P = CMCD_WIDE_DEPTH;     // chunks in flight per wave
+  f32x4 av[P], bv[P][4];
+  auto issue = [&](f32x4& a_, f32x4 (&b_)[4], int tt) {
+    if (CMCD_WIDE_BUF) {
+      const int ch = min(4 * tt + wvu, nch - 1);                 // past the end: a valid, unused reload of the last chunk
+      a_ = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, voffA, 32 * ch, 0));
+      const int wo = 8 * ch * ldwB;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        b_[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, voffW, wo + s * ldwB, 0));
+    } else {
+      const int ch = min(4 * tt + wv, nch - 1);
+      a_ = *reinterpret_cast<const f32x4*>(Ap + 8 * ch);
+      const float* wp = Wp + (int64_t)(8 * ch) * ldw;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) b_[s] = *reinterpret_cast<const f32x4*>(wp + s * ldw);
+    }
+  };
+  // the operand shift (K^-1 (x - mu0)) only in the segments that have one: the whole contraction loop exists twice behind a
+  // wave-uniform branch (as a select inside one loop the compiler kept the four subtractions AND added four selects per chunk)
+  auto contract = [&](auto sh_tag, const f32x4& a_, const f32x4 (&b_)[4]) {
+    constexpr bool SH = decltype(sh_tag)::value;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float as = SH ? a_[s] - shift : a_[s];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(as, b_[s][j], acc[j], 0, 0, 0);
+    }
+  };
+  auto run = [&](auto sh_tag) {
+#pragma unroll
+    for (int u = 0; u < P - 1; ++u) issue(av[u], bv[u], u);
+    // P chunks in flight; the body is UNCONDITIONAL (a branch around an issue makes the compiler's wait-count merge
+    // pessimistic: it put s_waitcnt vmcnt(0) at the loop head, draining the younger chunks on every trip).  The last
+    // T mod P chunks are already in flight when the loop ends.
+    int tt = 0;
+    for (; tt + P <= T; tt += P) {
+#pragma unroll
+      for (int u = 0; u < P; ++u) {
+        issue(av[(u + P - 1) % P], bv[(u + P - 1) % P], tt + u + P - 1);
+        __builtin_amdgcn_sched_barrier(0);     // the machine scheduler otherwise sinks these loads to just before their use
+        contract(sh_tag, av[u], bv[u]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < P - 1; ++u)
+      if (tt + u < T) contract(sh_tag, av[u], bv[u]);               // wave-uniform
+  };
+  if (!CMCD_WIDE_BUF || __builtin_amdgcn_readfirstlane(shift != 0.f ? 1 : 0)) run(std::true_type{});
+  else run(std::false_type{});
+
+  // ---- the consumer's own operands (outputs of EARLIER launches), all four elements of this thread requested at once, in
+  // flight across the cross-wave sum and its barrier (requested BEFORE the contraction they cost ~50 registers through the
+  // whole loop for no measurable gain: the consumer is VALU-bound): element q = (row (q 256 + tid) / 32, columns
+  // 4 ((q 256 + tid) % 32) ..+3)
   WideStepRegs sr[4];
   f32x4 eb[4], eu[4];      // ACT: bias and residual input
 #pragma unroll
@@ -308,48 +385,6 @@ __global__ __launch_bounds__(256, 2) void lgcp_wide_gemm_kernel(WideArgs a) {
     }
   }
   __builtin_amdgcn_sched_barrier(0);
-
-  // chunk ch = 4 tt + wave (interleaved over the waves: the workgroup walks the contraction front to back together).
-  // MFMA step s of a chunk contracts the k pair (k0 + s, k0 + 4 + s): lane half h supplies k0 + 4 h + s for both operands,
-  // so its four A values are ONE 16-byte load and step s's four B values (the four column blocks) another.
-#ifndef CMCD_WIDE_DEPTH
-#define CMCD_WIDE_DEPTH 3
-#endif
-  constexpr int P = CMCD_WIDE_DEPTH;     // chunks in flight per wave
-  f32x4 av[P], bv[P][4];
-  auto issue = [&](f32x4& a_, f32x4 (&b_)[4], int tt) {
-    const int ch = min(4 * tt + wv, nch - 1);                    // past the end: a valid, unused reload of the last chunk
-    a_ = *reinterpret_cast<const f32x4*>(Ap + 8 * ch);
-    const float* wp = Wp + (int64_t)(8 * ch) * ldw;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) b_[s] = *reinterpret_cast<const f32x4*>(wp + s * ldw);
-  };
-  auto contract = [&](const f32x4& a_, const f32x4 (&b_)[4]) {
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const float as = a_[s] - shift;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(as, b_[s][j], acc[j], 0, 0, 0);
-    }
-  };
-#pragma unroll
-  for (int u = 0; u < P - 1; ++u) issue(av[u], bv[u], u);
-  // P chunks in flight; the body is UNCONDITIONAL (a branch around an issue makes the compiler's wait-count merge
-  // pessimistic: it put s_waitcnt vmcnt(0) at the loop head, draining the younger chunks on every trip).  The last
-  // T mod P chunks are already in flight when the loop ends.
-  int tt = 0;
-  for (; tt + P <= T; tt += P) {
-#pragma unroll
-    for (int u = 0; u < P; ++u) {
-      issue(av[(u + P - 1) % P], bv[(u + P - 1) % P], tt + u + P - 1);
-      __builtin_amdgcn_sched_barrier(0);     // the machine scheduler otherwise sinks these loads to just before their use
-      contract(av[u], bv[u]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < P - 1; ++u)
-    if (tt + u < T) contract(av[u], bv[u]);                       // wave-uniform
 
   // ---- sum of the four waves' partial tiles, fixed order.  D layout of the MFMA: column = lane & 31 (= c, i.e. tile
   // column 4 c + block), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
