@@ -741,7 +741,7 @@ def main():
 
     if cfg["model"] == "lgcp":
         IN = dim + cfg["emb_dim"]
-        if n >= 224:
+        if n >= 225:     # cmcd_common.h: kLgcpWideMin
             # wide batches (cmcd_lgcp_wide.hip; the reference's evaluation batches): every particle shares ONE weight pass per
             # evaluation, intensity 2 n FLOP per 4 weight bytes >> the machine balance => matrix-pipe bound
             fl = 2.0 * (dim * dim + 2 * dim * IN + IN * IN) * (K + 1) * n

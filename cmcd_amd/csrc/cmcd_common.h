@@ -112,7 +112,7 @@ int lgcp_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout& sw,
                  double** partials_out, float* traj, void* stream, bool tables_ready = false, float* keep_gws = nullptr);
 // cmcd_lgcp_wide.hip: forward-only calls on wide batches (>= kLgcpWideMin particles): whole-batch launches of a real fp32
 // GEMM body (32 x 128 tiles over the whole contraction, no split-K seam) instead of 32-row weight-streaming passes
-constexpr int64_t kLgcpWideMin = 224;   // measured crossover against the 32-row passes on four lanes (profiles/r04_e_lgcp_crossover.txt: 13.2 vs 13.4 ms at 224)
+constexpr int64_t kLgcpWideMin = 225;   // measured crossover against the 32-row passes on four lanes (K = 128, profiles/r05_h_lgcp_wide_valu_trims.txt: seven passes 11.2 ms against 12.3 ms at 224, eight passes 15.7 against 12.3 at 256)
 bool lgcp_wide_supported(const cmcd_desc& d);
 bool lgcp_use_wide(const cmcd_desc& d, int64_t n, bool keeps_trajectory);    // the one selection rule (workspace query + launch)
 int64_t lgcp_wide_workspace_floats(const cmcd_desc& d, int64_t n, int64_t base);

@@ -71,7 +71,7 @@ struct WideStep {            // evaluation i at z_i: closes step i-1, opens step
   const float* kr;           // [Mp][ldx]  (z - mu0) K^-1 of this evaluation (launch B)
   const float* b3;           // packed, [Np]
   const float* mean;         // packed vd.mean
-  const float* sd;           // packed exp(vd.logdiag)
+  const float* sd;           // packed 1 / exp(vd.logdiag)^2
   const float* counts;       // packed
   const float* factor;       // factor_sn (device scalar)
   const uint32_t* gktab;     // [K][n][2]
@@ -223,9 +223,12 @@ __device__ __forceinline__ void wide_step4(const WideArgs& a, int m, int col, co
   for (int j = 0; j < 4; ++j) {
     const float z = zv[j], kr = krv[j], cnt = cnv[j], sd = sdv[j];
     const float sn = NO_NET ? 0.f : (o[j] + b3v[j]) * fac;       // factor_sn (u2 W3 + b3)        nn.py:70
-    const float ez = expf(z);
+    // e^z on v_exp_f32 (<= 4e-7 relative at the log-intensities of this target) and 1 / sd^2 from the packed vector: the libm
+    // exponential and an IEEE division were ~35 of this consumer's ~190 VALU instructions per element, on a SIMD where they
+    // add to the matrix time (launch C at N = 600: 37.5 -> see profiles/r05_h_lgcp_wide_valu_trims.txt)
+    const float ez = __builtin_amdgcn_exp2f(1.44269504088896340736f * z);
     float gp = -kr + cnt - pa * ez;                               // grad log p                    model_handler.py:386-396
-    float gq = -(z - mnv[j]) / (sd * sd);
+    float gq = -(z - mnv[j]) * sd;                                // sd holds 1 / std^2 (lgcp_wide_vec_kernel)
     if (clip_p) gp = fminf(fmaxf(gp, -clipv), clipv);
     if (clip_q) gq = fminf(fmaxf(gq, -clipv), clipv);
     float zn = 0.f;
@@ -465,7 +468,7 @@ __global__ void lgcp_wide_vec_kernel(WideVecArgs a) {
     const bool in = e < a.D;
     a.b3[n] = (a.has_net && in) ? a.params[a.lay.g_b3 + e] : 0.f;
     a.mean[n] = in ? a.params[a.lay.vd_mean + e] : 0.f;
-    a.sd[n] = in ? expf(a.params[a.lay.vd_logdiag + e]) : 1.f;
+    a.sd[n] = in ? expf(-2.0f * a.params[a.lay.vd_logdiag + e]) : 1.f;     // 1 / std^2: what the state update multiplies by
     a.counts[n] = in ? a.tc[(int64_t)a.D * a.D + e] : 0.f;
   }
 }

@@ -136,7 +136,7 @@ def test_lgcp_matches_oracle(hip_lib, param_set, monkeypatch, n, k, form):
 ])
 def test_lgcp_wide_batch_path_matches_oracle(hip_lib, param_set, monkeypatch, mode, n, k, over):
     """The wide-batch form of the d = 1600 path (cmcd_lgcp_wide.hip: whole-batch launches of a 32 x 128-tile fp32 GEMM body,
-    taken by forward-only calls of >= 224 particles (kLgcpWideMin: the crossover measured at K = 128) — the reference's evaluation batches, /root/reference/src/opt.py:167-197)
+    taken by forward-only calls of >= 225 particles (kLgcpWideMin: the crossover measured at K = 128) — the reference's evaluation batches, /root/reference/src/opt.py:167-197)
     pinned here at small sizes through the kernel-variant hook, for every mode flag of its state update, against the
     float64 oracle AND against the 32-row launch sequence on the same seeds."""
     from cmcd_amd import _lib
