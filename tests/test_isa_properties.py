@@ -32,6 +32,15 @@ def _asm(tmp_path_factory, src, extra=()):
     return out.read_text().split("\n")
 
 
+def _kernel_whole(lines, mangled_prefix):
+    """-> (every line of the function up to its .Lfunc_end, the metadata lines behind it): for kernels with more than one
+    `s_endpgm` (a role that leaves early sits in front of the loops)."""
+    start = next(i for i, l in enumerate(lines) if l.startswith(mangled_prefix + ":"))
+    end = next(i for i in range(start + 1, len(lines)) if lines[i].startswith(".Lfunc_end"))
+    tail = next(i for i in range(end, len(lines)) if "ScratchSize" in lines[i])
+    return lines[start:end + 1], lines[end:tail + 1]
+
+
 def _kernel(lines, mangled_prefix):
     start = next(i for i, l in enumerate(lines) if l.startswith(mangled_prefix) and l.rstrip().endswith(":") or
                  (l.startswith(mangled_prefix) and ": " in l and "; @" in l))
@@ -97,7 +106,7 @@ def test_headline_kernel_does_not_spill(coop_asm):
 
 
 def test_wave_per_tile_kernel_keeps_the_erfinv_tail_in_a_branch(traj_asm):
-    body, _ = _kernel(traj_asm, "_ZN4cmcd11traj_kernelILi2ELi1ELi2ELi4EEEvNS_8TrajArgsE")
+    body, _ = _kernel(traj_asm, "_ZN4cmcd11traj_kernelILi2ELi1ELi2ELi4ELb1EEEvNS_8TrajArgsE")
     marks = [i for i, l in enumerate(body) if "; erfinv tail" in l]
     assert marks, "marker of the tail branch not found"
     for i in marks:
@@ -112,9 +121,64 @@ def test_wave_per_tile_kernel_keeps_the_erfinv_tail_in_a_branch(traj_asm):
 
 
 def test_wave_per_tile_kernel_is_built_without_slp(traj_asm):
-    body, _ = _kernel(traj_asm, "_ZN4cmcd11traj_kernelILi2ELi1ELi2ELi4EEEvNS_8TrajArgsE")
+    body, _ = _kernel(traj_asm, "_ZN4cmcd11traj_kernelILi2ELi1ELi2ELi4ELb1EEEvNS_8TrajArgsE")
     packed = sum(1 for l in body if re.match(r"\s*v_pk_(fma|mul|add)_f32", l))
     assert packed <= 40, f"{packed} packed fp32 instructions: is -fno-slp-vectorize still applied to cmcd_kernels.hip?"
+
+
+def test_the_9_tile_net_keeps_the_next_fragments_in_flight(traj_asm):
+    """r05 (config 4 on one GPU 2.315 -> 2.003 ms): the layer-2 fragments of input tile ti + 1 are requested while tile ti's
+    matrix instructions run.  Left alone the machine scheduler sinks every `ds_read_b128` to just in front of the four matrix
+    instructions that use it, each behind a full `s_waitcnt lgkmcnt(0)`: 81 waits inside the matrix chain of one evaluation."""
+    body, tail = _kernel_whole(traj_asm, "_ZN4cmcd11traj_kernelILi2ELi0ELi2ELi9ELb1EEEvNS_8TrajArgsE")
+    loop_start = max(i for i, l in enumerate(body) if "Loop Header: Depth=1" in l)
+    loop = body[loop_start:]
+    m = [i for i, l in enumerate(loop) if "v_mfma_f32_16x16x4" in l]
+    assert len(m) >= 324                                            # 9 x 9 x 4 per evaluation
+    chain = loop[m[0]:m[323] + 1]
+    full_waits = sum(1 for l in chain if re.match(r"\s*s_waitcnt\s+lgkmcnt\(0\)", l))
+    assert full_waits <= 12, f"{full_waits} full LDS waits inside the matrix chain: the fragment reads were sunk to their uses"
+    assert not any("ScratchSize: " in l and "ScratchSize: 0" not in l for l in tail)
+
+
+@pytest.fixture(scope="module")
+def wide8_asm(tmp_path_factory):
+    return _asm(tmp_path_factory, "cmcd_coop_wide.hip")
+
+
+def test_funnel_dealt_coordinates_kernel_structure(wide8_asm):
+    """coop_wide8_kernel<geffner, 10, T = 4> (BASELINE configs[1]): no scratch, one loop per role with TWO barriers per
+    evaluation (r04's form had three), layer 2 on 32 `4x4x1` matrix instructions with row-broadcast activations, packed
+    fp32 in layers 1 / 3, the schedule row as the hand-issued scalar load."""
+    body, tail = _kernel_whole(wide8_asm, "_ZN4cmcd17coop_wide8_kernelILi0ELi10ELi4EEEvNS_8TrajArgsE")
+    assert any("ScratchSize: 0" in l for l in tail)
+    # one bridge loop per role (MLP, TGT, RNG, ACC; the compiler rotates and peels them, so barriers are counted for the whole
+    # function): 2 prologue + 2 per evaluation (once or twice in the text of a peeled loop) + 1 hand-over per role — the
+    # three-barrier form of r04 would need at least 4 x (2 + 3 + 1) with every loop emitted once
+    assert sum("Loop Header: Depth=1" in l for l in body) >= 4
+    nbar = sum(1 for l in body if l.strip() == "s_barrier")
+    assert 4 * 5 <= nbar <= 4 * 7 + 2, nbar
+    mf = [l for l in body if "v_mfma_f32_4x4x1" in l]
+    assert len(mf) >= 32 and all("blgp:" in l for l in mf)
+    assert sum(1 for l in body if re.match(r"\s*v_pk_(fma|mul)_f32", l)) >= 15
+    assert sum(1 for l in body if "s_load_dwordx4" in l) >= 2
+
+
+def test_wide_lgcp_gemm_loop_has_no_vector_address_arithmetic(tmp_path_factory):
+    """r05 (N = 600: 17.4 -> 15.8 ms): the operands of lgcp_wide_gemm_kernel come through buffer descriptors with the chunk's
+    position in a scalar offset — on gfx950 every VALU instruction of the loop adds to the matrix time of its SIMD."""
+    lines = _asm(tmp_path_factory, "cmcd_lgcp_wide.hip")
+    body, tail = _kernel_whole(lines, "_ZN4cmcd21lgcp_wide_gemm_kernelENS_8WideArgsE")
+    assert any("ScratchSize: 0" in l for l in tail)
+    m = [i for i, l in enumerate(body) if "v_mfma_f32_32x32x2" in l]
+    assert len(m) >= 128                                            # the contraction loop exists twice (with / without operand shift)
+    for lo, hi in ((m[0], m[63]), (m[-64], m[-1])):
+        seg = body[lo:hi + 1]
+        assert sum("buffer_load_dwordx4" in l for l in seg) >= 5            # 5 per chunk, 64 matrix instructions = 4 chunks
+        assert not any(re.match(r"\s*(v_lshl_add_u64|v_mad_i64_i32|global_load)", l) for l in seg), "vector addresses are back in the loop"
+    # one of the two loops subtracts the operand shift, the other has no VALU arithmetic between its matrix instructions
+    subs = [sum(1 for l in body[lo:hi + 1] if re.match(r"\s*v_sub_f32", l)) for lo, hi in ((m[0], m[63]), (m[-64], m[-1]))]
+    assert min(subs) == 0 and max(subs) >= 12, subs
 
 
 # ---------------------------------------------------------------------------------------------- 2nd-order mode (cmcd_uha.hip)
@@ -197,7 +261,7 @@ def test_wide_gemm_keeps_three_chunks_in_flight(wide_asm):
     end = next(i for i in range(start, len(body)) if "s_cbranch" in body[i])
     loop = body[start:end]
     mfma = [l for l in loop if "v_mfma_f32_32x32x2_f32" in l]
-    loads = [l for l in loop if "global_load_dwordx4" in l]
+    loads = [l for l in loop if "buffer_load_dwordx4" in l]        # r05: through buffer descriptors (scalar chunk offsets)
     waits = [int(re.search(r"vmcnt\((\d+)\)", l).group(1)) for l in loop if "s_waitcnt vmcnt" in l]
     assert len(mfma) == 48 and len(loads) == 15, (len(mfma), len(loads))     # 3 chunks x (16 matrix instructions, 5 loads)
     assert waits and min(waits) >= 10, waits          # the oldest chunk only: two younger ones (10 loads) stay in flight
@@ -206,18 +270,18 @@ def test_wide_gemm_keeps_three_chunks_in_flight(wide_asm):
 def test_no_split_k_gemm_issues_all_its_loads_before_the_first_matrix_instruction(lgcp_asm):
     """cmcd_lgcp.hip, lgcp_nsk_kernel: 26 sixteen-byte loads per lane in flight before the first wait (the scheduler left to
     itself keeps 43 registers and pays 26 round trips); the activation instance fits two workgroups per CU without spilling."""
-    body, tail = _kernel(lgcp_asm, "_ZN4cmcd15lgcp_nsk_kernelILi0ELb0ELi1EEEvNS_7NskArgsE")
+    body, tail = _kernel_whole(lgcp_asm, "_ZN4cmcd15lgcp_nsk_kernelILi0ELb0ELi1EEEvNS_7NskArgsE")
     assert _scratch(tail) == 0
     assert _vgprs(tail) <= 128
     first = next(i for i, l in enumerate(body) if "v_mfma_f32_16x16x4_f32" in l)
     assert sum("global_load_dwordx4" in l for l in body[:first]) >= 26
     assert sum("v_mfma_f32_16x16x4_f32" in l for l in body) == 52
     # the 17 .. 20-particle form runs its extra rows on 4x4x1 against the same weight registers
-    body_m, tail_m = _kernel(lgcp_asm, "_ZN4cmcd15lgcp_nsk_kernelILi0ELb1ELi1EEEvNS_7NskArgsE")
+    body_m, tail_m = _kernel_whole(lgcp_asm, "_ZN4cmcd15lgcp_nsk_kernelILi0ELb1ELi1EEEvNS_7NskArgsE")
     assert _scratch(tail_m) == 0
     assert sum("v_mfma_f32_4x4x1_16b_f32" in l for l in body_m) == 52 and sum("v_mfma_f32_16x16x4_f32" in l for l in body_m) == 52
     # the state-update instance waits for its OWN operands first: a vmcnt >= 26 in front of the first matrix instruction
-    body_s, tail_s = _kernel(lgcp_asm, "_ZN4cmcd15lgcp_nsk_kernelILi1ELb0ELi1EEEvNS_7NskArgsE")
+    body_s, tail_s = _kernel_whole(lgcp_asm, "_ZN4cmcd15lgcp_nsk_kernelILi1ELb0ELi1EEEvNS_7NskArgsE")
     assert _scratch(tail_s) == 0
     first_s = next(i for i, l in enumerate(body_s) if "v_mfma_f32_16x16x4_f32" in l)
     pre = [int(m.group(1)) for l in body_s[:first_s] for m in [re.search(r"vmcnt\((\d+)\)", l)] if m]
