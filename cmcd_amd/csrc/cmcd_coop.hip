@@ -134,6 +134,18 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
   const int K = a.K;
 
   for (int i = threadIdx.x; i < a.w.tgt_floats; i += blockDim.x) lds_tgt[i] = a.ws[a.w.tgt + i];
+  // r05: pull the per-bridge tables (schedule rows, first-layer bias rows [+ residual rows]: one contiguous block of the
+  // workspace) into THIS XCD's L2 while the key-chain prologue runs — one touch per 128-byte line, spread over the workgroup.
+  // In the default launch sequence the prep launch has just rewritten them (every XCD's copy is gone), each row is requested
+  // only one bridge ahead (~0.4 us) and the first reader of a row on an XCD pays a trip to the fabric for all its neighbours:
+  // the trajectory kernel ran 192.6 us behind the prep launch against 179.4 us on warm tables
+  // (profiles/r05_i_headline_gaps.txt, rocprofv3 kernel trace).  The value is only kept alive until the prologue's barrier.
+  float warm = 0.f;
+  {
+    const int64_t t0 = a.w.sched;
+    const int64_t t1 = (ARCH == CMCD_ARCH_GEFFNER ? a.w.utab : a.w.bias1) + (int64_t)(K + 1) * HP;
+    for (int64_t i = t0 + 32 * (int64_t)threadIdx.x; i < t1; i += 32 * (int64_t)blockDim.x) warm += a.ws[i];
+  }
   // issue priority of this wave's role against its SIMD partner (s_setprio takes an immediate)
   switch ((a.prio >> (is_mlp ? 0 : is_tgt ? 2 : is_rng ? 4 : 6)) & 3) {
     case 1: __builtin_amdgcn_s_setprio(1); break;
@@ -263,6 +275,7 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
     }
   };
   if (is_acc) convert(1, 0);
+  asm volatile("" ::"v"(warm));   // (the table touches above: complete by now, nothing else reads them)
   lds_barrier();
 
   // z0 = mean + std * normal(A, (D,)); w = -log q(z0)      diag_gauss.py:49-62, mcdboundingmachine.py:157

@@ -174,6 +174,14 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_wide8_kernel(TrajArgs a) {
 #ifdef CMCD_STAMPS
   unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
 #endif
+  // the per-bridge tables into this XCD's L2 while the prologue runs (cmcd_coop.hip: the prep launch has just rewritten them)
+  {
+    float warm = 0.f;
+    const int64_t t0 = a.w.sched;
+    const int64_t t1 = (ARCH == CMCD_ARCH_GEFFNER ? a.w.utab : a.w.bias1) + (int64_t)(K + 1) * HP;
+    for (int64_t i = t0 + 32 * (int64_t)threadIdx.x; i < t1; i += 32 * (int64_t)blockDim.x) warm += a.ws[i];
+    asm volatile("" ::"v"(warm));
+  }
   const float clipv = a.var_mode ? 1e2f : 1e3f;
   const bool clip_p = a.grad_clipping != 0, clip_q = clip_p && a.var_mode;
   const float cp = clip_p ? clipv : INFINITY, cq = clip_q ? clipv : INFINITY;

@@ -632,6 +632,13 @@ __global__ __launch_bounds__(512, (T > 4 || D > 4) ? 2 : 4) void traj_kernel(Tra
     for (int i = threadIdx.x; i < HP; i += blockDim.x) lds_b2[i] = a.ws[a.w.b2 + i];
     for (int i = threadIdx.x; i < 16; i += blockDim.x) lds_b3[i] = a.ws[a.w.b3 + i];
     for (int i = threadIdx.x; i < a.w.tgt_floats; i += blockDim.x) lds_tgt[i] = a.ws[a.w.tgt + i];
+    // r05: the per-bridge tables (schedule, bias rows [+ residual rows], one contiguous block) into this XCD's L2, one touch per
+    // 128-byte line (cmcd_coop.hip: behind the prep launch every XCD's copy is gone and a row is requested only when it is needed)
+    float warm = 0.f;
+    const int64_t t0 = a.w.sched;
+    const int64_t t1 = (ARCH == CMCD_ARCH_GEFFNER ? a.w.utab : a.w.bias1) + (int64_t)(a.K + 1) * HP;
+    for (int64_t i = t0 + 32 * (int64_t)threadIdx.x; i < t1; i += 32 * (int64_t)blockDim.x) warm += a.ws[i];
+    asm volatile("" ::"v"(warm));
   }
   __syncthreads();
 

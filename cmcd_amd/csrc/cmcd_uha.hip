@@ -201,6 +201,13 @@ __global__ __launch_bounds__(512, (T > 4 || D > 4) ? 2 : 4) void uha_traj_kernel
     for (int i = threadIdx.x; i < HP; i += blockDim.x) lds_b2[i] = a.ws[a.w.b2 + i];
     for (int i = threadIdx.x; i < 16; i += blockDim.x) lds_b3[i] = a.ws[a.w.b3 + i];
     for (int i = threadIdx.x; i < a.w.tgt_floats; i += blockDim.x) lds_tgt[i] = a.ws[a.w.tgt + i];
+    {   // r05: the per-bridge tables into this XCD's L2, one touch per 128-byte line (cmcd_coop.hip: behind the prep launch every XCD's copy is gone)
+      float warm = 0.f;
+      const int64_t wt0 = a.w.sched;
+      const int64_t wt1 = (ARCH == CMCD_ARCH_GEFFNER ? a.w.utab : a.w.bias1) + (int64_t)(a.K + 1) * (16 * T);
+      for (int64_t wi = wt0 + 32 * (int64_t)threadIdx.x; wi < wt1; wi += 32 * (int64_t)blockDim.x) warm += a.ws[wi];
+      asm volatile("" ::"v"(warm));
+    }
   }
   __syncthreads();
 
@@ -493,6 +500,13 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
   uint32_t* keyb = reinterpret_cast<uint32_t*>(nzb + 2 * 16 * D);   // [16][2]  gen_0 handed from the state wave to the RNG wave
   float* lds_tgt = nzb + 2 * 16 * D + 32;     // tgt_floats
   for (int i = threadIdx.x; i < a.w.tgt_floats; i += blockDim.x) lds_tgt[i] = a.ws[a.w.tgt + i];
+  {   // r05: the per-bridge tables into this XCD's L2, one touch per 128-byte line (cmcd_coop.hip: behind the prep launch every XCD's copy is gone)
+      float warm = 0.f;
+      const int64_t wt0 = a.w.sched;
+      const int64_t wt1 = (ARCH == CMCD_ARCH_GEFFNER ? a.w.utab : a.w.bias1) + (int64_t)(a.K + 1) * (16 * T);
+      for (int64_t wi = wt0 + 32 * (int64_t)threadIdx.x; wi < wt1; wi += 32 * (int64_t)blockDim.x) warm += a.ws[wi];
+      asm volatile("" ::"v"(warm));
+    }
 
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
