@@ -271,9 +271,18 @@ def _layout_no_net(unflatten):
     return lay
 
 
-def bound_forward(seeds, params_flat, unflatten, params_fixed, log_prob, eps_schedule=None, grad_clipping=False):
-    """One launch sequence of the hot path.  Returns (losses[N] f32, z[N,dim] f32, stats[5] f64),
-    all device tensors, enqueued asynchronously on the current stream."""
+_plans = {}      # what one forward call needs besides its tensors, per (parameter tree, net, mode, target, flags): see _plan
+
+
+def _plan(unflatten, params_fixed, log_prob, eps_schedule, grad_clipping):
+    """The descriptor, the layout struct and their byte images for one (unflatten, params_fixed, target, static flags): built
+    once, looked up per call.  A forward call of the smallest configuration is 18 us of GPU time; building two ctypes structs,
+    their byte keys and twenty dictionary searches per call made the HOST the bound there (29 us per call, r05
+    tools/probes/host_overhead.py)."""
+    key = (id(unflatten), params_fixed, id(log_prob), eps_schedule, bool(grad_clipping), KERNEL_VARIANT)
+    plan = _plans.get(key)
+    if plan is not None and plan[0]() is unflatten and plan[1]() is log_prob:
+        return plan
     dim, nbridges, mode, spec = params_fixed
     if mode not in _SUPPORTED:
         raise NotImplementedError("Mode not implemented.")  # same text as mcd_utils.py:190
@@ -281,63 +290,104 @@ def bound_forward(seeds, params_flat, unflatten, params_fixed, log_prob, eps_sch
         spec = ScoreNet("dds", dim, 64, 0, 64)   # placeholder: MCD_ULA has no network (apply_fun_sn is None)
     elif not isinstance(spec, ScoreNet):
         raise ValueError("params_fixed[3] must be the ScoreNet returned by initialize()")
-    if eps_schedule not in _lib.EPS_SCHEDULE:
-        eps_schedule = None  # the reference falls through to constant eps (mcd_cais.py:58-59)
     if not hasattr(log_prob, "target_id"):
         raise TypeError("log_prob must be a cmcd_amd.model_handler.Target (see load_model)")
     if log_prob.dim != dim:
         raise ValueError(f"target dim {log_prob.dim} != params_fixed dim {dim}")
+    sched = eps_schedule if eps_schedule in _lib.EPS_SCHEDULE else None   # the reference falls through to constant eps (mcd_cais.py:58-59)
+    desc = _lib.Desc(dim=dim, nbridges=nbridges, mode=_lib.MODE[mode], arch=_lib.ARCH[spec.arch],
+                     emb_dim=spec.emb_dim, target=log_prob.target_id,
+                     eps_schedule=_lib.EPS_SCHEDULE[sched], grad_clipping=int(bool(grad_clipping)),
+                     ngrid=unflatten.shape("mgridref_y")[0] - 1, reserved=KERNEL_VARIANT)
+    lay = _layout(unflatten, spec) if mode != "MCD_ULA" else _layout_no_net(unflatten)
+    plan = (weakref.ref(unflatten), weakref.ref(log_prob), desc, lay, bytes(desc), bytes(lay), spec, {})
+    while len(_plans) > 256:
+        _plans.pop(next(iter(_plans)))
+    _plans[key] = plan
+    return plan
+
+
+def bound_forward(seeds, params_flat, unflatten, params_fixed, log_prob, eps_schedule=None, grad_clipping=False):
+    """One launch sequence of the hot path.  Returns (losses[N] f32, z[N,dim] f32, stats[5] f64),
+    all device tensors, enqueued asynchronously on the current stream."""
+    _, _, desc, lay, desc_b, lay_b, spec, nbytes_of = _plan(unflatten, params_fixed, log_prob, eps_schedule, grad_clipping)
     if not params_flat.is_cuda:
         raise RuntimeError("the CMCD hot path runs on a ROCm device only: params_flat is not a device tensor")
-    L = _lib.lib()
-    device = params_flat.device
     if params_flat.dtype != torch.float32 or not params_flat.is_contiguous():
         raise ValueError("params_flat must be contiguous float32")
-    seeds = torch.as_tensor(seeds)
-    if seeds.device != device or seeds.dtype != torch.int32 or not seeds.is_contiguous():
-        seeds = seeds.to(device=device, dtype=torch.int32).contiguous()
+    device = params_flat.device
+    dev_index = device.index
+    if dev_index is None or torch._C._cuda_getDevice() != dev_index:
+        # the tensor's device is not the current one: every HIP call below belongs to `device` (rare; the common case pays
+        # no context manager)
+        with torch.cuda.device(device):
+            return _bound_forward_here(seeds, params_flat, log_prob, desc, lay, desc_b, lay_b, spec, nbytes_of,
+                                       torch.cuda.current_device(), params_fixed[0])
+    return _bound_forward_here(seeds, params_flat, log_prob, desc, lay, desc_b, lay_b, spec, nbytes_of, dev_index, params_fixed[0])
+
+
+def _forward_workspace(dev_index, device, stream, capturing, nbytes):
+    """_workspace for the forward call, with the stream handle and capture status already in hand (same cache, same rules)."""
+    if capturing:
+        return torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+    per_dev = _workspaces.setdefault(dev_index, {})
+    key = (stream, "")
+    ws = per_dev.pop(key, None)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _prepared.pop((dev_index, ws.data_ptr()), None)
+    per_dev[key] = ws
+    while len(per_dev) > _WORKSPACE_CACHE:
+        per_dev.pop(next(iter(per_dev)))
+    return ws
+
+
+def _bound_forward_here(seeds, params_flat, log_prob, desc, lay, desc_b, lay_b, spec, nbytes_of, dev_index, dim):
+    """bound_forward with `params_flat.device` current."""
+    L = _lib.lib()
+    device = params_flat.device
+    if not isinstance(seeds, torch.Tensor) or seeds.device != device or seeds.dtype != torch.int32 or not seeds.is_contiguous():
+        seeds = torch.as_tensor(seeds).to(device=device, dtype=torch.int32).contiguous()
     n = seeds.numel()
     if n < 1:
         raise ValueError("seeds is empty")
-
-    desc = _lib.Desc(dim=dim, nbridges=nbridges, mode=_lib.MODE[mode], arch=_lib.ARCH[spec.arch],
-                     emb_dim=spec.emb_dim, target=log_prob.target_id,
-                     eps_schedule=_lib.EPS_SCHEDULE[eps_schedule], grad_clipping=int(bool(grad_clipping)),
-                     ngrid=unflatten.shape("mgridref_y")[0] - 1, reserved=KERNEL_VARIANT)
-    lay = _layout(unflatten, spec) if mode != "MCD_ULA" else _layout_no_net(unflatten)
-    nbytes = L.cmcd_workspace_bytes(C.byref(desc), n)
-    if nbytes <= 0:
-        _lib.check(-2 if "not implemented" in _lib.last_error() or "no kernel" in _lib.last_error() else -1)
-    ws = _workspace(device, nbytes)
+    nbytes = nbytes_of.get(n)
+    if nbytes is None:
+        nbytes = L.cmcd_workspace_bytes(C.byref(desc), n)
+        if nbytes <= 0:
+            _lib.check(-2 if "not implemented" in _lib.last_error() or "no kernel" in _lib.last_error() else -1)
+        if len(nbytes_of) < 64:
+            nbytes_of[n] = nbytes
+    stream = torch._C._cuda_getCurrentRawStream(dev_index)
+    capturing = torch._C._cuda_isCurrentStreamCapturing()
+    ws = _forward_workspace(dev_index, device, stream, capturing, nbytes)
     consts = log_prob.consts_on(device)
     losses = torch.empty(n, dtype=torch.float32, device=device)
-    z = torch.empty(n, dim, dtype=torch.float32, device=device)
+    z = torch.empty((n, dim), dtype=torch.float32, device=device)
     stats = torch.empty(_lib.NSTATS, dtype=torch.float64, device=device)
-    with torch.cuda.device(device):
-        stream = torch.cuda.current_stream().cuda_stream
-        # the tables this workspace holds: formed by the previous call from exactly these inputs?  (see _prepared)
-        # `slot` names the buffer on EVERY call — in or out of fixed_parameters(), capturing or not — because every call
-        # overwrites the buffer's tables and must therefore retire whatever claim an earlier call left on it (r04 advisor:
-        # with the slot computed inside the context only, `with fixed: f(P)`; `f(Q)`; `with fixed: f(P)` ran P on Q's tables)
-        slot = (torch.cuda.current_device(), ws.data_ptr())
-        key = None
-        if (PREP_CACHE or getattr(_fixed, "depth", 0) > 0) and not torch.cuda.is_current_stream_capturing():
-            key = (params_flat.data_ptr(), params_flat._version, params_flat.numel(), n, bytes(desc), bytes(lay), spec,
-                   None if consts is None else (consts.data_ptr(), consts._version, consts.numel()))
-        # (key, weak references to the very tensor OBJECTS the tables were formed from): an address and a version counter alone
-        # do not identify a tensor — the caching allocator hands a freed tensor's address to the next one of the same size, whose
-        # counter starts at the same value (r04: two parameter sets of one test module collided exactly so)
-        hit = False
-        ent = _prepared.get(slot) if key is not None else None
-        if ent is not None and ent[0] == key and ent[1]() is params_flat and (consts is None or ent[2]() is consts):
-            hit = True
-        fn = L.cmcd_bound_forward_prepared if hit else L.cmcd_bound_forward
-        _prepared.pop(slot, None)            # unconditionally: this launch rewrites (or, on an error, may have rewritten) the tables
-        PREP_CALLS["prepared" if fn is L.cmcd_bound_forward_prepared else "full"] += 1
-        rc = fn(
-            C.byref(desc), C.byref(lay), seeds.data_ptr(), n, params_flat.data_ptr(), params_flat.numel(),
-            consts.data_ptr() if consts is not None else None, consts.numel() if consts is not None else 0,
-            ws.data_ptr(), ws.numel(), losses.data_ptr(), z.data_ptr(), stats.data_ptr(), stream)
+    # the tables this workspace holds: formed by the previous call from exactly these inputs?  (see _prepared)
+    # `slot` names the buffer on EVERY call — in or out of fixed_parameters(), capturing or not — because every call
+    # overwrites the buffer's tables and must therefore retire whatever claim an earlier call left on it (r04 advisor:
+    # with the slot computed inside the context only, `with fixed: f(P)`; `f(Q)`; `with fixed: f(P)` ran P on Q's tables)
+    slot = (dev_index, ws.data_ptr())
+    key = None
+    if (PREP_CACHE or getattr(_fixed, "depth", 0) > 0) and not capturing:
+        key = (params_flat.data_ptr(), params_flat._version, params_flat.numel(), n, desc_b, lay_b, spec,
+               None if consts is None else (consts.data_ptr(), consts._version, consts.numel()))
+    # (key, weak references to the very tensor OBJECTS the tables were formed from): an address and a version counter alone
+    # do not identify a tensor — the caching allocator hands a freed tensor's address to the next one of the same size, whose
+    # counter starts at the same value (r04: two parameter sets of one test module collided exactly so)
+    hit = False
+    ent = _prepared.get(slot) if key is not None else None
+    if ent is not None and ent[0] == key and ent[1]() is params_flat and (consts is None or ent[2]() is consts):
+        hit = True
+    fn = L.cmcd_bound_forward_prepared if hit else L.cmcd_bound_forward
+    _prepared.pop(slot, None)            # unconditionally: this launch rewrites (or, on an error, may have rewritten) the tables
+    PREP_CALLS["prepared" if hit else "full"] += 1
+    rc = fn(
+        C.byref(desc), C.byref(lay), seeds.data_ptr(), n, params_flat.data_ptr(), params_flat.numel(),
+        consts.data_ptr() if consts is not None else None, consts.numel() if consts is not None else 0,
+        ws.data_ptr(), ws.numel(), losses.data_ptr(), z.data_ptr(), stats.data_ptr(), stream)
     _lib.check(rc)
     if key is not None:
         _prepared[slot] = (key, weakref.ref(params_flat), weakref.ref(consts) if consts is not None else None)
