@@ -140,11 +140,15 @@ __global__ __launch_bounds__(64 * (T + (MERGE ? 3 : 4))) void coop_kernel(TrajAr
   // only one bridge ahead (~0.4 us) and the first reader of a row on an XCD pays a trip to the fabric for all its neighbours:
   // the trajectory kernel ran 192.6 us behind the prep launch against 179.4 us on warm tables
   // (profiles/r05_i_headline_gaps.txt, rocprofv3 kernel trace).  The value is only kept alive until the prologue's barrier.
+  // The lines are dealt to the workgroups that share an XCD (round-robin dispatch: workgroup b runs on XCD b % 8, its rank there
+  // is b / 8): a workgroup of the named grid touches 18 lines, not 578 (touching all of them in every workgroup cost the kernel
+  // 2 us on warm tables).
   float warm = 0.f;
   {
     const int64_t t0 = a.w.sched;
     const int64_t t1 = (ARCH == CMCD_ARCH_GEFFNER ? a.w.utab : a.w.bias1) + (int64_t)(K + 1) * HP;
-    for (int64_t i = t0 + 32 * (int64_t)threadIdx.x; i < t1; i += 32 * (int64_t)blockDim.x) warm += a.ws[i];
+    const int64_t per_xcd = (gridDim.x + 7) >> 3, rank = blockIdx.x >> 3;
+    for (int64_t i = t0 + 32 * (rank * blockDim.x + threadIdx.x); i < t1; i += 32 * per_xcd * blockDim.x) warm += a.ws[i];
   }
   // issue priority of this wave's role against its SIMD partner (s_setprio takes an immediate)
   switch ((a.prio >> (is_mlp ? 0 : is_tgt ? 2 : is_rng ? 4 : 6)) & 3) {

@@ -179,7 +179,8 @@ __global__ __launch_bounds__(64 * (T + 4)) void coop_wide8_kernel(TrajArgs a) {
     float warm = 0.f;
     const int64_t t0 = a.w.sched;
     const int64_t t1 = (ARCH == CMCD_ARCH_GEFFNER ? a.w.utab : a.w.bias1) + (int64_t)(K + 1) * HP;
-    for (int64_t i = t0 + 32 * (int64_t)threadIdx.x; i < t1; i += 32 * (int64_t)blockDim.x) warm += a.ws[i];
+    const int64_t per_xcd = (gridDim.x + 7) >> 3, rank = blockIdx.x >> 3;     // dealt to the workgroups that share an XCD
+    for (int64_t i = t0 + 32 * (rank * blockDim.x + threadIdx.x); i < t1; i += 32 * per_xcd * blockDim.x) warm += a.ws[i];
     asm volatile("" ::"v"(warm));
   }
   const float clipv = a.var_mode ? 1e2f : 1e3f;

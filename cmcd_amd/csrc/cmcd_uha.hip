@@ -205,7 +205,8 @@ __global__ __launch_bounds__(512, (T > 4 || D > 4) ? 2 : 4) void uha_traj_kernel
       float warm = 0.f;
       const int64_t wt0 = a.w.sched;
       const int64_t wt1 = (ARCH == CMCD_ARCH_GEFFNER ? a.w.utab : a.w.bias1) + (int64_t)(a.K + 1) * (16 * T);
-      for (int64_t wi = wt0 + 32 * (int64_t)threadIdx.x; wi < wt1; wi += 32 * (int64_t)blockDim.x) warm += a.ws[wi];
+      const int64_t per_xcd = (gridDim.x + 7) >> 3, rank = blockIdx.x >> 3;     // dealt to the workgroups that share an XCD
+      for (int64_t wi = wt0 + 32 * (rank * blockDim.x + threadIdx.x); wi < wt1; wi += 32 * per_xcd * blockDim.x) warm += a.ws[wi];
       asm volatile("" ::"v"(warm));
     }
   }
@@ -504,7 +505,8 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
       float warm = 0.f;
       const int64_t wt0 = a.w.sched;
       const int64_t wt1 = (ARCH == CMCD_ARCH_GEFFNER ? a.w.utab : a.w.bias1) + (int64_t)(a.K + 1) * (16 * T);
-      for (int64_t wi = wt0 + 32 * (int64_t)threadIdx.x; wi < wt1; wi += 32 * (int64_t)blockDim.x) warm += a.ws[wi];
+      const int64_t per_xcd = (gridDim.x + 7) >> 3, rank = blockIdx.x >> 3;     // dealt to the workgroups that share an XCD
+      for (int64_t wi = wt0 + 32 * (rank * blockDim.x + threadIdx.x); wi < wt1; wi += 32 * per_xcd * blockDim.x) warm += a.ws[wi];
       asm volatile("" ::"v"(warm));
     }
 
