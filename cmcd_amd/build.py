@@ -78,6 +78,40 @@ def build(force=False, verbose=False):
     return LIB
 
 
+BOUNDARY_LIB = os.path.join(HERE, "libcmcd_hip_boundary.so")
+HOOK_SOURCES = ("cmcd_kernels.hip", "cmcd_coop.hip", "cmcd_uha.hip")     # the translation units that define hooks of cmcd_hip_diag.h
+
+
+def build_boundary_only(force=False):
+    """libcmcd_hip_boundary.so: the same library with the measurement / diagnostic hooks compiled out (-DCMCD_NO_DIAG_HOOKS) —
+    its export list is include/cmcd_hip.h only.  Only the three sources that define hooks are recompiled; the other objects are
+    the product build's.  Load it with CMCD_LIB_PATH (tests/test_gpu_fullsize.py runs the boundary and bench.py on it)."""
+    build()
+    srcs = [os.path.join(CSRC, s) for s in HOOK_SOURCES]
+    if not force and os.path.exists(BOUNDARY_LIB) and \
+            not any(os.path.getmtime(d) > os.path.getmtime(BOUNDARY_LIB) for d in _deps() + srcs + [LIB]):
+        return BOUNDARY_LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DCMCD_NO_DIAG_HOOKS",
+              "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-Wno-format-security"]
+
+    def compile_one(src):
+        out = os.path.join(OBJ, src.replace(".hip", ".boundary.o"))
+        subprocess.run(common + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", out], check=True)
+        return out
+
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        special = dict(zip(HOOK_SOURCES, ex.map(compile_one, HOOK_SOURCES)))
+    objs = [special.get(s, _obj(s)) for s in SOURCES]
+    missing = [o for o in objs if not os.path.exists(o)]
+    if missing:      # the product library was current but its objects are gone (a fresh checkout of a built tree): rebuild them
+        build(force=True)
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", BOUNDARY_LIB] + objs, check=True)
+    return BOUNDARY_LIB
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose="-v" in sys.argv)
     print(LIB)
+    if "--boundary" in sys.argv:
+        print(build_boundary_only(force="--force" in sys.argv))

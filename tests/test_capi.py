@@ -35,6 +35,19 @@ def test_exports_every_declared_symbol(hip_lib):
     assert hip_lib.cmcd_version() == 3
 
 
+def test_boundary_library_exports_exactly_the_boundary_header():
+    """cmcd_amd/libcmcd_hip_boundary.so (built by __graft_entry__.build() / `python -m cmcd_amd.build --boundary`): its dynamic
+    export list IS include/cmcd_hip.h — every declared function, nothing else of the library's own."""
+    import subprocess
+    from cmcd_amd import build
+    if not os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not installed")
+    lib = build.build_boundary_only()
+    out = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l and l.split()[-1].startswith("cmcd_")}
+    assert exported == set(declared_functions()), exported ^ set(declared_functions())
+
+
 def test_boundary_only_build_exports_no_hooks(tmp_path):
     """-DCMCD_NO_DIAG_HOOKS (CMCD_DIAG_HOOKS=0 python -m cmcd_amd.build): every symbol of the hooks' header is gone from the three
     translation units that define them, every boundary symbol they define is still there (checked on the objects: no link, no GPU)."""

@@ -385,6 +385,46 @@ def test_the_prepared_entry_point_refuses_tables_of_another_call(hip_lib, name, 
     assert torch.equal(s4, s0)
 
 
+def test_the_boundary_only_library_runs_the_path_and_the_bench(hip_lib):
+    """cmcd_amd/libcmcd_hip_boundary.so (-DCMCD_NO_DIAG_HOOKS, built by __graft_entry__.build()): no measurement / diagnostic
+    export, and the Python boundary and bench.py run on it — same losses, bit for bit, as the in-tree library; bench.py's
+    kernel time falls back to the wall time per step."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from cmcd_amd import build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = build.build_boundary_only()
+    code = (
+        "import sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from cmcd_amd import _lib, synthetic\n"
+        "from cmcd_amd import mcdboundingmachine as mcdbm\n"
+        "b = synthetic.build('gmm_n300_k8', device='cuda')\n"
+        "seeds = torch.from_numpy(synthetic.parity_seeds(300)).cuda()\n"
+        "l, z, st = mcdbm.bound_forward(seeds, b['params_flat'], b['unflatten'], b['params_fixed'], b['target'],\n"
+        "                               eps_schedule=b['eps_schedule'], grad_clipping=b['grad_clipping'])\n"
+        "torch.cuda.synchronize()\n"
+        "L = _lib.lib()\n"
+        "print('HAS_DIAG', _lib.HAS_DIAG, hasattr(L, 'cmcd_profile_enable'), hasattr(L, 'cmcd_debug_capture_noise'), hasattr(L, 'cmcd_bound_forward'))\n"
+        "print('SUM', repr(float(l.double().sum())), repr(float(z.double().sum())))\n")
+    env = dict(os.environ, CMCD_LIB_PATH=lib)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "HAS_DIAG False False False True" in out.stdout, out.stdout
+    b = synthetic.build("gmm_n300_k8", device="cuda")
+    l, z, _ = _fwd(b, synthetic.parity_seeds(300))
+    want = f"SUM {float(l.double().sum())!r} {float(z.double().sum())!r}"
+    assert want in out.stdout, (want, out.stdout)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "gmm_n300_k8", "--steps", "5", "--warmup", "2",
+                          "--no-cpu-baseline", "--saturated", "0", "--no-legs"], capture_output=True, text=True, timeout=600,
+                         cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert r["value"] > 0 and r["roofline"]["kernel"] == "" and r["roofline"]["kernel_ms"] == pytest.approx(r["ms_per_step"], rel=0.35)
+
+
 def test_a_captured_forward_keeps_its_prep_launch(hip_lib, monkeypatch):
     """A forward call captured into a HIP graph must carry its prep launch (the prepared-table shortcut is refused while a
     stream is capturing): replays after an in-place parameter update have to see the new parameters."""
