@@ -472,15 +472,82 @@ __device__ __forceinline__ void tf_part2(TfState& t) {
 }
 #undef UHA_TF_ROUND
 
+// The launch's first draws on the columns layout of the state wave (g = row, c = column): (A, B) = split(PRNGKey(seed)),
+// z_0 = mean + std normal(A), then the two further splits that give rho_0 = normal(R) and the chain's first key gen_0
+// (mcd_under_lp_a_cais.py: the prologue of the bound) — every lane ends with all d coordinates of its particle.
+template <int D>
+__device__ __forceinline__ void uha_first_draws(const TrajArgs& a, int64_t p, bool valid, int g, int gb,
+                                                const float (&qmean)[D], const float (&qstd)[D], float (&z)[D],
+                                                float (&rho)[D], uint32_t& k0, uint32_t& k1) {
+  constexpr int Hh = (D + 1) / 2;
+  const int32_t seed = a.seeds[valid ? p : a.n - 1];
+  k0 = 0u; k1 = (uint32_t)seed;
+  uint32_t x0 = gb, x1 = 2 + gb;
+  threefry2x32(k0, k1, x0, x1);
+  uint32_t a0, a1, b0, b1;
+  rows01(x0, a0, a1);
+  rows01(x1, b0, b1);
+  float nz[2 * Hh];
+  draw_normal<D>(a0, a1, g, nz, a, 0, p, valid);
+#pragma unroll
+  for (int j = 0; j < D; ++j) z[j] = qstd[j] * nz[j] + qmean[j];
+  x0 = gb; x1 = 2 + gb;
+  threefry2x32(b0, b1, x0, x1);
+  uint32_t c0, c1;
+  rows01(x0, c0, c1);
+  x0 = gb; x1 = 2 + gb;
+  threefry2x32(c0, c1, x0, x1);
+  uint32_t r0, r1, p0, p1;
+  rows01(x0, r0, r1);
+  rows01(x1, p0, p1);
+  draw_normal<D>(r0, r1, g, nz, a, 1, p, valid);
+#pragma unroll
+  for (int j = 0; j < D; ++j) rho[j] = nz[j];
+  x0 = gb; x1 = 2 + gb;
+  threefry2x32(p0, p1, x0, x1);
+  rows01(x1, k0, k1);
+}
+
+// waves of one uha_coop_kernel workgroup: T MLP + state + RNG; the funnel on 8-particle tiles deals its state over TWO waves
+// (16 lanes per particle, lane = coordinate)
+constexpr bool uha_coop_dealt(int target, bool half) { return half && target == CMCD_TARGET_FUNNEL; }
+constexpr int uha_coop_waves(int target, int T, bool half, bool tail = false) {
+  return T - (tail ? 1 : 0) + 2 + (uha_coop_dealt(target, half) ? 1 : 0);
+}
+// TAIL (r05): the last tile of the padded width holds at most 4 real neurons (the funnel's geffner net: 2 x 10 + 48 = 68 of
+// 80) — a whole MLP wave for them doubled up with another MLP wave on one SIMD and was the pole of both matrix intervals
+// (profiles/r05_uha_funnel_stamps_dealt.txt: 1 728 / 1 932 cycles against 1 140 / 1 240 for a wave with a SIMD of its own).
+// With TAIL the workgroup runs T - 1 MLP waves and the last of them takes the 4 neurons along: one more 4x4x1 pass whose 16
+// blocks are 2 particle groups x 8 contraction slices (the slices ARE the activations the lane already fetched for its own
+// tile: no further LDS reads), a reduce-scatter over the 8 slices, one more activation per lane.
+__host__ __device__ constexpr bool uha_coop_tail_fits(int T, int real_width) { return T >= 2 && real_width <= 16 * (T - 1) + 4; }
+
+// reduce-scatter over the four rows of the wave (cmcd_coop_wide.hip has the same pair):
+//   uha_rs32(a, b): rows 0, 1 <- a(row r) + a(row r + 2);  rows 2, 3 <- b(row r - 2) + b(row r)
+//   uha_rs16(p, q): rows 0, 2 <- p(row r) + p(row r + 1);  rows 1, 3 <- q(row r - 1) + q(row r)
+__device__ __forceinline__ float uha_rs32(float x, float y) {
+  uint32_t r0, r1;
+  swap32(__float_as_uint(x), __float_as_uint(y), r0, r1);
+  return __uint_as_float(r0) + __uint_as_float(r1);
+}
+__device__ __forceinline__ float uha_rs16(float x, float y) {
+  uint32_t r0, r1;
+  swap16(__float_as_uint(x), __float_as_uint(y), r0, r1);
+  return __uint_as_float(r0) + __uint_as_float(r1);
+}
+
 // HALF: 8 particles per tile (batches of <= 2048 particles: twice the workgroups, on CUs that would otherwise idle).  The
 // state and RNG waves keep 16 columns — columns c and c + 8 carry the SAME particle (same seed: identical values in both)
 // — so a particle has 8 lanes for its target gradient; the MLP waves give every particle 8 lanes instead of 4 (lane (qi,
 // pg, kh, ng) = particle 4 pg + qi, neurons 4 ng + 2 kh + {0, 1} of the wave's 16) and run layer 2 on `4x4x1` (16 blocks of
 // 4 neurons x 4 particles, the activations broadcast from one 16-lane row by the instruction): half the matrix time and
 // half the element-wise work per lane — the overdamped kernel's form (cmcd_coop.hip), same operand table (w2q).
-template <int TARGET, int ARCH, int D, int T, bool HALF>
-__global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
+template <int TARGET, int ARCH, int D, int T, bool HALF, bool TAIL = false>
+__global__ __launch_bounds__(64 * uha_coop_waves(TARGET, T, HALF, TAIL)) void uha_coop_kernel(TrajArgs a) {
   constexpr int HP = 16 * T;
+  constexpr bool DEALT = uha_coop_dealt(TARGET, HALF);
+  static_assert(!TAIL || DEALT, "the 4-neuron tail rides on the dealt form");
+  constexpr int TM = TAIL ? T - 1 : T;        // MLP waves
   constexpr int DIN = 2 * D;
   constexpr int Hh = (D + 1) / 2;
   constexpr int PPT = HALF ? 8 : 16;          // particles per tile
@@ -501,6 +568,8 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
   uint32_t* keyb = reinterpret_cast<uint32_t*>(nzb + 2 * 16 * D);   // [16][2]  gen_0 handed from the state wave to the RNG wave
   float* lds_tgt = nzb + 2 * 16 * D + 32;     // tgt_floats
   for (int i = threadIdx.x; i < a.w.tgt_floats; i += blockDim.x) lds_tgt[i] = a.ws[a.w.tgt + i];
+  if constexpr (TAIL)                         // the pad neurons of the last tile are never written: zero weights, finite activations
+    for (int i = threadIdx.x; i < 8 * HQP + 32; i += blockDim.x) hbuf[i] = 0.f;   // (+ 16 zeros the tail's idle slices read)
   {   // r05: the per-bridge tables into this XCD's L2, one touch per 128-byte line (cmcd_coop.hip: behind the prep launch every XCD's copy is gone)
       float warm = 0.f;
       const int64_t wt0 = a.w.sched;
@@ -534,10 +603,12 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
 #endif
 
   // =========================================================================================== MLP waves
-  if (wv < T) {
+  if (wv < TM) {
     if constexpr (HALF) {
       const int ng = g, kh = (lane >> 3) & 1;
       const int nb = 16 * wv + 4 * ng + 2 * kh;        // first of this lane's two hidden units
+      const bool tail = TAIL && wv == TM - 1;          // wave-uniform: this wave takes the last tile's 4 neurons along
+      constexpr int NX = 16 * TM;                      // first neuron of the tail (lane: neuron NX + ng)
       float w1[DIN][2], w3[D][2], aq[NQ], b2p[2];
 #pragma unroll
       for (int j = 0; j < DIN; ++j)
@@ -551,25 +622,52 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
       for (int q = 0; q < NQ; ++q) aq[q] = a.ws[a.w.w2q + (int64_t)(wv * NQ + q) * 64 + lane];
 #pragma unroll
       for (int r = 0; r < 2; ++r) b2p[r] = a.ws[a.w.b2 + nb + r];
+      // tail: W1 column, W3 row (on the kh = 0 lane of the pair only: both hold the neuron), bias, and the A operands of
+      // the slice this lane already fetches for its own tile — inputs 40 kh + RSA ng + t, the table's rows of tile TM
+      float w1x[TAIL ? DIN : 1], w3x[TAIL ? D : 1], aqx[TAIL ? RSA : 1], b2x = 0.f;
+      if constexpr (TAIL) {
+#pragma unroll
+        for (int j = 0; j < DIN; ++j) w1x[j] = tail ? a.ws[a.w.w1z + j * HP + NX + ng] : 0.f;
+#pragma unroll
+        for (int j = 0; j < D; ++j) w3x[j] = (tail && kh == 0) ? a.ws[a.w.w3t + j * HP + NX + ng] : 0.f;
+#pragma unroll
+        for (int t = 0; t < RSA; ++t)
+          aqx[t] = (tail && RSA * ng + t < NQ) ? a.ws[a.w.w2q + (int64_t)(TM * NQ + RSA * ng + t) * 64 + (lane & 15)] : 0.f;
+        b2x = tail ? a.ws[a.w.b2 + NX + ng] : 0.f;
+      }
       const float* bias1 = a.ws + a.w.bias1;
       const float* utab = a.ws + a.w.utab;
       float2 brow_n = *reinterpret_cast<const float2*>(bias1 + nb), urow_n = {0.f, 0.f};
       if (GEF) urow_n = *reinterpret_cast<const float2*>(utab + nb);
+      float brx_n = 0.f, urx_n = 0.f;
+      if (tail) { brx_n = bias1[NX + ng]; if (GEF) urx_n = utab[NX + ng]; }
       float* const my_h = hbuf + cp * HQP + nb;
       const float* const rd_h = hbuf + cp * HQP + (HP / 2) * kh + RSA * ng;
+      // row 3's slice has NQ - 3 RSA real inputs; what it fetches beyond them belongs to the NEXT particle (unused by the
+      // broadcast passes).  The tail multiplies those slots by zero weights — they must not be another particle's inf / nan:
+      const float* const rd_h2 = (TAIL && RSA * ng + 4 >= NQ) ? hbuf + 8 * HQP + 16 - 4 : rd_h;
+      static_assert(!TAIL || NQ - 3 * RSA == 4, "row 3 of the tail keeps one quad of real inputs");
+      // layer-3 partials leave the wave reduce-scattered (d > 2): lane (kh, ng) ends with outputs j0 and j0 + 8
+      const int j0 = 4 * (ng & 1) + 2 * (ng >> 1) + kh;
+      float* const my_p = part + (wv * 16 + cp) * D + j0;
       uha_lds_barrier();                             // gen_0 and the first network input published
       uha_lds_barrier();                             // deviates of bridge 0 published
       USTAMP_START();
       for (int i = 0; i < K; ++i) {
         const float2 brow = brow_n, urow = urow_n;
+        const float brx = brx_n, urx = urx_n;
         if (i + 1 < K) {
           brow_n = *reinterpret_cast<const float2*>(bias1 + (int64_t)(i + 1) * HP + nb);
           if (GEF) urow_n = *reinterpret_cast<const float2*>(utab + (int64_t)(i + 1) * HP + nb);
+          if (tail) {
+            brx_n = bias1[(int64_t)(i + 1) * HP + NX + ng];
+            if (GEF) urx_n = utab[(int64_t)(i + 1) * HP + NX + ng];
+          }
         }
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
           // -------------------------------------------------------------- interval 1
-          float h[2];
+          float h[2], hx = 0.f;
           {
             float x[DIN];
 #pragma unroll
@@ -590,6 +688,15 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
               }
             }
             *reinterpret_cast<float2*>(my_h) = float2{h[0], h[1]};
+            if constexpr (TAIL) {
+              if (tail) {
+                float px = brx;
+#pragma unroll
+                for (int j = 0; j < DIN; ++j) px = fmaf(x[j], w1x[j], px);
+                hx = GEF ? urx + softplus(px) : gelu_fast(px);     // (NX >= 2 D: u comes from the table)
+                hbuf[cp * HQP + NX + ng] = hx;
+              }
+            }
           }
           USTAMP(pass * 6 + 0);
           uha_lds_barrier();
@@ -599,7 +706,7 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             f32x4 hb[RSA / 4];
 #pragma unroll
-            for (int q = 0; q < RSA / 4; ++q) hb[q] = *reinterpret_cast<const f32x4*>(rd_h + 4 * q);
+            for (int q = 0; q < RSA / 4; ++q) hb[q] = *reinterpret_cast<const f32x4*>((q == 0 ? rd_h : rd_h2) + 4 * q);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int sq = 0; sq < NQ; ++sq) {
@@ -611,6 +718,24 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
               else if (row == 2) ac = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[sq], bv, ac, 0, 0, 6);
               else ac = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[sq], bv, ac, 0, 0, 7);
             }
+            float h2x = 0.f;
+            if constexpr (TAIL) {
+              if (tail) {                              // the tail's 4 neurons: every block its own slice, no broadcast
+                f32x4 ax = {0.f, 0.f, 0.f, 0.f}, ax1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < RSA; ++t) {
+                  f32x4& ac = (t & 1) ? ax1 : ax;
+                  ac = __builtin_amdgcn_mfma_f32_4x4x1f32(aqx[t], hb[t / 4][t % 4], ac, 0, 0, 0);
+                }
+                ax += ax1;
+                // 8 slices (kh, ng) -> neuron ng on every lane of the row: rows first, then the two halves of the row
+                const float u01 = uha_rs16(ax[0], ax[1]), u23 = uha_rs16(ax[2], ax[3]);
+                float avx = uha_rs32(u01, u23);
+                avx += xor8(avx);
+                avx += b2x;
+                h2x = GEF ? hx + softplus(avx) : gelu_fast(avx);
+              }
+            }
             acc += acc1;
             // the two halves of the contraction sit in lanes l and l ^ 8; lane kh keeps neurons 2 kh + {0, 1} of its group
             float av[2], h2[2];
@@ -618,14 +743,43 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
             av[1] = ((kh ? acc[3] : acc[1]) + xor8(kh ? acc[1] : acc[3])) + b2p[1];
 #pragma unroll
             for (int r = 0; r < 2; ++r) h2[r] = GEF ? h[r] + softplus(av[r]) : gelu_fast(av[r]);
-            // outputs in pairs (j, j + 1): lane kh = 0 collects both halves of output j, lane kh = 1 both of output j + 1
+            if constexpr (D <= 2) {
+              // outputs in pairs (j, j + 1): lane kh = 0 collects both halves of output j, lane kh = 1 both of output j + 1
 #pragma unroll
-            for (int j = 0; j < D; j += 2) {
-              const float p0 = h2[0] * w3[j][0] + h2[1] * w3[j][1];
-              const float p1 = h2[0] * w3[j + 1][0] + h2[1] * w3[j + 1][1];
-              float pj = (kh ? p1 : p0) + xor8(kh ? p0 : p1);
-              pj = group_sum(pj);
-              if (ng == 0) part[(wv * 16 + cp) * D + j + kh] = pj;
+              for (int j = 0; j < D; j += 2) {
+                const float p0 = h2[0] * w3[j][0] + h2[1] * w3[j][1];
+                const float p1 = h2[0] * w3[j + 1][0] + h2[1] * w3[j + 1][1];
+                float pj = (kh ? p1 : p0) + xor8(kh ? p0 : p1);
+                pj = group_sum(pj);
+                if (ng == 0) part[(wv * 16 + cp) * D + j + kh] = pj;
+              }
+            } else {
+              // r05: a reduce-scatter instead of d / 2 full reductions — the pairs first (lane kh keeps output 2 m + kh),
+              // then the row pairs (rows 0, 1 keep m even, rows 2, 3 m odd), then the rows (even rows keep the lower of their
+              // two): lane (kh, ng) ends with outputs j0 = 4 (ng & 1) + 2 (ng >> 1) + kh and j0 + 8
+              static_assert(D <= 16, "two values per lane after the reduce-scatter");
+              constexpr int M = D / 2, M2 = (M + 1) / 2;
+              float pj[D];
+#pragma unroll
+              for (int j = 0; j < D; ++j) pj[j] = h2[0] * w3[j][0] + h2[1] * w3[j][1];
+              if constexpr (TAIL) {
+                if (tail) {
+#pragma unroll
+                  for (int j = 0; j < D; ++j) pj[j] = fmaf(h2x, w3x[j], pj[j]);
+                }
+              }
+              float qm[2 * M2], rm[4];
+#pragma unroll
+              for (int m = 0; m < 2 * M2; ++m)
+                qm[m] = m < M ? (kh ? pj[2 * m + 1] : pj[2 * m]) + xor8(kh ? pj[2 * m] : pj[2 * m + 1]) : 0.f;
+#pragma unroll
+              for (int ii = 0; ii < 4; ++ii) rm[ii] = ii < M2 ? uha_rs32(qm[2 * ii], qm[2 * ii + 1]) : 0.f;
+              const float t0 = uha_rs16(rm[0], rm[1]);
+              my_p[0] = t0;
+              if constexpr (D > 8) {
+                const float t1 = uha_rs16(rm[2], rm[3]);
+                if (j0 + 8 < D) my_p[8] = t1;
+              }
             }
           }
           USTAMP(pass * 6 + 2);
@@ -638,6 +792,7 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
         }
       }
       USTAMP_END();
+      if constexpr (DEALT) uha_lds_barrier();          // the state waves' hand-over of the tile's losses
       return;
     }
     float w1[DIN][4], w3[D][4];
@@ -738,7 +893,7 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
   }
 
   // =========================================================================================== RNG wave
-  if (wv == T + 1) {
+  if (wv == TM + 1) {
     uha_lds_barrier();                               // gen_0 published
     uint32_t k0 = keyb[2 * c], k1 = keyb[2 * c + 1];
     uint32_t sg0 = 0, sg1 = 0, sh0 = 0, sh1 = 0;     // (G, H) = split(gen)
@@ -785,8 +940,13 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
         if (g >= 2 && g - 2 < D) put(ib, g - 2, r0);
       } else if (g >= 2) {
         const int j = g - 2;
-        put(ib, j, bb0);
-        if (Hh + j < D) put(ib, Hh + j, bb1);
+        if constexpr (HALF) {                        // r05: the twin columns hold the same two words — one conversion each
+          const int idx = c >= 8 ? Hh + j : j;
+          if (idx < D) put(ib, idx, c >= 8 ? bb1 : bb0);
+        } else {
+          put(ib, j, bb0);
+          if (Hh + j < D) put(ib, Hh + j, bb1);
+        }
       }
     };
     auto pass_c1 = [&]() {                           // C: blocks 2 .. 5 of normal(G) on rows 0 .. 3
@@ -797,8 +957,13 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
     auto publish_c = [&](int ib) {
       const int j = 2 + g;
       if (j < Hh) {
-        put(ib, j, cb0);
-        if (Hh + j < D) put(ib, Hh + j, cb1);
+        if constexpr (HALF) {
+          const int idx = c >= 8 ? Hh + j : j;
+          if (idx < D) put(ib, idx, c >= 8 ? cb1 : cb0);
+        } else {
+          put(ib, j, cb0);
+          if (Hh + j < D) put(ib, Hh + j, cb1);
+        }
       }
     };
     pass_a();
@@ -827,6 +992,185 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
       USTAMP(8); uha_lds_barrier(); USTAMP(9);
     }
     USTAMP_END();
+    if constexpr (DEALT) uha_lds_barrier();
+    return;
+  }
+
+  // =========================================================================================== state waves, dealt (funnel, 8-particle tiles)
+  // r05: the columns layout below keeps all d coordinates of a particle in each of its 8 lanes — for d = 10 the two
+  // readings of the network output (5 waves x 10 partials per lane) and the ten-fold element-wise step made this wave the
+  // pole of pass 0's first interval and of the combine (profiles/r05_uha_funnel_stamps_before.txt: 1 202 and 980 of 6 700
+  // cycles per bridge, every MLP wave waiting).  Here a particle has 16 lanes on one of TWO waves and lane `sub` owns
+  // coordinate `sub` (the overdamped funnel's layout, cmcd_coop_wide.hip): one partial per MLP wave, one deviate, one step;
+  // the log-weight is kept as a per-coordinate share and summed over the coordinates once, at the end.  The funnel's
+  // gradient needs z_0 and the sum of squares of the rest: two 16-lane sums per point.
+  if constexpr (DEALT) {
+    float* tz = a.traj;
+    float* trho = a.traj ? a.traj + (int64_t)(K + 1) * a.n * D : nullptr;
+    float* trhop = a.traj ? a.traj + (int64_t)(2 * K + 2) * a.n * D : nullptr;
+    if (wv == TM) {                                   // the first draws, once, on the columns layout (all 8 particles)
+      float qmean[D], qstd[D], z[D], rho[D];
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        qmean[j] = a.params[a.lay.vd_mean + j];
+        qstd[j] = expf(a.params[a.lay.vd_logdiag + j]);
+      }
+      uint32_t k0, k1;
+      uha_first_draws<D>(a, p, valid, g, gb, qmean, qstd, z, rho, k0, k1);
+      if (g == 0) { keyb[2 * c] = k0; keyb[2 * c + 1] = k1; }
+      if (a.dbg_keys && valid && own) {
+        a.dbg_keys[p * 2] = k0;
+        a.dbg_keys[p * 2 + 1] = k1;
+      }
+      if (a.traj && valid && own) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          tz[p * D + j] = z[j];
+          trho[p * D + j] = rho[j];
+        }
+      }
+      if (own) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) { xin[cp * DIN + j] = z[j]; xin[cp * DIN + D + j] = rho[j]; }
+      }
+    }
+    uha_lds_barrier();                               // gen_0 and the first network input published
+    const int c4 = lane & 3, sub = lane >> 2;        // 4 particles per wave, 16 lanes each (part_sum<16>'s lanes)
+    const int pc = 4 * (wv == TM ? 0 : 1) + c4;
+    const int64_t pd = tile * 8 + pc;
+    const bool vld = pd < a.n;
+    const int j = sub < D ? sub : 0;                 // lanes sub >= d idle along on coordinate 0 and publish nothing
+    const bool act = sub < D;
+    const bool keepd = a.traj && vld && act;
+    const float qm = a.params[a.lay.vd_mean + j];
+    const float qs = expf(a.params[a.lay.vd_logdiag + j]);
+    const float qiv = 1.0f / (qs * qs);
+    const float gamma = a.params[a.lay.gamma];
+    const float factor = a.ws[a.w.b3 + 15], b3j = a.ws[a.w.b3 + j];
+    float zj = xin[pc * DIN + j], rj = xin[pc * DIN + D + j];
+    float wl;                                        // this coordinate's share of w
+    {
+      const float dz = zj - qm;
+      wl = (dz * dz) / (2.0f * qs * qs) + logf(qs) + kHalfLog2Pi;     // -log q(z_0)
+      wl += (rj * rj) * 0.5f + kHalfLog2Pi;                           // -log N(rho_0; 0, I)
+    }
+    // funnel (/root/reference/src/model_handler.py:124-143; Target<CMCD_TARGET_FUNNEL>::eval, cmcd_device.h):
+    float v = 0.f, ss = 0.f, gp = 0.f, gq = 0.f, lp = 0.f;
+    auto dist = [&]() {
+      v = part_sum<16>(sub == 0 ? zj : 0.f);
+      ss = part_sum<16>((act && j >= 1) ? zj * zj : 0.f);
+    };
+    auto grad = [&]() {
+      const float emv = __builtin_amdgcn_exp2f(-1.44269504088896340736f * v);
+      constexpr float c0 = -0.5f * kLog2Pi - 1.0986122886681098f, c1 = -0.5f * (D - 1) * kLog2Pi;
+      const float hes = 0.5f * emv * ss;
+      const float g0 = fmaf(v, -1.0f / 9.0f, hes - 0.5f * (D - 1));
+      gp = __builtin_amdgcn_fmed3f(j == 0 ? g0 : -zj * emv, -1e2f, 1e2f);
+      lp = fmaf(v * v, -1.0f / 18.0f, c0 + c1) - 0.5f * (D - 1) * v - hes;
+    };
+    dist();
+    grad();
+    gq = -(zj - qm) * qiv;
+    struct Sc { float beta, eps, eta, sig, inv2s2, cst, ome; };
+    auto scalars = [&](float beta, float eps) {
+      Sc q;
+      q.beta = beta; q.eps = eps;
+      q.eta = gamma * eps; q.sig = sqrtf(2.0f * q.eta);
+      q.inv2s2 = 1.0f / (2.0f * q.sig * q.sig); q.cst = logf(q.sig) + kHalfLog2Pi; q.ome = 1.0f - q.eta;
+      return q;
+    };
+    Sc sc_n = scalars(a.ws[a.w.beta], a.ws[a.w.eps]);
+    float cl_rome = 0.f, cl_rho = 0.f, cl_eta = 0.f, cl_inv2s2 = 0.f, cl_cst = 0.f, cl_fk = 0.f;
+    const float* const rd_p = part + pc * D + j;
+    auto net_out = [&]() {
+      float o = b3j;
+#pragma unroll
+      for (int u = 0; u < TM; ++u) o += rd_p[u * 16 * D];
+      return GEF ? o * factor : fminf(fmaxf(o, -1e4f), 1e4f);
+    };
+    auto close_bridge = [&]() {
+      const float s = net_out();
+      const float mb = cl_rome + 2.0f * cl_eta * s;
+      const float db = cl_rho - mb;
+      wl += (-(db * db) * cl_inv2s2 - cl_cst) - cl_fk;
+    };
+    uha_lds_barrier();                               // deviates of bridge 0 published
+    USTAMP_START();
+    for (int i = 0; i < K; ++i) {
+      const Sc q = sc_n;
+      float beta_n = 0.f, eps_n = 0.f;
+      if (i + 1 < K) { beta_n = a.ws[a.w.beta + i + 1]; eps_n = a.ws[a.w.eps + i + 1]; }
+      if (i > 0) close_bridge();                     // beside the first layer of pass 0
+      USTAMP(0); uha_lds_barrier(); USTAMP(1);
+      // pass 0, matrix interval: everything of rho' but the network
+      const float nzv = nzb[((i & 1) * 16 + pc) * D + j];
+      const float rome = rj * q.ome;
+      const float snz = q.sig * nzv;
+      const float uf = -1.0f * (q.beta * gp + (1.0f - q.beta) * gq);
+      const float huf = q.eps * uf / 2.0f;
+      if (i + 1 < K) sc_n = scalars(beta_n, eps_n);
+      USTAMP(2); uha_lds_barrier(); USTAMP(3);
+      // pass 0: rho' -> the second evaluation's input
+      const float s0 = net_out();
+      const float mf = rome - 2.0f * q.eta * s0;
+      const float rhop = mf + snz;
+      if (act) xin[pc * DIN + D + j] = rhop;
+      USTAMP(4); uha_lds_barrier(); USTAMP(5);
+      // pass 1, first layer: forward log-density, half step, z', the sums of grad log p(z')
+      const float df = rhop - mf;
+      const float rpp = rhop - huf;
+      cl_fk = -(df * df) * q.inv2s2 - q.cst;
+      cl_rho = rj;
+      cl_rome = rhop * q.ome;
+      cl_eta = q.eta; cl_inv2s2 = q.inv2s2; cl_cst = q.cst;
+      zj = zj + q.eps * rpp;
+      gq = -(zj - qm) * qiv;
+      dist();
+      USTAMP(6); uha_lds_barrier(); USTAMP(7);
+      // pass 1, matrix interval: grad log p(z'), second half step -> the NEXT bridge's input
+      grad();
+      const float ub = -1.0f * (q.beta * gp + (1.0f - q.beta) * gq);
+      rj = rpp - q.eps * ub / 2.0f;
+      if (act) { xin[pc * DIN + j] = zj; xin[pc * DIN + D + j] = rj; }
+      if (keepd) {
+        tz[((int64_t)(i + 1) * a.n + pd) * D + j] = zj;
+        trho[((int64_t)(i + 1) * a.n + pd) * D + j] = rj;
+        trhop[((int64_t)i * a.n + pd) * D + j] = rhop;
+      }
+      USTAMP(8); uha_lds_barrier(); USTAMP(9);
+    }
+    if (K > 0) close_bridge();
+    USTAMP_END();
+    wl += -(rj * rj) * 0.5f - kHalfLog2Pi;
+    const float loss = -(part_sum<16>(act ? wl : 0.f) + lp);
+    float* const lossb = reinterpret_cast<float*>(keyb);     // gen_0's slots, long read
+    if (sub == 0) lossb[pc] = loss;
+    if (vld && sub == 0) a.out_loss[pd] = loss;
+    if (vld && act) a.out_z[pd * D + j] = zj;
+    uha_lds_barrier();                               // the tile's 8 losses on the first state wave
+    if (wv == TM) {
+      const int l8 = lane & 7;
+      const bool use = lane < 8 && tile * 8 + l8 < a.n;
+      const float ls = lossb[l8];
+      double cnt = (use && isfinite(ls)) ? 1.0 : 0.0;
+      double sm = use ? (double)ls : 0.0;
+      double sq = use ? (double)ls * (double)ls : 0.0;
+      double mx = use ? -(double)ls : -INFINITY;
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) {
+        cnt += __shfl_xor(cnt, o);
+        sm += __shfl_xor(sm, o);
+        sq += __shfl_xor(sq, o);
+        mx = fmax(mx, __shfl_xor(mx, o));
+      }
+      double ex = (use && mx > -INFINITY && mx < INFINITY) ? exp(-(double)ls - mx) : 0.0;
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) ex += __shfl_xor(ex, o);
+      if (lane == 0) {
+        double* o = a.partials + tile * CMCD_NSTATS;
+        o[0] = cnt; o[1] = sm; o[2] = sq; o[3] = mx; o[4] = ex;
+      }
+    }
     return;
   }
 
@@ -849,38 +1193,14 @@ __global__ __launch_bounds__(64 * (T + 2)) void uha_coop_kernel(TrajArgs a) {
 #pragma unroll
   for (int j = 0; j < D; ++j) b3r[j] = a.ws[a.w.b3 + j];
   {
-    const int32_t seed = a.seeds[valid ? p : a.n - 1];
 #pragma unroll
     for (int j = 0; j < D; ++j) {
       qmean[j] = a.params[a.lay.vd_mean + j];
       qstd[j] = expf(a.params[a.lay.vd_logdiag + j]);
       qiv[j] = 1.0f / (qstd[j] * qstd[j]);
     }
-    uint32_t k0 = 0u, k1 = (uint32_t)seed;
-    uint32_t x0 = gb, x1 = 2 + gb;
-    threefry2x32(k0, k1, x0, x1);
-    uint32_t a0, a1, b0, b1;
-    rows01(x0, a0, a1);
-    rows01(x1, b0, b1);
-    float nz[2 * Hh];
-    draw_normal<D>(a0, a1, g, nz, a, 0, p, valid);
-#pragma unroll
-    for (int j = 0; j < D; ++j) z[j] = qstd[j] * nz[j] + qmean[j];
-    x0 = gb; x1 = 2 + gb;
-    threefry2x32(b0, b1, x0, x1);
-    uint32_t c0, c1;
-    rows01(x0, c0, c1);
-    x0 = gb; x1 = 2 + gb;
-    threefry2x32(c0, c1, x0, x1);
-    uint32_t r0, r1, p0, p1;
-    rows01(x0, r0, r1);
-    rows01(x1, p0, p1);
-    draw_normal<D>(r0, r1, g, nz, a, 1, p, valid);
-#pragma unroll
-    for (int j = 0; j < D; ++j) rho[j] = nz[j];
-    x0 = gb; x1 = 2 + gb;
-    threefry2x32(p0, p1, x0, x1);
-    rows01(x1, k0, k1);
+    uint32_t k0, k1;
+    uha_first_draws<D>(a, p, valid, g, gb, qmean, qstd, z, rho, k0, k1);
     if (g == 0) { keyb[2 * c] = k0; keyb[2 * c + 1] = k1; }
     if (a.dbg_keys && valid && own) {
       a.dbg_keys[p * 2] = k0;
@@ -1132,6 +1452,11 @@ static uha_fn uha_coop_pick_h(const cmcd_desc& d, int T) {
 static uha_fn uha_coop_pick(const cmcd_desc& d, int T, bool half) {
   return half ? uha_coop_pick_h<true>(d, T) : uha_coop_pick_h<false>(d, T);
 }
+// the 8-particle instance whose last MLP wave takes a 4-neuron tail along (uha_coop_tail_fits): the funnel's geffner net
+static bool uha_coop_has_tail(const cmcd_desc& d, int T) {
+  return d.arch == CMCD_ARCH_GEFFNER && d.target == CMCD_TARGET_FUNNEL && d.dim == 10 && T == 5 &&
+         uha_coop_tail_fits(T, net_in_dim(d) + d.emb_dim);
+}
 
 bool uha_available(const cmcd_desc& d, int T) { return uha_pick(d, T) != nullptr; }
 
@@ -1156,10 +1481,10 @@ int uha_forward_launch(const cmcd_desc& d, const TrajArgs& ta, void* stream_, in
   *n_records = w.n_waves;
   // kernel variant (desc.reserved, as for the overdamped kernels): 0 auto, 1 wave per tile, 2 cooperative, 3 cooperative on
   // 16-particle tiles, 4 cooperative on 8-particle tiles (auto: while those still get a CU each, n <= 8 x 256)
-  const bool forced = d.reserved >= 2 && d.reserved <= 4;
+  const bool forced = d.reserved >= 2 && d.reserved <= 5;
   const bool half_ok = uha_coop_pick(d, w.T, true) != nullptr;
-  if (d.reserved == 4 && !half_ok) return CMCD_ERR_UNSUPPORTED;
-  const bool half = d.reserved == 4 || (d.reserved != 3 && half_ok && ta.n <= 8 * 256);
+  if ((d.reserved == 4 || d.reserved == 5) && !half_ok) return CMCD_ERR_UNSUPPORTED;
+  const bool half = d.reserved == 4 || d.reserved == 5 || (d.reserved != 3 && half_ok && ta.n <= 8 * 256);
   uha_fn cfn = uha_coop_pick(d, w.T, half);
   if (forced && !cfn) return CMCD_ERR_UNSUPPORTED;
   if (cfn && (forced || (d.reserved != 1 && tiles <= uha_coop_max_tiles(d)))) {
@@ -1167,7 +1492,10 @@ int uha_forward_launch(const cmcd_desc& d, const TrajArgs& ta, void* stream_, in
     const int64_t wgs = half ? (ta.n + 7) / 8 : tiles;
     g_uha_kernel_name = half ? "uha_coop_kernel<8-particle tiles>" : "uha_coop_kernel<16-particle tiles>";
     *n_records = (int)wgs;
-    hipLaunchKernelGGL(cfn, dim3((unsigned)wgs), dim3(64 * (w.T + 2)), cl, stream, ta);
+    // (desc.reserved 5, as for the overdamped kernels: the 8-particle form WITHOUT the r05 tail, for A / B)
+    const bool tail = half && d.reserved != 5 && uha_coop_has_tail(d, w.T);
+    if (tail) cfn = uha_coop_kernel<CMCD_TARGET_FUNNEL, CMCD_ARCH_GEFFNER, 10, 5, true, true>;
+    hipLaunchKernelGGL(cfn, dim3((unsigned)wgs), dim3(64 * uha_coop_waves(d.target, w.T, half, tail)), cl, stream, ta);
     return hipGetLastError() == hipSuccess ? CMCD_OK : CMCD_ERR_HIP;
   }
   g_uha_kernel_name = "uha_traj_kernel";

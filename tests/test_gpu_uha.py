@@ -28,6 +28,7 @@ FWD_CASES = [
     ("gmm_n300_k8", 1500, dict(nbridges=3, nn_arch="dds")),                                # many tiles, 4-wave workgroups
     ("funnel_n300_k64", 64, dict(nbridges=5, nn_arch="dds", init_eps=0.05)),               # d = 10, dds first layer [84, 64]
     ("gmm_n300_k8", 33, dict(nbridges=1)),                                                 # a single bridge
+    ("funnel_n300_k64", 77, dict(emb_dim=56, nbridges=7, init_eps=0.05)),                  # 76 of 80 wide: five MLP waves, no tail
 ]
 
 
@@ -59,6 +60,34 @@ def _skip_without_instance(variant, name, over):
     emb = over.get("emb_dim", {"gmm": 20, "fun": 48, "man": 130}[name[:3]])
     if dim == 10 and 2 * dim + emb > 80:
         pytest.skip("the 9-tile nets on d = 10 have no 8-particle-tile instance")
+
+
+@pytest.mark.parametrize("n,over", [(300, dict(init_eps=0.05, init_gamma=4.0)), (77, dict(nbridges=9, init_eps=0.05)),
+                                    (5, dict(nbridges=3))])
+def test_funnel_on_8_particle_tiles_with_and_without_the_tail(hip_lib, param_set, monkeypatch, n, over):
+    """r05: the funnel's 8-particle form deals the state over two waves and lets the fourth MLP wave take the last tile's 4
+    real neurons along (form 4); form 5 keeps five MLP waves (the A / B partner).  Both against the restatement."""
+    name = "funnel_n300_k64"
+    b = synthetic.build(name, device="cuda", boundmode=MODE, **over)
+    seeds = synthetic.parity_seeds(n)
+    key = _case_key(param_set, name, n, over)
+    if key not in _ORACLE_FWD:
+        _ORACLE_FWD[key] = run_oracle(b, seeds, dtype=np.float64)
+    l_ref, z_ref = _ORACLE_FWD[key]
+    got = {}
+    for form in (4, 5):
+        monkeypatch.setattr(mcdbm, "KERNEL_VARIANT", form)
+        mean, (losses, z) = mcdbm.compute_bound(torch.from_numpy(seeds).cuda(), b["params_flat"], b["unflatten"],
+                                                b["params_fixed"], b["target"], eps_schedule=b["eps_schedule"],
+                                                grad_clipping=b["grad_clipping"])
+        torch.cuda.synchronize()
+        assert _lib.last_kernel_name() == KERNEL_NAMES[4]
+        compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"UHA funnel form {form} n={n}",
+                       K=b["params_fixed"][1])
+        got[form] = losses.cpu().numpy()
+    # same key chain, same arithmetic up to the summation order of layer 2 / 3: the two forms stay close to each other too
+    fin = np.isfinite(got[4]) & np.isfinite(got[5])
+    assert np.allclose(got[4][fin], got[5][fin], rtol=2e-3, atol=2e-3)
 
 
 @pytest.mark.parametrize("name,n,over", FWD_CASES)

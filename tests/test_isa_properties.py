@@ -189,10 +189,12 @@ def uha_asm(tmp_path_factory):
 
 
 # many_gmm (2), dds (1), D = 2, T = 4 on 8-particle tiles: the kernel bench.py's `second_order` line runs
-UHA_HALF = "_ZN4cmcd15uha_coop_kernelILi2ELi1ELi2ELi4ELb1EEEvNS_8TrajArgsE"
+UHA_HALF = "_ZN4cmcd15uha_coop_kernelILi2ELi1ELi2ELi4ELb1ELb0EEEvNS_8TrajArgsE"
 # funnel (1), geffner (0), D = 10, T = 5 on 16-particle tiles: the instance that spilled 344 bytes per lane (and ran 21 000
 # cycles per bridge) while the roles were branches of one loop body
-UHA_FUNNEL = "_ZN4cmcd15uha_coop_kernelILi1ELi0ELi10ELi5ELb0EEEvNS_8TrajArgsE"
+UHA_FUNNEL = "_ZN4cmcd15uha_coop_kernelILi1ELi0ELi10ELi5ELb0ELb0EEEvNS_8TrajArgsE"
+# r05: the same net on 8-particle tiles — state dealt over two waves, four MLP waves, the fourth with the 4-neuron tail
+UHA_FUNNEL_TAIL = "_ZN4cmcd15uha_coop_kernelILi1ELi0ELi10ELi5ELb1ELb1EEEvNS_8TrajArgsE"
 
 
 def _kernel_whole(lines, mangled_prefix):
@@ -226,7 +228,23 @@ def test_second_order_kernel_on_8_particle_tiles_broadcasts_the_layer2_operand(u
     assert all(re.search(r"blgp:[4-7]", l) for l in mfma), "a 4x4x1 matrix instruction without the row broadcast"
 
 
-@pytest.mark.parametrize("kern", [UHA_HALF, UHA_FUNNEL], ids=["named_shape_8_tiles", "funnel_16_tiles"])
+def test_second_order_funnel_on_8_particle_tiles_carries_the_tail_on_its_fourth_wave(uha_asm):
+    body, _ = _kernel_whole(uha_asm, UHA_FUNNEL_TAIL)
+    mfma = [l for l in body if "v_mfma_f32_4x4x1_16b_f32" in l]
+    own = [l for l in mfma if re.search(r"blgp:[4-7]", l)]
+    tail = [l for l in mfma if not re.search(r"blgp:", l)]
+    # per pass: 40 broadcast steps of the wave's own tile; the tail's 12 steps multiply every block by its own slice
+    assert len(own) == 80 and len(tail) == 24, (len(own), len(tail))
+    # the layer-3 partials leave reduce-scattered: two LDS stores per pass, not one per output pair
+    loop = body[body.index(own[0]):]
+    stores = [l for l in loop if l.strip().startswith("ds_write_b32")]
+    first_pass = loop[:loop.index(own[40])]
+    assert sum(l.strip().startswith("ds_write_b32") for l in first_pass) <= 3, "layer-3 partials stored per pair again"
+    assert stores
+
+
+@pytest.mark.parametrize("kern", [UHA_HALF, UHA_FUNNEL, UHA_FUNNEL_TAIL],
+                         ids=["named_shape_8_tiles", "funnel_16_tiles", "funnel_8_tiles_tail"])
 def test_second_order_kernels_do_not_spill(uha_asm, kern):
     _, meta = _kernel_whole(uha_asm, kern)
     scratch = next(l for l in meta if "ScratchSize" in l)
