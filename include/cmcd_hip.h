@@ -87,7 +87,8 @@ typedef struct cmcd_desc {
   int32_t grad_clipping;  /* 0 / 1                                                        */
   int32_t ngrid;          /* len(mgridref_y) - 1  (mcdboundingmachine.py:107-112)         */
   int32_t reserved;       /* kernel variant (testing): 0 auto, 1 wave-per-tile, 2 CU-cooperative, 3 / 4 cooperative on 16- / 8-particle
-                             tiles, 5 = 4 with a wide state (d = 10) kept on the narrow-state kernel (A / B) */
+                             tiles, 5 = 4 with a wide state (d = 10) kept on the narrow-state kernel (A / B); 2nd-order mode: 4 without the
+                             4-neuron tail on the last MLP wave (A / B) */
 } cmcd_desc;
 
 /* Offsets (in floats) of each leaf inside params_flat; -1 = absent for this arch.
