@@ -512,14 +512,15 @@ __device__ __forceinline__ void uha_first_draws(const TrajArgs& a, int64_t p, bo
 // (16 lanes per particle, lane = coordinate)
 constexpr bool uha_coop_dealt(int target, bool half) { return half && target == CMCD_TARGET_FUNNEL; }
 constexpr int uha_coop_waves(int target, int T, bool half, bool tail = false) {
-  return T - (tail ? 1 : 0) + 2 + (uha_coop_dealt(target, half) ? 1 : 0);
+  return T + 2 + (uha_coop_dealt(target, half) ? 1 : 0);      // (tail: T - 1 MLP waves + the tail wave)
 }
 // TAIL (r05): the last tile of the padded width holds at most 4 real neurons (the funnel's geffner net: 2 x 10 + 48 = 68 of
 // 80) — a whole MLP wave for them doubled up with another MLP wave on one SIMD and was the pole of both matrix intervals
 // (profiles/r05_uha_funnel_stamps_dealt.txt: 1 728 / 1 932 cycles against 1 140 / 1 240 for a wave with a SIMD of its own).
-// With TAIL the workgroup runs T - 1 MLP waves and the last of them takes the 4 neurons along: one more 4x4x1 pass whose 16
-// blocks are 2 particle groups x 8 contraction slices (the slices ARE the activations the lane already fetched for its own
-// tile: no further LDS reads), a reduce-scatter over the 8 slices, one more activation per lane.
+// With TAIL the workgroup runs T - 1 MLP waves and a light TAIL wave for the 4 neurons: ONE more 4x4x1 pass whose 16 blocks
+// are 2 particle groups x 8 contraction slices (12 steps instead of 40), a reduce-scatter over the slices, one activation
+// per lane; W3 of the 4 neurons is applied by the state waves.  (First form: the tail on the last MLP wave itself, 0.127 ms;
+// on its own wave with its own layer-3 reduce-scatter 0.123; as below 0.117 — profiles/r05_uha_funnel_forward_times.txt.)
 __host__ __device__ constexpr bool uha_coop_tail_fits(int T, int real_width) { return T >= 2 && real_width <= 16 * (T - 1) + 4; }
 
 // reduce-scatter over the four rows of the wave (cmcd_coop_wide.hip has the same pair):
@@ -548,6 +549,7 @@ __global__ __launch_bounds__(64 * uha_coop_waves(TARGET, T, HALF, TAIL)) void uh
   constexpr bool DEALT = uha_coop_dealt(TARGET, HALF);
   static_assert(!TAIL || DEALT, "the 4-neuron tail rides on the dealt form");
   constexpr int TM = TAIL ? T - 1 : T;        // MLP waves
+  constexpr bool TAILW = TAIL;                // the tail on wave TM + 3 (its 4 second-layer activations: row TM of `part`)
   constexpr int DIN = 2 * D;
   constexpr int Hh = (D + 1) / 2;
   constexpr int PPT = HALF ? 8 : 16;          // particles per tile
@@ -607,8 +609,6 @@ __global__ __launch_bounds__(64 * uha_coop_waves(TARGET, T, HALF, TAIL)) void uh
     if constexpr (HALF) {
       const int ng = g, kh = (lane >> 3) & 1;
       const int nb = 16 * wv + 4 * ng + 2 * kh;        // first of this lane's two hidden units
-      const bool tail = TAIL && wv == TM - 1;          // wave-uniform: this wave takes the last tile's 4 neurons along
-      constexpr int NX = 16 * TM;                      // first neuron of the tail (lane: neuron NX + ng)
       float w1[DIN][2], w3[D][2], aq[NQ], b2p[2];
 #pragma unroll
       for (int j = 0; j < DIN; ++j)
@@ -622,31 +622,12 @@ __global__ __launch_bounds__(64 * uha_coop_waves(TARGET, T, HALF, TAIL)) void uh
       for (int q = 0; q < NQ; ++q) aq[q] = a.ws[a.w.w2q + (int64_t)(wv * NQ + q) * 64 + lane];
 #pragma unroll
       for (int r = 0; r < 2; ++r) b2p[r] = a.ws[a.w.b2 + nb + r];
-      // tail: W1 column, W3 row (on the kh = 0 lane of the pair only: both hold the neuron), bias, and the A operands of
-      // the slice this lane already fetches for its own tile — inputs 40 kh + RSA ng + t, the table's rows of tile TM
-      float w1x[TAIL ? DIN : 1], w3x[TAIL ? D : 1], aqx[TAIL ? RSA : 1], b2x = 0.f;
-      if constexpr (TAIL) {
-#pragma unroll
-        for (int j = 0; j < DIN; ++j) w1x[j] = tail ? a.ws[a.w.w1z + j * HP + NX + ng] : 0.f;
-#pragma unroll
-        for (int j = 0; j < D; ++j) w3x[j] = (tail && kh == 0) ? a.ws[a.w.w3t + j * HP + NX + ng] : 0.f;
-#pragma unroll
-        for (int t = 0; t < RSA; ++t)
-          aqx[t] = (tail && RSA * ng + t < NQ) ? a.ws[a.w.w2q + (int64_t)(TM * NQ + RSA * ng + t) * 64 + (lane & 15)] : 0.f;
-        b2x = tail ? a.ws[a.w.b2 + NX + ng] : 0.f;
-      }
       const float* bias1 = a.ws + a.w.bias1;
       const float* utab = a.ws + a.w.utab;
       float2 brow_n = *reinterpret_cast<const float2*>(bias1 + nb), urow_n = {0.f, 0.f};
       if (GEF) urow_n = *reinterpret_cast<const float2*>(utab + nb);
-      float brx_n = 0.f, urx_n = 0.f;
-      if (tail) { brx_n = bias1[NX + ng]; if (GEF) urx_n = utab[NX + ng]; }
       float* const my_h = hbuf + cp * HQP + nb;
       const float* const rd_h = hbuf + cp * HQP + (HP / 2) * kh + RSA * ng;
-      // row 3's slice has NQ - 3 RSA real inputs; what it fetches beyond them belongs to the NEXT particle (unused by the
-      // broadcast passes).  The tail multiplies those slots by zero weights — they must not be another particle's inf / nan:
-      const float* const rd_h2 = (TAIL && RSA * ng + 4 >= NQ) ? hbuf + 8 * HQP + 16 - 4 : rd_h;
-      static_assert(!TAIL || NQ - 3 * RSA == 4, "row 3 of the tail keeps one quad of real inputs");
       // layer-3 partials leave the wave reduce-scattered (d > 2): lane (kh, ng) ends with outputs j0 and j0 + 8
       const int j0 = 4 * (ng & 1) + 2 * (ng >> 1) + kh;
       float* const my_p = part + (wv * 16 + cp) * D + j0;
@@ -655,19 +636,14 @@ __global__ __launch_bounds__(64 * uha_coop_waves(TARGET, T, HALF, TAIL)) void uh
       USTAMP_START();
       for (int i = 0; i < K; ++i) {
         const float2 brow = brow_n, urow = urow_n;
-        const float brx = brx_n, urx = urx_n;
         if (i + 1 < K) {
           brow_n = *reinterpret_cast<const float2*>(bias1 + (int64_t)(i + 1) * HP + nb);
           if (GEF) urow_n = *reinterpret_cast<const float2*>(utab + (int64_t)(i + 1) * HP + nb);
-          if (tail) {
-            brx_n = bias1[(int64_t)(i + 1) * HP + NX + ng];
-            if (GEF) urx_n = utab[(int64_t)(i + 1) * HP + NX + ng];
-          }
         }
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
           // -------------------------------------------------------------- interval 1
-          float h[2], hx = 0.f;
+          float h[2];
           {
             float x[DIN];
 #pragma unroll
@@ -688,15 +664,6 @@ __global__ __launch_bounds__(64 * uha_coop_waves(TARGET, T, HALF, TAIL)) void uh
               }
             }
             *reinterpret_cast<float2*>(my_h) = float2{h[0], h[1]};
-            if constexpr (TAIL) {
-              if (tail) {
-                float px = brx;
-#pragma unroll
-                for (int j = 0; j < DIN; ++j) px = fmaf(x[j], w1x[j], px);
-                hx = GEF ? urx + softplus(px) : gelu_fast(px);     // (NX >= 2 D: u comes from the table)
-                hbuf[cp * HQP + NX + ng] = hx;
-              }
-            }
           }
           USTAMP(pass * 6 + 0);
           uha_lds_barrier();
@@ -706,7 +673,7 @@ __global__ __launch_bounds__(64 * uha_coop_waves(TARGET, T, HALF, TAIL)) void uh
             f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             f32x4 hb[RSA / 4];
 #pragma unroll
-            for (int q = 0; q < RSA / 4; ++q) hb[q] = *reinterpret_cast<const f32x4*>((q == 0 ? rd_h : rd_h2) + 4 * q);
+            for (int q = 0; q < RSA / 4; ++q) hb[q] = *reinterpret_cast<const f32x4*>(rd_h + 4 * q);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int sq = 0; sq < NQ; ++sq) {
@@ -717,24 +684,6 @@ __global__ __launch_bounds__(64 * uha_coop_waves(TARGET, T, HALF, TAIL)) void uh
               else if (row == 1) ac = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[sq], bv, ac, 0, 0, 5);
               else if (row == 2) ac = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[sq], bv, ac, 0, 0, 6);
               else ac = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[sq], bv, ac, 0, 0, 7);
-            }
-            float h2x = 0.f;
-            if constexpr (TAIL) {
-              if (tail) {                              // the tail's 4 neurons: every block its own slice, no broadcast
-                f32x4 ax = {0.f, 0.f, 0.f, 0.f}, ax1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int t = 0; t < RSA; ++t) {
-                  f32x4& ac = (t & 1) ? ax1 : ax;
-                  ac = __builtin_amdgcn_mfma_f32_4x4x1f32(aqx[t], hb[t / 4][t % 4], ac, 0, 0, 0);
-                }
-                ax += ax1;
-                // 8 slices (kh, ng) -> neuron ng on every lane of the row: rows first, then the two halves of the row
-                const float u01 = uha_rs16(ax[0], ax[1]), u23 = uha_rs16(ax[2], ax[3]);
-                float avx = uha_rs32(u01, u23);
-                avx += xor8(avx);
-                avx += b2x;
-                h2x = GEF ? hx + softplus(avx) : gelu_fast(avx);
-              }
             }
             acc += acc1;
             // the two halves of the contraction sit in lanes l and l ^ 8; lane kh keeps neurons 2 kh + {0, 1} of its group
@@ -762,12 +711,6 @@ __global__ __launch_bounds__(64 * uha_coop_waves(TARGET, T, HALF, TAIL)) void uh
               float pj[D];
 #pragma unroll
               for (int j = 0; j < D; ++j) pj[j] = h2[0] * w3[j][0] + h2[1] * w3[j][1];
-              if constexpr (TAIL) {
-                if (tail) {
-#pragma unroll
-                  for (int j = 0; j < D; ++j) pj[j] = fmaf(h2x, w3x[j], pj[j]);
-                }
-              }
               float qm[2 * M2], rm[4];
 #pragma unroll
               for (int m = 0; m < 2 * M2; ++m)
@@ -996,6 +939,91 @@ __global__ __launch_bounds__(64 * uha_coop_waves(TARGET, T, HALF, TAIL)) void uh
     return;
   }
 
+  // =========================================================================================== tail wave (TAILW)
+  // The last tile's 4 real neurons on a wave of their own (wave TM + 3: the SIMD of the last MLP wave, which no auxiliary wave
+  // shares): lane (qi, pg, kh, ng) = particle 4 pg + qi, layer 1 of neuron NX + ng, layer 2 as ONE 4x4x1 pass whose 16 blocks are 2
+  // particle groups x 8 contraction slices (kh, ng) — the slice an MLP lane of the same (kh, ng) fetches for its own tile —
+  // reduce-scattered over the slices back to neuron ng; the 4 activations go to the state waves (row TM of `part`), which apply W3.
+  if constexpr (TAILW) {
+    if (wv == TM + 3) {
+      // (a raised issue priority for this short chain beside MLP wave TM - 1's long one: 4 218 -> 4 096 stamped cycles per
+      //  bridge, but 0.1164 -> 0.1169 ms per call on the product build: not kept)
+      const int ng = g, kh = (lane >> 3) & 1;
+      constexpr int NX = 16 * TM;
+      float w1x[DIN], aqx[RSA];
+#pragma unroll
+      for (int j = 0; j < DIN; ++j) w1x[j] = a.ws[a.w.w1z + j * HP + NX + ng];
+#pragma unroll
+      for (int t = 0; t < RSA; ++t)
+        aqx[t] = RSA * ng + t < NQ ? a.ws[a.w.w2q + (int64_t)(TM * NQ + RSA * ng + t) * 64 + (lane & 15)] : 0.f;
+      const float b2x = a.ws[a.w.b2 + NX + ng];
+      const float* bias1 = a.ws + a.w.bias1;
+      const float* utab = a.ws + a.w.utab;
+      float brx_n = bias1[NX + ng], urx_n = GEF ? utab[NX + ng] : 0.f;
+      const float* const rd_h = hbuf + cp * HQP + (HP / 2) * kh + RSA * ng;
+      // row 3's slice has NQ - 3 RSA real inputs; what lies behind them belongs to the NEXT particle: zero weights, but it
+      // must not be another particle's inf / nan — those quads come from 16 zeros behind the buffer
+      const float* const rd_h2 = (RSA * ng + 4 >= NQ) ? hbuf + 8 * HQP + 16 - 4 : rd_h;
+      static_assert(NQ - 3 * RSA == 4, "row 3 of the tail keeps one quad of real inputs");
+      float* const my_h2 = part + TM * 16 * D + cp * 4 + ng;   // [8][4] second-layer activations of the 4 neurons -> the state waves
+      uha_lds_barrier();                             // gen_0 and the first network input published
+      uha_lds_barrier();                             // deviates of bridge 0 published
+      USTAMP_START();
+      for (int i = 0; i < K; ++i) {
+        const float brx = brx_n, urx = urx_n;
+        if (i + 1 < K) {
+          brx_n = bias1[(int64_t)(i + 1) * HP + NX + ng];
+          if (GEF) urx_n = utab[(int64_t)(i + 1) * HP + NX + ng];
+        }
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+          float hx;
+          {
+            float px = brx;
+#pragma unroll
+            for (int j = 0; j < DIN; ++j) px = fmaf(xin[cp * DIN + j], w1x[j], px);
+            hx = GEF ? urx + softplus(px) : gelu_fast(px);     // (NX >= 2 D: u comes from the table)
+            hbuf[cp * HQP + NX + ng] = hx;
+          }
+          USTAMP(pass * 6 + 0);
+          uha_lds_barrier();
+          USTAMP(pass * 6 + 1);
+          {
+            f32x4 hb[RSA / 4];
+#pragma unroll
+            for (int q = 0; q < RSA / 4; ++q) hb[q] = *reinterpret_cast<const f32x4*>((q == 0 ? rd_h : rd_h2) + 4 * q);
+            f32x4 ax = {0.f, 0.f, 0.f, 0.f}, ax1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < RSA; ++t) {
+              f32x4& ac = (t & 1) ? ax1 : ax;
+              ac = __builtin_amdgcn_mfma_f32_4x4x1f32(aqx[t], hb[t / 4][t % 4], ac, 0, 0, 0);
+            }
+            ax += ax1;
+            // 8 slices (kh, ng) -> neuron ng on every lane of the row: rows first, then the two halves of the row
+            const float u01 = uha_rs16(ax[0], ax[1]), u23 = uha_rs16(ax[2], ax[3]);
+            float avx = uha_rs32(u01, u23);
+            avx += xor8(avx);
+            avx += b2x;
+            const float h2x = GEF ? hx + softplus(avx) : gelu_fast(avx);
+            // the 4 neurons' share of layer 3 is taken by the state waves (4 products per coordinate beside their sum of the
+            // MLP waves' partials): a reduce-scatter of ten outputs here was the longest chain of the interval
+            if (kh == 0) *my_h2 = h2x;
+          }
+          USTAMP(pass * 6 + 2);
+          uha_lds_barrier();
+          USTAMP(pass * 6 + 3);
+          if (pass == 0) {
+            uha_lds_barrier();
+            USTAMP(pass * 6 + 5);
+          }
+        }
+      }
+      USTAMP_END();
+      uha_lds_barrier();                             // the state waves' hand-over of the tile's losses
+      return;
+    }
+  }
+
   // =========================================================================================== state waves, dealt (funnel, 8-particle tiles)
   // r05: the columns layout below keeps all d coordinates of a particle in each of its 8 lanes — for d = 10 the two
   // readings of the network output (5 waves x 10 partials per lane) and the ten-fold element-wise step made this wave the
@@ -1082,10 +1110,20 @@ __global__ __launch_bounds__(64 * uha_coop_waves(TARGET, T, HALF, TAIL)) void uh
     Sc sc_n = scalars(a.ws[a.w.beta], a.ws[a.w.eps]);
     float cl_rome = 0.f, cl_rho = 0.f, cl_eta = 0.f, cl_inv2s2 = 0.f, cl_cst = 0.f, cl_fk = 0.f;
     const float* const rd_p = part + pc * D + j;
+    f32x4 w3s = {0.f, 0.f, 0.f, 0.f};                // TAILW: W3 rows of the tail's 4 neurons, this lane's coordinate
+    if constexpr (TAILW) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w3s[e] = a.ws[a.w.w3t + j * HP + 16 * TM + e];
+    }
+    const f32x4* const rd_t = reinterpret_cast<const f32x4*>(part + TM * 16 * D + pc * 4);
     auto net_out = [&]() {
       float o = b3j;
 #pragma unroll
       for (int u = 0; u < TM; ++u) o += rd_p[u * 16 * D];
+      if constexpr (TAILW) {
+        const f32x4 ht = *rd_t;
+        o += (ht[0] * w3s[0] + ht[1] * w3s[1]) + (ht[2] * w3s[2] + ht[3] * w3s[3]);
+      }
       return GEF ? o * factor : fminf(fmaxf(o, -1e4f), 1e4f);
     };
     auto close_bridge = [&]() {

@@ -65,8 +65,8 @@ def _skip_without_instance(variant, name, over):
 @pytest.mark.parametrize("n,over", [(300, dict(init_eps=0.05, init_gamma=4.0)), (77, dict(nbridges=9, init_eps=0.05)),
                                     (5, dict(nbridges=3))])
 def test_funnel_on_8_particle_tiles_with_and_without_the_tail(hip_lib, param_set, monkeypatch, n, over):
-    """r05: the funnel's 8-particle form deals the state over two waves and lets the fourth MLP wave take the last tile's 4
-    real neurons along (form 4); form 5 keeps five MLP waves (the A / B partner).  Both against the restatement."""
+    """r05: the funnel's 8-particle form deals the state over two waves and gives the last tile's 4 real neurons to a light
+    tail wave beside four MLP waves (form 4); form 5 keeps five MLP waves (the A / B partner).  Both against the restatement."""
     name = "funnel_n300_k64"
     b = synthetic.build(name, device="cuda", boundmode=MODE, **over)
     seeds = synthetic.parity_seeds(n)

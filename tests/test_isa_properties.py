@@ -193,7 +193,8 @@ UHA_HALF = "_ZN4cmcd15uha_coop_kernelILi2ELi1ELi2ELi4ELb1ELb0EEEvNS_8TrajArgsE"
 # funnel (1), geffner (0), D = 10, T = 5 on 16-particle tiles: the instance that spilled 344 bytes per lane (and ran 21 000
 # cycles per bridge) while the roles were branches of one loop body
 UHA_FUNNEL = "_ZN4cmcd15uha_coop_kernelILi1ELi0ELi10ELi5ELb0ELb0EEEvNS_8TrajArgsE"
-# r05: the same net on 8-particle tiles — state dealt over two waves, four MLP waves, the fourth with the 4-neuron tail
+# r05: the same net on 8-particle tiles — state dealt over two waves, four MLP waves and a light tail wave for the 4 real
+# neurons of the padded fifth tile
 UHA_FUNNEL_TAIL = "_ZN4cmcd15uha_coop_kernelILi1ELi0ELi10ELi5ELb1ELb1EEEvNS_8TrajArgsE"
 
 
@@ -228,12 +229,12 @@ def test_second_order_kernel_on_8_particle_tiles_broadcasts_the_layer2_operand(u
     assert all(re.search(r"blgp:[4-7]", l) for l in mfma), "a 4x4x1 matrix instruction without the row broadcast"
 
 
-def test_second_order_funnel_on_8_particle_tiles_carries_the_tail_on_its_fourth_wave(uha_asm):
+def test_second_order_funnel_on_8_particle_tiles_runs_the_tail_as_one_short_pass(uha_asm):
     body, _ = _kernel_whole(uha_asm, UHA_FUNNEL_TAIL)
     mfma = [l for l in body if "v_mfma_f32_4x4x1_16b_f32" in l]
     own = [l for l in mfma if re.search(r"blgp:[4-7]", l)]
     tail = [l for l in mfma if not re.search(r"blgp:", l)]
-    # per pass: 40 broadcast steps of the wave's own tile; the tail's 12 steps multiply every block by its own slice
+    # per pass: 40 broadcast steps of an MLP wave's own tile; the tail wave's 12 steps multiply every block by its own slice
     assert len(own) == 80 and len(tail) == 24, (len(own), len(tail))
     # the layer-3 partials leave reduce-scattered: two LDS stores per pass, not one per output pair
     loop = body[body.index(own[0]):]

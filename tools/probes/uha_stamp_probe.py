@@ -41,9 +41,10 @@ names = ["int1", "bar1", "int2", "bar2", "comb", "bar3"]
 print("cycles per bridge, workgroup 0 (pass 0 | pass 1):")
 nw = max(w for w in range(16) if buf[w * 16] or buf[w * 16 + 1]) + 1
 dealt = name.startswith("funnel") and os.environ["CMCD_KERNEL_VARIANT"] != "3" and n <= 2048   # two state waves
-T = nw - (3 if dealt else 2)
+tailw = dealt and b["cfg"].get("emb_dim", 48) == 48 and os.environ["CMCD_KERNEL_VARIANT"] != "5" and nw == 8   # r05: tail wave
+T = nw - (4 if tailw else 3 if dealt else 2)
 for wv in range(nw):
     row = [buf[wv * 16 + k] / K for k in range(12)]
-    role = "MLP%d" % wv if wv < T else ["STATE", "RNG", "STAT2"][wv - T]
+    role = "MLP%d" % wv if wv < T else ["STATE", "RNG", "STAT2", "TAILW"][wv - T]
     print("%5s " % role + "  ".join("%s=%5.0f" % (nm, v) for nm, v in zip(names, row[:6])) + "  |  " +
           "  ".join("%s=%5.0f" % (nm, v) for nm, v in zip(names, row[6:])) + "   total=%6.0f" % sum(row))
