@@ -601,6 +601,131 @@ __device__ __forceinline__ void eval_net(const float (&z)[D], const float* __res
   if (CMCD_TRAJ_ABL & 48) s[0] += dummy * 1e-30f;
 }
 
+// r05: the 132-wide net (BASELINE configuration 4: T = 9 = 8 full neuron tiles + 4 real neurons) without its 12 zero
+// neurons.  eval_net carries the ninth tile like any other: 4 k-steps of every output tile for 4 real inputs, a whole output
+// tile (36 matrix instructions) and 4 activations per lane for 4 real outputs — 324 `16x16x4` per evaluation.  Here:
+//   * layer 1: lane (g, c) takes the ONE tail neuron 128 + g of particle c (the C layout of a 17th row group);
+//   * tail INPUTS: that activation is exactly the B operand of one `16x16x4` step with k = g — one step per output tile
+//     instead of four, the A operand being element g of the packed fragment of lane (0, c);
+//   * tail OUTPUTS: `4x4x1` — block (g, c >> 2) = 4 neurons x 4 particles over contraction slice g = the activations the lane
+//     already holds (k = 16 t + 4 g + r), the A operand being the packed fragment of lane (g, c & 3) of output tile 8: 33 steps
+//     of 2 passes instead of 36 of 8; a reduce-scatter over the four rows leaves neuron 128 + g on lane (g, c).
+// 264 `16x16x4` + 33 `4x4x1` = 84 % of the matrix time, 66 activations instead of 72, no new table (every operand is read from
+// the fragment table eval_net reads).  Same sums up to the order of the tail's contraction.
+__device__ __forceinline__ float traj_rs32(float x, float y) {
+  uint32_t r0, r1;
+  swap32(__float_as_uint(x), __float_as_uint(y), r0, r1);
+  return __uint_as_float(r0) + __uint_as_float(r1);
+}
+__device__ __forceinline__ float traj_rs16(float x, float y) {
+  uint32_t r0, r1;
+  swap16(__float_as_uint(x), __float_as_uint(y), r0, r1);
+  return __uint_as_float(r0) + __uint_as_float(r1);
+}
+template <int ARCH, int D, int T>
+__device__ __forceinline__ void eval_net_tail4(const float (&z)[D], const float* __restrict__ brow,
+                                               const float* __restrict__ urow, const float* lds_w2,
+                                               const float* lds_w1z, const float* lds_b2, const float* lds_w3t,
+                                               const float* lds_b3, int lane, float (&s)[D]) {
+  static_assert(ARCH == CMCD_ARCH_GEFFNER && T >= 2 && D <= 16, "the tail form is the geffner net's");
+  constexpr int HP = 16 * T, TF = T - 1, NX = 16 * TF;
+  const int g = lane >> 4, c = lane & 15;
+  asm volatile("" ::: "memory");  // keep the LDS-resident weights streaming (no LICM into VGPRs)
+  f32x4 h[TF];
+#pragma unroll
+  for (int t = 0; t < TF; ++t) {
+    f32x4 pre = *reinterpret_cast<const f32x4*>(brow + 16 * t + 4 * g);
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(lds_w1z + j * HP + 16 * t + 4 * g);
+      pre += z[j] * wv;
+    }
+    f32x4 u = *reinterpret_cast<const f32x4*>(urow + 16 * t + 4 * g);
+    if (16 * t < D) {  // the first D neurons of u are z itself
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nidx = 16 * t + 4 * g + r;
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+          if (j >= 16 * t && j < 16 * t + 16) u[r] = (nidx == j) ? z[j] : u[r];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h[t][r] = u[r] + softplus(pre[r]);
+  }
+  float hx;                        // tail neuron NX + g of particle c
+  {
+    float px = brow[NX + g];
+#pragma unroll
+    for (int j = 0; j < D; ++j) px = fmaf(z[j], lds_w1z[j * HP + NX + g], px);
+    hx = urow[NX + g] + softplus(px);
+  }
+  f32x4 acc[TF], accx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < TF; ++t) acc[t] = *reinterpret_cast<const f32x4*>(lds_b2 + 16 * t + 4 * g);
+  const float* const w2x = lds_w2 + (TF * 64 + 16 * g + (c & 3)) * 4;   // + ti T 256: fragments of output tile TF, lane (g, c & 3)
+  {
+    f32x4 a[2][TF], ax[2];
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int to = 0; to < TF; ++to) a[0][to] = *reinterpret_cast<const f32x4*>(lds_w2 + (to * 64 + lane) * 4);
+    ax[0] = *reinterpret_cast<const f32x4*>(w2x);
+#pragma unroll
+    for (int ti = 0; ti < TF; ++ti) {
+      asm volatile("" ::: "memory");
+      if (ti + 1 < TF) {
+#pragma unroll
+        for (int to = 0; to < TF; ++to)
+          a[(ti + 1) & 1][to] = *reinterpret_cast<const f32x4*>(lds_w2 + (((ti + 1) * T + to) * 64 + lane) * 4);
+        ax[(ti + 1) & 1] = *reinterpret_cast<const f32x4*>(w2x + (ti + 1) * T * 256);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int to = 0; to < TF; ++to)
+          acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ti & 1][to][r], h[ti][r], acc[to], 0, 0, 0);
+        accx = __builtin_amdgcn_mfma_f32_4x4x1f32(ax[ti & 1][r], h[ti][r], accx, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  {
+    // the tail inputs (k = NX + g): element g of the fragments of lane (0, c) / lane (0, c & 3) of input tile TF
+    float a8[TF];
+#pragma unroll
+    for (int to = 0; to < TF; ++to) a8[to] = lds_w2[((TF * T + to) * 64 + c) * 4 + g];
+    const float axx = lds_w2[((TF * T + TF) * 64 + (c & 3)) * 4 + g];
+#pragma unroll
+    for (int to = 0; to < TF; ++to) acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(a8[to], hx, acc[to], 0, 0, 0);
+    accx = __builtin_amdgcn_mfma_f32_4x4x1f32(axx, hx, accx, 0, 0, 0);
+  }
+  // the four rows' slices of the tail outputs -> neuron NX + g on lane (g, c)
+  float h2x;
+  {
+    const float u01 = traj_rs16(accx[0], accx[1]), u23 = traj_rs16(accx[2], accx[3]);
+    const float avx = traj_rs32(u01, u23) + lds_b2[NX + g];
+    h2x = hx + softplus(avx);
+  }
+  float part[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) part[j] = h2x * lds_w3t[j * HP + NX + g];
+#pragma unroll
+  for (int t = 0; t < TF; ++t) {
+    f32x4 h2;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h2[r] = h[t][r] + softplus(acc[t][r]);
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(lds_w3t + j * HP + 16 * t + 4 * g);
+      part[j] += h2[0] * wv[0] + h2[1] * wv[1] + h2[2] * wv[2] + h2[3] * wv[3];
+    }
+  }
+  const float factor = lds_b3[15];
+#pragma unroll
+  for (int j = 0; j < D; ++j) s[j] = (group_sum(part[j]) + lds_b3[j]) * factor;
+}
+
 // which instances keep the next input tile's fragments in flight (eval_net<.., PF>), measured on saturating batches against the
 // r04 form (profiles/r05_f_traj_fragment_prefetch_ab.txt): the 9-tile net -11 % (config 4: 2.360 -> 2.107 ms), dds on the 2-d
 // targets -1.6 %, the 2-tile net -1.4 %; the 4-tile geffner net (+1.9 %: 12 bytes of scratch at 128 registers) and the funnel
@@ -608,7 +733,11 @@ __device__ __forceinline__ void eval_net(const float (&z)[D], const float* __res
 constexpr bool traj_pf(int ARCH, int D, int T) {
   return CMCD_TRAJ_PF != 0 && (T == 9 || (D == 2 && (T == 2 || ARCH == CMCD_ARCH_DDS)));
 }
-template <int TARGET, int ARCH, int D, int T, bool PF = traj_pf(ARCH, D, T)>
+// TAIL4: the 132-wide net on eval_net_tail4 (the launch picks the instance: traj_tail4)
+#ifndef CMCD_TRAJ_TAIL4
+#define CMCD_TRAJ_TAIL4 1
+#endif
+template <int TARGET, int ARCH, int D, int T, bool PF = traj_pf(ARCH, D, T), bool TAIL4 = false>
 __global__ __launch_bounds__(512, (T > 4 || D > 4) ? 2 : 4) void traj_kernel(TrajArgs a) {
   constexpr int HP = 16 * T;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -757,7 +886,8 @@ __global__ __launch_bounds__(512, (T > 4 || D > 4) ? 2 : 4) void traj_kernel(Tra
     } else {
       // CAIS: s(z_i, i) serves both kernels; MCD_ULA_sn: s(z_i, i - 1) serves the backward kernel only
       const int64_t row = (a.ula == 2) ? (i > 0 ? i - 1 : 0) : i;
-      eval_net<ARCH, D, T, PF>(z, bias1 + row * HP, utab + row * HP, lds_w2, lds_w1z, lds_b2, lds_w3t, lds_b3, lane, sn);
+      if constexpr (TAIL4) eval_net_tail4<ARCH, D, T>(z, bias1 + row * HP, utab + row * HP, lds_w2, lds_w1z, lds_b2, lds_w3t, lds_b3, lane, sn);
+      else eval_net<ARCH, D, T, PF>(z, bias1 + row * HP, utab + row * HP, lds_w2, lds_w1z, lds_b2, lds_w3t, lds_b3, lane, sn);
     }
     const float fsn = a.ula ? 0.f : 1.f;  // the ULA forward kernel has no network term
     float gq[D];
@@ -990,7 +1120,19 @@ static traj_fn pick_T(int T) {
   }
 }
 
+// the instances on eval_net_tail4: the geffner net of the 2-d targets whose ninth tile holds at most 4 real neurons (2 + 130 = 132)
+static bool traj_tail4(const cmcd_desc& d, int T) {
+  const int in = net_in_dim(d) + d.emb_dim;
+  return CMCD_TRAJ_TAIL4 != 0 && d.arch == CMCD_ARCH_GEFFNER && d.dim == 2 && T == 9 && in > 128 && in <= 132 &&
+         (d.target == CMCD_TARGET_MANY_GMM || d.target == CMCD_TARGET_GMM);
+}
+
 static traj_fn pick_kernel(const cmcd_desc& d, int T) {
+  if (traj_tail4(d, T)) {
+    constexpr bool pf = traj_pf(CMCD_ARCH_GEFFNER, 2, 9);
+    return d.target == CMCD_TARGET_MANY_GMM ? traj_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_GEFFNER, 2, 9, pf, true>
+                                            : traj_kernel<CMCD_TARGET_GMM, CMCD_ARCH_GEFFNER, 2, 9, pf, true>;
+  }
   if (d.arch == CMCD_ARCH_DDS) {
     if (T != 4) return nullptr;
     if (d.target == CMCD_TARGET_MANY_GMM && d.dim == 2) return traj_kernel<CMCD_TARGET_MANY_GMM, CMCD_ARCH_DDS, 2, 4>;

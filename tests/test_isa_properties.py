@@ -106,7 +106,7 @@ def test_headline_kernel_does_not_spill(coop_asm):
 
 
 def test_wave_per_tile_kernel_keeps_the_erfinv_tail_in_a_branch(traj_asm):
-    body, _ = _kernel(traj_asm, "_ZN4cmcd11traj_kernelILi2ELi1ELi2ELi4ELb1EEEvNS_8TrajArgsE")
+    body, _ = _kernel(traj_asm, "_ZN4cmcd11traj_kernelILi2ELi1ELi2ELi4ELb1ELb0EEEvNS_8TrajArgsE")
     marks = [i for i, l in enumerate(body) if "; erfinv tail" in l]
     assert marks, "marker of the tail branch not found"
     for i in marks:
@@ -121,7 +121,7 @@ def test_wave_per_tile_kernel_keeps_the_erfinv_tail_in_a_branch(traj_asm):
 
 
 def test_wave_per_tile_kernel_is_built_without_slp(traj_asm):
-    body, _ = _kernel(traj_asm, "_ZN4cmcd11traj_kernelILi2ELi1ELi2ELi4ELb1EEEvNS_8TrajArgsE")
+    body, _ = _kernel(traj_asm, "_ZN4cmcd11traj_kernelILi2ELi1ELi2ELi4ELb1ELb0EEEvNS_8TrajArgsE")
     packed = sum(1 for l in body if re.match(r"\s*v_pk_(fma|mul|add)_f32", l))
     assert packed <= 40, f"{packed} packed fp32 instructions: is -fno-slp-vectorize still applied to cmcd_kernels.hip?"
 
@@ -130,7 +130,7 @@ def test_the_9_tile_net_keeps_the_next_fragments_in_flight(traj_asm):
     """r05 (config 4 on one GPU 2.315 -> 2.003 ms): the layer-2 fragments of input tile ti + 1 are requested while tile ti's
     matrix instructions run.  Left alone the machine scheduler sinks every `ds_read_b128` to just in front of the four matrix
     instructions that use it, each behind a full `s_waitcnt lgkmcnt(0)`: 81 waits inside the matrix chain of one evaluation."""
-    body, tail = _kernel_whole(traj_asm, "_ZN4cmcd11traj_kernelILi2ELi0ELi2ELi9ELb1EEEvNS_8TrajArgsE")
+    body, tail = _kernel_whole(traj_asm, "_ZN4cmcd11traj_kernelILi2ELi0ELi2ELi9ELb1ELb0EEEvNS_8TrajArgsE")
     loop_start = max(i for i, l in enumerate(body) if "Loop Header: Depth=1" in l)
     loop = body[loop_start:]
     m = [i for i, l in enumerate(loop) if "v_mfma_f32_16x16x4" in l]
@@ -138,6 +138,18 @@ def test_the_9_tile_net_keeps_the_next_fragments_in_flight(traj_asm):
     chain = loop[m[0]:m[323] + 1]
     full_waits = sum(1 for l in chain if re.match(r"\s*s_waitcnt\s+lgkmcnt\(0\)", l))
     assert full_waits <= 12, f"{full_waits} full LDS waits inside the matrix chain: the fragment reads were sunk to their uses"
+    assert not any("ScratchSize: " in l and "ScratchSize: 0" not in l for l in tail)
+
+
+def test_the_132_wide_net_runs_without_its_twelve_zero_neurons(traj_asm):
+    """r05 (config 4 on one GPU 1.93 -> 1.77 ms): eval_net_tail4 — per evaluation 8 x 8 x 4 + 8 `16x16x4` steps (the 4 real inputs
+    of the ninth tile are ONE k-step) and 33 `4x4x1` steps for its 4 real outputs, instead of 324 `16x16x4`."""
+    body, tail = _kernel_whole(traj_asm, "_ZN4cmcd11traj_kernelILi2ELi0ELi2ELi9ELb1ELb1EEEvNS_8TrajArgsE")
+    loop_start = max(i for i, l in enumerate(body) if "Loop Header: Depth=1" in l)
+    loop = body[loop_start:]
+    big = sum("v_mfma_f32_16x16x4" in l for l in loop)
+    small = sum("v_mfma_f32_4x4x1" in l for l in loop)
+    assert big == 264 and small == 33, (big, small)
     assert not any("ScratchSize: " in l and "ScratchSize: 0" not in l for l in tail)
 
 
