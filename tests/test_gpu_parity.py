@@ -185,6 +185,7 @@ def test_lgcp_wide_batch_path_matches_oracle(hip_lib, param_set, monkeypatch, mo
     ("many_gmm_n2000_k256_dds", "MCD_ULA_sn", 200, dict(nbridges=32, init_eps=0.3, init_sigma=15.0)),
     ("many_gmm_n2000_k256_dds", "MCD_ULA", 200, dict(nbridges=32, init_eps=0.3, init_sigma=15.0)),
     ("funnel_n300_k64", "MCD_ULA_sn", 100, dict(nbridges=16)),
+    ("many_gmm_var_n16000_k256", "MCD_ULA_sn", 70, dict(nbridges=6)),     # the 132-wide net (eval_net_tail4 on the wave-per-tile form)
 ])
 def test_sibling_overdamped_modes_match_oracle(hip_lib, param_set, variant, name, mode, n, over):
     """config.boundmode = MCD_ULA / MCD_ULA_sn (reference mcd_over_orig.py) on the same kernels."""
@@ -252,6 +253,21 @@ def test_network_widths_between_the_instances_run_zero_padded(hip_lib, param_set
 
 
 @pytest.mark.parametrize("variant", [2, 3, 4])
+@pytest.mark.parametrize("emb_dim", [128, 130, 131])
+def test_gmm_target_on_the_132_wide_net(hip_lib, param_set, monkeypatch, emb_dim, variant):
+    """The 2-d gmm target with config 4's net width (emb_dim 130 -> 132 hidden units: eight tiles + 4 neurons; 128 -> 130: + 2;
+    131 -> 133: the general nine-tile form): the wave-per-tile kernel's tail form (eval_net_tail4, r05) has its own gmm instance."""
+    monkeypatch.setattr(mcdbm, "KERNEL_VARIANT", variant)
+    b = synthetic.build("gmm_n300_k8", device="cuda", emb_dim=emb_dim, nbridges=7)
+    seeds = synthetic.parity_seeds(77)
+    mean, (losses, z) = mcdbm.compute_bound(torch.from_numpy(seeds).cuda(), b["params_flat"], b["unflatten"],
+                                            b["params_fixed"], b["target"], eps_schedule=b["eps_schedule"],
+                                            grad_clipping=b["grad_clipping"])
+    torch.cuda.synchronize()
+    l_ref, z_ref = run_oracle(b, seeds, dtype=np.float64)
+    compare_losses(losses.cpu().numpy(), l_ref, z.cpu().numpy(), z_ref, tag=f"gmm emb_dim={emb_dim} variant={variant}", K=7)
+
+
 @pytest.mark.parametrize("emb_dim", [127, 128, 129, 130, 131, 136])
 def test_widths_around_the_132_wide_net_on_the_cooperative_kernels(hip_lib, param_set, monkeypatch, emb_dim, variant):
     """129 ... 132 hidden units (emb_dim 127 ... 130, d = 2) run the ninth MLP wave of the 8-particle tiling in its
