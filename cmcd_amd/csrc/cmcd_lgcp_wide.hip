@@ -33,6 +33,7 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "cmcd_common.h"
@@ -42,6 +43,7 @@
 namespace cmcd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x3 __attribute__((ext_vector_type(3)));
 
 constexpr int kWRows = 32;       // rows of a tile (one 32x32x2 MFMA block)
 constexpr int kWCols = 128;      // columns of a tile (four interleaved MFMA blocks)
@@ -58,6 +60,7 @@ struct WideSeg {
   int lda, ldw, Kp;  // Kp: multiple of 32
   int epi;
   float a_shift;     // the operand is A - a_shift   (K^-1 (x - mu0) without a subtraction pass)
+  int ncols;         // packed columns that hold weights (the rest of the last column tile is zero padding)
 };
 
 struct WideStep {            // evaluation i at z_i: closes step i-1, opens step i (i = K: collects log p(z_K))
@@ -86,6 +89,8 @@ struct WideStep {            // evaluation i at z_i: closes step i-1, opens step
 struct WideArgs {
   WideSeg seg[2];
   int nct0, CT, RT, M;       // column tiles of segment 0 / of the launch, row tiles, real rows
+  int narrow;                // many-round grid: tiles run only the column blocks that hold weights (wide_xcd_ranges)
+  int xbeg[9];               // XCD x runs tiles [xbeg[x], xbeg[x + 1]) of the order "row tiles of column tile 0, of column tile 1, ..."
   const float* bias;         // ACT1: bias1_i [IN] (workspace);  ACT2: packed b2
   const float* emb;          // ACT1: emb_i [E] (params)
   const float* x;            // [Mp][ldx]  z of this evaluation (operand of A / B's second product, read by ACT1 and STEP)
@@ -262,33 +267,47 @@ __device__ __forceinline__ void wide_step4(const WideArgs& a, int m, int col, co
   bk_s = bk_acc; fk_s = fk_acc; lp_s = lp_acc;
 }
 
+#ifndef CMCD_WIDE_BUF
+#define CMCD_WIDE_BUF 1
+#endif
+#ifndef CMCD_WIDE_NB
+#define CMCD_WIDE_NB 1        // 0: every tile runs all four column blocks (A / B)
+#endif
+// column blocks (of 32) a tile with `real` weight columns needs
+__host__ __device__ __forceinline__ int wide_tile_blocks(int real) {
+  if (!CMCD_WIDE_NB || !CMCD_WIDE_BUF) return 4;
+  const int b = (real + 31) >> 5;
+  return b < 1 ? 1 : (b > 4 ? 4 : b);
+}
+
 __global__ __launch_bounds__(256, 2) void lgcp_wide_gemm_kernel(WideArgs a) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][32 rows][kRedLd]
-  // XCD-aware tile mapping: workgroup b runs on XCD b % 8; XCD x takes the contiguous tile range [x per, (x + 1) per) of
-  // the order "row tiles of column tile 0, row tiles of column tile 1, ...", so the workgroups that share a column tile's
-  // weights share an L2
-  const int nt = a.CT * a.RT, per = (nt + 7) >> 3;
-  const int slot = blockIdx.x >> 3, t = (blockIdx.x & 7) * per + slot;
-  if (slot >= per || t >= nt) return;
+  // XCD-aware tile mapping: workgroup b runs on XCD b % 8; XCD x takes a contiguous tile range of the order "row tiles of
+  // column tile 0, row tiles of column tile 1, ...", so the workgroups that share a column tile's weights share an L2.  The
+  // ranges are cut by the host (wide_xcd_ranges): equal counts, or equal COST on many-round grids (a last column tile with
+  // fewer than four column blocks is cheaper, below)
+  const int xcd = blockIdx.x & 7, t = a.xbeg[xcd] + (int)(blockIdx.x >> 3);
+  if (t >= a.xbeg[xcd + 1]) return;
   const int ct = t / a.RT, rt = t - ct * a.RT;
   const int sI = ct >= a.nct0 ? 1 : 0;
   const WideSeg sg = a.seg[sI];
   const int ctl = ct - (sI ? a.nct0 : 0), n0 = ctl * kWCols;
+  // r05: column blocks of this tile that hold weights.  The last column tile of a 1620- / 1600-wide layer has 84 / 64 real
+  // columns of 128: with nb = 3 / 2 blocks the lane fetches 3 / 2 consecutive columns per k row (block j = columns nb c + j: the
+  // packed arrays keep their order) and issues 3 / 2 matrix instructions per step instead of 4
+  const int nb = (CMCD_WIDE_BUF && a.narrow) ? __builtin_amdgcn_readfirstlane(wide_tile_blocks(sg.ncols - n0)) : 4;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
   const int nch = sg.Kp >> 3, T = nch >> 2;                      // 8-deep chunks; T per wave (Kp is a multiple of 32)
   const float* Ap = sg.A + (int64_t)(rt * kWRows + c) * sg.lda + 4 * h;
   const float* Wp = sg.W + (int64_t)(4 * h) * sg.ldw + n0 + 4 * c;
   const int64_t ldw = sg.ldw;
   const float shift = sg.a_shift;
-#ifndef CMCD_WIDE_BUF
-#define CMCD_WIDE_BUF 1
-#endif
   // r05: the operands come through buffer descriptors — per-lane byte offset in a register that never changes, the chunk's
   // position in a SCALAR offset (`buffer_load ... s_off offen`): no vector address arithmetic in the loop (the flat form
   // spent ~10 of its ~14 VALU instructions per chunk on 64-bit addresses; on gfx950 VALU and fp32 matrix time add).
   const int wvu = __builtin_amdgcn_readfirstlane(wv);
   const uint32_t voffA = (uint32_t)(((rt * kWRows + c) * sg.lda + 4 * h) * 4);
-  const uint32_t voffW = (uint32_t)((4 * h * sg.ldw + n0 + 4 * c) * 4);
+  const uint32_t voffW = (uint32_t)((4 * h * sg.ldw + n0 + nb * c) * 4);
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(sg.A), 0, __builtin_amdgcn_readfirstlane(a.RT * kWRows * sg.lda * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
@@ -311,14 +330,27 @@ __global__ __launch_bounds__(256, 2) void lgcp_wide_gemm_kernel(WideArgs a) {
 #endif
   constexpr int P = CMCD_WIDE_DEPTH;     // chunks in flight per wave
   f32x4 av[P], bv[P][4];
-  auto issue = [&](f32x4& a_, f32x4 (&b_)[4], int tt) {
+  auto issue = [&](auto nb_tag, f32x4& a_, f32x4 (&b_)[4], int tt) {
+    constexpr int NB = decltype(nb_tag)::value;
     if (CMCD_WIDE_BUF) {
       const int ch = min(4 * tt + wvu, nch - 1);                 // past the end: a valid, unused reload of the last chunk
       a_ = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, voffA, 32 * ch, 0));
       const int wo = 8 * ch * ldwB;
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
-        b_[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, voffW, wo + s * ldwB, 0));
+      for (int s = 0; s < 4; ++s) {
+        if constexpr (NB == 4) {
+          b_[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, voffW, wo + s * ldwB, 0));
+        } else if constexpr (NB == 3) {
+          const f32x3 v = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(rsW, voffW, wo + s * ldwB, 0));
+          b_[s] = f32x4{v[0], v[1], v[2], 0.f};
+        } else if constexpr (NB == 2) {
+          const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsW, voffW, wo + s * ldwB, 0));
+          b_[s] = f32x4{v[0], v[1], 0.f, 0.f};
+        } else {
+          const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsW, voffW, wo + s * ldwB, 0));
+          b_[s] = f32x4{v, 0.f, 0.f, 0.f};
+        }
+      }
     } else {
       const int ch = min(4 * tt + wv, nch - 1);
       a_ = *reinterpret_cast<const f32x4*>(Ap + 8 * ch);
@@ -329,18 +361,19 @@ __global__ __launch_bounds__(256, 2) void lgcp_wide_gemm_kernel(WideArgs a) {
   };
   // the operand shift (K^-1 (x - mu0)) only in the segments that have one: the whole contraction loop exists twice behind a
   // wave-uniform branch (as a select inside one loop the compiler kept the four subtractions AND added four selects per chunk)
-  auto contract = [&](auto sh_tag, const f32x4& a_, const f32x4 (&b_)[4]) {
+  auto contract = [&](auto sh_tag, auto nb_tag, const f32x4& a_, const f32x4 (&b_)[4]) {
     constexpr bool SH = decltype(sh_tag)::value;
+    constexpr int NB = decltype(nb_tag)::value;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const float as = SH ? a_[s] - shift : a_[s];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(as, b_[s][j], acc[j], 0, 0, 0);
+      for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(as, b_[s][j], acc[j], 0, 0, 0);
     }
   };
-  auto run = [&](auto sh_tag) {
+  auto run = [&](auto sh_tag, auto nb_tag) {
 #pragma unroll
-    for (int u = 0; u < P - 1; ++u) issue(av[u], bv[u], u);
+    for (int u = 0; u < P - 1; ++u) issue(nb_tag, av[u], bv[u], u);
     // P chunks in flight; the body is UNCONDITIONAL (a branch around an issue makes the compiler's wait-count merge
     // pessimistic: it put s_waitcnt vmcnt(0) at the loop head, draining the younger chunks on every trip).  The last
     // T mod P chunks are already in flight when the loop ends.
@@ -348,18 +381,25 @@ __global__ __launch_bounds__(256, 2) void lgcp_wide_gemm_kernel(WideArgs a) {
     for (; tt + P <= T; tt += P) {
 #pragma unroll
       for (int u = 0; u < P; ++u) {
-        issue(av[(u + P - 1) % P], bv[(u + P - 1) % P], tt + u + P - 1);
+        issue(nb_tag, av[(u + P - 1) % P], bv[(u + P - 1) % P], tt + u + P - 1);
         __builtin_amdgcn_sched_barrier(0);     // the machine scheduler otherwise sinks these loads to just before their use
-        contract(sh_tag, av[u], bv[u]);
+        contract(sh_tag, nb_tag, av[u], bv[u]);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
 #pragma unroll
     for (int u = 0; u < P - 1; ++u)
-      if (tt + u < T) contract(sh_tag, av[u], bv[u]);               // wave-uniform
+      if (tt + u < T) contract(sh_tag, nb_tag, av[u], bv[u]);       // wave-uniform
   };
-  if (!CMCD_WIDE_BUF || __builtin_amdgcn_readfirstlane(shift != 0.f ? 1 : 0)) run(std::true_type{});
-  else run(std::false_type{});
+  auto run_nb = [&](auto sh_tag) {
+    // (the narrow forms only where they occur: the last column tile of a segment)
+    if (nb == 4) run(sh_tag, std::integral_constant<int, 4>{});
+    else if (nb == 3) run(sh_tag, std::integral_constant<int, 3>{});
+    else if (nb == 2) run(sh_tag, std::integral_constant<int, 2>{});
+    else run(sh_tag, std::integral_constant<int, 1>{});
+  };
+  if (!CMCD_WIDE_BUF || __builtin_amdgcn_readfirstlane(shift != 0.f ? 1 : 0)) run_nb(std::true_type{});
+  else run_nb(std::false_type{});
 
   // ---- the consumer's own operands (outputs of EARLIER launches), all four elements of this thread requested at once, in
   // flight across the cross-wave sum and its barrier (requested BEFORE the contraction they cost ~50 registers through the
@@ -391,12 +431,23 @@ __global__ __launch_bounds__(256, 2) void lgcp_wide_gemm_kernel(WideArgs a) {
 
   // ---- sum of the four waves' partial tiles, fixed order.  D layout of the MFMA: column = lane & 31 (= c, i.e. tile
   // column 4 c + block), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  if (nb == 4) {
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-    f32x4 v;
-    v[0] = acc[0][i]; v[1] = acc[1][i]; v[2] = acc[2][i]; v[3] = acc[3][i];
-    *reinterpret_cast<f32x4*>(red + (wv * kWRows + row) * kRedLd + 4 * c) = v;
+    for (int i = 0; i < 16; ++i) {
+      const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+      f32x4 v;
+      v[0] = acc[0][i]; v[1] = acc[1][i]; v[2] = acc[2][i]; v[3] = acc[3][i];
+      *reinterpret_cast<f32x4*>(red + (wv * kWRows + row) * kRedLd + 4 * c) = v;
+    }
+  } else {                                                       // tile column nb c + block (columns past 32 nb: never consumed)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+      float* rp = red + (wv * kWRows + row) * kRedLd + nb * c;
+      rp[0] = acc[0][i];
+      if (nb > 1) rp[1] = acc[1][i];
+      if (nb > 2) rp[2] = acc[2][i];
+    }
   }
   if (epi == WEPI_STEP || epi == WEPI_STEP_NONET) {   // the per-column vectors and the chain keys: in flight across the barrier
 #pragma unroll
@@ -600,6 +651,45 @@ static WideWs wide_ws(const cmcd_desc& d, int64_t n, int64_t base) {
   return w;
 }
 
+// XCD x runs the contiguous tile range [xbeg[x], xbeg[x + 1]) (tiles in the order: row tiles of column tile 0, of column tile
+// 1, ...).  Few-round grids (every CU gets about one tile): equal counts, as before.  Many-round grids: equal COST — a tile's
+// cost is its number of column blocks (wide_tile_blocks), so the XCD that holds the cheaper last column tiles takes more of them.
+// Returns the longest range (the grid is 8 x that).
+static int wide_xcd_ranges(WideArgs& g) {
+  const int nt = g.CT * g.RT;
+  auto blocks = [&](int ct) {
+    const int sI = ct >= g.nct0 ? 1 : 0, ctl = ct - (sI ? g.nct0 : 0);
+    return wide_tile_blocks(g.seg[sI].ncols - ctl * kWCols);
+  };
+  int64_t total = 0;
+  for (int ct = 0; ct < g.CT; ++ct) total += (int64_t)blocks(ct) * g.RT;
+  const bool by_cost = nt >= 8 * 64 && total != (int64_t)4 * nt;
+  g.narrow = by_cost ? 1 : 0;   // one-round grids wait for their slowest (full) tile anyway: plain form there
+  g.xbeg[0] = 0;
+  if (!by_cost) {
+    const int per = (nt + 7) / 8;
+    for (int x = 1; x <= 8; ++x) g.xbeg[x] = std::min(nt, x * per);
+  } else {
+    int ct = 0, rt = 0;
+    int64_t acc = 0;
+    for (int x = 1; x < 8; ++x) {
+      const int64_t want = (total * x + 7) / 8;
+      while (ct < g.CT && acc < want) {     // whole column tiles first, then rows of the one the cut falls into
+        const int b = blocks(ct);
+        const int64_t left = (int64_t)(g.RT - rt) * b;
+        if (acc + left <= want) { acc += left; ++ct; rt = 0; continue; }
+        const int rows = (int)((want - acc + b - 1) / b);
+        rt += rows; acc += (int64_t)rows * b;
+      }
+      g.xbeg[x] = std::min(nt, ct * g.RT + rt);
+    }
+    g.xbeg[8] = nt;
+  }
+  int longest = 0;
+  for (int x = 0; x < 8; ++x) longest = std::max(longest, g.xbeg[x + 1] - g.xbeg[x]);
+  return longest;
+}
+
 bool lgcp_wide_supported(const cmcd_desc& d) {
   const int D = d.dim, IN = D + d.emb_dim;
   return d.mode != CMCD_MODE_CAIS_UHA_SN && D % 4 == 0 && IN % 4 == 0 && D >= 32;
@@ -656,10 +746,20 @@ int lgcp_wide_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout
   st.wslot = ws + w.slots; st.fkslot = st.wslot + (int64_t)w.ctD * w.Mp; st.lpslot = st.fkslot + (int64_t)w.ctD * w.Mp;
   st.out_z = out_z; st.n = n; st.Mp = w.Mp; st.K = K;
   st.var_mode = d.mode == CMCD_MODE_CAIS_VAR_SN ? 1 : 0; st.grad_clipping = d.grad_clipping; st.ula = ula;
-  auto launch = [&](int ct_total) {
+  // the XCD ranges depend on the launch type only (segments' widths, tile counts): cut once per type, not per evaluation
+  struct Cut { int xbeg[9]; int longest = -1; int narrow = 0; };
+  Cut cuts[4];
+  auto launch = [&](int ct_total, int type) {
     g.CT = ct_total;
-    const int nt = g.CT * g.RT, per = (nt + 7) / 8;
-    hipLaunchKernelGGL(lgcp_wide_gemm_kernel, dim3(8 * per), dim3(256), kWideLds, stream, g);
+    Cut& cu = cuts[type];
+    if (cu.longest < 0) {
+      cu.longest = wide_xcd_ranges(g);
+      cu.narrow = g.narrow;
+      for (int x = 0; x < 9; ++x) cu.xbeg[x] = g.xbeg[x];
+    }
+    g.narrow = cu.narrow;
+    for (int x = 0; x < 9; ++x) g.xbeg[x] = cu.xbeg[x];
+    hipLaunchKernelGGL(lgcp_wide_gemm_kernel, dim3(8 * cu.longest), dim3(256), kWideLds, stream, g);
   };
   float* xbuf[3] = {ws + w.x, ws + w.xp, ws + w.xn};      // cur, prev, next
   for (int i = 0; i <= K; ++i) {
@@ -669,29 +769,30 @@ int lgcp_wide_forward(const cmcd_desc& d, const cmcd_layout& lay, const WsLayout
     // after this evaluation: prev <- cur, cur <- next (the old prev is the buffer the next evaluation writes)
     xbuf[0] = st.xn; xbuf[2] = xbuf[1]; xbuf[1] = xc;
     if (ula == 1) {    // MCD_ULA: one launch per evaluation, (x - mu0) K^-1 with the state update as its consumer
-      g.seg[0] = WideSeg{xc, ws + w.kip, w.ldx, w.NpD, w.KpD, WEPI_STEP_NONET, mu0};
+      g.seg[0] = WideSeg{xc, ws + w.kip, w.ldx, w.NpD, w.KpD, WEPI_STEP_NONET, mu0, D};
       g.nct0 = w.ctD;
-      launch(w.ctD);
+      launch(w.ctD, 3);
       continue;
     }
     // CAIS: s(z_i, i) serves both kernels; MCD_ULA_sn: s(z_i, i - 1) serves the backward kernel only
     const int it = ula == 2 ? (i > 0 ? i - 1 : 0) : i;
     const int ie = it < K ? it : K - 1;
     // A
-    g.seg[0] = WideSeg{xc, ws + w.w1p, w.ldx, w.NpIN, w.KpD, WEPI_ACT1, 0.f};
+    g.seg[0] = WideSeg{xc, ws + w.w1p, w.ldx, w.NpIN, w.KpD, WEPI_ACT1, 0.f, IN};
     g.nct0 = w.ctIN;
     g.bias = ws + w.bias1 + (int64_t)it * IN; g.emb = params + lay.g_emb + (int64_t)ie * E; g.u_out = ws + w.u1;
-    launch(w.ctIN);
+    launch(w.ctIN, 0);
     // B: the second layer and, beside it, the K^-1 product (needs only the state; consumed by C)
-    g.seg[0] = WideSeg{ws + w.u1, ws + w.w2p, w.ldu, w.NpIN, w.KpIN, WEPI_ACT2, 0.f};
-    g.seg[1] = WideSeg{xc, ws + w.kip, w.ldx, w.NpD, w.KpD, WEPI_KR, mu0};
+    g.seg[0] = WideSeg{ws + w.u1, ws + w.w2p, w.ldu, w.NpIN, w.KpIN, WEPI_ACT2, 0.f, IN};
+    g.seg[1] = WideSeg{xc, ws + w.kip, w.ldx, w.NpD, w.KpD, WEPI_KR, mu0, D};
     g.nct0 = w.ctIN;
     g.bias = ws + w.b2; g.u_prev = ws + w.u1; g.u_out = ws + w.u2; g.kr_out = ws + w.kr;
-    launch(w.ctIN + w.ctD);
+    launch(w.ctIN + w.ctD, 1);
     // C
-    g.seg[0] = WideSeg{ws + w.u2, ws + w.w3p, w.ldu, w.NpD, w.KpIN, WEPI_STEP, 0.f};
+    // (paired column order: tile ct holds elements [64 ct, 64 ct + 64) and their partners — 2 H = D packed columns in all)
+    g.seg[0] = WideSeg{ws + w.u2, ws + w.w3p, w.ldu, w.NpD, w.KpIN, WEPI_STEP, 0.f, D};
     g.nct0 = w.ctD;
-    launch(w.ctD);
+    launch(w.ctD, 2);
   }
   WideFinalArgs fa{ws + w.w0, st.wslot, st.lpslot, tc, out_loss, partials, n, w.Mp, D, w.ctD};
   hipLaunchKernelGGL(lgcp_wide_final_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, fa);

@@ -133,6 +133,10 @@ def test_lgcp_matches_oracle(hip_lib, param_set, monkeypatch, n, k, form):
     # one-wave grids, a 2.4-nat ELBO shift on the reference's 15 000-particle evaluation (tests/test_gpu_reference_tables.py)
     ("MCD_ULA", 2048, 3, dict(init_eps=2e-4)),
     ("MCD_CAIS_sn", 1100, 2, {}),
+    # r05: on many-round grids (>= 512 tiles per launch) the last column tile of a layer runs only the column blocks that hold
+    # weights (3 of 4 for the 1620-wide layers, 2 of 4 for the 1600-wide ones; 1612 wide: 3) and the XCD ranges are cut by cost
+    ("MCD_CAIS_sn", 1400, 2, {}),
+    ("MCD_CAIS_var_sn", 1320, 2, dict(emb_dim=12, grad_clipping=True)),
 ])
 def test_lgcp_wide_batch_path_matches_oracle(hip_lib, param_set, monkeypatch, mode, n, k, over):
     """The wide-batch form of the d = 1600 path (cmcd_lgcp_wide.hip: whole-batch launches of a 32 x 128-tile fp32 GEMM body,

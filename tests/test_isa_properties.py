@@ -182,15 +182,27 @@ def test_wide_lgcp_gemm_loop_has_no_vector_address_arithmetic(tmp_path_factory):
     lines = _asm(tmp_path_factory, "cmcd_lgcp_wide.hip")
     body, tail = _kernel_whole(lines, "_ZN4cmcd21lgcp_wide_gemm_kernelENS_8WideArgsE")
     assert any("ScratchSize: 0" in l for l in tail)
-    m = [i for i, l in enumerate(body) if "v_mfma_f32_32x32x2" in l]
-    assert len(m) >= 128                                            # the contraction loop exists twice (with / without operand shift)
-    for lo, hi in ((m[0], m[63]), (m[-64], m[-1])):
-        seg = body[lo:hi + 1]
-        assert sum("buffer_load_dwordx4" in l for l in seg) >= 5            # 5 per chunk, 64 matrix instructions = 4 chunks
+    # the contraction loop exists once per (operand shift or not) x (column blocks of the tile: 4, or 3 / 2 / 1 in the last column
+    # tile of a layer, r05): every copy is free of vector address arithmetic and keeps its loads on buffer descriptors
+    heads = [i for i, l in enumerate(body) if "Loop Header: Depth=1" in l]
+    loops = []
+    for h in heads:
+        end = next(i for i in range(h, len(body)) if "s_cbranch" in body[i])
+        seg = body[h:end]
+        n_mfma = sum("v_mfma_f32_32x32x2" in l for l in seg)
+        if n_mfma:
+            loops.append((n_mfma, seg))
+    assert sorted(n for n, _ in loops) == [12, 12, 24, 24, 36, 36, 48, 48], [n for n, _ in loops]
+    for n_mfma, seg in loops:
+        width = {48: "dwordx4", 36: "dwordx3", 24: "dwordx2", 12: "dword"}[n_mfma]
+        n_w = sum(bool(re.search(r"buffer_load_%s\b" % width, l)) for l in seg)
+        n_a = sum("buffer_load_dwordx4" in l for l in seg)
+        # 3 chunks x (4 weight rows + 1 row of activations, always 16 bytes)
+        assert (n_w == 15) if n_mfma == 48 else (n_w == 12 and n_a == 3), (n_mfma, width, n_w, n_a)
         assert not any(re.match(r"\s*(v_lshl_add_u64|v_mad_i64_i32|global_load)", l) for l in seg), "vector addresses are back in the loop"
-    # one of the two loops subtracts the operand shift, the other has no VALU arithmetic between its matrix instructions
-    subs = [sum(1 for l in body[lo:hi + 1] if re.match(r"\s*v_sub_f32", l)) for lo, hi in ((m[0], m[63]), (m[-64], m[-1]))]
-    assert min(subs) == 0 and max(subs) >= 12, subs
+    # of the two full-width loops one subtracts the operand shift, the other has no VALU arithmetic between its matrix instructions
+    subs = sorted(sum(1 for l in seg if re.match(r"\s*v_sub(rev)?_f32", l)) for n, seg in loops if n == 48)
+    assert subs[0] == 0 and subs[1] >= 12, subs
 
 
 # ---------------------------------------------------------------------------------------------- 2nd-order mode (cmcd_uha.hip)
